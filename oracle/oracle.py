@@ -1,0 +1,148 @@
+"""ctypes binding of the CPU oracle (oracle/libgfsoracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline leg
+of bench.py -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MAXLEVEL = 12
+SIDE_PERIODIC, SIDE_BOUNDARY, SIDE_EXTERNAL = 0, 1, 2
+BC_SYMMETRY, BC_DIRICHLET, BC_NEUMANN = 0, 1, 2
+
+
+class Norm(C.Structure):
+    _fields_ = [("bias", C.c_double), ("first", C.c_double), ("second", C.c_double),
+                ("infty", C.c_double), ("w", C.c_double)]
+
+    def as_tuple(self):
+        return (self.bias, self.first, self.second, self.infty, self.w)
+
+
+class MultilevelParams(C.Structure):
+    """GfsMultilevelParams (poisson.h:39-52)."""
+    _fields_ = [("tolerance", C.c_double), ("nrelax", C.c_uint), ("erelax", C.c_uint),
+                ("minlevel", C.c_uint), ("nitermax", C.c_uint), ("nitermin", C.c_uint),
+                ("dimension", C.c_uint), ("niter", C.c_uint), ("depth", C.c_uint),
+                ("weighted", C.c_int), ("function", C.c_int),
+                ("beta", C.c_double), ("omega", C.c_double),
+                ("residual_before", Norm), ("residual", Norm)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libgfsoracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(so) or \
+            any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        vp, i, d, u = C.c_void_p, C.c_int, C.c_double, C.c_uint
+        pd = C.POINTER(C.c_double)
+        sig = {
+            "go_domain_new": (vp, [i, i, C.POINTER(C.c_int)]),
+            "go_domain_destroy": (None, [vp]),
+            "go_level_size": (C.c_size_t, [vp, i]),
+            "go_order": (C.POINTER(C.c_int), [vp, i]),
+            "go_field_new": (vp, [vp, i]),
+            "go_field_destroy": (None, [vp]),
+            "go_field_level": (pd, [vp, i]),
+            "go_field_set_bc": (None, [vp, i, i, pd]),
+            "go_bc": (None, [vp, vp, i]),
+            "go_homogeneous_bc": (None, [vp, vp, i]),
+            "go_multilevel_params_init": (None, [C.POINTER(MultilevelParams), i]),
+            "go_poisson_coefficients": (None, [vp]),
+            "go_relax": (None, [vp, u, i, d, vp, vp, vp]),
+            "go_relax_lexicographic": (None, [vp, u, i, d, vp, vp, vp]),
+            "go_residual": (None, [vp, u, i, vp, vp, vp, vp]),
+            "go_norm_residual": (Norm, [vp, d, vp]),
+            "go_norm_variable": (Norm, [vp, vp]),
+            "go_poisson_cycle": (None, [vp, C.POINTER(MultilevelParams), vp, vp, vp, vp]),
+            "go_poisson_solve": (None, [vp, C.POINTER(MultilevelParams), vp, vp, vp, vp, d]),
+        }
+        for name, (res, args) in sig.items():
+            if hasattr(L, name):
+                f = getattr(L, name)
+                f.restype, f.argtypes = res, args
+        _LIB = L
+    return _LIB
+
+
+class Field:
+    def __init__(self, dom, component=-1):
+        self.dom = dom
+        self.ptr = lib().go_field_new(dom.ptr, component)
+
+    def level(self, l):
+        """numpy view (with ghosts) of level l, shape (n+2,)*dim, indexed [k, j, i] / [j, i]."""
+        n = (1 << l) + 2
+        shape = (n,) * self.dom.dim
+        p = lib().go_field_level(self.ptr, l)
+        return np.ctypeslib.as_array(p, shape=shape)
+
+    def leaf(self):
+        return self.level(self.dom.depth)
+
+    def interior(self, l=None):
+        l = self.dom.depth if l is None else l
+        a = self.level(l)
+        return a[(slice(1, -1),) * self.dom.dim]
+
+    def set_bc(self, d, kind, val=None):
+        if val is not None:
+            val = np.ascontiguousarray(val, dtype=np.float64).ravel()
+            lib().go_field_set_bc(self.ptr, d, kind, val.ctypes.data_as(C.POINTER(C.c_double)))
+        else:
+            lib().go_field_set_bc(self.ptr, d, kind, None)
+
+    def __del__(self):
+        try:
+            lib().go_field_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+class Domain:
+    def __init__(self, dim, depth, side=None):
+        self.dim, self.depth = dim, depth
+        s = (C.c_int * 6)(*(side if side is not None else [SIDE_BOUNDARY] * 6))
+        self.side = list(s)
+        self.ptr = lib().go_domain_new(dim, depth, s)
+
+    def field(self, component=-1):
+        return Field(self, component)
+
+    def params(self):
+        p = MultilevelParams()
+        lib().go_multilevel_params_init(C.byref(p), self.dim)
+        return p
+
+    def centres(self, l=None):
+        """cell-centre coordinate arrays (x, y[, z]) of the interior of level l, broadcastable
+        against interior() views."""
+        l = self.depth if l is None else l
+        n = 1 << l
+        c = -0.5 + (np.arange(1, n + 1) - 0.5) / n
+        if self.dim == 2:
+            return c[None, :], c[:, None]
+        return c[None, None, :], c[None, :, None], c[:, None, None]
+
+    def order(self, l):
+        n = 1 << l
+        return np.ctypeslib.as_array(lib().go_order(self.ptr, l), shape=(n ** self.dim,)).copy()
+
+    def __del__(self):
+        try:
+            lib().go_domain_destroy(self.ptr)
+        except Exception:
+            pass
