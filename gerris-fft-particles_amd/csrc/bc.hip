@@ -1,0 +1,77 @@
+// bc.hip -- K17: ghost-layer fill (symmetry, Dirichlet, Neumann, periodic).
+// Replaces box_bc / box_homogeneous_bc + gfs_boundary_send/receive of src/domain.c:723-965 and
+// the periodic pack/memcpy/unpack of src/boundary.c:1240-1451: on one box every side reads
+// interior cells only (all sides pack before any side unpacks), so all 2*dim faces are filled
+// by one launch.
+#include "gfship_internal.hpp"
+
+namespace gfship {
+
+__device__ __forceinline__ double ghost_value_bc (int type, int component, int c, double nb,
+						  int homogeneous, double val, double h)
+{
+  switch (type) {
+  case GFSHIP_BC_DIRICHLET:        /* src/boundary.c:253-268 */
+    return homogeneous ? - nb : 2.*val - nb;
+  case GFSHIP_BC_NEUMANN:          /* src/boundary.c:336-347 */
+    return homogeneous ? nb : nb + val*h;
+  default:                         /* symmetry, src/boundary.c:45-51 */
+    return component == c ? - nb : nb;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bc_kernel (Layout L, BcDesc bc, double * __restrict__ a)
+{
+  const int n = L.n;
+  const int nface = L.dim == 3 ? n*n : n;
+  int f = blockIdx.x*blockDim.x + threadIdx.x;
+  int d = blockIdx.y;
+  if (f >= nface) return;
+  if (bc.side[d] == GFSHIP_SIDE_EXTERNAL) return;
+  int c = d/2;
+  int t1 = f % n + 1, t2 = L.dim == 3 ? f / n + 1 : 0;
+  int ijk[3] = { 0, 0, 0 };
+  int ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
+  ijk[c] = (d & 1) ? 1 : n;
+  ijk[ta] = t1;
+  if (L.dim == 3) ijk[tb] = t2;
+  long o = c == 0 ? 1 : c == 1 ? L.sy : L.sz;
+  if (d & 1) o = - o;
+  long nb = L.idx (ijk[0], ijk[1], ijk[2]);
+  double v;
+  if (bc.side[d] == GFSHIP_SIDE_PERIODIC)
+    v = a[nb - (long) (n - 1)*o];
+  else {
+    double val = (!bc.homogeneous && bc.val[d]) ? bc.val[d][f] : 0.;
+    v = ghost_value_bc (bc.type[d], bc.component, c, a[nb], bc.homogeneous, val, 1./n);
+  }
+  a[nb + o] = v;
+}
+
+int launch_bc (gfship_domain * dom, Field * v, Field * v1, int level, int homogeneous)
+{
+  const Layout & L = dom->lay[level];
+  BcDesc bc;
+  for (int d = 0; d < 6; d++) {
+    bc.side[d] = dom->side[d];
+    bc.type[d] = v->bc[d];
+    bc.val[d] = (level == dom->depth) ? v->bcval[d] : nullptr;
+  }
+  if (!homogeneous && level != dom->depth)
+    for (int d = 0; d < 2*dom->dim; d++)
+      GFSHIP_CHECK (!(dom->side[d] == GFSHIP_SIDE_BOUNDARY && v->bc[d] != GFSHIP_BC_SYMMETRY &&
+		      v->bcval[d]),
+		    GFSHIP_EUNSUPPORTED,
+		    "non-homogeneous Dirichlet/Neumann values are held on the leaf level only");
+  bc.component = v->component;
+  bc.homogeneous = homogeneous;
+  int nface = dom->dim == 3 ? L.n*L.n : L.n;
+  int block = nface >= 256 ? 256 : 64;
+  dim3 grid ((nface + block - 1)/block, 2*dom->dim);
+  hipLaunchKernelGGL (bc_kernel, grid, dim3 (block), 0, dom->stream, L, bc, v1->lev[level]);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+} // namespace gfship

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Builds libgfship.so for gfx950 (cross-compiles without a GPU).
+# -ffp-contract=off: results must match the reference's non-FMA x86-64 arithmetic bit for bit.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -I$HERE/../../include -I$HERE -Wall -Wno-unused-function"
+OBJS=""
+for f in "$HERE"/*.hip; do
+  o="$OUT/$(basename "${f%.hip}").o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/gfship_internal.hpp" -nt "$o" ] || [ "$HERE/../../include/gfship.h" -nt "$o" ]; then
+    "$HIPCC" $FLAGS -c "$f" -o "$o" &
+  fi
+  OBJS="$OBJS $o"
+done
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgfship.so" $OBJS
+echo "built $OUT/libgfship.so"

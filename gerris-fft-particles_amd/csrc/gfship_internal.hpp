@@ -1,0 +1,101 @@
+// gfship_internal.hpp -- shared declarations of libgfship (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+#include <deque>
+#include <string>
+#include "gfship.h"
+
+namespace gfship {
+
+// Per-level dense layout (replaces FttOct pointers, src/ftt.h:134-159): (n+2)^(dim-1) rows of
+// px doubles.  Interior cell i = 1 sits at x index xo + 1 = 2 so that rows of interior cells
+// start 16-byte aligned (px is even); ghosts at xo + 0 and xo + n + 1.
+struct Layout {
+  int n = 0;        // cells per side
+  int px = 0;       // x pitch in doubles
+  int xo = 1;       // x offset of i = 0
+  int rows = 0;     // n + 2
+  int dim = 3;
+  long sy = 0;      // stride of j  (= px)
+  long sz = 0;      // stride of k  (= px*rows, 0 in 2-D)
+  size_t total = 0; // doubles per field-level
+  __host__ __device__ inline long idx (int i, int j, int k) const {
+    return xo + i + sy*j + sz*k;
+  }
+};
+
+struct Field {
+  bool used = false;
+  int component = -1;
+  double * lev[GFSHIP_MAXLEVEL + 1] = {};
+  int bc[6] = {0, 0, 0, 0, 0, 0};
+  double * bcval[6] = {};      // device, leaf-level face values or nullptr
+};
+
+// device-side description of the six sides for the BC kernel
+struct BcDesc {
+  int side[6];
+  int type[6];
+  const double * val[6];
+  int component;
+  int homogeneous;
+};
+
+} // namespace gfship
+
+struct gfship_domain {
+  int dim = 3, depth = 0, device = 0;
+  int side[6] = {1, 1, 1, 1, 1, 1};
+  int relax_mode = GFSHIP_RELAX_EXACT;
+  gfship::Layout lay[GFSHIP_MAXLEVEL + 1];
+  std::deque<gfship::Field> fields;   // deque: handles stay valid while fields are added
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double * d_scratch = nullptr;   // reduction scratch
+  size_t scratch_doubles = 0;
+  double * h_pinned = nullptr;    // pinned host buffer for small read-backs
+  bool unit_weights = false;      // gfship_poisson_coefficients called with alpha = NULL
+};
+
+namespace gfship {
+
+void set_error (const char * fmt, ...);
+int  hip_fail (hipError_t e, const char * what, const char * file, int line);
+
+#define GFSHIP_HIP(call) do { hipError_t e_ = (call); \
+    if (e_ != hipSuccess) return gfship::hip_fail (e_, #call, __FILE__, __LINE__); } while (0)
+
+#define GFSHIP_CHECK(cond, code, ...) do { if (!(cond)) { \
+    gfship::set_error (__VA_ARGS__); return (code); } } while (0)
+
+Field * get_field (gfship_domain * dom, gfship_field f);
+inline long ncells (const Layout & L) {
+  return L.dim == 3 ? (long) L.n*L.n*L.n : (long) L.n*L.n;
+}
+
+// kernels launchers (poisson_kernels.hip, bc.hip)
+int launch_bc (gfship_domain * dom, Field * v, Field * v1, int level, int homogeneous);
+int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, double omega,
+			double * u, const double * rhs, const double * dia);
+int launch_relax_loop_small (gfship_domain * dom, unsigned dimension, int level, double omega,
+			     Field * dp, Field * ubc, const double * rhs, const double * dia,
+			     unsigned nrelax, bool * done);
+int launch_relax_redblack (gfship_domain * dom, unsigned dimension, int level, double omega,
+			   double * u, const double * rhs, const double * dia);
+int launch_residual (gfship_domain * dom, int level, const double * u, const double * rhs,
+		     const double * dia, double * res);
+int launch_restrict (gfship_domain * dom, unsigned dimension, int level_coarse, double * v_coarse,
+		     const double * v_fine);
+int launch_prolongate (gfship_domain * dom, int level_coarse, const double * v_coarse,
+		       double * v_fine);
+int launch_correct (gfship_domain * dom, int level, double * u, const double * dp);
+int launch_fill (gfship_domain * dom, int level, double * a, double value);
+int launch_norm (gfship_domain * dom, int level, const double * a, double scale, double weight,
+		 double out[5] /* bias(sum of scaled), first, second, infty, raw sum */);
+
+} // namespace gfship

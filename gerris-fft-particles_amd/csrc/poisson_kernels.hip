@@ -1,0 +1,526 @@
+// poisson_kernels.hip -- CDNA4 kernels of the multigrid Poisson path (K1-K7 of SURVEY.md 2.5).
+//
+// All arithmetic is IEEE fp64, compiled with -ffp-contract=off, and written operation by
+// operation in the operand order of the reference (src/poisson.c, src/fluid.c) so that the
+// exact-mode results are bit-identical to the CPU algorithm.  Unit face weights
+// (gfs_poisson_coefficients with alpha = NULL on a uniform single box: every f[d].v == 1.).
+#include "gfship_internal.hpp"
+
+namespace gfship {
+
+// ---------------------------------------------------------------------------------------------
+// K1: relax / relax2D, src/poisson.c:507-557, with face_weighted_gradient's same-level branch
+// (src/fluid.c:858-864: g->a = w; g->b = w*u_nb) for w == 1.
+// ---------------------------------------------------------------------------------------------
+template <int DIM>
+__device__ __forceinline__ double relax_value (const double * __restrict__ u, long c, long sy, long sz,
+					       double rhs, double dia, unsigned dimension,
+					       double omega)
+{
+  double a = dia, b = 0.;
+  a += 1.; b += 1.*u[c + 1];
+  a += 1.; b += 1.*u[c - 1];
+  a += 1.; b += 1.*u[c + sy];
+  a += 1.; b += 1.*u[c - sy];
+  if (DIM == 3) {
+    a += 1.; b += 1.*u[c + sz];
+    a += 1.; b += 1.*u[c - sz];
+  }
+  if (dimension == 2)
+    return a != 0. ? (1. - omega)*u[c] + omega*(b - rhs)/a : 0.;
+  return a != 0. ? (b - rhs)/a : 0.;
+}
+
+// Exact-order sweep, one launch per hyperplane I + J + K = plane of the oriented coordinates
+// I = i - 1, J = n - j, K = n - k: the reference visits cells in tree pre-order with children
+// n = 0..7 at x:+ (bit0), y:- (bit1), z:- (bit2) (src/ftt.c:301-316,837-852); for a 7-point
+// stencil the result of the in-place sweep only depends on which of two neighbouring cells
+// is visited first, and that orientation is (+x, -y, -z) for every pair, so any topological
+// order of it -- here hyperplanes -- is bit-identical (tests/test_oracle_golden_poisson.py
+// checks the claim on the oracle).
+template <int DIM>
+__global__ void __launch_bounds__(256)
+relax_hyperplane_kernel (Layout L, int plane, unsigned dimension, double omega,
+			 double * __restrict__ u, const double * __restrict__ rhs,
+			 const double * __restrict__ dia)
+{
+  int n = L.n;
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  int J, K, I;
+  if (DIM == 3) {
+    if (t >= n*n) return;
+    J = t % n; K = t / n;
+    I = plane - J - K;
+  }
+  else {
+    if (t >= n) return;
+    J = t; K = 0;
+    I = plane - J;
+  }
+  if (I < 0 || I >= n) return;
+  long c = L.idx (I + 1, n - J, DIM == 3 ? n - K : 0);
+  u[c] = relax_value<DIM> (u, c, L.sy, L.sz, rhs[c], dia[c], dimension, omega);
+}
+
+int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, double omega,
+			double * u, const double * rhs, const double * dia)
+{
+  const Layout & L = dom->lay[level];
+  int n = L.n;
+  int nplanes = dom->dim == 3 ? 3*n - 2 : 2*n - 1;
+  int nthreads = dom->dim == 3 ? n*n : n;
+  int block = 256;
+  int grid = (nthreads + block - 1)/block;
+  for (int p = 0; p < nplanes; p++) {
+    if (dom->dim == 3)
+      hipLaunchKernelGGL (relax_hyperplane_kernel<3>, dim3 (grid), dim3 (block), 0, dom->stream,
+			  L, p, dimension, omega, u, rhs, dia);
+    else
+      hipLaunchKernelGGL (relax_hyperplane_kernel<2>, dim3 (grid), dim3 (block), 0, dom->stream,
+			  L, p, dimension, omega, u, rhs, dia);
+  }
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ghost-cell values, shared by the BC kernel and the LDS relax loop.
+// symmetry src/boundary.c:45-51, dirichlet :253-268, neumann :336-347.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double ghost_value (int type, int component, int c, double nb,
+					       int homogeneous, double val, double h)
+{
+  switch (type) {
+  case GFSHIP_BC_DIRICHLET:
+    return homogeneous ? - nb : 2.*val - nb;
+  case GFSHIP_BC_NEUMANN:
+    return homogeneous ? nb : nb + val*h;
+  default: /* GFSHIP_BC_SYMMETRY */
+    return component == c ? - nb : nb;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Whole relax_loop (src/poisson.c:1070-1089) of a level that fits in LDS, one workgroup:
+//   homogeneous BC ; (nrelax - 1) x { sweep ; homogeneous BC } ; sweep
+// The level (with ghosts) lives in LDS with the compact (n+2)^DIM layout; rhs and dia are
+// read from global memory.  Hyperplanes are separated by workgroup barriers.
+// ---------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(1024)
+relax_loop_lds_kernel (Layout L, BcDesc bc, unsigned dimension, double omega, unsigned nrelax,
+		       double * __restrict__ u, const double * __restrict__ rhs,
+		       const double * __restrict__ dia)
+{
+  extern __shared__ double s[];
+  const int n = L.n, r = n + 2;
+  const long ssy = r, ssz = DIM == 3 ? (long) r*r : 0;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int ncell = DIM == 3 ? n*n*n : n*n;
+  const int nface = DIM == 3 ? n*n : n;
+
+  // zero the tile (edge/corner ghosts are never written), then load the interior
+  for (int q = tid; q < (DIM == 3 ? r*r*r : r*r); q += nt)
+    s[q] = 0.;
+  __syncthreads ();
+  for (int q = tid; q < ncell; q += nt) {
+    int i = q % n + 1, j = (q / n) % n + 1, k = DIM == 3 ? q / (n*n) + 1 : 0;
+    s[i + ssy*j + ssz*k] = u[L.idx (i, j, k)];
+  }
+  __syncthreads ();
+
+  for (unsigned sweep = 0; sweep < nrelax; sweep++) {
+    // homogeneous BC on the ghost layer (every side reads interior cells only)
+    for (int q = tid; q < 2*DIM*nface; q += nt) {
+      int d = q / nface, f = q % nface;
+      int c = d/2;
+      int t1 = f % n + 1, t2 = DIM == 3 ? f / n + 1 : 0;
+      int ijk[3] = { 0, 0, 0 };
+      int ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
+      ijk[c] = (d & 1) ? 1 : n;
+      ijk[ta] = t1;
+      if (DIM == 3) ijk[tb] = t2;
+      long o = c == 0 ? 1 : c == 1 ? ssy : ssz;
+      if (d & 1) o = - o;
+      long nb = ijk[0] + ssy*ijk[1] + ssz*ijk[2];
+      double v;
+      if (bc.side[d] == GFSHIP_SIDE_PERIODIC)
+	v = s[nb - (long) (n - 1)*o];
+      else
+	v = ghost_value (bc.type[d], bc.component, c, s[nb], 1, 0., 0.);
+      s[nb + o] = v;
+    }
+    __syncthreads ();
+    // exact-order sweep by hyperplanes
+    const int nplanes = DIM == 3 ? 3*n - 2 : 2*n - 1;
+    for (int plane = 0; plane < nplanes; plane++) {
+      for (int t = tid; t < nface; t += nt) {
+	int J = t % n, K = DIM == 3 ? t / n : 0;
+	int I = plane - J - K;
+	if (I >= 0 && I < n) {
+	  int i = I + 1, j = n - J, k = DIM == 3 ? n - K : 0;
+	  long c = i + ssy*j + ssz*k;
+	  long g = L.idx (i, j, k);
+	  s[c] = relax_value<DIM> (s, c, ssy, ssz, rhs[g], dia[g], dimension, omega);
+	}
+      }
+      __syncthreads ();
+    }
+  }
+  // store interior and ghost layer (the reference's ghost cells keep the values of the last
+  // BC application, which get_from_above then reads: src/poisson.c:1160-1167)
+  const int nall = DIM == 3 ? r*r*r : r*r;
+  for (int q = tid; q < nall; q += nt) {
+    int i = q % r, j = (q / r) % r, k = DIM == 3 ? q / (r*r) : 0;
+    u[L.idx (i, j, k)] = s[q];
+  }
+}
+
+static bool lds_fits (const gfship_domain * dom, int level, size_t * bytes)
+{
+  const Layout & L = dom->lay[level];
+  size_t r = L.n + 2;
+  size_t b = (dom->dim == 3 ? r*r*r : r*r)*sizeof (double);
+  *bytes = b;
+  return b <= 64*1024; /* stay within the default dynamic-LDS limit */
+}
+
+int launch_relax_loop_small (gfship_domain * dom, unsigned dimension, int level, double omega,
+			     Field * dp, Field * ubc, const double * rhs, const double * dia,
+			     unsigned nrelax, bool * done)
+{
+  size_t bytes;
+  *done = false;
+  for (int d = 0; d < 2*dom->dim; d++)
+    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL)
+      return GFSHIP_OK; /* halos need the exchange between sweeps */
+  if (!lds_fits (dom, level, &bytes))
+    return GFSHIP_OK;
+  const Layout & L = dom->lay[level];
+  BcDesc bc;
+  for (int d = 0; d < 6; d++) {
+    bc.side[d] = dom->side[d];
+    bc.type[d] = ubc->bc[d];
+    bc.val[d] = nullptr;
+  }
+  bc.component = ubc->component;
+  bc.homogeneous = 1;
+  int nface = dom->dim == 3 ? L.n*L.n : L.n;
+  int block = nface <= 64 ? 64 : nface <= 256 ? 256 : 1024;
+  if (dom->dim == 3)
+    hipLaunchKernelGGL (relax_loop_lds_kernel<3>, dim3 (1), dim3 (block), bytes, dom->stream,
+			L, bc, dimension, omega, nrelax, dp->lev[level], rhs, dia);
+  else
+    hipLaunchKernelGGL (relax_loop_lds_kernel<2>, dim3 (1), dim3 (block), bytes, dom->stream,
+			L, bc, dimension, omega, nrelax, dp->lev[level], rhs, dia);
+  GFSHIP_HIP (hipGetLastError ());
+  *done = true;
+  return GFSHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Red-black Gauss-Seidel of the same operator (opt-in, not a reference algorithm): two colour
+// passes, each cell updated from the current values of its six neighbours.
+// ---------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(256)
+relax_redblack_kernel (Layout L, int colour, unsigned dimension, double omega,
+		       double * __restrict__ u, const double * __restrict__ rhs,
+		       const double * __restrict__ dia)
+{
+  int n = L.n;
+  int half = (n + 1)/2;
+  int ih = blockIdx.x*blockDim.x + threadIdx.x;
+  int j = blockIdx.y + 1;
+  int k = DIM == 3 ? blockIdx.z + 1 : 0;
+  if (ih >= half) return;
+  int i = 2*ih + 1 + ((j + k + colour) & 1);
+  if (i > n) return;
+  long c = L.idx (i, j, k);
+  u[c] = relax_value<DIM> (u, c, L.sy, L.sz, rhs[c], dia[c], dimension, omega);
+}
+
+int launch_relax_redblack (gfship_domain * dom, unsigned dimension, int level, double omega,
+			   double * u, const double * rhs, const double * dia)
+{
+  const Layout & L = dom->lay[level];
+  int half = (L.n + 1)/2;
+  int block = half >= 128 ? 128 : 64;
+  dim3 grid ((half + block - 1)/block, L.n, dom->dim == 3 ? L.n : 1);
+  for (int colour = 0; colour < 2; colour++) {
+    if (dom->dim == 3)
+      hipLaunchKernelGGL (relax_redblack_kernel<3>, grid, dim3 (block), 0, dom->stream,
+			  L, colour, dimension, omega, u, rhs, dia);
+    else
+      hipLaunchKernelGGL (relax_redblack_kernel<2>, grid, dim3 (block), 0, dom->stream,
+			  L, colour, dimension, omega, u, rhs, dia);
+  }
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cell-parallel kernels: one thread per interior cell, x fastest.
+// ---------------------------------------------------------------------------------------------
+#define CELL_LOOP_PROLOGUE(L)						\
+  int i = blockIdx.x*blockDim.x + threadIdx.x + 1;			\
+  int j = blockIdx.y + 1;						\
+  int k = (L).dim == 3 ? blockIdx.z + 1 : 0;				\
+  if (i > (L).n) return;						\
+  long c = (L).idx (i, j, k)
+
+static inline void cell_grid (const Layout & L, dim3 * grid, dim3 * block)
+{
+  int b = L.n >= 256 ? 256 : L.n >= 128 ? 128 : 64;
+  *block = dim3 (b);
+  *grid = dim3 ((L.n + b - 1)/b, L.n, L.dim == 3 ? L.n : 1);
+}
+
+// K2: residual_set / residual_set2D, src/poisson.c:634-678
+template <int DIM>
+__global__ void __launch_bounds__(256)
+residual_kernel (Layout L, const double * __restrict__ u, const double * __restrict__ rhs,
+		 const double * __restrict__ dia, double * __restrict__ res)
+{
+  CELL_LOOP_PROLOGUE (L);
+  double a = dia[c], b = 0.;
+  a += 1.; b += 1.*u[c + 1];
+  a += 1.; b += 1.*u[c - 1];
+  a += 1.; b += 1.*u[c + L.sy];
+  a += 1.; b += 1.*u[c - L.sy];
+  if (DIM == 3) {
+    a += 1.; b += 1.*u[c + L.sz];
+    a += 1.; b += 1.*u[c - L.sz];
+  }
+  res[c] = rhs[c] - (b - u[c]*a);
+}
+
+int launch_residual (gfship_domain * dom, int level, const double * u, const double * rhs,
+		     const double * dia, double * res)
+{
+  const Layout & L = dom->lay[level];
+  dim3 grid, block;
+  cell_grid (L, &grid, &block);
+  if (dom->dim == 3)
+    hipLaunchKernelGGL (residual_kernel<3>, grid, block, 0, dom->stream, L, u, rhs, dia, res);
+  else
+    hipLaunchKernelGGL (residual_kernel<2>, grid, block, 0, dom->stream, L, u, rhs, dia, res);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// K3: get_from_below_3D / _2D, src/poisson.c:1044-1068: sum of the children in child-id order
+// (child id bit0 -> +x, bit1 -> -y, bit2 -> -z), halved when dimension == 3.
+template <int DIM>
+__global__ void __launch_bounds__(256)
+restrict_kernel (Layout Lc, Layout Lf, unsigned dimension, double * __restrict__ vc,
+		 const double * __restrict__ vf)
+{
+  CELL_LOOP_PROLOGUE (Lc);
+  double val = 0.;
+#pragma unroll
+  for (int id = 0; id < (1 << DIM); id++) {
+    int ci = 2*i - 1 + (id & 1);
+    int cj = 2*j - 1 + ((id & 2) ? 0 : 1);
+    int ck = DIM == 3 ? 2*k - 1 + ((id & 4) ? 0 : 1) : 0;
+    val += vf[Lf.idx (ci, cj, ck)];
+  }
+  vc[c] = dimension == 2 ? val : val/2.;
+}
+
+int launch_restrict (gfship_domain * dom, unsigned dimension, int level_coarse, double * v_coarse,
+		     const double * v_fine)
+{
+  const Layout & Lc = dom->lay[level_coarse], & Lf = dom->lay[level_coarse + 1];
+  dim3 grid, block;
+  cell_grid (Lc, &grid, &block);
+  if (dom->dim == 3)
+    hipLaunchKernelGGL (restrict_kernel<3>, grid, block, 0, dom->stream, Lc, Lf, dimension,
+			v_coarse, v_fine);
+  else
+    hipLaunchKernelGGL (restrict_kernel<2>, grid, block, 0, dom->stream, Lc, Lf, dimension,
+			v_coarse, v_fine);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// K4: get_from_above, src/poisson.c:1005-1042, one thread per child (fine cell).
+// gfs_face_gradient at max_level = parent level (src/fluid.c:801-805): g.a = 1., g.b = nb.
+template <int DIM>
+__global__ void __launch_bounds__(256)
+prolongate_kernel (Layout Lc, Layout Lf, const double * __restrict__ vc,
+		   double * __restrict__ vf)
+{
+  CELL_LOOP_PROLOGUE (Lf);
+  int pi = (i + 1)/2, pj = (j + 1)/2, pk = DIM == 3 ? (k + 1)/2 : 0;
+  long p = Lc.idx (pi, pj, pk);
+  double pv = vc[p];
+  double h[3];
+  const long off[3] = { 1, Lc.sy, Lc.sz };
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++) {
+    double g1 = vc[p + off[cc]] - 1.*pv;
+    double g2 = vc[p - off[cc]] - 1.*pv;
+    h[cc] = (g1 - g2)/2.;
+  }
+  // relative position of the child, ftt_cell_relative_pos: coords[n]/4. (src/ftt.c:327-340)
+  double rel[3] = { ((i & 1) ? -1. : 1.)/4., ((j & 1) ? -1. : 1.)/4., ((k & 1) ? -1. : 1.)/4. };
+  double val = pv;
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++)
+    val += rel[cc]*h[cc];
+  vf[c] = val;
+}
+
+int launch_prolongate (gfship_domain * dom, int level_coarse, const double * v_coarse,
+		       double * v_fine)
+{
+  const Layout & Lc = dom->lay[level_coarse], & Lf = dom->lay[level_coarse + 1];
+  dim3 grid, block;
+  cell_grid (Lf, &grid, &block);
+  if (dom->dim == 3)
+    hipLaunchKernelGGL (prolongate_kernel<3>, grid, block, 0, dom->stream, Lc, Lf, v_coarse, v_fine);
+  else
+    hipLaunchKernelGGL (prolongate_kernel<2>, grid, block, 0, dom->stream, Lc, Lf, v_coarse, v_fine);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// K5: correct, src/poisson.c:998-1003
+__global__ void __launch_bounds__(256)
+correct_kernel (Layout L, double * __restrict__ u, const double * __restrict__ dp)
+{
+  CELL_LOOP_PROLOGUE (L);
+  u[c] += dp[c];
+}
+
+int launch_correct (gfship_domain * dom, int level, double * u, const double * dp)
+{
+  const Layout & L = dom->lay[level];
+  dim3 grid, block;
+  cell_grid (L, &grid, &block);
+  hipLaunchKernelGGL (correct_kernel, grid, block, 0, dom->stream, L, u, dp);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// K6: gfs_cell_reset (src/fluid.c:1995) and general fill, ghosts included
+__global__ void fill_kernel (double * __restrict__ a, size_t total, double value)
+{
+  size_t q = (size_t) blockIdx.x*blockDim.x + threadIdx.x;
+  size_t stride = (size_t) gridDim.x*blockDim.x;
+  for (; q < total; q += stride)
+    a[q] = value;
+}
+
+int launch_fill (gfship_domain * dom, int level, double * a, double value)
+{
+  const Layout & L = dom->lay[level];
+  int block = 256;
+  size_t g = (L.total + block - 1)/block;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL (fill_kernel, dim3 ((unsigned) g), dim3 (block), 0, dom->stream, a, L.total, value);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7: norms.  gfs_norm_add (src/fluid.c:2139-2154) per cell on val = a[c]/scale with weight w;
+// the sums are tree-reduced (deterministic, but not the reference's sequential order: they
+// agree to rounding); infty = max |val| is exact.  out = { sum w*val, sum w*|val|,
+// sum w*|val|*|val|, max |val|, sum a[c] }.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum (double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    v += __shfl_down (v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max (double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    v = fmax (v, __shfl_down (v, o, 64));
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+norm_partial_kernel (Layout L, const double * __restrict__ a, double scale, double weight,
+		     double * __restrict__ partial)
+{
+  long nc = L.dim == 3 ? (long) L.n*L.n*L.n : (long) L.n*L.n;
+  double s0 = 0., s1 = 0., s2 = 0., s3 = 0., s4 = 0.;
+  for (long q = (long) blockIdx.x*blockDim.x + threadIdx.x; q < nc;
+       q += (long) gridDim.x*blockDim.x) {
+    int i = q % L.n + 1, j = (q / L.n) % L.n + 1, k = L.dim == 3 ? q / ((long) L.n*L.n) + 1 : 0;
+    double raw = a[L.idx (i, j, k)];
+    double val = raw/scale;
+    s0 += weight*val;
+    val = fabs (val);
+    s3 = fmax (s3, val);
+    s1 += weight*val;
+    s2 += weight*val*val;
+    s4 += raw;
+  }
+  __shared__ double sh[5][4];
+  s0 = wave_sum (s0); s1 = wave_sum (s1); s2 = wave_sum (s2); s3 = wave_max (s3); s4 = wave_sum (s4);
+  int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { sh[0][w] = s0; sh[1][w] = s1; sh[2][w] = s2; sh[3][w] = s3; sh[4][w] = s4; }
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    int nw = blockDim.x >> 6;
+    double r0 = 0., r1 = 0., r2 = 0., r3 = 0., r4 = 0.;
+    for (int q = 0; q < nw; q++) {
+      r0 += sh[0][q]; r1 += sh[1][q]; r2 += sh[2][q]; r3 = fmax (r3, sh[3][q]); r4 += sh[4][q];
+    }
+    double * p = partial + 5*(size_t) blockIdx.x;
+    p[0] = r0; p[1] = r1; p[2] = r2; p[3] = r3; p[4] = r4;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+norm_final_kernel (const double * __restrict__ partial, int nblocks, double * __restrict__ out)
+{
+  double s0 = 0., s1 = 0., s2 = 0., s3 = 0., s4 = 0.;
+  for (int q = threadIdx.x; q < nblocks; q += blockDim.x) {
+    const double * p = partial + 5*(size_t) q;
+    s0 += p[0]; s1 += p[1]; s2 += p[2]; s3 = fmax (s3, p[3]); s4 += p[4];
+  }
+  __shared__ double sh[5][4];
+  s0 = wave_sum (s0); s1 = wave_sum (s1); s2 = wave_sum (s2); s3 = wave_max (s3); s4 = wave_sum (s4);
+  int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { sh[0][w] = s0; sh[1][w] = s1; sh[2][w] = s2; sh[3][w] = s3; sh[4][w] = s4; }
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    double r0 = 0., r1 = 0., r2 = 0., r3 = 0., r4 = 0.;
+    for (int q = 0; q < 4; q++) {
+      r0 += sh[0][q]; r1 += sh[1][q]; r2 += sh[2][q]; r3 = fmax (r3, sh[3][q]); r4 += sh[4][q];
+    }
+    out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3; out[4] = r4;
+  }
+}
+
+int launch_norm (gfship_domain * dom, int level, const double * a, double scale, double weight,
+		 double out[5])
+{
+  const Layout & L = dom->lay[level];
+  long nc = ncells (L);
+  int block = 256;
+  int nblocks = (int) ((nc + block - 1)/block);
+  if (nblocks > 1024) nblocks = 1024;
+  double * partial = dom->d_scratch;     // 5*1024 doubles
+  double * result = dom->d_scratch + 5*1024;
+  hipLaunchKernelGGL (norm_partial_kernel, dim3 (nblocks), dim3 (block), 0, dom->stream,
+		      L, a, scale, weight, partial);
+  hipLaunchKernelGGL (norm_final_kernel, dim3 (1), dim3 (256), 0, dom->stream,
+		      partial, nblocks, result);
+  GFSHIP_HIP (hipGetLastError ());
+  GFSHIP_HIP (hipMemcpyAsync (dom->h_pinned, result, 5*sizeof (double), hipMemcpyDeviceToHost,
+			      dom->stream));
+  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  memcpy (out, dom->h_pinned, 5*sizeof (double));
+  return GFSHIP_OK;
+}
+
+} // namespace gfship

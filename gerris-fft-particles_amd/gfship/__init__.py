@@ -1,0 +1,211 @@
+"""gfship -- host-side mirror of the libgfship C ABI (include/gfship.h).
+
+Thin ctypes layer used by tests/, bench.py and __graft_entry__.py: object names follow the
+reference (domain, variables, GfsMultilevelParams).  There is no CPU fallback: loading fails
+loudly when the HIP library is missing, and creating a domain fails without a device.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libgfship.so")
+
+SIDE_PERIODIC, SIDE_BOUNDARY, SIDE_EXTERNAL = 0, 1, 2
+BC_SYMMETRY, BC_DIRICHLET, BC_NEUMANN = 0, 1, 2
+RELAX_EXACT, RELAX_REDBLACK = 0, 1
+
+
+class GfshipError(RuntimeError):
+    pass
+
+
+class Norm(C.Structure):
+    _fields_ = [("bias", C.c_double), ("first", C.c_double), ("second", C.c_double),
+                ("infty", C.c_double), ("w", C.c_double)]
+
+
+class MultilevelParams(C.Structure):
+    """GfsMultilevelParams (src/poisson.h:39-52)."""
+    _fields_ = [("tolerance", C.c_double), ("nrelax", C.c_uint), ("erelax", C.c_uint),
+                ("minlevel", C.c_uint), ("nitermax", C.c_uint), ("nitermin", C.c_uint),
+                ("dimension", C.c_uint), ("niter", C.c_uint), ("depth", C.c_uint),
+                ("weighted", C.c_int), ("function", C.c_int),
+                ("beta", C.c_double), ("omega", C.c_double),
+                ("residual_before", Norm), ("residual", Norm)]
+
+
+_lib = None
+
+# every symbol include/gfship.h declares: name -> (restype, argtypes)
+_vp, _i, _d, _u = C.c_void_p, C.c_int, C.c_double, C.c_uint
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int)
+SIGNATURES = {
+    "gfship_last_error": (C.c_char_p, []),
+    "gfship_version": (_i, []),
+    "gfship_device_count": (_i, []),
+    "gfship_domain_create": (_i, [C.POINTER(_vp), _i, _i, _pi, _i]),
+    "gfship_domain_destroy": (None, [_vp]),
+    "gfship_domain_set_relax_mode": (_i, [_vp, _i]),
+    "gfship_domain_synchronize": (_i, [_vp]),
+    "gfship_domain_stream": (_vp, [_vp]),
+    "gfship_field_alloc": (_i, [_vp, _i]),
+    "gfship_field_free": (_i, [_vp, _i]),
+    "gfship_field_set_bc": (_i, [_vp, _i, _i, _i, _pd]),
+    "gfship_field_upload": (_i, [_vp, _i, _i, _pd]),
+    "gfship_field_download": (_i, [_vp, _i, _i, _pd]),
+    "gfship_field_fill": (_i, [_vp, _i, _i, _d]),
+    "gfship_field_device_ptr": (_vp, [_vp, _i, _i, _pi, _pi]),
+    "gfship_bc": (_i, [_vp, _i, _i, _i]),
+    "gfship_homogeneous_bc": (_i, [_vp, _i, _i, _i]),
+    "gfship_multilevel_params_init": (None, [C.POINTER(MultilevelParams), _i]),
+    "gfship_poisson_coefficients": (_i, [_vp]),
+    "gfship_relax": (_i, [_vp, _u, _i, _d, _i, _i, _i]),
+    "gfship_residual": (_i, [_vp, _u, _i, _i, _i, _i, _i]),
+    "gfship_norm_residual": (_i, [_vp, _d, _i, C.POINTER(Norm)]),
+    "gfship_norm_variable": (_i, [_vp, _i, C.POINTER(Norm)]),
+    "gfship_poisson_cycle": (_i, [_vp, C.POINTER(MultilevelParams), _i, _i, _i, _i]),
+    "gfship_poisson_solve": (_i, [_vp, C.POINTER(MultilevelParams), _i, _i, _i, _i, _d]),
+    "gfship_time_relax": (_i, [_vp, _u, _i, _i, _i, _i, _i, _pd]),
+}
+
+
+def lib():
+    """Load libgfship.so; raises if it was not built (no fallback of any kind)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GfshipError("%s not found: run __graft_entry__.build() "
+                              "(gerris-fft-particles_amd/csrc/build.sh)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)   # AttributeError if the library lacks a declared symbol
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise GfshipError("gfship error %d: %s" % (rc, lib().gfship_last_error().decode()))
+    return rc
+
+
+class Variable:
+    """A GfsVariable living on the device (all levels)."""
+
+    def __init__(self, dom, component=-1):
+        self.dom = dom
+        self.h = _check(lib().gfship_field_alloc(dom.ptr, component))
+
+    def _shape(self, level):
+        return ((1 << level) + 2,) * self.dom.dim
+
+    def upload(self, a, level=None):
+        level = self.dom.depth if level is None else level
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.shape == self._shape(level), (a.shape, self._shape(level))
+        _check(lib().gfship_field_upload(self.dom.ptr, self.h, level, a.ctypes.data_as(_pd)))
+
+    def download(self, level=None):
+        level = self.dom.depth if level is None else level
+        a = np.empty(self._shape(level), dtype=np.float64)
+        _check(lib().gfship_field_download(self.dom.ptr, self.h, level, a.ctypes.data_as(_pd)))
+        return a
+
+    def fill(self, value, level=None):
+        level = self.dom.depth if level is None else level
+        _check(lib().gfship_field_fill(self.dom.ptr, self.h, level, value))
+
+    def set_bc(self, d, kind, val=None):
+        if val is not None:
+            val = np.ascontiguousarray(val, dtype=np.float64).ravel()
+            p = val.ctypes.data_as(_pd)
+        else:
+            p = None
+        _check(lib().gfship_field_set_bc(self.dom.ptr, self.h, d, kind, p))
+
+    def free(self):
+        if self.h is not None and self.dom.ptr:
+            lib().gfship_field_free(self.dom.ptr, self.h)
+            self.h = None
+
+
+class Domain:
+    """One uniform GfsBox on one GPU."""
+
+    def __init__(self, dim, depth, side=None, device=0):
+        self.dim, self.depth = dim, depth
+        s = (C.c_int * 6)(*(side if side is not None else [SIDE_BOUNDARY] * 6))
+        p = _vp()
+        _check(lib().gfship_domain_create(C.byref(p), dim, depth, s, device))
+        self.ptr = p
+
+    def variable(self, component=-1):
+        return Variable(self, component)
+
+    def params(self):
+        par = MultilevelParams()
+        lib().gfship_multilevel_params_init(C.byref(par), self.dim)
+        return par
+
+    def set_relax_mode(self, mode):
+        _check(lib().gfship_domain_set_relax_mode(self.ptr, mode))
+
+    def synchronize(self):
+        _check(lib().gfship_domain_synchronize(self.ptr))
+
+    def bc(self, v, v1=None, level=None):
+        level = self.depth if level is None else level
+        _check(lib().gfship_bc(self.ptr, v.h, (v1 or v).h, level))
+
+    def homogeneous_bc(self, ov, v, level=None):
+        level = self.depth if level is None else level
+        _check(lib().gfship_homogeneous_bc(self.ptr, ov.h, v.h, level))
+
+    def poisson_coefficients(self):
+        _check(lib().gfship_poisson_coefficients(self.ptr))
+
+    def relax(self, u, rhs, dia, level=None, omega=1., d=None):
+        level = self.depth if level is None else level
+        _check(lib().gfship_relax(self.ptr, d or self.dim, level, omega, u.h, rhs.h, dia.h))
+
+    def residual(self, u, rhs, dia, res, level=None, d=None):
+        level = self.depth if level is None else level
+        _check(lib().gfship_residual(self.ptr, d or self.dim, level, u.h, rhs.h, dia.h, res.h))
+
+    def norm_residual(self, res, dt=1.):
+        n = Norm()
+        _check(lib().gfship_norm_residual(self.ptr, dt, res.h, C.byref(n)))
+        return n
+
+    def norm_variable(self, v):
+        n = Norm()
+        _check(lib().gfship_norm_variable(self.ptr, v.h, C.byref(n)))
+        return n
+
+    def poisson_cycle(self, par, u, rhs, dia, res):
+        _check(lib().gfship_poisson_cycle(self.ptr, C.byref(par), u.h, rhs.h, dia.h, res.h))
+
+    def poisson_solve(self, par, lhs, rhs, res, dia, dt=1.):
+        _check(lib().gfship_poisson_solve(self.ptr, C.byref(par), lhs.h, rhs.h, res.h, dia.h, dt))
+
+    def time_relax(self, u, rhs, dia, level=None, reps=10, d=None):
+        level = self.depth if level is None else level
+        ms = C.c_double()
+        _check(lib().gfship_time_relax(self.ptr, d or self.dim, level, u.h, rhs.h, dia.h, reps,
+                                       C.byref(ms)))
+        return ms.value
+
+    def destroy(self):
+        if self.ptr:
+            lib().gfship_domain_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

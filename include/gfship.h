@@ -1,0 +1,141 @@
+/* gfship.h -- C ABI of libgfship: the MI355X (gfx950) projection / advection / particle path
+ * of Gerris behind the reference's own solver-plugin boundary.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference tree).  Plain C types only: opaque domain handle, integer field handles, host
+ * pointers and sizes.  All functions returning int return 0 on success and a negative
+ * GFSHIP_E* code on failure; gfship_last_error() then holds a message (the reference's hooks
+ * return void and report through g_warning / g_log).
+ *
+ * The library is device-only: there is no CPU fallback.  gfship_domain_create() fails with
+ * GFSHIP_ENODEVICE when no HIP device is present.
+ *
+ * Host-side array convention (upload/download): level l of a field is (n+2)^dim doubles,
+ * n = 2^l, x fastest, one ghost layer per side; cell (i,j,k), 1 <= i,j,k <= n, is at
+ * i + (n+2)*(j + (n+2)*k).  j grows with y, k with z.  The box is the unit cube/square
+ * centred on the origin (GfsBox of size 1, boundary.h:319-327).
+ */
+#ifndef GFSHIP_H
+#define GFSHIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFSHIP_VERSION   1
+#define GFSHIP_MAXLEVEL  12
+
+enum { GFSHIP_OK = 0, GFSHIP_EINVAL = -1, GFSHIP_ENODEVICE = -2, GFSHIP_ENOMEM = -3,
+       GFSHIP_EHIP = -4, GFSHIP_EUNSUPPORTED = -5 };
+
+/* what is behind each side of the box: box->neighbor[d] (src/boundary.h:319-327) */
+enum { GFSHIP_SIDE_PERIODIC = 0,   /* GfsBoundaryPeriodic self edge, src/boundary.c:1704-1760 */
+       GFSHIP_SIDE_BOUNDARY = 1,   /* GfsBoundary + per-variable GfsBc (default symmetry)    */
+       GFSHIP_SIDE_EXTERNAL = 2 }; /* GfsBoundaryMpi, src/mpi_boundary.c:78-246              */
+
+/* GfsBc kinds on a GFSHIP_SIDE_BOUNDARY side: src/boundary.c:45-74 (symmetry, the default),
+   :253-279 (GfsBcDirichlet), :336-360 (GfsBcNeumann) */
+enum { GFSHIP_BC_SYMMETRY = 0, GFSHIP_BC_DIRICHLET = 1, GFSHIP_BC_NEUMANN = 2 };
+
+/* smoother of gfship_relax / gfship_poisson_cycle:
+   EXACT  reproduces the reference's in-place sweep (src/poisson.c:507-557, tree pre-order of
+          src/ftt.c:837-852) bit for bit on the device;
+   REDBLACK is a two-colour Gauss-Seidel of the same operator: same fixed point, different
+          iterates (not a reference algorithm; opt-in). */
+enum { GFSHIP_RELAX_EXACT = 0, GFSHIP_RELAX_REDBLACK = 1 };
+
+typedef struct gfship_domain gfship_domain;   /* GfsDomain + its per-level SoA device arrays */
+typedef int gfship_field;                     /* GfsVariable handle (>= 0) */
+
+typedef struct {           /* GfsNorm, src/fluid.h; filled as src/fluid.c:2107-2171 */
+  double bias, first, second, infty, w;
+} gfship_norm;
+
+typedef struct {           /* GfsMultilevelParams, src/poisson.h:39-52, field for field */
+  double tolerance;
+  unsigned nrelax, erelax;
+  unsigned minlevel;
+  unsigned nitermax, nitermin;
+  unsigned dimension;
+  unsigned niter;
+  unsigned depth;
+  int weighted, function;
+  double beta, omega;
+  gfship_norm residual_before, residual;
+} gfship_multilevel_params;
+
+const char * gfship_last_error (void);
+int          gfship_version (void);
+int          gfship_device_count (void);
+
+/* ---- domain and variables -------------------------------------------------------------- */
+
+/* One uniform GfsBox refined to `depth` (Refine depth): replaces the FttCell/FttOct tree of
+   src/ftt.h:134-159 and the per-cell GfsStateVector of src/fluid.h:39-52 by per-level SoA
+   device arrays.  side[d], d = 0..2*dim-1 in the order of src/ftt.h:78-89. */
+int  gfship_domain_create (gfship_domain ** dom, int dim, int depth, const int side[6],
+			   int device);
+void gfship_domain_destroy (gfship_domain * dom);
+int  gfship_domain_set_relax_mode (gfship_domain * dom, int mode);
+int  gfship_domain_synchronize (gfship_domain * dom);
+/* raw HIP stream (hipStream_t) all work of this domain is enqueued on */
+void * gfship_domain_stream (gfship_domain * dom);
+
+/* gfs_domain_add_variable / gfs_temporary_variable (src/domain.c:3271-3385);
+   component = 0..2 for a vector component (gfs_variable_set_vector), -1 for scalars */
+gfship_field gfship_field_alloc (gfship_domain * dom, int component);
+int  gfship_field_free (gfship_domain * dom, gfship_field f);
+/* GfsBc of variable f on side d (src/boundary.c:1853-2014 box reader); val = n^(dim-1)
+   leaf-level face-centre values (first tangential axis fastest) or NULL for 0 */
+int  gfship_field_set_bc (gfship_domain * dom, gfship_field f, int d, int type,
+			  const double * val);
+int  gfship_field_upload (gfship_domain * dom, gfship_field f, int level, const double * host);
+int  gfship_field_download (gfship_domain * dom, gfship_field f, int level, double * host);
+int  gfship_field_fill (gfship_domain * dom, gfship_field f, int level, double value);
+/* device pointer and layout of level `level`: cell (i,j,k) is at
+   ptr[xo + i + px*(j + (n+2)*k)] */
+void * gfship_field_device_ptr (gfship_domain * dom, gfship_field f, int level,
+				int * px, int * xo);
+
+/* gfs_domain_copy_bc (src/domain.c:846-867) / gfs_domain_homogeneous_bc (:945-965) */
+int  gfship_bc (gfship_domain * dom, gfship_field v, gfship_field v1, int level);
+int  gfship_homogeneous_bc (gfship_domain * dom, gfship_field ov, gfship_field v, int level);
+
+/* ---- Poisson multigrid (the GfsPoissonSolverFunc boundary, src/poisson.h:32-38) -------- */
+
+void gfship_multilevel_params_init (gfship_multilevel_params * par, int dim);
+						/* gfs_multilevel_params_init, src/poisson.c:70-89 */
+/* gfs_poisson_coefficients (src/poisson.c:856-901) with alpha = NULL */
+int  gfship_poisson_coefficients (gfship_domain * dom);
+/* gfs_relax, src/poisson.c:604-632: one in-place sweep of level `level` */
+int  gfship_relax (gfship_domain * dom, unsigned d, int level, double omega,
+		   gfship_field u, gfship_field rhs, gfship_field dia);
+/* gfs_residual, src/poisson.c:721-747 */
+int  gfship_residual (gfship_domain * dom, unsigned d, int level,
+		      gfship_field u, gfship_field rhs, gfship_field dia, gfship_field res);
+/* gfs_domain_norm_residual, src/domain.c:2239-2288 */
+int  gfship_norm_residual (gfship_domain * dom, double dt, gfship_field res, gfship_norm * out);
+/* gfs_domain_norm_variable on leaves, src/domain.c:2197-2232 */
+int  gfship_norm_variable (gfship_domain * dom, gfship_field v, gfship_norm * out);
+/* gfs_poisson_cycle, src/poisson.c:1109-1178 */
+int  gfship_poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
+			   gfship_field u, gfship_field rhs, gfship_field dia, gfship_field res);
+/* gfs_poisson_solve, src/poisson.c:1225-1269: the function installed in
+   GfsMultilevelParams.poisson_solve (called at src/timestep.c:423, src/simulation.c:2267) */
+int  gfship_poisson_solve (gfship_domain * dom, gfship_multilevel_params * par,
+			   gfship_field lhs, gfship_field rhs, gfship_field res,
+			   gfship_field dia, double dt);
+
+/* ---- instrumentation -------------------------------------------------------------------- */
+
+/* time (HIP events on the domain's stream) of `reps` back-to-back sweeps of gfship_relax on
+   `level`, in milliseconds per sweep; used by bench.py for the roofline entry */
+int  gfship_time_relax (gfship_domain * dom, unsigned d, int level, gfship_field u,
+			gfship_field rhs, gfship_field dia, int reps, double * ms_per_sweep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFSHIP_H */

@@ -1,0 +1,262 @@
+"""GPU parity of the Poisson path: libgfship (through the C ABI) against the CPU oracle on the
+same inputs.  Exact mode must be bit-identical (np.array_equal) for fields and for the
+max-norm; the summed norms are tree-reduced on the device and agree to 1e-12 relative."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import gfship
+from oracle import oracle as O
+from poisson_cases import dirichlet_case, oracle_dirichlet_solve
+
+pytestmark = pytest.mark.gpu
+RTOL_SUM = 1e-12
+
+
+def _pair(dim, level, side=None):
+    od = O.Domain(dim, level, side)
+    gd = gfship.Domain(dim, level, side)
+    return od, gd
+
+
+def _rand_fields(od, gd, names, rng, level=None):
+    level = od.depth if level is None else level
+    out = {}
+    for nm in names:
+        of, gf = od.field(), gd.variable()
+        a = rng.standard_normal(of.level(level).shape)
+        of.level(level)[...] = a
+        gf.upload(a, level)
+        out[nm] = (of, gf)
+    return out
+
+
+def _interior(a, dim):
+    return a[(slice(1, -1),) * dim]
+
+
+def _faces_equal(a, b, dim):
+    """interior plus face ghosts (edge/corner ghosts are not part of the reference's data)."""
+    if not np.array_equal(_interior(a, dim), _interior(b, dim)):
+        return False
+    for ax in range(dim):
+        for s in (0, -1):
+            sl = [slice(1, -1)] * dim
+            sl[ax] = s
+            if not np.array_equal(a[tuple(sl)], b[tuple(sl)]):
+                return False
+    return True
+
+
+@pytest.mark.parametrize("dim,level", [(2, 3), (2, 6), (3, 2), (3, 4), (3, 5)])
+def test_relax_sweeps_bit_exact(dim, level):
+    L = O.lib()
+    rng = np.random.default_rng(100 + 10 * dim + level)
+    od, gd = _pair(dim, level)
+    L.go_poisson_coefficients(od.ptr)
+    gd.poisson_coefficients()
+    f = _rand_fields(od, gd, ["u", "rhs", "dia"], rng)
+    f["dia"][0].leaf()[...] = 0.
+    f["dia"][1].fill(0.)
+    for omega in (1., 0.9):
+        for _ in range(3):
+            L.go_relax(od.ptr, dim, level, omega, f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr)
+            gd.relax(f["u"][1], f["rhs"][1], f["dia"][1], omega=omega)
+        assert np.array_equal(f["u"][0].leaf(), f["u"][1].download())
+
+
+@pytest.mark.parametrize("dim,level", [(2, 5), (3, 4)])
+def test_relax_with_nonzero_dia_bit_exact(dim, level):
+    L = O.lib()
+    rng = np.random.default_rng(5)
+    od, gd = _pair(dim, level)
+    L.go_poisson_coefficients(od.ptr)
+    gd.poisson_coefficients()
+    f = _rand_fields(od, gd, ["u", "rhs", "dia"], rng)
+    a = np.abs(f["dia"][0].leaf()) + 0.1
+    f["dia"][0].leaf()[...] = a
+    f["dia"][1].upload(a)
+    L.go_relax(od.ptr, dim, level, 1., f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr)
+    gd.relax(f["u"][1], f["rhs"][1], f["dia"][1])
+    assert np.array_equal(f["u"][0].leaf(), f["u"][1].download())
+
+
+@pytest.mark.parametrize("dim,level", [(2, 6), (3, 5)])
+def test_residual_and_norm(dim, level):
+    L = O.lib()
+    rng = np.random.default_rng(11)
+    od, gd = _pair(dim, level)
+    L.go_poisson_coefficients(od.ptr)
+    gd.poisson_coefficients()
+    f = _rand_fields(od, gd, ["u", "rhs", "dia", "res"], rng)
+    L.go_residual(od.ptr, dim, level, f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr,
+                  f["res"][0].ptr)
+    gd.residual(f["u"][1], f["rhs"][1], f["dia"][1], f["res"][1])
+    assert np.array_equal(_interior(f["res"][0].leaf(), dim), _interior(f["res"][1].download(), dim))
+    on = L.go_norm_residual(od.ptr, 0.7, f["res"][0].ptr)
+    gn = gd.norm_residual(f["res"][1], 0.7)
+    assert gn.infty == on.infty            # max is order independent: exact
+    for k in ("bias", "first", "second"):
+        assert getattr(gn, k) == pytest.approx(getattr(on, k), rel=RTOL_SUM, abs=1e-13)
+    on = L.go_norm_variable(od.ptr, f["u"][0].ptr)
+    gn = gd.norm_variable(f["u"][1])
+    assert gn.infty == on.infty
+    for k in ("bias", "first", "second"):
+        assert getattr(gn, k) == pytest.approx(getattr(on, k), rel=RTOL_SUM, abs=1e-15)
+
+
+SIDES = {
+    "dirichlet": ([O.SIDE_BOUNDARY] * 6, O.BC_DIRICHLET),
+    "neumann": ([O.SIDE_BOUNDARY] * 6, O.BC_NEUMANN),
+    "symmetry": ([O.SIDE_BOUNDARY] * 6, O.BC_SYMMETRY),
+    "periodic": ([O.SIDE_PERIODIC] * 6, O.BC_SYMMETRY),
+    "mixed": ([O.SIDE_PERIODIC, O.SIDE_PERIODIC, O.SIDE_BOUNDARY, O.SIDE_BOUNDARY,
+               O.SIDE_BOUNDARY, O.SIDE_BOUNDARY], O.BC_NEUMANN),
+}
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("kind", sorted(SIDES))
+def test_bc_ghost_fill(dim, kind):
+    L = O.lib()
+    level = 4
+    side, bck = SIDES[kind]
+    rng = np.random.default_rng(3)
+    od, gd = _pair(dim, level, side)
+    n = 1 << level
+    for component in (-1, 0, 1):
+        of, gf = od.field(component), gd.variable(component)
+        a = rng.standard_normal(of.leaf().shape)
+        # only interior values are inputs; ghosts start at zero on both sides
+        b = np.zeros_like(a)
+        b[(slice(1, -1),) * dim] = a[(slice(1, -1),) * dim]
+        of.leaf()[...] = b
+        gf.upload(b)
+        for d in range(2 * dim):
+            val = rng.standard_normal(n ** (dim - 1))
+            of.set_bc(d, bck, val)
+            gf.set_bc(d, bck, val)
+        L.go_bc(of.ptr, of.ptr, level)
+        gd.bc(gf)
+        assert _faces_equal(of.leaf(), gf.download(), dim)
+        L.go_homogeneous_bc(of.ptr, of.ptr, level)
+        gd.homogeneous_bc(gf, gf)
+        assert _faces_equal(of.leaf(), gf.download(), dim)
+
+
+@pytest.mark.parametrize("dim,level,kind", [(2, 5, "dirichlet"), (2, 5, "periodic"),
+                                            (3, 4, "dirichlet"), (3, 4, "periodic"),
+                                            (3, 5, "neumann"), (3, 5, "mixed")])
+def test_poisson_cycle_bit_exact(dim, level, kind):
+    """One full V-cycle (restriction, LDS relax loops on coarse levels, prolongation,
+    hyperplane sweeps, correction, BC, residual) against the oracle."""
+    L = O.lib()
+    side, bck = SIDES[kind]
+    rng = np.random.default_rng(17)
+    od, gd = _pair(dim, level, side)
+    L.go_poisson_coefficients(od.ptr)
+    gd.poisson_coefficients()
+    f = _rand_fields(od, gd, ["u", "rhs", "dia", "res"], rng)
+    f["dia"][0].leaf()[...] = 0.
+    f["dia"][1].fill(0.)
+    n = 1 << level
+    for d in range(2 * dim):
+        val = rng.standard_normal(n ** (dim - 1))
+        f["u"][0].set_bc(d, bck, val)
+        f["u"][1].set_bc(d, bck, val)
+    L.go_bc(f["u"][0].ptr, f["u"][0].ptr, level)
+    gd.bc(f["u"][1])
+    L.go_residual(od.ptr, dim, level, f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr,
+                  f["res"][0].ptr)
+    gd.residual(f["u"][1], f["rhs"][1], f["dia"][1], f["res"][1])
+    op, gp = od.params(), gd.params()
+    for p in (op, gp):
+        p.depth = level
+    for _ in range(2):
+        L.go_poisson_cycle(od.ptr, C.byref(op), f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr,
+                           f["res"][0].ptr)
+        gd.poisson_cycle(gp, f["u"][1], f["rhs"][1], f["dia"][1], f["res"][1])
+        assert _faces_equal(f["u"][0].leaf(), f["u"][1].download(), dim)
+        assert np.array_equal(_interior(f["res"][0].leaf(), dim),
+                              _interior(f["res"][1].download(), dim))
+
+
+def test_poisson_solve_reproduces_reference_golden_res7(golden_dir):
+    """The reference's own golden curve (test/poisson/res-7.ref, 2-D level 8) through the device
+    path: every printed digit of the max residual after N cycles."""
+    rows = [l.split() for l in open(os.path.join(golden_dir, "reference", "poisson_res-7.ref"))]
+    rhs, faces, _ = dirichlet_case(2, 8)
+    for row in rows[::2]:
+        cyc = int(row[0])
+        gd = gfship.Domain(2, 8)
+        P, div, res, dia = (gd.variable() for _ in range(4))
+        a = np.zeros((258, 258))
+        a[1:-1, 1:-1] = rhs
+        div.upload(a)
+        for d, fv in enumerate(faces):
+            P.set_bc(d, gfship.BC_DIRICHLET, fv)
+        gd.bc(P)
+        gd.poisson_coefficients()
+        par = gd.params()
+        par.tolerance, par.nitermin, par.nitermax = 1e-30, cyc, cyc
+        gd.poisson_solve(par, P, div, res, dia, 1.)
+        assert "%.3e" % par.residual.infty == row[2]
+        # and bit-exact against the oracle
+        od, oP, ores, opar, _ = oracle_dirichlet_solve(2, 8, cyc)
+        assert par.residual.infty == opar.residual.infty
+        assert np.array_equal(oP.interior(), P.download()[1:-1, 1:-1])
+        gd.destroy()
+
+
+@pytest.mark.parametrize("level", [5, 6])
+def test_poisson_solve_3d_dirichlet_bit_exact(level):
+    """3-D analogue of test/poisson (SURVEY.md 8d config B at a size the oracle finishes in
+    seconds): solve loop incl. niter, norms, stall logic."""
+    rhs, faces, ex = dirichlet_case(3, level)
+    n = 1 << level
+    gd = gfship.Domain(3, level)
+    P, div, res, dia = (gd.variable() for _ in range(4))
+    a = np.zeros((n + 2,) * 3)
+    a[1:-1, 1:-1, 1:-1] = rhs
+    div.upload(a)
+    for d, fv in enumerate(faces):
+        P.set_bc(d, gfship.BC_DIRICHLET, fv)
+    gd.bc(P)
+    gd.poisson_coefficients()
+    par = gd.params()
+    par.tolerance, par.nitermin, par.nitermax = 1e-30, 4, 4
+    gd.poisson_solve(par, P, div, res, dia, 1.)
+    od, oP, ores, opar, _ = oracle_dirichlet_solve(3, level, 4)
+    assert par.niter == opar.niter == 4
+    assert par.residual.infty == opar.residual.infty
+    assert par.residual_before.infty == opar.residual_before.infty
+    assert np.array_equal(oP.interior(), P.download()[1:-1, 1:-1, 1:-1])
+    assert np.array_equal(ores.interior(), res.download()[1:-1, 1:-1, 1:-1])
+
+
+def test_redblack_mode_converges_to_same_solution():
+    """The opt-in red-black smoother has different iterates but the same fixed point: converged
+    to round-off, P agrees with the exact-mode P to 1e-12 relative L-inf."""
+    level = 5
+    rhs, faces, ex = dirichlet_case(3, level)
+    n = 1 << level
+    sols = []
+    for mode in (gfship.RELAX_EXACT, gfship.RELAX_REDBLACK):
+        gd = gfship.Domain(3, level)
+        gd.set_relax_mode(mode)
+        P, div, res, dia = (gd.variable() for _ in range(4))
+        a = np.zeros((n + 2,) * 3)
+        a[1:-1, 1:-1, 1:-1] = rhs
+        div.upload(a)
+        for d, fv in enumerate(faces):
+            P.set_bc(d, gfship.BC_DIRICHLET, fv)
+        gd.bc(P)
+        gd.poisson_coefficients()
+        par = gd.params()
+        par.tolerance, par.nitermin, par.nitermax = 1e-30, 30, 30
+        gd.poisson_solve(par, P, div, res, dia, 1.)
+        sols.append(P.download()[1:-1, 1:-1, 1:-1])
+    err = np.abs(sols[0] - sols[1]).max() / np.abs(sols[0]).max()
+    assert err < 1e-12, err
