@@ -81,6 +81,7 @@ typedef struct {           /* one variable: all levels, ghosts included */
   int bc[6];               /* GO_BC_* per direction, used on GO_SIDE_BOUNDARY sides */
   double * bcval[6];       /* leaf-level face-centre values (n^(dim-1)) or NULL (= 0.) */
   int component;           /* vector component 0..2, or -1 for scalars (symmetry sign) */
+  int depth;               /* copy of dom->depth (lets a field outlive its domain safely) */
 } GoField;
 
 /* exchange hook for GO_SIDE_EXTERNAL sides: must fill the ghost layer of `a` (level `level`)

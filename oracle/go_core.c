@@ -106,6 +106,7 @@ GoField * go_field_new (GoDomain * dom, int component)
   GoField * f = calloc (1, sizeof (GoField));
   f->dom = dom;
   f->component = component;
+  f->depth = dom->depth;
   for (int l = 0; l <= dom->depth; l++)
     f->lev[l] = calloc (dom->size[l], sizeof (double));
   return f;
@@ -114,7 +115,7 @@ GoField * go_field_new (GoDomain * dom, int component)
 void go_field_destroy (GoField * f)
 {
   if (!f) return;
-  for (int l = 0; l <= f->dom->depth; l++)
+  for (int l = 0; l <= f->depth; l++)
     free (f->lev[l]);
   for (int d = 0; d < 6; d++)
     free (f->bcval[d]);

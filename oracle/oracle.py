@@ -146,3 +146,129 @@ class Domain:
             lib().go_domain_destroy(self.ptr)
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------
+# GfsSimulation (oracle/go_timestep.c)
+# ---------------------------------------------------------------------------------------------
+
+class AdvectionParams(C.Structure):
+    _fields_ = [("cfl", C.c_double), ("dt", C.c_double), ("gradient", C.c_int), ("gc", C.c_int)]
+
+
+def _sim_sigs(L):
+    vp, i, d, u = C.c_void_p, C.c_int, C.c_double, C.c_uint
+    pd = C.POINTER(C.c_double)
+    sig = {
+        "go_sim_new": (vp, [i, i, C.POINTER(C.c_int)]),
+        "go_sim_destroy": (None, [vp]),
+        "go_sim_field": (vp, [vp, i, i]),
+        "go_sim_domain": (vp, [vp]),
+        "go_sim_projection_params": (C.POINTER(MultilevelParams), [vp]),
+        "go_sim_approx_projection_params": (C.POINTER(MultilevelParams), [vp]),
+        "go_sim_advection_params": (C.POINTER(AdvectionParams), [vp]),
+        "go_sim_un": (pd, [vp, i]),
+        "go_sim_fv": (pd, [vp, i]),
+        "go_sim_time": (d, [vp]),
+        "go_sim_iter": (u, [vp]),
+        "go_sim_set_time": (None, [vp, d, d]),
+        "go_sim_add_tracer": (i, [vp]),
+        "go_predicted_face_velocities": (None, [vp]),
+        "go_domain_cfl": (d, [vp]),
+        "go_set_timestep": (None, [vp]),
+        "go_coarse_init": (None, [vp]),
+        "go_sim_start": (None, [vp]),
+        "go_sim_step": (None, [vp]),
+        "go_divergence": (None, [vp, vp]),
+        "go_tracer_advection": (None, [vp, vp, d]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+
+
+class _FieldView(Field):
+    """A field owned by a GoSim (not freed from python)."""
+
+    def __init__(self, dom, ptr):
+        self.dom, self.ptr = dom, ptr
+
+    def __del__(self):
+        pass
+
+
+class _DomView(Domain):
+    def __init__(self, dim, depth, ptr, side):
+        self.dim, self.depth, self.ptr, self.side = dim, depth, ptr, side
+
+    def __del__(self):
+        pass
+
+
+class Sim:
+    P, PMAC, U, G, GMAC, TRACER = 0, 1, 2, 3, 4, 5
+
+    def __init__(self, dim, depth, side=None):
+        L = lib()
+        if not getattr(L, "_sim_ready", False):
+            _sim_sigs(L)
+            L._sim_ready = True
+        s = (C.c_int * 6)(*(side if side is not None else [SIDE_BOUNDARY] * 6))
+        self.dim, self.depth = dim, depth
+        self.ptr = L.go_sim_new(dim, depth, s)
+        self.dom = _DomView(dim, depth, L.go_sim_domain(self.ptr), list(s))
+        self.p = self.field(self.P)
+        self.pmac = self.field(self.PMAC)
+        self.u = [self.field(self.U, c) for c in range(dim)]
+        self.g = [self.field(self.G, c) for c in range(dim)]
+        self.gmac = [self.field(self.GMAC, c) for c in range(dim)]
+        self.projection_params = L.go_sim_projection_params(self.ptr).contents
+        self.approx_projection_params = L.go_sim_approx_projection_params(self.ptr).contents
+        self.advection_params = L.go_sim_advection_params(self.ptr).contents
+
+    def field(self, which, c=0):
+        return _FieldView(self.dom, lib().go_sim_field(self.ptr, which, c))
+
+    def add_tracer(self):
+        t = lib().go_sim_add_tracer(self.ptr)
+        return self.field(self.TRACER, t)
+
+    def un(self, d):
+        n = (1 << self.depth) + 2
+        return np.ctypeslib.as_array(lib().go_sim_un(self.ptr, d), shape=(n,) * self.dim)
+
+    def fv(self, d):
+        n = (1 << self.depth) + 2
+        return np.ctypeslib.as_array(lib().go_sim_fv(self.ptr, d), shape=(n,) * self.dim)
+
+    def set_time(self, end=1.7976931348623157e308, dtmax=1.7976931348623157e308):
+        lib().go_sim_set_time(self.ptr, end, dtmax)
+
+    @property
+    def t(self):
+        return lib().go_sim_time(self.ptr)
+
+    @property
+    def i(self):
+        return lib().go_sim_iter(self.ptr)
+
+    @property
+    def dt(self):
+        return self.advection_params.dt
+
+    def start(self):
+        lib().go_sim_start(self.ptr)
+
+    def step(self):
+        lib().go_sim_step(self.ptr)
+
+    def divergence_norm(self):
+        e = self.dom.field()
+        lib().go_divergence(self.ptr, e.ptr)
+        return lib().go_norm_variable(self.dom.ptr, e.ptr)
+
+    def __del__(self):
+        try:
+            lib().go_sim_destroy(self.ptr)
+        except Exception:
+            pass
