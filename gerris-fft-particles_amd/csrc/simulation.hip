@@ -1,0 +1,414 @@
+// simulation.hip -- host control of the projection + advection time step: the body of
+// simulation_run (src/simulation.c:432-557) and the drivers of src/timestep.c, statement by
+// statement; every traversal is a kernel launch on the domain's stream.
+#include "gfship_internal.hpp"
+#include <cmath>
+#include <cfloat>
+
+using namespace gfship;
+
+#define G_MAXINT 2147483647
+
+struct gfship_sim {
+  gfship_domain * dom = nullptr;
+  gfship_field p = -1, pmac = -1, u[3] = {-1, -1, -1}, g[3] = {-1, -1, -1}, gmac[3] = {-1, -1, -1};
+  std::vector<gfship_field> tracers;
+  gfship_field un[3] = {-1, -1, -1};   // face normal velocities (see timestep_kernels.hip)
+  gfship_field fv[6] = {-1, -1, -1, -1, -1, -1};
+  gfship_field dia = -1, div = -1, res = -1, tmp = -1; // temporaries of mac_projection
+  gfship_multilevel_params projection_params, approx_projection_params;
+  gfship_advection_params advection_params;
+  double t = 0., end = DBL_MAX, dtmax = DBL_MAX, tnext = 0.;
+  unsigned i = 0, iend = G_MAXINT;
+};
+
+namespace {
+
+inline double * leaf (gfship_sim * s, gfship_field f)
+{
+  return s->dom->fields[f].lev[s->dom->depth];
+}
+
+void ptrs3 (gfship_sim * s, const gfship_field f[3], double * out[3])
+{
+  for (int c = 0; c < 3; c++)
+    out[c] = (c < s->dom->dim && f[c] >= 0) ? leaf (s, f[c]) : nullptr;
+}
+
+void ptrs6 (gfship_sim * s, double * out[6])
+{
+  for (int d = 0; d < 6; d++)
+    out[d] = d < 2*s->dom->dim ? leaf (s, s->fv[d]) : nullptr;
+}
+
+#define TRY(x) do { int r_ = (x); if (r_ != GFSHIP_OK) return r_; } while (0)
+
+int bc_leaf (gfship_sim * s, gfship_field v)
+{
+  Field * V = get_field (s->dom, v);
+  return launch_bc (s->dom, V, V, s->dom->depth, 0);
+}
+
+// mac_projection, src/timestep.c:356-444.  `pdata` supplies the storage of the pressure and
+// `pbc` the boundary conditions (gfs_variables_swap swaps storage only, src/variable.c:234-243).
+int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, gfship_field p,
+		    const gfship_field g[3])
+{
+  gfship_domain * dom = s->dom;
+  double * un[3], * gp[3];
+  ptrs3 (s, s->un, un);
+  ptrs3 (s, g, gp);
+  /* gfs_reset_gradients + no face sources: g is overwritten by centered_gradient below */
+  /* gfs_poisson_coefficients (alpha = NULL): unit weights */
+  TRY (gfship_poisson_coefficients (dom));
+  /* dia = 0 on all levels (gfs_cell_reset on FTT_TRAVERSE_ALL) */
+  for (int l = 0; l <= dom->depth; l++)
+    TRY (launch_fill (dom, l, dom->fields[s->dia].lev[l], 0.));
+  /* MAC divergence, scaled by 1/dt */
+  TRY (launch_divergence (dom, un, leaf (s, s->div), dt));
+  TRY (gfship_poisson_solve (dom, par, p, s->div, s->res, s->dia, dt));
+  /* gfs_correct_normal_velocities + gfs_scale_gradients */
+  TRY (launch_correct_un (dom, leaf (s, p), un, dt));
+  TRY (launch_centered_gradient (dom, leaf (s, p), gp));
+  for (int c = 0; c < dom->dim; c++)
+    TRY (bc_leaf (s, g[c]));
+  return GFSHIP_OK;
+}
+
+// gfs_correct_centered_velocities, src/timestep.c:498-530
+int correct_centered_velocities (gfship_sim * s, const gfship_field g[3], double dt)
+{
+  double * u[3], * gp[3];
+  ptrs3 (s, s->u, u);
+  ptrs3 (s, g, gp);
+  TRY (launch_correct_centered (s->dom, u, gp, dt));
+  for (int c = 0; c < s->dom->dim; c++)
+    TRY (bc_leaf (s, s->u[c]));
+  return GFSHIP_OK;
+}
+
+// face_values_set, src/timestep.c:644-654
+int face_values_set (gfship_sim * s, gfship_field v, double dt, int use_centered, int gradient)
+{
+  double * u[3], * un[3], * fv[6];
+  ptrs3 (s, s->u, u);
+  ptrs3 (s, s->un, un);
+  ptrs6 (s, fv);
+  TRY (launch_advected_face_values (s->dom, leaf (s, v), u, un, dt, use_centered, gradient, fv));
+  TRY (launch_face_bc (s->dom, get_field (s->dom, v), fv));
+  return GFSHIP_OK;
+}
+
+// variable_sources, src/timestep.c:872-921 (Godunov, no sources)
+int variable_sources (gfship_sim * s, gfship_field v, int gradient, bool velocity, double dt,
+		      const gfship_field gmac[3], const gfship_field g[3])
+{
+  double * un[3], * fv[6];
+  ptrs3 (s, s->un, un);
+  ptrs6 (s, fv);
+  TRY (face_values_set (s, v, dt, 0, gradient));
+  int c = s->dom->fields[v].component;
+  const double * gm = velocity ? leaf (s, gmac[c]) : nullptr;
+  const double * gc = (velocity && g) ? leaf (s, g[c]) : nullptr;
+  TRY (launch_flux_update (s->dom, velocity, leaf (s, v), un, fv, gm, gc, dt));
+  return GFSHIP_OK;
+}
+
+int advance_tracers (gfship_sim * s, double dt)
+{
+  for (gfship_field t : s->tracers)
+    TRY (gfship_tracer_advection (s, t, dt));
+  return GFSHIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int gfship_sim_create (gfship_sim ** out, gfship_domain * dom)
+{
+  GFSHIP_CHECK (out && dom, GFSHIP_EINVAL, "null argument");
+  *out = nullptr;
+  for (int d = 0; d < 2*dom->dim; d++)
+    GFSHIP_CHECK (dom->side[d] != GFSHIP_SIDE_EXTERNAL, GFSHIP_EUNSUPPORTED,
+		  "the time step does not handle GfsBoundaryMpi sides yet");
+  gfship_sim * s = new gfship_sim;
+  s->dom = dom;
+  auto alloc = [&] (int comp) { return gfship_field_alloc (dom, comp); };
+  s->p = alloc (-1);
+  s->pmac = alloc (-1);
+  for (int c = 0; c < dom->dim; c++) {
+    s->u[c] = alloc (c);
+    s->g[c] = alloc (c);      /* gfs_variable_set_vector (g / gmac), src/simulation.c:455-456 */
+    s->gmac[c] = alloc (c);
+    s->un[c] = alloc (-1);
+  }
+  for (int d = 0; d < 2*dom->dim; d++)
+    s->fv[d] = alloc (-1);
+  s->dia = alloc (-1);
+  s->div = alloc (-1);
+  s->res = alloc (-1);
+  gfship_multilevel_params_init (&s->projection_params, dom->dim);
+  gfship_multilevel_params_init (&s->approx_projection_params, dom->dim);
+  /* gfs_advection_params_init, src/advection.c:922-942 */
+  s->advection_params.cfl = 0.8;
+  s->advection_params.dt = 0.;
+  s->advection_params.gradient = 0;
+  s->advection_params.gc = 1;
+  if (s->res < 0) {
+    gfship_sim_destroy (s);
+    return GFSHIP_ENOMEM;
+  }
+  *out = s;
+  return GFSHIP_OK;
+}
+
+void gfship_sim_destroy (gfship_sim * s)
+{
+  if (!s) return;
+  gfship_domain * dom = s->dom;
+  auto fr = [&] (gfship_field f) { if (f >= 0) gfship_field_free (dom, f); };
+  fr (s->p); fr (s->pmac);
+  for (int c = 0; c < 3; c++) { fr (s->u[c]); fr (s->g[c]); fr (s->gmac[c]); fr (s->un[c]); }
+  for (int d = 0; d < 6; d++) fr (s->fv[d]);
+  fr (s->dia); fr (s->div); fr (s->res);
+  for (gfship_field t : s->tracers) fr (t);
+  delete s;
+}
+
+gfship_field gfship_sim_variable (gfship_sim * s, int which, int c)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  GFSHIP_CHECK (c >= 0 && (which == GFSHIP_VAR_TRACER || c < s->dom->dim), GFSHIP_EINVAL,
+		"component %d out of range", c);
+  switch (which) {
+  case GFSHIP_VAR_P: return s->p;
+  case GFSHIP_VAR_PMAC: return s->pmac;
+  case GFSHIP_VAR_U: return s->u[c];
+  case GFSHIP_VAR_G: return s->g[c];
+  case GFSHIP_VAR_GMAC: return s->gmac[c];
+  case GFSHIP_VAR_TRACER:
+    GFSHIP_CHECK ((size_t) c < s->tracers.size (), GFSHIP_EINVAL, "no tracer %d", c);
+    return s->tracers[c];
+  }
+  set_error ("unknown variable kind %d", which);
+  return GFSHIP_EINVAL;
+}
+
+gfship_multilevel_params * gfship_sim_projection_params (gfship_sim * s)
+{ return s ? &s->projection_params : nullptr; }
+gfship_multilevel_params * gfship_sim_approx_projection_params (gfship_sim * s)
+{ return s ? &s->approx_projection_params : nullptr; }
+gfship_advection_params * gfship_sim_advection_params (gfship_sim * s)
+{ return s ? &s->advection_params : nullptr; }
+
+int gfship_sim_set_time (gfship_sim * s, double end, double dtmax)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  s->end = end;
+  s->dtmax = dtmax;
+  return GFSHIP_OK;
+}
+
+double gfship_sim_time (gfship_sim * s) { return s ? s->t : 0.; }
+unsigned gfship_sim_iter (gfship_sim * s) { return s ? s->i : 0; }
+
+int gfship_sim_add_tracer (gfship_sim * s)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  gfship_field t = gfship_field_alloc (s->dom, -1);
+  if (t < 0) return t;
+  s->tracers.push_back (t);
+  return (int) s->tracers.size () - 1;
+}
+
+int gfship_predicted_face_velocities (gfship_sim * s)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  double * fv[6];
+  ptrs6 (s, fv);
+  /* the reset of every face (gfs_face_reset_normal_velocity) is implied: each component's
+     faces are all overwritten below */
+  for (int c = 0; c < s->dom->dim; c++) {
+    TRY (face_values_set (s, s->u[c], s->advection_params.dt, 1, s->advection_params.gradient));
+    TRY (launch_predict_un (s->dom, c, leaf (s, s->u[c]), fv, leaf (s, s->un[c])));
+  }
+  return GFSHIP_OK;
+}
+
+int gfship_mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt,
+			   gfship_field p, const gfship_field g[3])
+{
+  GFSHIP_CHECK (s && par && g, GFSHIP_EINVAL, "null argument");
+  return mac_projection (s, par, dt, p, g);
+}
+
+int gfship_approximate_projection (gfship_sim * s, gfship_multilevel_params * par, double dt,
+				   gfship_field p, const gfship_field g[3])
+{
+  GFSHIP_CHECK (s && par && g, GFSHIP_EINVAL, "null argument");
+  double * u[3], * un[3];
+  ptrs3 (s, s->u, u);
+  ptrs3 (s, s->un, un);
+  /* compute MAC velocities from centered velocities */
+  TRY (launch_face_interp_un (s->dom, u, un));
+  TRY (mac_projection (s, par, dt, p, g));
+  TRY (correct_centered_velocities (s, g, dt));
+  return GFSHIP_OK;
+}
+
+int gfship_centered_velocity_advection (gfship_sim * s, const gfship_field gmac[3],
+					const gfship_field g[3])
+{
+  GFSHIP_CHECK (s && gmac, GFSHIP_EINVAL, "null argument");
+  for (int c = 0; c < s->dom->dim; c++)
+    TRY (variable_sources (s, s->u[c], s->advection_params.gradient, true,
+			   s->advection_params.dt, gmac, g));
+  for (int c = 0; c < s->dom->dim; c++)
+    TRY (bc_leaf (s, s->u[c]));
+  return GFSHIP_OK;
+}
+
+int gfship_tracer_advection (gfship_sim * s, gfship_field t, double dt)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  if (!get_field (s->dom, t)) return GFSHIP_EINVAL;
+  /* tracers: van Leer gradient + gfs_face_advection_flux (src/variable.c:427-431) */
+  TRY (variable_sources (s, t, 1, false, dt, nullptr, nullptr));
+  TRY (bc_leaf (s, t));
+  return GFSHIP_OK;
+}
+
+int gfship_domain_cfl (gfship_sim * s, double * cfl)
+{
+  GFSHIP_CHECK (s && cfl, GFSHIP_EINVAL, "null argument");
+  double * u[3], * un[3];
+  ptrs3 (s, s->u, u);
+  ptrs3 (s, s->un, un);
+  double c2;
+  TRY (launch_cfl (s->dom, u, un, &c2));
+  *cfl = sqrt (c2);
+  return GFSHIP_OK;
+}
+
+int gfship_set_timestep (gfship_sim * s)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  double t = s->t;
+  double cfl = s->advection_params.cfl;
+  if (cfl < DBL_MAX) {
+    double dcfl;
+    TRY (gfship_domain_cfl (s, &dcfl));
+    s->advection_params.dt = cfl*dcfl;
+  }
+  else
+    s->advection_params.dt = G_MAXINT;
+  if (s->advection_params.dt > s->dtmax)
+    s->advection_params.dt = s->dtmax;
+
+  double tnext = G_MAXINT;
+  if (s->end < tnext)
+    tnext = s->end;
+
+  double n = ceil ((tnext - t)/s->advection_params.dt);
+  if (n > 0. && n < G_MAXINT) {
+    s->advection_params.dt = (tnext - t)/n;
+    if (n == 1.)
+      s->tnext = tnext;
+    else
+      s->tnext = t + s->advection_params.dt;
+  }
+  else
+    s->tnext = t + s->advection_params.dt;
+
+  if (s->advection_params.dt < 1e-9)
+    s->advection_params.dt = 1e-9;
+  return GFSHIP_OK;
+}
+
+int gfship_coarse_init (gfship_sim * s)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  gfship_domain * dom = s->dom;
+  TRY (launch_coarse_init (dom, get_field (dom, s->p)));
+  TRY (launch_coarse_init (dom, get_field (dom, s->pmac)));
+  for (int c = 0; c < dom->dim; c++)
+    TRY (launch_coarse_init (dom, get_field (dom, s->u[c])));
+  for (gfship_field t : s->tracers)
+    TRY (launch_coarse_init (dom, get_field (dom, t)));
+  return GFSHIP_OK;
+}
+
+int gfship_sim_start (gfship_sim * s)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  GFSHIP_CHECK (s->advection_params.gc, GFSHIP_EUNSUPPORTED, "gc = 0 is not supported");
+  /* gfs_simulation_init (src/simulation.c:1068-1103): BCs on every variable, coarse cells */
+  TRY (bc_leaf (s, s->p));
+  TRY (bc_leaf (s, s->pmac));
+  for (int c = 0; c < s->dom->dim; c++)
+    TRY (bc_leaf (s, s->u[c]));
+  for (gfship_field t : s->tracers)
+    TRY (bc_leaf (s, t));
+  TRY (gfship_coarse_init (s));
+
+  TRY (gfship_set_timestep (s));
+  if (s->i == 0) {
+    TRY (gfship_approximate_projection (s, &s->approx_projection_params, s->advection_params.dt,
+					s->p, s->g));
+    TRY (gfship_set_timestep (s));
+    TRY (advance_tracers (s, s->advection_params.dt/2.));
+  }
+  return GFSHIP_OK;
+}
+
+int gfship_sim_step (gfship_sim * s)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  gfship_domain * dom = s->dom;
+  const gfship_field * gc = s->g;
+
+  TRY (gfship_predicted_face_velocities (s));
+
+  /* gfs_variables_swap (p, pmac); gfs_mac_projection (...dt/2, p, gmac); swap back
+     (src/simulation.c:498-503): the projection runs on Pmac's storage with P's BCs */
+  {
+    Field * P = get_field (dom, s->p), * PM = get_field (dom, s->pmac);
+    std::swap (P->lev, PM->lev);
+    int r = mac_projection (s, &s->projection_params, s->advection_params.dt/2., s->p, s->gmac);
+    std::swap (P->lev, PM->lev);
+    if (r != GFSHIP_OK) return r;
+  }
+
+  TRY (gfship_centered_velocity_advection (s, s->gmac, s->i > 0 ? gc : s->gmac));
+  TRY (correct_centered_velocities (s, s->i > 0 ? gc : s->gmac, - s->advection_params.dt));
+
+  TRY (gfship_coarse_init (s));
+
+  TRY (gfship_approximate_projection (s, &s->approx_projection_params, s->advection_params.dt,
+				      s->p, s->g));
+  s->t = s->tnext;
+  s->i++;
+
+  TRY (gfship_set_timestep (s));
+  TRY (advance_tracers (s, s->advection_params.dt));
+  return GFSHIP_OK;
+}
+
+int gfship_divergence_norm (gfship_sim * s, gfship_norm * out)
+{
+  GFSHIP_CHECK (s && out, GFSHIP_EINVAL, "null argument");
+  double * u[3];
+  ptrs3 (s, s->u, u);
+  TRY (launch_velocity_divergence (s->dom, u, leaf (s, s->div)));
+  return gfship_norm_variable (s->dom, s->div, out);
+}
+
+int gfship_sim_download_un (gfship_sim * s, int c, double * host)
+{
+  GFSHIP_CHECK (s && host, GFSHIP_EINVAL, "null argument");
+  GFSHIP_CHECK (c >= 0 && c < s->dom->dim, GFSHIP_EINVAL, "component %d out of range", c);
+  return gfship_field_download (s->dom, s->un[c], s->dom->depth, host);
+}
+
+} // extern "C"

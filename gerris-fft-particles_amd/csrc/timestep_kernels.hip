@@ -1,0 +1,652 @@
+// timestep_kernels.hip -- CDNA4 kernels of the projection and Godunov advection path
+// (K8-K19 of SURVEY.md 2.5) on the leaf level of a uniform box.
+//
+// Face state.  The reference keeps two copies of every face quantity, one in each adjacent
+// cell (GfsStateVector.f[d].un / .v, src/fluid.h:39-52).  Here:
+//   un[c]   one array per component: entry of cell a = normal velocity on the face on the
+//           + side of a along c (so a.f[2c].un = un[c][a], a.f[2c+1].un = un[c][a - off_c]);
+//           valid for 0 <= coordinate c <= n (index 0 is the ghost cell's + face).
+//   fv[d]   six arrays: fv[d][a] = a.f[d].v (Godunov face value of the advected variable),
+//           ghosts filled by the face-BC kernel.
+// On a uniform grid both copies of the reference are always equal, so this is not a change
+// of algorithm, only of layout.  All formulas keep the reference's operand order; where the
+// reference scatters (+=) into both cells of a face in traversal order, the kernels gather per
+// cell in that same order (see flux_update_kernel).
+#include "gfship_internal.hpp"
+#include <cfloat>
+
+namespace gfship {
+
+#define CELL_PROLOGUE(L)						\
+  int i = blockIdx.x*blockDim.x + threadIdx.x + 1;			\
+  int j = blockIdx.y + 1;						\
+  int k = (L).dim == 3 ? blockIdx.z + 1 : 0;				\
+  if (i > (L).n) return;						\
+  long c = (L).idx (i, j, k)
+
+// cells 0..n in every direction (faces on the + side of the low ghost layer included)
+#define EXT_PROLOGUE(L)							\
+  int i = blockIdx.x*blockDim.x + threadIdx.x;				\
+  int j = blockIdx.y;							\
+  int k = (L).dim == 3 ? blockIdx.z : 0;				\
+  if (i > (L).n) return;						\
+  long c = (L).idx (i, j, k)
+
+static inline void cell_grid (const Layout & L, dim3 * grid, dim3 * block)
+{
+  int b = L.n >= 256 ? 256 : L.n >= 128 ? 128 : 64;
+  *block = dim3 (b);
+  *grid = dim3 ((L.n + b - 1)/b, L.n, L.dim == 3 ? L.n : 1);
+}
+
+static inline void ext_grid (const Layout & L, dim3 * grid, dim3 * block)
+{
+  int b = L.n >= 256 ? 256 : L.n >= 128 ? 128 : 64;
+  *block = dim3 (b);
+  *grid = dim3 ((L.n + 1 + b - 1)/b, L.n + 1, L.dim == 3 ? L.n + 1 : 1);
+}
+
+struct Ptr3  { double * p[3]; };
+struct CPtr3 { const double * p[3]; };
+struct Ptr6  { double * p[6]; };
+struct CPtr6 { const double * p[6]; };
+
+// gfs_face_interpolated_value, src/fluid.c:2186-2198, same-level neighbour (x1 = 1.)
+__device__ __forceinline__ double face_interp (double v0, double v1)
+{
+  double x1 = 1.;
+  return ((x1 - 0.5)*v0 + 0.5*v1)/x1;
+}
+
+// is (i,j,k) a valid "+ face of cell" location for component cc?
+template <int DIM>
+__device__ __forceinline__ bool face_valid (int n, int cc, int i, int j, int k)
+{
+  int q[3] = { i, j, k };
+#pragma unroll
+  for (int a = 0; a < DIM; a++)
+    if (a != cc && (q[a] < 1 || q[a] > n))
+      return false;
+  return true; /* coordinate cc is in [0,n] by construction of the launch */
+}
+
+// K12: gfs_face_interpolated_normal_velocity, src/advection.c:549-573 (after the reset :575-587)
+template <int DIM>
+__global__ void __launch_bounds__(256)
+face_interp_un_kernel (Layout L, CPtr3 u, Ptr3 un)
+{
+  EXT_PROLOGUE (L);
+  const long off[3] = { 1, L.sy, L.sz };
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++)
+    if (face_valid<DIM> (L.n, cc, i, j, k))
+      un.p[cc][c] = face_interp (u.p[cc][c], u.p[cc][c + off[cc]]);
+}
+
+// K9: gfs_normal_divergence (src/fluid.c:2310-2324) then scale_divergence (src/timestep.c:181-187)
+template <int DIM>
+__global__ void __launch_bounds__(256)
+divergence_kernel (Layout L, CPtr3 un, double * __restrict__ div, double dt)
+{
+  CELL_PROLOGUE (L);
+  const long off[3] = { 1, L.sy, L.sz };
+  double h = 1./L.n;
+  double d_ = 0.;
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++) {
+    d_ += 1.*un.p[cc][c]*1.;
+    d_ += -1.*un.p[cc][c - off[cc]]*1.;
+  }
+  double v = d_*h;
+  div[c] = v/dt;
+}
+
+// K10: correct_normal_velocity (src/timestep.c:118-144), unit weights:
+//   dp = (w*p[nb] - w*p[cell])/h; dp /= face_fraction (= 1.); un -= dp*dt
+template <int DIM>
+__global__ void __launch_bounds__(256)
+correct_un_kernel (Layout L, const double * __restrict__ p, Ptr3 un, double dt)
+{
+  EXT_PROLOGUE (L);
+  const long off[3] = { 1, L.sy, L.sz };
+  double h = 1./L.n;
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++)
+    if (face_valid<DIM> (L.n, cc, i, j, k)) {
+      double dp = (1.*p[c + off[cc]] - 1.*p[c])/h;
+      dp /= 1.;
+      un.p[cc][c] -= dp*dt;
+    }
+}
+
+// K10 + K11a: centred gradient: g[c] = (dp(- face)*1. + dp(+ face)*1.)/2.
+// (accumulation in correct_normal_velocity, halving in scale_cell_gradients src/timestep.c:60-87;
+// two addends only, so the traversal order of the two faces does not matter)
+template <int DIM>
+__global__ void __launch_bounds__(256)
+centered_gradient_kernel (Layout L, const double * __restrict__ p, Ptr3 g)
+{
+  CELL_PROLOGUE (L);
+  const long off[3] = { 1, L.sy, L.sz };
+  double h = 1./L.n;
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++) {
+    double dpm = (1.*p[c] - 1.*p[c - off[cc]])/h;
+    dpm /= 1.;
+    double dpp = (1.*p[c + off[cc]] - 1.*p[c])/h;
+    dpp /= 1.;
+    double v = 0.;
+    v += dpm*1.;
+    v += dpp*1.;
+    g.p[cc][c] = v/2.;
+  }
+}
+
+// K11b: correct (src/timestep.c:486-496): u[c] -= g[c]*dt
+template <int DIM>
+__global__ void __launch_bounds__(256)
+correct_centered_kernel (Layout L, Ptr3 u, CPtr3 g, double dt)
+{
+  CELL_PROLOGUE (L);
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++)
+    u.p[cc][c] -= g.p[cc][c]*dt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K13: gfs_cell_advected_face_values, src/advection.c:58-99
+// ---------------------------------------------------------------------------------------------
+#define GMIN(a, b) (((a) < (b)) ? (a) : (b))
+#define GMAX(a, b) (((a) > (b)) ? (a) : (b))
+#define GABS(a)    (((a) < 0) ? -(a) : (a))
+
+// gfs_center_gradient (src/fluid.c:434-457), both neighbours at the same level
+__device__ __forceinline__ double center_gradient (double v0, double v1, double v2)
+{
+  double x1 = 1., x2 = 1.;
+  return (x1*x1*(v2 - v0) + x2*x2*(v0 - v1))/(x1*x2*(x2 + x1));
+}
+
+// gfs_center_van_leer_gradient (src/fluid.c:522-561)
+__device__ __forceinline__ double van_leer_gradient (double v0, double v1, double v2)
+{
+  double x1 = 1., x2 = 1.;
+  double s1 = 2.*(v0 - v1);
+  double s2 = 2.*(v2 - v0);
+  if (s1*s2 <= 0.)
+    return 0.;
+  double s0 = (x1*x1*(v2 - v0) + x2*x2*(v0 - v1))/(x1*x2*(x2 + x1));
+  if (GABS (s2) < GABS (s1))
+    s1 = s2;
+  if (GABS (s0) < GABS (s1))
+    return s0;
+  return s1;
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+advected_face_values_kernel (Layout L, const double * __restrict__ v, CPtr3 u, CPtr3 un,
+			     double dt, int use_centered_velocity, int gradient, Ptr6 fv)
+{
+  CELL_PROLOGUE (L);
+  const long off[3] = { 1, L.sy, L.sz };
+  const double size = 1./L.n;
+  const double v0 = v[c];
+  // tangential / normal velocities
+  double vel[3];
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++)
+    vel[cc] = use_centered_velocity ? u.p[cc][c] : 0.;
+  // transverse_term, src/advection.c:27-47
+  double tt[3];
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++) {
+    double vtan = use_centered_velocity ? vel[cc] : (un.p[cc][c] + un.p[cc][c - off[cc]])/2.;
+    long nb = vtan > 0. ? c - off[cc] : c + off[cc];
+    double g = v[nb] - 1.*v0;         /* gfs_face_gradient: g.b - g.a*v0, src/fluid.c:801-805 */
+    if (vtan > 0.) g = - g;
+    tt[cc] = dt*vtan*g/(2.*size);
+  }
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++) {
+    double unorm = use_centered_velocity ?
+      dt*vel[cc]/size :
+      dt*(un.p[cc][c] + un.p[cc][c - off[cc]])/(2.*size);
+    double v1 = v[c - off[cc]], v2 = v[c + off[cc]];
+    double g = gradient ? van_leer_gradient (v0, v1, v2) : center_gradient (v0, v1, v2);
+    double vl = v0 + GMIN ((1. - unorm)/2., 0.5)*g;
+    double vr = v0 + GMAX ((- 1. - unorm)/2., -0.5)*g;
+    double src = dt*0./2.;
+    double dv;
+    if (DIM == 2)
+      dv = tt[(cc + 1) % 2];
+    else {
+      /* orthogonal[c] = {Y,Z}, {X,Z}, {X,Y} */
+      int o0 = cc == 0 ? 1 : 0, o1 = cc == 2 ? 1 : 2;
+      dv = tt[o0];
+      dv += tt[o1];
+    }
+    fv.p[2*cc][c]     = vl + src - dv;
+    fv.p[2*cc + 1][c] = vr + src - dv;
+  }
+}
+
+// gfs_domain_face_bc (src/domain.c:1209-1232): ghost face values.
+// face_symmetry src/boundary.c:64-74, face_dirichlet :275-279, face_neumann :354-360,
+// face_periodic/face_update :1251-1258,1343-1347.  The ghost cell G beyond side sd keeps its
+// value in fv[opposite(sd)][G]; symmetry/Dirichlet also overwrite the interior cell's fv[sd].
+template <int DIM>
+__global__ void __launch_bounds__(256)
+face_bc_kernel (Layout L, BcDesc bc, const double * __restrict__ v, Ptr6 fv)
+{
+  const int n = L.n;
+  const int nface = DIM == 3 ? n*n : n;
+  int f = blockIdx.x*blockDim.x + threadIdx.x;
+  int sd = blockIdx.y;
+  if (f >= nface) return;
+  if (bc.side[sd] == GFSHIP_SIDE_EXTERNAL) return;
+  int cc = sd/2, od = sd ^ 1;
+  int t1 = f % n + 1, t2 = DIM == 3 ? f / n + 1 : 0;
+  int ijk[3] = { 0, 0, 0 };
+  int ta = cc == 0 ? 1 : 0, tb = cc == 2 ? 1 : 2;
+  ijk[cc] = (sd & 1) ? 1 : n;
+  ijk[ta] = t1;
+  if (DIM == 3) ijk[tb] = t2;
+  long o = cc == 0 ? 1 : cc == 1 ? L.sy : L.sz;
+  if (sd & 1) o = - o;
+  long cell = L.idx (ijk[0], ijk[1], ijk[2]);
+  long G = cell + o;
+  if (bc.side[sd] == GFSHIP_SIDE_PERIODIC) {
+    fv.p[od][G] = fv.p[od][cell - (long) (n - 1)*o];
+    return;
+  }
+  double val = bc.val[sd] ? bc.val[sd][f] : 0.;
+  switch (bc.type[sd]) {
+  case GFSHIP_BC_DIRICHLET:
+    fv.p[od][G] = fv.p[sd][cell] = val;
+    break;
+  case GFSHIP_BC_NEUMANN:
+    fv.p[od][G] = v[cell] + val*(1./n)/2.;
+    break;
+  default:
+    if (bc.component == cc)
+      fv.p[od][G] = fv.p[sd][cell] = 0.;
+    else
+      fv.p[od][G] = fv.p[sd][cell];
+  }
+}
+
+// gfs_face_upwinded_value, src/advection.c:267-300, FTT_FINE_FINE: the face on the + side of
+// cell a (direction cc); a = left state owner, a + off = right state owner.
+__device__ __forceinline__ double upwinded (double un, double fl, double fr)
+{
+  return un > 0. ? fl : un < 0. ? fr : (fl + fr)/2.;
+}
+
+// K14: gfs_face_advected_normal_velocity with GFS_CENTERED_UPWINDING, src/advection.c:513-539
+template <int DIM>
+__global__ void __launch_bounds__(256)
+predict_un_kernel (Layout L, int cc, const double * __restrict__ uc,
+		   const double * __restrict__ fvp, const double * __restrict__ fvm,
+		   double * __restrict__ unc)
+{
+  EXT_PROLOGUE (L);
+  if (!face_valid<DIM> (L.n, cc, i, j, k)) return;
+  long o = cc == 0 ? 1 : cc == 1 ? L.sy : L.sz;
+  double s = face_interp (uc[c], uc[c + o]);
+  unc[c] = upwinded (s, fvp[c], fvm[c + o]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K15 + K16: gfs_face_velocity_advection_flux / gfs_face_advection_flux (src/advection.c:356-435),
+// gfs_advection_update (:817-818) and add_pressure_gradient (src/timestep.c:809-812).
+//
+// The reference zeroes fv on both sides of every face, then scatters -flux / +flux in face
+// traversal order (src/ftt.c:2152-2215): all cells in tree pre-order with their d = 0,2,4 faces,
+// then the cells along the d = 1,3,5 sides.  A cell C therefore receives, in this order:
+//   + F(x, C - ex)                    when its left neighbour was visited (x grows along the order)
+//   - F(x, C), - F(y, C), - F(z, C)   at its own visit
+//   + F(y, C - ey), + F(z, C - ez)    from the bottom and back neighbours, visited later
+//                                     (y and z decrease along the order), bottom first unless
+//                                     the back neighbour precedes it in the pre-order
+//   + F on the d = 1, 3, 5 box sides  for cells along those sides (second pass)
+// and the gather below adds the same bit patterns in the same order.
+// With J = n - j, K = n - k the 0-based oriented coordinates of C, the back neighbour
+// (J, K + 1) precedes the bottom neighbour (J + 1, K) in the pre-order iff the lowest zero bit of
+// J is above the lowest zero bit of K.
+// ---------------------------------------------------------------------------------------------
+template <int DIM, bool VELOCITY>
+__device__ __forceinline__ double face_flux (const Layout & L, int cf, long a, const CPtr3 & un,
+					     const CPtr6 & fv, const double * __restrict__ gm,
+					     double dt, double h)
+{
+  long o = cf == 0 ? 1 : cf == 1 ? L.sy : L.sz;
+  double unf = un.p[cf][a];
+  double upw = upwinded (unf, fv.p[2*cf][a], fv.p[2*cf + 1][a + o]);
+  if (VELOCITY) {
+    double flux = 1.*unf*dt/h;
+    flux *= upw - face_interp (gm[a], gm[a + o])*dt/2.;
+    return flux;
+  }
+  return 1.*unf*dt*upw/h;
+}
+
+template <int DIM, bool VELOCITY>
+__global__ void __launch_bounds__(256)
+flux_update_kernel (Layout L, double * __restrict__ v, CPtr3 un, CPtr6 fv,
+		    const double * __restrict__ gm, const double * __restrict__ gc, double dt)
+{
+  CELL_PROLOGUE (L);
+  const int n = L.n;
+  const double h = 1./n;
+  double acc = 0.;
+  if (i > 1)
+    acc += face_flux<DIM, VELOCITY> (L, 0, c - 1, un, fv, gm, dt, h);
+  acc -= face_flux<DIM, VELOCITY> (L, 0, c, un, fv, gm, dt, h);
+  acc -= face_flux<DIM, VELOCITY> (L, 1, c, un, fv, gm, dt, h);
+  if (DIM == 3) {
+    acc -= face_flux<DIM, VELOCITY> (L, 2, c, un, fv, gm, dt, h);
+    unsigned J = n - j, K = n - k;
+    bool back_first = __ffs (~J) > __ffs (~K);
+    if (back_first) {
+      if (k > 1) acc += face_flux<DIM, VELOCITY> (L, 2, c - L.sz, un, fv, gm, dt, h);
+      if (j > 1) acc += face_flux<DIM, VELOCITY> (L, 1, c - L.sy, un, fv, gm, dt, h);
+    }
+    else {
+      if (j > 1) acc += face_flux<DIM, VELOCITY> (L, 1, c - L.sy, un, fv, gm, dt, h);
+      if (k > 1) acc += face_flux<DIM, VELOCITY> (L, 2, c - L.sz, un, fv, gm, dt, h);
+    }
+  }
+  else if (j > 1)
+    acc += face_flux<DIM, VELOCITY> (L, 1, c - L.sy, un, fv, gm, dt, h);
+  if (i == 1)
+    acc += face_flux<DIM, VELOCITY> (L, 0, c - 1, un, fv, gm, dt, h);
+  if (j == 1)
+    acc += face_flux<DIM, VELOCITY> (L, 1, c - L.sy, un, fv, gm, dt, h);
+  if (DIM == 3 && k == 1)
+    acc += face_flux<DIM, VELOCITY> (L, 2, c - L.sz, un, fv, gm, dt, h);
+  double val = v[c];
+  val += acc/1.;
+  if (gc)
+    val -= gc[c]*dt;
+  v[c] = val;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K19: minimum_mac_cfl / minimum_cfl, src/domain.c:2824-2923: min of (h/|un|)^2 and (h/|u|)^2
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_min (double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    v = fmin (v, __shfl_down (v, o, 64));
+  return v;
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+cfl_partial_kernel (Layout L, CPtr3 u, CPtr3 un, double * __restrict__ partial)
+{
+  const int n = L.n;
+  const double length = 1./n;
+  const long r = n + 1;
+  const long next = DIM == 3 ? r*r*r : r*r;
+  const long off[3] = { 1, L.sy, L.sz };
+  double m = DBL_MAX;
+  for (long q = (long) blockIdx.x*blockDim.x + threadIdx.x; q < next;
+       q += (long) gridDim.x*blockDim.x) {
+    int i = q % r, j = (q / r) % r, k = DIM == 3 ? q / (r*r) : 0;
+    long c = L.idx (i, j, k);
+#pragma unroll
+    for (int cc = 0; cc < DIM; cc++)
+      if (face_valid<DIM> (n, cc, i, j, k)) {
+	double unf = un.p[cc][c];
+	if (unf != 0.) {
+	  double cflu = length/fabs (unf);
+	  m = fmin (m, cflu*cflu);
+	}
+      }
+    if (i >= 1 && j >= 1 && (DIM == 2 || k >= 1)) {
+#pragma unroll
+      for (int cc = 0; cc < DIM; cc++) {
+	double uv = u.p[cc][c];
+	if (uv != 0.) {
+	  double cflu = length/fabs (1.*uv);
+	  m = fmin (m, cflu*cflu);
+	}
+      }
+    }
+    (void) off;
+  }
+  __shared__ double sh[4];
+  m = wave_min (m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    double rmin = sh[0];
+    for (int q = 1; q < (int) (blockDim.x >> 6); q++) rmin = fmin (rmin, sh[q]);
+    partial[blockIdx.x] = rmin;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+min_final_kernel (const double * __restrict__ partial, int nblocks, double * __restrict__ out)
+{
+  double m = DBL_MAX;
+  for (int q = threadIdx.x; q < nblocks; q += blockDim.x)
+    m = fmin (m, partial[q]);
+  __shared__ double sh[4];
+  m = wave_min (m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads ();
+  if (threadIdx.x == 0)
+    out[0] = fmin (fmin (sh[0], sh[1]), fmin (sh[2], sh[3]));
+}
+
+// K18: gfs_get_from_below_intensive, src/fluid.c:1843-1864 (cell fractions = 1.)
+template <int DIM>
+__global__ void __launch_bounds__(256)
+coarse_init_kernel (Layout Lc, Layout Lf, double * __restrict__ vc, const double * __restrict__ vf)
+{
+  CELL_PROLOGUE (Lc);
+  double val = 0., sa = 0.;
+#pragma unroll
+  for (int id = 0; id < (1 << DIM); id++) {
+    int ci = 2*i - 1 + (id & 1);
+    int cj = 2*j - 1 + ((id & 2) ? 0 : 1);
+    int ck = DIM == 3 ? 2*k - 1 + ((id & 4) ? 0 : 1) : 0;
+    double a = 1.;
+    val += vf[Lf.idx (ci, cj, ck)]*a;
+    sa += a;
+  }
+  vc[c] = val/sa;
+}
+
+// derived variable Divergence: gfs_divergence, src/fluid.c:2357-2376
+template <int DIM>
+__global__ void __launch_bounds__(256)
+velocity_divergence_kernel (Layout L, CPtr3 u, double * __restrict__ out)
+{
+  CELL_PROLOGUE (L);
+  const long off[3] = { 1, L.sy, L.sz };
+  double h = 1./L.n;
+  double div = 0.;
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++) {
+    div += 1.*1.*face_interp (u.p[cc][c], u.p[cc][c + off[cc]]);
+    div += 1.*-1.*face_interp (u.p[cc][c], u.p[cc][c - off[cc]]);
+  }
+  out[c] = div/(1.*h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+#define DISPATCH(dom, kern, grid, block, ...)				\
+  do {									\
+    if ((dom)->dim == 3)						\
+      hipLaunchKernelGGL (kern<3>, grid, block, 0, (dom)->stream, __VA_ARGS__); \
+    else								\
+      hipLaunchKernelGGL (kern<2>, grid, block, 0, (dom)->stream, __VA_ARGS__); \
+    GFSHIP_HIP (hipGetLastError ());					\
+  } while (0)
+
+static CPtr3 c3 (double * const p[3]) { CPtr3 r; for (int q = 0; q < 3; q++) r.p[q] = p[q]; return r; }
+static Ptr3  m3 (double * const p[3]) { Ptr3 r; for (int q = 0; q < 3; q++) r.p[q] = p[q]; return r; }
+static CPtr6 c6 (double * const p[6]) { CPtr6 r; for (int q = 0; q < 6; q++) r.p[q] = p[q]; return r; }
+static Ptr6  m6 (double * const p[6]) { Ptr6 r; for (int q = 0; q < 6; q++) r.p[q] = p[q]; return r; }
+
+int launch_face_interp_un (gfship_domain * dom, double * const u[3], double * const un[3])
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid, block;
+  ext_grid (L, &grid, &block);
+  DISPATCH (dom, face_interp_un_kernel, grid, block, L, c3 (u), m3 (un));
+  return GFSHIP_OK;
+}
+
+int launch_divergence (gfship_domain * dom, double * const un[3], double * div, double dt)
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid, block;
+  cell_grid (L, &grid, &block);
+  DISPATCH (dom, divergence_kernel, grid, block, L, c3 (un), div, dt);
+  return GFSHIP_OK;
+}
+
+int launch_correct_un (gfship_domain * dom, const double * p, double * const un[3], double dt)
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid, block;
+  ext_grid (L, &grid, &block);
+  DISPATCH (dom, correct_un_kernel, grid, block, L, p, m3 (un), dt);
+  return GFSHIP_OK;
+}
+
+int launch_centered_gradient (gfship_domain * dom, const double * p, double * const g[3])
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid, block;
+  cell_grid (L, &grid, &block);
+  DISPATCH (dom, centered_gradient_kernel, grid, block, L, p, m3 (g));
+  return GFSHIP_OK;
+}
+
+int launch_correct_centered (gfship_domain * dom, double * const u[3], double * const g[3], double dt)
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid, block;
+  cell_grid (L, &grid, &block);
+  DISPATCH (dom, correct_centered_kernel, grid, block, L, m3 (u), c3 (g), dt);
+  return GFSHIP_OK;
+}
+
+int launch_advected_face_values (gfship_domain * dom, const double * v, double * const u[3],
+				 double * const un[3], double dt, int use_centered, int gradient,
+				 double * const fv[6])
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid, block;
+  cell_grid (L, &grid, &block);
+  DISPATCH (dom, advected_face_values_kernel, grid, block, L, v, c3 (u), c3 (un), dt,
+	    use_centered, gradient, m6 (fv));
+  return GFSHIP_OK;
+}
+
+int launch_face_bc (gfship_domain * dom, Field * v, double * const fv[6])
+{
+  const Layout & L = dom->lay[dom->depth];
+  BcDesc bc;
+  for (int d = 0; d < 6; d++) {
+    bc.side[d] = dom->side[d];
+    bc.type[d] = v->bc[d];
+    bc.val[d] = v->bcval[d];
+  }
+  bc.component = v->component;
+  bc.homogeneous = 0;
+  int nface = dom->dim == 3 ? L.n*L.n : L.n;
+  int block = nface >= 256 ? 256 : 64;
+  dim3 grid ((nface + block - 1)/block, 2*dom->dim);
+  DISPATCH (dom, face_bc_kernel, grid, dim3 (block), L, bc, (const double *) v->lev[dom->depth],
+	    m6 (fv));
+  return GFSHIP_OK;
+}
+
+int launch_predict_un (gfship_domain * dom, int cc, const double * uc, double * const fv[6],
+		       double * unc)
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid, block;
+  ext_grid (L, &grid, &block);
+  DISPATCH (dom, predict_un_kernel, grid, block, L, cc, uc, (const double *) fv[2*cc],
+	    (const double *) fv[2*cc + 1], unc);
+  return GFSHIP_OK;
+}
+
+int launch_flux_update (gfship_domain * dom, bool velocity, double * v, double * const un[3],
+			double * const fv[6], const double * gm, const double * gc, double dt)
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid, block;
+  cell_grid (L, &grid, &block);
+  if (dom->dim == 3) {
+    if (velocity)
+      hipLaunchKernelGGL ((flux_update_kernel<3, true>), grid, block, 0, dom->stream,
+			  L, v, c3 (un), c6 (fv), gm, gc, dt);
+    else
+      hipLaunchKernelGGL ((flux_update_kernel<3, false>), grid, block, 0, dom->stream,
+			  L, v, c3 (un), c6 (fv), gm, gc, dt);
+  }
+  else {
+    if (velocity)
+      hipLaunchKernelGGL ((flux_update_kernel<2, true>), grid, block, 0, dom->stream,
+			  L, v, c3 (un), c6 (fv), gm, gc, dt);
+    else
+      hipLaunchKernelGGL ((flux_update_kernel<2, false>), grid, block, 0, dom->stream,
+			  L, v, c3 (un), c6 (fv), gm, gc, dt);
+  }
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3], double * cfl2)
+{
+  const Layout & L = dom->lay[dom->depth];
+  long r = L.n + 1;
+  long next = dom->dim == 3 ? r*r*r : r*r;
+  int block = 256;
+  int nblocks = (int) ((next + block - 1)/block);
+  if (nblocks > 1024) nblocks = 1024;
+  double * partial = dom->d_scratch;
+  double * result = dom->d_scratch + 5*1024;
+  DISPATCH (dom, cfl_partial_kernel, dim3 (nblocks), dim3 (block), L, c3 (u), c3 (un), partial);
+  hipLaunchKernelGGL (min_final_kernel, dim3 (1), dim3 (256), 0, dom->stream, partial, nblocks, result);
+  GFSHIP_HIP (hipGetLastError ());
+  GFSHIP_HIP (hipMemcpyAsync (dom->h_pinned, result, sizeof (double), hipMemcpyDeviceToHost,
+			      dom->stream));
+  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  *cfl2 = dom->h_pinned[0];
+  return GFSHIP_OK;
+}
+
+int launch_coarse_init (gfship_domain * dom, Field * v)
+{
+  for (int l = dom->depth - 1; l >= 0; l--) {
+    const Layout & Lc = dom->lay[l], & Lf = dom->lay[l + 1];
+    dim3 grid, block;
+    cell_grid (Lc, &grid, &block);
+    DISPATCH (dom, coarse_init_kernel, grid, block, Lc, Lf, v->lev[l], (const double *) v->lev[l + 1]);
+  }
+  return GFSHIP_OK;
+}
+
+int launch_velocity_divergence (gfship_domain * dom, double * const u[3], double * out)
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid, block;
+  cell_grid (L, &grid, &block);
+  DISPATCH (dom, velocity_divergence_kernel, grid, block, L, c3 (u), out);
+  return GFSHIP_OK;
+}
+
+} // namespace gfship

@@ -36,6 +36,11 @@ class MultilevelParams(C.Structure):
                 ("residual_before", Norm), ("residual", Norm)]
 
 
+class AdvectionParams(C.Structure):
+    """The fields of GfsAdvectionParams used on this path (src/advection.h:50-69)."""
+    _fields_ = [("cfl", C.c_double), ("dt", C.c_double), ("gradient", C.c_int), ("gc", C.c_int)]
+
+
 _lib = None
 
 # every symbol include/gfship.h declares: name -> (restype, argtypes)
@@ -69,6 +74,28 @@ SIGNATURES = {
     "gfship_poisson_cycle": (_i, [_vp, C.POINTER(MultilevelParams), _i, _i, _i, _i]),
     "gfship_poisson_solve": (_i, [_vp, C.POINTER(MultilevelParams), _i, _i, _i, _i, _d]),
     "gfship_time_relax": (_i, [_vp, _u, _i, _i, _i, _i, _i, _pd]),
+    "gfship_sim_create": (_i, [C.POINTER(_vp), _vp]),
+    "gfship_sim_destroy": (None, [_vp]),
+    "gfship_sim_variable": (_i, [_vp, _i, _i]),
+    "gfship_sim_projection_params": (C.POINTER(MultilevelParams), [_vp]),
+    "gfship_sim_approx_projection_params": (C.POINTER(MultilevelParams), [_vp]),
+    "gfship_sim_advection_params": (C.POINTER(AdvectionParams), [_vp]),
+    "gfship_sim_set_time": (_i, [_vp, _d, _d]),
+    "gfship_sim_time": (_d, [_vp]),
+    "gfship_sim_iter": (_u, [_vp]),
+    "gfship_sim_add_tracer": (_i, [_vp]),
+    "gfship_sim_start": (_i, [_vp]),
+    "gfship_sim_step": (_i, [_vp]),
+    "gfship_predicted_face_velocities": (_i, [_vp]),
+    "gfship_mac_projection": (_i, [_vp, C.POINTER(MultilevelParams), _d, _i, _pi]),
+    "gfship_approximate_projection": (_i, [_vp, C.POINTER(MultilevelParams), _d, _i, _pi]),
+    "gfship_centered_velocity_advection": (_i, [_vp, _pi, _pi]),
+    "gfship_tracer_advection": (_i, [_vp, _i, _d]),
+    "gfship_domain_cfl": (_i, [_vp, _pd]),
+    "gfship_set_timestep": (_i, [_vp]),
+    "gfship_coarse_init": (_i, [_vp]),
+    "gfship_divergence_norm": (_i, [_vp, C.POINTER(Norm)]),
+    "gfship_sim_download_un": (_i, [_vp, _i, _pd]),
 }
 
 
@@ -207,5 +234,98 @@ class Domain:
     def __del__(self):
         try:
             self.destroy()
+        except Exception:
+            pass
+
+
+class _SimVariable(Variable):
+    """A variable owned by a Simulation (P, Pmac, U, ...)."""
+
+    def __init__(self, dom, handle):
+        self.dom, self.h = dom, handle
+
+    def free(self):
+        pass
+
+
+class Simulation:
+    """GfsSimulation on one box: the simulation_run loop (src/simulation.c:432-557)."""
+    VAR_P, VAR_PMAC, VAR_U, VAR_G, VAR_GMAC, VAR_TRACER = range(6)
+
+    def __init__(self, dom):
+        self.dom = dom
+        p = _vp()
+        _check(lib().gfship_sim_create(C.byref(p), dom.ptr))
+        self.ptr = p
+        L = lib()
+        dim = dom.dim
+        self.p = self._var(self.VAR_P)
+        self.pmac = self._var(self.VAR_PMAC)
+        self.u = [self._var(self.VAR_U, c) for c in range(dim)]
+        self.g = [self._var(self.VAR_G, c) for c in range(dim)]
+        self.gmac = [self._var(self.VAR_GMAC, c) for c in range(dim)]
+        self.projection_params = L.gfship_sim_projection_params(self.ptr).contents
+        self.approx_projection_params = L.gfship_sim_approx_projection_params(self.ptr).contents
+        self.advection_params = L.gfship_sim_advection_params(self.ptr).contents
+
+    def _var(self, which, c=0):
+        return _SimVariable(self.dom, _check(lib().gfship_sim_variable(self.ptr, which, c)))
+
+    def add_tracer(self):
+        t = _check(lib().gfship_sim_add_tracer(self.ptr))
+        return self._var(self.VAR_TRACER, t)
+
+    def set_time(self, end=1.7976931348623157e308, dtmax=1.7976931348623157e308):
+        _check(lib().gfship_sim_set_time(self.ptr, end, dtmax))
+
+    @property
+    def t(self):
+        return lib().gfship_sim_time(self.ptr)
+
+    @property
+    def i(self):
+        return lib().gfship_sim_iter(self.ptr)
+
+    @property
+    def dt(self):
+        return self.advection_params.dt
+
+    def start(self):
+        _check(lib().gfship_sim_start(self.ptr))
+
+    def step(self):
+        _check(lib().gfship_sim_step(self.ptr))
+
+    def predicted_face_velocities(self):
+        _check(lib().gfship_predicted_face_velocities(self.ptr))
+
+    def cfl(self):
+        v = C.c_double()
+        _check(lib().gfship_domain_cfl(self.ptr, C.byref(v)))
+        return v.value
+
+    def divergence_norm(self):
+        n = Norm()
+        _check(lib().gfship_divergence_norm(self.ptr, C.byref(n)))
+        return n
+
+    def tracer_advection(self, t, dt):
+        _check(lib().gfship_tracer_advection(self.ptr, t.h, dt))
+
+    def un(self, c):
+        n = (1 << self.dom.depth) + 2
+        a = np.empty((n,) * self.dom.dim)
+        _check(lib().gfship_sim_download_un(self.ptr, c, a.ctypes.data_as(_pd)))
+        return a
+
+    def destroy(self):
+        if self.ptr:
+            lib().gfship_sim_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if self.dom.ptr:
+                self.destroy()
         except Exception:
             pass

@@ -128,6 +128,55 @@ int  gfship_poisson_solve (gfship_domain * dom, gfship_multilevel_params * par,
 			   gfship_field lhs, gfship_field rhs, gfship_field res,
 			   gfship_field dia, double dt);
 
+/* ---- projection + advection time step (src/timestep.c, src/advection.c, src/simulation.c) -- */
+
+typedef struct gfship_sim gfship_sim;   /* GfsSimulation on one box, src/simulation.h:56-82 */
+
+typedef struct {           /* the fields of GfsAdvectionParams used here, src/advection.h:50-69 */
+  double cfl, dt;
+  int gradient;            /* 0 gfs_center_gradient (src/fluid.c:434-475),
+			      1 gfs_center_van_leer_gradient (:522-561) */
+  int gc;
+} gfship_advection_params;
+
+enum { GFSHIP_VAR_P = 0, GFSHIP_VAR_PMAC = 1, GFSHIP_VAR_U = 2, GFSHIP_VAR_G = 3,
+       GFSHIP_VAR_GMAC = 4, GFSHIP_VAR_TRACER = 5 };
+
+/* gfs_simulation_new + simulation_init (src/simulation.c:910-1015): allocates P, Pmac, U, V(, W),
+   the gradient vectors g[], gmac[] of simulation_run (:432-456) and the face state */
+int  gfship_sim_create (gfship_sim ** sim, gfship_domain * dom);
+void gfship_sim_destroy (gfship_sim * sim);
+gfship_field gfship_sim_variable (gfship_sim * sim, int which, int c);
+gfship_multilevel_params * gfship_sim_projection_params (gfship_sim * sim);
+gfship_multilevel_params * gfship_sim_approx_projection_params (gfship_sim * sim);
+gfship_advection_params *  gfship_sim_advection_params (gfship_sim * sim);
+int      gfship_sim_set_time (gfship_sim * sim, double end, double dtmax); /* GfsTime */
+double   gfship_sim_time (gfship_sim * sim);
+unsigned gfship_sim_iter (gfship_sim * sim);
+int      gfship_sim_add_tracer (gfship_sim * sim);       /* GfsVariableTracer, src/variable.c:427-431 */
+/* simulation_run before its loop (src/simulation.c:458-476): BCs, first time step, initial
+   approximate projection */
+int  gfship_sim_start (gfship_sim * sim);
+/* one iteration of the simulation_run loop body (src/simulation.c:479-548) */
+int  gfship_sim_step (gfship_sim * sim);
+/* the pieces, callable on their own: */
+int  gfship_predicted_face_velocities (gfship_sim * sim);      /* src/timestep.c:681-717 */
+int  gfship_mac_projection (gfship_sim * sim, gfship_multilevel_params * par, double dt,
+			    gfship_field p, const gfship_field g[3]);        /* :460-484 */
+int  gfship_approximate_projection (gfship_sim * sim, gfship_multilevel_params * par, double dt,
+				    gfship_field p, const gfship_field g[3]); /* :560-596 */
+int  gfship_centered_velocity_advection (gfship_sim * sim, const gfship_field gmac[3],
+					 const gfship_field g[3]);           /* :976-1016 */
+int  gfship_tracer_advection (gfship_sim * sim, gfship_field t, double dt);  /* :1028-1055 */
+int  gfship_domain_cfl (gfship_sim * sim, double * cfl);       /* src/domain.c:2824-2923 */
+int  gfship_set_timestep (gfship_sim * sim);                   /* src/simulation.c:1569-1633 */
+int  gfship_coarse_init (gfship_sim * sim);                    /* src/adaptive.c:43-58 */
+/* OutputScalarNorm { v = Divergence }: gfs_divergence (src/fluid.c:2357-2376) + norm */
+int  gfship_divergence_norm (gfship_sim * sim, gfship_norm * out);
+/* MAC normal velocity on the faces orthogonal to component c, as a host array in the cell
+   convention: entry (i,j,k) is the face on the + side of cell (i,j,k) (0 <= i <= n along c) */
+int  gfship_sim_download_un (gfship_sim * sim, int c, double * host);
+
 /* ---- instrumentation -------------------------------------------------------------------- */
 
 /* time (HIP events on the domain's stream) of `reps` back-to-back sweeps of gfship_relax on

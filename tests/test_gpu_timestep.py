@@ -1,0 +1,189 @@
+"""GPU parity of the projection + advection time step (libgfship through the C ABI) against the
+CPU oracle: bit-exact fields, face velocities and time steps, plus the reference's own golden
+divergence history (test/reynolds/div5.ref) through the device path."""
+import os
+
+import numpy as np
+import pytest
+
+import gfship
+from flow_cases import (PERIODIC, oracle_periodic, oracle_reynolds, oracle_taylor_green,
+                        periodic_init, reynolds_init, taylor_green_3d)
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _with_ghosts(a, dim):
+    n = a.shape[0]
+    b = np.zeros((n + 2,) * dim)
+    b[(slice(1, -1),) * dim] = a
+    return b
+
+
+def _interior(a, dim):
+    return a[(slice(1, -1),) * dim]
+
+
+def _device_sim(osim, side):
+    """a device simulation initialised from the oracle simulation's current state"""
+    dim, depth = osim.dim, osim.depth
+    gd = gfship.Domain(dim, depth, side)
+    gs = gfship.Simulation(gd)
+    for c in range(dim):
+        gs.u[c].upload(osim.u[c].leaf())
+    for name in ("projection_params", "approx_projection_params"):
+        op, gp = getattr(osim, name), getattr(gs, name)
+        for f in ("tolerance", "nrelax", "erelax", "minlevel", "nitermax", "nitermin", "omega"):
+            setattr(gp, f, getattr(op, f))
+    gs.advection_params.cfl = osim.advection_params.cfl
+    gs.advection_params.gradient = osim.advection_params.gradient
+    return gd, gs
+
+
+def _assert_same_state(osim, gs, what=""):
+    dim = osim.dim
+    for c in range(dim):
+        assert np.array_equal(osim.u[c].interior(), _interior(gs.u[c].download(), dim)), \
+            "%s U[%d]" % (what, c)
+        assert np.array_equal(osim.g[c].interior(), _interior(gs.g[c].download(), dim)), \
+            "%s g[%d]" % (what, c)
+    assert np.array_equal(osim.p.interior(), _interior(gs.p.download(), dim)), what + " P"
+    assert np.array_equal(osim.pmac.interior(), _interior(gs.pmac.download(), dim)), what + " Pmac"
+    assert osim.dt == gs.dt, what + " dt"
+    assert osim.t == gs.t
+
+
+def _assert_same_un(osim, gs, what=""):
+    """MAC velocities: oracle keeps cell.f[2c].un, the device the + face of each cell"""
+    dim = osim.dim
+    n = 1 << osim.depth
+    for c in range(dim):
+        a, b = osim.un(2 * c), gs.un(c)
+        # faces with tangential coordinates in 1..n and normal coordinate in 0..n
+        sl = [slice(1, n + 1)] * dim
+        sl[dim - 1 - c] = slice(0, n + 1)
+        assert np.array_equal(a[tuple(sl)], b[tuple(sl)]), "%s un[%d]" % (what, c)
+
+
+@pytest.mark.parametrize("level", [4, 5])
+def test_reynolds_2d_steps_bit_exact(level):
+    osim = oracle_reynolds(level)
+    gd, gs = _device_sim(osim, PERIODIC)
+    gs.set_time(end=2.)
+    osim.start()
+    gs.start()
+    _assert_same_state(osim, gs, "start")
+    _assert_same_un(osim, gs, "start")
+    for k in range(6):
+        osim.step()
+        gs.step()
+        _assert_same_state(osim, gs, "step %d" % k)
+        _assert_same_un(osim, gs, "step %d" % k)
+        assert gs.projection_params.niter == osim.projection_params.niter
+        assert gs.approx_projection_params.residual.infty == \
+            osim.approx_projection_params.residual.infty
+
+
+def test_reynolds_div5_golden_through_device(golden_dir):
+    """every printed digit of the reference's test/reynolds/div5.ref (80 steps)"""
+    ref = [l.split() for l in open(os.path.join(golden_dir, "reference", "reynolds_div5.ref"))]
+    osim = oracle_reynolds(5)
+    gd, gs = _device_sim(osim, PERIODIC)
+    gs.set_time(end=2.)
+    gs.start()
+    k = 0
+    while gs.t < 2.:
+        nm = gs.divergence_norm()
+        got = ("Divergence time: %g first: % 10.3e second: % 10.3e infty: % 10.3e"
+               % (gs.t, nm.first, nm.second, nm.infty)).split()
+        if k > 0:
+            assert got == ref[k], (k, got, ref[k])
+        gs.step()
+        k += 1
+    assert k == 80
+
+
+def test_periodic_2d_translating_vortex_bit_exact():
+    osim = oracle_periodic(5)
+    gd, gs = _device_sim(osim, PERIODIC)
+    gs.set_time(end=0.5)
+    osim.start()
+    gs.start()
+    for k in range(5):
+        osim.step()
+        gs.step()
+        _assert_same_state(osim, gs, "step %d" % k)
+
+
+@pytest.mark.parametrize("level", [3, 4, 5])
+def test_taylor_green_3d_steps_bit_exact(level):
+    """SURVEY.md 8d config C (triply periodic Taylor-Green, default parameters) at a size the
+    oracle finishes in seconds"""
+    osim = oracle_taylor_green(level)
+    gd, gs = _device_sim(osim, PERIODIC)
+    osim.start()
+    gs.start()
+    _assert_same_state(osim, gs, "start")
+    _assert_same_un(osim, gs, "start")
+    for k in range(3):
+        osim.step()
+        gs.step()
+        _assert_same_state(osim, gs, "step %d" % k)
+        _assert_same_un(osim, gs, "step %d" % k)
+    assert gs.cfl() == O.lib().go_domain_cfl(osim.ptr)
+    on, gn = osim.divergence_norm(), gs.divergence_norm()
+    assert gn.infty == on.infty
+    assert gn.second == pytest.approx(on.second, rel=1e-12)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_symmetry_box_steps_bit_exact(dim):
+    """closed box (default symmetry BCs on every side): exercises the non-periodic ghost and
+    face-BC paths and the boundary-deferred flux order"""
+    level = 4
+    side = [O.SIDE_BOUNDARY] * 6
+    osim = O.Sim(dim, level, side)
+    cs = osim.dom.centres()
+    rng = np.random.default_rng(2)
+    if dim == 2:
+        x, y = cs
+        vel = [np.sin(np.pi * (x + .5)) * np.cos(np.pi * (y + .5)),
+               -np.cos(np.pi * (x + .5)) * np.sin(np.pi * (y + .5))]
+    else:
+        x, y, z = cs
+        vel = [np.sin(np.pi * (x + .5)) * np.cos(np.pi * (y + .5)) * np.cos(np.pi * (z + .5)),
+               -np.cos(np.pi * (x + .5)) * np.sin(np.pi * (y + .5)) * np.cos(np.pi * (z + .5)),
+               0. * x * y * z]
+    for c in range(dim):
+        osim.u[c].interior()[...] = vel[c] + 0.01 * rng.standard_normal(vel[c].shape)
+    gd, gs = _device_sim(osim, side)
+    osim.start()
+    gs.start()
+    _assert_same_state(osim, gs, "start")
+    for k in range(3):
+        osim.step()
+        gs.step()
+        _assert_same_state(osim, gs, "step %d" % k)
+        _assert_same_un(osim, gs, "step %d" % k)
+
+
+def test_tracer_advection_bit_exact_and_conservative():
+    """GfsVariableTracer: van Leer + gfs_face_advection_flux; the sum of T is conserved to
+    round-off on a periodic box (the invariant of test/conservation)."""
+    level = 4
+    osim = oracle_taylor_green(level)
+    ot = osim.add_tracer()
+    x, y, z = osim.dom.centres()
+    T0 = np.exp(-40. * (x ** 2 + y ** 2 + z ** 2))
+    ot.interior()[...] = T0
+    gd, gs = _device_sim(osim, PERIODIC)
+    gt = gs.add_tracer()
+    gt.upload(ot.leaf())
+    osim.start()
+    gs.start()
+    for k in range(3):
+        osim.step()
+        gs.step()
+        assert np.array_equal(ot.interior(), _interior(gt.download(), 3)), k
+    assert abs(_interior(gt.download(), 3).sum() - T0.sum()) < 1e-10 * T0.sum()
