@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py -- Mcell-steps/s of the projection + advection time step (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one iteration of the simulation_run loop (src/simulation.c:479-548: predictor, MAC
+projection, velocity advection, approximate projection, CFL) on a 3-D 256^3 triply periodic
+Taylor-Green box with default parameters, one box per GPU.  Inputs are
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0, with
+  roofline      the exact-order relax sweep of the 256^3 level (dominant kernel), timed with
+                HIP events on the stream the kernels run on: 24 B/cell algorithmic traffic
+  cpu_baseline  the repo's CPU oracle (a port of the reference algorithm; the reference itself
+                cannot be built here) on a bounded sample, 1 core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "gerris-fft-particles_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+RELAX_BYTES_PER_CELL = 24.0    # read u, read rhs, write u
+
+
+def taylor_green(n):
+    c = -0.5 + (np.arange(1, n + 1) - 0.5) / n
+    x, y, z = c[None, None, :], c[None, :, None], c[:, None, None]
+    u = np.sin(2. * np.pi * x) * np.cos(2. * np.pi * y) * np.cos(2. * np.pi * z)
+    v = -np.cos(2. * np.pi * x) * np.sin(2. * np.pi * y) * np.cos(2. * np.pi * z)
+    w = np.zeros((n, n, n))
+    return u, v, w
+
+
+def with_ghosts(a):
+    n = a.shape[0]
+    b = np.zeros((n + 2,) * 3)
+    b[1:-1, 1:-1, 1:-1] = a
+    return b
+
+
+def cpu_baseline(level=7, steps=3):
+    """The oracle on a bounded sample of the same workload (64^3, same parameters), 1 core."""
+    from oracle import oracle as O
+    n = 1 << level
+    s = O.Sim(3, level, [O.SIDE_PERIODIC] * 6)
+    for c, a in enumerate(taylor_green(n)):
+        s.u[c].interior()[...] = a
+    s.start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.step()
+    dt = time.perf_counter() - t0
+    return {"value": n ** 3 * steps / dt / 1e6, "unit": "Mcell-steps/s", "cores": 1,
+            "kind": "port",
+            "sample": "%d^3 Taylor-Green, %d steps, CPU oracle (reference algorithm, "
+                      "reference traversal order)" % (n, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--level", type=int, default=8, help="Refine level (8 = 256^3)")
+    ap.add_argument("--mode", default="exact", choices=["exact", "redblack"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import gfship
+    n = 1 << args.level
+    dom = gfship.Domain(3, args.level, [gfship.SIDE_PERIODIC] * 6, device=local_rank)
+    if args.mode == "redblack":
+        dom.set_relax_mode(gfship.RELAX_REDBLACK)
+    sim = gfship.Simulation(dom)
+    for c, a in enumerate(taylor_green(n)):
+        sim.u[c].upload(with_ghosts(a))
+    sim.start()
+    for _ in range(args.warmup):
+        sim.step()
+    dom.synchronize()
+
+    def barrier():
+        dom.synchronize()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # roofline of the dominant kernel: one exact-order sweep of the 256^3 level
+    u, rhs, dia = dom.variable(), dom.variable(), dom.variable()
+    rng = np.random.default_rng(0)
+    u.upload(rng.standard_normal((n + 2,) * 3))
+    rhs.upload(rng.standard_normal((n + 2,) * 3))
+    dom.poisson_coefficients()
+    ms = dom.time_relax(u, rhs, dia, reps=5)
+    achieved = RELAX_BYTES_PER_CELL * n ** 3 / (ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "relax sweep, level %d (%d^3), mode %s" % (args.level, n, args.mode),
+                "ms_per_sweep": ms}
+
+    if rank == 0:
+        value = world * n ** 3 * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Mcell-steps/s (projection+advection), 3D 256^3 uniform",
+            "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "3-D periodic Taylor-Green, %d^3 per GPU, default "
+                                   "projection/advection parameters (SURVEY 8d config C)" % n,
+                       "relax_mode": args.mode,
+                       "parallelism": "1 box" if world == 1 else
+                                      "%d independent boxes (replicas)" % world,
+                       "poisson_niter": [int(sim.projection_params.niter),
+                                         int(sim.approx_projection_params.niter)]},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

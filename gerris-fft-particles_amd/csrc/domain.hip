@@ -112,6 +112,7 @@ void gfship_domain_destroy (gfship_domain * dom)
   for (size_t f = 0; f < dom->fields.size (); f++)
     if (dom->fields[f].used)
       gfship_field_free (dom, (gfship_field) f);
+  skew_free (dom);
   if (dom->d_scratch) (void) hipFree (dom->d_scratch);
   if (dom->h_pinned) (void) hipHostFree (dom->h_pinned);
   if (dom->ev0) (void) hipEventDestroy (dom->ev0);
@@ -123,9 +124,10 @@ void gfship_domain_destroy (gfship_domain * dom)
 int gfship_domain_set_relax_mode (gfship_domain * dom, int mode)
 {
   GFSHIP_CHECK (dom != nullptr, GFSHIP_EINVAL, "null domain");
-  GFSHIP_CHECK (mode == GFSHIP_RELAX_EXACT || mode == GFSHIP_RELAX_REDBLACK, GFSHIP_EINVAL,
-		"unknown relax mode %d", mode);
-  dom->relax_mode = mode;
+  GFSHIP_CHECK (mode == GFSHIP_RELAX_EXACT || mode == GFSHIP_RELAX_REDBLACK ||
+		mode == GFSHIP_RELAX_EXACT_HYPERPLANE, GFSHIP_EINVAL, "unknown relax mode %d", mode);
+  dom->force_hyperplane = (mode == GFSHIP_RELAX_EXACT_HYPERPLANE);
+  dom->relax_mode = mode == GFSHIP_RELAX_REDBLACK ? GFSHIP_RELAX_REDBLACK : GFSHIP_RELAX_EXACT;
   return GFSHIP_OK;
 }
 
@@ -164,6 +166,7 @@ gfship_field gfship_field_alloc (gfship_domain * dom, int component)
   size_t o = 0;
   for (int l = dom->depth; l >= 0; l--) { // finest level first: it gets the aligned base
     nf.lev[l] = base + o;
+    nf.zero[l] = true;
     o += (dom->lay[l].total + 31) & ~(size_t) 31;
   }
   dom->fields[slot] = nf;
@@ -224,6 +227,7 @@ int gfship_field_upload (gfship_domain * dom, gfship_field f, int level, const d
 				host, L.rows*sizeof (double),
 				L.rows*sizeof (double), rows, hipMemcpyHostToDevice, dom->stream));
   GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  F->zero[level] = false;
   return GFSHIP_OK;
 }
 
@@ -249,7 +253,9 @@ int gfship_field_fill (gfship_domain * dom, gfship_field f, int level, double va
   if (!F) return GFSHIP_EINVAL;
   int r = check_level (dom, level);
   if (r) return r;
-  return launch_fill (dom, level, F->lev[level], value);
+  r = launch_fill (dom, level, F->lev[level], value);
+  F->zero[level] = (r == GFSHIP_OK && value == 0.);
+  return r;
 }
 
 void * gfship_field_device_ptr (gfship_domain * dom, gfship_field f, int level, int * px, int * xo)
@@ -258,6 +264,7 @@ void * gfship_field_device_ptr (gfship_domain * dom, gfship_field f, int level, 
   if (!F || level < 0 || level > dom->depth) return nullptr;
   if (px) *px = dom->lay[level].px;
   if (xo) *xo = dom->lay[level].xo;
+  F->zero[level] = false; /* the caller may write through the raw pointer */
   return F->lev[level];
 }
 
@@ -267,6 +274,7 @@ int gfship_bc (gfship_domain * dom, gfship_field v, gfship_field v1, int level)
   if (!V || !V1) return GFSHIP_EINVAL;
   int r = check_level (dom, level);
   if (r) return r;
+  V1->zero[level] = false;
   return launch_bc (dom, V, V1, level, 0);
 }
 
@@ -276,6 +284,7 @@ int gfship_homogeneous_bc (gfship_domain * dom, gfship_field ov, gfship_field v,
   if (!OV || !V) return GFSHIP_EINVAL;
   int r = check_level (dom, level);
   if (r) return r;
+  OV->zero[level] = false;
   return launch_bc (dom, V, OV, level, 1);
 }
 

@@ -35,6 +35,20 @@ struct Field {
   double * lev[GFSHIP_MAXLEVEL + 1] = {};
   int bc[6] = {0, 0, 0, 0, 0, 0};
   double * bcval[6] = {};      // device, leaf-level face values or nullptr
+  // level is known to hold only zeros (set by alloc / fill (0.), cleared by every other writer
+  // of a *named* field: uploads and kernels that take the Field as output)
+  bool zero[GFSHIP_MAXLEVEL + 1] = {};
+};
+
+// scratch of the skewed exact-order sweep of one level (relax_skew.hip)
+struct SkewPlan {
+  int ntj = 0, RT = 0;
+  size_t hb_words = 0;
+  double * us = nullptr, * rs = nullptr, * ds = nullptr;
+  void * hb = nullptr;            // hand-off granules (J side then K side)
+  void * ctl = nullptr;           // { ticket, err }
+  unsigned long long * stats = nullptr; // optional per-tile timing (debug)
+  unsigned short * order = nullptr;
 };
 
 // device-side description of the six sides for the BC kernel
@@ -59,7 +73,10 @@ struct gfship_domain {
   double * d_scratch = nullptr;   // reduction scratch
   size_t scratch_doubles = 0;
   double * h_pinned = nullptr;    // pinned host buffer for small read-backs
+  gfship_field dp_cache = -1;     // the `dp` temporary of gfs_poisson_cycle, kept between cycles
+  bool force_hyperplane = false;  // debug/bench: per-hyperplane launches instead of relax_skew
   bool unit_weights = false;      // gfship_poisson_coefficients called with alpha = NULL
+  gfship::SkewPlan skew[GFSHIP_MAXLEVEL + 1];
 };
 
 namespace gfship {
@@ -116,5 +133,16 @@ int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3], 
 int launch_coarse_init (gfship_domain * dom, Field * v);
 int launch_velocity_divergence (gfship_domain * dom, double * const u[3], double * out);
 
+
+// relax_skew.hip
+bool skew_supported (const gfship_domain * dom, int level);
+int  launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * ubc,
+			     const double * rhs, const double * dia, bool dia_zero,
+			     unsigned nrelax, bool bc);
+void skew_free (gfship_domain * dom);
+int  skew_check_error (gfship_domain * dom);
+void skew_dump_stats (gfship_domain * dom, int level);
+int  skew_time_sweeps (gfship_domain * dom, int level, Field * u, const double * rhs,
+		       const double * dia, bool dia_zero, int reps, double * ms_per_sweep);
 
 } // namespace gfship

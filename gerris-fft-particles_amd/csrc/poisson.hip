@@ -5,6 +5,7 @@
 #include "gfship_internal.hpp"
 #include <cmath>
 #include <cfloat>
+#include <cstdlib>
 
 using namespace gfship;
 
@@ -14,9 +15,13 @@ namespace gfship {
 static int relax_level (gfship_domain * dom, unsigned dimension, int level, double omega,
 			Field * u, Field * rhs, Field * dia)
 {
+  u->zero[level] = false;
   if (dom->relax_mode == GFSHIP_RELAX_REDBLACK)
     return launch_relax_redblack (dom, dimension, level, omega, u->lev[level], rhs->lev[level],
 				  dia->lev[level]);
+  if (dimension == 3 && skew_supported (dom, level) && !dom->force_hyperplane)
+    return launch_relax_loop_skew (dom, level, u, u, rhs->lev[level], dia->lev[level],
+				   dia->zero[level], 1, false);
   return launch_relax_exact (dom, dimension, level, omega, u->lev[level], rhs->lev[level],
 			     dia->lev[level]);
 }
@@ -26,6 +31,11 @@ static int relax_loop (gfship_domain * dom, Field * dp, Field * u, unsigned dime
 		       double omega, Field * rhs, Field * dia, unsigned nrelax)
 {
   int r;
+  dp->zero[level] = false;
+  if (dom->relax_mode == GFSHIP_RELAX_EXACT && dimension == 3 && skew_supported (dom, level) &&
+      !dom->force_hyperplane)
+    return launch_relax_loop_skew (dom, level, dp, u, rhs->lev[level], dia->lev[level],
+				   dia->zero[level], nrelax, true);
   if (dom->relax_mode == GFSHIP_RELAX_EXACT) {
     bool done = false;
     if ((r = launch_relax_loop_small (dom, dimension, level, omega, dp, u, rhs->lev[level],
@@ -120,6 +130,7 @@ int gfship_residual (gfship_domain * dom, unsigned d, int level,
   if (!U || !R || !D || !S) return GFSHIP_EINVAL;
   GFSHIP_CHECK (level >= 0 && level <= dom->depth, GFSHIP_EINVAL, "level %d out of range", level);
   GFSHIP_CHECK (dom->unit_weights, GFSHIP_EINVAL, "call gfship_poisson_coefficients first");
+  S->zero[level] = false;
   return launch_residual (dom, level, U->lev[level], R->lev[level], D->lev[level], S->lev[level]);
 }
 
@@ -162,18 +173,24 @@ int gfship_poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
   GFSHIP_CHECK (p->dimension == 2 || p->dimension == 3, GFSHIP_EINVAL, "dimension must be 2 or 3");
   GFSHIP_CHECK (p->nrelax > 0 && p->erelax > 0, GFSHIP_EINVAL, "nrelax and erelax must be non zero");
   GFSHIP_CHECK (dom->unit_weights, GFSHIP_EINVAL, "call gfship_poisson_coefficients first");
-  gfship_field dpf = gfship_field_alloc (dom, -1);   /* gfs_temporary_variable */
+  /* gfs_temporary_variable: the allocation is kept between cycles (a hipMalloc/hipFree pair
+     per cycle would synchronise the device); its content is fully rewritten by the cycle */
+  if (dom->dp_cache < 0)
+    dom->dp_cache = gfship_field_alloc (dom, -1);
+  gfship_field dpf = dom->dp_cache;
   if (dpf < 0) return dpf;
   Field * U = get_field (dom, u), * R = get_field (dom, rhs), * D = get_field (dom, dia),
     * S = get_field (dom, res), * DP = get_field (dom, dpf);
   int r = GFSHIP_OK;
-  if (!U || !R || !D || !S) { gfship_field_free (dom, dpf); return GFSHIP_EINVAL; }
+  if (!U || !R || !D || !S) return GFSHIP_EINVAL;
   const int L = dom->depth;
   unsigned minlevel = p->minlevel; /* MAX (domain->rootlevel, p->minlevel), rootlevel = 0 */
   if (minlevel > (unsigned) L) minlevel = L;
   p->depth = L;
 
 #define TRY(x) do { if ((r = (x)) != GFSHIP_OK) goto done; } while (0)
+  for (int l = 0; l <= L; l++)
+    S->zero[l] = U->zero[l] = false;
   /* compute residual on non-leafs cells (get_from_below, post-order: finest parents first) */
   for (int l = L - 1; l >= 0; l--)
     TRY (launch_restrict (dom, p->dimension, l, S->lev[l], S->lev[l + 1]));
@@ -183,6 +200,8 @@ int gfship_poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
     unsigned nrelax = p->nrelax;
     for (unsigned l = minlevel; l < p->depth; l++)
       nrelax *= p->erelax;
+    for (int l = 0; l <= L; l++)
+      DP->zero[l] = false;
     TRY (launch_fill (dom, minlevel, DP->lev[minlevel], 0.));
     TRY (relax_loop (dom, DP, U, p->dimension, minlevel, p->omega, S, D, nrelax));
     nrelax /= p->erelax;
@@ -201,10 +220,6 @@ int gfship_poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
   TRY (launch_residual (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L]));
 #undef TRY
  done:
-  {
-    int r2 = gfship_field_free (dom, dpf);
-    if (r == GFSHIP_OK) r = r2;
-  }
   return r;
 }
 
@@ -224,6 +239,7 @@ int gfship_poisson_solve (gfship_domain * dom, gfship_multilevel_params * par,
   par->niter = 0;
 
   /* calculates the initial residual and its norm */
+  S->zero[L] = false;
   if ((r = launch_residual (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L]))) return r;
   if ((r = norm_residual (dom, dt, S, &par->residual))) return r;
   par->residual_before = par->residual;
@@ -243,6 +259,8 @@ int gfship_poisson_solve (gfship_domain * dom, gfship_multilevel_params * par,
   }
 
   par->minlevel = minlevel;
+  if (r == GFSHIP_OK)
+    r = skew_check_error (dom);
   return r;
 }
 
@@ -253,6 +271,16 @@ int gfship_time_relax (gfship_domain * dom, unsigned d, int level, gfship_field 
   if (!U || !R || !D || !ms_per_sweep || reps <= 0) return GFSHIP_EINVAL;
   GFSHIP_CHECK (level >= 0 && level <= dom->depth, GFSHIP_EINVAL, "level %d out of range", level);
   int r;
+  if (dom->relax_mode == GFSHIP_RELAX_EXACT && d == 3 && skew_supported (dom, level) &&
+      !dom->force_hyperplane) {
+    /* the pipelined sweep kernel alone: one launch per sweep */
+    U->zero[level] = false;
+    r = skew_time_sweeps (dom, level, U, R->lev[level], D->lev[level], D->zero[level], reps,
+			  ms_per_sweep);
+    if (r == GFSHIP_OK && getenv ("GFSHIP_SKEW_STATS"))
+      skew_dump_stats (dom, level);
+    return r;
+  }
   if ((r = relax_level (dom, d, level, 1., U, R, D))) return r; /* warm-up */
   GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
   for (int q = 0; q < reps; q++)
@@ -262,6 +290,8 @@ int gfship_time_relax (gfship_domain * dom, unsigned d, int level, gfship_field 
   float ms = 0.f;
   GFSHIP_HIP (hipEventElapsedTime (&ms, dom->ev0, dom->ev1));
   *ms_per_sweep = (double) ms/reps;
+  if (getenv ("GFSHIP_SKEW_STATS"))
+    skew_dump_stats (dom, level);
   return GFSHIP_OK;
 }
 

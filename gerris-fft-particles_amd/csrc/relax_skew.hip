@@ -1,0 +1,564 @@
+// relax_skew.hip -- exact-order Gauss-Seidel sweep as ONE pipelined launch per sweep (3-D).
+//
+// The reference's in-place sweep (src/poisson.c:507-530, tree pre-order of src/ftt.c:837-852) is
+// a lexicographic sweep in the oriented coordinates I = i - 1, J = n - j, K = n - k: cell
+// (I,J,K) needs the NEW values of (I-1,J,K), (I,J-1,K), (I,J,K-1) and the OLD values of the +1
+// neighbours.  Any schedule that respects these three dependencies gives the same bits.
+//
+// Schedule.  The (J,K) plane is cut into 16 x 16 tiles; a tile is a 256-thread workgroup and
+// every thread owns one full line along I.  Thread (a,b) of a tile works on I = t - a - b at
+// step t, so at one step the workgroup is on one hyperplane of its tile, and the values a thread
+// needs from threads (a-1,b) and (a,b-1) were produced at step t - 1 (exchanged through LDS,
+// one barrier per step).  Tiles run concurrently, each lagging its (J-1) and (K-1) neighbour
+// tiles: the new values of the two outgoing edges of a tile are handed to the next tiles
+// through small buffers of 8-byte granules pre-filled with a sentinel and written/polled with
+// agent-scope (sc1) accesses, so a consumer simply waits for the value it needs (the data is
+// the flag; cdna_hip_programming.md Guideline 16, form R2).  Tiles are claimed through a ticket
+// in anti-diagonal order, so a waiting tile only ever waits on tiles claimed before it:
+// no residency assumption, no deadlock; every spin is bounded.
+//
+// Layout.  During a relax loop the level lives in a tile-skewed ("hyperplane-major") copy:
+// element (I,a,b) of tile T sits at  T*RT*256 + (I + a + b)*256 + (a + 16 b),  RT = n + 30, so
+// that at step t every thread reads/writes row t (or t + 1) of its tile: fully coalesced
+// streaming with register prefetch, no LDS staging.  The natural array keeps the ghost layer;
+// cells adjacent to the box sides are mirrored into it by the sweep so that the BC kernel works
+// unchanged between sweeps.
+#include "gfship_internal.hpp"
+#include <cstdlib>
+
+namespace gfship {
+
+#define SK_T   16            /* tile edge (lines) */
+#define SK_NL  (SK_T*SK_T)   /* lines = threads per tile */
+#define SK_PAD (2*SK_T - 2)  /* extra rows of a tile: max skew */
+#define SK_D   8             /* prefetch distance (steps) */
+#define SK_DH  4             /* prefetch distance of the halo streams (divides SK_D): the lag */
+                             /* between neighbouring tiles grows with it                     */
+#define SK_FP  16            /* rows of padding in front of and behind every tile, so that */
+                             /* prefetch addresses never need clamping                      */
+
+typedef unsigned long long u64;
+#define SK_SENTINEL 0xFFFFFFFFFFFFFFFFull
+
+struct SkewArgs {
+  Layout L;
+  int ntj;                 // tiles per side
+  int RT;                  // rows per tile
+  double * us;             // skewed u
+  const double * rs;       // skewed rhs
+  const double * ds;       // skewed dia (or nullptr)
+  double * un;             // natural u (ghost layer + mirrored side cells)
+  u64 * hbJ;               // [tile][n + SK_T - 1][SK_T] new values of line a = 15
+  u64 * hbK;               // [tile][n + SK_T - 1][SK_T] new values of line b = 15
+  const unsigned short * order; // ticket -> tile (anti-diagonal major)
+  unsigned * ticket;       // ticket counter (zeroed before the launch)
+  unsigned * err;          // set to 1 when a bounded spin gives up
+  const u64 * dummy;       // 8 readable bytes for the streams a lane does not need
+  u64 * stats;             // optional per-tile { start, end, spins, slow entries } (debug)
+};
+
+typedef __attribute__((address_space(1))) u64 gu64;
+
+__device__ __forceinline__ u64 load_sc1 (const u64 * p)
+{
+  return __hip_atomic_load ((gu64 *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void store_sc1 (u64 * p, u64 v)
+{
+  __hip_atomic_store ((gu64 *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The main loop is written so that the compiler can count outstanding loads exactly
+// (s_waitcnt vmcnt(N), never vmcnt(0)): straight-line unrolled body, every lane issues the same
+// loads at every step from addresses that are always valid (padded layout), no load sits inside
+// a data-dependent loop, and the only divergent blocks hold stores.
+//
+// Per step a lane loads two values (its own old value one cell ahead and the right-hand side);
+// everything it needs from other lines goes through two LDS grids of 17 x 17 doubles:
+//   X  new values of the previous step  (column 0 / row 0: values handed over by the (J-1) /
+//      (K-1) tiles, or box-side ghosts)
+//   Y  old values one cell ahead        (column 16 / row 16: first line of the (J+1) / (K+1)
+//      tiles, or box-side ghosts)
+// The four halo strips are streamed by the 64 lanes of wave 0 (16 lanes each), which also wait
+// for hand-off granules that are still the sentinel (rare slow path).
+template <bool HAS_DIA, int VARIANT = 0>
+__global__ void __launch_bounds__(SK_NL)
+relax_skew_kernel (SkewArgs A)
+{
+  constexpr int XS = SK_T + 1;               // row pitch of the LDS grids
+  __shared__ double X[2][XS*XS];
+  __shared__ double Y[2][XS*XS];
+  __shared__ unsigned s_tile;
+
+  const int tid = threadIdx.x;
+  const int a = tid & (SK_T - 1), b = tid >> 4;
+  const int n = A.L.n;
+  const int ntj = A.ntj;
+  const long tstride = (long) (A.RT + 2*SK_FP)*SK_NL;  // doubles per tile incl. padding rows
+  const long hstride = (long) (n + 3*SK_T)*SK_T;       // granules per tile incl. padding rows
+
+  if (tid == 0)
+    s_tile = A.order[atomicAdd (A.ticket, 1u)];
+  __syncthreads ();
+  const int tile = s_tile;
+  u64 st_spins = 0, st_slow = 0;
+  const u64 st_start = A.stats ? __builtin_amdgcn_s_memrealtime () : 0;
+  const int P = tile % ntj, Q = tile / ntj;   // tile coordinates along J and K
+  const int j = n - (SK_T*P + a), k = n - (SK_T*Q + b);   // natural coordinates of the line
+  const int s = a + b;
+
+  double * ut = A.us + tile*tstride + SK_FP*SK_NL;
+
+  // ---- own streams: value for step t at base + t*256 ----
+  const double * qR = ut + SK_NL + tid;                          // own old value at I + 1
+  const double * qRhs = A.rs + tile*tstride + SK_FP*SK_NL + tid;
+  const double * qDia = HAS_DIA ? A.ds + tile*tstride + SK_FP*SK_NL + tid : nullptr;
+
+  // ---- halo streams of wave 0: strip g = tid / 16, position m = tid % 16 ----
+  const bool loader = __builtin_amdgcn_readfirstlane (tid >> 6) == 0;
+  const int g = tid >> 4, m = tid & 15;
+  const u64 * qH = A.dummy;     // value for step t at qH + t*hs
+  int hs = 0;
+  bool handoff = false;         // granule written by another tile in this launch
+  int xy_halo = 0;              // LDS index of the halo entry this lane fills
+  if (loader) {
+    const int jm = n - (SK_T*P + m), km = n - (SK_T*Q + m);
+    switch (g) {
+    case 0: // new values of line (-1, b = m): tile (P-1,Q) hand-off row I + b = t; box side j = n + 1
+      if (P > 0) { qH = A.hbJ + (tile - 1)*hstride + m; hs = SK_T; handoff = true; }
+      else       { qH = (const u64 *) (A.un + A.L.idx (1 - m, n + 1, km)); hs = 1; }
+      xy_halo = 0 + XS*(m + 1);
+      break;
+    case 1: // new values of line (a = m, -1): tile (P,Q-1) hand-off; box side k = n + 1
+      if (Q > 0) { qH = A.hbK + (tile - ntj)*hstride + m; hs = SK_T; handoff = true; }
+      else       { qH = (const u64 *) (A.un + A.L.idx (1 - m, jm, n + 1)); hs = 1; }
+      xy_halo = (m + 1) + XS*0;
+      break;
+    case 2: // old values of line (16, b = m) = line (0,m) of tile (P+1,Q), row I + m = t - 15;
+	    // box side j = 0
+      if (P + 1 < ntj) { qH = (const u64 *) (ut + tstride - (long) (SK_T - 1)*SK_NL + SK_T*m); hs = SK_NL; }
+      else             { qH = (const u64 *) (A.un + A.L.idx (1 - (SK_T - 1 + m), 0, km)); hs = 1; }
+      xy_halo = SK_T + XS*m;
+      break;
+    default: // old values of line (a = m, 16) = line (m,0) of tile (P,Q+1), row t - 15; box side k = 0
+      if (Q + 1 < ntj) { qH = (const u64 *) (ut + ntj*tstride - (long) (SK_T - 1)*SK_NL + m); hs = SK_NL; }
+      else             { qH = (const u64 *) (A.un + A.L.idx (1 - (m + SK_T - 1), jm, 0)); hs = 1; }
+      xy_halo = m + XS*SK_T;
+    }
+  }
+  bool failed = false;          // a bounded wait gave up: stop waiting, the host reports it
+  double * const halo_dst0 = (g < 2 ? &X[0][0] : &Y[0][0]) + xy_halo;
+  const u64 * const qH0 = qH;
+
+  // ghost cells at the two ends of the line (frozen during the sweep)
+  const double ghostL = A.un[A.L.idx (0, j, k)];
+  const double ghostR = A.un[A.L.idx (n + 1, j, k)];
+
+  // store pointers: own row t; hand-off row t - 15 of this tile's buffers; natural mirror
+  double * wU = ut + tid;
+  u64 * wJ = (a == SK_T - 1 && P + 1 < ntj) ? A.hbJ + tile*hstride + b - (long) (SK_T - 1)*SK_T : nullptr;
+  u64 * wK = (b == SK_T - 1 && Q + 1 < ntj) ? A.hbK + tile*hstride + a - (long) (SK_T - 1)*SK_T : nullptr;
+  const bool side_jk = (j == 1 || j == n || k == 1 || k == n);
+  double * nat = A.un + A.L.idx (1 - s, j, k);   // natural address of I at step t: nat[t]
+
+  // LDS indices
+  const int iOwnX = (a + 1) + XS*(b + 1), iT = a + XS*(b + 1), iF = (a + 1) + XS*b;
+  const int iOwnY = a + XS*b, iBo = (a + 1) + XS*b, iBk = a + XS*(b + 1);
+
+  // steps, rounded up to the unroll factor (the extra steps find every lane inactive) so that
+  // the unrolled body is one straight-line block and load counting stays exact
+  const int T = (n + SK_PAD + SK_D - 1)/SK_D*SK_D;
+  // register prefetch rings: slot q holds the loads for steps t = q (mod SK_D)
+  double pR[SK_D], pRhs[SK_D], pDia[SK_D], pH[SK_DH];
+
+#define SK_PREFETCH(q_)							\
+  do {									\
+    pR[q_]   = *qR;   qR += SK_NL;					\
+    pRhs[q_] = *qRhs; qRhs += SK_NL;					\
+    if (HAS_DIA) { pDia[q_] = *qDia; qDia += SK_NL; }			\
+  } while (0)
+#define SK_PREFETCH_HALO(q_)						\
+  do {									\
+    if (loader) {							\
+      pH[q_] = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs; \
+    }									\
+  } while (0)
+
+  // wave 0: put the halo value of step t_ (held in slot q_) into LDS buffer t_ & 1
+#define SK_HALO(t_, q_)							\
+  do {									\
+    if (loader) {							\
+      double hv = pH[q_];						\
+      /* a granule is awaited only for the steps at which the consuming line is active */ \
+      bool w = handoff && !failed && (unsigned) ((t_) - m) < (unsigned) n && \
+	(u64) __double_as_longlong (hv) == SK_SENTINEL;			\
+      if (__builtin_expect (__any (w), 0)) {				\
+	unsigned spins = 0;						\
+	st_slow++;							\
+	while (__any (w)) {						\
+	  st_spins++;							\
+	  __builtin_amdgcn_s_sleep (2);					\
+	  if (w) {							\
+	    hv = __longlong_as_double ((long long) load_sc1 (qH0 + (long) (t_)*hs)); \
+	    w = (u64) __double_as_longlong (hv) == SK_SENTINEL;		\
+	  }								\
+	  if (++spins > (1u << 16)) { *A.err = 1; failed = true; break; } \
+	}								\
+      }									\
+      halo_dst0[((t_) & 1)*(XS*XS)] = hv;				\
+    }									\
+  } while (0)
+
+  // the halo stream runs one step ahead of the others: its value for step t + 1 is put into
+  // LDS during step t, so halo slot q holds the value of step t + 1 for t = q (mod SK_DH)
+  double h0 = 0.;
+  if (loader) { h0 = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs; }
+#pragma unroll
+  for (int q = 0; q < SK_D; q++)
+    SK_PREFETCH (q);
+#pragma unroll
+  for (int q = 0; q < SK_DH; q++)
+    SK_PREFETCH_HALO (q);
+
+  // LDS state for step 0: old values one cell ahead and the halos of step 0
+  for (int q = tid; q < 2*XS*XS; q += SK_NL) {
+    (&X[0][0])[q] = 0.;
+    (&Y[0][0])[q] = 0.;
+  }
+  __syncthreads ();
+  Y[0][iOwnY] = pR[0];
+  {
+    double keep = pH[0];
+    pH[0] = h0;
+    SK_HALO (0, 0);
+    pH[0] = keep;
+  }
+  __syncthreads ();
+
+  double prev = ghostL;
+
+  for (int t0 = 0; t0 < T; t0 += SK_D) {
+#pragma unroll
+    for (int q = 0; q < SK_D; q++) {
+      const int t = t0 + q;
+      const int I = t - s;
+      const bool act = I >= 0 && I < n;
+      const int B = t & 1;
+      // values of the other lines: new ones of step t - 1, old ones one cell ahead
+      const double Tn = X[B][iT], Fn = X[B][iF], Bo = Y[B][iBo], Bk = Y[B][iBk];
+      // relax, src/poisson.c:507-530, unit weights, d = 0..5 = right,left,top,bottom,front,back
+      const double Rv = (I + 1 < n) ? pR[q] : ghostR;
+      double aa = HAS_DIA ? pDia[q] : 0., bb = 0.;
+      aa += 1.; bb += 1.*Rv;        // right  (+x, old)
+      aa += 1.; bb += 1.*prev;      // left   (-x, new)
+      aa += 1.; bb += 1.*Tn;        // top    (+y = J-1, new)
+      aa += 1.; bb += 1.*Bo;        // bottom (-y = J+1, old)
+      aa += 1.; bb += 1.*Fn;        // front  (+z = K-1, new)
+      aa += 1.; bb += 1.*Bk;        // back   (-z = K+1, old)
+      const double v = aa != 0. ? (bb - pRhs[q])/aa : 0.;
+      prev = act ? v : prev;
+      // publish for step t + 1
+      X[B ^ 1][iOwnX] = v;
+      Y[B ^ 1][iOwnY] = pR[(q + 1) % SK_D];
+      // wave 0: halo of step t + 1 into LDS; then refill slot q (steps t + SK_D, halo t + 1 + SK_D)
+      SK_HALO (t + 1, q % SK_DH);
+      SK_PREFETCH_HALO (q % SK_DH);
+      SK_PREFETCH (q);
+      if (act) {
+	if (VARIANT != 1) *wU = v;
+	if (wJ) store_sc1 (wJ, (u64) __double_as_longlong (v));
+	if (wK) store_sc1 (wK, (u64) __double_as_longlong (v));
+	if (VARIANT != 1 && (side_jk || I == 0 || I == n - 1))
+	  nat[t] = v;
+      }
+      wU += SK_NL;
+      if (wJ) wJ += SK_T;
+      if (wK) wK += SK_T;
+      // workgroup barrier that drains LDS traffic only: __syncthreads() would also wait for the
+      // prefetch loads just issued (s_waitcnt vmcnt(0)) and serialise every step on HBM latency
+      asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  }
+#undef SK_PREFETCH
+#undef SK_PREFETCH_HALO
+#undef SK_HALO
+  if (A.stats && tid == 0) {
+    u64 * st = A.stats + 4*tile;
+    st[0] = st_start; st[1] = __builtin_amdgcn_s_memrealtime (); st[2] = st_spins; st[3] = st_slow;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// natural <-> skewed copies through an LDS transpose.  One block = one tile, one b (a K plane of
+// 16 lines), one chunk of 16 cells along I: reads and writes are 128-byte segments on both sides.
+// Element (I,a,b) of the tile <-> skewed row I + a + b, column a + 16 b.
+// ---------------------------------------------------------------------------------------------
+struct PackArgs {
+  Layout L;
+  int ntj, RT;
+  const double * src[3];
+  double * dst[3];
+  int narr;
+};
+
+__global__ void __launch_bounds__(SK_NL)
+skew_pack_kernel (PackArgs A)
+{
+  __shared__ double tile_[3][SK_T][SK_T + 1];
+  const int tid = threadIdx.x;
+  const int lo = tid & (SK_T - 1), hi = tid >> 4;
+  const int tile = blockIdx.z;
+  const int b = blockIdx.y;
+  const int I0 = blockIdx.x*SK_T;
+  const int P = tile % A.ntj, Q = tile / A.ntj;
+  const int n = A.L.n;
+  const int k = n - (SK_T*Q + b);
+  const long tbase = (long) tile*(A.RT + 2*SK_FP)*SK_NL + SK_FP*SK_NL;
+  // read: hi = a, lo = cell along I (contiguous in memory)
+  {
+    const int j = n - (SK_T*P + hi);
+    long nidx = A.L.idx (I0 + lo + 1, j, k);
+    for (int q = 0; q < A.narr; q++)
+      tile_[q][hi][lo] = A.src[q][nidx];
+  }
+  __syncthreads ();
+  // write: lo = a (contiguous in the skewed row), hi selects the diagonal m = I - I0 + a
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int m = hi + SK_T*pass;            // 0 .. 30
+    const int di = m - lo;                   // I - I0
+    if (m <= 2*SK_T - 2 && di >= 0 && di < SK_T) {
+      long sidx = tbase + (long) (I0 + m + b)*SK_NL + lo + SK_T*b;
+      for (int q = 0; q < A.narr; q++)
+	A.dst[q][sidx] = tile_[q][lo][di];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(SK_NL)
+skew_unpack_kernel (PackArgs A)
+{
+  __shared__ double tile_[SK_T][SK_T + 1];
+  const int tid = threadIdx.x;
+  const int lo = tid & (SK_T - 1), hi = tid >> 4;
+  const int tile = blockIdx.z;
+  const int b = blockIdx.y;
+  const int I0 = blockIdx.x*SK_T;
+  const int P = tile % A.ntj, Q = tile / A.ntj;
+  const int n = A.L.n;
+  const int k = n - (SK_T*Q + b);
+  const long tbase = (long) tile*(A.RT + 2*SK_FP)*SK_NL + SK_FP*SK_NL;
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int m = hi + SK_T*pass;
+    const int di = m - lo;
+    if (m <= 2*SK_T - 2 && di >= 0 && di < SK_T)
+      tile_[lo][di] = A.src[0][tbase + (long) (I0 + m + b)*SK_NL + lo + SK_T*b];
+  }
+  __syncthreads ();
+  const int j = n - (SK_T*P + hi);
+  A.dst[0][A.L.idx (I0 + lo + 1, j, k)] = tile_[hi][lo];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+bool skew_supported (const gfship_domain * dom, int level)
+{
+  if (dom->dim != 3) return false;
+  int n = dom->lay[level].n;
+  if (n < 2*SK_T) return false;          /* smaller levels run the LDS relax loop */
+  for (int d = 0; d < 6; d++)
+    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL) return false;
+  return true;
+}
+
+static int skew_plan (gfship_domain * dom, int level, SkewPlan ** out)
+{
+  SkewPlan & S = dom->skew[level];
+  if (!S.us) {
+    const Layout & L = dom->lay[level];
+    S.ntj = L.n/SK_T;
+    S.RT = L.n + SK_PAD;
+    int ntiles = S.ntj*S.ntj;
+    size_t doubles = (size_t) ntiles*(S.RT + 2*SK_FP)*SK_NL + 64;  /* padding rows per tile */
+    S.hb_words = (size_t) ntiles*(L.n + 3*SK_T)*SK_T;   /* rows n + 15 used, rest padding */
+    GFSHIP_HIP (hipMalloc ((void **) &S.us, doubles*sizeof (double)));
+    GFSHIP_HIP (hipMalloc ((void **) &S.rs, doubles*sizeof (double)));
+    GFSHIP_HIP (hipMalloc ((void **) &S.ds, doubles*sizeof (double)));
+    GFSHIP_HIP (hipMalloc ((void **) &S.hb, 2*S.hb_words*sizeof (u64)));
+    GFSHIP_HIP (hipMalloc ((void **) &S.ctl, 64));
+    if (getenv ("GFSHIP_SKEW_STATS"))
+      GFSHIP_HIP (hipMalloc ((void **) &S.stats, (size_t) ntiles*4*sizeof (u64)));
+    // ticket -> tile, anti-diagonal major: a tile only depends on tiles of earlier diagonals
+    std::vector<unsigned short> order;
+    for (int d = 0; d <= 2*(S.ntj - 1); d++)
+      for (int Q = 0; Q < S.ntj; Q++) {
+	int P = d - Q;
+	if (P >= 0 && P < S.ntj)
+	  order.push_back ((unsigned short) (P + S.ntj*Q));
+      }
+    GFSHIP_HIP (hipMalloc ((void **) &S.order, order.size ()*sizeof (unsigned short)));
+    GFSHIP_HIP (hipMemcpy (S.order, order.data (), order.size ()*sizeof (unsigned short),
+			   hipMemcpyHostToDevice));
+    GFSHIP_HIP (hipMemsetAsync (S.ctl, 0, 64, dom->stream));
+  }
+  *out = &S;
+  return GFSHIP_OK;
+}
+
+void skew_free (gfship_domain * dom)
+{
+  for (int l = 0; l <= GFSHIP_MAXLEVEL; l++) {
+    SkewPlan & S = dom->skew[l];
+    if (S.us) (void) hipFree (S.us);
+    if (S.rs) (void) hipFree (S.rs);
+    if (S.ds) (void) hipFree (S.ds);
+    if (S.hb) (void) hipFree (S.hb);
+    if (S.ctl) (void) hipFree (S.ctl);
+    if (S.stats) (void) hipFree (S.stats);
+    if (S.order) (void) hipFree (S.order);
+    S = SkewPlan ();
+  }
+}
+
+static int skew_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u,
+		      const double * rhs, const double * dia)
+{
+  PackArgs A;
+  A.L = dom->lay[level]; A.ntj = S->ntj; A.RT = S->RT;
+  A.narr = 0;
+  A.src[A.narr] = u;   A.dst[A.narr++] = S->us;
+  A.src[A.narr] = rhs; A.dst[A.narr++] = S->rs;
+  if (dia) { A.src[A.narr] = dia; A.dst[A.narr++] = S->ds; }
+  dim3 grid (A.L.n/SK_T, SK_T, S->ntj*S->ntj);
+  hipLaunchKernelGGL (skew_pack_kernel, grid, dim3 (SK_NL), 0, dom->stream, A);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+static int skew_unpack (gfship_domain * dom, int level, SkewPlan * S, double * u)
+{
+  PackArgs A;
+  A.L = dom->lay[level]; A.ntj = S->ntj; A.RT = S->RT;
+  A.narr = 1;
+  A.src[0] = S->us; A.dst[0] = u;
+  dim3 grid (A.L.n/SK_T, SK_T, S->ntj*S->ntj);
+  hipLaunchKernelGGL (skew_unpack_kernel, grid, dim3 (SK_NL), 0, dom->stream, A);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+static int skew_launch (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia)
+{
+  SkewArgs A;
+  A.L = dom->lay[level]; A.ntj = S->ntj; A.RT = S->RT;
+  A.us = S->us; A.rs = S->rs; A.ds = has_dia ? S->ds : nullptr;
+  A.un = u_nat;
+  A.hbJ = (u64 *) S->hb; A.hbK = (u64 *) S->hb + S->hb_words;
+  A.order = S->order;
+  A.ticket = (unsigned *) S->ctl;
+  A.err = (unsigned *) S->ctl + 1;
+  A.dummy = (const u64 *) S->ctl + 2;
+  A.stats = S->stats;
+  int ntiles = S->ntj*S->ntj;
+  static const int variant = getenv ("GFSHIP_SKEW_VARIANT") ? atoi (getenv ("GFSHIP_SKEW_VARIANT")) : 0;
+  if (has_dia)
+    hipLaunchKernelGGL (relax_skew_kernel<true>, dim3 (ntiles), dim3 (SK_NL), 0, dom->stream, A);
+  else switch (variant) { /* variants 1-4: timing experiments only (wrong results) */
+    case 1: hipLaunchKernelGGL ((relax_skew_kernel<false, 1>), dim3 (ntiles), dim3 (SK_NL), 0, dom->stream, A); break;
+    default: hipLaunchKernelGGL (relax_skew_kernel<false>, dim3 (ntiles), dim3 (SK_NL), 0, dom->stream, A);
+  }
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+static int skew_sweep (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia)
+{
+  // ticket = 0 (err is sticky), hand-off granules = sentinel
+  GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
+  if (S->ntj > 1)
+    GFSHIP_HIP (hipMemsetAsync (S->hb, 0xFF, 2*S->hb_words*sizeof (u64), dom->stream));
+  return skew_launch (dom, level, S, u_nat, has_dia);
+}
+
+// the whole relax_loop (src/poisson.c:1070-1089) of one level in the skewed layout; for
+// nrelax = 1 and bc = false it is a single gfs_relax sweep
+int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * ubc,
+			    const double * rhs, const double * dia, bool dia_zero,
+			    unsigned nrelax, bool bc)
+{
+  SkewPlan * S;
+  int r;
+  if ((r = skew_plan (dom, level, &S))) return r;
+  double * u = dp->lev[level];
+  if (bc && (r = launch_bc (dom, ubc, dp, level, 1))) return r;
+  if ((r = skew_pack (dom, level, S, u, rhs, dia_zero ? nullptr : dia))) return r;
+  for (unsigned q = 0; q < nrelax; q++) {
+    if ((r = skew_sweep (dom, level, S, u, !dia_zero))) return r;
+    if (bc && q + 1 < nrelax && (r = launch_bc (dom, ubc, dp, level, 1))) return r;
+  }
+  return skew_unpack (dom, level, S, u);
+}
+
+// debug: print per-tile timing of the last sweep of `level` (GFSHIP_SKEW_STATS=1)
+void skew_dump_stats (gfship_domain * dom, int level)
+{
+  SkewPlan & S = dom->skew[level];
+  if (!S.stats) return;
+  (void) hipStreamSynchronize (dom->stream);
+  int nt = S.ntj*S.ntj;
+  std::vector<u64> h (4*nt);
+  (void) hipMemcpy (h.data (), S.stats, h.size ()*sizeof (u64), hipMemcpyDeviceToHost);
+  u64 t0 = ~0ull;
+  for (int q = 0; q < nt; q++) if (h[4*q] < t0) t0 = h[4*q];
+  for (int Q = 0; Q < S.ntj; Q++)
+    for (int P = 0; P < S.ntj; P++) {
+      int q = P + S.ntj*Q;
+      if (P == Q || P == 0 || Q == 0 || P == S.ntj - 1)
+	fprintf (stderr, "tile (%2d,%2d) start %8.2f us  dur %8.2f us  spins %6llu slow %5llu\n", P, Q,
+		 (h[4*q] - t0)/100., (h[4*q + 1] - h[4*q])/100., h[4*q + 2], h[4*q + 3]);
+    }
+}
+
+// time `reps` sweeps of the pipelined kernel alone (HIP events on the domain's stream)
+int skew_time_sweeps (gfship_domain * dom, int level, Field * u, const double * rhs,
+		      const double * dia, bool dia_zero, int reps, double * ms_per_sweep)
+{
+  SkewPlan * S;
+  int r;
+  if ((r = skew_plan (dom, level, &S))) return r;
+  if ((r = skew_pack (dom, level, S, u->lev[level], rhs, dia_zero ? nullptr : dia))) return r;
+  if ((r = skew_sweep (dom, level, S, u->lev[level], !dia_zero))) return r; /* warm-up */
+  float total = 0.f;
+  for (int q = 0; q < reps; q++) {
+    // the memsets that re-arm the hand-off buffers are outside the timed region
+    GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
+    if (S->ntj > 1)
+      GFSHIP_HIP (hipMemsetAsync (S->hb, 0xFF, 2*S->hb_words*sizeof (u64), dom->stream));
+    GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
+    if ((r = skew_launch (dom, level, S, u->lev[level], !dia_zero))) return r;
+    GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));
+    GFSHIP_HIP (hipEventSynchronize (dom->ev1));
+    float ms = 0.f;
+    GFSHIP_HIP (hipEventElapsedTime (&ms, dom->ev0, dom->ev1));
+    total += ms;
+  }
+  *ms_per_sweep = total/reps;
+  return skew_unpack (dom, level, S, u->lev[level]);
+}
+
+int skew_check_error (gfship_domain * dom)
+{
+  for (int l = 0; l <= dom->depth; l++)
+    if (dom->skew[l].ctl) {
+      unsigned e[2];
+      GFSHIP_HIP (hipMemcpy (e, dom->skew[l].ctl, sizeof (e), hipMemcpyDeviceToHost));
+      GFSHIP_CHECK (e[1] == 0, GFSHIP_EHIP,
+		    "relax_skew_kernel: a hand-off wait timed out on level %d", l);
+    }
+  return GFSHIP_OK;
+}
+
+} // namespace gfship

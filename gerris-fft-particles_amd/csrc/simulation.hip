@@ -63,7 +63,7 @@ int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, g
   TRY (gfship_poisson_coefficients (dom));
   /* dia = 0 on all levels (gfs_cell_reset on FTT_TRAVERSE_ALL) */
   for (int l = 0; l <= dom->depth; l++)
-    TRY (launch_fill (dom, l, dom->fields[s->dia].lev[l], 0.));
+    TRY (gfship_field_fill (dom, s->dia, l, 0.));
   /* MAC divergence, scaled by 1/dt */
   TRY (launch_divergence (dom, un, leaf (s, s->div), dt));
   TRY (gfship_poisson_solve (dom, par, p, s->div, s->res, s->dia, dt));

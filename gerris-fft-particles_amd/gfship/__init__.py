@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libgfship.so")
 
 SIDE_PERIODIC, SIDE_BOUNDARY, SIDE_EXTERNAL = 0, 1, 2
 BC_SYMMETRY, BC_DIRICHLET, BC_NEUMANN = 0, 1, 2
-RELAX_EXACT, RELAX_REDBLACK = 0, 1
+RELAX_EXACT, RELAX_REDBLACK, RELAX_EXACT_HYPERPLANE = 0, 1, 2
 
 
 class GfshipError(RuntimeError):

@@ -43,8 +43,10 @@ enum { GFSHIP_BC_SYMMETRY = 0, GFSHIP_BC_DIRICHLET = 1, GFSHIP_BC_NEUMANN = 2 };
    EXACT  reproduces the reference's in-place sweep (src/poisson.c:507-557, tree pre-order of
           src/ftt.c:837-852) bit for bit on the device;
    REDBLACK is a two-colour Gauss-Seidel of the same operator: same fixed point, different
-          iterates (not a reference algorithm; opt-in). */
-enum { GFSHIP_RELAX_EXACT = 0, GFSHIP_RELAX_REDBLACK = 1 };
+          iterates (not a reference algorithm; opt-in);
+   EXACT_HYPERPLANE is EXACT with one launch per hyperplane instead of the pipelined
+          tile sweep (same bits; kept as an independent implementation to test against). */
+enum { GFSHIP_RELAX_EXACT = 0, GFSHIP_RELAX_REDBLACK = 1, GFSHIP_RELAX_EXACT_HYPERPLANE = 2 };
 
 typedef struct gfship_domain gfship_domain;   /* GfsDomain + its per-level SoA device arrays */
 typedef int gfship_field;                     /* GfsVariable handle (>= 0) */

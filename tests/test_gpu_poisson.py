@@ -260,3 +260,63 @@ def test_redblack_mode_converges_to_same_solution():
         sols.append(P.download()[1:-1, 1:-1, 1:-1])
     err = np.abs(sols[0] - sols[1]).max() / np.abs(sols[0]).max()
     assert err < 1e-12, err
+
+
+# ---------------------------------------------------------------------------------------------
+# pipelined skewed-tile sweep (relax_skew.hip): levels with n >= 32 in 3-D
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("level,kind", [(5, "periodic"), (6, "dirichlet"), (6, "periodic"),
+                                        (6, "mixed"), (7, "neumann"), (7, "periodic")])
+def test_skew_sweep_bit_exact_vs_oracle(level, kind):
+    """multi-tile levels (64^3 = 4x4 tiles, 128^3 = 8x8 tiles): hand-offs between tiles, box-side
+    ghost streams of every BC kind, non-zero dia, several sweeps with BC in between"""
+    L = O.lib()
+    dim = 3
+    side, bck = SIDES[kind]
+    rng = np.random.default_rng(1000 + level)
+    od, gd = _pair(dim, level, side)
+    L.go_poisson_coefficients(od.ptr)
+    gd.poisson_coefficients()
+    f = _rand_fields(od, gd, ["u", "rhs", "dia"], rng)
+    for use_dia in (False, True):
+        if use_dia:
+            a = np.abs(f["dia"][0].leaf()) + 0.5
+            f["dia"][0].leaf()[...] = a
+            f["dia"][1].upload(a)
+        else:
+            f["dia"][0].leaf()[...] = 0.
+            f["dia"][1].fill(0.)
+        for d in range(2 * dim):
+            f["u"][0].set_bc(d, bck)
+            f["u"][1].set_bc(d, bck)
+        for _ in range(2):
+            L.go_homogeneous_bc(f["u"][0].ptr, f["u"][0].ptr, level)
+            gd.homogeneous_bc(f["u"][1], f["u"][1])
+            L.go_relax(od.ptr, dim, level, 1., f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr)
+            gd.relax(f["u"][1], f["rhs"][1], f["dia"][1])
+            assert _faces_equal(f["u"][0].leaf(), f["u"][1].download(), dim), (use_dia,)
+
+
+def test_skew_sweep_equals_hyperplane_sweep_256():
+    """full size (256^3, 16x16 tiles): the pipelined sweep against the independent
+    one-launch-per-hyperplane implementation, bit for bit, over 3 sweeps"""
+    level, dim = 8, 3
+    n = 1 << level
+    rng = np.random.default_rng(8)
+    u0 = rng.standard_normal((n + 2,) * 3)
+    r0 = rng.standard_normal((n + 2,) * 3)
+    out = []
+    for mode in (gfship.RELAX_EXACT, gfship.RELAX_EXACT_HYPERPLANE):
+        gd = gfship.Domain(dim, level, [gfship.SIDE_PERIODIC] * 6)
+        gd.set_relax_mode(mode)
+        gd.poisson_coefficients()
+        u, rhs, dia = gd.variable(), gd.variable(), gd.variable()
+        u.upload(u0)
+        rhs.upload(r0)
+        for _ in range(3):
+            gd.homogeneous_bc(u, u)
+            gd.relax(u, rhs, dia)
+        out.append(u.download()[1:-1, 1:-1, 1:-1])
+        gd.destroy()
+    assert np.array_equal(out[0], out[1])
