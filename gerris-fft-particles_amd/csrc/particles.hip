@@ -1,0 +1,400 @@
+// particles.hip -- Lagrangian tracers on the device: GfsParticle in a GfsParticleList
+// (src/particle.c:31-44, modules/particulatecommon.c:955-1015,3058-3395).
+//
+// One thread per particle, SoA storage (x, y, z, old position, id, alive).  Each step:
+//   remove_particles_not_in_domain -> gfs_particle_event (RK2 midpoint through
+//   gfs_domain_advect_point, src/domain.c:2764-2788) -> gfs_particle_bc (ray march to the exit
+//   face, periodic wrap).
+// locate = ftt_cell_locate's descent with its strict '>' comparisons (src/ftt.c:1535-1574);
+// interpolate = gfs_interpolate: corner values are inverse-distance weighted means of the cells
+// sharing the corner (src/fluid.c:2983-3101), then the reference's 8-corner polynomial
+// (:2640-2683).  All in the reference's operand order: cell indices and positions are
+// bit-identical to the CPU algorithm.  The reference has no test for this path (parity pinned
+// on the oracle and on analytic properties only).
+#include "gfship_internal.hpp"
+#include <algorithm>
+#include <numeric>
+
+struct gfship_particles {
+  gfship_sim * sim = nullptr;
+  gfship_domain * dom = nullptr;
+  int n = 0;                   // slots (alive or not)
+  double * pos[3] = {}, * old[3] = {};
+  unsigned * id = nullptr;
+  unsigned char * alive = nullptr;
+  unsigned * d_count = nullptr;
+};
+
+namespace gfship {
+
+struct PartArgs {
+  Layout L;
+  int side[6];
+  int n;
+  double * pos[3];
+  double * old[3];
+  unsigned char * alive;
+  const double * u[3];
+  double dt;
+  unsigned * count;
+};
+
+// ftt_cell_locate on the unit box centred on the origin, leaf level
+template <int DIM>
+__device__ __forceinline__ bool locate (int depth, const double target[3], int ijk[3])
+{
+  double pos[3] = { 0., 0., 0. };
+  double size = 1./2.;
+#pragma unroll
+  for (int c = 0; c < DIM; c++)
+    if (target[c] > pos[c] + size || target[c] < pos[c] - size)
+      return false;
+  int q[3] = { 0, 0, 0 };
+  for (int l = 0; l < depth; l++) {
+    size /= 2.;
+#pragma unroll
+    for (int c = 0; c < DIM; c++) {
+      bool up = target[c] > pos[c];
+      q[c] = 2*q[c] + (up ? 1 : 0);
+      pos[c] += (up ? 1. : -1.)*size;
+    }
+  }
+  ijk[0] = q[0] + 1; ijk[1] = q[1] + 1; ijk[2] = DIM == 3 ? q[2] + 1 : 0;
+  return true;
+}
+
+// gfs_interpolate (src/fluid.c:2697-2710) of one variable at p inside cell (i,j,k)
+template <int DIM>
+__device__ double interpolate (const Layout & L, const double * __restrict__ v, const int cell[3],
+			       const double p_[3])
+{
+  const int n = L.n;
+  const double h = 1./n;
+  constexpr int NC = 4*(DIM - 1);
+  // the 3^DIM neighbourhood (edge/corner ghosts are allocated, never used)
+  double nb[DIM == 3 ? 27 : 9];
+  bool outm[3], outp[3];    // is cell - 1 / cell + 1 a ghost along each axis?
+#pragma unroll
+  for (int a = 0; a < DIM; a++) {
+    outm[a] = cell[a] - 1 < 1;
+    outp[a] = cell[a] + 1 > n;
+  }
+  const long base = L.idx (cell[0], cell[1], cell[2]);
+#pragma unroll
+  for (int dz = (DIM == 3 ? -1 : 0); dz <= (DIM == 3 ? 1 : 0); dz++)
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++)
+	nb[(dx + 1) + 3*(dy + 1) + 9*(DIM == 3 ? dz + 1 : 0)] = v[base + dx + dy*L.sy + dz*L.sz];
+
+  const double a_ = 1./(h*(DIM == 2 ? 0.707106781185 : 0.866025403785) + 1e-12);
+  // corner directions, src/fluid.c:2588-2605
+  const int c2[4][3] = { {-1,-1,0}, {1,-1,0}, {1,1,0}, {-1,1,0} };
+  const int c3[8][3] = { {-1,-1,1}, {1,-1,1}, {1,1,1}, {-1,1,1},
+			 {-1,-1,-1}, {1,-1,-1}, {1,1,-1}, {-1,1,-1} };
+  double f[NC + 1];
+#pragma unroll
+  for (int ic = 0; ic < NC; ic++) {
+    int sg[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) sg[a] = DIM == 2 ? c2[ic][a] : c3[ic][a];
+    // gfs_cell_corner_interpolator (src/fluid.c:2983-3068): cells n[m], m = 0..2^DIM-1, offset by
+    // (m&1) along x, (m&2) along y, (m&4) along z towards the corner
+    double wsum = 0., w0 = 0.;
+    int cnt = 0, boundaries = 0;
+    bool ex[1 << DIM];
+#pragma unroll
+    for (int m = 0; m < (1 << DIM); m++) {
+      int out = 0;
+#pragma unroll
+      for (int a = 0; a < DIM; a++)
+	if (m & (1 << a))
+	  out += (sg[a] < 0 ? outm[a] : outp[a]) ? 1 : 0;
+      ex[m] = out <= 1;
+      if (ex[m]) {
+	if (cnt == 0) w0 = a_;
+	cnt++;
+	wsum += a_;
+	if (out > 0) boundaries++;
+      }
+    }
+    bool skip0 = (cnt == DIM + 1 && boundaries == DIM);   // domain corner: drop the central cell
+    if (skip0)
+      wsum -= w0;
+    const double scale = 1./wsum;
+    double r = 0.;
+#pragma unroll
+    for (int m = 0; m < (1 << DIM); m++) {
+      int ox = (m & 1) ? sg[0] : 0, oy = (m & 2) ? sg[1] : 0, oz = (DIM == 3 && (m & 4)) ? sg[2] : 0;
+      double val = nb[(ox + 1) + 3*(oy + 1) + 9*(DIM == 3 ? oz + 1 : 0)];
+      if (ex[m] && !(skip0 && m == 0)) {
+	double wm = a_*scale;
+	r += wm*val;
+      }
+    }
+    f[ic] = r;
+  }
+  f[NC] = nb[1 + 3 + (DIM == 3 ? 9 : 0)];
+
+  // gfs_interpolate_from_corners, src/fluid.c:2640-2683
+  double o[3] = { -0.5 + (cell[0] - 0.5)*h, -0.5 + (cell[1] - 0.5)*h,
+		  DIM == 3 ? -0.5 + (cell[2] - 0.5)*h : 0. };
+  const double size = h/2.;
+  double p[3];
+  p[0] = (p_[0] - o[0])/size;
+  p[1] = (p_[1] - o[1])/size;
+  if (DIM == 2) {
+    double x = (p[0] + p[1])/2., y = (p[1] - p[0])/2., val = f[4];
+    if (x > 0.)
+      val += x*(f[2] - f[4]);
+    else
+      val -= x*(f[0] - f[4]);
+    if (y > 0.)
+      val += y*(f[3] - f[4]);
+    else
+      val -= y*(f[1] - f[4]);
+    return val;
+  }
+  p[2] = (p_[2] - o[2])/size;
+  double c[8];
+  c[0] = - f[0] + f[1] + f[2] - f[3] - f[4] + f[5] + f[6] - f[7];
+  c[1] = - f[0] - f[1] + f[2] + f[3] - f[4] - f[5] + f[6] + f[7];
+  c[2] =   f[0] + f[1] + f[2] + f[3] - f[4] - f[5] - f[6] - f[7];
+  c[3] =   f[0] - f[1] + f[2] - f[3] + f[4] - f[5] + f[6] - f[7];
+  c[4] = - f[0] + f[1] + f[2] - f[3] + f[4] - f[5] - f[6] + f[7];
+  c[5] = - f[0] - f[1] + f[2] + f[3] + f[4] + f[5] - f[6] - f[7];
+  c[6] =   f[0] - f[1] + f[2] - f[3] - f[4] + f[5] - f[6] + f[7];
+  c[7] =   f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7];
+  return (c[0]*p[0] + c[1]*p[1] + c[2]*p[2] +
+	  c[3]*p[0]*p[1] + c[4]*p[0]*p[2] + c[5]*p[1]*p[2] +
+	  c[6]*p[0]*p[1]*p[2] +
+	  c[7])/8.;
+}
+
+// check_intersetion, modules/particulatecommon.c:3058-3146
+template <int DIM>
+__device__ bool check_intersection (const double cellpos[3], const double p0[3], const double p1[3],
+				    int * dstore, double size)
+{
+  for (int d = 0; d < 2*DIM; d++) {
+    double normal = (double) (d ^ 1) - (double) d;
+    int c = d/2;
+    if ((p1[c] - p0[c]) != 0 && normal*(p1[c] - p0[c]) > 0) {
+      double t = (cellpos[c] + normal*size*0.5 - p0[c])/(p1[c] - p0[c]);
+      bool inside = true;
+      for (int a = 0; a < DIM; a++)
+	if (a != c) {
+	  double pa = p0[a] + t*(p1[a] - p0[a]);
+	  if (!((pa - cellpos[a] + size*0.5)*(pa - cellpos[a] - size*0.5) <= 0))
+	    inside = false;
+	}
+      if (inside && t*(t - 1) <= 0) {
+	*dstore = d;
+	return true;
+      }
+    }
+  }
+  return false;
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+particle_list_event_kernel (PartArgs A, int depth)
+{
+  int q = blockIdx.x*blockDim.x + threadIdx.x;
+  if (q >= A.n) return;
+  if (!A.alive[q]) return;
+  const int n = A.L.n;
+  const double h = 1./n;
+  double p[3] = { A.pos[0][q], A.pos[1][q], DIM == 3 ? A.pos[2][q] : 0. };
+  int cell[3];
+  // remove_particles_not_in_domain, modules/particulatecommon.c:955-969
+  if (!locate<DIM> (depth, p, cell)) {
+    A.alive[q] = 0;
+    return;
+  }
+  // gfs_particle_event (src/particle.c:31-44): pos_old = pos; gfs_domain_advect_point
+  double po[3] = { p[0], p[1], p[2] };
+  {
+    double p1[3] = { p[0], p[1], p[2] };
+#pragma unroll
+    for (int c = 0; c < DIM; c++)
+      p1[c] += A.dt*interpolate<DIM> (A.L, A.u[c], cell, po)/2.;
+    int cell1[3];
+    if (locate<DIM> (depth, p1, cell1)) {
+#pragma unroll
+      for (int c = 0; c < DIM; c++)
+	p[c] += A.dt*interpolate<DIM> (A.L, A.u[c], cell1, p1);
+    }
+  }
+  // gfs_particle_bc, modules/particulatecommon.c:3326-3395
+  int cn[3];
+  bool keep = true;
+  if (!locate<DIM> (depth, p, cn)) {
+    // boundarycell (:3149-3186): march from the cell of pos_old to the box side
+    int d = 0;
+    int cc[3] = { cell[0], cell[1], cell[2] };
+    for (int guard = 0; guard < 4*n; guard++) {
+      double cellpos[3] = { -0.5 + (cc[0] - 0.5)*h, -0.5 + (cc[1] - 0.5)*h,
+			    DIM == 3 ? -0.5 + (cc[2] - 0.5)*h : 0. };
+      check_intersection<DIM> (cellpos, po, p, &d, h);
+      int c = d/2, next = cc[c] + ((d & 1) ? -1 : 1);
+      if (next < 1 || next > n)
+	break;
+      cc[c] = next;
+    }
+    if (A.side[d] != GFSHIP_SIDE_PERIODIC)
+      keep = false;                 /* taken off the list, nothing puts it back */
+    else {
+      // periodic_bc_particle (:3189-3214), box of size 1 matching itself
+      double size = 1.;
+      double normal = (double) (d ^ 1) - (double) d;
+      double box_face = 0., box_face_nbr = 0.;
+      box_face += normal*size/2.;
+      box_face_nbr -= normal*size/2.;
+      double tolerance = size/1.e8;
+      double distance = (p[d/2] - box_face)*normal;
+      p[d/2] = box_face_nbr + distance + normal*tolerance;
+      po[d/2] = p[d/2];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < DIM; c++) {
+    A.pos[c][q] = p[c];
+    A.old[c][q] = po[c];
+  }
+  if (!keep)
+    A.alive[q] = 0;
+}
+
+__global__ void __launch_bounds__(256)
+count_alive_kernel (const unsigned char * alive, int n, unsigned * count)
+{
+  int q = blockIdx.x*blockDim.x + threadIdx.x;
+  unsigned long long m = __ballot (q < n && alive[q]);
+  if ((threadIdx.x & 63) == 0 && m)
+    atomicAdd (count, (unsigned) __popcll (m));
+}
+
+} // namespace gfship
+
+using namespace gfship;
+
+extern "C" {
+
+struct gfship_sim_view { gfship_domain * dom; const gfship_field * u; double dt; };
+gfship_sim_view gfship_sim_view_get (gfship_sim * s);   /* simulation.hip */
+
+int gfship_particles_create (gfship_particles ** out, gfship_sim * sim, int np,
+			     const double * pos, const unsigned * id)
+{
+  GFSHIP_CHECK (out && sim && (np == 0 || (pos && id)) && np >= 0, GFSHIP_EINVAL, "invalid argument");
+  *out = nullptr;
+  gfship_particles * pl = new gfship_particles;
+  pl->sim = sim;
+  pl->dom = gfship_sim_view_get (sim).dom;
+  pl->n = np;
+  size_t m = std::max (np, 1);
+  std::vector<double> tmp (m);
+  for (int c = 0; c < 3; c++) {
+    GFSHIP_HIP (hipMalloc ((void **) &pl->pos[c], m*sizeof (double)));
+    GFSHIP_HIP (hipMalloc ((void **) &pl->old[c], m*sizeof (double)));
+    for (int q = 0; q < np; q++) tmp[q] = pos[3*(size_t) q + c];
+    GFSHIP_HIP (hipMemcpy (pl->pos[c], tmp.data (), m*sizeof (double), hipMemcpyHostToDevice));
+    GFSHIP_HIP (hipMemcpy (pl->old[c], tmp.data (), m*sizeof (double), hipMemcpyHostToDevice));
+  }
+  GFSHIP_HIP (hipMalloc ((void **) &pl->id, m*sizeof (unsigned)));
+  if (np) GFSHIP_HIP (hipMemcpy (pl->id, id, np*sizeof (unsigned), hipMemcpyHostToDevice));
+  GFSHIP_HIP (hipMalloc ((void **) &pl->alive, m));
+  GFSHIP_HIP (hipMemset (pl->alive, 1, m));
+  GFSHIP_HIP (hipMalloc ((void **) &pl->d_count, sizeof (unsigned)));
+  *out = pl;
+  return GFSHIP_OK;
+}
+
+void gfship_particles_destroy (gfship_particles * pl)
+{
+  if (!pl) return;
+  (void) hipStreamSynchronize (pl->dom->stream);
+  for (int c = 0; c < 3; c++) {
+    if (pl->pos[c]) (void) hipFree (pl->pos[c]);
+    if (pl->old[c]) (void) hipFree (pl->old[c]);
+  }
+  if (pl->id) (void) hipFree (pl->id);
+  if (pl->alive) (void) hipFree (pl->alive);
+  if (pl->d_count) (void) hipFree (pl->d_count);
+  delete pl;
+}
+
+int gfship_particle_list_event (gfship_particles * pl)
+{
+  GFSHIP_CHECK (pl != nullptr, GFSHIP_EINVAL, "null particle list");
+  if (pl->n == 0) return GFSHIP_OK;
+  gfship_sim_view v = gfship_sim_view_get (pl->sim);
+  gfship_domain * dom = pl->dom;
+  PartArgs A;
+  A.L = dom->lay[dom->depth];
+  for (int d = 0; d < 6; d++) A.side[d] = dom->side[d];
+  A.n = pl->n;
+  for (int c = 0; c < 3; c++) {
+    A.pos[c] = pl->pos[c];
+    A.old[c] = pl->old[c];
+    A.u[c] = c < dom->dim ? dom->fields[v.u[c]].lev[dom->depth] : nullptr;
+  }
+  A.alive = pl->alive;
+  A.dt = v.dt;
+  A.count = pl->d_count;
+  int block = 256, grid = (pl->n + block - 1)/block;
+  if (dom->dim == 3)
+    hipLaunchKernelGGL (particle_list_event_kernel<3>, dim3 (grid), dim3 (block), 0, dom->stream,
+			A, dom->depth);
+  else
+    hipLaunchKernelGGL (particle_list_event_kernel<2>, dim3 (grid), dim3 (block), 0, dom->stream,
+			A, dom->depth);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+int gfship_particles_count (gfship_particles * pl)
+{
+  GFSHIP_CHECK (pl != nullptr, GFSHIP_EINVAL, "null particle list");
+  if (pl->n == 0) return 0;
+  gfship_domain * dom = pl->dom;
+  GFSHIP_HIP (hipMemsetAsync (pl->d_count, 0, sizeof (unsigned), dom->stream));
+  int block = 256, grid = (pl->n + block - 1)/block;
+  hipLaunchKernelGGL (count_alive_kernel, dim3 (grid), dim3 (block), 0, dom->stream,
+		      pl->alive, pl->n, pl->d_count);
+  unsigned c = 0;
+  GFSHIP_HIP (hipMemcpyAsync (&c, pl->d_count, sizeof (unsigned), hipMemcpyDeviceToHost, dom->stream));
+  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  return (int) c;
+}
+
+int gfship_particles_download (gfship_particles * pl, double * pos, unsigned * id)
+{
+  GFSHIP_CHECK (pl && pos && id, GFSHIP_EINVAL, "null argument");
+  if (pl->n == 0) return 0;
+  gfship_domain * dom = pl->dom;
+  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  size_t m = pl->n;
+  std::vector<double> x (m), y (m), z (m);
+  std::vector<unsigned> ids (m);
+  std::vector<unsigned char> al (m);
+  GFSHIP_HIP (hipMemcpy (x.data (), pl->pos[0], m*sizeof (double), hipMemcpyDeviceToHost));
+  GFSHIP_HIP (hipMemcpy (y.data (), pl->pos[1], m*sizeof (double), hipMemcpyDeviceToHost));
+  GFSHIP_HIP (hipMemcpy (z.data (), pl->pos[2], m*sizeof (double), hipMemcpyDeviceToHost));
+  GFSHIP_HIP (hipMemcpy (ids.data (), pl->id, m*sizeof (unsigned), hipMemcpyDeviceToHost));
+  GFSHIP_HIP (hipMemcpy (al.data (), pl->alive, m, hipMemcpyDeviceToHost));
+  int k = 0;
+  for (size_t q = 0; q < m; q++)
+    if (al[q]) {
+      pos[3*(size_t) k] = x[q]; pos[3*(size_t) k + 1] = y[q];
+      pos[3*(size_t) k + 2] = dom->dim == 3 ? z[q] : 0.;
+      id[k] = ids[q];
+      k++;
+    }
+  return k;
+}
+
+} // extern "C"

@@ -125,6 +125,14 @@ int advance_tracers (gfship_sim * s, double dt)
 
 extern "C" {
 
+/* internal view of a simulation for particles.hip */
+struct gfship_sim_view { gfship_domain * dom; const gfship_field * u; double dt; };
+gfship_sim_view gfship_sim_view_get (gfship_sim * s)
+{
+  gfship_sim_view v = { s->dom, s->u, s->advection_params.dt };
+  return v;
+}
+
 int gfship_sim_create (gfship_sim ** out, gfship_domain * dom)
 {
   GFSHIP_CHECK (out && dom, GFSHIP_EINVAL, "null argument");

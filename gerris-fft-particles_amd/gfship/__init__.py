@@ -96,6 +96,11 @@ SIGNATURES = {
     "gfship_coarse_init": (_i, [_vp]),
     "gfship_divergence_norm": (_i, [_vp, C.POINTER(Norm)]),
     "gfship_sim_download_un": (_i, [_vp, _i, _pd]),
+    "gfship_particles_create": (_i, [C.POINTER(_vp), _vp, _i, _pd, C.POINTER(C.c_uint)]),
+    "gfship_particles_destroy": (None, [_vp]),
+    "gfship_particle_list_event": (_i, [_vp]),
+    "gfship_particles_count": (_i, [_vp]),
+    "gfship_particles_download": (_i, [_vp, _pd, C.POINTER(C.c_uint)]),
 }
 
 
@@ -329,3 +334,35 @@ class Simulation:
                 self.destroy()
         except Exception:
             pass
+
+
+class ParticleList:
+    """GfsParticleList of GfsParticle tracers on the device."""
+
+    def __init__(self, sim, pos, ids):
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        assert len(pos) == len(ids)
+        self.sim, self.n0 = sim, len(ids)
+        p = _vp()
+        _check(lib().gfship_particles_create(C.byref(p), sim.ptr, len(ids), pos.ctypes.data_as(_pd),
+                                             ids.ctypes.data_as(C.POINTER(C.c_uint))))
+        self.ptr = p
+
+    def event(self):
+        _check(lib().gfship_particle_list_event(self.ptr))
+
+    def count(self):
+        return _check(lib().gfship_particles_count(self.ptr))
+
+    def download(self):
+        pos = np.empty((self.n0, 3))
+        ids = np.empty(self.n0, dtype=np.uint32)
+        k = _check(lib().gfship_particles_download(self.ptr, pos.ctypes.data_as(_pd),
+                                                   ids.ctypes.data_as(C.POINTER(C.c_uint))))
+        return pos[:k].copy(), ids[:k].copy()
+
+    def destroy(self):
+        if self.ptr:
+            lib().gfship_particles_destroy(self.ptr)
+            self.ptr = None

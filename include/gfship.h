@@ -179,6 +179,24 @@ int  gfship_divergence_norm (gfship_sim * sim, gfship_norm * out);
    convention: entry (i,j,k) is the face on the + side of cell (i,j,k) (0 <= i <= n along c) */
 int  gfship_sim_download_un (gfship_sim * sim, int c, double * host);
 
+/* ---- Lagrangian tracers (src/particle.c, modules/particulatecommon.c) ------------------------ */
+
+typedef struct gfship_particles gfship_particles;   /* GfsParticleList of GfsParticle */
+
+/* GfsParticleList read (modules/particulatecommon.c:1022-1093): np particles, pos = 3*np doubles
+   (x y z per particle, z ignored in 2-D), id = np unsigned (src/particle.c:46-99 text format) */
+int  gfship_particles_create (gfship_particles ** pl, gfship_sim * sim, int np,
+			      const double * pos, const unsigned * id);
+void gfship_particles_destroy (gfship_particles * pl);
+/* gfs_particle_list_event (modules/particulatecommon.c:980-1015) without forces: drop particles
+   outside the domain, RK2-advect each with the simulation's current velocity and dt
+   (gfs_particle_event src/particle.c:31-44 -> gfs_domain_advect_point src/domain.c:2764-2788),
+   then gfs_particle_bc (:3375-3395, periodic wrap :3189-3214) */
+int  gfship_particle_list_event (gfship_particles * pl);
+int  gfship_particles_count (gfship_particles * pl);
+/* positions and ids of the particles still on the list, in list order; returns their number */
+int  gfship_particles_download (gfship_particles * pl, double * pos, unsigned * id);
+
 /* ---- instrumentation -------------------------------------------------------------------- */
 
 /* time (HIP events on the domain's stream) of `reps` back-to-back sweeps of gfship_relax on

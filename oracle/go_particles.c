@@ -1,0 +1,306 @@
+/* go_particles.c -- oracle: Lagrangian tracers (GfsParticle in a GfsParticleList).
+ * TEST INFRASTRUCTURE ONLY (see gfs_oracle.h).
+ *
+ * Follows src/particle.c:31-44 (gfs_particle_event), src/domain.c:2623-2638,2764-2788
+ * (gfs_domain_locate, gfs_domain_advect_point), src/ftt.c:1535-1574 (ftt_cell_locate),
+ * src/fluid.c:2596-2710,2938-3101 (corner interpolation) and
+ * modules/particulatecommon.c:955-1015,3058-3395 (list event, ray march to the exit face,
+ * periodic wrap).  The reference holds no test or golden data for any of this: parity of this
+ * file is UNPINNED by the reference; it is pinned only by analytic properties (tests/). */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <assert.h>
+#include "gfs_oracle.h"
+#include "go_sim.h"
+#include "go_particles.h"
+
+/* ftt_cell_locate on the box root (unit box centred on the origin), max_depth = -1:
+ * returns 0 if outside, else fills the 1-based cell coordinates of the leaf */
+int go_locate (const GoDomain * dom, const double target[3], int ijk[3])
+{
+  int dim = dom->dim, L = dom->depth;
+  double pos[3] = { 0., 0., 0. };
+  double size = 1./2.;
+  for (int c = 0; c < dim; c++)
+    if (target[c] > pos[c] + size || target[c] < pos[c] - size)
+      return 0;
+  int q[3] = { 0, 0, 0 }; /* 0-based coordinates while descending */
+  for (int l = 0; l < L; l++) {
+    /* index[z > pz][y > py][x > px] = {{{6,7},{4,5}},{{2,3},{0,1}}}: child id bit0 = x > px,
+       bit1 = !(y > py), bit2 = !(z > pz); coords[n] = (+-1, -+1, -+1) (ftt.c:301-316) */
+    size /= 2.;
+    for (int c = 0; c < dim; c++) {
+      int up = target[c] > pos[c];
+      q[c] = 2*q[c] + up;
+      pos[c] += (up ? 1. : -1.)*size;
+    }
+  }
+  for (int c = 0; c < 3; c++)
+    ijk[c] = c < dim ? q[c] + 1 : 0;
+  return 1;
+}
+
+/* does the cell (ci,cj,ck) (coordinates in 0..n+1) exist?  Interior cells and the one-cell ghost
+ * layer of each side exist; edge and corner ghosts do not (the boundary trees of the reference are
+ * flattened against one box side, boundary.c:576-685) */
+static int cell_exists (int n, int dim, const int c[3], int * is_boundary)
+{
+  int out = 0;
+  for (int a = 0; a < dim; a++)
+    if (c[a] < 1 || c[a] > n) {
+      if (c[a] < 0 || c[a] > n + 1) return 0;
+      out++;
+    }
+  *is_boundary = out > 0;
+  return out <= 1;
+}
+
+/* gfs_cell_corner_value (fluid.c:3081-3101) with gfs_cell_corner_interpolator (:2983-3068) on a
+ * uniform grid: the cells sharing the corner are n[m] = cell + (m&1) d0 + (m&2) d1 + (m&4) d2
+ * (path table :2938-2954), weights 1/(distance + 1e-12) normalised, domain corners lose the
+ * central cell. sgn[c] = +1/-1: direction of the corner along axis c. */
+static double corner_value (const GoDomain * dom, const double * v, const int cell[3],
+			    const int sgn[3])
+{
+  int dim = dom->dim, L = dom->depth, n = dom->n[L];
+  int ncells = 1 << dim;
+  double h = 1./n;
+  double w[8], val[8];
+  int cnt = 0, boundaries = 0;
+  double wsum = 0.;
+  for (int m = 0; m < ncells; m++) {
+    int c[3] = { cell[0], cell[1], cell[2] };
+    for (int a = 0; a < dim; a++)
+      if (m & (1 << a)) c[a] += sgn[a];
+    int isb;
+    if (!cell_exists (n, dim, c, &isb))
+      continue;
+    double dist = h*(dim == 2 ? 0.707106781185 : 0.866025403785);
+    double a_ = 1./(dist + 1e-12);
+    w[cnt] = a_;
+    val[cnt] = v[go_index (dom, L, c[0], c[1], dim == 3 ? c[2] : 0)];
+    cnt++;
+    wsum += a_;
+    if (isb) boundaries++;
+  }
+  int first = 0;
+  if (cnt == dim + 1 && boundaries == dim) {
+    /* remove central cell from interpolator */
+    wsum -= w[0];
+    first = 1;
+  }
+  double scale = 1./wsum;
+  double r = 0.;
+  for (int m = first; m < cnt; m++) {
+    double wm = w[m]*scale;
+    r += wm*val[m];
+  }
+  return r;
+}
+
+/* gfs_interpolate (fluid.c:2697-2710) = gfs_cell_corner_values (:2617-2631) +
+ * gfs_interpolate_from_corners (:2640-2683) */
+double go_interpolate (const GoDomain * dom, const double * v, const int cell[3], const double p_[3])
+{
+  int dim = dom->dim, L = dom->depth;
+  double f[9];
+  /* corner[] tables, fluid.c:2588-2605 */
+  static const int c2[4][3] = { {-1,-1,0}, {1,-1,0}, {1,1,0}, {-1,1,0} };
+  static const int c3[8][3] = { {-1,-1,1}, {1,-1,1}, {1,1,1}, {-1,1,1},
+				{-1,-1,-1}, {1,-1,-1}, {1,1,-1}, {-1,1,-1} };
+  int nc = 4*(dim - 1);
+  for (int i = 0; i < nc; i++)
+    f[i] = corner_value (dom, v, cell, dim == 2 ? c2[i] : c3[i]);
+  f[nc] = v[go_index (dom, L, cell[0], cell[1], dim == 3 ? cell[2] : 0)];
+
+  double o[3];
+  go_cell_pos (dom, L, cell[0], cell[1], cell[2], o);
+  double size = (1./dom->n[L])/2.;
+  double p[3];
+  p[0] = (p_[0] - o[0])/size;
+  p[1] = (p_[1] - o[1])/size;
+  if (dim == 2) {
+    double x = (p[0] + p[1])/2., y = (p[1] - p[0])/2., val = f[4];
+    if (x > 0.)
+      val += x*(f[2] - f[4]);
+    else
+      val -= x*(f[0] - f[4]);
+    if (y > 0.)
+      val += y*(f[3] - f[4]);
+    else
+      val -= y*(f[1] - f[4]);
+    return val;
+  }
+  double c[8];
+  p[2] = (p_[2] - o[2])/size;
+  c[0] = - f[0] + f[1] + f[2] - f[3] - f[4] + f[5] + f[6] - f[7];
+  c[1] = - f[0] - f[1] + f[2] + f[3] - f[4] - f[5] + f[6] + f[7];
+  c[2] =   f[0] + f[1] + f[2] + f[3] - f[4] - f[5] - f[6] - f[7];
+  c[3] =   f[0] - f[1] + f[2] - f[3] + f[4] - f[5] + f[6] - f[7];
+  c[4] = - f[0] + f[1] + f[2] - f[3] + f[4] - f[5] - f[6] + f[7];
+  c[5] = - f[0] - f[1] + f[2] + f[3] + f[4] + f[5] - f[6] - f[7];
+  c[6] =   f[0] - f[1] + f[2] - f[3] - f[4] + f[5] - f[6] + f[7];
+  c[7] =   f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7];
+  return (c[0]*p[0] + c[1]*p[1] + c[2]*p[2] +
+	  c[3]*p[0]*p[1] + c[4]*p[0]*p[2] + c[5]*p[1]*p[2] +
+	  c[6]*p[0]*p[1]*p[2] +
+	  c[7])/8.;
+}
+
+/* gfs_domain_advect_point, domain.c:2764-2788 */
+void go_advect_point (GoSim * s, double p[3], double dt)
+{
+  GoDomain * dom = s->dom;
+  int dim = dom->dim, L = dom->depth;
+  double p0[3] = { p[0], p[1], p[2] }, p1[3] = { p[0], p[1], p[2] };
+  int cell[3];
+  if (!go_locate (dom, p0, cell))
+    return;
+  for (int c = 0; c < dim; c++)
+    p1[c] += dt*go_interpolate (dom, s->u[c]->lev[L], cell, p0)/2.;
+  if (!go_locate (dom, p1, cell))
+    return;
+  for (int c = 0; c < dim; c++)
+    p[c] += dt*go_interpolate (dom, s->u[c]->lev[L], cell, p1);
+}
+
+/* check_intersetion, particulatecommon.c:3058-3146: first direction d whose face of the cell
+ * (centre cellpos, size) is crossed by the segment p0 -> p1 */
+static int check_intersection (int dim, const double cellpos[3], const double p0[3],
+			       const double p1[3], int * dstore, double size)
+{
+  for (int d = 0; d < 2*dim; d++) {
+    double normal = (double) (d ^ 1) - (double) d;
+    int c = d/2;
+    if ((p1[c] - p0[c]) != 0 && normal*(p1[c] - p0[c]) > 0) {
+      double t = (cellpos[c] + normal*size*0.5 - p0[c])/(p1[c] - p0[c]);
+      int inside = 1;
+      for (int a = 0; a < dim; a++)
+	if (a != c) {
+	  double pa = p0[a] + t*(p1[a] - p0[a]);
+	  if (!((pa - cellpos[a] + size*0.5)*(pa - cellpos[a] - size*0.5) <= 0))
+	    inside = 0;
+	}
+      if (inside && t*(t - 1) <= 0) {
+	*dstore = d;
+	return 1;
+      }
+    }
+  }
+  return 0; /* "Intersection finding algorithm failed": dstore is left as it was */
+}
+
+/* boundarycell, particulatecommon.c:3149-3186: march from the cell of pos_old along the path
+ * until the next cell would be a boundary (ghost) cell; returns the exit direction */
+static int boundary_direction (const GoDomain * dom, const double pos_old[3], const double pos[3])
+{
+  int dim = dom->dim, L = dom->depth, n = dom->n[L];
+  double size = 1./n;
+  int cell[3];
+  int ok = go_locate (dom, pos_old, cell);
+  assert (ok);
+  int d = 0; /* uninitialised in the reference when the search fails; 0 here */
+  for (int guard = 0; guard < 4*n; guard++) {
+    double cellpos[3];
+    go_cell_pos (dom, L, cell[0], cell[1], cell[2], cellpos);
+    check_intersection (dim, cellpos, pos_old, pos, &d, size);
+    int c = d/2, step = (d & 1) ? -1 : 1;
+    int next = cell[c] + step;
+    if (next < 1 || next > n)
+      return d; /* neighbour is a boundary cell */
+    cell[c] = next;
+  }
+  return d;
+}
+
+GoParticles * go_particles_new (int np, const double * pos, const unsigned * id)
+{
+  GoParticles * pl = calloc (1, sizeof (GoParticles));
+  pl->n = np;
+  pl->pos = malloc (3*(size_t) np*sizeof (double));
+  pl->pos_old = malloc (3*(size_t) np*sizeof (double));
+  pl->id = malloc ((size_t) np*sizeof (unsigned));
+  memcpy (pl->pos, pos, 3*(size_t) np*sizeof (double));
+  memcpy (pl->pos_old, pos, 3*(size_t) np*sizeof (double));
+  memcpy (pl->id, id, (size_t) np*sizeof (unsigned));
+  return pl;
+}
+
+void go_particles_destroy (GoParticles * pl)
+{
+  if (!pl) return;
+  free (pl->pos); free (pl->pos_old); free (pl->id);
+  free (pl);
+}
+
+int go_particles_count (const GoParticles * pl) { return pl->n; }
+double * go_particles_pos (GoParticles * pl) { return pl->pos; }
+unsigned * go_particles_id (GoParticles * pl) { return pl->id; }
+
+/* gfs_particle_list_event, particulatecommon.c:980-1015 (no forces):
+ *   remove_particles_not_in_domain (:955-969)
+ *   every particle: gfs_particle_event (src/particle.c:31-44)
+ *   gfs_particle_bc (:3375-3395): particles that left the box are wrapped through the periodic
+ *   side they crossed (periodic_bc_particle :3189-3214); on non-periodic sides they stay where
+ *   they are and are removed at the next event. */
+void go_particle_list_event (GoSim * s, GoParticles * pl)
+{
+  GoDomain * dom = s->dom;
+  double dt = s->advection_params.dt;
+  int cell[3];
+  /* remove particles not in domain (order of the survivors kept) */
+  int m = 0;
+  for (int q = 0; q < pl->n; q++)
+    if (go_locate (dom, pl->pos + 3*q, cell)) {
+      if (m != q) {
+	memcpy (pl->pos + 3*m, pl->pos + 3*q, 3*sizeof (double));
+	memcpy (pl->pos_old + 3*m, pl->pos_old + 3*q, 3*sizeof (double));
+	pl->id[m] = pl->id[q];
+      }
+      m++;
+    }
+  pl->n = m;
+  for (int q = 0; q < pl->n; q++) {
+    double * p = pl->pos + 3*q, * po = pl->pos_old + 3*q;
+    double pos[3] = { p[0], p[1], p[2] };
+    po[0] = p[0]; po[1] = p[1]; po[2] = p[2];
+    go_advect_point (s, pos, dt);
+    p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
+  }
+  /* boundary conditions: a particle that left the box is taken off the list
+     (list_boundary_particles :3326-3359) and only a periodic side puts it back */
+  char * drop = calloc (pl->n + 1, 1);
+  for (int q = 0; q < pl->n; q++) {
+    double * p = pl->pos + 3*q, * po = pl->pos_old + 3*q;
+    if (go_locate (dom, p, cell))
+      continue;
+    int d = boundary_direction (dom, po, p);
+    if (dom->side[d] != GO_SIDE_PERIODIC)
+      drop[q] = 1;
+    else {
+      /* periodic_bc_particle: box of size 1 centred on the origin, matching box = itself */
+      double size = 1.;
+      double normal = (double) (d ^ 1) - (double) d;
+      double box_face = 0., box_face_nbr = 0.;
+      box_face += normal*size/2.;
+      box_face_nbr -= normal*size/2.;
+      double tolerance = size/1.e8;
+      double distance = (p[d/2] - box_face)*normal;
+      p[d/2] = box_face_nbr + distance + normal*tolerance;
+      po[d/2] = p[d/2];
+    }
+  }
+  m = 0;
+  for (int q = 0; q < pl->n; q++)
+    if (!drop[q]) {
+      if (m != q) {
+	memcpy (pl->pos + 3*m, pl->pos + 3*q, 3*sizeof (double));
+	memcpy (pl->pos_old + 3*m, pl->pos_old + 3*q, 3*sizeof (double));
+	pl->id[m] = pl->id[q];
+      }
+      m++;
+    }
+  pl->n = m;
+  free (drop);
+}

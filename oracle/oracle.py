@@ -272,3 +272,56 @@ class Sim:
             lib().go_sim_destroy(self.ptr)
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------
+# GfsParticleList (oracle/go_particles.c)
+# ---------------------------------------------------------------------------------------------
+
+class Particles:
+    def __init__(self, sim, pos, ids):
+        L = lib()
+        if not getattr(L, "_part_ready", False):
+            vp, i = C.c_void_p, C.c_int
+            pd, pu = C.POINTER(C.c_double), C.POINTER(C.c_uint)
+            for name, (res, args) in {
+                "go_particles_new": (vp, [i, pd, pu]),
+                "go_particles_destroy": (None, [vp]),
+                "go_particles_count": (i, [vp]),
+                "go_particles_pos": (pd, [vp]),
+                "go_particles_id": (pu, [vp]),
+                "go_particle_list_event": (None, [vp, vp]),
+                "go_locate": (i, [vp, pd, C.POINTER(C.c_int)]),
+            }.items():
+                f = getattr(L, name)
+                f.restype, f.argtypes = res, args
+            L._part_ready = True
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        self.sim = sim
+        self.ptr = L.go_particles_new(len(ids), pos.ctypes.data_as(C.POINTER(C.c_double)),
+                                      ids.ctypes.data_as(C.POINTER(C.c_uint)))
+
+    def event(self):
+        lib().go_particle_list_event(self.sim.ptr, self.ptr)
+
+    def count(self):
+        return lib().go_particles_count(self.ptr)
+
+    def state(self):
+        n = self.count()
+        pos = np.ctypeslib.as_array(lib().go_particles_pos(self.ptr), shape=(max(n, 1), 3))[:n].copy()
+        ids = np.ctypeslib.as_array(lib().go_particles_id(self.ptr), shape=(max(n, 1),))[:n].copy()
+        return pos, ids
+
+    def locate(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        ijk = (C.c_int * 3)()
+        ok = lib().go_locate(self.sim.dom.ptr, p.ctypes.data_as(C.POINTER(C.c_double)), ijk)
+        return tuple(ijk) if ok else None
+
+    def __del__(self):
+        try:
+            lib().go_particles_destroy(self.ptr)
+        except Exception:
+            pass
