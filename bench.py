@@ -86,7 +86,16 @@ def main():
 
     import gfship
     n = 1 << args.level
-    dom = gfship.Domain(3, args.level, [gfship.SIDE_PERIODIC] * 6, device=local_rank)
+    hooks = None
+    if world > 1:
+        # one 256^3 GfsBox per GPU on a periodic lattice of boxes (2x1x1, 2x2x1, 2x2x2): the sides
+        # with a neighbour box are GfsBoundaryMpi sides served over RCCL (gfship/distributed.py)
+        from gfship import distributed as D
+        grid = D.BoxGrid(world, 3)
+        dom = gfship.Domain(3, args.level, grid.sides(rank), device=local_rank)
+        hooks = D.DeviceHooks(dom, D.Transport(grid, rank, torch.device("cuda", local_rank)))
+    else:
+        dom = gfship.Domain(3, args.level, [gfship.SIDE_PERIODIC] * 6, device=local_rank)
     if args.mode == "redblack":
         dom.set_relax_mode(gfship.RELAX_REDBLACK)
     sim = gfship.Simulation(dom)
@@ -141,7 +150,9 @@ def main():
                                    "projection/advection parameters (SURVEY 8d config C)" % n,
                        "relax_mode": args.mode,
                        "parallelism": "1 box" if world == 1 else
-                                      "%d independent boxes (replicas)" % world,
+                                      "%d boxes of %d^3, lattice %s, one per GPU, halo exchange "
+                                      "over RCCL p2p (reference semantics: overlap = 0)"
+                                      % (world, n, "x".join(map(str, grid.b))),
                        "poisson_niter": [int(sim.projection_params.niter),
                                          int(sim.approx_projection_params.niter)]},
             "roofline": roofline,

@@ -71,7 +71,90 @@ int launch_bc (gfship_domain * dom, Field * v, Field * v1, int level, int homoge
   dim3 grid ((nface + block - 1)/block, 2*dom->dim);
   hipLaunchKernelGGL (bc_kernel, grid, dim3 (block), 0, dom->stream, L, bc, v1->lev[level]);
   GFSHIP_HIP (hipGetLastError ());
+  /* GfsBoundaryMpi sides: ghost layer from the neighbour boxes */
+  return call_exchange (dom, v1->lev[level], level, 0);
+}
+
+int call_exchange (gfship_domain * dom, double * ptr, int level, int kind)
+{
+  if (!dom->has_external)
+    return GFSHIP_OK;
+  GFSHIP_CHECK (dom->exchange != nullptr, GFSHIP_EINVAL,
+		"the domain has GFSHIP_SIDE_EXTERNAL sides but no exchange hook "
+		"(gfship_domain_set_exchange)");
+  int r = (* dom->exchange) (dom->exchange_ctx, ptr, level, kind);
+  GFSHIP_CHECK (r == 0, GFSHIP_EHIP, "the exchange hook failed (%d)", r);
   return GFSHIP_OK;
 }
+
+int call_reduce (gfship_domain * dom, double * vals, int n, int op)
+{
+  if (!dom->has_external)
+    return GFSHIP_OK;
+  GFSHIP_CHECK (dom->reduce != nullptr, GFSHIP_EINVAL,
+		"the domain has GFSHIP_SIDE_EXTERNAL sides but no reduce hook "
+		"(gfship_domain_set_reduce)");
+  int r = (* dom->reduce) (dom->reduce_ctx, vals, n, op);
+  GFSHIP_CHECK (r == 0, GFSHIP_EHIP, "the reduce hook failed (%d)", r);
+  return GFSHIP_OK;
+}
+
+// sndbuf / rcvbuf of the periodic and MPI boundaries (src/boundary.c:1240-1258,1333-1347):
+// interior layer of `side` -> contiguous buffer, buffer -> ghost layer of `side`
+__global__ void __launch_bounds__(256)
+halo_copy_kernel (Layout L, int side, double * __restrict__ a, double * __restrict__ buf, int unpack)
+{
+  const int n = L.n;
+  const int nface = L.dim == 3 ? n*n : n;
+  int f = blockIdx.x*blockDim.x + threadIdx.x;
+  if (f >= nface) return;
+  int c = side/2;
+  int t1 = f % n + 1, t2 = L.dim == 3 ? f / n + 1 : 0;
+  int ijk[3] = { 0, 0, 0 };
+  int ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
+  ijk[c] = (side & 1) ? 1 : n;
+  ijk[ta] = t1;
+  if (L.dim == 3) ijk[tb] = t2;
+  long o = c == 0 ? 1 : c == 1 ? L.sy : L.sz;
+  if (side & 1) o = - o;
+  long nb = L.idx (ijk[0], ijk[1], ijk[2]);
+  if (unpack)
+    a[nb + o] = buf[f];
+  else
+    buf[f] = a[nb];
+}
+
+static int halo_copy (gfship_domain * dom, double * a, int level, int side, double * buf, int unpack)
+{
+  GFSHIP_CHECK (dom && a && buf, GFSHIP_EINVAL, "null argument");
+  GFSHIP_CHECK (level >= 0 && level <= dom->depth, GFSHIP_EINVAL, "level %d out of range", level);
+  GFSHIP_CHECK (side >= 0 && side < 2*dom->dim, GFSHIP_EINVAL, "side %d out of range", side);
+  const Layout & L = dom->lay[level];
+  int nface = dom->dim == 3 ? L.n*L.n : L.n;
+  int block = nface >= 256 ? 256 : 64;
+  hipLaunchKernelGGL (halo_copy_kernel, dim3 ((nface + block - 1)/block), dim3 (block), 0, dom->stream,
+		      L, side, a, buf, unpack);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+} // namespace gfship
+
+extern "C" {
+
+int gfship_halo_pack (gfship_domain * dom, const void * dev_ptr, int level, int side, void * dev_buf)
+{
+  return gfship::halo_copy (dom, (double *) dev_ptr, level, side, (double *) dev_buf, 0);
+}
+
+int gfship_halo_unpack (gfship_domain * dom, void * dev_ptr, int level, int side, const void * dev_buf)
+{
+  return gfship::halo_copy (dom, (double *) dev_ptr, level, side, (double *) dev_buf, 1);
+}
+
+} // extern "C"
+
+namespace gfship {
+
 
 } // namespace gfship

@@ -78,6 +78,9 @@ int gfship_domain_create (gfship_domain ** out, int dim, int depth, const int si
       set_error ("periodic sides must come in pairs (directions %d,%d)", d, d + 1);
       return GFSHIP_EINVAL;
     }
+  for (int d = 0; d < 2*dim; d++)
+    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL)
+      dom->has_external = true;
   for (int l = 0; l <= depth; l++) {
     Layout & L = dom->lay[l];
     L.n = 1 << l;
@@ -128,6 +131,22 @@ int gfship_domain_set_relax_mode (gfship_domain * dom, int mode)
 		mode == GFSHIP_RELAX_EXACT_HYPERPLANE, GFSHIP_EINVAL, "unknown relax mode %d", mode);
   dom->force_hyperplane = (mode == GFSHIP_RELAX_EXACT_HYPERPLANE);
   dom->relax_mode = mode == GFSHIP_RELAX_REDBLACK ? GFSHIP_RELAX_REDBLACK : GFSHIP_RELAX_EXACT;
+  return GFSHIP_OK;
+}
+
+int gfship_domain_set_exchange (gfship_domain * dom, gfship_exchange_fn fn, void * ctx)
+{
+  GFSHIP_CHECK (dom != nullptr, GFSHIP_EINVAL, "null domain");
+  dom->exchange = fn;
+  dom->exchange_ctx = ctx;
+  return GFSHIP_OK;
+}
+
+int gfship_domain_set_reduce (gfship_domain * dom, gfship_reduce_fn fn, void * ctx)
+{
+  GFSHIP_CHECK (dom != nullptr, GFSHIP_EINVAL, "null domain");
+  dom->reduce = fn;
+  dom->reduce_ctx = ctx;
   return GFSHIP_OK;
 }
 

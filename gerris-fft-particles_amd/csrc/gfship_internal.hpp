@@ -73,6 +73,9 @@ struct gfship_domain {
   double * d_scratch = nullptr;   // reduction scratch
   size_t scratch_doubles = 0;
   double * h_pinned = nullptr;    // pinned host buffer for small read-backs
+  gfship_exchange_fn exchange = nullptr; void * exchange_ctx = nullptr;  // GfsBoundaryMpi hooks
+  gfship_reduce_fn reduce = nullptr;     void * reduce_ctx = nullptr;
+  bool has_external = false;
   gfship_field dp_cache = -1;     // the `dp` temporary of gfs_poisson_cycle, kept between cycles
   bool force_hyperplane = false;  // debug/bench: per-hyperplane launches instead of relax_skew
   bool unit_weights = false;      // gfship_poisson_coefficients called with alpha = NULL
@@ -97,6 +100,8 @@ inline long ncells (const Layout & L) {
 
 // kernels launchers (poisson_kernels.hip, bc.hip)
 int launch_bc (gfship_domain * dom, Field * v, Field * v1, int level, int homogeneous);
+int call_exchange (gfship_domain * dom, double * ptr, int level, int kind);
+int call_reduce (gfship_domain * dom, double * vals, int n, int op);
 int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, double omega,
 			double * u, const double * rhs, const double * dia);
 int launch_relax_loop_small (gfship_domain * dom, unsigned dimension, int level, double omega,

@@ -61,6 +61,14 @@ static int norm_residual (gfship_domain * dom, double dt, Field * res, gfship_no
   int r = launch_norm (dom, dom->depth, res->lev[dom->depth], 1.*size*size, 1., s);
   if (r) return r;
   double w = (double) ncells (L);
+  if (dom->has_external) {
+    /* domain_norm_reduce + gfs_all_reduce (bias), src/domain.c:2135-2166,2279 */
+    double sums[4] = { s[0], s[1], s[2], w }, mx[1] = { s[3] }, raw[1] = { s[4] };
+    if ((r = call_reduce (dom, sums, 4, 0))) return r;
+    if ((r = call_reduce (dom, mx, 1, 1))) return r;
+    if ((r = call_reduce (dom, raw, 1, 0))) return r;
+    s[0] = sums[0]; s[1] = sums[1]; s[2] = sums[2]; w = sums[3]; s[3] = mx[0]; s[4] = raw[0];
+  }
   gfship_norm n;
   n.bias = s[0]; n.first = s[1]; n.second = s[2]; n.infty = s[3]; n.w = w;
   if (n.w > 0.) {
@@ -153,8 +161,15 @@ int gfship_norm_variable (gfship_domain * dom, gfship_field v, gfship_norm * out
   int r = launch_norm (dom, dom->depth, V->lev[dom->depth], 1., vol, s);
   if (r) return r;
   gfship_norm n;
+  double wv = vol*(double) ncells (L);
+  if (dom->has_external) {
+    double sums[4] = { s[0], s[1], s[2], wv }, mx[1] = { s[3] };
+    if ((r = call_reduce (dom, sums, 4, 0))) return r;
+    if ((r = call_reduce (dom, mx, 1, 1))) return r;
+    s[0] = sums[0]; s[1] = sums[1]; s[2] = sums[2]; wv = sums[3]; s[3] = mx[0];
+  }
   n.bias = s[0]; n.first = s[1]; n.second = s[2]; n.infty = s[3];
-  n.w = vol*(double) ncells (L);
+  n.w = wv;
   if (n.w > 0.) {
     n.bias /= n.w;
     n.first /= n.w;

@@ -369,8 +369,8 @@ bool skew_supported (const gfship_domain * dom, int level)
   if (dom->dim != 3) return false;
   int n = dom->lay[level].n;
   if (n < 2*SK_T) return false;          /* smaller levels run the LDS relax loop */
-  for (int d = 0; d < 6; d++)
-    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL) return false;
+  /* GFSHIP_SIDE_EXTERNAL sides are fine: with the reference's `overlap = 0` order their ghost
+     cells are frozen during a sweep like any other ghost cell */
   return true;
 }
 

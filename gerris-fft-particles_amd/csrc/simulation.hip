@@ -137,9 +137,6 @@ int gfship_sim_create (gfship_sim ** out, gfship_domain * dom)
 {
   GFSHIP_CHECK (out && dom, GFSHIP_EINVAL, "null argument");
   *out = nullptr;
-  for (int d = 0; d < 2*dom->dim; d++)
-    GFSHIP_CHECK (dom->side[d] != GFSHIP_SIDE_EXTERNAL, GFSHIP_EUNSUPPORTED,
-		  "the time step does not handle GfsBoundaryMpi sides yet");
   gfship_sim * s = new gfship_sim;
   s->dom = dom;
   auto alloc = [&] (int comp) { return gfship_field_alloc (dom, comp); };

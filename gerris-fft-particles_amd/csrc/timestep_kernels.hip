@@ -569,6 +569,13 @@ int launch_face_bc (gfship_domain * dom, Field * v, double * const fv[6])
   dim3 grid ((nface + block - 1)/block, 2*dom->dim);
   DISPATCH (dom, face_bc_kernel, grid, dim3 (block), L, bc, (const double *) v->lev[dom->depth],
 	    m6 (fv));
+  /* GfsBoundaryMpi sides: ghost face values fv[e] beyond side e^1 come from the neighbour box */
+  if (dom->has_external)
+    for (int e = 0; e < 2*dom->dim; e++)
+      if (dom->side[e ^ 1] == GFSHIP_SIDE_EXTERNAL) {
+	int r = call_exchange (dom, fv[e], dom->depth, 1 + e);
+	if (r) return r;
+      }
   return GFSHIP_OK;
 }
 
@@ -626,7 +633,7 @@ int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3], 
 			      dom->stream));
   GFSHIP_HIP (hipStreamSynchronize (dom->stream));
   *cfl2 = dom->h_pinned[0];
-  return GFSHIP_OK;
+  return call_reduce (dom, cfl2, 1, 2);   /* gfs_all_reduce (..., MPI_MIN), src/domain.c:2921 */
 }
 
 int launch_coarse_init (gfship_domain * dom, Field * v)

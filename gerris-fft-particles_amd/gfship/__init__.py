@@ -96,6 +96,10 @@ SIGNATURES = {
     "gfship_coarse_init": (_i, [_vp]),
     "gfship_divergence_norm": (_i, [_vp, C.POINTER(Norm)]),
     "gfship_sim_download_un": (_i, [_vp, _i, _pd]),
+    "gfship_domain_set_exchange": (_i, [_vp, _vp, _vp]),
+    "gfship_domain_set_reduce": (_i, [_vp, _vp, _vp]),
+    "gfship_halo_pack": (_i, [_vp, _vp, _i, _i, _vp]),
+    "gfship_halo_unpack": (_i, [_vp, _vp, _i, _i, _vp]),
     "gfship_particles_create": (_i, [C.POINTER(_vp), _vp, _i, _pd, C.POINTER(C.c_uint)]),
     "gfship_particles_destroy": (None, [_vp]),
     "gfship_particle_list_event": (_i, [_vp]),

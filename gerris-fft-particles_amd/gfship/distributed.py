@@ -1,0 +1,293 @@
+"""One GfsBox per rank: box layout, neighbour topology and the halo exchange / all-reduce hooks
+over torch.distributed (backend "nccl" = RCCL over xGMI on GPUs, "gloo" on CPUs).
+
+Mirrors the reference's parallel model (src/mpi_boundary.c:78-246, src/domain.c:2135-2166):
+  * boxes tile a periodic bx x by x bz lattice (gfs_domain_split / one box per PE); a side whose
+    lattice extent is 1 stays a local periodic side, the others become GfsBoundaryMpi sides;
+  * every BC application sends the interior layer along each MPI side to the neighbour across
+    that side and receives the neighbour's layer into the ghost layer (send :89-130,
+    receive :132-222); per peer the messages are matched in the order of the sender's side index
+    (the reference uses a tag built from the side, :78-83);
+  * norms and the CFL time step are all-reduced (sum / max / min).
+
+The same classes drive the CPU oracle (numpy views, gloo) in the CPU tests and libgfship
+(device buffers, RCCL) in bench.py: the transport logic is tested without GPUs.
+"""
+import ctypes as C
+
+import numpy as np
+
+SIDE_PERIODIC, SIDE_BOUNDARY, SIDE_EXTERNAL = 0, 1, 2
+
+
+def lattice(nboxes, dim=3):
+    """bx, by, bz for 1, 2, 4, 8 ... boxes: doubled along x, then y, then z."""
+    b = [1, 1, 1]
+    a = 0
+    n = nboxes
+    while n > 1:
+        if n % 2:
+            raise ValueError("the number of boxes must be a power of two (got %d)" % nboxes)
+        b[a % dim] *= 2
+        a += 1
+        n //= 2
+    return tuple(b)
+
+
+class BoxGrid:
+    """Periodic lattice of boxes; rank r sits at (r % bx, (r // bx) % by, r // (bx*by))."""
+
+    def __init__(self, nboxes, dim=3):
+        self.dim = dim
+        self.n = nboxes
+        self.b = lattice(nboxes, dim)
+
+    def coords(self, rank):
+        bx, by, bz = self.b
+        return (rank % bx, (rank // bx) % by, rank // (bx * by))
+
+    def rank_of(self, c):
+        bx, by, bz = self.b
+        return (c[0] % bx) + bx * ((c[1] % by) + by * (c[2] % bz))
+
+    def neighbour(self, rank, side):
+        c = list(self.coords(rank))
+        c[side // 2] += -1 if side & 1 else 1
+        return self.rank_of(c)
+
+    def sides(self, rank=0):
+        """side kinds of a box: local periodic where the lattice has one box, MPI elsewhere"""
+        s = [SIDE_PERIODIC] * 6
+        for d in range(2 * self.dim):
+            if self.b[d // 2] > 1:
+                s[d] = SIDE_EXTERNAL
+        return s
+
+    def external_sides(self):
+        return [d for d in range(2 * self.dim) if self.b[d // 2] > 1]
+
+
+class Transport:
+    """torch.distributed point-to-point + all-reduce for one rank of a BoxGrid."""
+
+    def __init__(self, grid, rank, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.grid, self.rank = grid, rank
+        self.device = device if device is not None else torch.device("cpu")
+        self._bufs = {}
+
+    def buffers(self, key, nface):
+        """(send, recv) buffers per side for messages of nface doubles"""
+        b = self._bufs.get((key, nface))
+        if b is None:
+            t = self.torch
+            b = ({s: t.empty(nface, dtype=t.float64, device=self.device)
+                  for s in self.grid.external_sides()},
+                 {s: t.empty(nface, dtype=t.float64, device=self.device)
+                  for s in self.grid.external_sides()})
+            self._bufs[(key, nface)] = b
+        return b
+
+    def exchange(self, send_sides, snd, recv_sides, rcv):
+        """send snd[s] (interior layer along my side s) to the neighbour across s, for s in
+        send_sides; receive into rcv[r], for r in recv_sides, the layer that the neighbour across
+        my side r sent from its side r^1."""
+        dist = self.dist
+        ops = []
+        # sends in increasing side index; receives in increasing order of the SENDER's side
+        # index (r^1), so that the messages between two ranks match pairwise in posting order
+        for s in sorted(send_sides):
+            ops.append(dist.P2POp(dist.isend, snd[s], self.grid.neighbour(self.rank, s), tag=s))
+        for r in sorted(recv_sides, key=lambda x: x ^ 1):
+            ops.append(dist.P2POp(dist.irecv, rcv[r], self.grid.neighbour(self.rank, r), tag=r ^ 1))
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+
+    def allreduce(self, vals, op):
+        t, dist = self.torch, self.dist
+        x = t.tensor(vals, dtype=t.float64, device=self.device)
+        dist.all_reduce(x, op={0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}[op])
+        return x.cpu().numpy()
+
+
+def _kind_sides(grid, kind):
+    """kind 0: every MPI side; kind 1 + e (face values fv[e]): my side e is sent, side e^1 filled"""
+    ext = grid.external_sides()
+    if kind == 0:
+        return ext
+    e = kind - 1
+    return [e] if e in ext else []
+
+
+# ---------------------------------------------------------------------------------------------
+# hooks for libgfship (device)
+# ---------------------------------------------------------------------------------------------
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+
+
+class DeviceHooks:
+    """Installs the exchange / reduce hooks of a gfship.Domain (include/gfship.h)."""
+
+    def __init__(self, dom, transport):
+        import gfship
+        self.dom, self.tr = dom, transport
+        self.lib = gfship.lib()
+        torch = transport.torch
+        # run torch's work on the library's stream: pack kernel -> send/recv -> unpack kernel are
+        # then ordered on one stream without host synchronisation
+        self.stream = torch.cuda.ExternalStream(int(self.lib.gfship_domain_stream(dom.ptr)),
+                                                device=transport.device)
+        self._ex = EXCHANGE_FN(self._exchange)
+        self._red = REDUCE_FN(self._reduce)
+        gfship._check(self.lib.gfship_domain_set_exchange(dom.ptr, C.cast(self._ex, C.c_void_p), None))
+        gfship._check(self.lib.gfship_domain_set_reduce(dom.ptr, C.cast(self._red, C.c_void_p), None))
+
+    def _exchange(self, ctx, dev_ptr, level, kind):
+        try:
+            grid = self.tr.grid
+            sides = _kind_sides(grid, kind)       # sides I send from
+            if not sides:
+                return 0
+            n = 1 << level
+            nface = n ** (self.dom.dim - 1)
+            snd, rcv = self.tr.buffers("dev", nface)
+            torch = self.tr.torch
+            with torch.cuda.stream(self.stream):
+                for s in sides:
+                    rc = self.lib.gfship_halo_pack(self.dom.ptr, dev_ptr, level, s,
+                                                   C.c_void_p(snd[s].data_ptr()))
+                    if rc:
+                        return rc
+                # kind 0: receive on the same set of sides; kind 1+e: receive on side e^1 only
+                recv_sides = [x ^ 1 for x in sides] if kind else sides
+                self.tr.exchange(sides, snd, recv_sides, rcv)
+                for s in recv_sides:
+                    rc = self.lib.gfship_halo_unpack(self.dom.ptr, dev_ptr, level, s,
+                                                     C.c_void_p(rcv[s].data_ptr()))
+                    if rc:
+                        return rc
+            return 0
+        except Exception as e:     # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _reduce(self, ctx, vals, n, op):
+        try:
+            a = np.ctypeslib.as_array(vals, shape=(n,))
+            with self.tr.torch.cuda.stream(self.stream):
+                a[...] = self.tr.allreduce(a.copy(), op)
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+
+# ---------------------------------------------------------------------------------------------
+# hooks for the CPU oracle (numpy views) -- used by the CPU tests only
+# ---------------------------------------------------------------------------------------------
+
+GO_EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+GO_REDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+
+
+def layer_slices(dim, n, side, ghost):
+    """numpy index of the interior layer (ghost=False) or ghost layer (ghost=True) along `side`
+    of an (n+2)^dim array indexed [k, j, i]"""
+    sl = [slice(1, n + 1)] * dim
+    axis = dim - 1 - side // 2
+    if ghost:
+        sl[axis] = 0 if side & 1 else n + 1
+    else:
+        sl[axis] = 1 if side & 1 else n
+    return tuple(sl)
+
+
+class OracleHooks:
+    def __init__(self, oracle_lib, dom_ptr, dim, transport):
+        self.dim, self.tr = dim, transport
+        self._ex = GO_EXCHANGE_FN(self._exchange)
+        self._red = GO_REDUCE_FN(self._reduce)
+        oracle_lib.go_domain_set_hooks.restype = None
+        oracle_lib.go_domain_set_hooks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p]
+        oracle_lib.go_domain_set_hooks(dom_ptr, C.cast(self._ex, C.c_void_p), None,
+                                       C.cast(self._red, C.c_void_p), None)
+
+    def _exchange(self, ctx, a, level, kind):
+        torch = self.tr.torch
+        n = 1 << level
+        arr = np.ctypeslib.as_array(a, shape=(n + 2,) * self.dim)
+        sides = _kind_sides(self.tr.grid, kind)
+        if not sides:
+            return
+        nface = n ** (self.dim - 1)
+        snd, rcv = self.tr.buffers("cpu", nface)
+        for s in sides:
+            # tangential order: first tangential axis fastest = C order of the [k, j, i] slice
+            snd[s].copy_(torch.from_numpy(np.ascontiguousarray(
+                arr[layer_slices(self.dim, n, s, False)]).ravel()))
+        recv_sides = [x ^ 1 for x in sides] if kind else sides
+        self.tr.exchange(sides, snd, recv_sides, rcv)
+        for s in recv_sides:
+            sl = layer_slices(self.dim, n, s, True)
+            arr[sl] = rcv[s].numpy().reshape(arr[sl].shape)
+
+    def _reduce(self, ctx, vals, n, op):
+        a = np.ctypeslib.as_array(vals, shape=(n,))
+        a[...] = self.tr.allreduce(a.copy(), op)
+
+
+# ---------------------------------------------------------------------------------------------
+# in-process transport: several boxes of one process (threads), used to exercise the
+# GFSHIP_SIDE_EXTERNAL path of libgfship on a single GPU
+# ---------------------------------------------------------------------------------------------
+
+class LocalFabric:
+    """shared state of the LocalTransports of one process"""
+
+    def __init__(self, nboxes):
+        import threading
+        self.n = nboxes
+        self.barrier = threading.Barrier(nboxes)
+        self.posted = [None] * nboxes
+        self.values = [None] * nboxes
+
+
+class LocalTransport:
+    def __init__(self, grid, rank, fabric, device=None):
+        import torch
+        self.torch = torch
+        self.grid, self.rank, self.fabric = grid, rank, fabric
+        self.device = device if device is not None else torch.device("cpu")
+        self._bufs = {}
+        self.stream = None      # set by DeviceHooks users that want stream synchronisation
+
+    buffers = Transport.buffers
+
+    def exchange(self, send_sides, snd, recv_sides, rcv):
+        f = self.fabric
+        if self.device.type == "cuda":
+            self.torch.cuda.current_stream().synchronize()     # my packs are complete
+        f.posted[self.rank] = {s: snd[s] for s in send_sides}
+        f.barrier.wait()
+        for r in recv_sides:
+            peer = self.grid.neighbour(self.rank, r)
+            rcv[r].copy_(f.posted[peer][r ^ 1])
+        if self.device.type == "cuda":
+            self.torch.cuda.current_stream().synchronize()     # my copies are complete
+        f.barrier.wait()
+
+    def allreduce(self, vals, op):
+        f = self.fabric
+        f.values[self.rank] = np.array(vals, dtype=np.float64)
+        f.barrier.wait()
+        stack = np.stack(f.values)
+        out = (stack.sum(0), stack.max(0), stack.min(0))[op]
+        f.barrier.wait()
+        return out

@@ -197,6 +197,33 @@ int  gfship_particles_count (gfship_particles * pl);
 /* positions and ids of the particles still on the list, in list order; returns their number */
 int  gfship_particles_download (gfship_particles * pl, double * pos, unsigned * id);
 
+/* ---- one box per GPU: GfsBoundaryMpi sides (src/mpi_boundary.c:78-246) ----------------------- */
+
+/* The library does not talk to a network itself: for every GFSHIP_SIDE_EXTERNAL side the caller
+   installs the two hooks below (bench.py and the tests implement them over torch.distributed:
+   RCCL on GPUs, gloo in the CPU tests).  Semantics are the reference's parallel run with the
+   domain parameter `overlap = 0` (src/domain.c:225,1104,1183): plain traversal order, ghost cells
+   of MPI sides refreshed by every BC application, i.e. lagged by one sweep exactly like the
+   periodic and MPI boundaries of the reference (send src/mpi_boundary.c:89-130, receive
+   :132-222).
+   exchange: fill the ghost layer of the level array `dev_ptr` (layout px, xo as in
+     gfship_field_device_ptr) on external sides from the neighbour boxes' interior layer;
+     kind = 0: a cell-centred variable, every external side (gfs_domain_copy_bc);
+     kind = 1 + e: the face-value array fv[e] of gfs_domain_face_bc: only side e^1 is needed.
+     Work must be ordered after everything already enqueued on gfship_domain_stream().
+   reduce: MPI_Allreduce of vals[0..n-1] over all boxes, op = 0 sum, 1 max, 2 min
+     (norms src/domain.c:2135-2166, CFL :2921). */
+typedef int (* gfship_exchange_fn) (void * ctx, void * dev_ptr, int level, int kind);
+typedef int (* gfship_reduce_fn) (void * ctx, double * vals, int n, int op);
+int  gfship_domain_set_exchange (gfship_domain * dom, gfship_exchange_fn fn, void * ctx);
+int  gfship_domain_set_reduce (gfship_domain * dom, gfship_reduce_fn fn, void * ctx);
+/* pack the interior layer adjacent to `side` of a level array into n^(dim-1) contiguous doubles
+   (first tangential axis fastest) / unpack such a buffer into the ghost layer of `side`
+   (the sndbuf / rcvbuf of src/boundary.c:1240-1258,1333-1347); device pointers, asynchronous on
+   the domain's stream */
+int  gfship_halo_pack (gfship_domain * dom, const void * dev_ptr, int level, int side, void * dev_buf);
+int  gfship_halo_unpack (gfship_domain * dom, void * dev_ptr, int level, int side, const void * dev_buf);
+
 /* ---- instrumentation -------------------------------------------------------------------- */
 
 /* time (HIP events on the domain's stream) of `reps` back-to-back sweeps of gfship_relax on

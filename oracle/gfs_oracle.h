@@ -87,6 +87,8 @@ typedef struct {           /* one variable: all levels, ghosts included */
 /* exchange hook for GO_SIDE_EXTERNAL sides: must fill the ghost layer of `a` (level `level`)
    on every external side from the neighbouring boxes' interior cells */
 typedef void (* GoExchangeFunc) (void * ctx, double * a, int level, int kind);
+/* MPI_Allreduce over the boxes: op 0 sum, 1 max, 2 min (domain.c:2135-2166, utils.h:36-42) */
+typedef void (* GoReduceFunc) (void * ctx, double * vals, int n, int op);
 
 struct GoDomain {
   int dim, depth;
@@ -100,6 +102,8 @@ struct GoDomain {
   double * w[6][GO_MAXLEVEL + 1];   /* GFS_STATE(cell)->f[d].v used as Poisson weights */
   GoExchangeFunc exchange;
   void * exchange_ctx;
+  GoReduceFunc reduce;
+  void * reduce_ctx;
   int mpi_order;                    /* 1: boundary-cells-first sweep order (domain.c:1093-1125) */
 };
 
@@ -115,6 +119,8 @@ double *   go_field_level (GoField * f, int level);
 void       go_field_set_bc (GoField * f, int d, int type, const double * val);
 void       go_bc (GoField * v, GoField * v1, int level);              /* gfs_domain_copy_bc */
 void       go_homogeneous_bc (GoField * ov, GoField * v, int level);  /* gfs_domain_homogeneous_bc */
+void       go_domain_set_hooks (GoDomain * dom, GoExchangeFunc ex, void * ex_ctx,
+				GoReduceFunc red, void * red_ctx);
 void       go_cell_pos (const GoDomain * dom, int level, int i, int j, int k, double pos[3]);
 
 /* ---- Poisson (go_poisson.c) ---- */

@@ -101,6 +101,13 @@ void go_domain_destroy (GoDomain * dom)
   free (dom);
 }
 
+void go_domain_set_hooks (GoDomain * dom, GoExchangeFunc ex, void * ex_ctx,
+			  GoReduceFunc red, void * red_ctx)
+{
+  dom->exchange = ex; dom->exchange_ctx = ex_ctx;
+  dom->reduce = red; dom->reduce_ctx = red_ctx;
+}
+
 GoField * go_field_new (GoDomain * dom, int component)
 {
   GoField * f = calloc (1, sizeof (GoField));

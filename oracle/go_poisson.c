@@ -241,6 +241,13 @@ GoNorm go_norm_residual (GoDomain * dom, double dt, GoField * res)
     norm_add (&nm, r/(1.*size*size), 1.);
     bias += r;
   }
+  if (dom->reduce) { /* domain_norm_reduce + gfs_all_reduce (bias), domain.c:2135-2166,2279 */
+    double sums[4] = { nm.bias, nm.first, nm.second, nm.w };
+    (* dom->reduce) (dom->reduce_ctx, sums, 4, 0);
+    (* dom->reduce) (dom->reduce_ctx, &nm.infty, 1, 1);
+    (* dom->reduce) (dom->reduce_ctx, &bias, 1, 0);
+    nm.bias = sums[0]; nm.first = sums[1]; nm.second = sums[2]; nm.w = sums[3];
+  }
   norm_update (&nm);
   dt *= dt;
   nm.bias = bias*dt;
@@ -264,6 +271,12 @@ GoNorm go_norm_variable (GoDomain * dom, GoField * v)
   norm_init (&nm);
   for (size_t q = 0; q < ncell; q++)
     norm_add (&nm, pv[order[q]], vol);
+  if (dom->reduce) {
+    double sums[4] = { nm.bias, nm.first, nm.second, nm.w };
+    (* dom->reduce) (dom->reduce_ctx, sums, 4, 0);
+    (* dom->reduce) (dom->reduce_ctx, &nm.infty, 1, 1);
+    nm.bias = sums[0]; nm.first = sums[1]; nm.second = sums[2]; nm.w = sums[3];
+  }
   norm_update (&nm);
   return nm;
 }

@@ -420,8 +420,9 @@ static void face_bc (GoSim * s, GoField * v)
     }
   }
   if (external && dom->exchange)
-    for (int d = 0; d < 2*dim; d++)
-      (* dom->exchange) (dom->exchange_ctx, s->fv[d], L, 1 + d);
+    for (int e = 0; e < 2*dim; e++)
+      if (dom->side[e ^ 1] == GO_SIDE_EXTERNAL)
+	(* dom->exchange) (dom->exchange_ctx, s->fv[e], L, 1 + e);
 }
 
 /* face_values_set, timestep.c:644-654 */
@@ -589,6 +590,8 @@ double go_domain_cfl (GoSim * s)
 	  cfl = cflu*cflu;
       }
     }
+  if (s->dom->reduce) /* gfs_all_reduce (domain, p.cfl, MPI_DOUBLE, MPI_MIN), domain.c:2921 */
+    (* s->dom->reduce) (s->dom->reduce_ctx, &cfl, 1, 2);
   return sqrt (cfl);
 }
 
