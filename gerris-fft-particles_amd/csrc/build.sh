@@ -10,7 +10,7 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-ma
 OBJS=""
 for f in "$HERE"/*.hip; do
   o="$OUT/$(basename "${f%.hip}").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/gfship_internal.hpp" -nt "$o" ] || [ "$HERE/../../include/gfship.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/relax_skew.hpp" -nt "$o" ] || [ "$HERE/gfship_internal.hpp" -nt "$o" ] || [ "$HERE/../../include/gfship.h" -nt "$o" ]; then
     "$HIPCC" $FLAGS -c "$f" -o "$o" &
   fi
   OBJS="$OBJS $o"

@@ -128,14 +128,14 @@ int launch_centered_gradient (gfship_domain * dom, const double * p, double * co
 int launch_correct_centered (gfship_domain * dom, double * const u[3], double * const g[3], double dt);
 int launch_advected_face_values (gfship_domain * dom, const double * v, double * const u[3],
 				 double * const un[3], double dt, int use_centered, int gradient,
-				 double * const fv[6]);
-int launch_face_bc (gfship_domain * dom, Field * v, double * const fv[6]);
+				 double * const fv[6], int cmask);
+int launch_face_bc (gfship_domain * dom, Field * v, double * const fv[6], int cmask);
 int launch_predict_un (gfship_domain * dom, int cc, const double * uc, double * const fv[6],
 		       double * unc);
 int launch_flux_update (gfship_domain * dom, bool velocity, double * v, double * const un[3],
 			double * const fv[6], const double * gm, const double * gc, double dt);
 int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3], double * cfl2);
-int launch_coarse_init (gfship_domain * dom, Field * v);
+int launch_coarse_init (gfship_domain * dom, Field * const * v, int nf);
 int launch_velocity_divergence (gfship_domain * dom, double * const u[3], double * out);
 
 

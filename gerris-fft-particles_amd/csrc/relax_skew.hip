@@ -23,51 +23,10 @@
 // streaming with register prefetch, no LDS staging.  The natural array keeps the ghost layer;
 // cells adjacent to the box sides are mirrored into it by the sweep so that the BC kernel works
 // unchanged between sweeps.
-#include "gfship_internal.hpp"
+#include "relax_skew.hpp"
 #include <cstdlib>
 
 namespace gfship {
-
-#define SK_T   16            /* tile edge (lines) */
-#define SK_NL  (SK_T*SK_T)   /* lines = threads per tile */
-#define SK_PAD (2*SK_T - 2)  /* extra rows of a tile: max skew */
-#define SK_D   8             /* prefetch distance (steps) */
-#define SK_DH  4             /* prefetch distance of the halo streams (divides SK_D): the lag */
-                             /* between neighbouring tiles grows with it                     */
-#define SK_FP  16            /* rows of padding in front of and behind every tile, so that */
-                             /* prefetch addresses never need clamping                      */
-
-typedef unsigned long long u64;
-#define SK_SENTINEL 0xFFFFFFFFFFFFFFFFull
-
-struct SkewArgs {
-  Layout L;
-  int ntj;                 // tiles per side
-  int RT;                  // rows per tile
-  double * us;             // skewed u
-  const double * rs;       // skewed rhs
-  const double * ds;       // skewed dia (or nullptr)
-  double * un;             // natural u (ghost layer + mirrored side cells)
-  u64 * hbJ;               // [tile][n + SK_T - 1][SK_T] new values of line a = 15
-  u64 * hbK;               // [tile][n + SK_T - 1][SK_T] new values of line b = 15
-  const unsigned short * order; // ticket -> tile (anti-diagonal major)
-  unsigned * ticket;       // ticket counter (zeroed before the launch)
-  unsigned * err;          // set to 1 when a bounded spin gives up
-  const u64 * dummy;       // 8 readable bytes for the streams a lane does not need
-  u64 * stats;             // optional per-tile { start, end, spins, slow entries } (debug)
-};
-
-typedef __attribute__((address_space(1))) u64 gu64;
-
-__device__ __forceinline__ u64 load_sc1 (const u64 * p)
-{
-  return __hip_atomic_load ((gu64 *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ void store_sc1 (u64 * p, u64 v)
-{
-  __hip_atomic_store ((gu64 *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // The main loop is written so that the compiler can count outstanding loads exactly
 // (s_waitcnt vmcnt(N), never vmcnt(0)): straight-line unrolled body, every lane issues the same
@@ -82,7 +41,7 @@ __device__ __forceinline__ void store_sc1 (u64 * p, u64 v)
 //      tiles, or box-side ghosts)
 // The four halo strips are streamed by the 64 lanes of wave 0 (16 lanes each), which also wait
 // for hand-off granules that are still the sentinel (rare slow path).
-template <bool HAS_DIA, int VARIANT = 0>
+template <bool HAS_DIA>
 __global__ void __launch_bounds__(SK_NL)
 relax_skew_kernel (SkewArgs A)
 {
@@ -157,8 +116,9 @@ relax_skew_kernel (SkewArgs A)
 
   // store pointers: own row t; hand-off row t - 15 of this tile's buffers; natural mirror
   double * wU = ut + tid;
-  u64 * wJ = (a == SK_T - 1 && P + 1 < ntj) ? A.hbJ + tile*hstride + b - (long) (SK_T - 1)*SK_T : nullptr;
-  u64 * wK = (b == SK_T - 1 && Q + 1 < ntj) ? A.hbK + tile*hstride + a - (long) (SK_T - 1)*SK_T : nullptr;
+  const bool hasJ = (a == SK_T - 1 && P + 1 < ntj), hasK = (b == SK_T - 1 && Q + 1 < ntj);
+  u64 * wJ = A.hbJ + tile*hstride + b - (long) (SK_T - 1)*SK_T;   // dereferenced only if hasJ
+  u64 * wK = A.hbK + tile*hstride + a - (long) (SK_T - 1)*SK_T;   // dereferenced only if hasK
   const bool side_jk = (j == 1 || j == n || k == 1 || k == n);
   double * nat = A.un + A.L.idx (1 - s, j, k);   // natural address of I at step t: nat[t]
 
@@ -265,16 +225,18 @@ relax_skew_kernel (SkewArgs A)
       SK_HALO (t + 1, q % SK_DH);
       SK_PREFETCH_HALO (q % SK_DH);
       SK_PREFETCH (q);
-      if (act) {
-	if (VARIANT != 1) *wU = v;
-	if (wJ) store_sc1 (wJ, (u64) __double_as_longlong (v));
-	if (wK) store_sc1 (wK, (u64) __double_as_longlong (v));
-	if (VARIANT != 1 && (side_jk || I == 0 || I == n - 1))
+      // own row of the skewed copy: stored unconditionally (for an inactive lane the slot is
+      // padding that nothing reads), which keeps the common path free of branches
+      *wU = v;
+      wU += SK_NL;
+      if (act && (hasJ || hasK || side_jk || I == 0 || I == n - 1)) {
+	if (hasJ) store_sc1 (wJ, (u64) __double_as_longlong (v));
+	if (hasK) store_sc1 (wK, (u64) __double_as_longlong (v));
+	if (side_jk || I == 0 || I == n - 1)
 	  nat[t] = v;
       }
-      wU += SK_NL;
-      if (wJ) wJ += SK_T;
-      if (wK) wK += SK_T;
+      wJ += SK_T;
+      wK += SK_T;
       // workgroup barrier that drains LDS traffic only: __syncthreads() would also wait for the
       // prefetch loads just issued (s_waitcnt vmcnt(0)) and serialise every step on HBM latency
       asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -463,13 +425,10 @@ static int skew_launch (gfship_domain * dom, int level, SkewPlan * S, double * u
   A.dummy = (const u64 *) S->ctl + 2;
   A.stats = S->stats;
   int ntiles = S->ntj*S->ntj;
-  static const int variant = getenv ("GFSHIP_SKEW_VARIANT") ? atoi (getenv ("GFSHIP_SKEW_VARIANT")) : 0;
   if (has_dia)
     hipLaunchKernelGGL (relax_skew_kernel<true>, dim3 (ntiles), dim3 (SK_NL), 0, dom->stream, A);
-  else switch (variant) { /* variants 1-4: timing experiments only (wrong results) */
-    case 1: hipLaunchKernelGGL ((relax_skew_kernel<false, 1>), dim3 (ntiles), dim3 (SK_NL), 0, dom->stream, A); break;
-    default: hipLaunchKernelGGL (relax_skew_kernel<false>, dim3 (ntiles), dim3 (SK_NL), 0, dom->stream, A);
-  }
+  else
+    hipLaunchKernelGGL (relax_skew_kernel<false>, dim3 (ntiles), dim3 (SK_NL), 0, dom->stream, A);
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
 }

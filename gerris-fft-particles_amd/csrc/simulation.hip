@@ -63,7 +63,8 @@ int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, g
   TRY (gfship_poisson_coefficients (dom));
   /* dia = 0 on all levels (gfs_cell_reset on FTT_TRAVERSE_ALL) */
   for (int l = 0; l <= dom->depth; l++)
-    TRY (gfship_field_fill (dom, s->dia, l, 0.));
+    if (!dom->fields[s->dia].zero[l])
+      TRY (gfship_field_fill (dom, s->dia, l, 0.));
   /* MAC divergence, scaled by 1/dt */
   TRY (launch_divergence (dom, un, leaf (s, s->div), dt));
   TRY (gfship_poisson_solve (dom, par, p, s->div, s->res, s->dia, dt));
@@ -88,14 +89,15 @@ int correct_centered_velocities (gfship_sim * s, const gfship_field g[3], double
 }
 
 // face_values_set, src/timestep.c:644-654
-int face_values_set (gfship_sim * s, gfship_field v, double dt, int use_centered, int gradient)
+int face_values_set (gfship_sim * s, gfship_field v, double dt, int use_centered, int gradient,
+		     int cmask = 7)
 {
   double * u[3], * un[3], * fv[6];
   ptrs3 (s, s->u, u);
   ptrs3 (s, s->un, un);
   ptrs6 (s, fv);
-  TRY (launch_advected_face_values (s->dom, leaf (s, v), u, un, dt, use_centered, gradient, fv));
-  TRY (launch_face_bc (s->dom, get_field (s->dom, v), fv));
+  TRY (launch_advected_face_values (s->dom, leaf (s, v), u, un, dt, use_centered, gradient, fv, cmask));
+  TRY (launch_face_bc (s->dom, get_field (s->dom, v), fv, cmask));
   return GFSHIP_OK;
 }
 
@@ -235,7 +237,8 @@ int gfship_predicted_face_velocities (gfship_sim * s)
   /* the reset of every face (gfs_face_reset_normal_velocity) is implied: each component's
      faces are all overwritten below */
   for (int c = 0; c < s->dom->dim; c++) {
-    TRY (face_values_set (s, s->u[c], s->advection_params.dt, 1, s->advection_params.gradient));
+    /* only the faces normal to component c are read by gfs_face_advected_normal_velocity */
+    TRY (face_values_set (s, s->u[c], s->advection_params.dt, 1, s->advection_params.gradient, 1 << c));
     TRY (launch_predict_un (s->dom, c, leaf (s, s->u[c]), fv, leaf (s, s->un[c])));
   }
   return GFSHIP_OK;
@@ -335,13 +338,14 @@ int gfship_coarse_init (gfship_sim * s)
 {
   GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
   gfship_domain * dom = s->dom;
-  TRY (launch_coarse_init (dom, get_field (dom, s->p)));
-  TRY (launch_coarse_init (dom, get_field (dom, s->pmac)));
+  std::vector<Field *> v;
+  v.push_back (get_field (dom, s->p));
+  v.push_back (get_field (dom, s->pmac));
   for (int c = 0; c < dom->dim; c++)
-    TRY (launch_coarse_init (dom, get_field (dom, s->u[c])));
+    v.push_back (get_field (dom, s->u[c]));
   for (gfship_field t : s->tracers)
-    TRY (launch_coarse_init (dom, get_field (dom, t)));
-  return GFSHIP_OK;
+    v.push_back (get_field (dom, t));
+  return launch_coarse_init (dom, v.data (), (int) v.size ());
 }
 
 int gfship_sim_start (gfship_sim * s)

@@ -186,7 +186,7 @@ __device__ __forceinline__ double van_leer_gradient (double v0, double v1, doubl
 template <int DIM>
 __global__ void __launch_bounds__(256)
 advected_face_values_kernel (Layout L, const double * __restrict__ v, CPtr3 u, CPtr3 un,
-			     double dt, int use_centered_velocity, int gradient, Ptr6 fv)
+			     double dt, int use_centered_velocity, int gradient, Ptr6 fv, int cmask)
 {
   CELL_PROLOGUE (L);
   const long off[3] = { 1, L.sy, L.sz };
@@ -226,8 +226,10 @@ advected_face_values_kernel (Layout L, const double * __restrict__ v, CPtr3 u, C
       dv = tt[o0];
       dv += tt[o1];
     }
-    fv.p[2*cc][c]     = vl + src - dv;
-    fv.p[2*cc + 1][c] = vr + src - dv;
+    if (cmask & (1 << cc)) {   /* the predictor only uses the faces normal to the component */
+      fv.p[2*cc][c]     = vl + src - dv;
+      fv.p[2*cc + 1][c] = vr + src - dv;
+    }
   }
 }
 
@@ -237,7 +239,7 @@ advected_face_values_kernel (Layout L, const double * __restrict__ v, CPtr3 u, C
 // value in fv[opposite(sd)][G]; symmetry/Dirichlet also overwrite the interior cell's fv[sd].
 template <int DIM>
 __global__ void __launch_bounds__(256)
-face_bc_kernel (Layout L, BcDesc bc, const double * __restrict__ v, Ptr6 fv)
+face_bc_kernel (Layout L, BcDesc bc, const double * __restrict__ v, Ptr6 fv, int cmask)
 {
   const int n = L.n;
   const int nface = DIM == 3 ? n*n : n;
@@ -245,6 +247,7 @@ face_bc_kernel (Layout L, BcDesc bc, const double * __restrict__ v, Ptr6 fv)
   int sd = blockIdx.y;
   if (f >= nface) return;
   if (bc.side[sd] == GFSHIP_SIDE_EXTERNAL) return;
+  if (!(cmask & (1 << (sd/2)))) return;
   int cc = sd/2, od = sd ^ 1;
   int t1 = f % n + 1, t2 = DIM == 3 ? f / n + 1 : 0;
   int ijk[3] = { 0, 0, 0 };
@@ -444,22 +447,26 @@ min_final_kernel (const double * __restrict__ partial, int nblocks, double * __r
 }
 
 // K18: gfs_get_from_below_intensive, src/fluid.c:1843-1864 (cell fractions = 1.)
+struct CoarseArgs { double * vc[8]; const double * vf[8]; int nf; };
+
 template <int DIM>
 __global__ void __launch_bounds__(256)
-coarse_init_kernel (Layout Lc, Layout Lf, double * __restrict__ vc, const double * __restrict__ vf)
+coarse_init_kernel (Layout Lc, Layout Lf, CoarseArgs A)
 {
   CELL_PROLOGUE (Lc);
-  double val = 0., sa = 0.;
+  for (int f = 0; f < A.nf; f++) {        // every variable of the domain (src/adaptive.c:43-58)
+    double val = 0., sa = 0.;
 #pragma unroll
-  for (int id = 0; id < (1 << DIM); id++) {
-    int ci = 2*i - 1 + (id & 1);
-    int cj = 2*j - 1 + ((id & 2) ? 0 : 1);
-    int ck = DIM == 3 ? 2*k - 1 + ((id & 4) ? 0 : 1) : 0;
-    double a = 1.;
-    val += vf[Lf.idx (ci, cj, ck)]*a;
-    sa += a;
+    for (int id = 0; id < (1 << DIM); id++) {
+      int ci = 2*i - 1 + (id & 1);
+      int cj = 2*j - 1 + ((id & 2) ? 0 : 1);
+      int ck = DIM == 3 ? 2*k - 1 + ((id & 4) ? 0 : 1) : 0;
+      double a = 1.;
+      val += A.vf[f][Lf.idx (ci, cj, ck)]*a;
+      sa += a;
+    }
+    A.vc[f][c] = val/sa;
   }
-  vc[c] = val/sa;
 }
 
 // derived variable Divergence: gfs_divergence, src/fluid.c:2357-2376
@@ -543,17 +550,17 @@ int launch_correct_centered (gfship_domain * dom, double * const u[3], double * 
 
 int launch_advected_face_values (gfship_domain * dom, const double * v, double * const u[3],
 				 double * const un[3], double dt, int use_centered, int gradient,
-				 double * const fv[6])
+				 double * const fv[6], int cmask)
 {
   const Layout & L = dom->lay[dom->depth];
   dim3 grid, block;
   cell_grid (L, &grid, &block);
   DISPATCH (dom, advected_face_values_kernel, grid, block, L, v, c3 (u), c3 (un), dt,
-	    use_centered, gradient, m6 (fv));
+	    use_centered, gradient, m6 (fv), cmask);
   return GFSHIP_OK;
 }
 
-int launch_face_bc (gfship_domain * dom, Field * v, double * const fv[6])
+int launch_face_bc (gfship_domain * dom, Field * v, double * const fv[6], int cmask)
 {
   const Layout & L = dom->lay[dom->depth];
   BcDesc bc;
@@ -568,11 +575,11 @@ int launch_face_bc (gfship_domain * dom, Field * v, double * const fv[6])
   int block = nface >= 256 ? 256 : 64;
   dim3 grid ((nface + block - 1)/block, 2*dom->dim);
   DISPATCH (dom, face_bc_kernel, grid, dim3 (block), L, bc, (const double *) v->lev[dom->depth],
-	    m6 (fv));
+	    m6 (fv), cmask);
   /* GfsBoundaryMpi sides: ghost face values fv[e] beyond side e^1 come from the neighbour box */
   if (dom->has_external)
     for (int e = 0; e < 2*dom->dim; e++)
-      if (dom->side[e ^ 1] == GFSHIP_SIDE_EXTERNAL) {
+      if (dom->side[e ^ 1] == GFSHIP_SIDE_EXTERNAL && (cmask & (1 << (e/2)))) {
 	int r = call_exchange (dom, fv[e], dom->depth, 1 + e);
 	if (r) return r;
       }
@@ -636,13 +643,23 @@ int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3], 
   return call_reduce (dom, cfl2, 1, 2);   /* gfs_all_reduce (..., MPI_MIN), src/domain.c:2921 */
 }
 
-int launch_coarse_init (gfship_domain * dom, Field * v)
+int launch_coarse_init (gfship_domain * dom, Field * const * v, int nf)
 {
-  for (int l = dom->depth - 1; l >= 0; l--) {
-    const Layout & Lc = dom->lay[l], & Lf = dom->lay[l + 1];
-    dim3 grid, block;
-    cell_grid (Lc, &grid, &block);
-    DISPATCH (dom, coarse_init_kernel, grid, block, Lc, Lf, v->lev[l], (const double *) v->lev[l + 1]);
+  for (int f0 = 0; f0 < nf; f0 += 8) {
+    int m = nf - f0 < 8 ? nf - f0 : 8;
+    for (int l = dom->depth - 1; l >= 0; l--) {
+      const Layout & Lc = dom->lay[l], & Lf = dom->lay[l + 1];
+      CoarseArgs A;
+      A.nf = m;
+      for (int f = 0; f < m; f++) {
+	A.vc[f] = v[f0 + f]->lev[l];
+	A.vf[f] = v[f0 + f]->lev[l + 1];
+	v[f0 + f]->zero[l] = false;
+      }
+      dim3 grid, block;
+      cell_grid (Lc, &grid, &block);
+      DISPATCH (dom, coarse_init_kernel, grid, block, Lc, Lf, A);
+    }
   }
   return GFSHIP_OK;
 }

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libgfship.so")
+LIB_PATH = os.environ.get("GFSHIP_LIB", os.path.join(_PKG, "lib", "libgfship.so"))
 
 SIDE_PERIODIC, SIDE_BOUNDARY, SIDE_EXTERNAL = 0, 1, 2
 BC_SYMMETRY, BC_DIRICHLET, BC_NEUMANN = 0, 1, 2
