@@ -133,8 +133,17 @@ def main():
     dom.poisson_coefficients()
     ms = dom.time_relax(u, rhs, dia, reps=5)
     achieved = RELAX_BYTES_PER_CELL * n ** 3 / (ms * 1e-3) / 1e9
+    # HBM bytes per launch from the rocprofv3 PMC passes of the same kernel at the same size
+    # (profiles/r01_pmc_relax_256.json: FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md);
+    # counters cannot be read from inside this process, so the committed summary is reported
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_relax_256.json")
+    if args.level == 8 and args.mode == "exact" and os.path.exists(pmc):
+        with open(pmc) as f:
+            traffic = json.load(f)["kernels"]["relax_skew_kernel"]["hbm_bytes_per_launch_guide_corrected"]
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": RELAX_BYTES_PER_CELL * n ** 3,
                 "kernel": "relax sweep, level %d (%d^3), mode %s" % (args.level, n, args.mode),
                 "ms_per_sweep": ms}
 
