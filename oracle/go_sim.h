@@ -16,6 +16,8 @@ typedef struct GoSim {
   GoMultilevelParams projection_params, approx_projection_params;
   GoAdvectionParams advection_params;
   double t, end, dtmax, tnext;   /* GfsTime */
+  double visc[3];                /* SourceDiffusion {} U nu: constant diffusion coefficient, 0 = none */
+  GoMultilevelParams diffusion_params[3]; /* GfsDiffusion.par (source.c:966-974) */
   unsigned i, iend;
 } GoSim;
 
@@ -45,4 +47,10 @@ void    go_coarse_init (GoSim * s);
 void    go_sim_start (GoSim * s);
 void    go_sim_step (GoSim * s);
 void    go_divergence (GoSim * s, GoField * out);
+void    go_sim_set_viscosity (GoSim * s, int c, double nu);
+GoMultilevelParams * go_sim_diffusion_params (GoSim * s, int c);
+/* go_diffusion.c */
+double  go_source_diffusion_value (GoSim * s, GoField * phi, int cell, double D);
+void    go_variable_diffusion (GoSim * s, GoField * v, GoField * rhs, double D, double dt,
+			       GoMultilevelParams * par);
 #endif

@@ -80,6 +80,10 @@ GoSim * go_sim_new (int dim, int depth, const int side[6])
   s->advection_params.dt = 0.;
   s->advection_params.gradient = 0;
   s->advection_params.gc = 1;
+  for (int c = 0; c < 3; c++) { /* diffusion_init, source.c:966-974 */
+    go_multilevel_params_init (&s->diffusion_params[c], dim);
+    s->diffusion_params[c].tolerance = 1e-6;
+  }
   /* gfs_time_init, simulation.c:1660-1670 */
   s->t = 0.; s->end = DBL_MAX; s->i = 0; s->iend = (unsigned) G_MAXINT; s->dtmax = DBL_MAX;
   s->tnext = 0.;
@@ -133,6 +137,9 @@ void go_sim_set_time (GoSim * s, double end, double dtmax)
   s->end = end;
   s->dtmax = dtmax;
 }
+
+void go_sim_set_viscosity (GoSim * s, int c, double nu) { s->visc[c] = nu; }
+GoMultilevelParams * go_sim_diffusion_params (GoSim * s, int c) { return &s->diffusion_params[c]; }
 
 int go_sim_add_tracer (GoSim * s)
 {
@@ -361,7 +368,12 @@ static void cell_advected_face_values (GoSim * s, const AdvPar * par, int cell)
       center_gradient (dom, L, v, cell, c);
     double vl = v[cell] + MIN ((1. - unorm)/2., 0.5)*g;
     double vr = v[cell] + MAX ((- 1. - unorm)/2., -0.5)*g;
-    double src = par->dt*0./2.; /* gfs_variable_mac_source: no sources */
+    /* gfs_variable_mac_source (source.c:38-59): the explicit diffusion term of an implicit
+       GfsSourceDiffusion (source_diffusion_value, source.c:1105-1144) */
+    double msrc = 0.;
+    if (par->v->component >= 0 && s->visc[par->v->component] != 0.)
+      msrc = 0. + go_source_diffusion_value (s, par->v, cell, s->visc[par->v->component]);
+    double src = par->dt*msrc/2.;
     double dv;
     if (dim == 2)
       dv = transverse_term (s, par, cell, msize, (c + 1) % 2);
@@ -513,8 +525,8 @@ static void face_advection_flux (GoSim * s, int cell, int nb, int d, void * data
 }
 
 /* variable_sources, timestep.c:872-921 (Godunov, no sinking velocity, no sources) */
-static void variable_sources (GoSim * s, GoField * v, int gradient, int velocity_flux, double dt,
-			      GoField ** gmac, GoField ** g)
+static void variable_sources (GoSim * s, GoField * v, GoField * sv, int gradient, int velocity_flux,
+			      double dt, GoField ** gmac, GoField ** g)
 {
   int L = s->dom->depth;
   GoField * fvar = go_field_new (s->dom, -1);
@@ -523,23 +535,37 @@ static void variable_sources (GoSim * s, GoField * v, int gradient, int velocity
   face_traverse (s, -1, face_reset, &fp);
   face_values_set (s, &ap);
   face_traverse (s, -1, velocity_flux ? face_velocity_advection_flux : face_advection_flux, &fp);
-  /* gfs_advection_update (non-merged), advection.c:817-818 */
+  /* gfs_advection_update (non-merged) into sv (par->v = sv), advection.c:817-818 */
   LEAF_LOOP (s, cell)
-    v->lev[L][cell] += fvar->lev[L][cell]/1.;
+    sv->lev[L][cell] += fvar->lev[L][cell]/1.;
   go_field_destroy (fvar);
   if (g)
-    /* add_pressure_gradient, timestep.c:809-812 */
+    /* add_pressure_gradient on sv, timestep.c:809-812 */
     LEAF_LOOP (s, cell)
-      v->lev[L][cell] -= g[v->component]->lev[L][cell]*dt;
+      sv->lev[L][cell] -= g[v->component]->lev[L][cell]*dt;
 }
 
 /* gfs_centered_velocity_advection_diffusion, timestep.c:976-1016 (no diffusion source) */
 void go_centered_velocity_advection (GoSim * s, GoField ** gmac, GoField ** g)
 {
   int dim = s->dom->dim, L = s->dom->depth;
-  for (int c = 0; c < dim; c++)
-    variable_sources (s, s->u[c], s->advection_params.gradient, 1, s->advection_params.dt,
-		      gmac, g);
+  for (int c = 0; c < dim; c++) {
+    if (s->visc[c] != 0.) {
+      /* source_diffusion (v[c]): rhs = copy of v, sources into rhs, then the implicit solve
+	 (timestep.c:996-1007) */
+      GoField * rhs = go_field_new (s->dom, -1);
+      LEAF_LOOP (s, cell)
+	rhs->lev[L][cell] = s->u[c]->lev[L][cell];
+      variable_sources (s, s->u[c], rhs, s->advection_params.gradient, 1, s->advection_params.dt,
+			gmac, g);
+      go_variable_diffusion (s, s->u[c], rhs, s->visc[c], s->advection_params.dt,
+			     &s->diffusion_params[c]);
+      go_field_destroy (rhs);
+    }
+    else
+      variable_sources (s, s->u[c], s->u[c], s->advection_params.gradient, 1,
+			s->advection_params.dt, gmac, g);
+  }
   for (int c = 0; c < dim; c++)
     go_bc (s->u[c], s->u[c], L);
 }
@@ -548,7 +574,7 @@ void go_centered_velocity_advection (GoSim * s, GoField ** gmac, GoField ** g)
    tracers default to the van Leer gradient and gfs_face_advection_flux (variable.c:427-431) */
 void go_tracer_advection (GoSim * s, GoField * t, double dt)
 {
-  variable_sources (s, t, 1, 0, dt, NULL, NULL);
+  variable_sources (s, t, t, 1, 0, dt, NULL, NULL);
   go_bc (t, t, s->dom->depth);
 }
 
@@ -588,6 +614,14 @@ double go_domain_cfl (GoSim * s)
 	double cflu = length/fabs (fm*u);
 	if (cflu*cflu < cfl)
 	  cfl = cflu*cflu;
+      }
+      if (s->visc[c] != 0.) { /* p->v[c]->sources: acceleration scale, domain.c:2893-2901 */
+	double g = 0. + go_source_diffusion_value (s, s->u[c], cell, s->visc[c]);
+	if (g != 0.) {
+	  double cflg = 2.*length/fabs (fm*g);
+	  if (cflg < cfl)
+	    cfl = cflg;
+	}
       }
     }
   if (s->dom->reduce) /* gfs_all_reduce (domain, p.cfl, MPI_DOUBLE, MPI_MIN), domain.c:2921 */

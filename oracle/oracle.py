@@ -181,6 +181,8 @@ def _sim_sigs(L):
         "go_sim_step": (None, [vp]),
         "go_divergence": (None, [vp, vp]),
         "go_tracer_advection": (None, [vp, vp, d]),
+        "go_sim_set_viscosity": (None, [vp, i, d]),
+        "go_sim_diffusion_params": (C.POINTER(MultilevelParams), [vp, i]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -215,6 +217,7 @@ class Sim:
             L._sim_ready = True
         s = (C.c_int * 6)(*(side if side is not None else [SIDE_BOUNDARY] * 6))
         self.dim, self.depth = dim, depth
+        self.end = 1.7976931348623157e308
         self.ptr = L.go_sim_new(dim, depth, s)
         self.dom = _DomView(dim, depth, L.go_sim_domain(self.ptr), list(s))
         self.p = self.field(self.P)
@@ -241,7 +244,15 @@ class Sim:
         n = (1 << self.depth) + 2
         return np.ctypeslib.as_array(lib().go_sim_fv(self.ptr, d), shape=(n,) * self.dim)
 
+    def set_viscosity(self, c, nu):
+        """SourceDiffusion {} U|V|W nu (implicit, Crank-Nicholson beta = 1 by default)"""
+        lib().go_sim_set_viscosity(self.ptr, c, nu)
+
+    def diffusion_params(self, c):
+        return lib().go_sim_diffusion_params(self.ptr, c).contents
+
     def set_time(self, end=1.7976931348623157e308, dtmax=1.7976931348623157e308):
+        self.end = end
         lib().go_sim_set_time(self.ptr, end, dtmax)
 
     @property
@@ -261,6 +272,25 @@ class Sim:
 
     def step(self):
         lib().go_sim_step(self.ptr)
+
+    def output_location(self, points, fields):
+        """GfsOutputLocation (src/output.c:1153-1203): locate each point, then gfs_interpolate of
+        every field there; rows of points outside the domain are dropped."""
+        L = lib()
+        pd = C.POINTER(C.c_double)
+        L.go_locate.restype, L.go_locate.argtypes = C.c_int, [C.c_void_p, pd, C.POINTER(C.c_int)]
+        L.go_interpolate.restype = C.c_double
+        L.go_interpolate.argtypes = [C.c_void_p, pd, C.POINTER(C.c_int), pd]
+        rows = []
+        for p in np.asarray(points, dtype=np.float64).reshape(-1, 3):
+            p = np.ascontiguousarray(p)
+            ijk = (C.c_int * 3)()
+            if not L.go_locate(self.dom.ptr, p.ctypes.data_as(pd), ijk):
+                continue
+            rows.append(list(p) + [L.go_interpolate(self.dom.ptr,
+                                                    L.go_field_level(f.ptr, self.depth), ijk,
+                                                    p.ctypes.data_as(pd)) for f in fields])
+        return np.array(rows)
 
     def divergence_norm(self):
         e = self.dom.field()

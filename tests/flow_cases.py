@@ -56,3 +56,35 @@ def oracle_taylor_green(level):
     for c, a in enumerate(taylor_green_3d(x, y, z)):
         s.u[c].interior()[...] = a
     return s
+
+
+def oracle_lid(level=6, nu=1e-3):
+    # test/lid/lid.gfs: unit box, Dirichlet walls, lid U = 1 on top, SourceDiffusion U/V nu
+    s = O.Sim(2, level, [O.SIDE_BOUNDARY] * 6)
+    n = 1 << level
+    for c in range(2):
+        for d in range(4):
+            val = np.full(n, 1. if (c == 0 and d == 2) else 0.)
+            s.u[c].set_bc(d, O.BC_DIRICHLET, val)
+        s.set_viscosity(c, nu)
+    s.set_time(end=300.)
+    return s
+
+
+def run_until_steady(s, var, every=10, tol=1e-4, max_steps=100000):
+    """simulation_run with GfsEventStop { istep = every } var tol (src/event.c:1797-1835): every
+    `every` steps (and at step 0) compare var with its previous copy; stop when max|diff| <= tol."""
+    s.start()
+    old = None
+    hist = []
+    while s.t < s.end and s.i < max_steps:
+        if s.i % every == 0:
+            cur = var.interior().copy()
+            if old is not None:
+                du = np.abs(cur - old).max()
+                hist.append((s.i, s.t, du))
+                if du <= tol:
+                    break
+            old = cur
+        s.step()
+    return hist

@@ -64,3 +64,23 @@ def test_periodic_r0_matches_ref(golden_dir):
         e.interior()[...] = s.u[0].interior() - exact
         nm = O.lib().go_norm_variable(s.dom.ptr, e.ptr)
         assert ["%.3e" % nm.second, "%.3e" % nm.infty] == row[1:3], (level, nm.second, nm.infty, row)
+
+
+def test_lid_driven_cavity_ghia(golden_dir):
+    """test/lid (BASELINE config A): 64^2 lid-driven cavity at Re = 1000 with implicit viscosity,
+    run to the GfsEventStop steady state, then OutputLocation profiles against Ghia et al. with
+    the tolerances of test/lid/lid.sh:11-12 (Curve difference, infinity norm)."""
+    from flow_cases import oracle_lid, run_until_steady
+    s = oracle_lid()
+    hist = run_until_steady(s, s.u[0])
+    assert hist[-1][2] <= 1e-4 and s.t < 300.
+    g = os.path.join(golden_dir, "reference")
+    xp = s.output_location(np.loadtxt(os.path.join(g, "lid_xprofile")), [s.u[0], s.u[1]])
+    yp = s.output_location(np.loadtxt(os.path.join(g, "lid_yprofile")), [s.u[0], s.u[1]])
+    gx = np.loadtxt(os.path.join(g, "xprof.ghia"))
+    gy = np.loadtxt(os.path.join(g, "yprof.ghia"))
+    # Curve('xprof',3,7) - Curve('xprof.ghia',1,2): U(y) on x = 0 interpolated at Ghia's abscissae
+    ex = np.abs(np.interp(gx[:, 0], xp[:, 1], xp[:, 3]) - gx[:, 1]).max()
+    # Curve('yprof',2,8) - Curve('yprof.ghia',1,2): V(x) on y = 0
+    ey = np.abs(np.interp(gy[:, 0], yp[:, 0], yp[:, 4]) - gy[:, 1]).max()
+    assert ex <= 2e-2 and ey <= 1.7e-2, (ex, ey)
