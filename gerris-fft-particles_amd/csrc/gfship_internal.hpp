@@ -51,6 +51,13 @@ struct SkewPlan {
   unsigned short * order = nullptr;
 };
 
+// cell update of the exact-order sweeps: kind 0 = Poisson relax (unit weights), kind 1 =
+// diffusion_relax with the level's uniform face weight w and h2 = h*h
+struct RelaxOp {
+  int kind = 0;
+  double w = 1., h2 = 1.;
+};
+
 // device-side description of the six sides for the BC kernel
 struct BcDesc {
   int side[6];
@@ -80,6 +87,9 @@ struct gfship_domain {
   bool force_hyperplane = false;  // debug/bench: per-hyperplane launches instead of relax_skew
   bool unit_weights = false;      // gfship_poisson_coefficients called with alpha = NULL
   gfship::SkewPlan skew[GFSHIP_MAXLEVEL + 1];
+  double diff_w[GFSHIP_MAXLEVEL + 1] = {};  // diffusion face weight of each level
+  gfship_field res_cache = -1;    // the `res` temporary of gfs_diffusion
+  bool diff_ready = false;        // gfship_diffusion_coefficients called
 };
 
 namespace gfship {
@@ -103,10 +113,11 @@ int launch_bc (gfship_domain * dom, Field * v, Field * v1, int level, int homoge
 int call_exchange (gfship_domain * dom, double * ptr, int level, int kind);
 int call_reduce (gfship_domain * dom, double * vals, int n, int op);
 int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, double omega,
-			double * u, const double * rhs, const double * dia);
+			double * u, const double * rhs, const double * dia,
+			const RelaxOp * op = nullptr);
 int launch_relax_loop_small (gfship_domain * dom, unsigned dimension, int level, double omega,
 			     Field * dp, Field * ubc, const double * rhs, const double * dia,
-			     unsigned nrelax, bool * done);
+			     unsigned nrelax, bool * done, const RelaxOp * op = nullptr);
 int launch_relax_redblack (gfship_domain * dom, unsigned dimension, int level, double omega,
 			   double * u, const double * rhs, const double * dia);
 int launch_residual (gfship_domain * dom, int level, const double * u, const double * rhs,
@@ -128,13 +139,14 @@ int launch_centered_gradient (gfship_domain * dom, const double * p, double * co
 int launch_correct_centered (gfship_domain * dom, double * const u[3], double * const g[3], double dt);
 int launch_advected_face_values (gfship_domain * dom, const double * v, double * const u[3],
 				 double * const un[3], double dt, int use_centered, int gradient,
-				 double * const fv[6], int cmask);
+				 double * const fv[6], int cmask, double visc = 0.);
 int launch_face_bc (gfship_domain * dom, Field * v, double * const fv[6], int cmask);
 int launch_predict_un (gfship_domain * dom, int cc, const double * uc, double * const fv[6],
 		       double * unc);
 int launch_flux_update (gfship_domain * dom, bool velocity, double * v, double * const un[3],
 			double * const fv[6], const double * gm, const double * gc, double dt);
-int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3], double * cfl2);
+int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3],
+		const double visc[3], double * cfl2);
 int launch_coarse_init (gfship_domain * dom, Field * const * v, int nf);
 int launch_velocity_divergence (gfship_domain * dom, double * const u[3], double * out);
 

@@ -11,12 +11,30 @@ namespace gfship {
 // ---------------------------------------------------------------------------------------------
 // K1: relax / relax2D, src/poisson.c:507-557, with face_weighted_gradient's same-level branch
 // (src/fluid.c:858-864: g->a = w; g->b = w*u_nb) for w == 1.
+//
+// OP == 1 is diffusion_relax, src/poisson.c:1455-1484, with gfs_face_cm_weighted_gradient's
+// same-level branch (src/fluid.c:1361-1366: g->a = w; g->b = w*u_nb) for the uniform face
+// weight w of the level and h2 = h*h:  a = dia*h*h ; g.a = 1. + g.a/a ; u = (g.b/a + res)/g.a.
 // ---------------------------------------------------------------------------------------------
-template <int DIM>
+template <int DIM, int OP>
 __device__ __forceinline__ double relax_value (const double * __restrict__ u, long c, long sy, long sz,
 					       double rhs, double dia, unsigned dimension,
-					       double omega)
+					       double omega, double w, double h2)
 {
+  if (OP == 1) {
+    double ga = 0., gb = 0.;
+    ga += w; gb += w*u[c + 1];
+    ga += w; gb += w*u[c - 1];
+    ga += w; gb += w*u[c + sy];
+    ga += w; gb += w*u[c - sy];
+    if (DIM == 3) {
+      ga += w; gb += w*u[c + sz];
+      ga += w; gb += w*u[c - sz];
+    }
+    double a = dia*h2;
+    ga = 1. + ga/a;
+    return (gb/a + rhs)/ga;
+  }
   double a = dia, b = 0.;
   a += 1.; b += 1.*u[c + 1];
   a += 1.; b += 1.*u[c - 1];
@@ -38,9 +56,9 @@ __device__ __forceinline__ double relax_value (const double * __restrict__ u, lo
 // is visited first, and that orientation is (+x, -y, -z) for every pair, so any topological
 // order of it -- here hyperplanes -- is bit-identical (tests/test_oracle_golden_poisson.py
 // checks the claim on the oracle).
-template <int DIM>
+template <int DIM, int OP>
 __global__ void __launch_bounds__(256)
-relax_hyperplane_kernel (Layout L, int plane, unsigned dimension, double omega,
+relax_hyperplane_kernel (Layout L, int plane, unsigned dimension, double omega, double w, double h2,
 			 double * __restrict__ u, const double * __restrict__ rhs,
 			 const double * __restrict__ dia)
 {
@@ -59,12 +77,14 @@ relax_hyperplane_kernel (Layout L, int plane, unsigned dimension, double omega,
   }
   if (I < 0 || I >= n) return;
   long c = L.idx (I + 1, n - J, DIM == 3 ? n - K : 0);
-  u[c] = relax_value<DIM> (u, c, L.sy, L.sz, rhs[c], dia[c], dimension, omega);
+  u[c] = relax_value<DIM, OP> (u, c, L.sy, L.sz, rhs[c], dia[c], dimension, omega, w, h2);
 }
 
 int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, double omega,
-			double * u, const double * rhs, const double * dia)
+			double * u, const double * rhs, const double * dia, const RelaxOp * op)
 {
+  const int kind = op ? op->kind : 0;
+  const double w = op ? op->w : 1., h2 = op ? op->h2 : 1.;
   const Layout & L = dom->lay[level];
   int n = L.n;
   int nplanes = dom->dim == 3 ? 3*n - 2 : 2*n - 1;
@@ -72,12 +92,11 @@ int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, doub
   int block = 256;
   int grid = (nthreads + block - 1)/block;
   for (int p = 0; p < nplanes; p++) {
-    if (dom->dim == 3)
-      hipLaunchKernelGGL (relax_hyperplane_kernel<3>, dim3 (grid), dim3 (block), 0, dom->stream,
-			  L, p, dimension, omega, u, rhs, dia);
-    else
-      hipLaunchKernelGGL (relax_hyperplane_kernel<2>, dim3 (grid), dim3 (block), 0, dom->stream,
-			  L, p, dimension, omega, u, rhs, dia);
+#define HP_LAUNCH(D, O) hipLaunchKernelGGL ((relax_hyperplane_kernel<D, O>), dim3 (grid), dim3 (block), \
+					    0, dom->stream, L, p, dimension, omega, w, h2, u, rhs, dia)
+    if (dom->dim == 3) { if (kind) HP_LAUNCH (3, 1); else HP_LAUNCH (3, 0); }
+    else               { if (kind) HP_LAUNCH (2, 1); else HP_LAUNCH (2, 0); }
+#undef HP_LAUNCH
   }
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
@@ -106,10 +125,10 @@ __device__ __forceinline__ double ghost_value (int type, int component, int c, d
 // The level (with ghosts) lives in LDS with the compact (n+2)^DIM layout; rhs and dia are
 // read from global memory.  Hyperplanes are separated by workgroup barriers.
 // ---------------------------------------------------------------------------------------------
-template <int DIM>
+template <int DIM, int OP>
 __global__ void __launch_bounds__(1024)
-relax_loop_lds_kernel (Layout L, BcDesc bc, unsigned dimension, double omega, unsigned nrelax,
-		       double * __restrict__ u, const double * __restrict__ rhs,
+relax_loop_lds_kernel (Layout L, BcDesc bc, unsigned dimension, double omega, double w, double h2,
+		       unsigned nrelax, double * __restrict__ u, const double * __restrict__ rhs,
 		       const double * __restrict__ dia)
 {
   extern __shared__ double s[];
@@ -161,7 +180,7 @@ relax_loop_lds_kernel (Layout L, BcDesc bc, unsigned dimension, double omega, un
 	  int i = I + 1, j = n - J, k = DIM == 3 ? n - K : 0;
 	  long c = i + ssy*j + ssz*k;
 	  long g = L.idx (i, j, k);
-	  s[c] = relax_value<DIM> (s, c, ssy, ssz, rhs[g], dia[g], dimension, omega);
+	  s[c] = relax_value<DIM, OP> (s, c, ssy, ssz, rhs[g], dia[g], dimension, omega, w, h2);
 	}
       }
       __syncthreads ();
@@ -187,8 +206,10 @@ static bool lds_fits (const gfship_domain * dom, int level, size_t * bytes)
 
 int launch_relax_loop_small (gfship_domain * dom, unsigned dimension, int level, double omega,
 			     Field * dp, Field * ubc, const double * rhs, const double * dia,
-			     unsigned nrelax, bool * done)
+			     unsigned nrelax, bool * done, const RelaxOp * op)
 {
+  const int kind = op ? op->kind : 0;
+  const double w = op ? op->w : 1., h2 = op ? op->h2 : 1.;
   size_t bytes;
   *done = false;
   for (int d = 0; d < 2*dom->dim; d++)
@@ -207,12 +228,12 @@ int launch_relax_loop_small (gfship_domain * dom, unsigned dimension, int level,
   bc.homogeneous = 1;
   int nface = dom->dim == 3 ? L.n*L.n : L.n;
   int block = nface <= 64 ? 64 : nface <= 256 ? 256 : 1024;
-  if (dom->dim == 3)
-    hipLaunchKernelGGL (relax_loop_lds_kernel<3>, dim3 (1), dim3 (block), bytes, dom->stream,
-			L, bc, dimension, omega, nrelax, dp->lev[level], rhs, dia);
-  else
-    hipLaunchKernelGGL (relax_loop_lds_kernel<2>, dim3 (1), dim3 (block), bytes, dom->stream,
-			L, bc, dimension, omega, nrelax, dp->lev[level], rhs, dia);
+#define LDS_LAUNCH(D, O) hipLaunchKernelGGL ((relax_loop_lds_kernel<D, O>), dim3 (1), dim3 (block), bytes, \
+					     dom->stream, L, bc, dimension, omega, w, h2, nrelax, \
+					     dp->lev[level], rhs, dia)
+  if (dom->dim == 3) { if (kind) LDS_LAUNCH (3, 1); else LDS_LAUNCH (3, 0); }
+  else               { if (kind) LDS_LAUNCH (2, 1); else LDS_LAUNCH (2, 0); }
+#undef LDS_LAUNCH
   GFSHIP_HIP (hipGetLastError ());
   *done = true;
   return GFSHIP_OK;
@@ -237,7 +258,7 @@ relax_redblack_kernel (Layout L, int colour, unsigned dimension, double omega,
   int i = 2*ih + 1 + ((j + k + colour) & 1);
   if (i > n) return;
   long c = L.idx (i, j, k);
-  u[c] = relax_value<DIM> (u, c, L.sy, L.sz, rhs[c], dia[c], dimension, omega);
+  u[c] = relax_value<DIM, 0> (u, c, L.sy, L.sz, rhs[c], dia[c], dimension, omega, 1., 1.);
 }
 
 int launch_relax_redblack (gfship_domain * dom, unsigned dimension, int level, double omega,

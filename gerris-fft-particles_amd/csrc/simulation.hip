@@ -20,6 +20,9 @@ struct gfship_sim {
   gfship_advection_params advection_params;
   double t = 0., end = DBL_MAX, dtmax = DBL_MAX, tnext = 0.;
   unsigned i = 0, iend = G_MAXINT;
+  double visc[3] = {0., 0., 0.};   // GfsSourceDiffusion on U, V, W (constant coefficient)
+  gfship_multilevel_params diffusion_params[3];
+  gfship_field drhs = -1, rhoc = -1;   // temporaries of variable_diffusion
 };
 
 namespace {
@@ -96,14 +99,20 @@ int face_values_set (gfship_sim * s, gfship_field v, double dt, int use_centered
   ptrs3 (s, s->u, u);
   ptrs3 (s, s->un, un);
   ptrs6 (s, fv);
-  TRY (launch_advected_face_values (s->dom, leaf (s, v), u, un, dt, use_centered, gradient, fv, cmask));
+  /* v->sources: the implicit diffusion of a velocity component acts as MAC source */
+  double visc = 0.;
+  for (int c = 0; c < s->dom->dim; c++)
+    if (v == s->u[c])
+      visc = s->visc[c];
+  TRY (launch_advected_face_values (s->dom, leaf (s, v), u, un, dt, use_centered, gradient, fv, cmask,
+				    visc));
   TRY (launch_face_bc (s->dom, get_field (s->dom, v), fv, cmask));
   return GFSHIP_OK;
 }
 
-// variable_sources, src/timestep.c:872-921 (Godunov, no sources)
-int variable_sources (gfship_sim * s, gfship_field v, int gradient, bool velocity, double dt,
-		      const gfship_field gmac[3], const gfship_field g[3])
+// variable_sources, src/timestep.c:872-921 (Godunov; the update goes into sv)
+int variable_sources (gfship_sim * s, gfship_field v, gfship_field sv, int gradient, bool velocity,
+		      double dt, const gfship_field gmac[3], const gfship_field g[3])
 {
   double * un[3], * fv[6];
   ptrs3 (s, s->un, un);
@@ -112,7 +121,23 @@ int variable_sources (gfship_sim * s, gfship_field v, int gradient, bool velocit
   int c = s->dom->fields[v].component;
   const double * gm = velocity ? leaf (s, gmac[c]) : nullptr;
   const double * gc = (velocity && g) ? leaf (s, g[c]) : nullptr;
-  TRY (launch_flux_update (s->dom, velocity, leaf (s, v), un, fv, gm, gc, dt));
+  s->dom->fields[sv].zero[s->dom->depth] = false;
+  TRY (launch_flux_update (s->dom, velocity, leaf (s, sv), un, fv, gm, gc, dt));
+  return GFSHIP_OK;
+}
+
+// variable_diffusion, src/timestep.c:923-949
+int variable_diffusion (gfship_sim * s, int c, gfship_field rhs)
+{
+  gfship_domain * dom = s->dom;
+  gfship_multilevel_params * par = &s->diffusion_params[c];
+  double dt = s->advection_params.dt;
+  if (s->rhoc < 0)
+    s->rhoc = gfship_field_alloc (dom, -1);
+  if (s->rhoc < 0) return s->rhoc;
+  TRY (gfship_diffusion_coefficients (dom, s->visc[c], dt, s->rhoc, par->beta));
+  TRY (gfship_diffusion_rhs (dom, s->u[c], rhs, s->rhoc, par->beta));
+  TRY (gfship_diffusion (dom, par, s->u[c], rhs, s->rhoc));
   return GFSHIP_OK;
 }
 
@@ -157,6 +182,10 @@ int gfship_sim_create (gfship_sim ** out, gfship_domain * dom)
   s->res = alloc (-1);
   gfship_multilevel_params_init (&s->projection_params, dom->dim);
   gfship_multilevel_params_init (&s->approx_projection_params, dom->dim);
+  for (int c = 0; c < 3; c++) { /* diffusion_init, src/source.c:966-974 */
+    gfship_multilevel_params_init (&s->diffusion_params[c], dom->dim);
+    s->diffusion_params[c].tolerance = 1e-6;
+  }
   /* gfs_advection_params_init, src/advection.c:922-942 */
   s->advection_params.cfl = 0.8;
   s->advection_params.dt = 0.;
@@ -178,7 +207,7 @@ void gfship_sim_destroy (gfship_sim * s)
   fr (s->p); fr (s->pmac);
   for (int c = 0; c < 3; c++) { fr (s->u[c]); fr (s->g[c]); fr (s->gmac[c]); fr (s->un[c]); }
   for (int d = 0; d < 6; d++) fr (s->fv[d]);
-  fr (s->dia); fr (s->div); fr (s->res);
+  fr (s->dia); fr (s->div); fr (s->res); fr (s->drhs); fr (s->rhoc);
   for (gfship_field t : s->tracers) fr (t);
   delete s;
 }
@@ -219,6 +248,18 @@ int gfship_sim_set_time (gfship_sim * s, double end, double dtmax)
 
 double gfship_sim_time (gfship_sim * s) { return s ? s->t : 0.; }
 unsigned gfship_sim_iter (gfship_sim * s) { return s ? s->i : 0; }
+
+int gfship_sim_set_viscosity (gfship_sim * s, int c, double nu)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  GFSHIP_CHECK (c >= 0 && c < s->dom->dim, GFSHIP_EINVAL, "component %d out of range", c);
+  GFSHIP_CHECK (nu >= 0., GFSHIP_EINVAL, "the diffusion coefficient must be positive");
+  s->visc[c] = nu;
+  return GFSHIP_OK;
+}
+
+gfship_multilevel_params * gfship_sim_diffusion_params (gfship_sim * s, int c)
+{ return (s && c >= 0 && c < 3) ? &s->diffusion_params[c] : nullptr; }
 
 int gfship_sim_add_tracer (gfship_sim * s)
 {
@@ -269,9 +310,25 @@ int gfship_centered_velocity_advection (gfship_sim * s, const gfship_field gmac[
 					const gfship_field g[3])
 {
   GFSHIP_CHECK (s && gmac, GFSHIP_EINVAL, "null argument");
-  for (int c = 0; c < s->dom->dim; c++)
-    TRY (variable_sources (s, s->u[c], s->advection_params.gradient, true,
-			   s->advection_params.dt, gmac, g));
+  for (int c = 0; c < s->dom->dim; c++) {
+    if (s->visc[c] != 0.) {
+      /* source_diffusion (v[c]): rhs = copy of v on the leaves, sources into rhs, implicit
+	 solve (src/timestep.c:996-1007) */
+      gfship_domain * dom = s->dom;
+      if (s->drhs < 0)
+	s->drhs = gfship_field_alloc (dom, -1);
+      if (s->drhs < 0) return s->drhs;
+      GFSHIP_HIP (hipMemcpyAsync (leaf (s, s->drhs), leaf (s, s->u[c]),
+				  dom->lay[dom->depth].total*sizeof (double),
+				  hipMemcpyDeviceToDevice, dom->stream));
+      TRY (variable_sources (s, s->u[c], s->drhs, s->advection_params.gradient, true,
+			     s->advection_params.dt, gmac, g));
+      TRY (variable_diffusion (s, c, s->drhs));
+    }
+    else
+      TRY (variable_sources (s, s->u[c], s->u[c], s->advection_params.gradient, true,
+			     s->advection_params.dt, gmac, g));
+  }
   for (int c = 0; c < s->dom->dim; c++)
     TRY (bc_leaf (s, s->u[c]));
   return GFSHIP_OK;
@@ -282,7 +339,7 @@ int gfship_tracer_advection (gfship_sim * s, gfship_field t, double dt)
   GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
   if (!get_field (s->dom, t)) return GFSHIP_EINVAL;
   /* tracers: van Leer gradient + gfs_face_advection_flux (src/variable.c:427-431) */
-  TRY (variable_sources (s, t, 1, false, dt, nullptr, nullptr));
+  TRY (variable_sources (s, t, t, 1, false, dt, nullptr, nullptr));
   TRY (bc_leaf (s, t));
   return GFSHIP_OK;
 }
@@ -294,7 +351,7 @@ int gfship_domain_cfl (gfship_sim * s, double * cfl)
   ptrs3 (s, s->u, u);
   ptrs3 (s, s->un, un);
   double c2;
-  TRY (launch_cfl (s->dom, u, un, &c2));
+  TRY (launch_cfl (s->dom, u, un, s->visc, &c2));
   *cfl = sqrt (c2);
   return GFSHIP_OK;
 }

@@ -50,6 +50,7 @@ struct Ptr3  { double * p[3]; };
 struct CPtr3 { const double * p[3]; };
 struct Ptr6  { double * p[6]; };
 struct CPtr6 { const double * p[6]; };
+struct Visc3 { double d[3]; };
 
 // gfs_face_interpolated_value, src/fluid.c:2186-2198, same-level neighbour (x1 = 1.)
 __device__ __forceinline__ double face_interp (double v0, double v1)
@@ -183,10 +184,28 @@ __device__ __forceinline__ double van_leer_gradient (double v0, double v1, doubl
   return s1;
 }
 
+// source_diffusion_value, src/source.c:1105-1144: the explicit diffusion term of an implicit
+// GfsSourceDiffusion with constant coefficient D (gfs_face_gradient at the cell's level:
+// e.a = 1., e.b = neighbour value), used as MAC source of the predictor and in the CFL scale
+template <int DIM>
+__device__ __forceinline__ double source_diffusion_value (const double * __restrict__ v, long c,
+							  const long * off, double D, double h)
+{
+  double ga = 0., gb = 0.;
+  const double v0 = v[c];
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++) {
+    ga += D*1.; gb += D*v[c + off[cc]];
+    ga += D*1.; gb += D*v[c - off[cc]];
+  }
+  return 1.*(gb - ga*v0)/(h*h);
+}
+
 template <int DIM>
 __global__ void __launch_bounds__(256)
 advected_face_values_kernel (Layout L, const double * __restrict__ v, CPtr3 u, CPtr3 un,
-			     double dt, int use_centered_velocity, int gradient, Ptr6 fv, int cmask)
+			     double dt, int use_centered_velocity, int gradient, Ptr6 fv, int cmask,
+			     double visc)
 {
   CELL_PROLOGUE (L);
   const long off[3] = { 1, L.sy, L.sz };
@@ -216,7 +235,11 @@ advected_face_values_kernel (Layout L, const double * __restrict__ v, CPtr3 u, C
     double g = gradient ? van_leer_gradient (v0, v1, v2) : center_gradient (v0, v1, v2);
     double vl = v0 + GMIN ((1. - unorm)/2., 0.5)*g;
     double vr = v0 + GMAX ((- 1. - unorm)/2., -0.5)*g;
-    double src = dt*0./2.;
+    /* gfs_variable_mac_source, src/source.c:38-59 */
+    double msrc = 0.;
+    if (visc != 0.)
+      msrc = 0. + source_diffusion_value<DIM> (v, c, off, visc, size);
+    double src = dt*msrc/2.;
     double dv;
     if (DIM == 2)
       dv = tt[(cc + 1) % 2];
@@ -388,7 +411,7 @@ __device__ __forceinline__ double wave_min (double v)
 
 template <int DIM>
 __global__ void __launch_bounds__(256)
-cfl_partial_kernel (Layout L, CPtr3 u, CPtr3 un, double * __restrict__ partial)
+cfl_partial_kernel (Layout L, CPtr3 u, CPtr3 un, Visc3 visc, double * __restrict__ partial)
 {
   const int n = L.n;
   const double length = 1./n;
@@ -417,9 +440,16 @@ cfl_partial_kernel (Layout L, CPtr3 u, CPtr3 un, double * __restrict__ partial)
 	  double cflu = length/fabs (1.*uv);
 	  m = fmin (m, cflu*cflu);
 	}
+	if (visc.d[cc] != 0. && i <= n && j <= n && (DIM == 2 || k <= n)) {
+	  /* p->v[c]->sources: acceleration time scale, src/domain.c:2893-2901 */
+	  double g = 0. + source_diffusion_value<DIM> (u.p[cc], c, off, visc.d[cc], length);
+	  if (g != 0.) {
+	    double cflg = 2.*length/fabs (1.*g);
+	    m = fmin (m, cflg);
+	  }
+	}
       }
     }
-    (void) off;
   }
   __shared__ double sh[4];
   m = wave_min (m);
@@ -550,13 +580,13 @@ int launch_correct_centered (gfship_domain * dom, double * const u[3], double * 
 
 int launch_advected_face_values (gfship_domain * dom, const double * v, double * const u[3],
 				 double * const un[3], double dt, int use_centered, int gradient,
-				 double * const fv[6], int cmask)
+				 double * const fv[6], int cmask, double visc)
 {
   const Layout & L = dom->lay[dom->depth];
   dim3 grid, block;
   cell_grid (L, &grid, &block);
   DISPATCH (dom, advected_face_values_kernel, grid, block, L, v, c3 (u), c3 (un), dt,
-	    use_centered, gradient, m6 (fv), cmask);
+	    use_centered, gradient, m6 (fv), cmask, visc);
   return GFSHIP_OK;
 }
 
@@ -623,8 +653,11 @@ int launch_flux_update (gfship_domain * dom, bool velocity, double * v, double *
   return GFSHIP_OK;
 }
 
-int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3], double * cfl2)
+int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3],
+		const double visc[3], double * cfl2)
 {
+  Visc3 vs;
+  for (int c = 0; c < 3; c++) vs.d[c] = visc ? visc[c] : 0.;
   const Layout & L = dom->lay[dom->depth];
   long r = L.n + 1;
   long next = dom->dim == 3 ? r*r*r : r*r;
@@ -633,7 +666,7 @@ int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3], 
   if (nblocks > 1024) nblocks = 1024;
   double * partial = dom->d_scratch;
   double * result = dom->d_scratch + 5*1024;
-  DISPATCH (dom, cfl_partial_kernel, dim3 (nblocks), dim3 (block), L, c3 (u), c3 (un), partial);
+  DISPATCH (dom, cfl_partial_kernel, dim3 (nblocks), dim3 (block), L, c3 (u), c3 (un), vs, partial);
   hipLaunchKernelGGL (min_final_kernel, dim3 (1), dim3 (256), 0, dom->stream, partial, nblocks, result);
   GFSHIP_HIP (hipGetLastError ());
   GFSHIP_HIP (hipMemcpyAsync (dom->h_pinned, result, sizeof (double), hipMemcpyDeviceToHost,

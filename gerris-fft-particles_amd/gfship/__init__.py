@@ -6,6 +6,7 @@ loudly when the HIP library is missing, and creating a domain fails without a de
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -73,6 +74,11 @@ SIGNATURES = {
     "gfship_norm_variable": (_i, [_vp, _i, C.POINTER(Norm)]),
     "gfship_poisson_cycle": (_i, [_vp, C.POINTER(MultilevelParams), _i, _i, _i, _i]),
     "gfship_poisson_solve": (_i, [_vp, C.POINTER(MultilevelParams), _i, _i, _i, _i, _d]),
+    "gfship_diffusion_coefficients": (_i, [_vp, _d, _d, _i, _d]),
+    "gfship_diffusion_rhs": (_i, [_vp, _i, _i, _i, _d]),
+    "gfship_diffusion_residual": (_i, [_vp, _i, _i, _i, _i]),
+    "gfship_diffusion_cycle": (_i, [_vp, _u, _u, _u, _i, _i, _i, _i]),
+    "gfship_diffusion": (_i, [_vp, C.POINTER(MultilevelParams), _i, _i, _i]),
     "gfship_time_relax": (_i, [_vp, _u, _i, _i, _i, _i, _i, _pd]),
     "gfship_sim_create": (_i, [C.POINTER(_vp), _vp]),
     "gfship_sim_destroy": (None, [_vp]),
@@ -84,6 +90,8 @@ SIGNATURES = {
     "gfship_sim_time": (_d, [_vp]),
     "gfship_sim_iter": (_u, [_vp]),
     "gfship_sim_add_tracer": (_i, [_vp]),
+    "gfship_sim_set_viscosity": (_i, [_vp, _i, _d]),
+    "gfship_sim_diffusion_params": (C.POINTER(MultilevelParams), [_vp, _i]),
     "gfship_sim_start": (_i, [_vp]),
     "gfship_sim_step": (_i, [_vp]),
     "gfship_predicted_face_velocities": (_i, [_vp]),
@@ -115,6 +123,16 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise GfshipError("%s not found: run __graft_entry__.build() "
                               "(gerris-fft-particles_amd/csrc/build.sh)" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64
+        # and loads them by unversioned names, so if libgfship pulled in /opt/rocm's copy first a
+        # later `import torch` would start a second HSA runtime that finds no GPU.  Loading torch
+        # first makes libgfship's NEEDED libamdhip64.so.7 resolve to the already loaded runtime.
+        # (A C host that never loads torch uses /opt/rocm's runtime directly.)
+        if "torch" not in sys.modules and os.environ.get("GFSHIP_NO_TORCH") is None:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)   # AttributeError if the library lacks a declared symbol
@@ -228,6 +246,22 @@ class Domain:
     def poisson_solve(self, par, lhs, rhs, res, dia, dt=1.):
         _check(lib().gfship_poisson_solve(self.ptr, C.byref(par), lhs.h, rhs.h, res.h, dia.h, dt))
 
+    def diffusion_coefficients(self, D, dt, rhoc, beta=1.):
+        _check(lib().gfship_diffusion_coefficients(self.ptr, D, dt, rhoc.h, beta))
+
+    def diffusion_rhs(self, v, rhs, rhoc, beta=1.):
+        _check(lib().gfship_diffusion_rhs(self.ptr, v.h, rhs.h, rhoc.h, beta))
+
+    def diffusion_residual(self, u, rhs, rhoc, res):
+        _check(lib().gfship_diffusion_residual(self.ptr, u.h, rhs.h, rhoc.h, res.h))
+
+    def diffusion_cycle(self, levelmin, nrelax, u, rhs, rhoc, res):
+        _check(lib().gfship_diffusion_cycle(self.ptr, levelmin, self.depth, nrelax,
+                                            u.h, rhs.h, rhoc.h, res.h))
+
+    def diffusion(self, par, v, rhs, rhoc):
+        _check(lib().gfship_diffusion(self.ptr, C.byref(par), v.h, rhs.h, rhoc.h))
+
     def time_relax(self, u, rhs, dia, level=None, reps=10, d=None):
         level = self.depth if level is None else level
         ms = C.c_double()
@@ -266,6 +300,7 @@ class Simulation:
         p = _vp()
         _check(lib().gfship_sim_create(C.byref(p), dom.ptr))
         self.ptr = p
+        self.end = 1.7976931348623157e308
         L = lib()
         dim = dom.dim
         self.p = self._var(self.VAR_P)
@@ -280,11 +315,19 @@ class Simulation:
     def _var(self, which, c=0):
         return _SimVariable(self.dom, _check(lib().gfship_sim_variable(self.ptr, which, c)))
 
+    def set_viscosity(self, c, nu):
+        """SourceDiffusion {} U|V|W nu"""
+        _check(lib().gfship_sim_set_viscosity(self.ptr, c, nu))
+
+    def diffusion_params(self, c):
+        return lib().gfship_sim_diffusion_params(self.ptr, c).contents
+
     def add_tracer(self):
         t = _check(lib().gfship_sim_add_tracer(self.ptr))
         return self._var(self.VAR_TRACER, t)
 
     def set_time(self, end=1.7976931348623157e308, dtmax=1.7976931348623157e308):
+        self.end = end
         _check(lib().gfship_sim_set_time(self.ptr, end, dtmax))
 
     @property

@@ -130,6 +130,27 @@ int  gfship_poisson_solve (gfship_domain * dom, gfship_multilevel_params * par,
 			   gfship_field lhs, gfship_field rhs, gfship_field res,
 			   gfship_field dia, double dt);
 
+/* ---- implicit diffusion (GfsSourceDiffusion with a constant coefficient, no solids) ---------- */
+
+/* gfs_diffusion_coefficients, src/poisson.c:1357-1390: face weights lambda2*beta*dt*D on every
+   level (one scalar per level on a uniform box) and rhoc = 1. on every cell */
+int  gfship_diffusion_coefficients (gfship_domain * dom, double D, double dt, gfship_field rhoc,
+				    double beta);
+/* gfs_diffusion_rhs, src/poisson.c:1447-1453 (diffusion_rhs :1392-1436) */
+int  gfship_diffusion_rhs (gfship_domain * dom, gfship_field v, gfship_field rhs,
+			   gfship_field rhoc, double beta);
+/* gfs_diffusion_residual, src/poisson.c:1587-1612 (diffusion_residual :1519-1556) */
+int  gfship_diffusion_residual (gfship_domain * dom, gfship_field u, gfship_field rhs,
+				gfship_field rhoc, gfship_field res);
+/* gfs_diffusion_cycle, src/poisson.c:1633-1690 */
+int  gfship_diffusion_cycle (gfship_domain * dom, unsigned levelmin, unsigned depth,
+			     unsigned nrelax, gfship_field u, gfship_field rhs, gfship_field rhoc,
+			     gfship_field res);
+/* gfs_diffusion, src/timestep.c:735-788: the function installed in
+   GfsAdvectionParams.diffusion_solve (called at src/timestep.c:944) */
+int  gfship_diffusion (gfship_domain * dom, gfship_multilevel_params * par, gfship_field v,
+		       gfship_field rhs, gfship_field rhoc);
+
 /* ---- projection + advection time step (src/timestep.c, src/advection.c, src/simulation.c) -- */
 
 typedef struct gfship_sim gfship_sim;   /* GfsSimulation on one box, src/simulation.h:56-82 */
@@ -156,6 +177,11 @@ int      gfship_sim_set_time (gfship_sim * sim, double end, double dtmax); /* Gf
 double   gfship_sim_time (gfship_sim * sim);
 unsigned gfship_sim_iter (gfship_sim * sim);
 int      gfship_sim_add_tracer (gfship_sim * sim);       /* GfsVariableTracer, src/variable.c:427-431 */
+/* GfsSourceDiffusion {} U|V|W nu (src/source.c:933-1160): constant implicit viscosity of
+   velocity component c (0. removes it), and the GfsMultilevelParams of its solver
+   (tolerance 1e-6, beta 1: diffusion_init, src/source.c:966-974) */
+int      gfship_sim_set_viscosity (gfship_sim * sim, int c, double nu);
+gfship_multilevel_params * gfship_sim_diffusion_params (gfship_sim * sim, int c);
 /* simulation_run before its loop (src/simulation.c:458-476): BCs, first time step, initial
    approximate projection */
 int  gfship_sim_start (gfship_sim * sim);

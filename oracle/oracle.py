@@ -182,6 +182,7 @@ def _sim_sigs(L):
         "go_divergence": (None, [vp, vp]),
         "go_tracer_advection": (None, [vp, vp, d]),
         "go_sim_set_viscosity": (None, [vp, i, d]),
+        "go_variable_diffusion": (None, [vp, vp, vp, d, d, C.POINTER(MultilevelParams)]),
         "go_sim_diffusion_params": (C.POINTER(MultilevelParams), [vp, i]),
     }
     for name, (res, args) in sig.items():
@@ -247,6 +248,10 @@ class Sim:
     def set_viscosity(self, c, nu):
         """SourceDiffusion {} U|V|W nu (implicit, Crank-Nicholson beta = 1 by default)"""
         lib().go_sim_set_viscosity(self.ptr, c, nu)
+
+    def variable_diffusion(self, v, rhs, D, dt, par):
+        """variable_diffusion (src/timestep.c:923-949): implicit solve of v with source rhs"""
+        lib().go_variable_diffusion(self.ptr, v.ptr, rhs.ptr, D, dt, C.byref(par))
 
     def diffusion_params(self, c):
         return lib().go_sim_diffusion_params(self.ptr, c).contents

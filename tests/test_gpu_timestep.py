@@ -232,3 +232,133 @@ def test_two_boxes_with_mpi_sides_on_one_gpu_reproduce_single_box():
     for rank in range(2):
         gd, gs, hooks = sims[rank]
         _assert_same_state(osim, gs, "box %d" % rank)
+
+
+# ---------------------------------------------------------------------------------------------
+# implicit viscosity (GfsSourceDiffusion) and the lid-driven cavity, BASELINE config A
+# ---------------------------------------------------------------------------------------------
+
+def _device_lid(osim, level, nu):
+    side = [O.SIDE_BOUNDARY] * 6
+    gd, gs = _device_sim(osim, side)
+    n = 1 << level
+    nface = n ** (osim.dim - 1)
+    for c in range(osim.dim):
+        for d in range(2 * osim.dim):
+            val = np.full(nface, 1. if (c == 0 and d == 2) else 0.)
+            gs.u[c].set_bc(d, gfship.BC_DIRICHLET, val)
+        gs.set_viscosity(c, nu)
+    return gd, gs
+
+
+def _assert_same_diffusion(osim, gs, what):
+    for c in range(osim.dim):
+        a, b = osim.diffusion_params(c), gs.diffusion_params(c)
+        assert a.niter == b.niter, what
+        assert a.residual.infty == b.residual.infty, what
+        assert a.residual_before.infty == b.residual_before.infty, what
+
+
+def test_lid_2d_steps_bit_exact():
+    """test/lid/lid.gfs on 64^2: Dirichlet walls, implicit viscosity (diffusion multigrid, MAC
+    source term in the predictor, acceleration term of the CFL condition)"""
+    from flow_cases import oracle_lid
+    osim = oracle_lid(6, 1e-3)
+    gd, gs = _device_lid(osim, 6, 1e-3)
+    gs.set_time(end=300.)
+    osim.start()
+    gs.start()
+    _assert_same_state(osim, gs, "start")
+    for k in range(25):
+        osim.step()
+        gs.step()
+        _assert_same_state(osim, gs, "step %d" % k)
+        _assert_same_un(osim, gs, "step %d" % k)
+        _assert_same_diffusion(osim, gs, "step %d" % k)
+
+
+@pytest.mark.parametrize("level", [3, 5])
+def test_viscous_box_3d_steps_bit_exact(level):
+    """3-D lid-driven box with implicit viscosity: level 3 runs the LDS relax loop, level 5 the
+    per-hyperplane launches, both with the diffusion cell update"""
+    side = [O.SIDE_BOUNDARY] * 6
+    osim = O.Sim(3, level, side)
+    n = 1 << level
+    for c in range(3):
+        for d in range(6):
+            osim.u[c].set_bc(d, O.BC_DIRICHLET, np.full(n * n, 1. if (c == 0 and d == 2) else 0.))
+        osim.set_viscosity(c, 1e-2)
+    gd, gs = _device_lid(osim, level, 1e-2)
+    osim.start()
+    gs.start()
+    _assert_same_state(osim, gs, "start")
+    for k in range(3):
+        osim.step()
+        gs.step()
+        _assert_same_state(osim, gs, "step %d" % k)
+        _assert_same_diffusion(osim, gs, "step %d" % k)
+
+
+@pytest.mark.parametrize("dim,beta", [(2, 0.5), (3, 0.5), (2, 1.)])
+def test_diffusion_solver_matches_oracle(dim, beta):
+    """gfs_diffusion_coefficients / rhs / gfs_diffusion on their own, Crank-Nicholson
+    (beta = 0.5) included, on a periodic box with a random field"""
+    level = 4
+    osim = O.Sim(dim, level, PERIODIC)
+    rng = np.random.default_rng(11)
+    n = 1 << level
+    v0 = rng.standard_normal((n,) * dim)
+    ov, orhs = osim.dom.field(), osim.dom.field()
+    ov.interior()[...] = v0
+    orhs.interior()[...] = v0
+    O.lib().go_bc(ov.ptr, ov.ptr, level)
+    par = osim.diffusion_params(0)
+    par.beta = beta
+    osim.variable_diffusion(ov, orhs, 0.05, 0.1, par)
+
+    gd = gfship.Domain(dim, level, PERIODIC)
+    gv, grhs, grhoc = gd.variable(), gd.variable(), gd.variable()
+    gv.upload(_with_ghosts(v0, dim))
+    grhs.upload(_with_ghosts(v0, dim))
+    gd.bc(gv, gv, level)
+    gpar = gd.params()
+    gpar.tolerance = 1e-6
+    gpar.beta = beta
+    gd.diffusion_coefficients(0.05, 0.1, grhoc, beta)
+    gd.diffusion_rhs(gv, grhs, grhoc, beta)
+    gd.diffusion(gpar, gv, grhs, grhoc)
+    assert gpar.niter == par.niter and gpar.niter >= 1
+    assert gpar.residual.infty == par.residual.infty
+    assert np.array_equal(ov.interior(), _interior(gv.download(), dim))
+    assert np.array_equal(orhs.interior(), _interior(grhs.download(), dim))
+
+
+def test_lid_ghia_through_device(golden_dir):
+    """test/lid end to end on the device: run to the GfsEventStop steady state (U changes by
+    less than 1e-4 over 10 steps), same number of steps and bit-identical fields as the oracle,
+    then the Ghia et al. profile check of test/lid/lid.sh:11-12 on the device fields."""
+    from flow_cases import oracle_lid, run_until_steady
+    osim = oracle_lid(6, 1e-3)
+    gd, gs = _device_lid(osim, 6, 1e-3)
+    gs.set_time(end=300.)
+    ohist = run_until_steady(osim, osim.u[0])
+
+    class _U:   # the EventStop driver reads var.interior()
+        def interior(self):
+            return _interior(gs.u[0].download(), 2)
+    ghist = run_until_steady(gs, _U())
+    assert [(i, t) for i, t, _ in ghist] == [(i, t) for i, t, _ in ohist]
+    assert ghist[-1][2] == ohist[-1][2] <= 1e-4
+    _assert_same_state(osim, gs, "steady")
+    # profiles from the device fields (ghost layer included), interpolated like OutputLocation
+    chk = O.Sim(2, 6, [O.SIDE_BOUNDARY] * 6)
+    for c in range(2):
+        chk.u[c].leaf()[...] = gs.u[c].download()
+    g = os.path.join(golden_dir, "reference")
+    xp = chk.output_location(np.loadtxt(os.path.join(g, "lid_xprofile")), [chk.u[0], chk.u[1]])
+    yp = chk.output_location(np.loadtxt(os.path.join(g, "lid_yprofile")), [chk.u[0], chk.u[1]])
+    gx = np.loadtxt(os.path.join(g, "xprof.ghia"))
+    gy = np.loadtxt(os.path.join(g, "yprof.ghia"))
+    ex = np.abs(np.interp(gx[:, 0], xp[:, 1], xp[:, 3]) - gx[:, 1]).max()
+    ey = np.abs(np.interp(gy[:, 0], yp[:, 0], yp[:, 4]) - gy[:, 1]).max()
+    assert ex <= 2e-2 and ey <= 1.7e-2, (ex, ey)
