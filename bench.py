@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--level", type=int, default=8, help="Refine level (8 = 256^3)")
     ap.add_argument("--mode", default="exact", choices=["exact", "redblack"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--particles", type=int, default=2000000,
+                    help="tracers of the config D line (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,6 +149,37 @@ def main():
                 "kernel": "relax sweep, level %d (%d^3), mode %s" % (args.level, n, args.mode),
                 "ms_per_sweep": ms}
 
+    # config D: the same box with 2e6 GfsParticle tracers (positions from the
+    # fixed-seed LCG, ids 1..Np): the particle event alone, and the step with the event in it
+    particles = None
+    if world == 1 and args.particles > 0:
+        from particle_cases import lcg_positions_fast
+        pos, ids = lcg_positions_fast(args.particles)
+        pl = gfship.ParticleList(sim, pos, ids)
+        pl.event()
+        dom.synchronize()
+        nev = 32
+        t0 = time.perf_counter()
+        for _ in range(nev):
+            pl.event()
+        dom.synchronize()
+        t_event = (time.perf_counter() - t0) / nev
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pl.event()          # simulation_run: events first, then the flow step
+            sim.step()
+        dom.synchronize()
+        t_both = (time.perf_counter() - t0) / args.steps
+        particles = {"workload": "config D: %d tracers (RK2 midpoint, corner interpolation, "
+                                 "periodic wrap), slots re-sorted by cell every 16 events"
+                                 % args.particles,
+                     "n": args.particles, "events": nev,
+                     "value": args.particles / t_event / 1e6, "unit": "Mparticle-steps/s",
+                     "ms_per_event": t_event * 1e3,
+                     "combined_mcell_steps_per_s": n ** 3 / t_both / 1e6,
+                     "alive": pl.count()}
+        pl.destroy()
+
     if rank == 0:
         value = world * n ** 3 * args.steps / elapsed / 1e6
         out = {
@@ -166,6 +199,8 @@ def main():
                                          int(sim.approx_projection_params.niter)]},
             "roofline": roofline,
         }
+        if particles is not None:
+            out["particles"] = particles
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

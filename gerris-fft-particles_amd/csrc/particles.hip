@@ -11,7 +11,17 @@
 // (:2640-2683).  All in the reference's operand order: cell indices and positions are
 // bit-identical to the CPU algorithm.  The reference has no test for this path (parity pinned
 // on the oracle and on analytic properties only).
+//
+// Sort by cell: the gather of a particle reads the 27 cells around it for three components and
+// two RK stages, so particles of one wavefront should sit in neighbouring cells.  Every
+// `sort_every` events the slots are reordered by the linear index of the containing leaf cell
+// (stable LSD radix sort of (cell, slot) pairs, rocPRIM through hipCUB), which changes where a
+// particle is stored, never its arithmetic: `orig` remembers the slot a particle was created in
+// and gfship_particles_download returns the survivors in that order (the reference's list
+// order).  Tracers move less than one cell per step (CFL < 1), so the order stays good between
+// sorts.
 #include "gfship_internal.hpp"
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <numeric>
 
@@ -23,6 +33,15 @@ struct gfship_particles {
   unsigned * id = nullptr;
   unsigned char * alive = nullptr;
   unsigned * d_count = nullptr;
+  // sort by cell
+  unsigned * orig = nullptr;          // creation slot of the particle stored in each slot
+  double * pos2[3] = {}, * old2[3] = {};   // gather targets (swapped with pos/old after a sort)
+  unsigned * id2 = nullptr, * orig2 = nullptr;
+  unsigned char * alive2 = nullptr;
+  unsigned * key = nullptr, * key2 = nullptr, * slot = nullptr, * slot2 = nullptr;
+  void * sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  int sort_every = 16, events_since_sort = -1;   // -1: never sorted yet
 };
 
 namespace gfship {
@@ -268,6 +287,55 @@ particle_list_event_kernel (PartArgs A, int depth)
     A.alive[q] = 0;
 }
 
+// key = linear index of the containing leaf cell, dead or outside particles last
+template <int DIM>
+__global__ void __launch_bounds__(256)
+particle_keys_kernel (Layout L, int depth, int n, const double * __restrict__ x,
+		      const double * __restrict__ y, const double * __restrict__ z,
+		      const unsigned char * __restrict__ alive, unsigned * __restrict__ key,
+		      unsigned * __restrict__ slot)
+{
+  int q = blockIdx.x*blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  unsigned k = 0xFFFFFFFFu;
+  if (alive[q]) {
+    double p[3] = { x[q], y[q], DIM == 3 ? z[q] : 0. };
+    int c[3];
+    if (locate<DIM> (depth, p, c))
+      k = (unsigned) (c[0] - 1) + (unsigned) L.n*((unsigned) (c[1] - 1) +
+						 (DIM == 3 ? (unsigned) L.n*(unsigned) (c[2] - 1) : 0u));
+  }
+  key[q] = k;
+  slot[q] = q;
+}
+
+struct GatherArgs {
+  int n;
+  const unsigned * slot;
+  const double * pos[3], * old[3];
+  const unsigned * id, * orig;
+  const unsigned char * alive;
+  double * pos2[3], * old2[3];
+  unsigned * id2, * orig2;
+  unsigned char * alive2;
+};
+
+__global__ void __launch_bounds__(256)
+particle_gather_kernel (GatherArgs G)
+{
+  int q = blockIdx.x*blockDim.x + threadIdx.x;
+  if (q >= G.n) return;
+  unsigned s = G.slot[q];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    G.pos2[c][q] = G.pos[c][s];
+    G.old2[c][q] = G.old[c][s];
+  }
+  G.id2[q] = G.id[s];
+  G.orig2[q] = G.orig[s];
+  G.alive2[q] = G.alive[s];
+}
+
 __global__ void __launch_bounds__(256)
 count_alive_kernel (const unsigned char * alive, int n, unsigned * count)
 {
@@ -309,6 +377,19 @@ int gfship_particles_create (gfship_particles ** out, gfship_sim * sim, int np,
   GFSHIP_HIP (hipMalloc ((void **) &pl->alive, m));
   GFSHIP_HIP (hipMemset (pl->alive, 1, m));
   GFSHIP_HIP (hipMalloc ((void **) &pl->d_count, sizeof (unsigned)));
+  for (int c = 0; c < 3; c++) {
+    GFSHIP_HIP (hipMalloc ((void **) &pl->pos2[c], m*sizeof (double)));
+    GFSHIP_HIP (hipMalloc ((void **) &pl->old2[c], m*sizeof (double)));
+  }
+  unsigned ** ua[] = { &pl->orig, &pl->orig2, &pl->id2, &pl->key, &pl->key2, &pl->slot, &pl->slot2 };
+  for (unsigned ** a : ua)
+    GFSHIP_HIP (hipMalloc ((void **) a, m*sizeof (unsigned)));
+  GFSHIP_HIP (hipMalloc ((void **) &pl->alive2, m));
+  {
+    std::vector<unsigned> iota (m);
+    std::iota (iota.begin (), iota.end (), 0u);
+    GFSHIP_HIP (hipMemcpy (pl->orig, iota.data (), m*sizeof (unsigned), hipMemcpyHostToDevice));
+  }
   *out = pl;
   return GFSHIP_OK;
 }
@@ -324,13 +405,88 @@ void gfship_particles_destroy (gfship_particles * pl)
   if (pl->id) (void) hipFree (pl->id);
   if (pl->alive) (void) hipFree (pl->alive);
   if (pl->d_count) (void) hipFree (pl->d_count);
+  for (int c = 0; c < 3; c++) {
+    if (pl->pos2[c]) (void) hipFree (pl->pos2[c]);
+    if (pl->old2[c]) (void) hipFree (pl->old2[c]);
+  }
+  void * extra[] = { pl->orig, pl->orig2, pl->id2, pl->key, pl->key2, pl->slot, pl->slot2,
+		     pl->alive2, pl->sort_tmp };
+  for (void * a : extra)
+    if (a) (void) hipFree (a);
   delete pl;
+}
+
+int gfship_particles_set_sort_interval (gfship_particles * pl, int every)
+{
+  GFSHIP_CHECK (pl != nullptr && every >= 0, GFSHIP_EINVAL, "invalid argument");
+  pl->sort_every = every;
+  return GFSHIP_OK;
+}
+
+int gfship_particles_sort (gfship_particles * pl)
+{
+  GFSHIP_CHECK (pl != nullptr, GFSHIP_EINVAL, "null particle list");
+  if (pl->n == 0) return GFSHIP_OK;
+  gfship_domain * dom = pl->dom;
+  const Layout & L = dom->lay[dom->depth];
+  int block = 256, grid = (pl->n + block - 1)/block;
+  if (dom->dim == 3)
+    hipLaunchKernelGGL (particle_keys_kernel<3>, dim3 (grid), dim3 (block), 0, dom->stream, L,
+			dom->depth, pl->n, pl->pos[0], pl->pos[1], pl->pos[2], pl->alive, pl->key,
+			pl->slot);
+  else
+    hipLaunchKernelGGL (particle_keys_kernel<2>, dim3 (grid), dim3 (block), 0, dom->stream, L,
+			dom->depth, pl->n, pl->pos[0], pl->pos[1], pl->pos[2], pl->alive, pl->key,
+			pl->slot);
+  GFSHIP_HIP (hipGetLastError ());
+  size_t need = 0;
+  GFSHIP_HIP (hipcub::DeviceRadixSort::SortPairs (nullptr, need, pl->key, pl->key2, pl->slot,
+						  pl->slot2, pl->n, 0, 32, dom->stream));
+  if (need > pl->sort_tmp_bytes) {
+    if (pl->sort_tmp) GFSHIP_HIP (hipFree (pl->sort_tmp));
+    pl->sort_tmp = nullptr;
+    GFSHIP_HIP (hipMalloc (&pl->sort_tmp, need));
+    pl->sort_tmp_bytes = need;
+  }
+  /* the key needs dim*depth bits (+1 so that the all-ones key of the dead sorts last) */
+  int bits = dom->dim*dom->depth + 1;
+  if (bits > 32) bits = 32;
+  size_t tmp_bytes = pl->sort_tmp_bytes;
+  GFSHIP_HIP (hipcub::DeviceRadixSort::SortPairs (pl->sort_tmp, tmp_bytes, pl->key, pl->key2,
+						  pl->slot, pl->slot2, pl->n, 0, bits, dom->stream));
+  GatherArgs G;
+  G.n = pl->n;
+  G.slot = pl->slot2;
+  for (int c = 0; c < 3; c++) {
+    G.pos[c] = pl->pos[c]; G.old[c] = pl->old[c];
+    G.pos2[c] = pl->pos2[c]; G.old2[c] = pl->old2[c];
+  }
+  G.id = pl->id; G.orig = pl->orig; G.alive = pl->alive;
+  G.id2 = pl->id2; G.orig2 = pl->orig2; G.alive2 = pl->alive2;
+  hipLaunchKernelGGL (particle_gather_kernel, dim3 (grid), dim3 (block), 0, dom->stream, G);
+  GFSHIP_HIP (hipGetLastError ());
+  for (int c = 0; c < 3; c++) {
+    std::swap (pl->pos[c], pl->pos2[c]);
+    std::swap (pl->old[c], pl->old2[c]);
+  }
+  std::swap (pl->id, pl->id2);
+  std::swap (pl->orig, pl->orig2);
+  std::swap (pl->alive, pl->alive2);
+  pl->events_since_sort = 0;
+  return GFSHIP_OK;
 }
 
 int gfship_particle_list_event (gfship_particles * pl)
 {
   GFSHIP_CHECK (pl != nullptr, GFSHIP_EINVAL, "null particle list");
   if (pl->n == 0) return GFSHIP_OK;
+  if (pl->sort_every > 0 &&
+      (pl->events_since_sort < 0 || pl->events_since_sort >= pl->sort_every)) {
+    int r = gfship_particles_sort (pl);
+    if (r) return r;
+  }
+  if (pl->events_since_sort >= 0)
+    pl->events_since_sort++;
   gfship_sim_view v = gfship_sim_view_get (pl->sim);
   gfship_domain * dom = pl->dom;
   PartArgs A;
@@ -379,21 +535,27 @@ int gfship_particles_download (gfship_particles * pl, double * pos, unsigned * i
   GFSHIP_HIP (hipStreamSynchronize (dom->stream));
   size_t m = pl->n;
   std::vector<double> x (m), y (m), z (m);
-  std::vector<unsigned> ids (m);
+  std::vector<unsigned> ids (m), orig (m), where (m);
   std::vector<unsigned char> al (m);
+  GFSHIP_HIP (hipMemcpy (orig.data (), pl->orig, m*sizeof (unsigned), hipMemcpyDeviceToHost));
   GFSHIP_HIP (hipMemcpy (x.data (), pl->pos[0], m*sizeof (double), hipMemcpyDeviceToHost));
   GFSHIP_HIP (hipMemcpy (y.data (), pl->pos[1], m*sizeof (double), hipMemcpyDeviceToHost));
   GFSHIP_HIP (hipMemcpy (z.data (), pl->pos[2], m*sizeof (double), hipMemcpyDeviceToHost));
   GFSHIP_HIP (hipMemcpy (ids.data (), pl->id, m*sizeof (unsigned), hipMemcpyDeviceToHost));
   GFSHIP_HIP (hipMemcpy (al.data (), pl->alive, m, hipMemcpyDeviceToHost));
-  int k = 0;
+  /* survivors in creation order (the reference's list order), whatever the storage order */
   for (size_t q = 0; q < m; q++)
+    where[orig[q]] = (unsigned) q;
+  int k = 0;
+  for (size_t o = 0; o < m; o++) {
+    size_t q = where[o];
     if (al[q]) {
       pos[3*(size_t) k] = x[q]; pos[3*(size_t) k + 1] = y[q];
       pos[3*(size_t) k + 2] = dom->dim == 3 ? z[q] : 0.;
       id[k] = ids[q];
       k++;
     }
+  }
   return k;
 }
 

@@ -112,6 +112,8 @@ SIGNATURES = {
     "gfship_particles_destroy": (None, [_vp]),
     "gfship_particle_list_event": (_i, [_vp]),
     "gfship_particles_count": (_i, [_vp]),
+    "gfship_particles_sort": (_i, [_vp]),
+    "gfship_particles_set_sort_interval": (_i, [_vp, _i]),
     "gfship_particles_download": (_i, [_vp, _pd, C.POINTER(C.c_uint)]),
 }
 
@@ -398,6 +400,12 @@ class ParticleList:
 
     def event(self):
         _check(lib().gfship_particle_list_event(self.ptr))
+
+    def sort(self):
+        _check(lib().gfship_particles_sort(self.ptr))
+
+    def set_sort_interval(self, every):
+        _check(lib().gfship_particles_set_sort_interval(self.ptr, every))
 
     def count(self):
         return _check(lib().gfship_particles_count(self.ptr))

@@ -219,6 +219,10 @@ void gfship_particles_destroy (gfship_particles * pl);
    (gfs_particle_event src/particle.c:31-44 -> gfs_domain_advect_point src/domain.c:2764-2788),
    then gfs_particle_bc (:3375-3395, periodic wrap :3189-3214) */
 int  gfship_particle_list_event (gfship_particles * pl);
+/* storage order only (no reference counterpart; arithmetic and download order unchanged): sort
+   the slots by containing cell now / every `every` events (default 16, 0 = never) */
+int  gfship_particles_sort (gfship_particles * pl);
+int  gfship_particles_set_sort_interval (gfship_particles * pl, int every);
 int  gfship_particles_count (gfship_particles * pl);
 /* positions and ids of the particles still on the list, in list order; returns their number */
 int  gfship_particles_download (gfship_particles * pl, double * pos, unsigned * id);

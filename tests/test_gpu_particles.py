@@ -58,7 +58,11 @@ def test_tracers_2d_periodic_bit_exact():
     _run(osim, PERIODIC, pos, ids, 8, end=2.)
 
 
-def test_tracers_closed_box_drop_list_identical():
+@pytest.mark.parametrize("sort_every", [0, 1, 3])
+def test_tracers_closed_box_drop_list_identical(sort_every):
+    """particles leave through a non-periodic side and are dropped; the storage order (never
+    sorted, sorted by cell every event, every third event) must not change positions, ids or
+    the order of the downloaded list"""
     level = 4
     side = [O.SIDE_BOUNDARY] * 6
     osim = O.Sim(3, level, side)
@@ -77,6 +81,7 @@ def test_tracers_closed_box_drop_list_identical():
     gs.advection_params.dt = 0.03
     opl = O.Particles(osim, pos, ids)
     gpl = gfship.ParticleList(gs, pos, ids)
+    gpl.set_sort_interval(sort_every)
     for k in range(10):
         opl.event()
         gpl.event()
