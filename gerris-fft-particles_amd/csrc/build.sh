@@ -18,3 +18,13 @@ done
 wait
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgfship.so" $OBJS
 echo "built $OUT/libgfship.so"
+# host front end: the reference's gerris2D / gerris3D command, on libgfship (C ABI only)
+BIN="$HERE/../bin"
+mkdir -p "$BIN"
+CXX="${CXX:-g++}"
+if [ ! -f "$BIN/gfship2D" ] || [ "$HERE/host/gfsrun.cpp" -nt "$BIN/gfship2D" ] || [ "$HERE/host/gfs_text.hpp" -nt "$BIN/gfship2D" ] || [ "$HERE/host/gfs_function.hpp" -nt "$BIN/gfship2D" ] || [ "$HERE/../../include/gfship.h" -nt "$BIN/gfship2D" ]; then
+  "$CXX" -O2 -std=c++17 -Wall -I"$HERE/../../include" -I"$HERE/host" "$HERE/host/gfsrun.cpp" \
+    -o "$BIN/gfship2D" -L"$OUT" -lgfship -ldl -Wl,-rpath,'$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
+  cp "$BIN/gfship2D" "$BIN/gfship3D"
+fi
+echo "built $BIN/gfship2D $BIN/gfship3D"

@@ -1,0 +1,1244 @@
+// gfsrun.cpp -- `gfship2D` / `gfship3D`: run a Gerris simulation file (.gfs) on libgfship.
+//
+// The host side of the drop-in: it reads the reference's simulation-file format, builds the
+// domain and the simulation through the C ABI of include/gfship.h (nothing else is called),
+// and drives the reference's event loop:
+//   GfsSimulation   simulation_run     src/simulation.c:432-557
+//   GfsPoisson      poisson_run        src/simulation.c:2213-2285
+// with the events and outputs the reference's own test cases use (test/poisson, test/lid,
+// test/reynolds, test/periodic ...), printed in the reference's formats so that the awk/python
+// checks of test/*/*.sh read them unchanged.  Supported: one GfsBox (periodic through self
+// edges `1 1 right`), uniform `Refine <int>`, Boundary { BcDirichlet | BcNeumann }, Time,
+// ProjectionParams, ApproxProjectionParams, AdvectionParams, Init, SourceDiffusion (constant
+// coefficient on U, V, W), VariableTracer, EventStop, EventScript, GModule (ignored: the device
+// solver replaces hypre/agmg), OutputTime, OutputProjectionStats, OutputDiffusionStats,
+// OutputScalarNorm, OutputScalarSum, OutputScalarStats, OutputErrorNorm, OutputLocation,
+// OutputSimulation (text format).  Anything else fails loudly with the line number.
+//
+//   gfship2D [-D NAME=VALUE ...] [--device N] file.gfs     (gfship3D for three dimensions)
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <fstream>
+#include <functional>
+#include <sstream>
+#include "gfship.h"
+#include "gfs_text.hpp"
+#include "gfs_function.hpp"
+
+using namespace gfs;
+
+namespace {
+
+#define CHECK(call) do { int rc_ = (call); if (rc_ < 0) {			\
+      fprintf (stderr, "gfship: %s failed: %s\n", #call, gfship_last_error ()); exit (1); } } while (0)
+
+const char * side_name[6] = { "right", "left", "top", "bottom", "front", "back" };
+
+// ----------------------------------------------------------------------------------------------
+// variables: the reference's domain->variables list (P, Pmac, U, V[, W], then the ones the file
+// adds).  Device variables live in libgfship; the others are host arrays used by Init, outputs
+// and EventStop only.
+// ----------------------------------------------------------------------------------------------
+struct Variable {
+  std::string name;
+  gfship_field dev = -1;          // -1: host only
+  std::vector<double> host;       // (n+2)^dim with ghosts, [k][j][i]
+  double host_time = -1.;         // simulation step the host copy of a device variable is from
+  std::function<void (Variable &)> derive;   // derived variables (Velocity, Divergence ...)
+};
+
+struct Event {                     // GfsEvent, src/event.c:60-169
+  double t = 0., start = 0., end = DBL_MAX, step = DBL_MAX;
+  unsigned i = 0, istart = 0, iend = INT_MAX, istep = INT_MAX;
+  unsigned n = 0;
+  bool end_event = false, realised = false, dead = false;
+  std::string cls;
+  int line = 0;
+  std::function<void ()> action;
+};
+
+struct Output {                    // GfsOutput, src/output.c:143-212
+  std::string format;             // stdout, stderr, a file name or a { shell script }
+  FILE * fp = nullptr;
+  bool pipe = false;
+  FILE * open () {
+    if (fp) return fp;
+    if (format == "stdout") fp = stdout;
+    else if (format == "stderr") fp = stderr;
+    else if (!format.empty () && format[0] == '{') {
+      std::string script = format.substr (1, format.size () - 2);
+      fflush (stdout);
+      fp = popen (script.c_str (), "w");
+      pipe = true;
+    }
+    else
+      fp = fopen (format.c_str (), "w");
+    if (!fp) { fprintf (stderr, "gfship: cannot open output `%s'\n", format.c_str ()); exit (1); }
+    return fp;
+  }
+  void close () {
+    if (!fp) return;
+    if (pipe) pclose (fp);
+    else if (fp != stdout && fp != stderr) fclose (fp);
+    else fflush (fp);
+    fp = nullptr;
+  }
+};
+
+struct BcSpec { int kind = GFSHIP_BC_SYMMETRY; Function * val = nullptr; };
+
+struct Run {
+  int dim = 2, level = 0, device = 0;
+  std::string sim_class = "Simulation";
+  int side[6] = { GFSHIP_SIDE_BOUNDARY, GFSHIP_SIDE_BOUNDARY, GFSHIP_SIDE_BOUNDARY,
+		  GFSHIP_SIDE_BOUNDARY, GFSHIP_SIDE_BOUNDARY, GFSHIP_SIDE_BOUNDARY };
+  std::map<std::string, BcSpec> bc[6];       // per side: variable name -> condition
+  // GfsTime, src/simulation.c:1660-1670
+  double t = 0., end = DBL_MAX, dtmax = DBL_MAX;
+  unsigned i = 0, iend = INT_MAX;
+  std::map<std::string, std::string> proj_set, approx_set, adv_set;
+  double visc[3] = { 0., 0., 0. };
+  std::map<std::string, std::string> diff_set[3];
+  std::vector<std::string> tracers;
+  std::vector<std::pair<std::string, Function *>> init;   // Init {} { var = f }
+  std::vector<Variable> vars;
+  std::vector<std::unique_ptr<Event>> events;
+  std::vector<std::unique_ptr<Output>> outputs;
+  FunctionSet functions;
+  gfship_domain * dom = nullptr;
+  gfship_sim * sim = nullptr;
+  std::chrono::steady_clock::time_point clock0;
+
+  int n () const { return 1 << level; }
+  size_t total () const { size_t r = n () + 2; return dim == 3 ? r*r*r : r*r; }
+  size_t idx (int i, int j, int k) const {
+    size_t r = n () + 2;
+    return i + r*(j + (dim == 3 ? r*(size_t) k : 0));
+  }
+  int var_index (const std::string & name) const {
+    for (size_t q = 0; q < vars.size (); q++)
+      if (vars[q].name == name) return (int) q;
+    return -1;
+  }
+  int get_or_add_variable (const std::string & name) {
+    int v = var_index (name);
+    if (v >= 0) return v;
+    Variable nv;
+    nv.name = name;
+    vars.push_back (nv);
+    return (int) vars.size () - 1;
+  }
+  std::vector<std::string> var_names () const {
+    std::vector<std::string> r;
+    for (const Variable & v : vars) r.push_back (v.name);
+    return r;
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// host copies of the fields
+// ----------------------------------------------------------------------------------------------
+std::vector<double> & host_of (Run & R, int v)
+{
+  Variable & V = R.vars[v];
+  if (V.dev >= 0) {
+    if (V.host.size () != R.total () || V.host_time != (double) R.i) {
+      V.host.resize (R.total ());
+      CHECK (gfship_field_download (R.dom, V.dev, R.level, V.host.data ()));
+      V.host_time = (double) R.i;
+    }
+  }
+  else if (V.derive) {
+    if (V.host.size () != R.total () || V.host_time != (double) R.i) {
+      V.host.assign (R.total (), 0.);
+      V.derive (V);
+      V.host_time = (double) R.i;
+    }
+  }
+  else if (V.host.size () != R.total ())
+    V.host.assign (R.total (), 0.);
+  return V.host;
+}
+
+void invalidate_device_copies (Run & R)
+{
+  for (Variable & V : R.vars)
+    if (V.dev >= 0 || V.derive)
+      V.host_time = -1.;
+}
+
+void cell_pos (const Run & R, int i, int j, int k, double p[3])
+{
+  // ftt_cell_pos on the unit box centred on the origin, src/ftt.c:349-367
+  double h = 1./R.n ();
+  p[0] = -0.5 + (i - 0.5)*h;
+  p[1] = -0.5 + (j - 0.5)*h;
+  p[2] = R.dim == 3 ? -0.5 + (k - 0.5)*h : 0.;
+}
+
+double eval (Run & R, const Function * f, const double p[3], long cell)
+{
+  switch (f->kind) {
+  case Function::CONSTANT: return f->val;
+  case Function::VARIABLE:
+    if (cell < 0) { fprintf (stderr, "gfship: a variable cannot be used in a boundary value\n"); exit (1); }
+    return host_of (R, f->var)[cell];
+  case Function::COMPILED: {
+    double v[32];
+    if (f->args.size () > 32) { fprintf (stderr, "gfship: too many variables in a function\n"); exit (1); }
+    for (size_t q = 0; q < f->args.size (); q++) {
+      if (cell < 0) { fprintf (stderr, "gfship: a variable cannot be used in a boundary value\n"); exit (1); }
+      v[q] = host_of (R, f->args[q])[cell];
+    }
+    return f->fn (p[0], p[1], p[2], R.t, v);
+  }
+  default: break;
+  }
+  fprintf (stderr, "gfship: unresolved function\n");
+  exit (1);
+}
+
+template <class F> void for_each_cell (const Run & R, F f)
+{
+  int n = R.n ();
+  for (int k = 1; k <= (R.dim == 3 ? n : 1); k++)
+    for (int j = 1; j <= n; j++)
+      for (int i = 1; i <= n; i++) {
+	int kk = R.dim == 3 ? k : 0;
+	f (i, j, kk, R.idx (i, j, kk));
+      }
+}
+
+// gfs_domain_norm_variable with volume weights, src/domain.c:2197-2232, fluid.c:2139-2171
+gfship_norm norm_of (const Run & R, const std::vector<double> & a)
+{
+  gfship_norm nm = { 0., 0., 0., 0., 0. };
+  double h = 1./R.n ();
+  double w = R.dim == 3 ? h*h*h : h*h;
+  for_each_cell (R, [&] (int, int, int, size_t c) {
+    double val = a[c];
+    nm.bias += w*val;
+    val = fabs (val);
+    if (val > nm.infty) nm.infty = val;
+    nm.first += w*val;
+    nm.second += w*val*val;
+    nm.w += w;
+  });
+  if (nm.w > 0.) {
+    nm.bias /= nm.w;
+    nm.first /= nm.w;
+    nm.second = sqrt (nm.second/nm.w);
+  }
+  else
+    nm.infty = 0.;
+  return nm;
+}
+
+// ----------------------------------------------------------------------------------------------
+// parsing
+// ----------------------------------------------------------------------------------------------
+void read_event_params (Reader & r, Event & e)
+{
+  // gfs_event_read, src/event.c:171-300
+  if (r.peek (false) != '{') return;
+  auto m = r.assignments ();
+  bool set_start = m.count ("start"), set_end = m.count ("end"), set_step = m.count ("step"),
+    set_istart = m.count ("istart"), set_iend = m.count ("iend"), set_istep = m.count ("istep");
+  for (auto & kv : m)
+    if (kv.first != "start" && kv.first != "end" && kv.first != "step" && kv.first != "istart" &&
+	kv.first != "iend" && kv.first != "istep")
+      r.fail ("unknown event parameter `" + kv.first + "'");
+  if (set_end) e.end = atof (m["end"].c_str ());
+  if (set_step) e.step = atof (m["step"].c_str ());
+  if (set_istart) e.istart = (unsigned) atol (m["istart"].c_str ());
+  if (set_iend) e.iend = (unsigned) atol (m["iend"].c_str ());
+  if (set_istep) e.istep = (unsigned) atol (m["istep"].c_str ());
+  if (set_start) {
+    if (m["start"] == "end") {
+      e.end_event = true;
+      if (set_end || set_step || set_istart || set_iend || set_istep)
+	r.fail ("no other parameter can be set for an `end' event");
+    }
+    else
+      e.start = atof (m["start"].c_str ());
+  }
+  if (set_step && set_istep) r.fail ("step and istep cannot be set simultaneously");
+  if (set_step) e.istep = INT_MAX;
+  if (set_step && e.step <= 0.) r.fail ("step must be strictly positive");
+  if (!set_step && !set_istep && set_end) r.fail ("expecting a number (step or istep)");
+  if (set_end && e.end <= e.start) r.fail ("end must be larger than start");
+  if (e.start < 0. && set_step) e.start = 0.;
+  if (set_start || !set_istart) e.t = e.start;
+  else e.t = e.start = DBL_MAX/2.;
+  if (!set_istep && !set_step && set_iend) r.fail ("expecting a number (istep or step)");
+  if (set_istart && e.iend <= e.istart) r.fail ("iend must be larger than istart");
+  if (set_istart || !set_start) e.i = e.istart;
+  else e.i = e.istart = INT_MAX/2;
+}
+
+void read_multilevel (Reader & r, std::map<std::string, std::string> & set)
+{
+  // gfs_multilevel_params_read, src/poisson.c:70-126
+  static const char * keys[] = { "tolerance", "nrelax", "erelax", "minlevel", "nitermax",
+				 "nitermin", "weighted", "beta", "omega", "function", nullptr };
+  auto m = r.assignments ();
+  for (auto & kv : m) {
+    bool ok = false;
+    for (const char ** k = keys; *k; k++) ok = ok || kv.first == *k;
+    if (!ok) r.fail ("unknown keyword `" + kv.first + "'");
+    set[kv.first] = kv.second;
+  }
+}
+
+void apply_multilevel (gfship_multilevel_params * p, const std::map<std::string, std::string> & m)
+{
+  for (auto & kv : m) {
+    const char * v = kv.second.c_str ();
+    if (kv.first == "tolerance") p->tolerance = atof (v);
+    else if (kv.first == "nrelax") p->nrelax = (unsigned) atol (v);
+    else if (kv.first == "erelax") p->erelax = (unsigned) atol (v);
+    else if (kv.first == "minlevel") p->minlevel = (unsigned) atol (v);
+    else if (kv.first == "nitermax") p->nitermax = (unsigned) atol (v);
+    else if (kv.first == "nitermin") p->nitermin = (unsigned) atol (v);
+    else if (kv.first == "weighted") p->weighted = atoi (v);
+    else if (kv.first == "beta") p->beta = atof (v);
+    else if (kv.first == "omega") p->omega = atof (v);
+  }
+  if (p->tolerance <= 0. || p->nrelax == 0 || p->erelax == 0 || p->beta < 0.5 || p->beta > 1.) {
+    fprintf (stderr, "gfship: invalid multilevel parameters\n");
+    exit (1);
+  }
+}
+
+Output * read_output (Run & R, Reader & r)
+{
+  R.outputs.emplace_back (new Output);
+  Output * o = R.outputs.back ().get ();
+  if (r.peek (false) == '{')
+    o->format = "{" + r.braces () + "}";
+  else
+    o->format = r.word (false);
+  return o;
+}
+
+double rate (double a, double b, unsigned n)
+{
+  if (a > 0. && b > 0. && n > 0) return exp (log (b/a)/n);
+  return 0.;
+}
+
+void stats_write (const gfship_multilevel_params * par, FILE * fp)
+{
+  // gfs_multilevel_params_stats_write, src/poisson.c:142-172
+  fprintf (fp,
+	   "    niter: %4d\n"
+	   "    residual.bias:   % 10.3e % 10.3e\n"
+	   "    residual.first:  % 10.3e % 10.3e %6.2g\n"
+	   "    residual.second: % 10.3e % 10.3e %6.2g\n"
+	   "    residual.infty:  % 10.3e % 10.3e %6.2g\n",
+	   par->niter, par->residual_before.bias, par->residual.bias,
+	   par->residual_before.first, par->residual.first,
+	   rate (par->residual.first, par->residual_before.first, par->niter),
+	   par->residual_before.second, par->residual.second,
+	   rate (par->residual.second, par->residual_before.second, par->niter),
+	   par->residual_before.infty, par->residual.infty,
+	   rate (par->residual.infty, par->residual_before.infty, par->niter));
+}
+
+// the scalar of a GfsOutputScalar: { v = function ... }, src/output.c:1670-1830
+struct ScalarSpec { Function * f = nullptr; std::string name; Function * w = nullptr; std::string format; };
+
+ScalarSpec read_scalar (Run & R, Reader & r)
+{
+  ScalarSpec s;
+  int l0 = r.line ();
+  Reader b (r.braces (), "simulation file", l0);
+  while (!b.eof ()) {
+    std::string k = b.word ();
+    b.expect ('=');
+    if (k == "v") {
+      FunctionText t = b.function ();
+      s.f = R.functions.add (t, b.line ());
+      s.name = t.text;       /* gfs_function_description */
+    }
+    else if (k == "w")
+      s.w = R.functions.add (b.function (), b.line ());
+    else if (k == "format")
+      s.format = b.word ();
+    else if (k == "min" || k == "max" || k == "maxlevel")
+      b.word ();
+    else
+      b.fail ("unsupported GfsOutputScalar keyword `" + k + "'");
+  }
+  if (!s.f) r.fail ("expecting `v = ...'");
+  return s;
+}
+
+std::vector<double> scalar_values (Run & R, const ScalarSpec & s)
+{
+  std::vector<double> a (R.total (), 0.);
+  for_each_cell (R, [&] (int i, int j, int k, size_t c) {
+    double p[3];
+    cell_pos (R, i, j, k, p);
+    a[c] = eval (R, s.f, p, (long) c);
+  });
+  return a;
+}
+
+void add_event (Run & R, Event * e, const std::string & cls, int line)
+{
+  e->cls = cls;
+  e->line = line;
+  R.events.emplace_back (e);
+}
+
+void parse_object (Run & R, Reader & r)
+{
+  int line = r.line ();
+  std::string cls = strip_gfs (r.word ());
+  if (cls == "Time") {
+    auto m = r.assignments ();
+    for (auto & kv : m) {
+      const char * v = kv.second.c_str ();
+      if (kv.first == "t") R.t = atof (v);
+      else if (kv.first == "i") R.i = (unsigned) atol (v);
+      else if (kv.first == "end") R.end = atof (v);
+      else if (kv.first == "iend") R.iend = (unsigned) atol (v);
+      else if (kv.first == "dtmax") R.dtmax = atof (v);
+      else r.fail ("unknown GfsTime keyword `" + kv.first + "'");
+    }
+  }
+  else if (cls == "Refine") {
+    FunctionText t = r.function ();
+    char * endp;
+    long l = strtol (t.text.c_str (), &endp, 10);
+    if (t.block || *endp != '\0' || l < 0 || l > GFSHIP_MAXLEVEL)
+      r.fail ("only a uniform `Refine <integer>` is supported (got `" + t.text + "')");
+    R.level = (int) l;
+  }
+  else if (cls == "GModule") {
+    std::string name = r.word (false);
+    if (r.peek (false) == '{') r.braces ();
+    fprintf (stderr, "gfship: GModule %s ignored (the Poisson and diffusion solvers are libgfship's)\n",
+	     name.c_str ());
+  }
+  else if (cls == "ApproxProjectionParams") read_multilevel (r, R.approx_set);
+  else if (cls == "ProjectionParams") read_multilevel (r, R.proj_set);
+  else if (cls == "AdvectionParams") {
+    auto m = r.assignments ();
+    for (auto & kv : m) {
+      if (kv.first == "cfl" || kv.first == "gradient" || kv.first == "gc")
+	R.adv_set[kv.first] = kv.second;
+      else
+	r.fail ("unsupported GfsAdvectionParams keyword `" + kv.first + "'");
+    }
+  }
+  else if (cls == "Init") {
+    Event e;
+    read_event_params (r, e);
+    int l0 = r.line ();
+    Reader b (r.braces (), "simulation file", l0);
+    while (!b.eof ()) {
+      std::string name = b.word ();
+      b.expect ('=');
+      Function * f = R.functions.add (b.function (), b.line ());
+      R.get_or_add_variable (name);
+      R.init.emplace_back (name, f);
+    }
+  }
+  else if (cls == "SourceDiffusion" || cls == "SourceViscosity") {
+    Event e;
+    read_event_params (r, e);
+    std::vector<std::string> comps;
+    if (cls == "SourceDiffusion") comps.push_back (r.word (false));
+    else { comps = { "U", "V" }; if (R.dim == 3) comps.push_back ("W"); }
+    FunctionText t = r.function ();
+    if (t.block || !Reader::is_number (t.text))
+      r.fail ("only a constant diffusion coefficient is supported");
+    std::map<std::string, std::string> par;
+    if (r.peek (false) == '{') read_multilevel (r, par);
+    for (const std::string & v : comps) {
+      int c = v == "U" ? 0 : v == "V" ? 1 : (v == "W" && R.dim == 3) ? 2 : -1;
+      if (c < 0) r.fail ("diffusion is supported on the velocity components only (got `" + v + "')");
+      R.visc[c] = atof (t.text.c_str ());
+      R.diff_set[c] = par;
+    }
+  }
+  else if (cls == "VariableTracer") {
+    std::string name = r.word (false);
+    if (r.peek (false) == '{') {
+      auto m = r.assignments ();
+      for (auto & kv : m)
+	if (!(kv.first == "gradient" && kv.second == "gfs_center_van_leer_gradient"))
+	  r.fail ("tracers use the default van Leer limiter only (got " + kv.first + " = " + kv.second + ")");
+    }
+    R.tracers.push_back (name);
+    R.get_or_add_variable (name);
+  }
+  else if (cls == "EventStop") {
+    // gfs_event_stop_read / _event, src/event.c:1737-1835
+    Event * e = new Event;
+    read_event_params (r, *e);
+    std::string vname = r.word (false);
+    double max = r.number ();
+    std::string dname;
+    if (!r.at_end_of_object ()) dname = r.word (false);
+    int v = R.var_index (vname);
+    if (v < 0) r.fail ("unknown variable `" + vname + "'");
+    int dv = dname.empty () ? -1 : R.get_or_add_variable (dname);
+    auto oldv = std::make_shared<std::vector<double>> ();
+    auto last = std::make_shared<double> (-1.);
+    Run * pr = &R;
+    e->action = [pr, v, dv, max, oldv, last] () {
+      Run & R = *pr;
+      const std::vector<double> & cur = host_of (R, v);
+      if (*last >= 0.) {
+	std::vector<double> d (R.total (), 0.);
+	for_each_cell (R, [&] (int, int, int, size_t c) { d[c] = (*oldv)[c] - cur[c]; });
+	gfship_norm nm = norm_of (R, d);
+	if (nm.infty <= max)
+	  R.end = R.t;
+	if (dv >= 0) R.vars[dv].host = d;
+      }
+      *oldv = cur;
+      *last = R.t;
+    };
+    add_event (R, e, cls, line);
+  }
+  else if (cls == "EventScript") {
+    Event * e = new Event;
+    read_event_params (r, *e);
+    std::string script = r.braces ();
+    e->action = [script] () {
+      fflush (stdout);
+      if (system (script.c_str ()) != 0)
+	fprintf (stderr, "gfship: EventScript returned a non-zero status\n");
+    };
+    add_event (R, e, cls, line);
+  }
+  else if (cls == "OutputTime") {
+    Event * e = new Event;
+    read_event_params (r, *e);
+    Output * o = read_output (R, r);
+    Run * pr = &R;
+    e->action = [pr, o] () {
+      // time_event, src/output.c:370-392
+      Run & R = *pr;
+      double real = std::chrono::duration<double> (std::chrono::steady_clock::now () - R.clock0).count ();
+      fprintf (o->open (), "step: %7u t: %15.8f dt: %13.6e cpu: %15.8f real: %15.8f\n",
+	       R.i, R.t, R.sim ? gfship_sim_advection_params (R.sim)->dt : 0., real, real);
+      fflush (o->fp);
+    };
+    add_event (R, e, cls, line);
+  }
+  else if (cls == "OutputProjectionStats" || cls == "OutputDiffusionStats") {
+    Event * e = new Event;
+    read_event_params (r, *e);
+    Output * o = read_output (R, r);
+    Run * pr = &R;
+    bool diffusion = cls == "OutputDiffusionStats";
+    e->action = [pr, o, diffusion] () {
+      Run & R = *pr;
+      FILE * fp = o->open ();
+      if (diffusion) {
+	// gfs_output_diffusion_stats_event, src/output.c:560-600
+	const char * names[3] = { "U", "V", "W" };
+	for (int c = 0; c < R.dim; c++)
+	  if (R.visc[c] != 0.) {
+	    fprintf (fp, "%s diffusion\n", names[c]);
+	    stats_write (gfship_sim_diffusion_params (R.sim, c), fp);
+	  }
+      }
+      else {
+	// projection_stats_event, src/output.c:486-500
+	const gfship_multilevel_params * p = gfship_sim_projection_params (R.sim);
+	if (p->niter > 0) {
+	  fprintf (fp, "MAC projection        before     after       rate\n");
+	  stats_write (p, fp);
+	}
+	fprintf (fp, "Approximate projection\n");
+	stats_write (gfship_sim_approx_projection_params (R.sim), fp);
+      }
+      fflush (fp);
+    };
+    add_event (R, e, cls, line);
+  }
+  else if (cls == "OutputScalarNorm" || cls == "OutputScalarSum" || cls == "OutputScalarStats") {
+    Event * e = new Event;
+    read_event_params (r, *e);
+    Output * o = read_output (R, r);
+    ScalarSpec s = read_scalar (R, r);
+    Run * pr = &R;
+    std::string kind = cls;
+    e->action = [pr, o, s, kind] () {
+      Run & R = *pr;
+      std::vector<double> a = scalar_values (R, s);
+      FILE * fp = o->open ();
+      if (kind == "OutputScalarNorm") {
+	// gfs_output_scalar_norm_event, src/output.c:1966-1986
+	gfship_norm nm = norm_of (R, a);
+	fprintf (fp, "%s time: %g first: % 10.3e second: % 10.3e infty: % 10.3e\n",
+		 s.name.c_str (), R.t, nm.first, nm.second, nm.infty);
+      }
+      else if (kind == "OutputScalarSum") {
+	// gfs_output_scalar_sum_event, src/output.c:2089-2123
+	double h = 1./R.n (), vol = R.dim == 3 ? h*h*h : h*h, sum = 0.;
+	for_each_cell (R, [&] (int i, int j, int k, size_t c) {
+	  double w = vol;
+	  if (s.w) { double p[3]; cell_pos (R, i, j, k, p); w = eval (R, s.w, p, (long) c); }
+	  sum += w*a[c];
+	});
+	if (!s.format.empty ()) {
+	  std::string f = "%s time: " + s.format + " sum: " + s.format + "\n";
+	  fprintf (fp, f.c_str (), s.name.c_str (), R.t, sum);
+	}
+	else
+	  fprintf (fp, "%s time: %g sum: % 15.6e\n", s.name.c_str (), R.t, sum);
+      }
+      else {
+	// gfs_output_scalar_stats_event, src/output.c:2030-2060 (GtsRange: min, avg, stddev, max)
+	double mn = DBL_MAX, mx = -DBL_MAX, sum = 0., sum2 = 0.;
+	size_t nn = 0;
+	for_each_cell (R, [&] (int, int, int, size_t c) {
+	  mn = std::min (mn, a[c]); mx = std::max (mx, a[c]);
+	  sum += a[c]; sum2 += a[c]*a[c]; nn++;
+	});
+	double avg = sum/nn, sd = sqrt (std::max (0., (sum2 - sum*sum/nn)/nn));
+	fprintf (fp, "%s time: %g min: %10.3e avg: %10.3e | %10.3e max: %10.3e\n",
+		 s.name.c_str (), R.t, mn, avg, sd, mx);
+      }
+      fflush (fp);
+    };
+    add_event (R, e, cls, line);
+  }
+  else if (cls == "OutputErrorNorm") {
+    // gfs_output_error_norm_read / _event, src/output.c:2780-3035
+    Event * e = new Event;
+    read_event_params (r, *e);
+    Output * o = read_output (R, r);
+    ScalarSpec s = read_scalar (R, r);
+    Function * ref = nullptr, * w = nullptr;
+    int unbiased = 0, relative = 0, ev = -1;
+    int l0 = r.line ();
+    Reader b (r.braces (), "simulation file", l0);
+    while (!b.eof ()) {
+      std::string k = b.word ();
+      b.expect ('=');
+      if (k == "s") ref = R.functions.add (b.function (), b.line ());
+      else if (k == "w") w = R.functions.add (b.function (), b.line ());
+      else if (k == "unbiased") unbiased = atoi (b.word ().c_str ());
+      else if (k == "relative") relative = atoi (b.word ().c_str ());
+      else if (k == "v") ev = R.get_or_add_variable (b.word ());
+      else b.fail ("unknown identifier `" + k + "'");
+    }
+    if (!ref) r.fail ("expecting `s = ...'");
+    if (w) r.fail ("weighted error norms are not supported");
+    Run * pr = &R;
+    e->action = [pr, o, s, ref, unbiased, relative, ev] () {
+      Run & R = *pr;
+      std::vector<double> val = scalar_values (R, s), err (R.total (), 0.), sol (R.total (), 0.);
+      for_each_cell (R, [&] (int i, int j, int k, size_t c) {
+	double p[3];
+	cell_pos (R, i, j, k, p);
+	sol[c] = eval (R, ref, p, (long) c);
+	err[c] = val[c] - sol[c];
+      });
+      gfship_norm snorm = { 0., 0., 0., 0., 0. };
+      if (relative) snorm = norm_of (R, sol);
+      gfship_norm nm = norm_of (R, err);
+      if (unbiased) {
+	for_each_cell (R, [&] (int, int, int, size_t c) { err[c] -= nm.bias; });
+	nm = norm_of (R, err);
+      }
+      if (ev >= 0) { R.vars[ev].host = err; }
+      if (relative) {
+	if (snorm.first > 0.) nm.first /= snorm.first;
+	if (snorm.second > 0.) nm.second /= snorm.second;
+	if (snorm.infty > 0.) nm.infty /= snorm.infty;
+      }
+      FILE * fp = o->open ();
+      if (!s.format.empty ()) {
+	const std::string & f = s.format;
+	std::string fmt = "%s time: " + f + " first: " + f + " second: " + f + " infty: " + f +
+	  " bias: " + f + "\n";
+	fprintf (fp, fmt.c_str (), s.name.c_str (), R.t, nm.first, nm.second, nm.infty, nm.bias);
+      }
+      else
+	fprintf (fp, "%s time: %g first: %10.3e second: %10.3e infty: %10.3e bias: %10.3e\n",
+		 s.name.c_str (), R.t, nm.first, nm.second, nm.infty, nm.bias);
+      fflush (fp);
+    };
+    add_event (R, e, cls, line);
+  }
+  else if (cls == "OutputLocation") {
+    // gfs_output_location_read / _event, src/output.c:1037-1203
+    Event * e = new Event;
+    read_event_params (r, *e);
+    Output * o = read_output (R, r);
+    auto pts = std::make_shared<std::vector<double>> ();
+    if (r.peek (false) == '{') {
+      std::istringstream in (r.braces ());
+      double x;
+      while (in >> x) pts->push_back (x);
+    }
+    else {
+      std::string w = r.word (false);
+      if (Reader::is_number (w)) {
+	pts->push_back (atof (w.c_str ()));
+	pts->push_back (r.number ());
+	pts->push_back (r.number ());
+      }
+      else {
+	std::ifstream in (w);
+	if (!in) r.fail ("cannot open file `" + w + "'");
+	double x;
+	while (in >> x) pts->push_back (x);
+      }
+    }
+    if (pts->size () % 3) r.fail ("expecting x y z triplets");
+    if (r.peek (false) == '{') r.braces ();     /* label, precision: defaults only */
+    Run * pr = &R;
+    auto first = std::make_shared<bool> (true);
+    e->action = [pr, o, pts, first] () {
+      Run & R = *pr;
+      FILE * fp = o->open ();
+      int np = (int) pts->size ()/3;
+      if (*first) {
+	fputs ("# 1:t 2:x 3:y 4:z", fp);
+	int nv = 5;
+	for (const Variable & V : R.vars)
+	  if (!V.derive) fprintf (fp, " %d:%s", nv++, V.name.c_str ());
+	fputc ('\n', fp);
+	*first = false;
+      }
+      std::vector<std::vector<double>> cols;
+      std::vector<unsigned char> inside (np, 1);
+      for (Variable & V : R.vars) {
+	if (V.derive) continue;
+	std::vector<double> out (np, 0.);
+	gfship_field f = V.dev;
+	gfship_field tmp = -1;
+	if (f < 0) {          /* host-only variable: sample it through a scratch device field */
+	  tmp = gfship_field_alloc (R.dom, -1);
+	  CHECK (tmp);
+	  size_t vi = &V - &R.vars[0];
+	  CHECK (gfship_field_upload (R.dom, tmp, R.level, host_of (R, (int) vi).data ()));
+	  CHECK (gfship_bc (R.dom, tmp, tmp, R.level));
+	  f = tmp;
+	}
+	CHECK (gfship_field_interpolate (R.dom, f, np, pts->data (), out.data (), inside.data ()));
+	if (tmp >= 0) gfship_field_free (R.dom, tmp);
+	cols.push_back (out);
+      }
+      for (int q = 0; q < np; q++) {
+	if (!inside[q]) continue;
+	fprintf (fp, "%g %g %g %g", R.t, (*pts)[3*q], (*pts)[3*q + 1], (*pts)[3*q + 2]);
+	for (auto & c : cols) fprintf (fp, " %g", c[q]);
+	fputc ('\n', fp);
+      }
+      fflush (fp);
+    };
+    add_event (R, e, cls, line);
+  }
+  else if (cls == "OutputSimulation") {
+    // text format of gfs_output_simulation_event (format = text), src/output.c:1330-1350
+    Event * e = new Event;
+    read_event_params (r, *e);
+    Output * o = read_output (R, r);
+    if (r.peek (false) == '{') r.braces ();
+    Run * pr = &R;
+    e->action = [pr, o] () {
+      Run & R = *pr;
+      FILE * fp = o->open ();
+      fputs ("# 1:x 2:y 3:z", fp);
+      int nv = 4;
+      std::vector<int> list;
+      for (size_t q = 0; q < R.vars.size (); q++)
+	if (!R.vars[q].derive) { fprintf (fp, " %d:%s", nv++, R.vars[q].name.c_str ()); list.push_back ((int) q); }
+      fputc ('\n', fp);
+      for_each_cell (R, [&] (int i, int j, int k, size_t c) {
+	double p[3];
+	cell_pos (R, i, j, k, p);
+	fprintf (fp, "%g %g %g", p[0], p[1], p[2]);
+	for (int q : list) fprintf (fp, " %g", host_of (R, q)[c]);
+	fputc ('\n', fp);
+      });
+      o->close ();
+    };
+    add_event (R, e, cls, line);
+  }
+  else if (cls == "OutputPPM" || cls == "OutputGRD" || cls == "OutputTiming" ||
+	   cls == "OutputBalance" || cls == "OutputSolidStats" || cls == "OutputAdaptStats") {
+    std::string rest = r.rest_of_object ();
+    fprintf (stderr, "gfship: line %d: %s is not produced (skipped)\n", line, cls.c_str ());
+  }
+  else
+    r.fail ("unsupported object `" + cls + "'");
+  if (!r.at_end_of_object ())
+    r.fail ("unexpected text after " + cls);
+}
+
+int side_from_name (const std::string & s)
+{
+  for (int d = 0; d < 6; d++)
+    if (s == side_name[d]) return d;
+  return -1;
+}
+
+void parse_box (Run & R, Reader & r)
+{
+  // gfs_box_read, src/domain.c:3608-3730
+  std::string cls = strip_gfs (r.word ());
+  if (cls != "Box") r.fail ("expecting GfsBox");
+  int l0 = r.line ();
+  Reader b (r.braces (), "simulation file", l0);
+  while (!b.eof ()) {
+    std::string k = b.word ();
+    b.expect ('=');
+    int d = side_from_name (k);
+    if (d < 0) {
+      if (k == "id" || k == "pid" || k == "size" || k == "x" || k == "y" || k == "z") { b.word (); continue; }
+      b.fail ("unknown GfsBox keyword `" + k + "'");
+    }
+    if (d >= 2*R.dim) b.fail ("direction `" + k + "' does not exist in 2-D");
+    std::string bcls = strip_gfs (b.word ());
+    if (bcls != "Boundary") b.fail ("unsupported boundary class `" + bcls + "'");
+    R.side[d] = GFSHIP_SIDE_BOUNDARY;
+    if (b.peek (false) != '{') continue;
+    int l1 = b.line ();
+    Reader c (b.braces (), "simulation file", l1);
+    while (!c.eof ()) {
+      // gfs_bc_value_read, src/boundary.c:130-180
+      std::string bc = strip_gfs (c.word ());
+      BcSpec spec;
+      if (bc == "BcDirichlet") spec.kind = GFSHIP_BC_DIRICHLET;
+      else if (bc == "BcNeumann") spec.kind = GFSHIP_BC_NEUMANN;
+      else c.fail ("unsupported boundary condition `" + bc + "'");
+      std::string v = c.word ();
+      spec.val = R.functions.add (c.function (), c.line ());
+      R.bc[d][v] = spec;
+    }
+  }
+}
+
+// whole-word -D substitution (the test scripts of the reference do this with sed / m4)
+std::string substitute (const std::string & text, const std::map<std::string, std::string> & defs)
+{
+  if (defs.empty ()) return text;
+  std::string out;
+  size_t p = 0;
+  while (p < text.size ()) {
+    if (isalpha ((unsigned char) text[p]) || text[p] == '_') {
+      size_t b = p;
+      while (p < text.size () && (isalnum ((unsigned char) text[p]) || text[p] == '_')) p++;
+      std::string id = text.substr (b, p - b);
+      auto it = defs.find (id);
+      out += it != defs.end () ? it->second : id;
+    }
+    else
+      out += text[p++];
+  }
+  return out;
+}
+
+void parse_file (Run & R, const std::string & text, const std::string & name)
+{
+  Reader r (text, name);
+  // `nboxes nedges SimClass BoxClass EdgeClass { graph parameters } {`, src/simulation.c:1563-1600
+  int nboxes = (int) r.number ();
+  int nedges = (int) r.number ();
+  R.sim_class = strip_gfs (r.word ());
+  r.word (); r.word ();
+  if (r.peek () != '{') r.fail ("expecting an opening brace");
+  r.braces ();
+  if (nboxes != 1)
+    r.fail ("one GfsBox per process: multi-box files map to one box per GPU through "
+	    "gfship/distributed.py, not through this front end");
+  if (R.sim_class != "Simulation" && R.sim_class != "Poisson")
+    r.fail ("unsupported simulation class Gfs" + R.sim_class);
+  // default variables of gfs_simulation_init (src/simulation.c:958-985)
+  R.get_or_add_variable ("P");
+  R.get_or_add_variable ("Pmac");
+  R.get_or_add_variable ("U");
+  R.get_or_add_variable ("V");
+  if (R.dim == 3) R.get_or_add_variable ("W");
+  if (R.sim_class == "Poisson") R.get_or_add_variable ("Div");
+  {
+    int l0 = r.line ();
+    Reader body (r.braces (), name, l0);
+    while (!body.eof ())
+      parse_object (R, body);
+  }
+  parse_box (R, r);
+  for (int e = 0; e < nedges; e++) {
+    int a = (int) r.number (), b = (int) r.number ();
+    int d = side_from_name (r.word ());
+    if (a != 1 || b != 1 || d < 0 || d >= 2*R.dim || (d & 1))
+      r.fail ("expecting a periodic self edge `1 1 right|top|front'");
+    R.side[d] = R.side[d + 1] = GFSHIP_SIDE_PERIODIC;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// derived variables, src/simulation.c:660-905
+// ----------------------------------------------------------------------------------------------
+void add_derived (Run & R)
+{
+  Run * pr = &R;
+  auto add = [&] (const std::string & name, std::function<void (Variable &)> f) {
+    int v = R.get_or_add_variable (name);
+    R.vars[v].derive = f;
+  };
+  auto vel = [pr] (int c) -> const std::vector<double> & {
+    static const char * nm[3] = { "U", "V", "W" };
+    return host_of (*pr, pr->var_index (nm[c]));
+  };
+  add ("Velocity2", [pr, vel] (Variable & V) {
+    for_each_cell (*pr, [&] (int, int, int, size_t c) {
+      double s = 0.;
+      for (int q = 0; q < pr->dim; q++) s += vel (q)[c]*vel (q)[c];
+      V.host[c] = s;
+    });
+  });
+  add ("Velocity", [pr, vel] (Variable & V) {
+    for_each_cell (*pr, [&] (int, int, int, size_t c) {
+      double s = 0.;
+      for (int q = 0; q < pr->dim; q++) s += vel (q)[c]*vel (q)[c];
+      V.host[c] = sqrt (s);
+    });
+  });
+  add ("Divergence", [pr, vel] (Variable & V) {
+    // gfs_divergence: sum of gfs_center_gradient (u_c) / size, src/fluid.c:2356-2372
+    double h = 1./pr->n ();
+    size_t r = pr->n () + 2, off[3] = { 1, r, r*r };
+    for_each_cell (*pr, [&] (int, int, int, size_t c) {
+      double div = 0.;
+      for (int q = 0; q < pr->dim; q++)
+	div += (vel (q)[c + off[q]] - vel (q)[c - off[q]])/2.;
+      V.host[c] = div/h;
+    });
+  });
+  if (R.dim == 2)
+    add ("Vorticity", [pr, vel] (Variable & V) {
+      // gfs_vorticity, src/fluid.c:2391-2402: (dV/dx - dU/dy)/size
+      double h = 1./pr->n ();
+      size_t r = pr->n () + 2;
+      for_each_cell (*pr, [&] (int, int, int, size_t c) {
+	V.host[c] = ((vel (1)[c + 1] - vel (1)[c - 1])/2. - (vel (0)[c + r] - vel (0)[c - r])/2.)/h;
+      });
+    });
+}
+
+// ----------------------------------------------------------------------------------------------
+// events, src/event.c:60-127,410-459
+// ----------------------------------------------------------------------------------------------
+bool event_fires (Run & R, Event & e)
+{
+  if (e.dead) return false;
+  if (e.t >= e.end || e.i >= e.iend || R.t > e.end || R.i > e.iend) { e.dead = true; return false; }
+  if (e.end_event) {
+    if (e.n == 0 && (R.t >= R.end || R.i >= R.iend)) { e.n = 1; return (e.realised = true); }
+    return (e.realised = false);
+  }
+  if (R.t >= e.t) {
+    if (e.istep < INT_MAX) {
+      if (e.n == 0) { e.i = R.i + e.istep; e.n++; return (e.realised = true); }
+    }
+    else {
+      e.n++;
+      e.t = e.start + e.n*e.step;
+      return (e.realised = true);
+    }
+  }
+  if (R.i >= e.i) {
+    if (e.step < DBL_MAX) {
+      if (e.n == 0) { e.start = R.t; e.t = e.start + e.step; e.n = 1; return (e.realised = true); }
+    }
+    else {
+      e.n++;
+      e.i += e.istep;
+      return (e.realised = true);
+    }
+  }
+  return (e.realised = false);
+}
+
+void events_init (Run & R)
+{
+  for (auto & pe : R.events) {
+    Event & e = *pe;
+    if (e.end_event) e.t = e.start = DBL_MAX/2.;
+    else if (e.istep < INT_MAX)
+      while (e.i < R.i) { e.n++; e.i += e.istep; }
+    else
+      while (e.t < R.t) { e.n++; e.t = e.start + e.n*e.step; }
+  }
+}
+
+void events_do (Run & R)
+{
+  invalidate_device_copies (R);
+  for (auto & pe : R.events)
+    if (event_fires (R, *pe))
+      pe->action ();
+}
+
+// gfs_event_next, src/event.c:46-71
+double event_next (const Event & e, double t, unsigned i)
+{
+  if (t < e.t) return e.t;
+  if (e.t >= e.end || e.i >= e.iend || t > e.end || i > e.iend) return DBL_MAX;
+  if (e.end_event) return DBL_MAX;
+  if (t >= e.t) {
+    if (e.istep < INT_MAX) {
+      if (e.n == 0) return DBL_MAX;
+    }
+    else
+      return e.start + (e.n + 1)*e.step;
+  }
+  if (i >= e.i && e.step < DBL_MAX && e.n == 0)
+    return t + e.step;
+  return DBL_MAX;
+}
+
+// the event loop of gfs_simulation_set_timestep (src/simulation.c:1603-1610), called back by
+// libgfship from inside gfship_set_timestep
+double next_event_hook (void * ctx, double t, unsigned i)
+{
+  const Run & R = *(const Run *) ctx;
+  double tnext = INT_MAX;
+  for (auto & pe : R.events) {
+    if (pe->dead) continue;
+    double next = event_next (*pe, t, i);
+    if (t < next && next < tnext)
+      tnext = next + 1e-9;
+  }
+  return tnext;
+}
+
+// ----------------------------------------------------------------------------------------------
+// set-up of the device simulation
+// ----------------------------------------------------------------------------------------------
+void set_boundary_conditions (Run & R)
+{
+  int n = R.n ();
+  size_t nface = R.dim == 3 ? (size_t) n*n : n;
+  for (int d = 0; d < 2*R.dim; d++)
+    for (auto & kv : R.bc[d]) {
+      int v = R.var_index (kv.first);
+      if (v < 0 || R.vars[v].dev < 0) {
+	fprintf (stderr, "gfship: boundary condition on unknown variable `%s'\n", kv.first.c_str ());
+	exit (1);
+      }
+      // value at the centre of every boundary face, first tangential axis fastest
+      std::vector<double> val (nface);
+      int c = d/2, ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
+      double h = 1./n;
+      for (size_t f = 0; f < nface; f++) {
+	int ijk[3] = { 1, 1, 1 };
+	ijk[c] = (d & 1) ? 1 : n;
+	ijk[ta] = (int) (f % n) + 1;
+	if (R.dim == 3) ijk[tb] = (int) (f / n) + 1;
+	double p[3];
+	cell_pos (R, ijk[0], ijk[1], R.dim == 3 ? ijk[2] : 0, p);
+	p[c] += (d & 1) ? -h/2. : h/2.;      /* ftt_face_pos */
+	val[f] = eval (R, kv.second.val, p, -1);
+      }
+      CHECK (gfship_field_set_bc (R.dom, R.vars[v].dev, d, kv.second.kind, val.data ()));
+    }
+}
+
+void apply_init (Run & R)
+{
+  // gfs_init_event, src/init.c: every `var = function` in file order, on the leaf cells
+  for (auto & kv : R.init) {
+    int v = R.var_index (kv.first);
+    std::vector<double> a = host_of (R, v);     /* copy: the function may read the variable */
+    for_each_cell (R, [&] (int i, int j, int k, size_t c) {
+      double p[3];
+      cell_pos (R, i, j, k, p);
+      a[c] = eval (R, kv.second, p, (long) c);
+    });
+    R.vars[v].host = a;
+    if (R.vars[v].dev >= 0) {
+      CHECK (gfship_field_upload (R.dom, R.vars[v].dev, R.level, a.data ()));
+      R.vars[v].host_time = (double) R.i;
+    }
+  }
+}
+
+int run (Run & R)
+{
+  R.clock0 = std::chrono::steady_clock::now ();
+  CHECK (gfship_domain_create (&R.dom, R.dim, R.level, R.side, R.device));
+  CHECK (gfship_sim_create (&R.sim, R.dom));
+  R.vars[R.var_index ("P")].dev = gfship_sim_variable (R.sim, GFSHIP_VAR_P, 0);
+  R.vars[R.var_index ("Pmac")].dev = gfship_sim_variable (R.sim, GFSHIP_VAR_PMAC, 0);
+  const char * un[3] = { "U", "V", "W" };
+  for (int c = 0; c < R.dim; c++)
+    R.vars[R.var_index (un[c])].dev = gfship_sim_variable (R.sim, GFSHIP_VAR_U, c);
+  for (const std::string & t : R.tracers) {
+    int k = gfship_sim_add_tracer (R.sim);
+    CHECK (k);
+    R.vars[R.var_index (t)].dev = gfship_sim_variable (R.sim, GFSHIP_VAR_TRACER, k);
+  }
+  gfship_field div = -1;
+  if (R.sim_class == "Poisson") {
+    div = gfship_field_alloc (R.dom, -1);     /* the temporary `div` of poisson_run */
+    CHECK (div);
+  }
+  add_derived (R);
+  R.functions.resolve (R.var_names ());
+
+  apply_multilevel (gfship_sim_projection_params (R.sim), R.proj_set);
+  apply_multilevel (gfship_sim_approx_projection_params (R.sim), R.approx_set);
+  gfship_advection_params * adv = gfship_sim_advection_params (R.sim);
+  for (auto & kv : R.adv_set) {
+    if (kv.first == "cfl") adv->cfl = atof (kv.second.c_str ());
+    else if (kv.first == "gc") adv->gc = atoi (kv.second.c_str ());
+    else if (kv.first == "gradient") {
+      if (kv.second == "gfs_center_gradient") adv->gradient = 0;
+      else if (kv.second == "gfs_center_van_leer_gradient") adv->gradient = 1;
+      else { fprintf (stderr, "gfship: unsupported gradient `%s'\n", kv.second.c_str ()); return 1; }
+    }
+  }
+  for (int c = 0; c < R.dim; c++)
+    if (R.visc[c] != 0.) {
+      CHECK (gfship_sim_set_viscosity (R.sim, c, R.visc[c]));
+      apply_multilevel (gfship_sim_diffusion_params (R.sim, c), R.diff_set[c]);
+    }
+  set_boundary_conditions (R);
+  apply_init (R);
+  events_init (R);
+
+  if (R.sim_class == "Poisson") {
+    // poisson_run, src/simulation.c:2213-2285 (P has a Dirichlet condition somewhere, or the
+    // mean of Div is removed by correct_div: only the Dirichlet case is supported here)
+    gfship_field p = R.vars[R.var_index ("P")].dev;
+    bool dirichlet = false;
+    for (int d = 0; d < 2*R.dim; d++)
+      if (R.bc[d].count ("P") && R.bc[d]["P"].kind == GFSHIP_BC_DIRICHLET) dirichlet = true;
+    if (!dirichlet) { fprintf (stderr, "gfship: GfsPoisson needs a Dirichlet condition on P\n"); return 1; }
+    gfship_field res = gfship_field_alloc (R.dom, -1), dia = gfship_field_alloc (R.dom, -1);
+    CHECK (res); CHECK (dia);
+    CHECK (gfship_bc (R.dom, p, p, R.level));
+    gfship_multilevel_params * par = gfship_sim_approx_projection_params (R.sim);
+    while (R.i < R.iend && R.t < R.end) {
+      {
+	/* correct_div with a Dirichlet condition: rescale_div only, div = Div*size*size*fraction
+	   (src/simulation.c:2156-2162,2170-2211) */
+	const std::vector<double> & Div = host_of (R, R.var_index ("Div"));
+	std::vector<double> scaled (R.total (), 0.);
+	double size = 1./R.n ();
+	for_each_cell (R, [&] (int, int, int, size_t c) { scaled[c] = Div[c]*(size*size*1.); });
+	CHECK (gfship_field_upload (R.dom, div, R.level, scaled.data ()));
+      }
+      CHECK (gfship_poisson_coefficients (R.dom));
+      for (int l = 0; l <= R.level; l++)
+	CHECK (gfship_field_fill (R.dom, dia, l, 0.));
+      CHECK (gfship_poisson_solve (R.dom, par, p, div, res, dia, 1.));
+      R.t = 0.;         /* sim->time.t = sim->tnext, and tnext stays 0. (src/simulation.c:1014,2269) */
+      R.i++;
+      events_do (R);
+    }
+  }
+  else {
+    // simulation_run, src/simulation.c:432-557
+    CHECK (gfship_sim_set_time (R.sim, R.end, R.dtmax));
+    CHECK (gfship_sim_set_next_event (R.sim, next_event_hook, &R));
+    CHECK (gfship_sim_start (R.sim));
+    while (R.t < R.end && R.i < R.iend) {
+      events_do (R);
+      /* a GfsEventStop may just have set time.end = time.t: the reference still completes this
+	 iteration of the loop and stops at the next test of its condition */
+      CHECK (gfship_sim_set_time (R.sim, R.end, R.dtmax));
+      CHECK (gfship_sim_step (R.sim));
+      R.t = gfship_sim_time (R.sim);
+      R.i = gfship_sim_iter (R.sim);
+    }
+    events_do (R);
+  }
+  for (auto & o : R.outputs) o->close ();
+  gfship_sim_destroy (R.sim);
+  gfship_domain_destroy (R.dom);
+  return 0;
+}
+
+} // namespace
+
+// --check: parse, compile the functions and describe the run without touching a device
+int check (Run & R)
+{
+  add_derived (R);
+  R.functions.resolve (R.var_names ());
+  printf ("class Gfs%s dim %d level %d\n", R.sim_class.c_str (), R.dim, R.level);
+  printf ("sides");
+  for (int d = 0; d < 2*R.dim; d++)
+    printf (" %s=%s", side_name[d], R.side[d] == GFSHIP_SIDE_PERIODIC ? "periodic" : "boundary");
+  printf ("\ntime t %g i %u end %g iend %u\n", R.t, R.i, R.end, R.iend);
+  double p[3] = { 0.125, -0.25, R.dim == 3 ? 0.375 : 0. };
+  for (auto & kv : R.init) {
+    bool reads_vars = kv.second->kind == Function::VARIABLE || !kv.second->args.empty ();
+    if (reads_vars) printf ("init %s = <function of variables>\n", kv.first.c_str ());
+    else printf ("init %s (0.125,-0.25,%g) = %.17g\n", kv.first.c_str (), p[2], eval (R, kv.second, p, -1));
+  }
+  for (int d = 0; d < 2*R.dim; d++)
+    for (auto & kv : R.bc[d])
+      printf ("bc %s %s %s %.17g\n", side_name[d], kv.first.c_str (),
+	      kv.second.kind == GFSHIP_BC_DIRICHLET ? "dirichlet" : "neumann",
+	      eval (R, kv.second.val, p, -1));
+  for (int c = 0; c < R.dim; c++)
+    if (R.visc[c] != 0.) printf ("viscosity %d %g\n", c, R.visc[c]);
+  for (auto & e : R.events)
+    printf ("event %s line %d start %g step %g istep %u end_event %d\n", e->cls.c_str (), e->line,
+	    e->start, e->step == DBL_MAX ? -1. : e->step, e->istep == INT_MAX ? 0 : e->istep,
+	    (int) e->end_event);
+  return 0;
+}
+
+int main (int argc, char ** argv)
+{
+  Run R;
+  bool check_only = false;
+  // dimension from the program name, like gerris2D / gerris3D
+  std::string prog = argv[0];
+  R.dim = prog.find ("3D") != std::string::npos ? 3 : 2;
+  std::map<std::string, std::string> defs;
+  std::string file;
+  for (int a = 1; a < argc; a++) {
+    std::string s = argv[a];
+    if (s == "-2") R.dim = 2;
+    else if (s == "-3") R.dim = 3;
+    else if (s == "--device" && a + 1 < argc) R.device = atoi (argv[++a]);
+    else if (s == "--check") check_only = true;
+    else if (s.compare (0, 2, "-D") == 0) {
+      std::string d = s.size () > 2 ? s.substr (2) : (a + 1 < argc ? argv[++a] : "");
+      size_t eq = d.find ('=');
+      if (eq == std::string::npos) defs[d] = "1";
+      else defs[d.substr (0, eq)] = d.substr (eq + 1);
+    }
+    else if (s == "-h" || s == "--help") {
+      printf ("Usage: %s [-2|-3] [-DNAME=VALUE] [--device N] file.gfs\n", argv[0]);
+      return 0;
+    }
+    else file = s;
+  }
+  if (file.empty ()) { fprintf (stderr, "gfship: no simulation file given\n"); return 1; }
+  std::ifstream in (file);
+  if (!in) { fprintf (stderr, "gfship: cannot open `%s'\n", file.c_str ()); return 1; }
+  std::stringstream ss;
+  ss << in.rdbuf ();
+  try {
+    parse_file (R, substitute (ss.str (), defs), file);
+    return check_only ? check (R) : run (R);
+  }
+  catch (const ParseError & e) {
+    fprintf (stderr, "gfship: %s\n", e.what ());
+    return 1;
+  }
+}

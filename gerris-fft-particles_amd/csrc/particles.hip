@@ -336,6 +336,27 @@ particle_gather_kernel (GatherArgs G)
   G.alive2[q] = G.alive[s];
 }
 
+// GfsOutputLocation (src/output.c:1182-1199): gfs_domain_locate then gfs_interpolate of one
+// variable at arbitrary points
+template <int DIM>
+__global__ void __launch_bounds__(256)
+sample_kernel (Layout L, int depth, int np, const double * __restrict__ pos,
+	       const double * __restrict__ v, double * __restrict__ out,
+	       unsigned char * __restrict__ inside)
+{
+  int q = blockIdx.x*blockDim.x + threadIdx.x;
+  if (q >= np) return;
+  double p[3] = { pos[3*(size_t) q], pos[3*(size_t) q + 1], DIM == 3 ? pos[3*(size_t) q + 2] : 0. };
+  int cell[3];
+  if (!locate<DIM> (depth, p, cell)) {
+    inside[q] = 0;
+    out[q] = 0.;
+    return;
+  }
+  inside[q] = 1;
+  out[q] = interpolate<DIM> (L, v, cell, p);
+}
+
 __global__ void __launch_bounds__(256)
 count_alive_kernel (const unsigned char * alive, int n, unsigned * count)
 {
@@ -414,6 +435,44 @@ void gfship_particles_destroy (gfship_particles * pl)
   for (void * a : extra)
     if (a) (void) hipFree (a);
   delete pl;
+}
+
+int gfship_field_interpolate (gfship_domain * dom, gfship_field v, int np, const double * pos,
+			      double * out, unsigned char * inside)
+{
+  GFSHIP_CHECK (dom && pos && out && inside && np >= 0, GFSHIP_EINVAL, "invalid argument");
+  Field * V = get_field (dom, v);
+  if (!V) return GFSHIP_EINVAL;
+  if (np == 0) return GFSHIP_OK;
+  double * dpos = nullptr, * dout = nullptr;
+  unsigned char * din = nullptr;
+  GFSHIP_HIP (hipMalloc ((void **) &dpos, 3*(size_t) np*sizeof (double)));
+  GFSHIP_HIP (hipMalloc ((void **) &dout, (size_t) np*sizeof (double)));
+  GFSHIP_HIP (hipMalloc ((void **) &din, (size_t) np));
+  int r = GFSHIP_OK;
+  hipError_t e = hipMemcpyAsync (dpos, pos, 3*(size_t) np*sizeof (double), hipMemcpyHostToDevice,
+				 dom->stream);
+  if (e == hipSuccess) {
+    int block = 256, grid = (np + block - 1)/block;
+    const Layout & L = dom->lay[dom->depth];
+    if (dom->dim == 3)
+      hipLaunchKernelGGL (sample_kernel<3>, dim3 (grid), dim3 (block), 0, dom->stream, L, dom->depth,
+			  np, dpos, V->lev[dom->depth], dout, din);
+    else
+      hipLaunchKernelGGL (sample_kernel<2>, dim3 (grid), dim3 (block), 0, dom->stream, L, dom->depth,
+			  np, dpos, V->lev[dom->depth], dout, din);
+    e = hipGetLastError ();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync (out, dout, (size_t) np*sizeof (double), hipMemcpyDeviceToHost, dom->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync (inside, din, (size_t) np, hipMemcpyDeviceToHost, dom->stream);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize (dom->stream);
+  if (e != hipSuccess)
+    r = hip_fail (e, "gfship_field_interpolate", __FILE__, __LINE__);
+  (void) hipFree (dpos); (void) hipFree (dout); (void) hipFree (din);
+  return r;
 }
 
 int gfship_particles_set_sort_interval (gfship_particles * pl, int every)

@@ -23,6 +23,7 @@ struct gfship_sim {
   double visc[3] = {0., 0., 0.};   // GfsSourceDiffusion on U, V, W (constant coefficient)
   gfship_multilevel_params diffusion_params[3];
   gfship_field drhs = -1, rhoc = -1;   // temporaries of variable_diffusion
+  gfship_next_event_fn next_event = nullptr; void * next_event_ctx = nullptr;
 };
 
 namespace {
@@ -261,6 +262,14 @@ int gfship_sim_set_viscosity (gfship_sim * s, int c, double nu)
 gfship_multilevel_params * gfship_sim_diffusion_params (gfship_sim * s, int c)
 { return (s && c >= 0 && c < 3) ? &s->diffusion_params[c] : nullptr; }
 
+int gfship_sim_set_next_event (gfship_sim * s, gfship_next_event_fn fn, void * ctx)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  s->next_event = fn;
+  s->next_event_ctx = ctx;
+  return GFSHIP_OK;
+}
+
 int gfship_sim_add_tracer (gfship_sim * s)
 {
   GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
@@ -371,7 +380,11 @@ int gfship_set_timestep (gfship_sim * s)
   if (s->advection_params.dt > s->dtmax)
     s->advection_params.dt = s->dtmax;
 
+  /* the events bound the step (gfs_event_next loop, src/simulation.c:1603-1610): the host that
+     owns the GfsEvent list answers through the hook */
   double tnext = G_MAXINT;
+  if (s->next_event)
+    tnext = s->next_event (s->next_event_ctx, t, s->i);
   if (s->end < tnext)
     tnext = s->end;
 

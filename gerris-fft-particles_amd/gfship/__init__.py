@@ -87,6 +87,7 @@ SIGNATURES = {
     "gfship_sim_approx_projection_params": (C.POINTER(MultilevelParams), [_vp]),
     "gfship_sim_advection_params": (C.POINTER(AdvectionParams), [_vp]),
     "gfship_sim_set_time": (_i, [_vp, _d, _d]),
+    "gfship_sim_set_next_event": (_i, [_vp, _vp, _vp]),
     "gfship_sim_time": (_d, [_vp]),
     "gfship_sim_iter": (_u, [_vp]),
     "gfship_sim_add_tracer": (_i, [_vp]),
@@ -108,6 +109,7 @@ SIGNATURES = {
     "gfship_domain_set_reduce": (_i, [_vp, _vp, _vp]),
     "gfship_halo_pack": (_i, [_vp, _vp, _i, _i, _vp]),
     "gfship_halo_unpack": (_i, [_vp, _vp, _i, _i, _vp]),
+    "gfship_field_interpolate": (_i, [_vp, _i, _i, _pd, _pd, C.POINTER(C.c_ubyte)]),
     "gfship_particles_create": (_i, [C.POINTER(_vp), _vp, _i, _pd, C.POINTER(C.c_uint)]),
     "gfship_particles_destroy": (None, [_vp]),
     "gfship_particle_list_event": (_i, [_vp]),
@@ -263,6 +265,16 @@ class Domain:
 
     def diffusion(self, par, v, rhs, rhoc):
         _check(lib().gfship_diffusion(self.ptr, C.byref(par), v.h, rhs.h, rhoc.h))
+
+    def interpolate(self, v, points):
+        """GfsOutputLocation sampling: (values, inside) of variable v at points (np x 3)"""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        out = np.empty(len(pts))
+        inside = np.empty(len(pts), dtype=np.uint8)
+        _check(lib().gfship_field_interpolate(self.ptr, v.h, len(pts), pts.ctypes.data_as(_pd),
+                                              out.ctypes.data_as(_pd),
+                                              inside.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        return out, inside.astype(bool)
 
     def time_relax(self, u, rhs, dia, level=None, reps=10, d=None):
         level = self.depth if level is None else level

@@ -174,6 +174,12 @@ gfship_multilevel_params * gfship_sim_projection_params (gfship_sim * sim);
 gfship_multilevel_params * gfship_sim_approx_projection_params (gfship_sim * sim);
 gfship_advection_params *  gfship_sim_advection_params (gfship_sim * sim);
 int      gfship_sim_set_time (gfship_sim * sim, double end, double dtmax); /* GfsTime */
+/* gfs_simulation_set_timestep shortens the step so that it lands on the next event
+   (src/simulation.c:1603-1610: for every GfsEvent, `if (t < next && next < tnext) tnext = next +
+   1e-9` with next = gfs_event_next, starting from G_MAXINT).  The events belong to the host:
+   the hook returns that tnext for the simulation time t and iteration i it is given. */
+typedef double (* gfship_next_event_fn) (void * ctx, double t, unsigned i);
+int      gfship_sim_set_next_event (gfship_sim * sim, gfship_next_event_fn fn, void * ctx);
 double   gfship_sim_time (gfship_sim * sim);
 unsigned gfship_sim_iter (gfship_sim * sim);
 int      gfship_sim_add_tracer (gfship_sim * sim);       /* GfsVariableTracer, src/variable.c:427-431 */
@@ -204,6 +210,12 @@ int  gfship_divergence_norm (gfship_sim * sim, gfship_norm * out);
 /* MAC normal velocity on the faces orthogonal to component c, as a host array in the cell
    convention: entry (i,j,k) is the face on the + side of cell (i,j,k) (0 <= i <= n along c) */
 int  gfship_sim_download_un (gfship_sim * sim, int c, double * host);
+
+/* GfsOutputLocation's sampling (src/output.c:1182-1199): gfs_domain_locate + gfs_interpolate
+   (src/fluid.c:2983-3101) of variable v at np points (pos = 3*np doubles); inside[q] = 0 where
+   the point is outside the domain (out[q] is then 0) */
+int  gfship_field_interpolate (gfship_domain * dom, gfship_field v, int np, const double * pos,
+			       double * out, unsigned char * inside);
 
 /* ---- Lagrangian tracers (src/particle.c, modules/particulatecommon.c) ------------------------ */
 

@@ -73,18 +73,21 @@ def oracle_lid(level=6, nu=1e-3):
 
 def run_until_steady(s, var, every=10, tol=1e-4, max_steps=100000):
     """simulation_run with GfsEventStop { istep = every } var tol (src/event.c:1797-1835): every
-    `every` steps (and at step 0) compare var with its previous copy; stop when max|diff| <= tol."""
+    `every` steps compare var with its previous copy; when max|diff| <= tol the event sets
+    time.end = time.t, the loop body still completes (src/simulation.c:476-548) and the loop
+    condition ends the run."""
     s.start()
     old = None
     hist = []
-    while s.t < s.end and s.i < max_steps:
+    end = s.end
+    while s.t < end and s.i < max_steps:
         if s.i % every == 0:
             cur = var.interior().copy()
             if old is not None:
                 du = np.abs(cur - old).max()
                 hist.append((s.i, s.t, du))
                 if du <= tol:
-                    break
+                    end = s.t
             old = cur
         s.step()
     return hist

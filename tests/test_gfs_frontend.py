@@ -1,0 +1,147 @@
+"""The .gfs front end (gerris-fft-particles_amd/bin/gfship2D, built by csrc/build.sh).
+
+CPU part: the reader and the function compiler (`--check`: parse, compile the C expressions
+with the system compiler, describe the run; no device is touched).
+GPU part: the repo's own case files (tests/cases/*.gfs: the set-ups of the reference's
+test/poisson, test/lid, test/reynolds and test/periodic, written for this repo) run end to end on
+the device and are checked against the reference's golden files exactly the way the reference's
+test scripts do (poisson.sh, lid.sh, reynolds.sh, periodic.sh)."""
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "gerris-fft-particles_amd", "bin", "gfship2D")
+CASES = os.path.join(ROOT, "tests", "cases")
+
+
+def _run(case, defs, cwd=None, check=False, exe=BIN):
+    cmd = [exe] + (["--check"] if check else []) + ["-D%s=%s" % kv for kv in defs.items()] + \
+        [os.path.join(CASES, case)]
+    r = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def _rows(golden_dir, name):
+    return [l.split() for l in open(os.path.join(golden_dir, "reference", name)) if l.strip()]
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU: reader + function compiler
+# ---------------------------------------------------------------------------------------------
+
+def test_front_end_is_built():
+    assert os.path.exists(BIN), "run __graft_entry__.build()"
+    assert os.path.exists(BIN.replace("2D", "3D"))
+
+
+def test_check_poisson_case_functions():
+    out = _run("dirichlet_multigrid.gfs", {"LEVEL": 5, "CYCLE": 3}, check=True)
+    assert "class GfsPoisson dim 2 level 5" in out
+    assert "iend 1" in out
+    x, y = 0.125, -0.25
+    div = -math.pi * math.pi * 18 * math.sin(3 * math.pi * x) * math.sin(3 * math.pi * y)
+    line = [l for l in out.splitlines() if l.startswith("init Div")][0]
+    assert float(line.split("=")[1]) == pytest.approx(div, rel=1e-15)
+    bcs = [l.split() for l in out.splitlines() if l.startswith("bc ")]
+    assert sorted(b[1] for b in bcs) == ["bottom", "left", "right", "top"]
+    assert all(b[2] == "P" and b[3] == "dirichlet" for b in bcs)
+    assert float(bcs[0][4]) == pytest.approx(math.sin(3 * math.pi * x) * math.sin(3 * math.pi * y),
+                                             rel=1e-15)
+    ev = [l.split()[1] for l in out.splitlines() if l.startswith("event ")]
+    assert ev == ["OutputProjectionStats", "OutputErrorNorm"]
+
+
+def test_check_cavity_and_periodic_cases(golden_dir):
+    g = os.path.join(golden_dir, "reference")
+    out = _run("cavity.gfs", {"LEVEL": 6, "XPROFILE": os.path.join(g, "lid_xprofile"),
+                              "YPROFILE": os.path.join(g, "lid_yprofile")}, check=True)
+    assert "viscosity 0 0.001" in out and "viscosity 1 0.001" in out
+    assert "bc top U dirichlet 1" in out
+    assert "event EventStop line" in out and "istep 10" in out
+    out = _run("vortex_decay.gfs", {"LEVEL": 5}, check=True)
+    assert "right=periodic left=periodic top=periodic bottom=periodic" in out
+    assert "init U = <function of variables>" in out       # U = U0: a variable name
+    out = _run("vortex_translation.gfs", {"LEVEL": 5}, check=True)
+    assert "end 0.5" in out
+
+
+def test_unsupported_input_fails_loudly(tmp_path):
+    bad = tmp_path / "bad.gfs"
+    bad.write_text("1 0 GfsSimulation GfsBox GfsGEdge {} {\n  Refine (x > 0 ? 5 : 4)\n}\nGfsBox {}\n")
+    r = subprocess.run([BIN, "--check", str(bad)], capture_output=True, text=True)
+    assert r.returncode != 0 and "uniform" in r.stderr and ":2:" in r.stderr
+    bad.write_text("1 0 GfsSimulation GfsBox GfsGEdge {} {\n  Refine 4\n  Solid (x*x + y*y - 0.1)\n}\nGfsBox {}\n")
+    r = subprocess.run([BIN, "--check", str(bad)], capture_output=True, text=True)
+    assert r.returncode != 0 and "unsupported object `Solid'" in r.stderr
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU: the cases end to end, checked like the reference's test scripts
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_poisson_case_matches_res7_and_error_refs(golden_dir):
+    """test/poisson/poisson.sh: residual after CYCLE V-cycles at level 8 (res-7.ref column 3) and
+    error norms after 10 cycles for levels 3..8 (error.ref), read from OutputProjectionStats and
+    OutputErrorNorm"""
+    for row in _rows(golden_dir, "poisson_res-7.ref"):
+        cyc = int(row[0])
+        out = _run("dirichlet_multigrid.gfs", {"LEVEL": 8, "CYCLE": cyc})
+        res = [l.split() for l in out.splitlines() if l.split()[:1] == ["residual.infty:"]]
+        # awk '{if ($1 == "residual.infty:") print CYCLE, $3, $4;}': after, rate
+        assert res[-1][2] == row[2], (cyc, res, row)
+    for row in _rows(golden_dir, "poisson_error.ref"):
+        out = _run("dirichlet_multigrid.gfs", {"LEVEL": int(row[0]), "CYCLE": 10})
+        err = [l.split() for l in out.splitlines() if l.startswith("P time:")][-1]
+        # awk '{print LEVEL, $5, $7, $9}'
+        assert [err[4], err[6], err[8]] == row[1:4], (row, err)
+
+
+@pytest.mark.gpu
+def test_cavity_case_meets_ghia(golden_dir, tmp_path):
+    g = os.path.join(golden_dir, "reference")
+    _run("cavity.gfs", {"LEVEL": 6, "XPROFILE": os.path.join(g, "lid_xprofile"),
+                        "YPROFILE": os.path.join(g, "lid_yprofile")}, cwd=str(tmp_path))
+    xp = np.loadtxt(tmp_path / "xprof")
+    yp = np.loadtxt(tmp_path / "yprof")
+    assert xp.shape == (101, 9) and yp.shape == (101, 9)      # t x y z P Pmac U V DU
+    gx = np.loadtxt(os.path.join(g, "xprof.ghia"))
+    gy = np.loadtxt(os.path.join(g, "yprof.ghia"))
+    # lid.sh: Curve('xprof',3,7) - Curve('xprof.ghia',1,2), Curve('yprof',2,8) - ...
+    ex = np.abs(np.interp(gx[:, 0], xp[:, 2], xp[:, 6]) - gx[:, 1]).max()
+    ey = np.abs(np.interp(gy[:, 0], yp[:, 1], yp[:, 7]) - gy[:, 1]).max()
+    assert ex <= 2e-2 and ey <= 1.7e-2, (ex, ey)
+    du = open(tmp_path / "du").read().splitlines()
+    assert du[-1].startswith("DU time:") and float(du[-1].split()[-1]) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_vortex_decay_case_matches_div5_and_reynolds_refs(golden_dir, tmp_path):
+    """test/reynolds/reynolds.sh at level 5: the Divergence history equals div5.ref line by line,
+    and the effective Reynolds number from the kinetic energy file matches reynolds.ref"""
+    _run("vortex_decay.gfs", {"LEVEL": 5}, cwd=str(tmp_path))
+    got = open(tmp_path / "div").read().splitlines()
+    ref = open(os.path.join(golden_dir, "reference", "reynolds_div5.ref")).read().splitlines()
+    assert len(got) == len(ref)
+    assert got[0].split()[:3] == ref[0].split()[:3]       # t = 0 is round-off noise
+    assert got[1:] == ref[1:]
+    kin = [l.split() for l in open(tmp_path / "kinetic")]
+    ke0, ke1, t1 = float(kin[0][-1]), float(kin[-1][-1]), float(kin[-1][2])
+    a = -math.log(ke1 / ke0) / t1
+    nu = a / (4. * (2. * 3.14159265359) ** 2)
+    rey = {r[0]: float(r[1]) for r in _rows(golden_dir, "reynolds_reynolds.ref")}
+    assert 1. / nu == pytest.approx(rey["5"], rel=2e-5)
+
+
+@pytest.mark.gpu
+def test_vortex_translation_case_matches_r0_ref(golden_dir):
+    for row in _rows(golden_dir, "periodic_r0.ref")[:2]:
+        out = _run("vortex_translation.gfs", {"LEVEL": int(row[0])})
+        err = [l.split() for l in out.splitlines() if l.startswith("U time:")][-1]
+        # periodic.sh: awk '{print LEVEL, $7, $9}': second, infty
+        assert [err[6], err[8]] == row[1:3], (row, err)
