@@ -128,8 +128,10 @@ int gfship_domain_set_relax_mode (gfship_domain * dom, int mode)
 {
   GFSHIP_CHECK (dom != nullptr, GFSHIP_EINVAL, "null domain");
   GFSHIP_CHECK (mode == GFSHIP_RELAX_EXACT || mode == GFSHIP_RELAX_REDBLACK ||
-		mode == GFSHIP_RELAX_EXACT_HYPERPLANE, GFSHIP_EINVAL, "unknown relax mode %d", mode);
+		mode == GFSHIP_RELAX_EXACT_HYPERPLANE || mode == GFSHIP_RELAX_EXACT_PER_SWEEP,
+		GFSHIP_EINVAL, "unknown relax mode %d", mode);
   dom->force_hyperplane = (mode == GFSHIP_RELAX_EXACT_HYPERPLANE);
+  dom->no_fused_loop = (mode == GFSHIP_RELAX_EXACT_PER_SWEEP);
   dom->relax_mode = mode == GFSHIP_RELAX_REDBLACK ? GFSHIP_RELAX_REDBLACK : GFSHIP_RELAX_EXACT;
   return GFSHIP_OK;
 }

@@ -46,6 +46,9 @@ struct SkewPlan {
   size_t hb_words = 0;
   double * us = nullptr, * rs = nullptr, * ds = nullptr;
   void * hb = nullptr;            // hand-off granules (J side then K side)
+  void * hbf = nullptr;           // granules of the fused relax loop (relax_skew_loop.hip)
+  unsigned * prog = nullptr;      // per-tile progress words of the fused relax loop
+  void * stats_loop = nullptr;    // optional per-tile, per-sweep timing of the fused loop (debug)
   void * ctl = nullptr;           // { ticket, err }
   unsigned long long * stats = nullptr; // optional per-tile timing (debug)
   unsigned short * order = nullptr;
@@ -84,6 +87,8 @@ struct gfship_domain {
   gfship_reduce_fn reduce = nullptr;     void * reduce_ctx = nullptr;
   bool has_external = false;
   gfship_field dp_cache = -1;     // the `dp` temporary of gfs_poisson_cycle, kept between cycles
+  int skew_resident = -1;         // workgroups of the fused relax loop that fit on the device
+  bool no_fused_loop = false;     // one launch per sweep even where the fused loop applies
   bool force_hyperplane = false;  // debug/bench: per-hyperplane launches instead of relax_skew
   bool unit_weights = false;      // gfship_poisson_coefficients called with alpha = NULL
   gfship::SkewPlan skew[GFSHIP_MAXLEVEL + 1];
@@ -157,6 +162,12 @@ int  launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field *
 			     const double * rhs, const double * dia, bool dia_zero,
 			     unsigned nrelax, bool bc);
 void skew_free (gfship_domain * dom);
+bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool bc);
+int  skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia,
+		    unsigned nrelax, float * ms = nullptr);
+int  skew_time_loop (gfship_domain * dom, int level, Field * u, const double * rhs,
+		     const double * dia, bool dia_zero, unsigned nrelax, int reps,
+		     double * ms_per_loop, int * fused);
 int  skew_check_error (gfship_domain * dom);
 void skew_dump_stats (gfship_domain * dom, int level);
 int  skew_time_sweeps (gfship_domain * dom, int level, Field * u, const double * rhs,

@@ -378,6 +378,9 @@ void skew_free (gfship_domain * dom)
     if (S.rs) (void) hipFree (S.rs);
     if (S.ds) (void) hipFree (S.ds);
     if (S.hb) (void) hipFree (S.hb);
+    if (S.hbf) (void) hipFree (S.hbf);
+    if (S.prog) (void) hipFree (S.prog);
+    if (S.stats_loop) (void) hipFree (S.stats_loop);
     if (S.ctl) (void) hipFree (S.ctl);
     if (S.stats) (void) hipFree (S.stats);
     if (S.order) (void) hipFree (S.order);
@@ -454,6 +457,11 @@ int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * 
   double * u = dp->lev[level];
   if (bc && (r = launch_bc (dom, ubc, dp, level, 1))) return r;
   if ((r = skew_pack (dom, level, S, u, rhs, dia_zero ? nullptr : dia))) return r;
+  if (!dom->no_fused_loop && skew_loop_supported (dom, level, nrelax, bc)) {
+    /* the sweeps of the loop pipelined in one launch (relax_skew_loop.hip) */
+    if ((r = skew_loop_run (dom, level, S, u, !dia_zero, nrelax))) return r;
+    return skew_unpack (dom, level, S, u);
+  }
   for (unsigned q = 0; q < nrelax; q++) {
     if ((r = skew_sweep (dom, level, S, u, !dia_zero))) return r;
     if (bc && q + 1 < nrelax && (r = launch_bc (dom, ubc, dp, level, 1))) return r;
@@ -506,6 +514,47 @@ int skew_time_sweeps (gfship_domain * dom, int level, Field * u, const double * 
   }
   *ms_per_sweep = total/reps;
   return skew_unpack (dom, level, S, u->lev[level]);
+}
+
+// time `reps` relax loops (nrelax sweeps, homogeneous BC of u itself between them): the sweep
+// kernels alone
+int skew_time_loop (gfship_domain * dom, int level, Field * u, const double * rhs,
+		    const double * dia, bool dia_zero, unsigned nrelax, int reps,
+		    double * ms_per_loop, int * fused)
+{
+  SkewPlan * S;
+  int r;
+  if ((r = skew_plan (dom, level, &S))) return r;
+  double * un = u->lev[level];
+  bool fuse = !dom->no_fused_loop && skew_loop_supported (dom, level, nrelax, true);
+  *fused = fuse;
+  double total = 0.;
+  for (int q = -1; q < reps; q++) {       /* q = -1: warm-up */
+    if ((r = launch_bc (dom, u, u, level, 1))) return r;
+    if ((r = skew_pack (dom, level, S, un, rhs, dia_zero ? nullptr : dia))) return r;
+    float ms = 0.f;
+    if (fuse) {
+      if ((r = skew_loop_run (dom, level, S, un, !dia_zero, nrelax, &ms))) return r;
+    }
+    else
+      for (unsigned w = 0; w < nrelax; w++) {
+	GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
+	if (S->ntj > 1)
+	  GFSHIP_HIP (hipMemsetAsync (S->hb, 0xFF, 2*S->hb_words*sizeof (u64), dom->stream));
+	GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
+	if ((r = skew_launch (dom, level, S, un, !dia_zero))) return r;
+	GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));
+	GFSHIP_HIP (hipEventSynchronize (dom->ev1));
+	float m1 = 0.f;
+	GFSHIP_HIP (hipEventElapsedTime (&m1, dom->ev0, dom->ev1));
+	ms += m1;
+	if (w + 1 < nrelax && (r = launch_bc (dom, u, u, level, 1))) return r;
+      }
+    if ((r = skew_unpack (dom, level, S, un))) return r;
+    if (q >= 0) total += ms;
+  }
+  *ms_per_loop = total/reps;
+  return GFSHIP_OK;
 }
 
 int skew_check_error (gfship_domain * dom)

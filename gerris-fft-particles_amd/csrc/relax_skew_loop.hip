@@ -1,0 +1,414 @@
+// relax_skew_loop.hip -- a whole relax_loop (src/poisson.c:1070-1089) of a periodic 3-D level as
+// ONE launch: the sweeps of the loop are pipelined behind each other.
+//
+// One exact-order sweep has a dependency chain of 3n - 2 hyperplanes, during which most of the
+// chip idles (only a diagonal band of tiles is active, relax_skew.hip).  The next sweep of the
+// loop does not have to wait for the end of the previous one: cell (I,J,K) of sweep s + 1 needs
+//   - the sweep-s values of its +1 neighbours (one hyperplane later in sweep s), and
+//   - the homogeneous-BC ghosts, which on a periodic box are the sweep-s values of the cells on
+//     the opposite side (gfs_domain_homogeneous_bc between the sweeps, src/poisson.c:1078-1086):
+//     ghost I = -1 is cell I = n - 1 of the same line, so a line can start sweep s + 1 as soon as
+//     it has finished sweep s.
+// So every workgroup keeps its tile for the whole loop and starts sweep s + 1 right after its own
+// sweep s: the loop takes one sweep plus (nrelax - 1) tile-sweeps (~ n steps each) instead of
+// nrelax full sweeps (~ 3 n steps each).  Same arithmetic, same order per cell: bit-identical to
+// the sweep-by-sweep schedule (tests/test_gpu_poisson.py compares both with the oracle).
+//
+// What sweep s + 1 reads from sweep s, and how it knows the data is there:
+//   own line, one cell ahead ........ written by the same thread (program order)
+//   ghost I = -1 / I = n ............. last / first value of the own line: registers
+//   line (-1,b) / (a,-1) ............. hand-off granules of the neighbour tile, as in relax_skew.hip;
+//                                      for the first tile row / column the periodic image comes
+//                                      from the last tile row / column of sweep s (same granules,
+//                                      written for the wrap as well)
+//   line (16,b) / (a,16) ............. the first lines (a = 0 / b = 0) of the neighbour tile.  They
+//                                      are overwritten in place by that tile's next sweep (the
+//                                      periodic image tile is even AHEAD of the reader), so every
+//                                      tile snapshots them per sweep into granule buffers
+//                                      (data-is-flag, sentinel), read by the next sweep
+// Granule buffers exist once per sweep of the loop (no re-arming inside the launch).  Every
+// wait is bounded and reported through *err.  All tiles must be resident at once (a tile of
+// sweep s + 1 waits on tiles of sweep s): the host checks the occupancy and otherwise falls back
+// to one launch per sweep.
+#include "relax_skew.hpp"
+#include <cstdlib>
+#include <vector>
+
+#define SK_MAXF 8    /* sweeps per launch */
+
+namespace gfship {
+
+struct SkewLoopArgs {
+  Layout L;
+  int ntj, RT, nsweeps;
+  double * us;             // skewed u (in place)
+  const double * rs;       // skewed rhs
+  const double * ds;       // skewed dia (or nullptr)
+  double * un;             // natural u: ghosts of sweep 0 are read, ghosts of the last BC written
+  u64 * hb;                // per sweep: [J hand-off | K hand-off | J snapshot | K snapshot]
+  long hb_sweep;           // granules per sweep
+  long hb_words;           // granules of one hand-off array (ntiles*hstride)
+  const unsigned short * order;
+  unsigned * ticket, * err;
+  const u64 * dummy;
+  u64 * stats;             // optional [tile][sweep]{start, end} (debug, GFSHIP_SKEW_STATS)
+};
+
+template <bool HAS_DIA>
+__global__ void __launch_bounds__(SK_NL)
+relax_skew_loop_kernel (SkewLoopArgs A)
+{
+  constexpr int XS = SK_T + 1;
+  __shared__ double X[2][XS*XS];
+  __shared__ double Y[2][XS*XS];
+  __shared__ unsigned s_tile;
+
+  const int tid = threadIdx.x;
+  const int a = tid & (SK_T - 1), b = tid >> 4;
+  const int n = A.L.n;
+  const int ntj = A.ntj;
+  const long tstride = (long) (A.RT + 2*SK_FP)*SK_NL;
+  const long hstride = (long) (n + 3*SK_T)*SK_T;
+
+  if (tid == 0)
+    s_tile = A.order[atomicAdd (A.ticket, 1u)];
+  __syncthreads ();
+  const int tile = s_tile;
+  const int P = tile % ntj, Q = tile / ntj;
+  const int j = n - (SK_T*P + a), k = n - (SK_T*Q + b);
+  const int s = a + b;
+  // periodic neighbours of the tile
+  const int tJm = (P > 0 ? P - 1 : ntj - 1) + ntj*Q, tJp = (P + 1 < ntj ? P + 1 : 0) + ntj*Q;
+  const int tKm = P + ntj*(Q > 0 ? Q - 1 : ntj - 1), tKp = P + ntj*(Q + 1 < ntj ? Q + 1 : 0);
+
+  double * const ut = A.us + tile*tstride + SK_FP*SK_NL;
+  const bool loader = __builtin_amdgcn_readfirstlane (tid >> 6) == 0;
+  const int g = tid >> 4, m = tid & 15;
+  const int jm = n - (SK_T*P + m), km = n - (SK_T*Q + m);
+  bool failed = false;
+
+  const int iOwnX = (a + 1) + XS*(b + 1), iT = a + XS*(b + 1), iF = (a + 1) + XS*b;
+  const int iOwnY = a + XS*b, iBo = (a + 1) + XS*b, iBk = a + XS*(b + 1);
+  const int T = (n + SK_PAD + SK_D - 1)/SK_D*SK_D;
+
+  // ghost cells at the two ends of the line: natural ghosts for the first sweep, then the
+  // periodic images kept in registers
+  double ghostL = A.un[A.L.idx (0, j, k)];
+  double ghostR = A.un[A.L.idx (n + 1, j, k)];
+
+  for (int sw = 0; sw < A.nsweeps; sw++) {
+    const bool more = sw + 1 < A.nsweeps;            // another sweep follows
+    const bool write_ghosts = sw + 2 == A.nsweeps;   // its BC application is the last one
+    u64 * const hbJ = A.hb + sw*A.hb_sweep, * const hbK = hbJ + A.hb_words;
+    u64 * const snJ = hbK + A.hb_words, * const snK = snJ + A.hb_words;
+    const u64 * const hbJp = hbJ - A.hb_sweep, * const hbKp = hbK - A.hb_sweep;   // previous sweep
+    const u64 * const snJp = snJ - A.hb_sweep, * const snKp = snK - A.hb_sweep;
+
+    // ---- own streams ----
+    const double * qR = ut + SK_NL + tid;
+    const double * qRhs = A.rs + tile*tstride + SK_FP*SK_NL + tid;
+    const double * qDia = HAS_DIA ? A.ds + tile*tstride + SK_FP*SK_NL + tid : nullptr;
+
+    // ---- halo streams of wave 0 ----
+    const u64 * qH = A.dummy;
+    int hs = 0;
+    bool handoff = false;       // sentinel-guarded granule stream
+    int xy_halo = 0;
+    if (loader) {
+      switch (g) {
+      case 0: // new values of line (-1, m)
+	if (P > 0)       { qH = hbJ + (long) tJm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = hbJp + (long) tJm*hstride + m; hs = SK_T; handoff = true; }
+	else             { qH = (const u64 *) (A.un + A.L.idx (1 - m, n + 1, km)); hs = 1; }
+	xy_halo = 0 + XS*(m + 1);
+	break;
+      case 1: // new values of line (m, -1)
+	if (Q > 0)       { qH = hbK + (long) tKm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = hbKp + (long) tKm*hstride + m; hs = SK_T; handoff = true; }
+	else             { qH = (const u64 *) (A.un + A.L.idx (1 - m, jm, n + 1)); hs = 1; }
+	xy_halo = (m + 1) + XS*0;
+	break;
+      case 2: // old values of line (16, m) = line (0, m) of tile (P+1, Q), row t - 15
+	if (sw > 0) { qH = snJp + (long) tJp*hstride + m; hs = SK_T; handoff = true; }
+	else if (P + 1 < ntj) {
+	  qH = (const u64 *) (A.us + tJp*tstride + SK_FP*SK_NL - (long) (SK_T - 1)*SK_NL + SK_T*m);
+	  hs = SK_NL;
+	}
+	else { qH = (const u64 *) (A.un + A.L.idx (1 - (SK_T - 1 + m), 0, km)); hs = 1; }
+	xy_halo = SK_T + XS*m;
+	break;
+      default: // old values of line (m, 16) = line (m, 0) of tile (P, Q+1), row t - 15
+	if (sw > 0) { qH = snKp + (long) tKp*hstride + m; hs = SK_T; handoff = true; }
+	else if (Q + 1 < ntj) {
+	  qH = (const u64 *) (A.us + tKp*tstride + SK_FP*SK_NL - (long) (SK_T - 1)*SK_NL + m);
+	  hs = SK_NL;
+	}
+	else { qH = (const u64 *) (A.un + A.L.idx (1 - (m + SK_T - 1), jm, 0)); hs = 1; }
+	xy_halo = m + XS*SK_T;
+      }
+    }
+    double * const halo_dst0 = (g < 2 ? &X[0][0] : &Y[0][0]) + xy_halo;
+    const u64 * const qH0 = qH;
+    // a granule stream is awaited only at the steps at which its consumer line is active:
+    // strips 0/1 feed lines (0,m)/(m,0) (I = t - m), strips 2/3 feed lines (15,m)/(m,15)
+    const int hlag = g < 2 ? m : m + SK_T - 1;
+
+    // store pointers
+    double * wU = ut + tid;
+    const bool hasJ = a == SK_T - 1 && (P + 1 < ntj || more);
+    const bool hasK = b == SK_T - 1 && (Q + 1 < ntj || more);
+    const bool snapJ = more && a == 0, snapK = more && b == 0;
+    u64 * wJ = hbJ + (long) tile*hstride + b - (long) (SK_T - 1)*SK_T;
+    u64 * wK = hbK + (long) tile*hstride + a - (long) (SK_T - 1)*SK_T;
+    u64 * wSJ = snJ + (long) tile*hstride + b + (long) (SK_T - 1)*SK_T;   // row t + 15
+    u64 * wSK = snK + (long) tile*hstride + a + (long) (SK_T - 1)*SK_T;
+
+    double pR[SK_D], pRhs[SK_D], pDia[SK_D], pH[SK_DH];
+
+#define SK_PREFETCH(q_)							\
+    do {								\
+      pR[q_]   = *qR;   qR += SK_NL;					\
+      pRhs[q_] = *qRhs; qRhs += SK_NL;					\
+      if (HAS_DIA) { pDia[q_] = *qDia; qDia += SK_NL; }			\
+    } while (0)
+#define SK_PREFETCH_HALO(q_)						\
+    do {								\
+      if (loader) {							\
+	pH[q_] = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs; \
+      }									\
+    } while (0)
+#define SK_HALO(t_, q_)							\
+    do {								\
+      if (loader) {							\
+	double hv = pH[q_];						\
+	bool w = handoff && !failed && (unsigned) ((t_) - hlag) < (unsigned) n && \
+	  (u64) __double_as_longlong (hv) == SK_SENTINEL;		\
+	if (__builtin_expect (__any (w), 0)) {				\
+	  unsigned spins = 0;						\
+	  _Pragma ("nounroll")						\
+	  while (__any (w)) {						\
+	    __builtin_amdgcn_s_sleep (2);				\
+	    if (w) {							\
+	      hv = __longlong_as_double ((long long) load_sc1 (qH0 + (long) (t_)*hs)); \
+	      w = (u64) __double_as_longlong (hv) == SK_SENTINEL;	\
+	    }								\
+	    if (++spins > (1u << 18)) { *A.err = 1; failed = true; break; } \
+	  }								\
+	}								\
+	halo_dst0[((t_) & 1)*(XS*XS)] = hv;				\
+      }									\
+    } while (0)
+
+    if (A.stats && tid == 0)
+      A.stats[2*(tile*SK_MAXF + sw)] = __builtin_amdgcn_s_memrealtime ();
+    double h0 = 0.;
+    if (loader) { h0 = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs; }
+#pragma unroll
+    for (int q = 0; q < SK_D; q++)
+      SK_PREFETCH (q);
+#pragma unroll
+    for (int q = 0; q < SK_DH; q++)
+      SK_PREFETCH_HALO (q);
+
+    __syncthreads ();      // the LDS grids of the previous sweep are no longer read
+    for (int q = tid; q < 2*XS*XS; q += SK_NL) {
+      (&X[0][0])[q] = 0.;
+      (&Y[0][0])[q] = 0.;
+    }
+    __syncthreads ();
+    Y[0][iOwnY] = pR[0];
+    {
+      double keep = pH[0];
+      pH[0] = h0;
+      SK_HALO (0, 0);
+      pH[0] = keep;
+    }
+    __syncthreads ();
+
+    double prev = ghostL, first = 0.;
+
+    for (int t0 = 0; t0 < T; t0 += SK_D) {
+#pragma unroll
+      for (int q = 0; q < SK_D; q++) {
+	const int t = t0 + q;
+	const int I = t - s;
+	const bool act = I >= 0 && I < n;
+	const int B = t & 1;
+	const double Tn = X[B][iT], Fn = X[B][iF], Bo = Y[B][iBo], Bk = Y[B][iBk];
+	// relax, src/poisson.c:507-530, unit weights, d = 0..5 = right,left,top,bottom,front,back
+	const double Rv = (I + 1 < n) ? pR[q] : ghostR;
+	double aa = HAS_DIA ? pDia[q] : 0., bb = 0.;
+	aa += 1.; bb += 1.*Rv;
+	aa += 1.; bb += 1.*prev;
+	aa += 1.; bb += 1.*Tn;
+	aa += 1.; bb += 1.*Bo;
+	aa += 1.; bb += 1.*Fn;
+	aa += 1.; bb += 1.*Bk;
+	const double v = aa != 0. ? (bb - pRhs[q])/aa : 0.;
+	prev = act ? v : prev;
+	first = I == 0 ? v : first;
+	X[B ^ 1][iOwnX] = v;
+	Y[B ^ 1][iOwnY] = pR[(q + 1) % SK_D];
+	SK_HALO (t + 1, q % SK_DH);
+	SK_PREFETCH_HALO (q % SK_DH);
+	SK_PREFETCH (q);
+	// own row of the skewed copy (read back by the same thread only)
+	*wU = v;
+	wU += SK_NL;
+	if (act && (hasJ || hasK || snapJ || snapK || (write_ghosts && (I == 0 || I == n - 1)))) {
+	  const u64 bits = (u64) __double_as_longlong (v);
+	  if (hasJ) store_sc1 (wJ, bits);
+	  if (hasK) store_sc1 (wK, bits);
+	  if (snapJ) store_sc1 (wSJ, bits);
+	  if (snapK) store_sc1 (wSK, bits);
+	  if (write_ghosts) {
+	    // the ghost layer the last BC application of the loop leaves behind (read by
+	    // get_from_above, poisson.c:1160-1167): the x ghosts of a line are only ever read by
+	    // its own thread (at the start of the launch), so they can be written here; the y and
+	    // z ghost planes are still read by tiles in their first sweep and are filled after
+	    // the launch from the granules of this sweep (skew_loop_ghosts_kernel)
+	    if (I == 0) A.un[A.L.idx (n + 1, j, k)] = v;
+	    if (I == n - 1) A.un[A.L.idx (0, j, k)] = v;
+	  }
+	}
+	wJ += SK_T;
+	wK += SK_T;
+	wSJ += SK_T;
+	wSK += SK_T;
+	asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+    // end of the sweep: the periodic line ghosts of the next one
+    if (A.stats && tid == 0)
+      A.stats[2*(tile*SK_MAXF + sw) + 1] = __builtin_amdgcn_s_memrealtime ();
+    ghostL = prev;      // value at I = n - 1
+    ghostR = first;     // value at I = 0
+#undef SK_PREFETCH
+#undef SK_PREFETCH_HALO
+#undef SK_HALO
+  }
+}
+
+// y and z ghost planes left by the last BC application of the loop = periodic images of the
+// side cells after sweep nsweeps - 2, taken from that sweep's granules:
+//   hand-off J of tile (ntj-1,Q): line a = 15 (j = 1)  -> ghost j = n + 1     row I + b
+//   snapshot J of tile (0,Q):     line a = 0  (j = n)  -> ghost j = 0         row I + b + 15
+//   hand-off K of tile (P,ntj-1): line b = 15 (k = 1)  -> ghost k = n + 1     row I + a
+//   snapshot K of tile (P,0):     line b = 0  (k = n)  -> ghost k = 0         row I + a + 15
+__global__ void __launch_bounds__(256)
+skew_loop_ghosts_kernel (SkewLoopArgs A)
+{
+  const int n = A.L.n, ntj = A.ntj;
+  const long hstride = (long) (n + 3*SK_T)*SK_T;
+  const int sw = A.nsweeps - 2;
+  const u64 * hbJ = A.hb + sw*A.hb_sweep, * hbK = hbJ + A.hb_words;
+  const u64 * snJ = hbK + A.hb_words, * snK = snJ + A.hb_words;
+  const int I = blockIdx.x*blockDim.x + threadIdx.x;     // 0 .. n-1
+  const int c = blockIdx.y;                               // the other tangential index, 0 .. n-1
+  const int plane = blockIdx.z;
+  if (I >= n) return;
+  const int T_ = c / SK_T, l = c % SK_T;                  // tile and line of the tangential index
+  u64 bits;
+  long dst;
+  switch (plane) {
+  case 0: bits = hbJ[(long) ((ntj - 1) + ntj*T_)*hstride + (long) (I + l)*SK_T + l];
+    dst = A.L.idx (I + 1, n + 1, n - c); break;
+  case 1: bits = snJ[(long) (0 + ntj*T_)*hstride + (long) (I + l + SK_T - 1)*SK_T + l];
+    dst = A.L.idx (I + 1, 0, n - c); break;
+  case 2: bits = hbK[(long) (T_ + ntj*(ntj - 1))*hstride + (long) (I + l)*SK_T + l];
+    dst = A.L.idx (I + 1, n - c, n + 1); break;
+  default: bits = snK[(long) (T_ + ntj*0)*hstride + (long) (I + l + SK_T - 1)*SK_T + l];
+    dst = A.L.idx (I + 1, n - c, 0);
+  }
+  A.un[dst] = __longlong_as_double ((long long) bits);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+
+bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool bc)
+{
+  if (!bc || nrelax < 2 || nrelax > SK_MAXF) return false;
+  if (!skew_supported (dom, level)) return false;
+  for (int d = 0; d < 6; d++)
+    if (dom->side[d] != GFSHIP_SIDE_PERIODIC) return false;
+  // every tile waits on tiles of the previous sweep: all of them must be resident
+  int ntj = dom->lay[level].n/SK_T, ntiles = ntj*ntj;
+  if (dom->skew_resident < 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice (&dev) != hipSuccess || hipGetDeviceProperties (&prop, dev) != hipSuccess ||
+	hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_skew_loop_kernel<true>,
+						      SK_NL, 0) != hipSuccess)
+      dom->skew_resident = 0;
+    else
+      dom->skew_resident = per_cu*prop.multiProcessorCount;
+  }
+  return ntiles <= dom->skew_resident;
+}
+
+int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia,
+		   unsigned nrelax, float * ms)
+{
+  const Layout & L = dom->lay[level];
+  int ntiles = S->ntj*S->ntj;
+  long hstride = (long) (L.n + 3*SK_T)*SK_T;
+  long hb_words = (long) ntiles*hstride;
+  long hb_sweep = 4*hb_words;
+  if (!S->hbf) {
+    GFSHIP_HIP (hipMalloc ((void **) &S->hbf, (size_t) SK_MAXF*hb_sweep*sizeof (u64)));
+  }
+  GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
+  GFSHIP_HIP (hipMemsetAsync (S->hbf, 0xFF, (size_t) nrelax*hb_sweep*sizeof (u64), dom->stream));
+  SkewLoopArgs A;
+  A.L = L; A.ntj = S->ntj; A.RT = S->RT; A.nsweeps = (int) nrelax;
+  A.us = S->us; A.rs = S->rs; A.ds = has_dia ? S->ds : nullptr;
+  A.un = u_nat;
+  A.hb = (u64 *) S->hbf; A.hb_sweep = hb_sweep; A.hb_words = hb_words;
+  A.order = S->order;
+  A.ticket = (unsigned *) S->ctl;
+  A.err = (unsigned *) S->ctl + 1;
+  A.dummy = (const u64 *) S->ctl + 2;
+  A.stats = nullptr;
+  if (getenv ("GFSHIP_SKEW_STATS")) {
+    if (!S->stats_loop)
+      GFSHIP_HIP (hipMalloc ((void **) &S->stats_loop, (size_t) ntiles*SK_MAXF*2*sizeof (u64)));
+    A.stats = (u64 *) S->stats_loop;
+  }
+  if (ms) GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
+  if (has_dia)
+    hipLaunchKernelGGL (relax_skew_loop_kernel<true>, dim3 (ntiles), dim3 (SK_NL), 0, dom->stream, A);
+  else
+    hipLaunchKernelGGL (relax_skew_loop_kernel<false>, dim3 (ntiles), dim3 (SK_NL), 0, dom->stream, A);
+  GFSHIP_HIP (hipGetLastError ());
+  if (ms) {
+    GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));
+    GFSHIP_HIP (hipEventSynchronize (dom->ev1));
+    GFSHIP_HIP (hipEventElapsedTime (ms, dom->ev0, dom->ev1));
+  }
+  int block = L.n >= 256 ? 256 : L.n >= 128 ? 128 : 64;
+  hipLaunchKernelGGL (skew_loop_ghosts_kernel, dim3 ((L.n + block - 1)/block, L.n, 4), dim3 (block),
+		      0, dom->stream, A);
+  GFSHIP_HIP (hipGetLastError ());
+  if (A.stats && ms) {
+    (void) hipStreamSynchronize (dom->stream);
+    std::vector<u64> h ((size_t) ntiles*SK_MAXF*2);
+    (void) hipMemcpy (h.data (), A.stats, h.size ()*sizeof (u64), hipMemcpyDeviceToHost);
+    u64 t0 = ~0ull;
+    for (int q = 0; q < ntiles; q++) if (h[2*(size_t) q*SK_MAXF] < t0) t0 = h[2*(size_t) q*SK_MAXF];
+    for (int Q = 0; Q < S->ntj; Q++)
+      for (int P = 0; P < S->ntj; P++)
+	if ((P == Q && (P % 5 == 0 || P == S->ntj - 1)) || (Q == 0 && P == S->ntj - 1)) {
+	  fprintf (stderr, "tile (%2d,%2d)", P, Q);
+	  for (unsigned w = 0; w < nrelax; w++) {
+	    size_t o = 2*((size_t) (P + S->ntj*Q)*SK_MAXF + w);
+	    fprintf (stderr, "  s%u %7.1f-%7.1f", w, (h[o] - t0)/100., (h[o + 1] - t0)/100.);
+	  }
+	  fprintf (stderr, " us\n");
+	}
+  }
+  return GFSHIP_OK;
+}
+
+} // namespace gfship

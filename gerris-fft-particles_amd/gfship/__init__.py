@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GFSHIP_LIB", os.path.join(_PKG, "lib", "libgfship.so"
 
 SIDE_PERIODIC, SIDE_BOUNDARY, SIDE_EXTERNAL = 0, 1, 2
 BC_SYMMETRY, BC_DIRICHLET, BC_NEUMANN = 0, 1, 2
-RELAX_EXACT, RELAX_REDBLACK, RELAX_EXACT_HYPERPLANE = 0, 1, 2
+RELAX_EXACT, RELAX_REDBLACK, RELAX_EXACT_HYPERPLANE, RELAX_EXACT_PER_SWEEP = 0, 1, 2, 3
 
 
 class GfshipError(RuntimeError):
@@ -80,6 +80,7 @@ SIGNATURES = {
     "gfship_diffusion_cycle": (_i, [_vp, _u, _u, _u, _i, _i, _i, _i]),
     "gfship_diffusion": (_i, [_vp, C.POINTER(MultilevelParams), _i, _i, _i]),
     "gfship_time_relax": (_i, [_vp, _u, _i, _i, _i, _i, _i, _pd]),
+    "gfship_time_relax_loop": (_i, [_vp, _i, _i, _i, _i, _u, _i, _pd, _pi]),
     "gfship_sim_create": (_i, [C.POINTER(_vp), _vp]),
     "gfship_sim_destroy": (None, [_vp]),
     "gfship_sim_variable": (_i, [_vp, _i, _i]),
@@ -265,6 +266,14 @@ class Domain:
 
     def diffusion(self, par, v, rhs, rhoc):
         _check(lib().gfship_diffusion(self.ptr, C.byref(par), v.h, rhs.h, rhoc.h))
+
+    def time_relax_loop(self, u, rhs, dia, nrelax=4, level=None, reps=5):
+        """(ms per relax loop of the sweep kernels alone, fused?)"""
+        level = self.depth if level is None else level
+        ms, fused = C.c_double(), C.c_int()
+        _check(lib().gfship_time_relax_loop(self.ptr, level, u.h, rhs.h, dia.h, nrelax, reps,
+                                            C.byref(ms), C.byref(fused)))
+        return ms.value, bool(fused.value)
 
     def interpolate(self, v, points):
         """GfsOutputLocation sampling: (values, inside) of variable v at points (np x 3)"""

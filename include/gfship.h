@@ -45,8 +45,11 @@ enum { GFSHIP_BC_SYMMETRY = 0, GFSHIP_BC_DIRICHLET = 1, GFSHIP_BC_NEUMANN = 2 };
    REDBLACK is a two-colour Gauss-Seidel of the same operator: same fixed point, different
           iterates (not a reference algorithm; opt-in);
    EXACT_HYPERPLANE is EXACT with one launch per hyperplane instead of the pipelined
-          tile sweep (same bits; kept as an independent implementation to test against). */
-enum { GFSHIP_RELAX_EXACT = 0, GFSHIP_RELAX_REDBLACK = 1, GFSHIP_RELAX_EXACT_HYPERPLANE = 2 };
+          tile sweep (same bits; kept as an independent implementation to test against);
+   EXACT_PER_SWEEP is EXACT with one launch per sweep of a relax loop even where the sweeps of
+          the loop can be pipelined in a single launch (same bits). */
+enum { GFSHIP_RELAX_EXACT = 0, GFSHIP_RELAX_REDBLACK = 1, GFSHIP_RELAX_EXACT_HYPERPLANE = 2,
+       GFSHIP_RELAX_EXACT_PER_SWEEP = 3 };
 
 typedef struct gfship_domain gfship_domain;   /* GfsDomain + its per-level SoA device arrays */
 typedef int gfship_field;                     /* GfsVariable handle (>= 0) */
@@ -272,6 +275,14 @@ int  gfship_halo_unpack (gfship_domain * dom, void * dev_ptr, int level, int sid
    `level`, in milliseconds per sweep; used by bench.py for the roofline entry */
 int  gfship_time_relax (gfship_domain * dom, unsigned d, int level, gfship_field u,
 			gfship_field rhs, gfship_field dia, int reps, double * ms_per_sweep);
+
+/* the same for a whole relax loop of `nrelax` sweeps with the homogeneous BC between them
+   (src/poisson.c:1070-1089): milliseconds per loop of the sweep kernel(s) alone (pack / unpack of
+   the level and the re-arming memsets are outside the timed region); *fused is set to 1 when the
+   sweeps ran pipelined in one launch */
+int  gfship_time_relax_loop (gfship_domain * dom, int level, gfship_field u, gfship_field rhs,
+			     gfship_field dia, unsigned nrelax, int reps, double * ms_per_loop,
+			     int * fused);
 
 #ifdef __cplusplus
 }

@@ -320,3 +320,76 @@ def test_skew_sweep_equals_hyperplane_sweep_256():
         out.append(u.download()[1:-1, 1:-1, 1:-1])
         gd.destroy()
     assert np.array_equal(out[0], out[1])
+
+
+# ---------------------------------------------------------------------------------------------
+# relax loop with its sweeps pipelined in one launch (relax_skew_loop.hip): periodic 3-D levels
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("level,use_dia", [(5, False), (6, False), (6, True), (7, False)])
+def test_fused_relax_loop_cycles_bit_exact_vs_oracle(level, use_dia):
+    """V-cycles on a triply periodic box: the relax loops of the levels with n >= 32 run as one
+    launch each (4 sweeps in flight behind each other, periodic images through the wrap
+    hand-offs / snapshots, progress words).  Fields, the ghost layer left by the last BC
+    application and the residual must equal the oracle bit for bit."""
+    L = O.lib()
+    dim = 3
+    side, bck = SIDES["periodic"]
+    rng = np.random.default_rng(4000 + level)
+    od, gd = _pair(dim, level, side)
+    L.go_poisson_coefficients(od.ptr)
+    gd.poisson_coefficients()
+    f = _rand_fields(od, gd, ["u", "rhs", "dia", "res"], rng)
+    if use_dia:
+        for l in range(level + 1):
+            a = np.abs(rng.standard_normal(f["dia"][0].level(l).shape)) + 0.5
+            f["dia"][0].level(l)[...] = a
+            f["dia"][1].upload(a, l)
+    else:
+        for l in range(level + 1):
+            f["dia"][0].level(l)[...] = 0.
+            f["dia"][1].fill(0., l)
+    L.go_bc(f["u"][0].ptr, f["u"][0].ptr, level)
+    gd.bc(f["u"][1])
+    L.go_residual(od.ptr, dim, level, f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr,
+                  f["res"][0].ptr)
+    gd.residual(f["u"][1], f["rhs"][1], f["dia"][1], f["res"][1])
+    op, gp = od.params(), gd.params()
+    for p in (op, gp):
+        p.depth = level
+    for _ in range(2):
+        L.go_poisson_cycle(od.ptr, C.byref(op), f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr,
+                           f["res"][0].ptr)
+        gd.poisson_cycle(gp, f["u"][1], f["rhs"][1], f["dia"][1], f["res"][1])
+        assert _faces_equal(f["u"][0].leaf(), f["u"][1].download(), dim)
+        assert np.array_equal(_interior(f["res"][0].leaf(), dim),
+                              _interior(f["res"][1].download(), dim))
+
+
+@pytest.mark.parametrize("nrelax", [2, 3, 4])
+def test_fused_relax_loop_equals_per_sweep_launches_256(nrelax):
+    """full size (256^3, 16 x 16 tiles): one V-cycle with the relax loops fused against the
+    one-launch-per-sweep schedule, bit for bit (interior, ghost layer, residual)"""
+    level, dim = 8, 3
+    n = 1 << level
+    rng = np.random.default_rng(80 + nrelax)
+    u0 = rng.standard_normal((n + 2,) * 3)
+    r0 = rng.standard_normal((n + 2,) * 3)
+    out = []
+    for mode in (gfship.RELAX_EXACT, gfship.RELAX_EXACT_PER_SWEEP):
+        gd = gfship.Domain(dim, level, [gfship.SIDE_PERIODIC] * 6)
+        gd.set_relax_mode(mode)
+        gd.poisson_coefficients()
+        u, rhs, dia, res = gd.variable(), gd.variable(), gd.variable(), gd.variable()
+        u.upload(u0)
+        rhs.upload(r0)
+        gd.bc(u)
+        gd.residual(u, rhs, dia, res)
+        par = gd.params()
+        par.depth = level
+        par.nrelax = nrelax
+        gd.poisson_cycle(par, u, rhs, dia, res)
+        out.append((u.download(), res.download()[1:-1, 1:-1, 1:-1]))
+        gd.destroy()
+    assert _faces_equal(out[0][0], out[1][0], 3)
+    assert np.array_equal(out[0][1], out[1][1])

@@ -14,3 +14,9 @@ rng = np.random.default_rng(0)
 u.upload(rng.standard_normal((n + 2,) * 3))
 rhs.upload(rng.standard_normal((n + 2,) * 3))
 print("ms per sweep: %.4f" % gd.time_relax(u, rhs, dia, reps=5))
+for mode, name in ((gfship.RELAX_EXACT, "fused"), (gfship.RELAX_EXACT_PER_SWEEP, "per sweep")):
+    gd.set_relax_mode(mode)
+    for nrelax in (2, 4):
+        ms, fused = gd.time_relax_loop(u, rhs, dia, nrelax=nrelax, reps=5)
+        print("relax loop nrelax %d (%s, fused=%s): %.4f ms = %.4f ms/sweep, %.0f GB/s algorithmic"
+              % (nrelax, name, fused, ms, ms / nrelax, 24. * n ** 3 * nrelax / ms / 1e6))
