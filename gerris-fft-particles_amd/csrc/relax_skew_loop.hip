@@ -35,6 +35,9 @@
 #include <vector>
 
 #define SK_MAXF 8    /* sweeps per launch */
+#ifndef SK_KO
+#define SK_KO 0      /* timing experiments only: knock out parts of the step (wrong results) */
+#endif
 
 namespace gfship {
 
@@ -54,8 +57,13 @@ struct SkewLoopArgs {
   u64 * stats;             // optional [tile][sweep]{start, end} (debug, GFSHIP_SKEW_STATS)
 };
 
+// Workgroup = 4 compute waves (256 lines) + 1 halo wave: the halo wave streams the four halo
+// strips into LDS (and polls the granules that are not there yet), so that the compute waves,
+// which all wait for the slowest of them at the barrier of every step, carry no halo code.
+#define SK_NTHREADS (SK_NL + 64)
+
 template <bool HAS_DIA>
-__global__ void __launch_bounds__(SK_NL)
+__global__ void __launch_bounds__(SK_NTHREADS)
 relax_skew_loop_kernel (SkewLoopArgs A)
 {
   constexpr int XS = SK_T + 1;
@@ -63,14 +71,16 @@ relax_skew_loop_kernel (SkewLoopArgs A)
   __shared__ double Y[2][XS*XS];
   __shared__ unsigned s_tile;
 
-  const int tid = threadIdx.x;
+  const int tid0 = threadIdx.x;
+  const bool compute = __builtin_amdgcn_readfirstlane (tid0 >> 6) < SK_NL/64;   // wave-uniform
+  const int tid = tid0 & (SK_NL - 1);      // line of a compute lane; lane index of the halo wave
   const int a = tid & (SK_T - 1), b = tid >> 4;
   const int n = A.L.n;
   const int ntj = A.ntj;
   const long tstride = (long) (A.RT + 2*SK_FP)*SK_NL;
-  const long hstride = (long) (n + 3*SK_T)*SK_T;
+  const long hstride = (long) SK_HROWS (n)*SK_T;
 
-  if (tid == 0)
+  if (tid0 == 0)
     s_tile = A.order[atomicAdd (A.ticket, 1u)];
   __syncthreads ();
   const int tile = s_tile;
@@ -82,8 +92,8 @@ relax_skew_loop_kernel (SkewLoopArgs A)
   const int tKm = P + ntj*(Q > 0 ? Q - 1 : ntj - 1), tKp = P + ntj*(Q + 1 < ntj ? Q + 1 : 0);
 
   double * const ut = A.us + tile*tstride + SK_FP*SK_NL;
-  const bool loader = __builtin_amdgcn_readfirstlane (tid >> 6) == 0;
-  const int g = tid >> 4, m = tid & 15;
+  const bool loader = !compute;
+  const int g = (tid >> 4) & 3, m = tid & 15;
   const int jm = n - (SK_T*P + m), km = n - (SK_T*Q + m);
   bool failed = false;
 
@@ -153,15 +163,33 @@ relax_skew_loop_kernel (SkewLoopArgs A)
     // strips 0/1 feed lines (0,m)/(m,0) (I = t - m), strips 2/3 feed lines (15,m)/(m,15)
     const int hlag = g < 2 ? m : m + SK_T - 1;
 
-    // store pointers
+    // store pointers.  Besides its own row a lane writes at most two granule streams: the
+    // hand-off of line a = 15 / b = 15 to the next tile (also to the periodic image tile when
+    // another sweep follows) and the snapshot of line a = 0 / b = 0 for the next sweep.  The roles
+    // of a lane do not change during the sweep, so they are folded into two (pointer, flag)
+    // slots: two predicated stores per step instead of a tree of branches.
     double * wU = ut + tid;
-    const bool hasJ = a == SK_T - 1 && (P + 1 < ntj || more);
-    const bool hasK = b == SK_T - 1 && (Q + 1 < ntj || more);
-    const bool snapJ = more && a == 0, snapK = more && b == 0;
-    u64 * wJ = hbJ + (long) tile*hstride + b - (long) (SK_T - 1)*SK_T;
-    u64 * wK = hbK + (long) tile*hstride + a - (long) (SK_T - 1)*SK_T;
-    u64 * wSJ = snJ + (long) tile*hstride + b + (long) (SK_T - 1)*SK_T;   // row t + 15
-    u64 * wSK = snK + (long) tile*hstride + a + (long) (SK_T - 1)*SK_T;
+    u64 * p1 = nullptr, * p2 = nullptr;
+    {
+      const bool hasJ = a == SK_T - 1 && (P + 1 < ntj || more);
+      const bool hasK = b == SK_T - 1 && (Q + 1 < ntj || more);
+      const bool snapJ = more && a == 0, snapK = more && b == 0;
+      u64 * const cand[4] = {
+	hbJ + (long) tile*hstride + b - (long) (SK_T - 1)*SK_T,     // row t - 15
+	hbK + (long) tile*hstride + a - (long) (SK_T - 1)*SK_T,
+	snJ + (long) tile*hstride + b + (long) (SK_T - 1)*SK_T,     // row t + 15
+	snK + (long) tile*hstride + a + (long) (SK_T - 1)*SK_T };
+      const bool has[4] = { hasJ, hasK, snapJ, snapK };
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+	if (has[c]) {
+	  if (!p1) p1 = cand[c];
+	  else p2 = cand[c];
+	}
+    }
+    const bool r1 = p1 != nullptr, r2 = p2 != nullptr;
+    if (!r1) p1 = (u64 *) A.dummy;      // never dereferenced
+    if (!r2) p2 = (u64 *) A.dummy;
 
     double pR[SK_D], pRhs[SK_D], pDia[SK_D], pH[SK_DH];
 
@@ -173,13 +201,14 @@ relax_skew_loop_kernel (SkewLoopArgs A)
     } while (0)
 #define SK_PREFETCH_HALO(q_)						\
     do {								\
-      if (loader) {							\
-	pH[q_] = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs; \
-      }									\
+      pH[q_] = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs; \
     } while (0)
-#define SK_HALO(t_, q_)							\
+#define SK_HALO(t_, q_) SK_HALO_ (t_, q_, 0)
+#define SK_HALO_STEP(t_, q_) SK_HALO_ (t_, q_, 1)
+    // wave 0: halo value of step t_ (slot q_) into LDS buffer t_ & 1; refill_: then reload the slot
+#define SK_HALO_(t_, q_, refill_)					\
     do {								\
-      if (loader) {							\
+      {									\
 	double hv = pH[q_];						\
 	bool w = handoff && !failed && (unsigned) ((t_) - hlag) < (unsigned) n && \
 	  (u64) __double_as_longlong (hv) == SK_SENTINEL;		\
@@ -196,96 +225,117 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 	  }								\
 	}								\
 	halo_dst0[((t_) & 1)*(XS*XS)] = hv;				\
+	if (refill_) {							\
+	  pH[q_] = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs; \
+	}								\
       }									\
     } while (0)
 
-    if (A.stats && tid == 0)
+    if (A.stats && tid0 == 0)
       A.stats[2*(tile*SK_MAXF + sw)] = __builtin_amdgcn_s_memrealtime ();
     double h0 = 0.;
-    if (loader) { h0 = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs; }
+    if (loader) {
+      h0 = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs;
 #pragma unroll
-    for (int q = 0; q < SK_D; q++)
-      SK_PREFETCH (q);
+      for (int q = 0; q < SK_DH; q++)
+	SK_PREFETCH_HALO (q);
+    }
+    else {
 #pragma unroll
-    for (int q = 0; q < SK_DH; q++)
-      SK_PREFETCH_HALO (q);
+      for (int q = 0; q < SK_D; q++)
+	SK_PREFETCH (q);
+    }
 
     __syncthreads ();      // the LDS grids of the previous sweep are no longer read
-    for (int q = tid; q < 2*XS*XS; q += SK_NL) {
+    for (int q = tid0; q < 2*XS*XS; q += SK_NTHREADS) {
       (&X[0][0])[q] = 0.;
       (&Y[0][0])[q] = 0.;
     }
     __syncthreads ();
-    Y[0][iOwnY] = pR[0];
-    {
+    if (loader) {
       double keep = pH[0];
       pH[0] = h0;
       SK_HALO (0, 0);
       pH[0] = keep;
     }
+    else
+      Y[0][iOwnY] = pR[0];
     __syncthreads ();
 
     double prev = ghostL, first = 0.;
 
-    for (int t0 = 0; t0 < T; t0 += SK_D) {
+    if (loader) {
+      // ---- halo wave: one LDS write (+ one granule load) per step, same barriers ----
+      for (int t0 = 0; t0 < T; t0 += SK_D) {
 #pragma unroll
-      for (int q = 0; q < SK_D; q++) {
-	const int t = t0 + q;
-	const int I = t - s;
-	const bool act = I >= 0 && I < n;
-	const int B = t & 1;
-	const double Tn = X[B][iT], Fn = X[B][iF], Bo = Y[B][iBo], Bk = Y[B][iBk];
-	// relax, src/poisson.c:507-530, unit weights, d = 0..5 = right,left,top,bottom,front,back
-	const double Rv = (I + 1 < n) ? pR[q] : ghostR;
-	double aa = HAS_DIA ? pDia[q] : 0., bb = 0.;
-	aa += 1.; bb += 1.*Rv;
-	aa += 1.; bb += 1.*prev;
-	aa += 1.; bb += 1.*Tn;
-	aa += 1.; bb += 1.*Bo;
-	aa += 1.; bb += 1.*Fn;
-	aa += 1.; bb += 1.*Bk;
-	const double v = aa != 0. ? (bb - pRhs[q])/aa : 0.;
-	prev = act ? v : prev;
-	first = I == 0 ? v : first;
-	X[B ^ 1][iOwnX] = v;
-	Y[B ^ 1][iOwnY] = pR[(q + 1) % SK_D];
-	SK_HALO (t + 1, q % SK_DH);
-	SK_PREFETCH_HALO (q % SK_DH);
-	SK_PREFETCH (q);
-	// own row of the skewed copy (read back by the same thread only)
-	*wU = v;
-	wU += SK_NL;
-	if (act && (hasJ || hasK || snapJ || snapK || (write_ghosts && (I == 0 || I == n - 1)))) {
-	  const u64 bits = (u64) __double_as_longlong (v);
-	  if (hasJ) store_sc1 (wJ, bits);
-	  if (hasK) store_sc1 (wK, bits);
-	  if (snapJ) store_sc1 (wSJ, bits);
-	  if (snapK) store_sc1 (wSK, bits);
-	  if (write_ghosts) {
-	    // the ghost layer the last BC application of the loop leaves behind (read by
-	    // get_from_above, poisson.c:1160-1167): the x ghosts of a line are only ever read by
-	    // its own thread (at the start of the launch), so they can be written here; the y and
-	    // z ghost planes are still read by tiles in their first sweep and are filled after
-	    // the launch from the granules of this sweep (skew_loop_ghosts_kernel)
-	    if (I == 0) A.un[A.L.idx (n + 1, j, k)] = v;
-	    if (I == n - 1) A.un[A.L.idx (0, j, k)] = v;
-	  }
+	for (int q = 0; q < SK_D; q++) {
+	  const int t = t0 + q;
+	  if (!(SK_KO & 2))
+	    SK_HALO_STEP (t + 1, q % SK_DH);
+	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 	}
-	wJ += SK_T;
-	wK += SK_T;
-	wSJ += SK_T;
-	wSK += SK_T;
-	asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+    else {
+      // ---- compute waves ----
+      for (int t0 = 0; t0 < T; t0 += SK_D) {
+#pragma unroll
+	for (int q = 0; q < SK_D; q++) {
+	  const int t = t0 + q;
+	  const int I = t - s;
+	  const bool act = I >= 0 && I < n;
+	  const int B = t & 1;
+	  const double Tn = X[B][iT], Fn = X[B][iF], Bo = Y[B][iBo], Bk = Y[B][iBk];
+	  // relax, src/poisson.c:507-530, unit weights, d = 0..5 = right,left,top,bottom,front,back
+	  const double Rv = (I + 1 < n) ? pR[q] : ghostR;
+	  double aa = HAS_DIA ? pDia[q] : 0., bb = 0.;
+	  aa += 1.; bb += 1.*Rv;
+	  aa += 1.; bb += 1.*prev;
+	  aa += 1.; bb += 1.*Tn;
+	  aa += 1.; bb += 1.*Bo;
+	  aa += 1.; bb += 1.*Fn;
+	  aa += 1.; bb += 1.*Bk;
+	  const double v = HAS_DIA ? (aa != 0. ? (bb - pRhs[q])/aa : 0.) : divide_by_6 (bb - pRhs[q]);
+	  prev = act ? v : prev;
+	  first = I == 0 ? v : first;
+	  X[B ^ 1][iOwnX] = v;
+	  Y[B ^ 1][iOwnY] = pR[(q + 1) % SK_D];
+	  if (!(SK_KO & 8))
+	    SK_PREFETCH (q);
+	  // own row of the skewed copy (read back by the same thread only)
+	  if (!(SK_KO & 4))
+	    *wU = v;
+	  wU += SK_NL;
+	  if (!(SK_KO & 1)) {
+	    const u64 bits = (u64) __double_as_longlong (v);
+	    if (act && r1) store_sc1 (p1, bits);
+	    if (act && r2) store_sc1 (p2, bits);
+	  }
+	  p1 += SK_T;
+	  p2 += SK_T;
+	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	}
       }
     }
     // end of the sweep: the periodic line ghosts of the next one
-    if (A.stats && tid == 0)
+    if (A.stats && tid0 == 0)
       A.stats[2*(tile*SK_MAXF + sw) + 1] = __builtin_amdgcn_s_memrealtime ();
     ghostL = prev;      // value at I = n - 1
     ghostR = first;     // value at I = 0
+    if (write_ghosts && compute) {
+      // the ghost layer the last BC application of the loop leaves behind (read by
+      // get_from_above, poisson.c:1160-1167): the x ghosts of a line are only ever read by its
+      // own thread (at the start of the launch), so they can be written here; the y and z ghost
+      // planes are still read by tiles in their first sweep and are filled after the launch
+      // from the granules of this sweep (skew_loop_ghosts_kernel)
+      A.un[A.L.idx (n + 1, j, k)] = first;
+      A.un[A.L.idx (0, j, k)] = prev;
+    }
 #undef SK_PREFETCH
 #undef SK_PREFETCH_HALO
 #undef SK_HALO
+#undef SK_HALO_STEP
+#undef SK_HALO_
   }
 }
 
@@ -299,7 +349,7 @@ __global__ void __launch_bounds__(256)
 skew_loop_ghosts_kernel (SkewLoopArgs A)
 {
   const int n = A.L.n, ntj = A.ntj;
-  const long hstride = (long) (n + 3*SK_T)*SK_T;
+  const long hstride = (long) SK_HROWS (n)*SK_T;
   const int sw = A.nsweeps - 2;
   const u64 * hbJ = A.hb + sw*A.hb_sweep, * hbK = hbJ + A.hb_words;
   const u64 * snJ = hbK + A.hb_words, * snK = snJ + A.hb_words;
@@ -340,7 +390,7 @@ bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool 
     hipDeviceProp_t prop;
     if (hipGetDevice (&dev) != hipSuccess || hipGetDeviceProperties (&prop, dev) != hipSuccess ||
 	hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_skew_loop_kernel<true>,
-						      SK_NL, 0) != hipSuccess)
+						      SK_NTHREADS, 0) != hipSuccess)
       dom->skew_resident = 0;
     else
       dom->skew_resident = per_cu*prop.multiProcessorCount;
@@ -353,7 +403,7 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
 {
   const Layout & L = dom->lay[level];
   int ntiles = S->ntj*S->ntj;
-  long hstride = (long) (L.n + 3*SK_T)*SK_T;
+  long hstride = (long) SK_HROWS (L.n)*SK_T;
   long hb_words = (long) ntiles*hstride;
   long hb_sweep = 4*hb_words;
   if (!S->hbf) {
@@ -378,9 +428,9 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   }
   if (ms) GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
   if (has_dia)
-    hipLaunchKernelGGL (relax_skew_loop_kernel<true>, dim3 (ntiles), dim3 (SK_NL), 0, dom->stream, A);
+    hipLaunchKernelGGL (relax_skew_loop_kernel<true>, dim3 (ntiles), dim3 (SK_NTHREADS), 0, dom->stream, A);
   else
-    hipLaunchKernelGGL (relax_skew_loop_kernel<false>, dim3 (ntiles), dim3 (SK_NL), 0, dom->stream, A);
+    hipLaunchKernelGGL (relax_skew_loop_kernel<false>, dim3 (ntiles), dim3 (SK_NTHREADS), 0, dom->stream, A);
   GFSHIP_HIP (hipGetLastError ());
   if (ms) {
     GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));
