@@ -7,8 +7,9 @@ A "step" is one iteration of the simulation_run loop (src/simulation.c:479-548: 
 projection, velocity advection, approximate projection, CFL) on a 3-D 256^3 triply periodic
 Taylor-Green box with default parameters, one box per GPU.  Inputs are
 resident in HBM before the timed region.  Prints ONE JSON line on rank 0, with
-  roofline      the exact-order relax sweep of the 256^3 level (dominant kernel), timed with
-                HIP events on the stream the kernels run on: 24 B/cell algorithmic traffic
+  roofline      the exact-order relax loop (4 pipelined sweeps) of the 256^3 level (dominant
+                kernel), timed with HIP events on the stream the kernels run on: 24 B per cell
+                and sweep algorithmic traffic
   cpu_baseline  the repo's CPU oracle (a port of the reference algorithm; the reference itself
                 cannot be built here) on a bounded sample, 1 core.
 """
@@ -127,27 +128,46 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # roofline of the dominant kernel: one exact-order sweep of the 256^3 level
+    # roofline of the dominant kernel: the exact-order relax loop of the 256^3 level (nrelax = 4
+    # sweeps with the homogeneous BC between them, src/poisson.c:1070-1089) -- on a periodic box one
+    # launch of relax_skew_loop_kernel with the sweeps pipelined behind each other; timed with HIP
+    # events on the library's stream.  Algorithmic traffic: 24 B per cell and sweep.
     u, rhs, dia = dom.variable(), dom.variable(), dom.variable()
     rng = np.random.default_rng(0)
     u.upload(rng.standard_normal((n + 2,) * 3))
     rhs.upload(rng.standard_normal((n + 2,) * 3))
     dom.poisson_coefficients()
-    ms = dom.time_relax(u, rhs, dia, reps=5)
-    achieved = RELAX_BYTES_PER_CELL * n ** 3 / (ms * 1e-3) / 1e9
-    # HBM bytes per launch from the rocprofv3 PMC passes of the same kernel at the same size
-    # (profiles/r01_pmc_relax_256.json: FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md);
-    # counters cannot be read from inside this process, so the committed summary is reported
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_relax_256.json")
-    if args.level == 8 and args.mode == "exact" and os.path.exists(pmc):
-        with open(pmc) as f:
-            traffic = json.load(f)["kernels"]["relax_skew_kernel"]["hbm_bytes_per_launch_guide_corrected"]
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": RELAX_BYTES_PER_CELL * n ** 3,
-                "kernel": "relax sweep, level %d (%d^3), mode %s" % (args.level, n, args.mode),
-                "ms_per_sweep": ms}
+    nrelax = 4
+    ms_sweep = dom.time_relax(u, rhs, dia, reps=5)            # one sweep launched on its own
+    roofline = None
+    if args.mode == "exact":
+        ms_loop, fused = dom.time_relax_loop(u, rhs, dia, nrelax=nrelax, reps=5)
+        bytes_loop = RELAX_BYTES_PER_CELL * n ** 3 * nrelax
+        achieved = bytes_loop / (ms_loop * 1e-3) / 1e9
+        # HBM bytes per launch from rocprofv3 PMC passes of the same kernel at the same size
+        # (FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes): counters cannot
+        # be read from inside this process, so the committed summary is reported
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_relax_loop_256.json")
+        if args.level == 8 and fused and os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f)["kernels"]["relax_skew_loop_kernel"]["hbm_bytes_per_launch_guide_corrected"]
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": bytes_loop,
+                    "kernel": "relax loop (%d sweeps%s), level %d (%d^3), mode exact"
+                              % (nrelax, ", one pipelined launch" if fused else
+                                 ", one launch per sweep", args.level, n),
+                    "ms_per_launch": ms_loop if fused else ms_loop / nrelax,
+                    "ms_per_sweep_in_loop": ms_loop / nrelax,
+                    "ms_single_sweep_launch": ms_sweep}
+    else:
+        achieved = RELAX_BYTES_PER_CELL * n ** 3 / (ms_sweep * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": RELAX_BYTES_PER_CELL * n ** 3,
+                    "kernel": "relax sweep, level %d (%d^3), mode %s" % (args.level, n, args.mode),
+                    "ms_per_launch": ms_sweep}
 
     # config D: the same box with 2e6 GfsParticle tracers (positions from the
     # fixed-seed LCG, ids 1..Np): the particle event alone, and the step with the event in it
