@@ -132,6 +132,7 @@ int gfship_domain_set_relax_mode (gfship_domain * dom, int mode)
 		GFSHIP_EINVAL, "unknown relax mode %d", mode);
   dom->force_hyperplane = (mode == GFSHIP_RELAX_EXACT_HYPERPLANE);
   dom->no_fused_loop = (mode == GFSHIP_RELAX_EXACT_PER_SWEEP);
+  dom->no_fused_godunov = (mode == GFSHIP_RELAX_EXACT_PER_SWEEP);   /* the unfused reference paths */
   dom->relax_mode = mode == GFSHIP_RELAX_REDBLACK ? GFSHIP_RELAX_REDBLACK : GFSHIP_RELAX_EXACT;
   return GFSHIP_OK;
 }

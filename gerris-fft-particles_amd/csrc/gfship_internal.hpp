@@ -88,6 +88,7 @@ struct gfship_domain {
   bool has_external = false;
   gfship_field dp_cache = -1;     // the `dp` temporary of gfs_poisson_cycle, kept between cycles
   int skew_resident = -1;         // workgroups of the fused relax loop that fit on the device
+  bool no_fused_godunov = false;  // face-value arrays + separate kernels even on periodic boxes
   bool no_fused_loop = false;     // one launch per sweep even where the fused loop applies
   bool force_hyperplane = false;  // debug/bench: per-hyperplane launches instead of relax_skew
   bool unit_weights = false;      // gfship_poisson_coefficients called with alpha = NULL
@@ -154,6 +155,12 @@ int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3],
 		const double visc[3], double * cfl2);
 int launch_coarse_init (gfship_domain * dom, Field * const * v, int nf);
 int launch_velocity_divergence (gfship_domain * dom, double * const u[3], double * out);
+bool godunov_fused_supported (const gfship_domain * dom);
+int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt, int gradient,
+			     const double visc[3], double * const un[3]);
+int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, double * out,
+			 double * const un[3], const double * gm, const double * gc, double dt,
+			 int gradient, double visc);
 
 
 // relax_skew.hip

@@ -23,6 +23,7 @@ struct gfship_sim {
   double visc[3] = {0., 0., 0.};   // GfsSourceDiffusion on U, V, W (constant coefficient)
   gfship_multilevel_params diffusion_params[3];
   gfship_field drhs = -1, rhoc = -1;   // temporaries of variable_diffusion
+  gfship_field adv_tmp = -1;           // output of the fused advection kernel (swapped with v)
   gfship_next_event_fn next_event = nullptr; void * next_event_ctx = nullptr;
 };
 
@@ -118,8 +119,32 @@ int variable_sources (gfship_sim * s, gfship_field v, gfship_field sv, int gradi
   double * un[3], * fv[6];
   ptrs3 (s, s->un, un);
   ptrs6 (s, fv);
-  TRY (face_values_set (s, v, dt, 0, gradient));
   int c = s->dom->fields[v].component;
+  if (godunov_fused_supported (s->dom)) {
+    /* periodic box: face values recomputed inside the flux kernel, no face-value arrays */
+    gfship_domain * dom = s->dom;
+    const int L = dom->depth;
+    const double * gm = velocity ? leaf (s, gmac[c]) : nullptr;
+    const double * gc = (velocity && g) ? leaf (s, g[c]) : nullptr;
+    double visc = 0.;
+    for (int q = 0; q < dom->dim; q++)
+      if (v == s->u[q])
+	visc = s->visc[q];
+    dom->fields[sv].zero[L] = false;
+    if (sv != v)      /* sv holds a copy of v (source_diffusion): out = sv */
+      return launch_advect_fused (dom, velocity, leaf (s, v), leaf (s, sv), un, gm, gc, dt,
+				  gradient, visc);
+    /* in place in the reference: here into a scratch leaf level, then the storage is swapped
+       (every cell reads the old values of its neighbours) */
+    if (s->adv_tmp < 0)
+      s->adv_tmp = gfship_field_alloc (dom, -1);
+    if (s->adv_tmp < 0) return s->adv_tmp;
+    TRY (launch_advect_fused (dom, velocity, leaf (s, v), leaf (s, s->adv_tmp), un, gm, gc, dt,
+			      gradient, visc));
+    std::swap (dom->fields[v].lev[L], dom->fields[s->adv_tmp].lev[L]);
+    return GFSHIP_OK;
+  }
+  TRY (face_values_set (s, v, dt, 0, gradient));
   const double * gm = velocity ? leaf (s, gmac[c]) : nullptr;
   const double * gc = (velocity && g) ? leaf (s, g[c]) : nullptr;
   s->dom->fields[sv].zero[s->dom->depth] = false;
@@ -208,7 +233,7 @@ void gfship_sim_destroy (gfship_sim * s)
   fr (s->p); fr (s->pmac);
   for (int c = 0; c < 3; c++) { fr (s->u[c]); fr (s->g[c]); fr (s->gmac[c]); fr (s->un[c]); }
   for (int d = 0; d < 6; d++) fr (s->fv[d]);
-  fr (s->dia); fr (s->div); fr (s->res); fr (s->drhs); fr (s->rhoc);
+  fr (s->dia); fr (s->div); fr (s->res); fr (s->drhs); fr (s->rhoc); fr (s->adv_tmp);
   for (gfship_field t : s->tracers) fr (t);
   delete s;
 }
@@ -286,6 +311,13 @@ int gfship_predicted_face_velocities (gfship_sim * s)
   ptrs6 (s, fv);
   /* the reset of every face (gfs_face_reset_normal_velocity) is implied: each component's
      faces are all overwritten below */
+  if (godunov_fused_supported (s->dom)) {
+    double * u[3], * un[3];
+    ptrs3 (s, s->u, u);
+    ptrs3 (s, s->un, un);
+    return launch_predict_un_fused (s->dom, u, s->advection_params.dt,
+				    s->advection_params.gradient, s->visc, un);
+  }
   for (int c = 0; c < s->dom->dim; c++) {
     /* only the faces normal to component c are read by gfs_face_advected_normal_velocity */
     TRY (face_values_set (s, s->u[c], s->advection_params.dt, 1, s->advection_params.gradient, 1 << c));

@@ -189,8 +189,10 @@ __device__ __forceinline__ double van_leer_gradient (double v0, double v1, doubl
 // e.a = 1., e.b = neighbour value), used as MAC source of the predictor and in the CFL scale
 template <int DIM>
 __device__ __forceinline__ double source_diffusion_value (const double * __restrict__ v, long c,
-							  const long * off, double D, double h)
+							  const long * off, double D, int n)
 {
+  /* h = 1/n is a power of two: the division by h*h is an exact scaling by n*n */
+  const double rh2 = (double) n*(double) n;
   double ga = 0., gb = 0.;
   const double v0 = v[c];
 #pragma unroll
@@ -198,7 +200,7 @@ __device__ __forceinline__ double source_diffusion_value (const double * __restr
     ga += D*1.; gb += D*v[c + off[cc]];
     ga += D*1.; gb += D*v[c - off[cc]];
   }
-  return 1.*(gb - ga*v0)/(h*h);
+  return 1.*(gb - ga*v0)*rh2;
 }
 
 template <int DIM>
@@ -238,7 +240,7 @@ advected_face_values_kernel (Layout L, const double * __restrict__ v, CPtr3 u, C
     /* gfs_variable_mac_source, src/source.c:38-59 */
     double msrc = 0.;
     if (visc != 0.)
-      msrc = 0. + source_diffusion_value<DIM> (v, c, off, visc, size);
+      msrc = 0. + source_diffusion_value<DIM> (v, c, off, visc, L.n);
     double src = dt*msrc/2.;
     double dv;
     if (DIM == 2)
@@ -399,6 +401,265 @@ flux_update_kernel (Layout L, double * __restrict__ v, CPtr3 un, CPtr6 fv,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused Godunov step on periodic boxes: K13 + face BC + K14 (predictor) and K13 + face BC + K15 +
+// K16 (advection) without the six face-value arrays.
+//
+// The reference stores the two face values of every cell and direction (f[d].v), applies the
+// face BC, then visits the faces.  On a periodic box the face value of a ghost cell is the face
+// value of its periodic image (face_periodic, src/boundary.c:1251-1258), so every face value a
+// face needs can be recomputed on the spot from the cell-centred field: same expression, same
+// operand order, same bits as advected_face_values_kernel -- but 56 B/cell of HBM traffic per
+// advected component instead of 184 (and 48 instead of 240 for the three predictor passes).
+// ---------------------------------------------------------------------------------------------
+struct FacePair { double l, r; };   // f[2*d].v ("left state" of the + face) and f[2*d+1].v
+
+// the two face values of direction D of the cell at index c (an interior cell or the periodic
+// image of a ghost cell): gfs_cell_advected_face_values (src/advection.c:58-99) for one direction.
+// The cell size is a power of two (1/n, n = 2^level), so the reference's divisions by size and
+// 2.*size are exact scalings and are written as multiplications by n and n/2: same bits, without
+// the 14-instruction division sequences.
+template <int DIM, int D>
+__device__ __forceinline__ FacePair face_values_dir (const Layout & L, const double * __restrict__ v,
+						     const CPtr3 & u, const CPtr3 & un, long c,
+						     double dt, int use_centered_velocity, int gradient,
+						     double visc)
+{
+  const long off[3] = { 1, L.sy, L.sz };
+  const double rsize = (double) L.n, rsize2 = (double) L.n/2.;   /* 1/size, 1/(2.*size) */
+  const double v0 = v[c];
+  double tt[3] = { 0., 0., 0. };
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++)
+    if (cc != D) {
+      double vtan = use_centered_velocity ? u.p[cc][c] : (un.p[cc][c] + un.p[cc][c - off[cc]])/2.;
+      long nb = vtan > 0. ? c - off[cc] : c + off[cc];
+      double g = v[nb] - 1.*v0;
+      if (vtan > 0.) g = - g;
+      tt[cc] = dt*vtan*g*rsize2;
+    }
+  double unorm = use_centered_velocity ?
+    dt*u.p[D][c]*rsize :
+    dt*(un.p[D][c] + un.p[D][c - off[D]])*rsize2;
+  double v1 = v[c - off[D]], v2 = v[c + off[D]];
+  double g = gradient ? van_leer_gradient (v0, v1, v2) : center_gradient (v0, v1, v2);
+  double vl = v0 + GMIN ((1. - unorm)/2., 0.5)*g;
+  double vr = v0 + GMAX ((- 1. - unorm)/2., -0.5)*g;
+  double msrc = 0.;
+  if (visc != 0.)
+    msrc = 0. + source_diffusion_value<DIM> (v, c, off, visc, L.n);
+  double src = dt*msrc/2.;
+  double dv;
+  if (DIM == 2)
+    dv = tt[(D + 1) % 2];
+  else {
+    const int o0 = D == 0 ? 1 : 0, o1 = D == 2 ? 1 : 2;
+    dv = tt[o0];
+    dv += tt[o1];
+  }
+  FacePair f;
+  f.l = vl + src - dv;
+  f.r = vr + src - dv;
+  return f;
+}
+
+// index of the interior image of cell (i,j,k), each coordinate in [0, n+1]
+template <int DIM>
+__device__ __forceinline__ long image (const Layout & L, int i, int j, int k)
+{
+  const int n = L.n;
+  i = i < 1 ? i + n : i > n ? i - n : i;
+  j = j < 1 ? j + n : j > n ? j - n : j;
+  if (DIM == 3) k = k < 1 ? k + n : k > n ? k - n : k;
+  return L.idx (i, j, k);
+}
+
+// Tiles of GX x GY x GZ cells, one thread per cell.  Phase 1: every thread computes the face
+// values of its own cell once and stores them in LDS; the cells just outside the six faces of
+// the tile (periodic images at the box sides) are computed by the first threads, one direction
+// each.  Phase 2: the faces are visited from LDS.  1.3 face-value evaluations per cell instead of
+// the 3 of a per-face recomputation.
+#define GX 32
+#define GY 4
+#define GZ 4
+#define GN (GX*GY*GZ)
+
+struct TileIdx {
+  int tx, ty, tz, i, j, k;
+  __device__ __forceinline__ TileIdx () {
+    int tid = threadIdx.x;
+    tx = tid % GX; ty = (tid / GX) % GY; tz = tid / (GX*GY);
+    i = blockIdx.x*GX + tx + 1; j = blockIdx.y*GY + ty + 1; k = blockIdx.z*GZ + tz + 1;
+  }
+  __device__ __forceinline__ int own () const { return tx + GX*(ty + GY*tz); }
+};
+
+// predictor of the three components in one pass: gfs_face_advected_normal_velocity
+// (src/advection.c:513-539) with the face values of u[c] along c computed in place
+// (use_centered_velocity = TRUE)
+__global__ void __launch_bounds__(GN)
+predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, int gradient, Visc3 visc)
+{
+  __shared__ double fl[3][GN], fr[3][GN];
+  __shared__ double hp[3][GX*GZ];          // r of the cell beyond the + face of the tile
+  const TileIdx T;
+  const int n = L.n;
+  const long c = L.idx (T.i, T.j, T.k);
+  const long off[3] = { 1, L.sy, L.sz };
+  CPtr3 none = { { nullptr, nullptr, nullptr } };
+  {
+    FacePair f = face_values_dir<3, 0> (L, u.p[0], u, none, c, dt, 1, gradient, visc.d[0]);
+    fl[0][T.own ()] = f.l; fr[0][T.own ()] = f.r;
+    f = face_values_dir<3, 1> (L, u.p[1], u, none, c, dt, 1, gradient, visc.d[1]);
+    fl[1][T.own ()] = f.l; fr[1][T.own ()] = f.r;
+    f = face_values_dir<3, 2> (L, u.p[2], u, none, c, dt, 1, gradient, visc.d[2]);
+    fl[2][T.own ()] = f.l; fr[2][T.own ()] = f.r;
+  }
+  // halo: the cell beyond the + face of the tile in each direction.  Waves 0-3 take y, waves 4-7
+  // z (one cell each, no divergence inside a wave), the first 16 lanes also x
+  {
+    const int h = threadIdx.x;
+    if (h < GX*GZ) {
+      int p = h % GX, q = h / GX;
+      long ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + GY + 1, blockIdx.z*GZ + q + 1);
+      hp[1][h] = face_values_dir<3, 1> (L, u.p[1], u, none, ci, dt, 1, gradient, visc.d[1]).r;
+    }
+    else if (h < GX*GZ + GX*GY) {
+      int hh = h - GX*GZ, p = hh % GX, q = hh / GX;
+      long ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + q + 1, blockIdx.z*GZ + GZ + 1);
+      hp[2][hh] = face_values_dir<3, 2> (L, u.p[2], u, none, ci, dt, 1, gradient, visc.d[2]).r;
+    }
+    if (h < GY*GZ) {
+      int p = h % GY, q = h / GY;
+      long ci = image<3> (L, blockIdx.x*GX + GX + 1, blockIdx.y*GY + p + 1, blockIdx.z*GZ + q + 1);
+      hp[0][h] = face_values_dir<3, 0> (L, u.p[0], u, none, ci, dt, 1, gradient, visc.d[0]).r;
+    }
+  }
+  __syncthreads ();
+  const int t3[3] = { T.tx, T.ty, T.tz }, g3[3] = { GX, GY, GZ }, ijk[3] = { T.i, T.j, T.k };
+  const int so[3] = { 1, GX, GX*GY };
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const double * ud = u.p[d];
+    // + face of the own cell
+    double r;
+    if (t3[d] + 1 < g3[d])
+      r = fr[d][T.own () + so[d]];
+    else
+      r = hp[d][d == 0 ? T.ty + GY*T.tz : d == 1 ? T.tx + GX*T.tz : T.tx + GX*T.ty];
+    double s_ = face_interp (ud[c], ud[c + off[d]]);
+    double val = upwinded (s_, fl[d][T.own ()], r);
+    un.p[d][c] = val;
+    // the face on the low side of the box is the periodic image of the one on the high side
+    if (ijk[d] == n)
+      un.p[d][c - (long) n*off[d]] = val;
+  }
+}
+
+// variable_sources (src/timestep.c:872-921) of one advected variable: out = v + fluxes - g*dt,
+// the fluxes gathered in the reference's scatter order (see flux_update_kernel)
+template <bool VELOCITY>
+__global__ void __launch_bounds__(GN)
+advect_tiled_kernel (Layout L, const double * __restrict__ v, double * __restrict__ out, CPtr3 un,
+		     const double * __restrict__ gm, const double * __restrict__ gc, double dt,
+		     int gradient, double visc)
+{
+  __shared__ double fl[3][GN], fr[3][GN];
+  __shared__ double hm[3][GX*GZ], hp[3][GX*GZ];   // l of the cell before / r of the cell after the tile
+  const TileIdx T;
+  const int n = L.n;
+  const double rn = (double) n;
+  const long c = L.idx (T.i, T.j, T.k);
+  const long off[3] = { 1, L.sy, L.sz };
+  CPtr3 none = { { nullptr, nullptr, nullptr } };
+  {
+    FacePair f = face_values_dir<3, 0> (L, v, none, un, c, dt, 0, gradient, visc);
+    fl[0][T.own ()] = f.l; fr[0][T.own ()] = f.r;
+    f = face_values_dir<3, 1> (L, v, none, un, c, dt, 0, gradient, visc);
+    fl[1][T.own ()] = f.l; fr[1][T.own ()] = f.r;
+    f = face_values_dir<3, 2> (L, v, none, un, c, dt, 0, gradient, visc);
+    fl[2][T.own ()] = f.l; fr[2][T.own ()] = f.r;
+  }
+  // halo cells: l of the cell before the tile (minus side), r of the cell after it (plus side).
+  // Waves 0-1: y minus, 2-3: y plus, 4-5: z minus, 6-7: z plus (one cell per lane, one direction
+  // per wave); the first 32 lanes also take the x halos
+  {
+    const int h = threadIdx.x;
+    const int grp = h / (GX*GZ), idx = h % (GX*GZ), p = idx % GX, q = idx / GX;
+    if (grp < 2) {
+      long ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + (grp ? GY + 1 : 0), blockIdx.z*GZ + q + 1);
+      FacePair f = face_values_dir<3, 1> (L, v, none, un, ci, dt, 0, gradient, visc);
+      if (grp) hp[1][idx] = f.r; else hm[1][idx] = f.l;
+    }
+    else {
+      long ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + q + 1, blockIdx.z*GZ + (grp == 3 ? GZ + 1 : 0));
+      FacePair f = face_values_dir<3, 2> (L, v, none, un, ci, dt, 0, gradient, visc);
+      if (grp == 3) hp[2][idx] = f.r; else hm[2][idx] = f.l;
+    }
+    if (h < 2*GY*GZ) {
+      const int plus = h >= GY*GZ, hh = h % (GY*GZ), py = hh % GY, qz = hh / GY;
+      long ci = image<3> (L, blockIdx.x*GX + (plus ? GX + 1 : 0), blockIdx.y*GY + py + 1, blockIdx.z*GZ + qz + 1);
+      FacePair f = face_values_dir<3, 0> (L, v, none, un, ci, dt, 0, gradient, visc);
+      if (plus) hp[0][hh] = f.r; else hm[0][hh] = f.l;
+    }
+  }
+  __syncthreads ();
+  const int t3[3] = { T.tx, T.ty, T.tz }, g3[3] = { GX, GY, GZ };
+  const int so[3] = { 1, GX, GX*GY };
+  const int hi[3] = { T.ty + GY*T.tz, T.tx + GX*T.tz, T.tx + GX*T.ty };
+  // flux through the + face (direction cf) of the own cell (minus = 0) or of the cell before it
+  auto flux = [&] (int cf, int minus) -> double {
+    long a = minus ? c - off[cf] : c;
+    double l_, r_;
+    if (!minus) {
+      l_ = fl[cf][T.own ()];
+      r_ = t3[cf] + 1 < g3[cf] ? fr[cf][T.own () + so[cf]] : hp[cf][hi[cf]];
+    }
+    else {
+      l_ = t3[cf] > 0 ? fl[cf][T.own () - so[cf]] : hm[cf][hi[cf]];
+      r_ = fr[cf][T.own ()];
+    }
+    double unf = un.p[cf][a];
+    double upw = upwinded (unf, l_, r_);
+    if (VELOCITY) {
+      double f = 1.*unf*dt*rn;          /* /h, h = 1/n a power of two: exact scaling */
+      f *= upw - face_interp (gm[a], gm[a + off[cf]])*dt/2.;
+      return f;
+    }
+    return 1.*unf*dt*upw*rn;
+  };
+  const int i = T.i, j = T.j, k = T.k;
+  double acc = 0.;
+  if (i > 1)
+    acc += flux (0, 1);
+  acc -= flux (0, 0);
+  acc -= flux (1, 0);
+  acc -= flux (2, 0);
+  {
+    unsigned J = n - j, K = n - k;
+    bool back_first = __ffs (~J) > __ffs (~K);
+    if (back_first) {
+      if (k > 1) acc += flux (2, 1);
+      if (j > 1) acc += flux (1, 1);
+    }
+    else {
+      if (j > 1) acc += flux (1, 1);
+      if (k > 1) acc += flux (2, 1);
+    }
+  }
+  if (i == 1)
+    acc += flux (0, 1);
+  if (j == 1)
+    acc += flux (1, 1);
+  if (k == 1)
+    acc += flux (2, 1);
+  double val = v[c];
+  val += acc/1.;
+  if (gc)
+    val -= gc[c]*dt;
+  out[c] = val;
+}
+
+// ---------------------------------------------------------------------------------------------
 // K19: minimum_mac_cfl / minimum_cfl, src/domain.c:2824-2923: min of (h/|un|)^2 and (h/|u|)^2
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_min (double v)
@@ -442,7 +703,7 @@ cfl_partial_kernel (Layout L, CPtr3 u, CPtr3 un, Visc3 visc, double * __restrict
 	}
 	if (visc.d[cc] != 0. && i <= n && j <= n && (DIM == 2 || k <= n)) {
 	  /* p->v[c]->sources: acceleration time scale, src/domain.c:2893-2901 */
-	  double g = 0. + source_diffusion_value<DIM> (u.p[cc], c, off, visc.d[cc], length);
+	  double g = 0. + source_diffusion_value<DIM> (u.p[cc], c, off, visc.d[cc], n);
 	  if (g != 0.) {
 	    double cflg = 2.*length/fabs (1.*g);
 	    m = fmin (m, cflg);
@@ -649,6 +910,44 @@ int launch_flux_update (gfship_domain * dom, bool velocity, double * v, double *
       hipLaunchKernelGGL ((flux_update_kernel<2, false>), grid, block, 0, dom->stream,
 			  L, v, c3 (un), c6 (fv), gm, gc, dt);
   }
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+bool godunov_fused_supported (const gfship_domain * dom)
+{
+  if (dom->dim != 3 || dom->no_fused_godunov) return false;
+  const int n = dom->lay[dom->depth].n;
+  if (n % GX) return false;
+  for (int d = 0; d < 6; d++)
+    if (dom->side[d] != GFSHIP_SIDE_PERIODIC) return false;
+  return true;
+}
+
+int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt, int gradient,
+			     const double visc[3], double * const un[3])
+{
+  const Layout & L = dom->lay[dom->depth];
+  Visc3 vs;
+  for (int c = 0; c < 3; c++) vs.d[c] = visc[c];
+  hipLaunchKernelGGL (predict_un_tiled_kernel, dim3 (L.n/GX, L.n/GY, L.n/GZ), dim3 (GN), 0,
+		      dom->stream, L, c3 (u), m3 (un), dt, gradient, vs);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, double * out,
+			 double * const un[3], const double * gm, const double * gc, double dt,
+			 int gradient, double visc)
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid (L.n/GX, L.n/GY, L.n/GZ);
+  if (velocity)
+    hipLaunchKernelGGL (advect_tiled_kernel<true>, grid, dim3 (GN), 0, dom->stream,
+			L, v, out, c3 (un), gm, gc, dt, gradient, visc);
+  else
+    hipLaunchKernelGGL (advect_tiled_kernel<false>, grid, dim3 (GN), 0, dom->stream,
+			L, v, out, c3 (un), gm, gc, dt, gradient, visc);
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
 }

@@ -47,7 +47,9 @@ enum { GFSHIP_BC_SYMMETRY = 0, GFSHIP_BC_DIRICHLET = 1, GFSHIP_BC_NEUMANN = 2 };
    EXACT_HYPERPLANE is EXACT with one launch per hyperplane instead of the pipelined
           tile sweep (same bits; kept as an independent implementation to test against);
    EXACT_PER_SWEEP is EXACT with one launch per sweep of a relax loop even where the sweeps of
-          the loop can be pipelined in a single launch (same bits). */
+          the loop can be pipelined in a single launch, and with the advection step through the
+          face-value arrays even where it can be fused (same bits; the general paths, kept
+          selectable to test the fused ones against them). */
 enum { GFSHIP_RELAX_EXACT = 0, GFSHIP_RELAX_REDBLACK = 1, GFSHIP_RELAX_EXACT_HYPERPLANE = 2,
        GFSHIP_RELAX_EXACT_PER_SWEEP = 3 };
 

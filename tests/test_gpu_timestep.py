@@ -362,3 +362,28 @@ def test_lid_ghia_through_device(golden_dir):
     ex = np.abs(np.interp(gx[:, 0], xp[:, 1], xp[:, 3]) - gx[:, 1]).max()
     ey = np.abs(np.interp(gy[:, 0], yp[:, 0], yp[:, 4]) - gy[:, 1]).max()
     assert ex <= 2e-2 and ey <= 1.7e-2, (ex, ey)
+
+
+@pytest.mark.parametrize("dim,level", [(2, 5), (3, 5)])
+def test_fused_periodic_paths_equal_general_paths(dim, level):
+    """periodic boxes take the fused kernels (relax loop in one launch, Godunov step without the
+    face-value arrays); RELAX_EXACT_PER_SWEEP selects the general kernels: same bits, with a
+    tracer and implicit viscosity in the mix"""
+    osim = oracle_reynolds(level) if dim == 2 else oracle_taylor_green(level)
+    res = []
+    for mode in (gfship.RELAX_EXACT, gfship.RELAX_EXACT_PER_SWEEP):
+        gd, gs = _device_sim(osim, PERIODIC)
+        gd.set_relax_mode(mode)
+        t = gs.add_tracer()
+        rng = np.random.default_rng(5)
+        t.upload(_with_ghosts(rng.random(((1 << level),) * dim), dim))
+        gs.set_viscosity(0, 1e-3)
+        gs.start()
+        for _ in range(3):
+            gs.step()
+        res.append([gs.u[c].download() for c in range(dim)] + [gs.p.download(), t.download()] +
+                   [gs.un(c) for c in range(dim)] + [np.array([gs.t, gs.dt])])
+        gd.destroy()
+    for a, b in zip(*res):
+        assert np.array_equal(_interior(a, dim) if a.ndim == dim else a,
+                              _interior(b, dim) if b.ndim == dim else b)
