@@ -117,6 +117,7 @@ void gfship_domain_destroy (gfship_domain * dom)
       gfship_field_free (dom, (gfship_field) f);
   skew_free (dom);
   if (dom->d_scratch) (void) hipFree (dom->d_scratch);
+  if (dom->cfl_partial) (void) hipFree (dom->cfl_partial);
   if (dom->h_pinned) (void) hipHostFree (dom->h_pinned);
   if (dom->ev0) (void) hipEventDestroy (dom->ev0);
   if (dom->ev1) (void) hipEventDestroy (dom->ev1);

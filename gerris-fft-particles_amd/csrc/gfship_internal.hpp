@@ -94,6 +94,8 @@ struct gfship_domain {
   bool unit_weights = false;      // gfship_poisson_coefficients called with alpha = NULL
   gfship::SkewPlan skew[GFSHIP_MAXLEVEL + 1];
   double diff_w[GFSHIP_MAXLEVEL + 1] = {};  // diffusion face weight of each level
+  double * cfl_partial = nullptr;   // per-block max |un|, |u| of the fused projection update
+  size_t cfl_nblocks = 0, cfl_used = 0;
   gfship_field res_cache = -1;    // the `res` temporary of gfs_diffusion
   bool diff_ready = false;        // gfship_diffusion_coefficients called
 };
@@ -156,6 +158,11 @@ int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3],
 int launch_coarse_init (gfship_domain * dom, Field * const * v, int nf);
 int launch_velocity_divergence (gfship_domain * dom, double * const u[3], double * out);
 bool godunov_fused_supported (const gfship_domain * dom);
+int launch_project_correct (gfship_domain * dom, const double * p, double * const un[3],
+			    double * const g[3], double * const u[3], double dt, bool want_max);
+int launch_cfl_from_max (gfship_domain * dom, double * cfl2);
+int launch_face_interp_div (gfship_domain * dom, double * const u[3], double * const un[3],
+			    double * div, double dt);
 int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt, int gradient,
 			     const double visc[3], double * const un[3]);
 int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, double * out,

@@ -23,6 +23,7 @@ struct gfship_sim {
   double visc[3] = {0., 0., 0.};   // GfsSourceDiffusion on U, V, W (constant coefficient)
   gfship_multilevel_params diffusion_params[3];
   gfship_field drhs = -1, rhoc = -1;   // temporaries of variable_diffusion
+  bool cfl_ready = false;              // maxima for the CFL condition left by the last projection
   gfship_field adv_tmp = -1;           // output of the fused advection kernel (swapped with v)
   gfship_next_event_fn next_event = nullptr; void * next_event_ctx = nullptr;
 };
@@ -57,12 +58,13 @@ int bc_leaf (gfship_sim * s, gfship_field v)
 // mac_projection, src/timestep.c:356-444.  `pdata` supplies the storage of the pressure and
 // `pbc` the boundary conditions (gfs_variables_swap swaps storage only, src/variable.c:234-243).
 int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, gfship_field p,
-		    const gfship_field g[3])
+		    const gfship_field g[3], bool approximate = false)
 {
   gfship_domain * dom = s->dom;
-  double * un[3], * gp[3];
+  double * un[3], * gp[3], * u[3];
   ptrs3 (s, s->un, un);
   ptrs3 (s, g, gp);
+  ptrs3 (s, s->u, u);
   /* gfs_reset_gradients + no face sources: g is overwritten by centered_gradient below */
   /* gfs_poisson_coefficients (alpha = NULL): unit weights */
   TRY (gfship_poisson_coefficients (dom));
@@ -70,14 +72,27 @@ int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, g
   for (int l = 0; l <= dom->depth; l++)
     if (!dom->fields[s->dia].zero[l])
       TRY (gfship_field_fill (dom, s->dia, l, 0.));
-  /* MAC divergence, scaled by 1/dt */
-  TRY (launch_divergence (dom, un, leaf (s, s->div), dt));
+  /* MAC divergence, scaled by 1/dt (approximate projection: together with the MAC velocities
+     interpolated from the centred ones, gfs_approximate_projection src/timestep.c:572-580) */
+  if (approximate)
+    TRY (launch_face_interp_div (dom, u, un, leaf (s, s->div), dt));
+  else
+    TRY (launch_divergence (dom, un, leaf (s, s->div), dt));
   TRY (gfship_poisson_solve (dom, par, p, s->div, s->res, s->dia, dt));
-  /* gfs_correct_normal_velocities + gfs_scale_gradients */
-  TRY (launch_correct_un (dom, leaf (s, p), un, dt));
-  TRY (launch_centered_gradient (dom, leaf (s, p), gp));
+  /* gfs_correct_normal_velocities + gfs_scale_gradients, and for the approximate projection
+     gfs_correct_centered_velocities (src/timestep.c:486-530), in one pass over p.  The pass
+     also leaves the largest |un|, |u| behind for the CFL condition of the next time step. */
+  s->cfl_ready = false;
+  bool want_max = approximate;
+  for (int c = 0; c < dom->dim; c++)
+    if (s->visc[c] != 0.) want_max = false;   /* the acceleration term needs the full kernel */
+  TRY (launch_project_correct (dom, leaf (s, p), un, gp, approximate ? u : nullptr, dt, want_max));
+  s->cfl_ready = want_max;
   for (int c = 0; c < dom->dim; c++)
     TRY (bc_leaf (s, g[c]));
+  if (approximate)
+    for (int c = 0; c < dom->dim; c++)
+      TRY (bc_leaf (s, s->u[c]));
   return GFSHIP_OK;
 }
 
@@ -337,13 +352,8 @@ int gfship_approximate_projection (gfship_sim * s, gfship_multilevel_params * pa
 				   gfship_field p, const gfship_field g[3])
 {
   GFSHIP_CHECK (s && par && g, GFSHIP_EINVAL, "null argument");
-  double * u[3], * un[3];
-  ptrs3 (s, s->u, u);
-  ptrs3 (s, s->un, un);
-  /* compute MAC velocities from centered velocities */
-  TRY (launch_face_interp_un (s->dom, u, un));
-  TRY (mac_projection (s, par, dt, p, g));
-  TRY (correct_centered_velocities (s, g, dt));
+  /* MAC velocities from the centred ones, projection, correction of the centred velocities */
+  TRY (mac_projection (s, par, dt, p, g, true));
   return GFSHIP_OK;
 }
 
@@ -385,6 +395,21 @@ int gfship_tracer_advection (gfship_sim * s, gfship_field t, double dt)
   return GFSHIP_OK;
 }
 
+static int domain_cfl (gfship_sim * s, double * cfl, bool cached)
+{
+  double * u[3], * un[3];
+  ptrs3 (s, s->u, u);
+  ptrs3 (s, s->un, un);
+  double c2;
+  if (cached && s->cfl_ready)
+    TRY (launch_cfl_from_max (s->dom, &c2));
+  else
+    TRY (launch_cfl (s->dom, u, un, s->visc, &c2));
+  s->cfl_ready = false;
+  *cfl = sqrt (c2);
+  return GFSHIP_OK;
+}
+
 int gfship_domain_cfl (gfship_sim * s, double * cfl)
 {
   GFSHIP_CHECK (s && cfl, GFSHIP_EINVAL, "null argument");
@@ -392,19 +417,21 @@ int gfship_domain_cfl (gfship_sim * s, double * cfl)
   ptrs3 (s, s->u, u);
   ptrs3 (s, s->un, un);
   double c2;
+  s->cfl_ready = false;
   TRY (launch_cfl (s->dom, u, un, s->visc, &c2));
   *cfl = sqrt (c2);
   return GFSHIP_OK;
 }
 
-int gfship_set_timestep (gfship_sim * s)
+// cached: the velocities have not changed since the approximate projection that has just run
+// (only gfship_sim_start / gfship_sim_step say so), its maxima give the CFL time scale
+static int set_timestep (gfship_sim * s, bool cached)
 {
-  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
   double t = s->t;
   double cfl = s->advection_params.cfl;
   if (cfl < DBL_MAX) {
     double dcfl;
-    TRY (gfship_domain_cfl (s, &dcfl));
+    TRY (domain_cfl (s, &dcfl, cached));
     s->advection_params.dt = cfl*dcfl;
   }
   else
@@ -434,6 +461,12 @@ int gfship_set_timestep (gfship_sim * s)
   if (s->advection_params.dt < 1e-9)
     s->advection_params.dt = 1e-9;
   return GFSHIP_OK;
+}
+
+int gfship_set_timestep (gfship_sim * s)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  return set_timestep (s, false);
 }
 
 int gfship_coarse_init (gfship_sim * s)
@@ -467,7 +500,7 @@ int gfship_sim_start (gfship_sim * s)
   if (s->i == 0) {
     TRY (gfship_approximate_projection (s, &s->approx_projection_params, s->advection_params.dt,
 					s->p, s->g));
-    TRY (gfship_set_timestep (s));
+    TRY (set_timestep (s, true));
     TRY (advance_tracers (s, s->advection_params.dt/2.));
   }
   return GFSHIP_OK;
@@ -501,7 +534,7 @@ int gfship_sim_step (gfship_sim * s)
   s->t = s->tnext;
   s->i++;
 
-  TRY (gfship_set_timestep (s));
+  TRY (set_timestep (s, true));
   TRY (advance_tracers (s, s->advection_params.dt));
   return GFSHIP_OK;
 }

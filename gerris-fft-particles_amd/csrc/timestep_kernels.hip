@@ -154,6 +154,149 @@ correct_centered_kernel (Layout L, Ptr3 u, CPtr3 g, double dt)
     u.p[cc][c] -= g.p[cc][c]*dt;
 }
 
+// K10 + K11 in one pass over the pressure: correct_normal_velocity on every face, the centred
+// gradient of every cell (both kernels above, same expressions: each thread recomputes the
+// gradient of its - faces instead of reading it back), optionally K11b on the centred velocities
+// (approximate projection) and then the largest |un|, |u| for the CFL condition: (h/|x|)^2 is
+// monotonically non-increasing in |x|, roundings included, so the minimum of minimum_mac_cfl /
+// minimum_cfl (src/domain.c:2824-2890) is that expression of the maximum.
+// h = 1/n is a power of two: /h is written as an exact scaling by n.
+__device__ __forceinline__ double wave_max_d (double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    v = fmax (v, __shfl_down (v, o, 64));
+  return v;
+}
+
+// Index space: one thread per (i,j,k) with i in 1..n, j and k in 0..n; the thread of i = 1 also
+// takes the column i = 0 (faces on the low x side), so that rows map to whole 256-thread blocks.
+template <int DIM, bool FUSE_U>
+__global__ void __launch_bounds__(256)
+project_correct_kernel (Layout L, const double * __restrict__ p, Ptr3 un, Ptr3 g, Ptr3 u,
+			double dt, double * __restrict__ partial_max)
+{
+  const int i1 = blockIdx.x*blockDim.x + threadIdx.x + 1;
+  const int j = blockIdx.y;
+  const int k = DIM == 3 ? blockIdx.z : 0;
+  const int n = L.n;
+  const double rn = (double) n;
+  const long off[3] = { 1, L.sy, L.sz };
+  double mx = 0.;
+  auto body = [&] (int i) {
+    const long c = L.idx (i, j, k);
+    const bool interior = i >= 1 && j >= 1 && (DIM == 2 || k >= 1);
+#pragma unroll
+    for (int cc = 0; cc < DIM; cc++) {
+      const bool valid = face_valid<DIM> (n, cc, i, j, k);
+      if (valid || interior) {
+	double dpp = (1.*p[c + off[cc]] - 1.*p[c])*rn;
+	dpp /= 1.;
+	if (valid) {
+	  double w = un.p[cc][c];
+	  w -= dpp*dt;
+	  un.p[cc][c] = w;
+	  mx = fmax (mx, fabs (w));
+	}
+	if (interior) {
+	  double dpm = (1.*p[c] - 1.*p[c - off[cc]])*rn;
+	  dpm /= 1.;
+	  double v = 0.;
+	  v += dpm*1.;
+	  v += dpp*1.;
+	  double gg = v/2.;
+	  g.p[cc][c] = gg;
+	  if (FUSE_U) {
+	    double w = u.p[cc][c];
+	    w -= gg*dt;
+	    u.p[cc][c] = w;
+	    mx = fmax (mx, fabs (1.*w));
+	  }
+	}
+      }
+    }
+  };
+  if (i1 <= n) {
+    body (i1);
+    if (i1 == 1)
+      body (0);
+  }
+  if (partial_max) {
+    __shared__ double sh[4];
+    mx = wave_max_d (mx);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads ();
+    if (threadIdx.x == 0) {
+      double r = sh[0];
+      for (int q = 1; q < (int) (blockDim.x >> 6); q++) r = fmax (r, sh[q]);
+      partial_max[blockIdx.x + gridDim.x*(blockIdx.y + (size_t) gridDim.y*blockIdx.z)] = r;
+    }
+  }
+}
+
+// cfl^2 = (h/max)^2 from the per-block maxima
+__global__ void __launch_bounds__(256)
+cfl_from_max_kernel (const double * __restrict__ partial_max, int nblocks, double length,
+		     double * __restrict__ out)
+{
+  double m = 0.;
+  for (int q = threadIdx.x; q < nblocks; q += blockDim.x)
+    m = fmax (m, partial_max[q]);
+  __shared__ double sh[4];
+  m = wave_max_d (m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    m = fmax (fmax (sh[0], sh[1]), fmax (sh[2], sh[3]));
+    double r = DBL_MAX;
+    if (m != 0.) {
+      double cflu = length/fabs (m);
+      r = cflu*cflu;
+    }
+    out[0] = r;
+  }
+}
+
+// K12 + K9 in one pass over the centred velocities (approximate projection): the MAC velocities
+// and their divergence scaled by 1/dt; the - face of a cell is recomputed, not read back
+template <int DIM>
+__global__ void __launch_bounds__(256)
+face_interp_div_kernel (Layout L, CPtr3 u, Ptr3 un, double * __restrict__ div, double dt)
+{
+  const int i1 = blockIdx.x*blockDim.x + threadIdx.x + 1;
+  const int j = blockIdx.y;
+  const int k = DIM == 3 ? blockIdx.z : 0;
+  if (i1 > L.n) return;
+  const long off[3] = { 1, L.sy, L.sz };
+  const double h = 1./L.n;
+  auto body = [&] (int i) {
+    const long c = L.idx (i, j, k);
+    const bool interior = i >= 1 && j >= 1 && (DIM == 2 || k >= 1);
+    double d_ = 0.;
+#pragma unroll
+    for (int cc = 0; cc < DIM; cc++) {
+      const bool valid = face_valid<DIM> (L.n, cc, i, j, k);
+      double unp = 0.;
+      if (valid || interior)
+	unp = face_interp (u.p[cc][c], u.p[cc][c + off[cc]]);
+      if (valid)
+	un.p[cc][c] = unp;
+      if (interior) {
+	double unm = face_interp (u.p[cc][c - off[cc]], u.p[cc][c]);
+	d_ += 1.*unp*1.;
+	d_ += -1.*unm*1.;
+      }
+    }
+    if (interior) {
+      double v = d_*h;
+      div[c] = v/dt;
+    }
+  };
+  body (i1);
+  if (i1 == 1)
+    body (0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K13: gfs_cell_advected_face_values, src/advection.c:58-99
 // ---------------------------------------------------------------------------------------------
@@ -911,6 +1054,72 @@ int launch_flux_update (gfship_domain * dom, bool velocity, double * v, double *
 			  L, v, c3 (un), c6 (fv), gm, gc, dt);
   }
   GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// grid of the kernels above: i = 1..n in blocks along x (the thread of i = 1 also does i = 0),
+// j and k = 0..n
+static inline void ext1_grid (const Layout & L, dim3 * grid, dim3 * block)
+{
+  int b = L.n >= 256 ? 256 : L.n >= 128 ? 128 : 64;
+  *block = dim3 (b);
+  *grid = dim3 ((L.n + b - 1)/b, L.n + 1, L.dim == 3 ? L.n + 1 : 1);
+}
+
+int launch_project_correct (gfship_domain * dom, const double * p, double * const un[3],
+			    double * const g[3], double * const u[3] /* or nullptr */, double dt,
+			    bool want_max)
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid, block;
+  ext1_grid (L, &grid, &block);
+  double * pm = nullptr;
+  if (want_max) {
+    size_t nb = (size_t) grid.x*grid.y*grid.z;
+    if (dom->cfl_nblocks < nb) {
+      if (dom->cfl_partial) GFSHIP_HIP (hipFree (dom->cfl_partial));
+      dom->cfl_partial = nullptr;
+      GFSHIP_HIP (hipMalloc ((void **) &dom->cfl_partial, nb*sizeof (double)));
+      dom->cfl_nblocks = nb;
+    }
+    dom->cfl_used = nb;
+    pm = dom->cfl_partial;
+  }
+  Ptr3 none = { { nullptr, nullptr, nullptr } };
+  if (dom->dim == 3) {
+    if (u) hipLaunchKernelGGL ((project_correct_kernel<3, true>), grid, block, 0, dom->stream, L, p, m3 (un), m3 (g), m3 (u), dt, pm);
+    else   hipLaunchKernelGGL ((project_correct_kernel<3, false>), grid, block, 0, dom->stream, L, p, m3 (un), m3 (g), none, dt, pm);
+  }
+  else {
+    if (u) hipLaunchKernelGGL ((project_correct_kernel<2, true>), grid, block, 0, dom->stream, L, p, m3 (un), m3 (g), m3 (u), dt, pm);
+    else   hipLaunchKernelGGL ((project_correct_kernel<2, false>), grid, block, 0, dom->stream, L, p, m3 (un), m3 (g), none, dt, pm);
+  }
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// the CFL time scale from the maxima left by launch_project_correct (want_max)
+int launch_cfl_from_max (gfship_domain * dom, double * cfl2)
+{
+  const Layout & L = dom->lay[dom->depth];
+  double * result = dom->d_scratch + 5*1024;
+  hipLaunchKernelGGL (cfl_from_max_kernel, dim3 (1), dim3 (256), 0, dom->stream, dom->cfl_partial,
+		      (int) dom->cfl_used, 1./L.n, result);
+  GFSHIP_HIP (hipGetLastError ());
+  GFSHIP_HIP (hipMemcpyAsync (dom->h_pinned, result, sizeof (double), hipMemcpyDeviceToHost,
+			      dom->stream));
+  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  *cfl2 = dom->h_pinned[0];
+  return call_reduce (dom, cfl2, 1, 2);
+}
+
+int launch_face_interp_div (gfship_domain * dom, double * const u[3], double * const un[3],
+			    double * div, double dt)
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid, block;
+  ext1_grid (L, &grid, &block);
+  DISPATCH (dom, face_interp_div_kernel, grid, block, L, c3 (u), m3 (un), div, dt);
   return GFSHIP_OK;
 }
 
