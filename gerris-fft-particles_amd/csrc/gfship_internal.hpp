@@ -96,6 +96,7 @@ struct gfship_domain {
   double diff_w[GFSHIP_MAXLEVEL + 1] = {};  // diffusion face weight of each level
   double * cfl_partial = nullptr;   // per-block max |un|, |u| of the fused projection update
   size_t cfl_nblocks = 0, cfl_used = 0;
+  bool cfl_dirty = false;
   gfship_field res_cache = -1;    // the `res` temporary of gfs_diffusion
   bool diff_ready = false;        // gfship_diffusion_coefficients called
 };

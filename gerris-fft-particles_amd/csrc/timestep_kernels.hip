@@ -229,19 +229,25 @@ project_correct_kernel (Layout L, const double * __restrict__ p, Ptr3 un, Ptr3 g
     if (threadIdx.x == 0) {
       double r = sh[0];
       for (int q = 1; q < (int) (blockDim.x >> 6); q++) r = fmax (r, sh[q]);
-      partial_max[blockIdx.x + gridDim.x*(blockIdx.y + (size_t) gridDim.y*blockIdx.z)] = r;
+      // non-negative doubles order like their bit patterns: one atomic per block into 1024 slots
+      if (r > 0.)
+	atomicMax ((unsigned long long *) partial_max +
+		   ((blockIdx.x + gridDim.x*(blockIdx.y + (size_t) gridDim.y*blockIdx.z)) & 1023),
+		   (unsigned long long) __double_as_longlong (r));
     }
   }
 }
 
-// cfl^2 = (h/max)^2 from the per-block maxima
+// cfl^2 = (h/max)^2 from the 1024 slots, which are cleared for the next use
 __global__ void __launch_bounds__(256)
-cfl_from_max_kernel (const double * __restrict__ partial_max, int nblocks, double length,
+cfl_from_max_kernel (double * __restrict__ partial_max, int nblocks, double length,
 		     double * __restrict__ out)
 {
   double m = 0.;
-  for (int q = threadIdx.x; q < nblocks; q += blockDim.x)
+  for (int q = threadIdx.x; q < nblocks; q += blockDim.x) {
     m = fmax (m, partial_max[q]);
+    partial_max[q] = 0.;
+  }
   __shared__ double sh[4];
   m = wave_max_d (m);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
@@ -1075,14 +1081,16 @@ int launch_project_correct (gfship_domain * dom, const double * p, double * cons
   ext1_grid (L, &grid, &block);
   double * pm = nullptr;
   if (want_max) {
-    size_t nb = (size_t) grid.x*grid.y*grid.z;
-    if (dom->cfl_nblocks < nb) {
-      if (dom->cfl_partial) GFSHIP_HIP (hipFree (dom->cfl_partial));
-      dom->cfl_partial = nullptr;
+    const size_t nb = 1024;
+    if (!dom->cfl_partial) {
       GFSHIP_HIP (hipMalloc ((void **) &dom->cfl_partial, nb*sizeof (double)));
+      GFSHIP_HIP (hipMemsetAsync (dom->cfl_partial, 0, nb*sizeof (double), dom->stream));
       dom->cfl_nblocks = nb;
     }
     dom->cfl_used = nb;
+    if (dom->cfl_dirty)     /* maxima of an earlier projection that nobody consumed */
+      GFSHIP_HIP (hipMemsetAsync (dom->cfl_partial, 0, nb*sizeof (double), dom->stream));
+    dom->cfl_dirty = true;
     pm = dom->cfl_partial;
   }
   Ptr3 none = { { nullptr, nullptr, nullptr } };
@@ -1105,6 +1113,7 @@ int launch_cfl_from_max (gfship_domain * dom, double * cfl2)
   double * result = dom->d_scratch + 5*1024;
   hipLaunchKernelGGL (cfl_from_max_kernel, dim3 (1), dim3 (256), 0, dom->stream, dom->cfl_partial,
 		      (int) dom->cfl_used, 1./L.n, result);
+  dom->cfl_dirty = false;
   GFSHIP_HIP (hipGetLastError ());
   GFSHIP_HIP (hipMemcpyAsync (dom->h_pinned, result, sizeof (double), hipMemcpyDeviceToHost,
 			      dom->stream));
