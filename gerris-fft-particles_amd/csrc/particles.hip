@@ -28,7 +28,8 @@
 struct gfship_particles {
   gfship_sim * sim = nullptr;
   gfship_domain * dom = nullptr;
-  int n = 0;                   // slots (alive or not)
+  int n = 0;                   // slots in use (alive or not)
+  int cap = 0;                 // slots allocated
   double * pos[3] = {}, * old[3] = {};
   unsigned * id = nullptr;
   unsigned char * alive = nullptr;
@@ -42,6 +43,11 @@ struct gfship_particles {
   void * sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   int sort_every = 16, events_since_sort = -1;   // -1: never sorted yet
+  // migration through GfsBoundaryMpi sides
+  gfship_particle_migrate_fn migrate = nullptr; void * migrate_ctx = nullptr;
+  double * outbox = nullptr;          // device, 6 x out_cap records of 7 doubles
+  unsigned * out_count = nullptr;     // device, 6 counters
+  int out_cap = 0;
 };
 
 namespace gfship {
@@ -56,6 +62,7 @@ struct PartArgs {
   const double * u[3];
   double dt;
   unsigned * count;
+  int migrate;                 // particles leaving through an external side are kept for the hook
 };
 
 // ftt_cell_locate on the unit box centred on the origin, leaf level
@@ -223,7 +230,7 @@ particle_list_event_kernel (PartArgs A, int depth)
 {
   int q = blockIdx.x*blockDim.x + threadIdx.x;
   if (q >= A.n) return;
-  if (!A.alive[q]) return;
+  if (A.alive[q] != 1) return;
   const int n = A.L.n;
   const double h = 1./n;
   double p[3] = { A.pos[0][q], A.pos[1][q], DIM == 3 ? A.pos[2][q] : 0. };
@@ -250,6 +257,7 @@ particle_list_event_kernel (PartArgs A, int depth)
   // gfs_particle_bc, modules/particulatecommon.c:3326-3395
   int cn[3];
   bool keep = true;
+  int mig = 0;
   if (!locate<DIM> (depth, p, cn)) {
     // boundarycell (:3149-3186): march from the cell of pos_old to the box side
     int d = 0;
@@ -263,7 +271,9 @@ particle_list_event_kernel (PartArgs A, int depth)
 	break;
       cc[c] = next;
     }
-    if (A.side[d] != GFSHIP_SIDE_PERIODIC)
+    if (A.side[d] == GFSHIP_SIDE_EXTERNAL && A.migrate)
+      mig = 2 + d;                  /* GfsBoundaryMpi: sent to the box across the side */
+    else if (A.side[d] != GFSHIP_SIDE_PERIODIC)
       keep = false;                 /* taken off the list, nothing puts it back */
     else {
       // periodic_bc_particle (:3189-3214), box of size 1 matching itself
@@ -285,6 +295,41 @@ particle_list_event_kernel (PartArgs A, int depth)
   }
   if (!keep)
     A.alive[q] = 0;
+  else if (mig)
+    A.alive[q] = (unsigned char) mig;
+}
+
+// mpi_send_particle (modules/particulatecommon.c:3218-3222): the particles marked 2 + d go into the
+// packet of side d (7 doubles: position and old position in the coordinates of the receiving
+// box -- the same point of space, one box size less along the normal -- and the id) and leave
+// the list
+struct OutboxArgs {
+  int n, out_cap;
+  const double * pos[3], * old[3];
+  const unsigned * id;
+  unsigned char * alive;
+  double * outbox;
+  unsigned * out_count;
+};
+
+__global__ void __launch_bounds__(256)
+particle_outbox_kernel (OutboxArgs A)
+{
+  int q = blockIdx.x*blockDim.x + threadIdx.x;
+  if (q >= A.n) return;
+  int code = A.alive[q];
+  if (code < 2) return;
+  int d = code - 2;
+  A.alive[q] = 0;
+  unsigned k = atomicAdd (A.out_count + d, 1u);
+  if (k >= (unsigned) A.out_cap) return;      /* the host sees the count and reports the overflow */
+  double * r = A.outbox + 7*((size_t) d*A.out_cap + k);
+  double normal = (double) (d ^ 1) - (double) d;
+#pragma unroll
+  for (int c = 0; c < 3; c++) { r[c] = A.pos[c][q]; r[3 + c] = A.old[c][q]; }
+  r[d/2] -= normal*1.;
+  r[3 + d/2] -= normal*1.;
+  r[6] = (double) A.id[q];
 }
 
 // key = linear index of the containing leaf cell, dead or outside particles last
@@ -298,7 +343,7 @@ particle_keys_kernel (Layout L, int depth, int n, const double * __restrict__ x,
   int q = blockIdx.x*blockDim.x + threadIdx.x;
   if (q >= n) return;
   unsigned k = 0xFFFFFFFFu;
-  if (alive[q]) {
+  if (alive[q] == 1) {
     double p[3] = { x[q], y[q], DIM == 3 ? z[q] : 0. };
     int c[3];
     if (locate<DIM> (depth, p, c))
@@ -361,7 +406,7 @@ __global__ void __launch_bounds__(256)
 count_alive_kernel (const unsigned char * alive, int n, unsigned * count)
 {
   int q = blockIdx.x*blockDim.x + threadIdx.x;
-  unsigned long long m = __ballot (q < n && alive[q]);
+  unsigned long long m = __ballot (q < n && alive[q] == 1);
   if ((threadIdx.x & 63) == 0 && m)
     atomicAdd (count, (unsigned) __popcll (m));
 }
@@ -384,7 +429,8 @@ int gfship_particles_create (gfship_particles ** out, gfship_sim * sim, int np,
   pl->sim = sim;
   pl->dom = gfship_sim_view_get (sim).dom;
   pl->n = np;
-  size_t m = std::max (np, 1);
+  pl->cap = std::max (np, 1);
+  size_t m = pl->cap;
   std::vector<double> tmp (m);
   for (int c = 0; c < 3; c++) {
     GFSHIP_HIP (hipMalloc ((void **) &pl->pos[c], m*sizeof (double)));
@@ -431,7 +477,7 @@ void gfship_particles_destroy (gfship_particles * pl)
     if (pl->old2[c]) (void) hipFree (pl->old2[c]);
   }
   void * extra[] = { pl->orig, pl->orig2, pl->id2, pl->key, pl->key2, pl->slot, pl->slot2,
-		     pl->alive2, pl->sort_tmp };
+		     pl->alive2, pl->sort_tmp, pl->outbox, pl->out_count };
   for (void * a : extra)
     if (a) (void) hipFree (a);
   delete pl;
@@ -535,10 +581,135 @@ int gfship_particles_sort (gfship_particles * pl)
   return GFSHIP_OK;
 }
 
+// grow the per-particle arrays to at least `need` slots (contents of the live arrays kept)
+static int particles_reserve (gfship_particles * pl, int need)
+{
+  if (need <= pl->cap) return GFSHIP_OK;
+  gfship_domain * dom = pl->dom;
+  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  size_t m = std::max (need, 2*pl->cap), old = pl->cap;
+  auto grow = [&] (void ** a, size_t elem, bool keep) -> hipError_t {
+    void * nw = nullptr;
+    hipError_t e = hipMalloc (&nw, m*elem);
+    if (e != hipSuccess) return e;
+    if (keep && *a) e = hipMemcpy (nw, *a, old*elem, hipMemcpyDeviceToDevice);
+    if (*a) (void) hipFree (*a);
+    *a = nw;
+    return e;
+  };
+  for (int c = 0; c < 3; c++) {
+    GFSHIP_HIP (grow ((void **) &pl->pos[c], sizeof (double), true));
+    GFSHIP_HIP (grow ((void **) &pl->old[c], sizeof (double), true));
+    GFSHIP_HIP (grow ((void **) &pl->pos2[c], sizeof (double), false));
+    GFSHIP_HIP (grow ((void **) &pl->old2[c], sizeof (double), false));
+  }
+  GFSHIP_HIP (grow ((void **) &pl->id, sizeof (unsigned), true));
+  GFSHIP_HIP (grow ((void **) &pl->orig, sizeof (unsigned), true));
+  GFSHIP_HIP (grow ((void **) &pl->alive, 1, true));
+  unsigned ** scratch[] = { &pl->orig2, &pl->id2, &pl->key, &pl->key2, &pl->slot, &pl->slot2 };
+  for (unsigned ** a : scratch)
+    GFSHIP_HIP (grow ((void **) a, sizeof (unsigned), false));
+  GFSHIP_HIP (grow ((void **) &pl->alive2, 1, false));
+  pl->cap = (int) m;
+  return GFSHIP_OK;
+}
+
+// send_particles / rcv_particles through the GfsBoundaryMpi sides
+// (modules/particulatecommon.c:3247-3312): packets per side out, the neighbours' packets in
+static int particles_migrate (gfship_particles * pl)
+{
+  gfship_domain * dom = pl->dom;
+  const int want = std::max (4096, pl->n/4);
+  if (pl->out_cap < want) {
+    if (pl->outbox) GFSHIP_HIP (hipFree (pl->outbox));
+    pl->outbox = nullptr;
+    GFSHIP_HIP (hipMalloc ((void **) &pl->outbox, 6*(size_t) want*7*sizeof (double)));
+    pl->out_cap = want;
+  }
+  if (!pl->out_count)
+    GFSHIP_HIP (hipMalloc ((void **) &pl->out_count, 6*sizeof (unsigned)));
+  GFSHIP_HIP (hipMemsetAsync (pl->out_count, 0, 6*sizeof (unsigned), dom->stream));
+  OutboxArgs O;
+  O.n = pl->n; O.out_cap = pl->out_cap;
+  for (int c = 0; c < 3; c++) { O.pos[c] = pl->pos[c]; O.old[c] = pl->old[c]; }
+  O.id = pl->id; O.alive = pl->alive; O.outbox = pl->outbox; O.out_count = pl->out_count;
+  if (pl->n > 0) {
+    hipLaunchKernelGGL (particle_outbox_kernel, dim3 ((pl->n + 255)/256), dim3 (256), 0, dom->stream, O);
+    GFSHIP_HIP (hipGetLastError ());
+  }
+  unsigned cnt[6];
+  GFSHIP_HIP (hipMemcpyAsync (cnt, pl->out_count, sizeof (cnt), hipMemcpyDeviceToHost, dom->stream));
+  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  std::vector<double> send[6];
+  int nsend[6], nrecv[6] = { 0, 0, 0, 0, 0, 0 };
+  const double * sp[6], * rp[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  for (int d = 0; d < 6; d++) {
+    GFSHIP_CHECK (cnt[d] <= (unsigned) pl->out_cap, GFSHIP_ENOMEM,
+		  "%u particles leave through side %d in one step: more than the %d the packet holds",
+		  cnt[d], d, pl->out_cap);
+    nsend[d] = (int) cnt[d];
+    send[d].resize (7*(size_t) cnt[d]);
+    if (cnt[d])
+      GFSHIP_HIP (hipMemcpy (send[d].data (), pl->outbox + 7*(size_t) d*pl->out_cap,
+			     7*(size_t) cnt[d]*sizeof (double), hipMemcpyDeviceToHost));
+    /* the device fills the packet in no particular order: sort it by id */
+    std::vector<size_t> o (cnt[d]);
+    std::iota (o.begin (), o.end (), (size_t) 0);
+    std::sort (o.begin (), o.end (), [&] (size_t a, size_t b) { return send[d][7*a + 6] < send[d][7*b + 6]; });
+    std::vector<double> sorted (send[d].size ());
+    for (size_t q = 0; q < o.size (); q++)
+      memcpy (&sorted[7*q], &send[d][7*o[q]], 7*sizeof (double));
+    send[d].swap (sorted);
+    sp[d] = send[d].data ();
+  }
+  int r = pl->migrate (pl->migrate_ctx, nsend, sp, nrecv, rp);
+  GFSHIP_CHECK (r == 0, GFSHIP_EHIP, "the particle migration hook failed (%d)", r);
+  int total = 0;
+  for (int d = 0; d < 6; d++) total += nrecv[d];
+  if (total == 0) return GFSHIP_OK;
+  if ((r = particles_reserve (pl, pl->n + total))) return r;
+  std::vector<double> col (total);
+  std::vector<unsigned> ids (total), orig (total);
+  std::vector<unsigned char> one (total, 1);
+  for (int c = 0; c < 6; c++) {
+    size_t k = 0;
+    for (int d = 0; d < 6; d++)             /* box_rcv_bc: side by side, in packet order */
+      for (int q = 0; q < nrecv[d]; q++)
+	col[k++] = rp[d][7*(size_t) q + c];
+    GFSHIP_HIP (hipMemcpy ((c < 3 ? pl->pos[c] : pl->old[c - 3]) + pl->n, col.data (),
+			   total*sizeof (double), hipMemcpyHostToDevice));
+  }
+  size_t k = 0;
+  for (int d = 0; d < 6; d++)
+    for (int q = 0; q < nrecv[d]; q++, k++) {
+      ids[k] = (unsigned) rp[d][7*(size_t) q + 6];
+      orig[k] = (unsigned) (pl->n + k);
+    }
+  GFSHIP_HIP (hipMemcpy (pl->id + pl->n, ids.data (), total*sizeof (unsigned), hipMemcpyHostToDevice));
+  GFSHIP_HIP (hipMemcpy (pl->orig + pl->n, orig.data (), total*sizeof (unsigned), hipMemcpyHostToDevice));
+  GFSHIP_HIP (hipMemcpy (pl->alive + pl->n, one.data (), total, hipMemcpyHostToDevice));
+  pl->n += total;
+  return GFSHIP_OK;
+}
+
+int gfship_particles_set_migrate (gfship_particles * pl, gfship_particle_migrate_fn fn, void * ctx)
+{
+  GFSHIP_CHECK (pl != nullptr, GFSHIP_EINVAL, "null particle list");
+  pl->migrate = fn;
+  pl->migrate_ctx = ctx;
+  return GFSHIP_OK;
+}
+
+int gfship_particles_slots (gfship_particles * pl)
+{
+  GFSHIP_CHECK (pl != nullptr, GFSHIP_EINVAL, "null particle list");
+  return pl->n;
+}
+
 int gfship_particle_list_event (gfship_particles * pl)
 {
   GFSHIP_CHECK (pl != nullptr, GFSHIP_EINVAL, "null particle list");
-  if (pl->n == 0) return GFSHIP_OK;
+  if (pl->n == 0 && !pl->migrate) return GFSHIP_OK;
   if (pl->sort_every > 0 &&
       (pl->events_since_sort < 0 || pl->events_since_sort >= pl->sort_every)) {
     int r = gfship_particles_sort (pl);
@@ -560,14 +731,19 @@ int gfship_particle_list_event (gfship_particles * pl)
   A.alive = pl->alive;
   A.dt = v.dt;
   A.count = pl->d_count;
+  A.migrate = pl->migrate != nullptr;
   int block = 256, grid = (pl->n + block - 1)/block;
-  if (dom->dim == 3)
-    hipLaunchKernelGGL (particle_list_event_kernel<3>, dim3 (grid), dim3 (block), 0, dom->stream,
-			A, dom->depth);
-  else
-    hipLaunchKernelGGL (particle_list_event_kernel<2>, dim3 (grid), dim3 (block), 0, dom->stream,
-			A, dom->depth);
-  GFSHIP_HIP (hipGetLastError ());
+  if (pl->n > 0) {
+    if (dom->dim == 3)
+      hipLaunchKernelGGL (particle_list_event_kernel<3>, dim3 (grid), dim3 (block), 0, dom->stream,
+			  A, dom->depth);
+    else
+      hipLaunchKernelGGL (particle_list_event_kernel<2>, dim3 (grid), dim3 (block), 0, dom->stream,
+			  A, dom->depth);
+    GFSHIP_HIP (hipGetLastError ());
+  }
+  if (pl->migrate)
+    return particles_migrate (pl);
   return GFSHIP_OK;
 }
 
@@ -608,7 +784,7 @@ int gfship_particles_download (gfship_particles * pl, double * pos, unsigned * i
   int k = 0;
   for (size_t o = 0; o < m; o++) {
     size_t q = where[o];
-    if (al[q]) {
+    if (al[q] == 1) {
       pos[3*(size_t) k] = x[q]; pos[3*(size_t) k + 1] = y[q];
       pos[3*(size_t) k + 2] = dom->dim == 3 ? z[q] : 0.;
       id[k] = ids[q];

@@ -115,6 +115,8 @@ SIGNATURES = {
     "gfship_particles_destroy": (None, [_vp]),
     "gfship_particle_list_event": (_i, [_vp]),
     "gfship_particles_count": (_i, [_vp]),
+    "gfship_particles_set_migrate": (_i, [_vp, _vp, _vp]),
+    "gfship_particles_slots": (_i, [_vp]),
     "gfship_particles_sort": (_i, [_vp]),
     "gfship_particles_set_sort_interval": (_i, [_vp, _i]),
     "gfship_particles_download": (_i, [_vp, _pd, C.POINTER(C.c_uint)]),
@@ -432,8 +434,9 @@ class ParticleList:
         return _check(lib().gfship_particles_count(self.ptr))
 
     def download(self):
-        pos = np.empty((self.n0, 3))
-        ids = np.empty(self.n0, dtype=np.uint32)
+        m = max(_check(lib().gfship_particles_slots(self.ptr)), 1)
+        pos = np.empty((m, 3))
+        ids = np.empty(m, dtype=np.uint32)
         k = _check(lib().gfship_particles_download(self.ptr, pos.ctypes.data_as(_pd),
                                                    ids.ctypes.data_as(C.POINTER(C.c_uint))))
         return pos[:k].copy(), ids[:k].copy()

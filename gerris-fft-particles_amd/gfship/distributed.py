@@ -105,6 +105,29 @@ class Transport:
         for q in dist.batch_isend_irecv(ops):
             q.wait()
 
+    def exchange_records(self, out):
+        """out[s]: (n, 7) records leaving through my MPI side s; returns {r: records arriving
+        through my side r}.  Counts first, then the payloads, matched like the halo messages."""
+        t, dist = self.torch, self.dist
+        sides = sorted(out)
+        cnt_s = {s: t.tensor([len(out[s])], dtype=t.int64, device=self.device) for s in sides}
+        cnt_r = {s: t.zeros(1, dtype=t.int64, device=self.device) for s in sides}
+        self.exchange(sides, cnt_s, sides, cnt_r)
+        snd = {s: t.from_numpy(np.ascontiguousarray(out[s]).ravel()).to(self.device)
+               for s in sides if len(out[s])}
+        rcv = {r: t.empty(7 * int(cnt_r[r].item()), dtype=t.float64, device=self.device)
+               for r in sides if int(cnt_r[r].item())}
+        # every box knows which of its messages are empty on both ends: only the others are posted
+        ops = []
+        for s in sorted(snd):
+            ops.append(dist.P2POp(dist.isend, snd[s], self.grid.neighbour(self.rank, s), tag=100 + s))
+        for r in sorted(rcv, key=lambda x: x ^ 1):
+            ops.append(dist.P2POp(dist.irecv, rcv[r], self.grid.neighbour(self.rank, r), tag=100 + (r ^ 1)))
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+        return {r: rcv[r].cpu().numpy().reshape(-1, 7) for r in rcv}
+
     def allreduce(self, vals, op):
         t, dist = self.torch, self.dist
         x = t.tensor(vals, dtype=t.float64, device=self.device)
@@ -181,6 +204,48 @@ class DeviceHooks:
             a = np.ctypeslib.as_array(vals, shape=(n,))
             with self.tr.torch.cuda.stream(self.stream):
                 a[...] = self.tr.allreduce(a.copy(), op)
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+
+MIGRATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_double)),
+                         C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_double)))
+
+
+class ParticleMigration:
+    """Installs the migration hook of a gfship.ParticleList: the packets of particles that left
+    through the MPI sides go to the neighbour boxes, theirs come in
+    (modules/particulatecommon.c:3218-3312)."""
+
+    def __init__(self, plist, transport):
+        import gfship
+        self.pl, self.tr = plist, transport
+        self._fn = MIGRATE_FN(self._migrate)
+        self._keep = {}
+        gfship._check(gfship.lib().gfship_particles_set_migrate(plist.ptr, C.cast(self._fn, C.c_void_p),
+                                                              None))
+
+    def _migrate(self, ctx, nsend, send, nrecv, recv):
+        try:
+            out = {}
+            for d in self.tr.grid.external_sides():
+                n = nsend[d]
+                out[d] = (np.ctypeslib.as_array(send[d], shape=(n, 7)).copy() if n
+                          else np.empty((0, 7)))
+            inc = self.tr.exchange_records(out)
+            self._keep = {}
+            for d in range(6):
+                a = inc.get(d)
+                if a is None or len(a) == 0:
+                    nrecv[d] = 0
+                    continue
+                a = np.ascontiguousarray(a, dtype=np.float64)
+                self._keep[d] = a
+                nrecv[d] = len(a)
+                recv[d] = a.ctypes.data_as(C.POINTER(C.c_double))
             return 0
         except Exception:
             import traceback
@@ -282,6 +347,19 @@ class LocalTransport:
         if self.device.type == "cuda":
             self.torch.cuda.current_stream().synchronize()     # my copies are complete
         f.barrier.wait()
+
+    def exchange_records(self, out):
+        f = self.fabric
+        f.posted[self.rank] = out
+        f.barrier.wait()
+        inc = {}
+        for r in self.grid.external_sides():
+            peer = self.grid.neighbour(self.rank, r)
+            a = f.posted[peer].get(r ^ 1)
+            if a is not None and len(a):
+                inc[r] = np.array(a, copy=True)
+        f.barrier.wait()
+        return inc
 
     def allreduce(self, vals, op):
         f = self.fabric

@@ -240,6 +240,19 @@ int  gfship_particle_list_event (gfship_particles * pl);
    the slots by containing cell now / every `every` events (default 16, 0 = never) */
 int  gfship_particles_sort (gfship_particles * pl);
 int  gfship_particles_set_sort_interval (gfship_particles * pl, int every);
+/* particles crossing a GFSHIP_SIDE_EXTERNAL side go to the box across it (send_particles /
+   rcv_particles, modules/particulatecommon.c:3218-3312).  Without a hook they are dropped like at any
+   non-periodic side.  The hook is called once per event by every box: nsend[d] records leave
+   through side d (send[d]: 7 doubles each -- position, old position, id -- already in the
+   coordinates of the receiving box, sorted by id); it returns in nrecv[d] / recv[d] the records
+   that arrive through side d (host memory owned by the hook until its next call); they join the
+   list in side order */
+typedef int (* gfship_particle_migrate_fn) (void * ctx, const int nsend[6],
+					    const double * const send[6], int nrecv[6],
+					    const double * recv[6]);
+int  gfship_particles_set_migrate (gfship_particles * pl, gfship_particle_migrate_fn fn, void * ctx);
+/* slots in use (alive or not): upper bound of the count, size of the download buffers */
+int  gfship_particles_slots (gfship_particles * pl);
 int  gfship_particles_count (gfship_particles * pl);
 /* positions and ids of the particles still on the list, in list order; returns their number */
 int  gfship_particles_download (gfship_particles * pl, double * pos, unsigned * id);

@@ -217,7 +217,7 @@ static int boundary_direction (const GoDomain * dom, const double pos_old[3], co
 GoParticles * go_particles_new (int np, const double * pos, const unsigned * id)
 {
   GoParticles * pl = calloc (1, sizeof (GoParticles));
-  pl->n = np;
+  pl->n = pl->cap = np;
   pl->pos = malloc (3*(size_t) np*sizeof (double));
   pl->pos_old = malloc (3*(size_t) np*sizeof (double));
   pl->id = malloc ((size_t) np*sizeof (unsigned));
@@ -231,7 +231,37 @@ void go_particles_destroy (GoParticles * pl)
 {
   if (!pl) return;
   free (pl->pos); free (pl->pos_old); free (pl->id);
+  for (int d = 0; d < 6; d++) free (pl->out[d]);
   free (pl);
+}
+
+/* the packet of particles sent through side d (7 doubles per particle) */
+int go_particles_outbox (GoParticles * pl, int d, double ** rec)
+{
+  *rec = pl->out[d];
+  return pl->nout[d];
+}
+
+void go_particles_clear_outbox (GoParticles * pl)
+{
+  for (int d = 0; d < 6; d++) pl->nout[d] = 0;
+}
+
+/* mpi_rcv_particle, particulatecommon.c:3224-3245: the received particles join the list */
+void go_particles_append (GoParticles * pl, int n, const double * rec)
+{
+  if (pl->n + n > pl->cap) {
+    pl->cap = 2*(pl->n + n);
+    pl->pos = realloc (pl->pos, 3*(size_t) pl->cap*sizeof (double));
+    pl->pos_old = realloc (pl->pos_old, 3*(size_t) pl->cap*sizeof (double));
+    pl->id = realloc (pl->id, (size_t) pl->cap*sizeof (unsigned));
+  }
+  for (int q = 0; q < n; q++) {
+    memcpy (pl->pos + 3*(pl->n + q), rec + 7*q, 3*sizeof (double));
+    memcpy (pl->pos_old + 3*(pl->n + q), rec + 7*q + 3, 3*sizeof (double));
+    pl->id[pl->n + q] = (unsigned) rec[7*q + 6];
+  }
+  pl->n += n;
 }
 
 int go_particles_count (const GoParticles * pl) { return pl->n; }
@@ -276,7 +306,20 @@ void go_particle_list_event (GoSim * s, GoParticles * pl)
     if (go_locate (dom, p, cell))
       continue;
     int d = boundary_direction (dom, po, p);
-    if (dom->side[d] != GO_SIDE_PERIODIC)
+    if (dom->side[d] == GO_SIDE_EXTERNAL) {
+      /* GfsBoundaryMpi: the particle object is sent to the process across the side
+	 (send_particles :3247-3268); its position is the same point of space, i.e. one box size
+	 less along the normal in the coordinates of the receiving box */
+      double normal = (double) (d ^ 1) - (double) d;
+      pl->out[d] = realloc (pl->out[d], 7*(size_t) (pl->nout[d] + 1)*sizeof (double));
+      double * r = pl->out[d] + 7*(size_t) pl->nout[d]++;
+      for (int c = 0; c < 3; c++) { r[c] = p[c]; r[3 + c] = po[c]; }
+      r[d/2] -= normal*1.;
+      r[3 + d/2] -= normal*1.;
+      r[6] = (double) pl->id[q];
+      drop[q] = 1;
+    }
+    else if (dom->side[d] != GO_SIDE_PERIODIC)
       drop[q] = 1;
     else {
       /* periodic_bc_particle: box of size 1 centred on the origin, matching box = itself */

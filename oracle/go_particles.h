@@ -4,9 +4,14 @@
 #include "go_sim.h"
 
 typedef struct {
-  int n;
+  int n, cap;
   double * pos, * pos_old;   /* 3 doubles per particle (z = 0 in 2-D) */
   unsigned * id;
+  /* particles that left through a GfsBoundaryMpi side d, as sent to the neighbour
+     (mpi_send_particle, particulatecommon.c:3218-3222): 7 doubles each (pos, pos_old, id) in
+     the neighbour's coordinates */
+  int nout[6];
+  double * out[6];
 } GoParticles;
 
 int    go_locate (const GoDomain * dom, const double target[3], int ijk[3]);
@@ -15,6 +20,9 @@ void   go_advect_point (GoSim * s, double p[3], double dt);
 GoParticles * go_particles_new (int np, const double * pos, const unsigned * id);
 void   go_particles_destroy (GoParticles * pl);
 int    go_particles_count (const GoParticles * pl);
+int    go_particles_outbox (GoParticles * pl, int d, double ** rec);
+void   go_particles_clear_outbox (GoParticles * pl);
+void   go_particles_append (GoParticles * pl, int n, const double * rec);
 double * go_particles_pos (GoParticles * pl);
 unsigned * go_particles_id (GoParticles * pl);
 void   go_particle_list_event (GoSim * s, GoParticles * pl);

@@ -327,6 +327,9 @@ class Particles:
                 "go_particles_id": (pu, [vp]),
                 "go_particle_list_event": (None, [vp, vp]),
                 "go_locate": (i, [vp, pd, C.POINTER(C.c_int)]),
+                "go_particles_outbox": (i, [vp, i, C.POINTER(pd)]),
+                "go_particles_clear_outbox": (None, [vp]),
+                "go_particles_append": (None, [vp, i, pd]),
             }.items():
                 f = getattr(L, name)
                 f.restype, f.argtypes = res, args
@@ -342,6 +345,22 @@ class Particles:
 
     def count(self):
         return lib().go_particles_count(self.ptr)
+
+    def outbox(self, d):
+        """records (n x 7: pos, pos_old, id) of the particles sent through MPI side d"""
+        rec = C.POINTER(C.c_double)()
+        n = lib().go_particles_outbox(self.ptr, d, C.byref(rec))
+        if n == 0:
+            return np.empty((0, 7))
+        return np.ctypeslib.as_array(rec, shape=(n, 7)).copy()
+
+    def clear_outbox(self):
+        lib().go_particles_clear_outbox(self.ptr)
+
+    def append(self, rec):
+        rec = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, 7)
+        if len(rec):
+            lib().go_particles_append(self.ptr, len(rec), rec.ctypes.data_as(C.POINTER(C.c_double)))
 
     def state(self):
         n = self.count()

@@ -28,11 +28,28 @@ def main():
     # every box holds one period of the Taylor-Green field: the global field is continuous
     x, y, z = sim.dom.centres()
     for c, a in enumerate(taylor_green_3d(x, y, z)):
-        sim.u[c].interior()[...] = a
+        sim.u[c].interior()[...] = a + (1. if c == 0 else 0.)    # + a uniform flow through the MPI sides
+    # tracers: every box starts with the same set; what leaves through an MPI side goes to the
+    # neighbour box (the same transport moves the packets)
+    from particle_cases import lcg_positions
+    pos, ids = lcg_positions(600)
+    pos[:40, 0] = 0.5 - 1e-3 * (1 + np.arange(40))       # some right at the +x MPI side
+    pl = O.Particles(sim, pos, ids)
+    counts, moved = [], 0
     sim.start()
     for _ in range(nsteps):
+        pl.event()                                        # events first (simulation.c:483)
+        packets = {d: pl.outbox(d) for d in grid.external_sides()}
+        moved += sum(len(a) for a in packets.values())
+        pl.clear_outbox()
+        inc = tr.exchange_records(packets)
+        for d in sorted(inc):
+            pl.append(inc[d])
+        counts.append(pl.count())
         sim.step()
+    ppos, pid = pl.state()
     np.savez(os.path.join(out, "rank%d.npz" % rank),
+             ppos=ppos, pid=pid, counts=np.array(counts), moved=moved,
              u=sim.u[0].interior(), v=sim.u[1].interior(), w=sim.u[2].interior(),
              p=sim.p.interior(), dt=sim.dt, t=sim.t,
              niter=sim.approx_projection_params.niter,

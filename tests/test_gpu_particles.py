@@ -89,3 +89,114 @@ def test_tracers_closed_box_drop_list_identical(sort_every):
         gp, gi = gpl.download()
         assert np.array_equal(oi, gi) and np.array_equal(op, gp), k
     assert 0 < gpl.count() < 2000     # some particles left through the +x side and were dropped
+
+
+class _MirrorTransport:
+    """One box of a 2 x 1 x 1 lattice whose other box is its mirror image (same fields, same
+    particles): what the neighbour sends is what this box sends.  Drives the ORACLE as the
+    reference of the two-box device run below."""
+
+    def __init__(self, grid):
+        import torch
+        self.torch, self.grid, self.rank = torch, grid, 0
+        self.device = torch.device("cpu")
+        self._bufs = {}
+
+    def buffers(self, key, nface):
+        from gfship import distributed as D
+        return D.Transport.buffers(self, key, nface)
+
+    def exchange(self, send_sides, snd, recv_sides, rcv):
+        for r in recv_sides:
+            rcv[r].copy_(snd[r ^ 1])
+
+    def allreduce(self, vals, op):
+        a = np.array(vals, dtype=np.float64)
+        return a + a if op == 0 else a
+
+    def exchange_records(self, out):
+        return {r: out[r ^ 1] for r in out if len(out[r ^ 1])}
+
+
+def test_particles_migrate_between_two_boxes_on_one_gpu():
+    """particles leaving through a GfsBoundaryMpi side are packed on the device, handed to the
+    migration hook and join the neighbour's list (modules/particulatecommon.c:3218-3312): two device
+    boxes in one process against the oracle run of one box of the same lattice"""
+    import threading
+    import torch
+    from gfship import distributed as D
+    level, nsteps, npart = 5, 4, 3000
+    grid = D.BoxGrid(2, 3)
+    pos, ids = lcg_positions(npart)
+    pos[:200, 0] = 0.5 - 2e-4 * (1 + np.arange(200))          # a crowd next to the +x MPI side
+    pos[200:300, 0] = -0.5 + 2e-4 * (1 + np.arange(100))
+
+    def init(sim_u, x, y, z):
+        from flow_cases import taylor_green_3d
+        for c, a in enumerate(taylor_green_3d(x, y, z)):
+            sim_u[c][...] = a + (0.7 if c == 0 else 0.)          # through-flow along x
+
+    # oracle reference: one box + its mirror image
+    osim = O.Sim(3, level, grid.sides(0))
+    mt = _MirrorTransport(grid)
+    ohooks = D.OracleHooks(O.lib(), osim.dom.ptr, 3, mt)
+    init([osim.u[c].interior() for c in range(3)], *osim.dom.centres())
+    opl = O.Particles(osim, pos, ids)
+    osim.start()
+    ostates, moved = [], 0
+    for _ in range(nsteps):
+        opl.event()
+        out = {d: opl.outbox(d) for d in grid.external_sides()}
+        moved += sum(len(a) for a in out.values())
+        opl.clear_outbox()
+        for d, a in sorted(mt.exchange_records(out).items()):
+            opl.append(a)
+        ostates.append(opl.state())
+        osim.step()
+    assert moved > 50
+
+    fabric = D.LocalFabric(2)
+    dev = torch.device("cuda", 0)
+    results, errors = [None, None], []
+    u0 = [osim.dom.field() for _ in range(3)]
+    init([f.interior() for f in u0], *osim.dom.centres())
+
+    def worker(rank):
+        try:
+            gd = gfship.Domain(3, level, grid.sides(rank))
+            gs = gfship.Simulation(gd)
+            tr = D.LocalTransport(grid, rank, fabric, dev)
+            hooks = D.DeviceHooks(gd, tr)
+            for c in range(3):
+                gs.u[c].upload(u0[c].leaf())
+            gpl = gfship.ParticleList(gs, pos, ids)
+            gpl.set_sort_interval(2)
+            mig = D.ParticleMigration(gpl, tr)
+            gs.start()
+            states = []
+            for _ in range(nsteps):
+                gpl.event()
+                states.append(gpl.download() + (gpl.count(),))
+                gs.step()
+            gd.synchronize()
+            results[rank] = (states, gd, gs, hooks, mig, gpl)
+        except Exception as e:       # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            errors.append(e)
+            fabric.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=180)
+    assert not errors, errors
+    for rank in range(2):
+        for k, (gp, gi, cnt) in enumerate(results[rank][0]):
+            op, oi = ostates[k]
+            assert cnt == len(oi) == len(gi), (rank, k)
+            a, b = np.argsort(gi, kind="stable"), np.argsort(oi, kind="stable")
+            assert np.array_equal(gi[a], oi[b]), (rank, k)
+            assert np.array_equal(gp[a], op[b]), (rank, k, np.abs(gp[a] - op[b]).max())
+    del ohooks
