@@ -97,6 +97,7 @@ struct gfship_domain {
   double * cfl_partial = nullptr;   // per-block max |un|, |u| of the fused projection update
   size_t cfl_nblocks = 0, cfl_used = 0;
   bool cfl_dirty = false;
+  bool coarse_attr_set = false;   // dynamic-LDS limit of coarse_cycle_kernel raised
   gfship_field res_cache = -1;    // the `res` temporary of gfs_diffusion
   bool diff_ready = false;        // gfship_diffusion_coefficients called
 };
@@ -127,6 +128,9 @@ int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, doub
 int launch_relax_loop_small (gfship_domain * dom, unsigned dimension, int level, double omega,
 			     Field * dp, Field * ubc, const double * rhs, const double * dia,
 			     unsigned nrelax, bool * done, const RelaxOp * op = nullptr);
+int coarse_cycle_top (gfship_domain * dom, int minlevel);
+int launch_coarse_cycle (gfship_domain * dom, unsigned dimension, double omega, int lmin, int ltop,
+			 const unsigned * nrelax, Field * dp, Field * ubc, Field * res, Field * dia);
 int launch_relax_redblack (gfship_domain * dom, unsigned dimension, int level, double omega,
 			   double * u, const double * rhs, const double * dia);
 int launch_residual (gfship_domain * dom, int level, const double * u, const double * rhs,

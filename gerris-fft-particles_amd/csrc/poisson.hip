@@ -206,26 +206,40 @@ int gfship_poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
 #define TRY(x) do { if ((r = (x)) != GFSHIP_OK) goto done; } while (0)
   for (int l = 0; l <= L; l++)
     S->zero[l] = U->zero[l] = false;
-  /* compute residual on non-leafs cells (get_from_below, post-order: finest parents first) */
-  for (int l = L - 1; l >= 0; l--)
-    TRY (launch_restrict (dom, p->dimension, l, S->lev[l], S->lev[l + 1]));
-
   {
-    /* relax top level */
-    unsigned nrelax = p->nrelax;
-    for (unsigned l = minlevel; l < p->depth; l++)
-      nrelax *= p->erelax;
+    /* relaxations per level (nrelax at the leaves, times erelax per level above) */
+    unsigned nrl[GFSHIP_MAXLEVEL + 1];
+    {
+      unsigned nr = p->nrelax;
+      for (int l = L; l >= 0; l--) {
+	nrl[l] = nr;
+	if (l > (int) minlevel) nr *= p->erelax;
+      }
+    }
     for (int l = 0; l <= L; l++)
       DP->zero[l] = false;
-    TRY (launch_fill (dom, minlevel, DP->lev[minlevel], 0.));
-    TRY (relax_loop (dom, DP, U, p->dimension, minlevel, p->omega, S, D, nrelax));
-    nrelax /= p->erelax;
-
+    /* the coarse end of the cycle (restrictions, relax loops and prolongations of the levels that
+       fit in LDS together) in one launch where that applies */
+    const int ctop = coarse_cycle_top (dom, (int) minlevel);
+    /* compute residual on non-leafs cells (get_from_below, post-order: finest parents first) */
+    for (int l = L - 1; l >= (ctop >= 0 ? ctop + 1 : 0); l--)
+      TRY (launch_restrict (dom, p->dimension, l, S->lev[l], S->lev[l + 1]));
+    unsigned first = minlevel;
+    if (ctop >= 0) {
+      TRY (launch_coarse_cycle (dom, p->dimension, p->omega, (int) minlevel, ctop, nrl, DP, U, S, D));
+      first = ctop + 1;
+    }
+    else {
+      /* relax top level */
+      TRY (launch_fill (dom, minlevel, DP->lev[minlevel], 0.));
+      TRY (relax_loop (dom, DP, U, p->dimension, minlevel, p->omega, S, D, nrl[minlevel]));
+      first = minlevel + 1;
+    }
     /* relax from top to bottom */
-    for (unsigned l = minlevel + 1; l <= p->depth; l++, nrelax /= p->erelax) {
+    for (unsigned l = first; l <= p->depth; l++) {
       /* get initial guess from coarser grid */
       TRY (launch_prolongate (dom, l - 1, DP->lev[l - 1], DP->lev[l]));
-      TRY (relax_loop (dom, DP, U, p->dimension, l, p->omega, S, D, nrelax));
+      TRY (relax_loop (dom, DP, U, p->dimension, l, p->omega, S, D, nrl[l]));
     }
   }
   /* correct on leaf cells, then BC on u (gfs_traverse_and_bc ... correct, u, u) */

@@ -240,6 +240,227 @@ int launch_relax_loop_small (gfship_domain * dom, unsigned dimension, int level,
 }
 
 // ---------------------------------------------------------------------------------------------
+// The coarse end of a V-cycle in one launch (one workgroup, everything in LDS): the levels
+// lmin .. ltop whose relax loops would otherwise be one launch each plus their restrictions,
+// prolongations, fills and BC kernels (src/poisson.c:1131-1168):
+//   res[l] = get_from_below (res[l+1])            l = ltop .. lmin   (res[ltop+1] from global)
+//   dp[lmin] = 0 ; relax_loop (dp, lmin)
+//   dp[l] = get_from_above (dp[l-1]) ; relax_loop (dp, l)             l = lmin+1 .. ltop
+// Results: dp[ltop] with its ghost layer (what the prolongation to ltop+1 reads) and the
+// restricted residuals, written to global memory in the natural layout.  Same arithmetic and
+// same order per cell as the per-level kernels (relax_loop_lds_kernel, restrict_kernel,
+// prolongate_kernel).
+// ---------------------------------------------------------------------------------------------
+struct CoarseCycleArgs {
+  Layout lay[GFSHIP_MAXLEVEL + 1];
+  int lmin, ltop;
+  unsigned nrelax[GFSHIP_MAXLEVEL + 1];
+  double * dp[GFSHIP_MAXLEVEL + 1];          // natural, all levels lmin..ltop are written
+  double * res[GFSHIP_MAXLEVEL + 2];         // natural; res[ltop + 1] is the input
+  const double * dia[GFSHIP_MAXLEVEL + 1];   // nullptr: dia == 0 on that level
+  BcDesc bc;
+  unsigned dimension;
+  double omega;
+};
+
+template <int DIM>
+__global__ void __launch_bounds__(1024)
+coarse_cycle_kernel (CoarseCycleArgs A)
+{
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // LDS map: per level a dp array and a res array of (n+2)^DIM doubles
+  double * sdp[GFSHIP_MAXLEVEL + 1], * sres[GFSHIP_MAXLEVEL + 1];
+  {
+    size_t o = 0;
+    for (int l = A.lmin; l <= A.ltop; l++) {
+      size_t r = A.lay[l].n + 2, m = DIM == 3 ? r*r*r : r*r;
+      sdp[l] = lds + o; o += m;
+      sres[l] = lds + o; o += m;
+    }
+    for (size_t q = tid; q < o; q += nt)
+      lds[q] = 0.;
+  }
+  __syncthreads ();
+  // ---- restrictions, finest first ----
+  for (int l = A.ltop; l >= A.lmin; l--) {
+    const Layout & Lc = A.lay[l], & Lf = A.lay[l + 1];
+    const int n = Lc.n, r = n + 2, rf = 2*n + 2;
+    const int ncell = DIM == 3 ? n*n*n : n*n;
+    for (int q = tid; q < ncell; q += nt) {
+      int i = q % n + 1, j = (q / n) % n + 1, k = DIM == 3 ? q / (n*n) + 1 : 0;
+      double val = 0.;
+#pragma unroll
+      for (int id = 0; id < (1 << DIM); id++) {
+	int ci = 2*i - 1 + (id & 1);
+	int cj = 2*j - 1 + ((id & 2) ? 0 : 1);
+	int ck = DIM == 3 ? 2*k - 1 + ((id & 4) ? 0 : 1) : 0;
+	val += l == A.ltop ? A.res[l + 1][Lf.idx (ci, cj, ck)]
+	  : sres[l + 1][ci + rf*(cj + (DIM == 3 ? rf*ck : 0))];
+      }
+      double v = A.dimension == 2 ? val : val/2.;
+      sres[l][i + r*(j + (DIM == 3 ? r*k : 0))] = v;
+      A.res[l][Lc.idx (i, j, k)] = v;
+    }
+    __syncthreads ();
+  }
+  // ---- relax loops from the coarsest level up ----
+  for (int l = A.lmin; l <= A.ltop; l++) {
+    const Layout & L = A.lay[l];
+    const int n = L.n, r = n + 2;
+    const long ssy = r, ssz = DIM == 3 ? (long) r*r : 0;
+    const int ncell = DIM == 3 ? n*n*n : n*n;
+    const int nface = DIM == 3 ? n*n : n;
+    double * s = sdp[l];
+    if (l > A.lmin) {
+      // get_from_above, src/poisson.c:1005-1042 (prolongate_kernel), one thread per fine cell
+      const int nc = n/2, rc = nc + 2;
+      const long cy = rc, cz = DIM == 3 ? (long) rc*rc : 0;
+      const double * vc = sdp[l - 1];
+      for (int q = tid; q < ncell; q += nt) {
+	int i = q % n + 1, j = (q / n) % n + 1, k = DIM == 3 ? q / (n*n) + 1 : 0;
+	int pi = (i + 1)/2, pj = (j + 1)/2, pk = DIM == 3 ? (k + 1)/2 : 0;
+	long p = pi + cy*pj + cz*pk;
+	double pv = vc[p];
+	double h[3];
+	const long off[3] = { 1, cy, cz };
+#pragma unroll
+	for (int cc = 0; cc < DIM; cc++) {
+	  double g1 = vc[p + off[cc]] - 1.*pv;
+	  double g2 = vc[p - off[cc]] - 1.*pv;
+	  h[cc] = (g1 - g2)/2.;
+	}
+	double rel[3] = { ((i & 1) ? -1. : 1.)/4., ((j & 1) ? -1. : 1.)/4., ((k & 1) ? -1. : 1.)/4. };
+	double val = pv;
+#pragma unroll
+	for (int cc = 0; cc < DIM; cc++)
+	  val += rel[cc]*h[cc];
+	s[i + ssy*j + ssz*k] = val;
+      }
+      __syncthreads ();
+    }
+    const double * rhs = sres[l];
+    const double * dia = A.dia[l];
+    for (unsigned sweep = 0; sweep < A.nrelax[l]; sweep++) {
+      for (int q = tid; q < 2*DIM*nface; q += nt) {
+	int d = q / nface, f = q % nface;
+	int c = d/2;
+	int t1 = f % n + 1, t2 = DIM == 3 ? f / n + 1 : 0;
+	int ijk[3] = { 0, 0, 0 };
+	int ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
+	ijk[c] = (d & 1) ? 1 : n;
+	ijk[ta] = t1;
+	if (DIM == 3) ijk[tb] = t2;
+	long o = c == 0 ? 1 : c == 1 ? ssy : ssz;
+	if (d & 1) o = - o;
+	long nb = ijk[0] + ssy*ijk[1] + ssz*ijk[2];
+	double v;
+	if (A.bc.side[d] == GFSHIP_SIDE_PERIODIC)
+	  v = s[nb - (long) (n - 1)*o];
+	else
+	  v = ghost_value (A.bc.type[d], A.bc.component, c, s[nb], 1, 0., 0.);
+	s[nb + o] = v;
+      }
+      __syncthreads ();
+      const int nplanes = DIM == 3 ? 3*n - 2 : 2*n - 1;
+      for (int plane = 0; plane < nplanes; plane++) {
+	for (int t = tid; t < nface; t += nt) {
+	  int J = t % n, K = DIM == 3 ? t / n : 0;
+	  int I = plane - J - K;
+	  if (I >= 0 && I < n) {
+	    int i = I + 1, j = n - J, k = DIM == 3 ? n - K : 0;
+	    long c = i + ssy*j + ssz*k;
+	    double dv = dia ? dia[L.idx (i, j, k)] : 0.;
+	    s[c] = relax_value<DIM, 0> (s, c, ssy, ssz, rhs[c], dv, A.dimension, A.omega, 1., 1.);
+	  }
+	}
+	__syncthreads ();
+      }
+    }
+    // natural copy with the ghost layer of the last BC application
+    const int nall = DIM == 3 ? r*r*r : r*r;
+    for (int q = tid; q < nall; q += nt) {
+      int i = q % r, j = (q / r) % r, k = DIM == 3 ? q / (r*r) : 0;
+      A.dp[l][L.idx (i, j, k)] = s[q];
+    }
+    __syncthreads ();
+  }
+}
+
+// highest level of the coarse end that fits (0 .. ltop in LDS); -1 when it does not apply
+int coarse_cycle_top (gfship_domain * dom, int minlevel)
+{
+  for (int d = 0; d < 2*dom->dim; d++)
+    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL)
+      return -1;      /* halos need the exchange between sweeps */
+  if (dom->relax_mode != GFSHIP_RELAX_EXACT || dom->force_hyperplane || dom->no_fused_loop)
+    return -1;
+  int top = -1;
+  size_t bytes = 0;
+  for (int l = minlevel; l < dom->depth; l++) {     /* the leaf level is never part of it */
+    if (dom->dim == 3 && skew_supported (dom, l)) break;
+    size_t r = dom->lay[l].n + 2;
+    bytes += 2*(dom->dim == 3 ? r*r*r : r*r)*sizeof (double);
+    if (bytes > 150*1024) break;
+    top = l;
+  }
+  return top > minlevel ? top : -1;   /* a single level: the plain LDS loop does it */
+}
+
+int launch_coarse_cycle (gfship_domain * dom, unsigned dimension, double omega, int lmin, int ltop,
+			 const unsigned * nrelax, Field * dp, Field * ubc, Field * res, Field * dia)
+{
+  CoarseCycleArgs A;
+  size_t bytes = 0;
+  for (int l = 0; l <= GFSHIP_MAXLEVEL; l++) {
+    A.lay[l] = dom->lay[l <= dom->depth ? l : dom->depth];
+    A.nrelax[l] = 0; A.dp[l] = nullptr; A.res[l] = nullptr; A.dia[l] = nullptr;
+  }
+  A.res[GFSHIP_MAXLEVEL + 1] = nullptr;
+  for (int l = lmin; l <= ltop; l++) {
+    size_t r = dom->lay[l].n + 2;
+    bytes += 2*(dom->dim == 3 ? r*r*r : r*r)*sizeof (double);
+    A.nrelax[l] = nrelax[l];
+    A.dp[l] = dp->lev[l];
+    A.res[l] = res->lev[l];
+    A.dia[l] = dia->zero[l] ? nullptr : dia->lev[l];
+    dp->zero[l] = false;
+    res->zero[l] = false;
+  }
+  A.res[ltop + 1] = res->lev[ltop + 1];
+  A.lmin = lmin; A.ltop = ltop;
+  for (int d = 0; d < 6; d++) {
+    A.bc.side[d] = dom->side[d];
+    A.bc.type[d] = ubc->bc[d];
+    A.bc.val[d] = nullptr;
+  }
+  A.bc.component = ubc->component;
+  A.bc.homogeneous = 1;
+  A.dimension = dimension;
+  A.omega = omega;
+  if (dom->dim == 3) {
+    if (!dom->coarse_attr_set) {
+      GFSHIP_HIP (hipFuncSetAttribute ((const void *) coarse_cycle_kernel<3>,
+				       hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
+      GFSHIP_HIP (hipFuncSetAttribute ((const void *) coarse_cycle_kernel<2>,
+				       hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
+      dom->coarse_attr_set = true;
+    }
+    hipLaunchKernelGGL (coarse_cycle_kernel<3>, dim3 (1), dim3 (1024), bytes, dom->stream, A);
+  }
+  else {
+    if (!dom->coarse_attr_set) {
+      GFSHIP_HIP (hipFuncSetAttribute ((const void *) coarse_cycle_kernel<2>,
+				       hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
+      dom->coarse_attr_set = true;
+    }
+    hipLaunchKernelGGL (coarse_cycle_kernel<2>, dim3 (1), dim3 (1024), bytes, dom->stream, A);
+  }
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Red-black Gauss-Seidel of the same operator (opt-in, not a reference algorithm): two colour
 // passes, each cell updated from the current values of its six neighbours.
 // ---------------------------------------------------------------------------------------------
