@@ -456,6 +456,32 @@ int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * 
   if ((r = skew_plan (dom, level, &S))) return r;
   double * u = dp->lev[level];
   if (bc && (r = launch_bc (dom, ubc, dp, level, 1))) return r;
+  if (!dom->no_fused_loop && !S->loop_checked && skew_loop_supported (dom, level, nrelax, bc)) {
+    /* Once per level: a trial run of the fused loop on zeros.  Its tiles wait on each other, so
+       all of them must really be resident at the same time; the occupancy query says they are,
+       but if the device does not deliver (CUs in use by someone else ...) the bounded waits
+       time out and report it -- then this domain keeps to one launch per sweep. */
+    S->loop_checked = true;
+    const Layout & L = dom->lay[level];
+    size_t doubles = (size_t) S->ntj*S->ntj*(S->RT + 2*SK_FP)*SK_NL;
+    double * zero_nat = nullptr;
+    GFSHIP_HIP (hipMalloc ((void **) &zero_nat, L.total*sizeof (double)));
+    GFSHIP_HIP (hipMemsetAsync (zero_nat, 0, L.total*sizeof (double), dom->stream));
+    GFSHIP_HIP (hipMemsetAsync (S->us, 0, doubles*sizeof (double), dom->stream));
+    GFSHIP_HIP (hipMemsetAsync (S->rs, 0, doubles*sizeof (double), dom->stream));
+    r = skew_loop_run (dom, level, S, zero_nat, false, 2);
+    unsigned e[2] = { 0, 0 };
+    if (r == GFSHIP_OK) {
+      GFSHIP_HIP (hipMemcpyAsync (e, S->ctl, sizeof (e), hipMemcpyDeviceToHost, dom->stream));
+      GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+    }
+    (void) hipFree (zero_nat);
+    if (r != GFSHIP_OK) return r;
+    if (e[1]) {
+      dom->no_fused_loop = true;
+      GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, 2*sizeof (unsigned), dom->stream));
+    }
+  }
   if ((r = skew_pack (dom, level, S, u, rhs, dia_zero ? nullptr : dia))) return r;
   if (!dom->no_fused_loop && skew_loop_supported (dom, level, nrelax, bc)) {
     /* the sweeps of the loop pipelined in one launch (relax_skew_loop.hip) */

@@ -35,6 +35,9 @@
 #include <vector>
 
 #define SK_MAXF 8    /* sweeps per launch */
+#ifndef SK_POLL_SLEEP
+#define SK_POLL_SLEEP 2   /* s_sleep argument between two polls of a hand-off granule */
+#endif
 #ifndef SK_KO
 #define SK_KO 0      /* timing experiments only: knock out parts of the step (wrong results) */
 #endif
@@ -216,7 +219,7 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 	  unsigned spins = 0;						\
 	  _Pragma ("nounroll")						\
 	  while (__any (w)) {						\
-	    __builtin_amdgcn_s_sleep (2);				\
+	    __builtin_amdgcn_s_sleep (SK_POLL_SLEEP);			\
 	    if (w) {							\
 	      hv = __longlong_as_double ((long long) load_sc1 (qH0 + (long) (t_)*hs)); \
 	      w = (u64) __double_as_longlong (hv) == SK_SENTINEL;	\
