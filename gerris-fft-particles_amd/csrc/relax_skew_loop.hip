@@ -60,10 +60,17 @@ struct SkewLoopArgs {
   u64 * stats;             // optional [tile][sweep]{start, end} (debug, GFSHIP_SKEW_STATS)
 };
 
-// Workgroup = 4 compute waves (256 lines) + 1 halo wave: the halo wave streams the four halo
-// strips into LDS (and polls the granules that are not there yet), so that the compute waves,
-// which all wait for the slowest of them at the barrier of every step, carry no halo code.
-#define SK_NTHREADS (SK_NL + 64)
+// Workgroup = 4 compute waves (256 lines) + 1 halo wave + 1 store wave.  The halo wave streams
+// the four halo strips into LDS (and polls the granules that are not there yet); the store wave
+// reads the new values of the four outgoing lines (a = 15, b = 15: hand-off; a = 0, b = 0:
+// snapshot) from LDS one step after they were computed and writes the granules.  The compute
+// waves, which all wait for the slowest of them at the barrier of every step, carry neither halo
+// code nor agent-scope stores: those complete late, and since loads and stores share the in-order
+// vmcnt counter they would hold back the prefetched loads behind them (tools/lab/step_lab.hip:
+// two predicated sc1 stores cost a compute wave 0.09 us of a 0.15 us step).  (Moving the streaming
+// loads and the row stores into further waves as well was tried and lost: the hops between tiles
+// became slower and the step no faster.)
+#define SK_NTHREADS (SK_NL + 128)
 
 template <bool HAS_DIA>
 __global__ void __launch_bounds__(SK_NTHREADS)
@@ -75,7 +82,8 @@ relax_skew_loop_kernel (SkewLoopArgs A)
   __shared__ unsigned s_tile;
 
   const int tid0 = threadIdx.x;
-  const bool compute = __builtin_amdgcn_readfirstlane (tid0 >> 6) < SK_NL/64;   // wave-uniform
+  const int wave = __builtin_amdgcn_readfirstlane (tid0 >> 6);                   // wave-uniform
+  const bool compute = wave < SK_NL/64;
   const int tid = tid0 & (SK_NL - 1);      // line of a compute lane; lane index of the halo wave
   const int a = tid & (SK_T - 1), b = tid >> 4;
   const int n = A.L.n;
@@ -95,7 +103,7 @@ relax_skew_loop_kernel (SkewLoopArgs A)
   const int tKm = P + ntj*(Q > 0 ? Q - 1 : ntj - 1), tKp = P + ntj*(Q + 1 < ntj ? Q + 1 : 0);
 
   double * const ut = A.us + tile*tstride + SK_FP*SK_NL;
-  const bool loader = !compute;
+  const bool loader = wave == SK_NL/64, storer = wave == SK_NL/64 + 1;
   const int g = (tid >> 4) & 3, m = tid & 15;
   const int jm = n - (SK_T*P + m), km = n - (SK_T*Q + m);
   bool failed = false;
@@ -166,33 +174,28 @@ relax_skew_loop_kernel (SkewLoopArgs A)
     // strips 0/1 feed lines (0,m)/(m,0) (I = t - m), strips 2/3 feed lines (15,m)/(m,15)
     const int hlag = g < 2 ? m : m + SK_T - 1;
 
-    // store pointers.  Besides its own row a lane writes at most two granule streams: the
-    // hand-off of line a = 15 / b = 15 to the next tile (also to the periodic image tile when
-    // another sweep follows) and the snapshot of line a = 0 / b = 0 for the next sweep.  The roles
-    // of a lane do not change during the sweep, so they are folded into two (pointer, flag)
-    // slots: two predicated stores per step instead of a tree of branches.
+    // own row of the skewed copy (compute waves)
     double * wU = ut + tid;
-    u64 * p1 = nullptr, * p2 = nullptr;
-    {
-      const bool hasJ = a == SK_T - 1 && (P + 1 < ntj || more);
-      const bool hasK = b == SK_T - 1 && (Q + 1 < ntj || more);
-      const bool snapJ = more && a == 0, snapK = more && b == 0;
-      u64 * const cand[4] = {
-	hbJ + (long) tile*hstride + b - (long) (SK_T - 1)*SK_T,     // row t - 15
-	hbK + (long) tile*hstride + a - (long) (SK_T - 1)*SK_T,
-	snJ + (long) tile*hstride + b + (long) (SK_T - 1)*SK_T,     // row t + 15
-	snK + (long) tile*hstride + a + (long) (SK_T - 1)*SK_T };
-      const bool has[4] = { hasJ, hasK, snapJ, snapK };
-#pragma unroll
-      for (int c = 0; c < 4; c++)
-	if (has[c]) {
-	  if (!p1) p1 = cand[c];
-	  else p2 = cand[c];
-	}
+    // store wave: lane (g, m) owns one outgoing line
+    //   g = 0  line (15, m)  hand-off to tile (P+1, Q), also its periodic image when a sweep follows
+    //   g = 1  line (m, 15)  hand-off to tile (P, Q+1)
+    //   g = 2  line (0, m)   snapshot for the next sweep of tile (P-1, Q)
+    //   g = 3  line (m, 0)   snapshot for the next sweep of tile (P, Q-1)
+    u64 * pS = (u64 *) A.dummy;
+    bool sOn = false;
+    int sX = 0, sLag = 0;       // LDS index of the line's new value; skew a + b of the line
+    if (storer) {
+      switch (g) {
+      case 0: sOn = P + 1 < ntj || more; pS = hbJ + (long) tile*hstride + m - (long) (SK_T - 1)*SK_T;
+	sX = SK_T + XS*(m + 1); sLag = SK_T - 1 + m; break;
+      case 1: sOn = Q + 1 < ntj || more; pS = hbK + (long) tile*hstride + m - (long) (SK_T - 1)*SK_T;
+	sX = (m + 1) + XS*SK_T; sLag = SK_T - 1 + m; break;
+      case 2: sOn = more; pS = snJ + (long) tile*hstride + m + (long) (SK_T - 1)*SK_T;
+	sX = 1 + XS*(m + 1); sLag = m; break;
+      default: sOn = more; pS = snK + (long) tile*hstride + m + (long) (SK_T - 1)*SK_T;
+	sX = (m + 1) + XS*1; sLag = m;
+      }
     }
-    const bool r1 = p1 != nullptr, r2 = p2 != nullptr;
-    if (!r1) p1 = (u64 *) A.dummy;      // never dereferenced
-    if (!r2) p2 = (u64 *) A.dummy;
 
     double pR[SK_D], pRhs[SK_D], pDia[SK_D], pH[SK_DH];
 
@@ -243,7 +246,7 @@ relax_skew_loop_kernel (SkewLoopArgs A)
       for (int q = 0; q < SK_DH; q++)
 	SK_PREFETCH_HALO (q);
     }
-    else {
+    else if (compute) {
 #pragma unroll
       for (int q = 0; q < SK_D; q++)
 	SK_PREFETCH (q);
@@ -261,7 +264,7 @@ relax_skew_loop_kernel (SkewLoopArgs A)
       SK_HALO (0, 0);
       pH[0] = keep;
     }
-    else
+    else if (compute)
       Y[0][iOwnY] = pR[0];
     __syncthreads ();
 
@@ -275,6 +278,21 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 	  const int t = t0 + q;
 	  if (!(SK_KO & 2))
 	    SK_HALO_STEP (t + 1, q % SK_DH);
+	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	}
+      }
+    }
+    else if (storer) {
+      // ---- store wave: the value a line computed at step t - 1 sits in X[t & 1]; its granule
+      //      belongs to row (t - 1) -+ 15 of the line's buffer ----
+      for (int t0 = 0; t0 < T; t0 += SK_D) {
+#pragma unroll
+	for (int q = 0; q < SK_D; q++) {
+	  const int t = t0 + q;
+	  const int I = t - 1 - sLag;
+	  if (!(SK_KO & 1) && sOn && I >= 0 && I < n)
+	    store_sc1 (pS - SK_T, (u64) __double_as_longlong (X[t & 1][sX]));
+	  pS += SK_T;
 	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 	}
       }
@@ -309,13 +327,6 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 	  if (!(SK_KO & 4))
 	    *wU = v;
 	  wU += SK_NL;
-	  if (!(SK_KO & 1)) {
-	    const u64 bits = (u64) __double_as_longlong (v);
-	    if (act && r1) store_sc1 (p1, bits);
-	    if (act && r2) store_sc1 (p2, bits);
-	  }
-	  p1 += SK_T;
-	  p2 += SK_T;
 	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 	}
       }
