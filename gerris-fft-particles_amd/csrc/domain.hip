@@ -103,6 +103,7 @@ int gfship_domain_create (gfship_domain ** out, int dim, int depth, const int si
     gfship_domain_destroy (dom);
     return r;
   }
+  dom->skew_old = getenv ("GFSHIP_SKEW_OLD") != nullptr;
   *out = dom;
   return GFSHIP_OK;
 }

@@ -438,6 +438,10 @@ static int skew_launch (gfship_domain * dom, int level, SkewPlan * S, double * u
 
 static int skew_sweep (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia)
 {
+  /* the six-wave kernel of relax_skew_loop.hip also runs a single sweep (any sides); the
+     four-wave kernel below is kept as an independent implementation (GFSHIP_SKEW_OLD=1) */
+  if (!dom->skew_old)
+    return skew_loop_run (dom, level, S, u_nat, has_dia, 1);
   // ticket = 0 (err is sticky), hand-off granules = sentinel
   GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
   if (S->ntj > 1)
@@ -526,16 +530,21 @@ int skew_time_sweeps (gfship_domain * dom, int level, Field * u, const double * 
   if ((r = skew_sweep (dom, level, S, u->lev[level], !dia_zero))) return r; /* warm-up */
   float total = 0.f;
   for (int q = 0; q < reps; q++) {
-    // the memsets that re-arm the hand-off buffers are outside the timed region
-    GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
-    if (S->ntj > 1)
-      GFSHIP_HIP (hipMemsetAsync (S->hb, 0xFF, 2*S->hb_words*sizeof (u64), dom->stream));
-    GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
-    if ((r = skew_launch (dom, level, S, u->lev[level], !dia_zero))) return r;
-    GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));
-    GFSHIP_HIP (hipEventSynchronize (dom->ev1));
     float ms = 0.f;
-    GFSHIP_HIP (hipEventElapsedTime (&ms, dom->ev0, dom->ev1));
+    if (!dom->skew_old) {
+      if ((r = skew_loop_run (dom, level, S, u->lev[level], !dia_zero, 1, &ms))) return r;
+    }
+    else {
+      // the memsets that re-arm the hand-off buffers are outside the timed region
+      GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
+      if (S->ntj > 1)
+	GFSHIP_HIP (hipMemsetAsync (S->hb, 0xFF, 2*S->hb_words*sizeof (u64), dom->stream));
+      GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
+      if ((r = skew_launch (dom, level, S, u->lev[level], !dia_zero))) return r;
+      GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));
+      GFSHIP_HIP (hipEventSynchronize (dom->ev1));
+      GFSHIP_HIP (hipEventElapsedTime (&ms, dom->ev0, dom->ev1));
+    }
     total += ms;
   }
   *ms_per_sweep = total/reps;
@@ -564,15 +573,20 @@ int skew_time_loop (gfship_domain * dom, int level, Field * u, const double * rh
     }
     else
       for (unsigned w = 0; w < nrelax; w++) {
-	GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
-	if (S->ntj > 1)
-	  GFSHIP_HIP (hipMemsetAsync (S->hb, 0xFF, 2*S->hb_words*sizeof (u64), dom->stream));
-	GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
-	if ((r = skew_launch (dom, level, S, un, !dia_zero))) return r;
-	GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));
-	GFSHIP_HIP (hipEventSynchronize (dom->ev1));
 	float m1 = 0.f;
-	GFSHIP_HIP (hipEventElapsedTime (&m1, dom->ev0, dom->ev1));
+	if (!dom->skew_old) {
+	  if ((r = skew_loop_run (dom, level, S, un, !dia_zero, 1, &m1))) return r;
+	}
+	else {
+	  GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
+	  if (S->ntj > 1)
+	    GFSHIP_HIP (hipMemsetAsync (S->hb, 0xFF, 2*S->hb_words*sizeof (u64), dom->stream));
+	  GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
+	  if ((r = skew_launch (dom, level, S, un, !dia_zero))) return r;
+	  GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));
+	  GFSHIP_HIP (hipEventSynchronize (dom->ev1));
+	  GFSHIP_HIP (hipEventElapsedTime (&m1, dom->ev0, dom->ev1));
+	}
 	ms += m1;
 	if (w + 1 < nrelax && (r = launch_bc (dom, u, u, level, 1))) return r;
       }

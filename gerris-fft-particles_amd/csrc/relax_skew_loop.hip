@@ -38,6 +38,10 @@
 #ifndef SK_POLL_SLEEP
 #define SK_POLL_SLEEP 2   /* s_sleep argument between two polls of a hand-off granule */
 #endif
+#ifndef SK_EXP
+#define SK_EXP 0    /* timing experiments: 1 plain halo prefetch loads, 2 plain granule stores */
+#endif
+#define SK_HLOAD(p_) ((SK_EXP & 1) ? *(p_) : load_sc1 (p_))
 #ifndef SK_KO
 #define SK_KO 0      /* timing experiments only: knock out parts of the step (wrong results) */
 #endif
@@ -47,6 +51,8 @@ namespace gfship {
 struct SkewLoopArgs {
   Layout L;
   int ntj, RT, nsweeps;
+  int mirror;              // single sweep with the BC kernel around it: cells next to the box sides
+                           // are also written to the natural array (any kind of side)
   double * us;             // skewed u (in place)
   const double * rs;       // skewed rhs
   const double * ds;       // skewed dia (or nullptr)
@@ -184,16 +190,24 @@ relax_skew_loop_kernel (SkewLoopArgs A)
     u64 * pS = (u64 *) A.dummy;
     bool sOn = false;
     int sX = 0, sLag = 0;       // LDS index of the line's new value; skew a + b of the line
+    double * pNat = nullptr;    // mirror mode: the line lies along a box side, natural address of I = -1 - sLag + t
     if (storer) {
       switch (g) {
       case 0: sOn = P + 1 < ntj || more; pS = hbJ + (long) tile*hstride + m - (long) (SK_T - 1)*SK_T;
-	sX = SK_T + XS*(m + 1); sLag = SK_T - 1 + m; break;
+	sX = SK_T + XS*(m + 1); sLag = SK_T - 1 + m;
+	if (A.mirror && P == ntj - 1) pNat = A.un + A.L.idx (0, 1, km) - sLag;
+	break;
       case 1: sOn = Q + 1 < ntj || more; pS = hbK + (long) tile*hstride + m - (long) (SK_T - 1)*SK_T;
-	sX = (m + 1) + XS*SK_T; sLag = SK_T - 1 + m; break;
+	sX = (m + 1) + XS*SK_T; sLag = SK_T - 1 + m;
+	if (A.mirror && Q == ntj - 1) pNat = A.un + A.L.idx (0, jm, 1) - sLag;
+	break;
       case 2: sOn = more; pS = snJ + (long) tile*hstride + m + (long) (SK_T - 1)*SK_T;
-	sX = 1 + XS*(m + 1); sLag = m; break;
+	sX = 1 + XS*(m + 1); sLag = m;
+	if (A.mirror && P == 0) pNat = A.un + A.L.idx (0, n, km) - sLag;
+	break;
       default: sOn = more; pS = snK + (long) tile*hstride + m + (long) (SK_T - 1)*SK_T;
 	sX = (m + 1) + XS*1; sLag = m;
+	if (A.mirror && Q == 0) pNat = A.un + A.L.idx (0, jm, n) - sLag;
       }
     }
 
@@ -207,7 +221,7 @@ relax_skew_loop_kernel (SkewLoopArgs A)
     } while (0)
 #define SK_PREFETCH_HALO(q_)						\
     do {								\
-      pH[q_] = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs; \
+      pH[q_] = __longlong_as_double ((long long) SK_HLOAD (qH)); qH += hs; \
     } while (0)
 #define SK_HALO(t_, q_) SK_HALO_ (t_, q_, 0)
 #define SK_HALO_STEP(t_, q_) SK_HALO_ (t_, q_, 1)
@@ -232,7 +246,7 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 	}								\
 	halo_dst0[((t_) & 1)*(XS*XS)] = hv;				\
 	if (refill_) {							\
-	  pH[q_] = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs; \
+	  pH[q_] = __longlong_as_double ((long long) SK_HLOAD (qH)); qH += hs; \
 	}								\
       }									\
     } while (0)
@@ -290,8 +304,11 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 	for (int q = 0; q < SK_D; q++) {
 	  const int t = t0 + q;
 	  const int I = t - 1 - sLag;
+	  if (pNat && I >= 0 && I < n)
+	    pNat[t] = X[t & 1][sX];          /* cell i = I + 1 = t - sLag of the side line */
 	  if (!(SK_KO & 1) && sOn && I >= 0 && I < n)
-	    store_sc1 (pS - SK_T, (u64) __double_as_longlong (X[t & 1][sX]));
+	    { if (SK_EXP & 2) *(pS - SK_T) = (u64) __double_as_longlong (X[t & 1][sX]);
+	      else store_sc1 (pS - SK_T, (u64) __double_as_longlong (X[t & 1][sX])); }
 	  pS += SK_T;
 	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 	}
@@ -336,6 +353,10 @@ relax_skew_loop_kernel (SkewLoopArgs A)
       A.stats[2*(tile*SK_MAXF + sw) + 1] = __builtin_amdgcn_s_memrealtime ();
     ghostL = prev;      // value at I = n - 1
     ghostR = first;     // value at I = 0
+    if (A.mirror && compute) {
+      A.un[A.L.idx (1, j, k)] = first;
+      A.un[A.L.idx (n, j, k)] = prev;
+    }
     if (write_ghosts && compute) {
       // the ghost layer the last BC application of the loop leaves behind (read by
       // get_from_above, poisson.c:1160-1167): the x ghosts of a line are only ever read by its
@@ -412,6 +433,9 @@ bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool 
   return ntiles <= dom->skew_resident;
 }
 
+// nrelax >= 2: the fused loop of a periodic level.  nrelax == 1: one sweep of any level the
+// pipelined sweep runs on (any sides; the BC kernel is applied around it by the caller, so the
+// cells next to the box sides are mirrored into the natural array).
 int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia,
 		   unsigned nrelax, float * ms)
 {
@@ -424,9 +448,12 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
     GFSHIP_HIP (hipMalloc ((void **) &S->hbf, (size_t) SK_MAXF*hb_sweep*sizeof (u64)));
   }
   GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
-  GFSHIP_HIP (hipMemsetAsync (S->hbf, 0xFF, (size_t) nrelax*hb_sweep*sizeof (u64), dom->stream));
+  /* a single sweep only uses the two hand-off arrays of its granule set */
+  GFSHIP_HIP (hipMemsetAsync (S->hbf, 0xFF, (nrelax > 1 ? (size_t) nrelax*hb_sweep : (size_t) 2*hb_words)*
+			      sizeof (u64), dom->stream));
   SkewLoopArgs A;
   A.L = L; A.ntj = S->ntj; A.RT = S->RT; A.nsweeps = (int) nrelax;
+  A.mirror = nrelax == 1;
   A.us = S->us; A.rs = S->rs; A.ds = has_dia ? S->ds : nullptr;
   A.un = u_nat;
   A.hb = (u64 *) S->hbf; A.hb_sweep = hb_sweep; A.hb_words = hb_words;
@@ -451,6 +478,8 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
     GFSHIP_HIP (hipEventSynchronize (dom->ev1));
     GFSHIP_HIP (hipEventElapsedTime (ms, dom->ev0, dom->ev1));
   }
+  if (nrelax < 2)
+    return GFSHIP_OK;
   int block = L.n >= 256 ? 256 : L.n >= 128 ? 128 : 64;
   hipLaunchKernelGGL (skew_loop_ghosts_kernel, dim3 ((L.n + block - 1)/block, L.n, 4), dim3 (block),
 		      0, dom->stream, A);

@@ -393,3 +393,28 @@ def test_fused_relax_loop_equals_per_sweep_launches_256(nrelax):
         gd.destroy()
     assert _faces_equal(out[0][0], out[1][0], 3)
     assert np.array_equal(out[0][1], out[1][1])
+
+
+def test_four_wave_sweep_kernel_still_bit_exact(monkeypatch):
+    """GFSHIP_SKEW_OLD=1 selects the older four-wave sweep kernel (relax_skew_kernel), kept as an
+    independent implementation of the same sweep: mixed sides, 64^3, against the oracle"""
+    monkeypatch.setenv("GFSHIP_SKEW_OLD", "1")
+    L = O.lib()
+    level, dim = 6, 3
+    side, bck = SIDES["mixed"]
+    rng = np.random.default_rng(77)
+    od, gd = _pair(dim, level, side)
+    L.go_poisson_coefficients(od.ptr)
+    gd.poisson_coefficients()
+    f = _rand_fields(od, gd, ["u", "rhs", "dia"], rng)
+    f["dia"][0].leaf()[...] = 0.
+    f["dia"][1].fill(0.)
+    for d in range(2 * dim):
+        f["u"][0].set_bc(d, bck)
+        f["u"][1].set_bc(d, bck)
+    for _ in range(2):
+        L.go_homogeneous_bc(f["u"][0].ptr, f["u"][0].ptr, level)
+        gd.homogeneous_bc(f["u"][1], f["u"][1])
+        L.go_relax(od.ptr, dim, level, 1., f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr)
+        gd.relax(f["u"][1], f["rhs"][1], f["dia"][1])
+        assert _faces_equal(f["u"][0].leaf(), f["u"][1].download(), dim)
