@@ -238,6 +238,21 @@ static int check_level (gfship_domain * dom, int level)
   return GFSHIP_OK;
 }
 
+} // extern "C"
+
+namespace gfship {
+// bring the non-leaf levels of F up to date before level `level` (< depth) is read or written
+int coarse_flush (gfship_domain * dom, Field * F, int level)
+{
+  if (!F->coarse_stale || level >= dom->depth) return GFSHIP_OK;
+  F->coarse_stale = false;
+  Field * one[1] = { F };
+  return launch_coarse_init (dom, one, 1);
+}
+}
+
+extern "C" {
+
 int gfship_field_upload (gfship_domain * dom, gfship_field f, int level, const double * host)
 {
   Field * F = get_field (dom, f);
@@ -245,6 +260,7 @@ int gfship_field_upload (gfship_domain * dom, gfship_field f, int level, const d
   GFSHIP_CHECK (host != nullptr, GFSHIP_EINVAL, "null host pointer");
   int r = check_level (dom, level);
   if (r) return r;
+  if ((r = coarse_flush (dom, F, level))) return r;
   const Layout & L = dom->lay[level];
   size_t rows = (size_t) L.rows*(dom->dim == 3 ? L.rows : 1);
   GFSHIP_HIP (hipMemcpy2DAsync (F->lev[level] + L.xo, L.px*sizeof (double),
@@ -262,6 +278,7 @@ int gfship_field_download (gfship_domain * dom, gfship_field f, int level, doubl
   GFSHIP_CHECK (host != nullptr, GFSHIP_EINVAL, "null host pointer");
   int r = check_level (dom, level);
   if (r) return r;
+  if ((r = coarse_flush (dom, F, level))) return r;
   const Layout & L = dom->lay[level];
   size_t rows = (size_t) L.rows*(dom->dim == 3 ? L.rows : 1);
   GFSHIP_HIP (hipMemcpy2DAsync (host, L.rows*sizeof (double),
@@ -277,6 +294,7 @@ int gfship_field_fill (gfship_domain * dom, gfship_field f, int level, double va
   if (!F) return GFSHIP_EINVAL;
   int r = check_level (dom, level);
   if (r) return r;
+  if ((r = coarse_flush (dom, F, level))) return r;
   r = launch_fill (dom, level, F->lev[level], value);
   F->zero[level] = (r == GFSHIP_OK && value == 0.);
   return r;
@@ -288,6 +306,7 @@ void * gfship_field_device_ptr (gfship_domain * dom, gfship_field f, int level, 
   if (!F || level < 0 || level > dom->depth) return nullptr;
   if (px) *px = dom->lay[level].px;
   if (xo) *xo = dom->lay[level].xo;
+  if (coarse_flush (dom, F, level) != GFSHIP_OK) return nullptr;
   F->zero[level] = false; /* the caller may write through the raw pointer */
   return F->lev[level];
 }
@@ -298,6 +317,7 @@ int gfship_bc (gfship_domain * dom, gfship_field v, gfship_field v1, int level)
   if (!V || !V1) return GFSHIP_EINVAL;
   int r = check_level (dom, level);
   if (r) return r;
+  if ((r = coarse_flush (dom, V1, level))) return r;
   V1->zero[level] = false;
   return launch_bc (dom, V, V1, level, 0);
 }
@@ -308,6 +328,7 @@ int gfship_homogeneous_bc (gfship_domain * dom, gfship_field ov, gfship_field v,
   if (!OV || !V) return GFSHIP_EINVAL;
   int r = check_level (dom, level);
   if (r) return r;
+  if ((r = coarse_flush (dom, OV, level))) return r;
   OV->zero[level] = false;
   return launch_bc (dom, V, OV, level, 1);
 }

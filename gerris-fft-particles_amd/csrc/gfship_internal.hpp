@@ -38,6 +38,10 @@ struct Field {
   // level is known to hold only zeros (set by alloc / fill (0.), cleared by every other writer
   // of a *named* field: uploads and kernels that take the Field as output)
   bool zero[GFSHIP_MAXLEVEL + 1] = {};
+  // set by a caller that wants the non-leaf levels recomputed (gfs_cell_coarse_init,
+  // src/adaptive.c:43-58) the next time one of them is read or written (coarse_flush); the
+  // simulation loop does not use it: its coarse values are a snapshot taken in mid-step
+  bool coarse_stale = false;
 };
 
 // scratch of the skewed exact-order sweep of one level (relax_skew.hip)
@@ -116,6 +120,7 @@ int  hip_fail (hipError_t e, const char * what, const char * file, int line);
     gfship::set_error (__VA_ARGS__); return (code); } } while (0)
 
 Field * get_field (gfship_domain * dom, gfship_field f);
+int coarse_flush (gfship_domain * dom, Field * F, int level);
 inline long ncells (const Layout & L) {
   return L.dim == 3 ? (long) L.n*L.n*L.n : (long) L.n*L.n;
 }

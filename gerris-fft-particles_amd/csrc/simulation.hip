@@ -469,18 +469,24 @@ int gfship_set_timestep (gfship_sim * s)
   return set_timestep (s, false);
 }
 
-int gfship_coarse_init (gfship_sim * s)
+static void sim_variables (gfship_sim * s, std::vector<Field *> & v)
 {
-  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
   gfship_domain * dom = s->dom;
-  std::vector<Field *> v;
   v.push_back (get_field (dom, s->p));
   v.push_back (get_field (dom, s->pmac));
   for (int c = 0; c < dom->dim; c++)
     v.push_back (get_field (dom, s->u[c]));
   for (gfship_field t : s->tracers)
     v.push_back (get_field (dom, t));
-  return launch_coarse_init (dom, v.data (), (int) v.size ());
+}
+
+int gfship_coarse_init (gfship_sim * s)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  std::vector<Field *> v;
+  sim_variables (s, v);
+  for (Field * F : v) F->coarse_stale = false;
+  return launch_coarse_init (s->dom, v.data (), (int) v.size ());
 }
 
 int gfship_sim_start (gfship_sim * s)
@@ -494,6 +500,8 @@ int gfship_sim_start (gfship_sim * s)
     TRY (bc_leaf (s, s->u[c]));
   for (gfship_field t : s->tracers)
     TRY (bc_leaf (s, t));
+  /* gfs_cell_coarse_init at this point of the loop (src/simulation.c:530-533): the non-leaf
+     values are those of the state before the approximate projection, so it cannot be deferred */
   TRY (gfship_coarse_init (s));
 
   TRY (gfship_set_timestep (s));
@@ -527,6 +535,8 @@ int gfship_sim_step (gfship_sim * s)
   TRY (gfship_centered_velocity_advection (s, s->gmac, s->i > 0 ? gc : s->gmac));
   TRY (correct_centered_velocities (s, s->i > 0 ? gc : s->gmac, - s->advection_params.dt));
 
+  /* gfs_cell_coarse_init at this point of the loop (src/simulation.c:530-533): the non-leaf
+     values are those of the state before the approximate projection, so it cannot be deferred */
   TRY (gfship_coarse_init (s));
 
   TRY (gfship_approximate_projection (s, &s->approx_projection_params, s->advection_params.dt,

@@ -567,12 +567,14 @@ struct FacePair { double l, r; };   // f[2*d].v ("left state" of the + face) and
 // The cell size is a power of two (1/n, n = 2^level), so the reference's divisions by size and
 // 2.*size are exact scalings and are written as multiplications by n and n/2: same bits, without
 // the 14-instruction division sequences.
-template <int DIM, int D>
+// CEN: centred velocities (predictor) or MAC velocities; VL: van Leer or centred gradient; VS: a
+// viscous MAC source may be present (all compile-time: the tiled kernels are issue-bound)
+template <int DIM, int D, bool CEN, bool VL, bool VS>
 __device__ __forceinline__ FacePair face_values_dir (const Layout & L, const double * __restrict__ v,
 						     const CPtr3 & u, const CPtr3 & un, long c,
-						     double dt, int use_centered_velocity, int gradient,
-						     double visc)
+						     double dt, double visc)
 {
+  const int use_centered_velocity = CEN, gradient = VL;
   const long off[3] = { 1, L.sy, L.sz };
   const double rsize = (double) L.n, rsize2 = (double) L.n/2.;   /* 1/size, 1/(2.*size) */
   const double v0 = v[c];
@@ -594,7 +596,7 @@ __device__ __forceinline__ FacePair face_values_dir (const Layout & L, const dou
   double vl = v0 + GMIN ((1. - unorm)/2., 0.5)*g;
   double vr = v0 + GMAX ((- 1. - unorm)/2., -0.5)*g;
   double msrc = 0.;
-  if (visc != 0.)
+  if (VS && visc != 0.)
     msrc = 0. + source_diffusion_value<DIM> (v, c, off, visc, L.n);
   double src = dt*msrc/2.;
   double dv;
@@ -645,8 +647,9 @@ struct TileIdx {
 // predictor of the three components in one pass: gfs_face_advected_normal_velocity
 // (src/advection.c:513-539) with the face values of u[c] along c computed in place
 // (use_centered_velocity = TRUE)
+template <bool VL, bool VS>
 __global__ void __launch_bounds__(GN)
-predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, int gradient, Visc3 visc)
+predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc)
 {
   __shared__ double fl[3][GN], fr[3][GN];
   __shared__ double hp[3][GX*GZ];          // r of the cell beyond the + face of the tile
@@ -656,11 +659,11 @@ predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, int gradient, Vi
   const long off[3] = { 1, L.sy, L.sz };
   CPtr3 none = { { nullptr, nullptr, nullptr } };
   {
-    FacePair f = face_values_dir<3, 0> (L, u.p[0], u, none, c, dt, 1, gradient, visc.d[0]);
+    FacePair f = face_values_dir<3, 0, true, VL, VS> (L, u.p[0], u, none, c, dt, visc.d[0]);
     fl[0][T.own ()] = f.l; fr[0][T.own ()] = f.r;
-    f = face_values_dir<3, 1> (L, u.p[1], u, none, c, dt, 1, gradient, visc.d[1]);
+    f = face_values_dir<3, 1, true, VL, VS> (L, u.p[1], u, none, c, dt, visc.d[1]);
     fl[1][T.own ()] = f.l; fr[1][T.own ()] = f.r;
-    f = face_values_dir<3, 2> (L, u.p[2], u, none, c, dt, 1, gradient, visc.d[2]);
+    f = face_values_dir<3, 2, true, VL, VS> (L, u.p[2], u, none, c, dt, visc.d[2]);
     fl[2][T.own ()] = f.l; fr[2][T.own ()] = f.r;
   }
   // halo: the cell beyond the + face of the tile in each direction.  Waves 0-3 take y, waves 4-7
@@ -670,17 +673,17 @@ predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, int gradient, Vi
     if (h < GX*GZ) {
       int p = h % GX, q = h / GX;
       long ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + GY + 1, blockIdx.z*GZ + q + 1);
-      hp[1][h] = face_values_dir<3, 1> (L, u.p[1], u, none, ci, dt, 1, gradient, visc.d[1]).r;
+      hp[1][h] = face_values_dir<3, 1, true, VL, VS> (L, u.p[1], u, none, ci, dt, visc.d[1]).r;
     }
     else if (h < GX*GZ + GX*GY) {
       int hh = h - GX*GZ, p = hh % GX, q = hh / GX;
       long ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + q + 1, blockIdx.z*GZ + GZ + 1);
-      hp[2][hh] = face_values_dir<3, 2> (L, u.p[2], u, none, ci, dt, 1, gradient, visc.d[2]).r;
+      hp[2][hh] = face_values_dir<3, 2, true, VL, VS> (L, u.p[2], u, none, ci, dt, visc.d[2]).r;
     }
     if (h < GY*GZ) {
       int p = h % GY, q = h / GY;
       long ci = image<3> (L, blockIdx.x*GX + GX + 1, blockIdx.y*GY + p + 1, blockIdx.z*GZ + q + 1);
-      hp[0][h] = face_values_dir<3, 0> (L, u.p[0], u, none, ci, dt, 1, gradient, visc.d[0]).r;
+      hp[0][h] = face_values_dir<3, 0, true, VL, VS> (L, u.p[0], u, none, ci, dt, visc.d[0]).r;
     }
   }
   __syncthreads ();
@@ -706,11 +709,11 @@ predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, int gradient, Vi
 
 // variable_sources (src/timestep.c:872-921) of one advected variable: out = v + fluxes - g*dt,
 // the fluxes gathered in the reference's scatter order (see flux_update_kernel)
-template <bool VELOCITY>
+template <bool VELOCITY, bool VL, bool VS>
 __global__ void __launch_bounds__(GN)
 advect_tiled_kernel (Layout L, const double * __restrict__ v, double * __restrict__ out, CPtr3 un,
 		     const double * __restrict__ gm, const double * __restrict__ gc, double dt,
-		     int gradient, double visc)
+		     double visc)
 {
   __shared__ double fl[3][GN], fr[3][GN];
   __shared__ double hm[3][GX*GZ], hp[3][GX*GZ];   // l of the cell before / r of the cell after the tile
@@ -721,11 +724,11 @@ advect_tiled_kernel (Layout L, const double * __restrict__ v, double * __restric
   const long off[3] = { 1, L.sy, L.sz };
   CPtr3 none = { { nullptr, nullptr, nullptr } };
   {
-    FacePair f = face_values_dir<3, 0> (L, v, none, un, c, dt, 0, gradient, visc);
+    FacePair f = face_values_dir<3, 0, false, VL, VS> (L, v, none, un, c, dt, visc);
     fl[0][T.own ()] = f.l; fr[0][T.own ()] = f.r;
-    f = face_values_dir<3, 1> (L, v, none, un, c, dt, 0, gradient, visc);
+    f = face_values_dir<3, 1, false, VL, VS> (L, v, none, un, c, dt, visc);
     fl[1][T.own ()] = f.l; fr[1][T.own ()] = f.r;
-    f = face_values_dir<3, 2> (L, v, none, un, c, dt, 0, gradient, visc);
+    f = face_values_dir<3, 2, false, VL, VS> (L, v, none, un, c, dt, visc);
     fl[2][T.own ()] = f.l; fr[2][T.own ()] = f.r;
   }
   // halo cells: l of the cell before the tile (minus side), r of the cell after it (plus side).
@@ -736,18 +739,18 @@ advect_tiled_kernel (Layout L, const double * __restrict__ v, double * __restric
     const int grp = h / (GX*GZ), idx = h % (GX*GZ), p = idx % GX, q = idx / GX;
     if (grp < 2) {
       long ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + (grp ? GY + 1 : 0), blockIdx.z*GZ + q + 1);
-      FacePair f = face_values_dir<3, 1> (L, v, none, un, ci, dt, 0, gradient, visc);
+      FacePair f = face_values_dir<3, 1, false, VL, VS> (L, v, none, un, ci, dt, visc);
       if (grp) hp[1][idx] = f.r; else hm[1][idx] = f.l;
     }
     else {
       long ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + q + 1, blockIdx.z*GZ + (grp == 3 ? GZ + 1 : 0));
-      FacePair f = face_values_dir<3, 2> (L, v, none, un, ci, dt, 0, gradient, visc);
+      FacePair f = face_values_dir<3, 2, false, VL, VS> (L, v, none, un, ci, dt, visc);
       if (grp == 3) hp[2][idx] = f.r; else hm[2][idx] = f.l;
     }
     if (h < 2*GY*GZ) {
       const int plus = h >= GY*GZ, hh = h % (GY*GZ), py = hh % GY, qz = hh / GY;
       long ci = image<3> (L, blockIdx.x*GX + (plus ? GX + 1 : 0), blockIdx.y*GY + py + 1, blockIdx.z*GZ + qz + 1);
-      FacePair f = face_values_dir<3, 0> (L, v, none, un, ci, dt, 0, gradient, visc);
+      FacePair f = face_values_dir<3, 0, false, VL, VS> (L, v, none, un, ci, dt, visc);
       if (plus) hp[0][hh] = f.r; else hm[0][hh] = f.l;
     }
   }
@@ -1148,8 +1151,13 @@ int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt
   const Layout & L = dom->lay[dom->depth];
   Visc3 vs;
   for (int c = 0; c < 3; c++) vs.d[c] = visc[c];
-  hipLaunchKernelGGL (predict_un_tiled_kernel, dim3 (L.n/GX, L.n/GY, L.n/GZ), dim3 (GN), 0,
-		      dom->stream, L, c3 (u), m3 (un), dt, gradient, vs);
+  const bool anyv = visc[0] != 0. || visc[1] != 0. || visc[2] != 0.;
+  const dim3 grid (L.n/GX, L.n/GY, L.n/GZ);
+#define PK(VL_, VS_) hipLaunchKernelGGL ((predict_un_tiled_kernel<VL_, VS_>), grid, dim3 (GN), 0, \
+					 dom->stream, L, c3 (u), m3 (un), dt, vs)
+  if (gradient) { if (anyv) PK (true, true); else PK (true, false); }
+  else          { if (anyv) PK (false, true); else PK (false, false); }
+#undef PK
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
 }
@@ -1160,12 +1168,18 @@ int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, d
 {
   const Layout & L = dom->lay[dom->depth];
   dim3 grid (L.n/GX, L.n/GY, L.n/GZ);
-  if (velocity)
-    hipLaunchKernelGGL (advect_tiled_kernel<true>, grid, dim3 (GN), 0, dom->stream,
-			L, v, out, c3 (un), gm, gc, dt, gradient, visc);
-  else
-    hipLaunchKernelGGL (advect_tiled_kernel<false>, grid, dim3 (GN), 0, dom->stream,
-			L, v, out, c3 (un), gm, gc, dt, gradient, visc);
+#define AK(VE_, VL_, VS_) hipLaunchKernelGGL ((advect_tiled_kernel<VE_, VL_, VS_>), grid, dim3 (GN), 0, \
+					      dom->stream, L, v, out, c3 (un), gm, gc, dt, visc)
+  const bool vs = visc != 0.;
+  if (velocity) {
+    if (gradient) { if (vs) AK (true, true, true); else AK (true, true, false); }
+    else          { if (vs) AK (true, false, true); else AK (true, false, false); }
+  }
+  else {
+    if (gradient) { if (vs) AK (false, true, true); else AK (false, true, false); }
+    else          { if (vs) AK (false, false, true); else AK (false, false, false); }
+  }
+#undef AK
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
 }

@@ -135,6 +135,11 @@ def test_taylor_green_3d_steps_bit_exact(level):
     on, gn = osim.divergence_norm(), gs.divergence_norm()
     assert gn.infty == on.infty
     assert gn.second == pytest.approx(on.second, rel=1e-12)
+    # gfs_cell_coarse_init (simulation.c:530-533): the non-leaf levels hold the restriction of the
+    # state before the approximate projection of the step, exactly as the reference's loop leaves them
+    for l in (level - 1, 2, 0):
+        for name, of, gf in (("U", osim.u[0], gs.u[0]), ("P", osim.p, gs.p)):
+            assert np.array_equal(_interior(of.level(l), 3), _interior(gf.download(l), 3)), (name, l)
 
 
 @pytest.mark.parametrize("dim", [2, 3])
