@@ -1,3 +1,8 @@
-timeout -k 10 600 python -m pytest tests/test_gpu_poisson.py tests/test_gpu_timestep.py -x -q -m gpu 2>&1 | tail -3
-timeout -k 10 100 python tools/relax_only.py 8 2>&1 | grep -E "ms per sweep|nrelax 4" | tail -3
-GFSHIP_SKEW_OLD=1 timeout -k 10 100 python tools/relax_only.py 8 2>&1 | grep -E "ms per sweep" | tail -1
+#!/bin/bash
+# Compare builds of the pipelined sweep with other compile-time parameters (tools/build_variant.sh
+# NAME "-DSK_DH=8" ... first): per-tile timing of the first tile and the loop time at 256^3.
+for v in "" "$@"; do
+  export GFSHIP_LIB=${GRAFT_REPO_ROOT:-/root/repo}/gerris-fft-particles_amd/lib/libgfship$v.so
+  echo "== variant '$v'"
+  GFSHIP_SKEW_STATS=1 timeout -k 10 100 python tools/relax_only.py 8 2>&1 | grep -E "tile \( 0, 0\)|tile \(15,15\)|nrelax 4 \(fused" | tail -3 | cut -c1-110
+done
