@@ -124,6 +124,58 @@ halo_copy_kernel (Layout L, int side, double * __restrict__ a, double * __restri
     buf[f] = a[nb];
 }
 
+// the same for several sides in one launch: blockIdx.y = entry of the side list
+struct HaloSides { int n; int side[6]; double * buf[6]; };
+
+__global__ void __launch_bounds__(256)
+halo_copy_sides_kernel (Layout L, HaloSides H, double * __restrict__ a, int unpack)
+{
+  const int n = L.n;
+  const int nface = L.dim == 3 ? n*n : n;
+  int f = blockIdx.x*blockDim.x + threadIdx.x;
+  if (f >= nface) return;
+  const int side = H.side[blockIdx.y];
+  double * __restrict__ buf = H.buf[blockIdx.y];
+  int c = side/2;
+  int t1 = f % n + 1, t2 = L.dim == 3 ? f / n + 1 : 0;
+  int ijk[3] = { 0, 0, 0 };
+  int ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
+  ijk[c] = (side & 1) ? 1 : n;
+  ijk[ta] = t1;
+  if (L.dim == 3) ijk[tb] = t2;
+  long o = c == 0 ? 1 : c == 1 ? L.sy : L.sz;
+  if (side & 1) o = - o;
+  long nb = L.idx (ijk[0], ijk[1], ijk[2]);
+  if (unpack)
+    a[nb + o] = buf[f];
+  else
+    buf[f] = a[nb];
+}
+
+static int halo_copy_sides (gfship_domain * dom, double * a, int level, int nsides, const int * sides,
+			    void * const * bufs, int unpack)
+{
+  GFSHIP_CHECK (dom && a && sides && bufs, GFSHIP_EINVAL, "null argument");
+  GFSHIP_CHECK (level >= 0 && level <= dom->depth, GFSHIP_EINVAL, "level %d out of range", level);
+  GFSHIP_CHECK (nsides >= 0 && nsides <= 6, GFSHIP_EINVAL, "at most six sides");
+  if (nsides == 0) return GFSHIP_OK;
+  HaloSides H;
+  H.n = nsides;
+  for (int q = 0; q < nsides; q++) {
+    GFSHIP_CHECK (sides[q] >= 0 && sides[q] < 2*dom->dim && bufs[q], GFSHIP_EINVAL,
+		  "side %d out of range or null buffer", sides[q]);
+    H.side[q] = sides[q];
+    H.buf[q] = (double *) bufs[q];
+  }
+  const Layout & L = dom->lay[level];
+  int nface = dom->dim == 3 ? L.n*L.n : L.n;
+  int block = nface >= 256 ? 256 : 64;
+  hipLaunchKernelGGL (halo_copy_sides_kernel, dim3 ((nface + block - 1)/block, nsides), dim3 (block), 0,
+		      dom->stream, L, H, a, unpack);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
 static int halo_copy (gfship_domain * dom, double * a, int level, int side, double * buf, int unpack)
 {
   GFSHIP_CHECK (dom && a && buf, GFSHIP_EINVAL, "null argument");
@@ -150,6 +202,18 @@ int gfship_halo_pack (gfship_domain * dom, const void * dev_ptr, int level, int 
 int gfship_halo_unpack (gfship_domain * dom, void * dev_ptr, int level, int side, const void * dev_buf)
 {
   return gfship::halo_copy (dom, (double *) dev_ptr, level, side, (double *) dev_buf, 1);
+}
+
+int gfship_halo_pack_sides (gfship_domain * dom, const void * dev_ptr, int level, int nsides,
+			    const int * sides, void * const * dev_bufs)
+{
+  return gfship::halo_copy_sides (dom, (double *) dev_ptr, level, nsides, sides, dev_bufs, 0);
+}
+
+int gfship_halo_unpack_sides (gfship_domain * dom, void * dev_ptr, int level, int nsides,
+			      const int * sides, void * const * dev_bufs)
+{
+  return gfship::halo_copy_sides (dom, (double *) dev_ptr, level, nsides, sides, dev_bufs, 1);
 }
 
 } // extern "C"

@@ -44,12 +44,23 @@ static int relax_loop (gfship_domain * dom, Field * dp, Field * u, unsigned dime
     if (done)
       return GFSHIP_OK;
   }
+  /* boxes with GfsBoundaryMpi sides: the halo exchange comes between the sweeps, but a level that
+     fits in LDS still runs each sweep as one launch instead of one launch per hyperplane */
+  auto sweep = [&] () -> int {
+    if (dom->relax_mode == GFSHIP_RELAX_EXACT && dom->has_external) {
+      bool done = false;
+      int rr = launch_relax_loop_small (dom, dimension, level, omega, dp, u, rhs->lev[level],
+					dia->lev[level], 1, &done);
+      if (rr || done) return rr;
+    }
+    return relax_level (dom, dimension, level, omega, dp, rhs, dia);
+  };
   if ((r = launch_bc (dom, u, dp, level, 1))) return r;
   for (unsigned n = 0; n < nrelax - 1; n++) {
-    if ((r = relax_level (dom, dimension, level, omega, dp, rhs, dia))) return r;
+    if ((r = sweep ())) return r;
     if ((r = launch_bc (dom, u, dp, level, 1))) return r;
   }
-  return relax_level (dom, dimension, level, omega, dp, rhs, dia);
+  return sweep ();
 }
 
 static int norm_residual_finish (gfship_domain * dom, double dt, double s[5], gfship_norm * out);

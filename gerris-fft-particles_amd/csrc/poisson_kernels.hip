@@ -165,6 +165,13 @@ relax_loop_lds_kernel (Layout L, BcDesc bc, unsigned dimension, double omega, do
       double v;
       if (bc.side[d] == GFSHIP_SIDE_PERIODIC)
 	v = s[nb - (long) (n - 1)*o];
+      else if (bc.side[d] == GFSHIP_SIDE_EXTERNAL) {
+	/* GfsBoundaryMpi: the ghost holds what the neighbour box sent before this launch (single
+	   sweep per launch on such domains) */
+	int gi[3] = { ijk[0], ijk[1], ijk[2] };
+	gi[c] += (d & 1) ? -1 : 1;
+	v = u[L.idx (gi[0], gi[1], gi[2])];
+      }
       else
 	v = ghost_value (bc.type[d], bc.component, c, s[nb], 1, 0., 0.);
       s[nb + o] = v;
@@ -213,8 +220,8 @@ int launch_relax_loop_small (gfship_domain * dom, unsigned dimension, int level,
   size_t bytes;
   *done = false;
   for (int d = 0; d < 2*dom->dim; d++)
-    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL)
-      return GFSHIP_OK; /* halos need the exchange between sweeps */
+    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL && nrelax > 1)
+      return GFSHIP_OK; /* halos need the exchange between sweeps: one sweep per launch only */
   if (!lds_fits (dom, level, &bytes))
     return GFSHIP_OK;
   const Layout & L = dom->lay[level];

@@ -110,6 +110,8 @@ SIGNATURES = {
     "gfship_domain_set_reduce": (_i, [_vp, _vp, _vp]),
     "gfship_halo_pack": (_i, [_vp, _vp, _i, _i, _vp]),
     "gfship_halo_unpack": (_i, [_vp, _vp, _i, _i, _vp]),
+    "gfship_halo_pack_sides": (_i, [_vp, _vp, _i, _i, _pi, C.POINTER(_vp)]),
+    "gfship_halo_unpack_sides": (_i, [_vp, _vp, _i, _i, _pi, C.POINTER(_vp)]),
     "gfship_field_interpolate": (_i, [_vp, _i, _i, _pd, _pd, C.POINTER(C.c_ubyte)]),
     "gfship_particles_create": (_i, [C.POINTER(_vp), _vp, _i, _pd, C.POINTER(C.c_uint)]),
     "gfship_particles_destroy": (None, [_vp]),

@@ -77,6 +77,7 @@ class Transport:
         self.grid, self.rank = grid, rank
         self.device = device if device is not None else torch.device("cpu")
         self._bufs = {}
+        self._ops = {}
 
     def buffers(self, key, nface):
         """(send, recv) buffers per side for messages of nface doubles"""
@@ -95,13 +96,18 @@ class Transport:
         send_sides; receive into rcv[r], for r in recv_sides, the layer that the neighbour across
         my side r sent from its side r^1."""
         dist = self.dist
-        ops = []
-        # sends in increasing side index; receives in increasing order of the SENDER's side
-        # index (r^1), so that the messages between two ranks match pairwise in posting order
-        for s in sorted(send_sides):
-            ops.append(dist.P2POp(dist.isend, snd[s], self.grid.neighbour(self.rank, s), tag=s))
-        for r in sorted(recv_sides, key=lambda x: x ^ 1):
-            ops.append(dist.P2POp(dist.irecv, rcv[r], self.grid.neighbour(self.rank, r), tag=r ^ 1))
+        # the descriptors only name persistent buffers: built once per (buffers, sides)
+        key = (id(snd), id(rcv), tuple(send_sides), tuple(recv_sides))
+        ops = self._ops.get(key)
+        if ops is None:
+            ops = []
+            # sends in increasing side index; receives in increasing order of the SENDER's side
+            # index (r^1), so that the messages between two ranks match pairwise in posting order
+            for s in sorted(send_sides):
+                ops.append(dist.P2POp(dist.isend, snd[s], self.grid.neighbour(self.rank, s), tag=s))
+            for r in sorted(recv_sides, key=lambda x: x ^ 1):
+                ops.append(dist.P2POp(dist.irecv, rcv[r], self.grid.neighbour(self.rank, r), tag=r ^ 1))
+            self._ops[key] = ops
         for q in dist.batch_isend_irecv(ops):
             q.wait()
 
@@ -164,35 +170,49 @@ class DeviceHooks:
         # then ordered on one stream without host synchronisation
         self.stream = torch.cuda.ExternalStream(int(self.lib.gfship_domain_stream(dom.ptr)),
                                                 device=transport.device)
+        self._plans = {}
         self._ex = EXCHANGE_FN(self._exchange)
         self._red = REDUCE_FN(self._reduce)
         gfship._check(self.lib.gfship_domain_set_exchange(dom.ptr, C.cast(self._ex, C.c_void_p), None))
         gfship._check(self.lib.gfship_domain_set_reduce(dom.ptr, C.cast(self._red, C.c_void_p), None))
 
-    def _exchange(self, ctx, dev_ptr, level, kind):
-        try:
-            grid = self.tr.grid
-            sides = _kind_sides(grid, kind)       # sides I send from
+    def _plan(self, level, kind):
+        """what one exchange of (level, kind) needs, built once: side lists, buffers and the
+        argument arrays of the pack / unpack calls"""
+        key = (level, kind)
+        p = self._plans.get(key)
+        if p is None:
+            sides = _kind_sides(self.tr.grid, kind)       # sides I send from
             if not sides:
-                return 0
-            n = 1 << level
-            nface = n ** (self.dom.dim - 1)
-            snd, rcv = self.tr.buffers("dev", nface)
-            torch = self.tr.torch
-            with torch.cuda.stream(self.stream):
-                for s in sides:
-                    rc = self.lib.gfship_halo_pack(self.dom.ptr, dev_ptr, level, s,
-                                                   C.c_void_p(snd[s].data_ptr()))
-                    if rc:
-                        return rc
+                p = False
+            else:
+                nface = (1 << level) ** (self.dom.dim - 1)
+                snd, rcv = self.tr.buffers("dev", nface)
                 # kind 0: receive on the same set of sides; kind 1+e: receive on side e^1 only
                 recv_sides = [x ^ 1 for x in sides] if kind else sides
+                arr = lambda xs: (C.c_int * len(xs))(*xs)
+                ptrs = lambda bufs, xs: (C.c_void_p * len(xs))(*[bufs[x].data_ptr() for x in xs])
+                p = (sides, recv_sides, snd, rcv, arr(sides), ptrs(snd, sides), arr(recv_sides),
+                     ptrs(rcv, recv_sides))
+            self._plans[key] = p
+        return p
+
+    def _exchange(self, ctx, dev_ptr, level, kind):
+        try:
+            p = self._plan(level, kind)
+            if not p:
+                return 0
+            sides, recv_sides, snd, rcv, s_arr, s_ptr, r_arr, r_ptr = p
+            torch = self.tr.torch
+            with torch.cuda.stream(self.stream):
+                rc = self.lib.gfship_halo_pack_sides(self.dom.ptr, dev_ptr, level, len(sides), s_arr, s_ptr)
+                if rc:
+                    return rc
                 self.tr.exchange(sides, snd, recv_sides, rcv)
-                for s in recv_sides:
-                    rc = self.lib.gfship_halo_unpack(self.dom.ptr, dev_ptr, level, s,
-                                                     C.c_void_p(rcv[s].data_ptr()))
-                    if rc:
-                        return rc
+                rc = self.lib.gfship_halo_unpack_sides(self.dom.ptr, dev_ptr, level, len(recv_sides),
+                                                       r_arr, r_ptr)
+                if rc:
+                    return rc
             return 0
         except Exception as e:     # never let an exception cross the C boundary
             import traceback

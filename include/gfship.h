@@ -283,6 +283,11 @@ int  gfship_domain_set_reduce (gfship_domain * dom, gfship_reduce_fn fn, void * 
    the domain's stream */
 int  gfship_halo_pack (gfship_domain * dom, const void * dev_ptr, int level, int side, void * dev_buf);
 int  gfship_halo_unpack (gfship_domain * dom, void * dev_ptr, int level, int side, const void * dev_buf);
+/* the same for several sides with one kernel launch each way: sides[q] -> dev_bufs[q] */
+int  gfship_halo_pack_sides (gfship_domain * dom, const void * dev_ptr, int level, int nsides,
+			     const int * sides, void * const * dev_bufs);
+int  gfship_halo_unpack_sides (gfship_domain * dom, void * dev_ptr, int level, int nsides,
+			       const int * sides, void * const * dev_bufs);
 
 /* ---- instrumentation -------------------------------------------------------------------- */
 
