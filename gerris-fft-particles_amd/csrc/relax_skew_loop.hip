@@ -110,6 +110,9 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 
   double * const ut = A.us + tile*tstride + SK_FP*SK_NL;
   const bool loader = wave == SK_NL/64, storer = wave == SK_NL/64 + 1;
+#if SK_EXP & 4
+  if (compute) __builtin_amdgcn_s_setprio (3);     /* experiment: compute waves first on their SIMD */
+#endif
   const int g = (tid >> 4) & 3, m = tid & 15;
   const int jm = n - (SK_T*P + m), km = n - (SK_T*Q + m);
   bool failed = false;
