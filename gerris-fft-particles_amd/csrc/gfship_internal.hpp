@@ -190,7 +190,7 @@ int  launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field *
 void skew_free (gfship_domain * dom);
 bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool bc);
 int  skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia,
-		    unsigned nrelax, float * ms = nullptr);
+		    unsigned nrelax, float * ms = nullptr, const Field * ubc = nullptr);
 int  skew_time_loop (gfship_domain * dom, int level, Field * u, const double * rhs,
 		     const double * dia, bool dia_zero, unsigned nrelax, int reps,
 		     double * ms_per_loop, int * fused);

@@ -489,7 +489,7 @@ int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * 
   if ((r = skew_pack (dom, level, S, u, rhs, dia_zero ? nullptr : dia))) return r;
   if (!dom->no_fused_loop && skew_loop_supported (dom, level, nrelax, bc)) {
     /* the sweeps of the loop pipelined in one launch (relax_skew_loop.hip) */
-    if ((r = skew_loop_run (dom, level, S, u, !dia_zero, nrelax))) return r;
+    if ((r = skew_loop_run (dom, level, S, u, !dia_zero, nrelax, nullptr, ubc))) return r;
     return skew_unpack (dom, level, S, u);
   }
   for (unsigned q = 0; q < nrelax; q++) {
@@ -569,7 +569,7 @@ int skew_time_loop (gfship_domain * dom, int level, Field * u, const double * rh
     if ((r = skew_pack (dom, level, S, un, rhs, dia_zero ? nullptr : dia))) return r;
     float ms = 0.f;
     if (fuse) {
-      if ((r = skew_loop_run (dom, level, S, un, !dia_zero, nrelax, &ms))) return r;
+      if ((r = skew_loop_run (dom, level, S, un, !dia_zero, nrelax, &ms, u))) return r;
     }
     else
       for (unsigned w = 0; w < nrelax; w++) {

@@ -26,6 +26,10 @@
 //                                      periodic image tile is even AHEAD of the reader), so every
 //                                      tile snapshots them per sweep into granule buffers
 //                                      (data-is-flag, sentinel), read by the next sweep
+// Non-periodic sides (Dirichlet, Neumann, symmetry; homogeneous between the sweeps) work the same
+// way with the tile's OWN outgoing lines as sources: ghost line = +-(line next to the side), taken
+// from the tile's snapshot (a = 0 / b = 0) or hand-off (a = 15 / b = 15) granules of the previous
+// sweep, the sign applied when the value goes into LDS.
 // Granule buffers exist once per sweep of the loop (no re-arming inside the launch).  Every
 // wait is bounded and reported through *err.  All tiles must be resident at once (a tile of
 // sweep s + 1 waits on tiles of sweep s): the host checks the occupancy and otherwise falls back
@@ -51,6 +55,10 @@ namespace gfship {
 struct SkewLoopArgs {
   Layout L;
   int ntj, RT, nsweeps;
+  // homogeneous BC of the sides d = 0..5 (right, left, top, bottom, front, back) between the sweeps
+  // of a fused loop: sgn[d] = 0 periodic; otherwise ghost = sgn[d] * adjacent interior value (-1
+  // Dirichlet and the normal component at a symmetry side, +1 Neumann and symmetry otherwise)
+  double sgn[6];
   int mirror;              // single sweep with the BC kernel around it: cells next to the box sides
                            // are also written to the natural array (any kind of side)
   double * us;             // skewed u (in place)
@@ -143,23 +151,30 @@ relax_skew_loop_kernel (SkewLoopArgs A)
     const u64 * qH = A.dummy;
     int hs = 0;
     bool handoff = false;       // sentinel-guarded granule stream
+    double hsgn = 1.;           // sign of a homogeneous BC whose ghost this stream carries
     int xy_halo = 0;
     if (loader) {
       switch (g) {
       case 0: // new values of line (-1, m)
 	if (P > 0)       { qH = hbJ + (long) tJm*hstride + m; hs = SK_T; handoff = true; }
-	else if (sw > 0) { qH = hbJp + (long) tJm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0 && A.sgn[2] == 0.) { qH = hbJp + (long) tJm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = snJp + (long) tile*hstride + m + (long) (SK_T - 1)*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[2]; }      /* own line a = 0, row t + 15 */
 	else             { qH = (const u64 *) (A.un + A.L.idx (1 - m, n + 1, km)); hs = 1; }
 	xy_halo = 0 + XS*(m + 1);
 	break;
       case 1: // new values of line (m, -1)
 	if (Q > 0)       { qH = hbK + (long) tKm*hstride + m; hs = SK_T; handoff = true; }
-	else if (sw > 0) { qH = hbKp + (long) tKm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0 && A.sgn[4] == 0.) { qH = hbKp + (long) tKm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = snKp + (long) tile*hstride + m + (long) (SK_T - 1)*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[4]; }      /* own line b = 0 */
 	else             { qH = (const u64 *) (A.un + A.L.idx (1 - m, jm, n + 1)); hs = 1; }
 	xy_halo = (m + 1) + XS*0;
 	break;
       case 2: // old values of line (16, m) = line (0, m) of tile (P+1, Q), row t - 15
-	if (sw > 0) { qH = snJp + (long) tJp*hstride + m; hs = SK_T; handoff = true; }
+	if (sw > 0 && (P + 1 < ntj || A.sgn[3] == 0.)) { qH = snJp + (long) tJp*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = hbJp + (long) tile*hstride + m - (long) (SK_T - 1)*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[3]; }      /* own line a = 15, row t - 15 */
 	else if (P + 1 < ntj) {
 	  qH = (const u64 *) (A.us + tJp*tstride + SK_FP*SK_NL - (long) (SK_T - 1)*SK_NL + SK_T*m);
 	  hs = SK_NL;
@@ -168,7 +183,9 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 	xy_halo = SK_T + XS*m;
 	break;
       default: // old values of line (m, 16) = line (m, 0) of tile (P, Q+1), row t - 15
-	if (sw > 0) { qH = snKp + (long) tKp*hstride + m; hs = SK_T; handoff = true; }
+	if (sw > 0 && (Q + 1 < ntj || A.sgn[5] == 0.)) { qH = snKp + (long) tKp*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = hbKp + (long) tile*hstride + m - (long) (SK_T - 1)*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[5]; }      /* own line b = 15 */
 	else if (Q + 1 < ntj) {
 	  qH = (const u64 *) (A.us + tKp*tstride + SK_FP*SK_NL - (long) (SK_T - 1)*SK_NL + m);
 	  hs = SK_NL;
@@ -247,7 +264,7 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 	    if (++spins > (1u << 18)) { *A.err = 1; failed = true; break; } \
 	  }								\
 	}								\
-	halo_dst0[((t_) & 1)*(XS*XS)] = hv;				\
+	halo_dst0[((t_) & 1)*(XS*XS)] = hv*hsgn;			\
 	if (refill_) {							\
 	  pH[q_] = __longlong_as_double ((long long) SK_HLOAD (qH)); qH += hs; \
 	}								\
@@ -354,8 +371,12 @@ relax_skew_loop_kernel (SkewLoopArgs A)
     // end of the sweep: the periodic line ghosts of the next one
     if (A.stats && tid0 == 0)
       A.stats[2*(tile*SK_MAXF + sw) + 1] = __builtin_amdgcn_s_memrealtime ();
-    ghostL = prev;      // value at I = n - 1
-    ghostR = first;     // value at I = 0
+    // ghosts of the line for the next sweep: the periodic image, or the homogeneous BC of the side
+    {
+      const double last = prev;                                  // value at I = n - 1
+      ghostL = A.sgn[1] == 0. ? last : A.sgn[1]*first;         // I = -1 (left side)
+      ghostR = A.sgn[0] == 0. ? first : A.sgn[0]*last;         // I = n  (right side)
+    }
     if (A.mirror && compute) {
       A.un[A.L.idx (1, j, k)] = first;
       A.un[A.L.idx (n, j, k)] = prev;
@@ -366,8 +387,8 @@ relax_skew_loop_kernel (SkewLoopArgs A)
       // own thread (at the start of the launch), so they can be written here; the y and z ghost
       // planes are still read by tiles in their first sweep and are filled after the launch
       // from the granules of this sweep (skew_loop_ghosts_kernel)
-      A.un[A.L.idx (n + 1, j, k)] = first;
-      A.un[A.L.idx (0, j, k)] = prev;
+      A.un[A.L.idx (n + 1, j, k)] = ghostR;
+      A.un[A.L.idx (0, j, k)] = ghostL;
     }
 #undef SK_PREFETCH
 #undef SK_PREFETCH_HALO
@@ -377,8 +398,9 @@ relax_skew_loop_kernel (SkewLoopArgs A)
   }
 }
 
-// y and z ghost planes left by the last BC application of the loop = periodic images of the
-// side cells after sweep nsweeps - 2, taken from that sweep's granules:
+// y and z ghost planes left by the last BC application of the loop = periodic images (or, at a
+// non-periodic side, +- the adjacent line) of the side cells after sweep nsweeps - 2, taken from
+// that sweep's granules:
 //   hand-off J of tile (ntj-1,Q): line a = 15 (j = 1)  -> ghost j = n + 1     row I + b
 //   snapshot J of tile (0,Q):     line a = 0  (j = n)  -> ghost j = 0         row I + b + 15
 //   hand-off K of tile (P,ntj-1): line b = 15 (k = 1)  -> ghost k = n + 1     row I + a
@@ -396,19 +418,25 @@ skew_loop_ghosts_kernel (SkewLoopArgs A)
   const int plane = blockIdx.z;
   if (I >= n) return;
   const int T_ = c / SK_T, l = c % SK_T;                  // tile and line of the tangential index
+  // periodic: the line next to the opposite side; otherwise sgn * the line next to the same side
+  const long lastJ = (long) ((ntj - 1) + ntj*T_)*hstride, firstJ = (long) (0 + ntj*T_)*hstride;
+  const long lastK = (long) (T_ + ntj*(ntj - 1))*hstride, firstK = (long) (T_ + ntj*0)*hstride;
+  const long rowHb = (long) (I + l)*SK_T + l, rowSn = (long) (I + l + SK_T - 1)*SK_T + l;
   u64 bits;
   long dst;
+  double sg;
   switch (plane) {
-  case 0: bits = hbJ[(long) ((ntj - 1) + ntj*T_)*hstride + (long) (I + l)*SK_T + l];
+  case 0: sg = A.sgn[2]; bits = sg == 0. ? hbJ[lastJ + rowHb] : snJ[firstJ + rowSn];     // ghost j = n + 1
     dst = A.L.idx (I + 1, n + 1, n - c); break;
-  case 1: bits = snJ[(long) (0 + ntj*T_)*hstride + (long) (I + l + SK_T - 1)*SK_T + l];
+  case 1: sg = A.sgn[3]; bits = sg == 0. ? snJ[firstJ + rowSn] : hbJ[lastJ + rowHb];     // ghost j = 0
     dst = A.L.idx (I + 1, 0, n - c); break;
-  case 2: bits = hbK[(long) (T_ + ntj*(ntj - 1))*hstride + (long) (I + l)*SK_T + l];
+  case 2: sg = A.sgn[4]; bits = sg == 0. ? hbK[lastK + rowHb] : snK[firstK + rowSn];     // ghost k = n + 1
     dst = A.L.idx (I + 1, n - c, n + 1); break;
-  default: bits = snK[(long) (T_ + ntj*0)*hstride + (long) (I + l + SK_T - 1)*SK_T + l];
+  default: sg = A.sgn[5]; bits = sg == 0. ? snK[firstK + rowSn] : hbK[lastK + rowHb];    // ghost k = 0
     dst = A.L.idx (I + 1, n - c, 0);
   }
-  A.un[dst] = __longlong_as_double ((long long) bits);
+  const double v = __longlong_as_double ((long long) bits);
+  A.un[dst] = sg == 0. ? v : sg*v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -420,7 +448,7 @@ bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool 
   if (!bc || nrelax < 2 || nrelax > SK_MAXF) return false;
   if (!skew_supported (dom, level)) return false;
   for (int d = 0; d < 6; d++)
-    if (dom->side[d] != GFSHIP_SIDE_PERIODIC) return false;
+    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL) return false;   /* the exchange comes between the sweeps */
   // every tile waits on tiles of the previous sweep: all of them must be resident
   int ntj = dom->lay[level].n/SK_T, ntiles = ntj*ntj;
   if (dom->skew_resident < 0) {
@@ -440,7 +468,7 @@ bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool 
 // pipelined sweep runs on (any sides; the BC kernel is applied around it by the caller, so the
 // cells next to the box sides are mirrored into the natural array).
 int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia,
-		   unsigned nrelax, float * ms)
+		   unsigned nrelax, float * ms, const Field * ubc)
 {
   const Layout & L = dom->lay[level];
   int ntiles = S->ntj*S->ntj;
@@ -457,6 +485,17 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   SkewLoopArgs A;
   A.L = L; A.ntj = S->ntj; A.RT = S->RT; A.nsweeps = (int) nrelax;
   A.mirror = nrelax == 1;
+  for (int d = 0; d < 6; d++) {
+    /* homogeneous BC of side d: symmetry src/boundary.c:45-51, dirichlet :253-268, neumann :336-347 */
+    double sg = 0.;
+    if (dom->side[d] != GFSHIP_SIDE_PERIODIC && ubc)
+      switch (ubc->bc[d]) {
+      case GFSHIP_BC_DIRICHLET: sg = -1.; break;
+      case GFSHIP_BC_NEUMANN: sg = 1.; break;
+      default: sg = ubc->component == d/2 ? -1. : 1.;
+      }
+    A.sgn[d] = sg;
+  }
   A.us = S->us; A.rs = S->rs; A.ds = has_dia ? S->ds : nullptr;
   A.un = u_nat;
   A.hb = (u64 *) S->hbf; A.hb_sweep = hb_sweep; A.hb_words = hb_words;

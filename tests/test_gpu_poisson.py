@@ -418,3 +418,50 @@ def test_four_wave_sweep_kernel_still_bit_exact(monkeypatch):
         L.go_relax(od.ptr, dim, level, 1., f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr)
         gd.relax(f["u"][1], f["rhs"][1], f["dia"][1])
         assert _faces_equal(f["u"][0].leaf(), f["u"][1].download(), dim)
+
+
+@pytest.mark.parametrize("level,kind,component", [(5, "dirichlet", -1), (6, "neumann", -1),
+                                                  (5, "symmetry", 1), (6, "mixed", -1),
+                                                  (5, "symmetry", -1)])
+def test_fused_relax_loop_non_periodic_sides_bit_exact(level, kind, component):
+    """the relax loop in one launch on boxes with Dirichlet / Neumann / symmetry sides (ghost lines
+    = +- the tile's own side lines of the previous sweep; the sign of a symmetry side depends on
+    the component of the variable) and on mixed periodic / non-periodic boxes, with a non-zero
+    dia: V-cycles against the oracle, interior, ghost layer and residual"""
+    L = O.lib()
+    dim = 3
+    side, bck = SIDES[kind]
+    rng = np.random.default_rng(5000 + level)
+    od, gd = _pair(dim, level, side)
+    L.go_poisson_coefficients(od.ptr)
+    gd.poisson_coefficients()
+    f = _rand_fields(od, gd, ["rhs", "dia", "res"], rng)
+    ou, gu = od.field(component), gd.variable(component)
+    a = rng.standard_normal(ou.leaf().shape)
+    ou.leaf()[...] = a
+    gu.upload(a)
+    f["u"] = (ou, gu)
+    for l in range(level + 1):
+        a = np.abs(rng.standard_normal(f["dia"][0].level(l).shape)) * 0.3
+        f["dia"][0].level(l)[...] = a
+        f["dia"][1].upload(a, l)
+    n = 1 << level
+    for d in range(2 * dim):
+        val = rng.standard_normal(n * n)
+        f["u"][0].set_bc(d, bck, val)
+        f["u"][1].set_bc(d, bck, val)
+    L.go_bc(f["u"][0].ptr, f["u"][0].ptr, level)
+    gd.bc(f["u"][1])
+    L.go_residual(od.ptr, dim, level, f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr,
+                  f["res"][0].ptr)
+    gd.residual(f["u"][1], f["rhs"][1], f["dia"][1], f["res"][1])
+    op, gp = od.params(), gd.params()
+    for p in (op, gp):
+        p.depth = level
+    for _ in range(2):
+        L.go_poisson_cycle(od.ptr, C.byref(op), f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr,
+                           f["res"][0].ptr)
+        gd.poisson_cycle(gp, f["u"][1], f["rhs"][1], f["dia"][1], f["res"][1])
+        assert _faces_equal(f["u"][0].leaf(), f["u"][1].download(), dim)
+        assert np.array_equal(_interior(f["res"][0].leaf(), dim),
+                              _interior(f["res"][1].download(), dim))
