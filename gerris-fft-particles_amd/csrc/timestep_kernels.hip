@@ -571,11 +571,13 @@ struct FacePair { double l, r; };   // f[2*d].v ("left state" of the + face) and
 // viscous MAC source may be present (all compile-time: the tiled kernels are issue-bound)
 template <int DIM, int D, bool CEN, bool VL, bool VS>
 __device__ __forceinline__ FacePair face_values_dir (const Layout & L, const double * __restrict__ v,
-						     const CPtr3 & u, const CPtr3 & un, long c,
+						     const CPtr3 & u, const CPtr3 & un, int c,
 						     double dt, double visc)
 {
   const int use_centered_velocity = CEN, gradient = VL;
-  const long off[3] = { 1, L.sy, L.sz };
+  // 32-bit cell indices (a level has far fewer than 2^31 doubles): the loads take a uniform base
+  // pointer plus a 32-bit offset instead of 64-bit address arithmetic per access
+  const int off[3] = { 1, (int) L.sy, (int) L.sz };
   const double rsize = (double) L.n, rsize2 = (double) L.n/2.;   /* 1/size, 1/(2.*size) */
   const double v0 = v[c];
   double tt[3] = { 0., 0., 0. };
@@ -583,7 +585,7 @@ __device__ __forceinline__ FacePair face_values_dir (const Layout & L, const dou
   for (int cc = 0; cc < DIM; cc++)
     if (cc != D) {
       double vtan = use_centered_velocity ? u.p[cc][c] : (un.p[cc][c] + un.p[cc][c - off[cc]])/2.;
-      long nb = vtan > 0. ? c - off[cc] : c + off[cc];
+      int nb = vtan > 0. ? c - off[cc] : c + off[cc];
       double g = v[nb] - 1.*v0;
       if (vtan > 0.) g = - g;
       tt[cc] = dt*vtan*g*rsize2;
@@ -596,8 +598,10 @@ __device__ __forceinline__ FacePair face_values_dir (const Layout & L, const dou
   double vl = v0 + GMIN ((1. - unorm)/2., 0.5)*g;
   double vr = v0 + GMAX ((- 1. - unorm)/2., -0.5)*g;
   double msrc = 0.;
-  if (VS && visc != 0.)
-    msrc = 0. + source_diffusion_value<DIM> (v, c, off, visc, L.n);
+  if (VS && visc != 0.) {
+    const long off64[3] = { 1, L.sy, L.sz };
+    msrc = 0. + source_diffusion_value<DIM> (v, c, off64, visc, L.n);
+  }
   double src = dt*msrc/2.;
   double dv;
   if (DIM == 2)
@@ -615,13 +619,13 @@ __device__ __forceinline__ FacePair face_values_dir (const Layout & L, const dou
 
 // index of the interior image of cell (i,j,k), each coordinate in [0, n+1]
 template <int DIM>
-__device__ __forceinline__ long image (const Layout & L, int i, int j, int k)
+__device__ __forceinline__ int image (const Layout & L, int i, int j, int k)
 {
   const int n = L.n;
   i = i < 1 ? i + n : i > n ? i - n : i;
   j = j < 1 ? j + n : j > n ? j - n : j;
   if (DIM == 3) k = k < 1 ? k + n : k > n ? k - n : k;
-  return L.idx (i, j, k);
+  return (int) L.idx (i, j, k);
 }
 
 // Tiles of GX x GY x GZ cells, one thread per cell.  Phase 1: every thread computes the face
@@ -655,8 +659,8 @@ predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc)
   __shared__ double hp[3][GX*GZ];          // r of the cell beyond the + face of the tile
   const TileIdx T;
   const int n = L.n;
-  const long c = L.idx (T.i, T.j, T.k);
-  const long off[3] = { 1, L.sy, L.sz };
+  const int c = (int) L.idx (T.i, T.j, T.k);
+  const int off[3] = { 1, (int) L.sy, (int) L.sz };
   CPtr3 none = { { nullptr, nullptr, nullptr } };
   {
     FacePair f = face_values_dir<3, 0, true, VL, VS> (L, u.p[0], u, none, c, dt, visc.d[0]);
@@ -672,17 +676,17 @@ predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc)
     const int h = threadIdx.x;
     if (h < GX*GZ) {
       int p = h % GX, q = h / GX;
-      long ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + GY + 1, blockIdx.z*GZ + q + 1);
+      int ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + GY + 1, blockIdx.z*GZ + q + 1);
       hp[1][h] = face_values_dir<3, 1, true, VL, VS> (L, u.p[1], u, none, ci, dt, visc.d[1]).r;
     }
     else if (h < GX*GZ + GX*GY) {
       int hh = h - GX*GZ, p = hh % GX, q = hh / GX;
-      long ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + q + 1, blockIdx.z*GZ + GZ + 1);
+      int ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + q + 1, blockIdx.z*GZ + GZ + 1);
       hp[2][hh] = face_values_dir<3, 2, true, VL, VS> (L, u.p[2], u, none, ci, dt, visc.d[2]).r;
     }
     if (h < GY*GZ) {
       int p = h % GY, q = h / GY;
-      long ci = image<3> (L, blockIdx.x*GX + GX + 1, blockIdx.y*GY + p + 1, blockIdx.z*GZ + q + 1);
+      int ci = image<3> (L, blockIdx.x*GX + GX + 1, blockIdx.y*GY + p + 1, blockIdx.z*GZ + q + 1);
       hp[0][h] = face_values_dir<3, 0, true, VL, VS> (L, u.p[0], u, none, ci, dt, visc.d[0]).r;
     }
   }
@@ -703,7 +707,7 @@ predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc)
     un.p[d][c] = val;
     // the face on the low side of the box is the periodic image of the one on the high side
     if (ijk[d] == n)
-      un.p[d][c - (long) n*off[d]] = val;
+      un.p[d][c - n*off[d]] = val;
   }
 }
 
@@ -720,8 +724,8 @@ advect_tiled_kernel (Layout L, const double * __restrict__ v, double * __restric
   const TileIdx T;
   const int n = L.n;
   const double rn = (double) n;
-  const long c = L.idx (T.i, T.j, T.k);
-  const long off[3] = { 1, L.sy, L.sz };
+  const int c = (int) L.idx (T.i, T.j, T.k);
+  const int off[3] = { 1, (int) L.sy, (int) L.sz };
   CPtr3 none = { { nullptr, nullptr, nullptr } };
   {
     FacePair f = face_values_dir<3, 0, false, VL, VS> (L, v, none, un, c, dt, visc);
@@ -738,18 +742,18 @@ advect_tiled_kernel (Layout L, const double * __restrict__ v, double * __restric
     const int h = threadIdx.x;
     const int grp = h / (GX*GZ), idx = h % (GX*GZ), p = idx % GX, q = idx / GX;
     if (grp < 2) {
-      long ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + (grp ? GY + 1 : 0), blockIdx.z*GZ + q + 1);
+      int ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + (grp ? GY + 1 : 0), blockIdx.z*GZ + q + 1);
       FacePair f = face_values_dir<3, 1, false, VL, VS> (L, v, none, un, ci, dt, visc);
       if (grp) hp[1][idx] = f.r; else hm[1][idx] = f.l;
     }
     else {
-      long ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + q + 1, blockIdx.z*GZ + (grp == 3 ? GZ + 1 : 0));
+      int ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + q + 1, blockIdx.z*GZ + (grp == 3 ? GZ + 1 : 0));
       FacePair f = face_values_dir<3, 2, false, VL, VS> (L, v, none, un, ci, dt, visc);
       if (grp == 3) hp[2][idx] = f.r; else hm[2][idx] = f.l;
     }
     if (h < 2*GY*GZ) {
       const int plus = h >= GY*GZ, hh = h % (GY*GZ), py = hh % GY, qz = hh / GY;
-      long ci = image<3> (L, blockIdx.x*GX + (plus ? GX + 1 : 0), blockIdx.y*GY + py + 1, blockIdx.z*GZ + qz + 1);
+      int ci = image<3> (L, blockIdx.x*GX + (plus ? GX + 1 : 0), blockIdx.y*GY + py + 1, blockIdx.z*GZ + qz + 1);
       FacePair f = face_values_dir<3, 0, false, VL, VS> (L, v, none, un, ci, dt, visc);
       if (plus) hp[0][hh] = f.r; else hm[0][hh] = f.l;
     }
@@ -760,7 +764,7 @@ advect_tiled_kernel (Layout L, const double * __restrict__ v, double * __restric
   const int hi[3] = { T.ty + GY*T.tz, T.tx + GX*T.tz, T.tx + GX*T.ty };
   // flux through the + face (direction cf) of the own cell (minus = 0) or of the cell before it
   auto flux = [&] (int cf, int minus) -> double {
-    long a = minus ? c - off[cf] : c;
+    int a = minus ? c - off[cf] : c;
     double l_, r_;
     if (!minus) {
       l_ = fl[cf][T.own ()];
