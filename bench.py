@@ -84,8 +84,16 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # GFSHIP_DIST_BACKEND=gloo: rehearsal of the N > 1 path with several ranks on one GPU
+        # (halos staged through the host, gfship/distributed.py); never used for reported numbers
+        backend = os.environ.get("GFSHIP_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
 
     import gfship
     n = 1 << args.level

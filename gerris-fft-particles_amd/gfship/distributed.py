@@ -78,6 +78,9 @@ class Transport:
         self.device = device if device is not None else torch.device("cpu")
         self._bufs = {}
         self._ops = {}
+        # rehearsal of the device path without RCCL (several ranks on one GPU, which RCCL
+        # refuses): device buffers are staged through the host and sent over gloo
+        self.staged = self.device.type == "cuda" and dist.get_backend() == "gloo"
 
     def buffers(self, key, nface):
         """(send, recv) buffers per side for messages of nface doubles"""
@@ -96,6 +99,18 @@ class Transport:
         send_sides; receive into rcv[r], for r in recv_sides, the layer that the neighbour across
         my side r sent from its side r^1."""
         dist = self.dist
+        if self.staged:
+            hs = {s: snd[s].cpu() for s in send_sides}
+            hr = {r: self.torch.empty(rcv[r].shape, dtype=rcv[r].dtype) for r in recv_sides}
+            ops = [dist.P2POp(dist.isend, hs[s], self.grid.neighbour(self.rank, s), tag=s)
+                   for s in sorted(send_sides)]
+            ops += [dist.P2POp(dist.irecv, hr[r], self.grid.neighbour(self.rank, r), tag=r ^ 1)
+                    for r in sorted(recv_sides, key=lambda x: x ^ 1)]
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+            for r in recv_sides:
+                rcv[r].copy_(hr[r])
+            return
         # the descriptors only name persistent buffers: built once per (buffers, sides)
         key = (id(snd), id(rcv), tuple(send_sides), tuple(recv_sides))
         ops = self._ops.get(key)
@@ -116,12 +131,21 @@ class Transport:
         through my side r}.  Counts first, then the payloads, matched like the halo messages."""
         t, dist = self.torch, self.dist
         sides = sorted(out)
-        cnt_s = {s: t.tensor([len(out[s])], dtype=t.int64, device=self.device) for s in sides}
-        cnt_r = {s: t.zeros(1, dtype=t.int64, device=self.device) for s in sides}
-        self.exchange(sides, cnt_s, sides, cnt_r)
-        snd = {s: t.from_numpy(np.ascontiguousarray(out[s]).ravel()).to(self.device)
+        dev = "cpu" if self.staged else self.device
+        cnt_s = {s: t.tensor([len(out[s])], dtype=t.int64, device=dev) for s in sides}
+        cnt_r = {s: t.zeros(1, dtype=t.int64, device=dev) for s in sides}
+        if self.staged:
+            ops = [dist.P2POp(dist.isend, cnt_s[s], self.grid.neighbour(self.rank, s), tag=50 + s)
+                   for s in sides]
+            ops += [dist.P2POp(dist.irecv, cnt_r[r], self.grid.neighbour(self.rank, r), tag=50 + (r ^ 1))
+                    for r in sorted(sides, key=lambda x: x ^ 1)]
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+        else:
+            self.exchange(sides, cnt_s, sides, cnt_r)
+        snd = {s: t.from_numpy(np.ascontiguousarray(out[s]).ravel()).to(dev)
                for s in sides if len(out[s])}
-        rcv = {r: t.empty(7 * int(cnt_r[r].item()), dtype=t.float64, device=self.device)
+        rcv = {r: t.empty(7 * int(cnt_r[r].item()), dtype=t.float64, device=dev)
                for r in sides if int(cnt_r[r].item())}
         # every box knows which of its messages are empty on both ends: only the others are posted
         ops = []
@@ -136,7 +160,7 @@ class Transport:
 
     def allreduce(self, vals, op):
         t, dist = self.torch, self.dist
-        x = t.tensor(vals, dtype=t.float64, device=self.device)
+        x = t.tensor(vals, dtype=t.float64, device="cpu" if self.staged else self.device)
         dist.all_reduce(x, op={0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}[op])
         return x.cpu().numpy()
 
