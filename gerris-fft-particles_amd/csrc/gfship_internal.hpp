@@ -93,6 +93,7 @@ struct gfship_domain {
   bool has_external = false;
   gfship_field dp_cache = -1;     // the `dp` temporary of gfs_poisson_cycle, kept between cycles
   int skew_resident = -1;         // workgroups of the fused relax loop that fit on the device
+  bool wave_loop = false;         // fused relax loops by the experimental one-wave-per-tile kernel (GFSHIP_WAVE_LOOP=1)
   bool skew_old = false;          // single sweeps by the older four-wave kernel (GFSHIP_SKEW_OLD)
   bool no_fused_godunov = false;  // face-value arrays + separate kernels even on periodic boxes
   bool no_fused_loop = false;     // one launch per sweep even where the fused loop applies

@@ -17,10 +17,10 @@ namespace gfship {
 /* rows of padding in front of and behind every tile, so that prefetch addresses never need
    clamping: 15 rows in front (first lines of the next tile are read at row t - 15), 2*SK_D behind
    (rows up to T + SK_D, T rounded up to SK_D) */
-#define SK_FP  (2*SK_D > 16 ? 2*SK_D : 16)
+#define SK_FP  48
 /* rows of a tile's hand-off / snapshot granule array: n + 30 used, the streams read ahead by up
    to SK_D (rounding of T) + SK_DH + 1 rows */
-#define SK_HROWS(n_) ((n_) + 2*SK_T + SK_D + SK_DH)
+#define SK_HROWS(n_) ((n_) + 2*SK_T + SK_D + SK_DH + 16)
 
 typedef unsigned long long u64;
 #define SK_SENTINEL 0xFFFFFFFFFFFFFFFFull

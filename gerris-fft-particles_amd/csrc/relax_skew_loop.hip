@@ -398,6 +398,326 @@ relax_skew_loop_kernel (SkewLoopArgs A)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Staggered waves: the exchange between neighbouring lines taken off LDS + barrier.
+//
+// The sweeps of a loop on a periodic box follow each other at the pace of the dependency chain
+// across the box (the first tile row needs the hand-off of the last one: 15 hops per sweep), so a
+// loop takes ~ 75 hops and a hop is ~ 21 steps + the hand-off latency: what counts is the latency
+// of ONE step.  In the six-wave kernel above a step is LDS write -> barrier -> LDS read -> 10
+// dependent fp64 operations (0.18 us without any memory instruction, tools/lab/step_lab.hip).
+// Here wave w = 0..3 owns the lines b = 4w .. 4w+3, lane (a, p): a = lane & 15, p = lane >> 4,
+// b = 4w + p (column a + 16 b = lane + 64 w: a wave's cells of a row are 512 contiguous bytes),
+// and runs w steps behind wave 0: I = t - w - a - b.  Then
+//   line (a, b-1), new .... ds_bpermute from lane - 16 of the same wave; for p = 0 the value wave
+//                           w - 1 computed TWO steps earlier (one step of slack: through LDS, read
+//                           a step ahead, off the chain) or the K- strip of the helper wave
+//   line (a-1, b), new .... DPP row_shr:1 (rows of 16 lanes = one b); lane a = 0 keeps the DPP
+//                           `old' operand = the J- strip value
+//   line (a+1, b), old .... DPP row_shl:1 of the prefetched row, `old' = J+ strip value
+//   line (a, b+1), old .... its own prefetched global load (same row, 16 columns on)
+// so no barrier and no LDS round trip is on the chain of a step; the barrier that all waves still
+// meet at once per step only orders the LDS buffers.  (One wave per tile with four lines per lane,
+// tools/lab/wave_lab.hip, was tried first: a wave64 instruction takes 4 cycles on the 16-lane
+// SIMD, 190 instructions per step = 0.37 us.)  The helper wave does what the halo and store
+// waves do above, two steps ahead / one step behind.  Same layout, granules and ghost kernel.
+// ---------------------------------------------------------------------------------------------
+#ifndef WV_D
+#define WV_D 16                /* prefetch distance of the own streams (steps) */
+#endif
+#ifndef WV_DH
+#define WV_DH 8                /* prefetch distance of the helper wave's strips (steps) */
+#endif
+#define WV_TQ 16               /* the step count is a multiple of WV_D and WV_DH */
+#define WV_NTHREADS 320
+#ifndef WV_KO
+#define WV_KO 0      /* timing experiments only: knock out parts of the step (wrong results) */
+#endif
+#define WV_BARRIER() asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define WV_STEP_BARRIER() do { if (WV_KO & 8) asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory"); else WV_BARRIER (); } while (0)
+
+// lanes without a source in the row keep oldv
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64 (double oldv, double v)
+{
+  const long long bv = __double_as_longlong (v), ov = __double_as_longlong (oldv);
+  const int lo = __builtin_amdgcn_update_dpp ((int) ov, (int) bv, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp ((int) (ov >> 32), (int) (bv >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double (((long long) hi << 32) | (unsigned) lo);
+}
+
+__device__ __forceinline__ double bperm_f64 (int addr, double v)
+{
+  const long long bv = __double_as_longlong (v);
+  const int lo = __builtin_amdgcn_ds_bpermute (addr, (int) bv);
+  const int hi = __builtin_amdgcn_ds_bpermute (addr, (int) (bv >> 32));
+  return __longlong_as_double (((long long) hi << 32) | (unsigned) lo);
+}
+
+__global__ void __launch_bounds__(WV_NTHREADS)
+relax_wave_loop_kernel (SkewLoopArgs A)
+{
+  // strips by g = 0..3, 16 values each: in  (-1,m) new, (m,-1) new, (16,m) old, (m,16) old
+  //                                      out (15,m), (m,15) hand-off, (0,m), (m,0) snapshot
+  __shared__ double H[4][64];     // slot t & 3: incoming strips of step t (strip 0 = XW[0])
+  __shared__ double O[2][64];     // slot (t + 1) & 1: outgoing values of step t
+  __shared__ double XW[4][4][16]; // [w][slot t & 3]: line (a, 4w - 1) for wave w at step t
+  __shared__ unsigned s_tile;
+
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane (tid0 >> 6);
+  const int lane = tid0 & 63;
+  const int n = A.L.n;
+  const int ntj = A.ntj;
+  const long tstride = (long) (A.RT + 2*SK_FP)*SK_NL;
+  const long hstride = (long) SK_HROWS (n)*SK_T;
+
+  if (tid0 == 0)
+    s_tile = A.order[atomicAdd (A.ticket, 1u)];
+  __syncthreads ();
+  const int tile = s_tile;
+  const int P = tile % ntj, Q = tile / ntj;
+  // local steps 0 .. n + 30 of wave 3 end at step n + 33; one more for the helper wave
+  const int T = (n + SK_PAD + 4 + WV_TQ)/WV_TQ*WV_TQ;
+  double * const ut = A.us + tile*tstride + SK_FP*SK_NL;
+
+  // The compute waves and the helper wave run through separate code from here on (same number of
+  // barriers): the counted s_waitcnt vmcnt of the software pipeline must not be merged with the
+  // memory operations of the other role by the compiler.
+  if (wave < 4) {
+    // =========================== compute waves ===========================
+    const int w = wave;
+    const int a = lane & 15, p = lane >> 4, b = 4*w + p;
+    const int j = n - (SK_T*P + a), k = n - (SK_T*Q + b);
+    const int se = w + a + b;                      // I = t - se
+    const int col = a + SK_T*b;                    // = lane + 64 w: the wave's cells of a row are contiguous
+    const int up = ((lane - 16) & 63)*4;
+    const bool lastB = b == SK_T - 1;              // line (a, 16) comes from the helper wave
+    const double * const frontsrc = w == 0 ? &H[0][16] + a : &XW[w][0][0] + a;
+    const int frontstride = w == 0 ? 64 : 16;      // doubles per slot
+
+    double ghostL = A.un[A.L.idx (0, j, k)];
+    double ghostR = A.un[A.L.idx (n + 1, j, k)];
+    asm volatile ("" :: "v" (ghostL), "v" (ghostR));   // complete before the pipeline starts
+
+    for (int sw = 0; sw < A.nsweeps; sw++) {
+      const bool write_ghosts = sw + 2 == A.nsweeps;
+      // wave w is at row t - w
+      const double * qR = ut + (long) (1 - w)*SK_NL + col;
+      const double * qRhs = A.rs + tile*tstride + (long) (SK_FP - w)*SK_NL + col;
+      double * wU = ut - (long) w*SK_NL + col;
+      double pR[WV_D], pB[WV_D], pRhs[WV_D];
+
+      if (A.stats && tid0 == 0)
+	A.stats[2*(tile*SK_MAXF + sw)] = __builtin_amdgcn_s_memrealtime ();
+      // prologue with the memory instructions of WV_D steps (the stores go to unused rows in front
+      // of the tile): same vmcnt distances as in the loop
+#pragma unroll
+      for (int q = 0; q < WV_D; q++) {
+	pR[q] = qR[0]; pB[q] = qR[SK_T]; qR += SK_NL;
+	pRhs[q] = *qRhs; qRhs += SK_NL;
+	*(wU - (long) (WV_D - q)*SK_NL) = 0.;
+	asm volatile ("" ::: "memory");          /* keep the order */
+      }
+      WV_BARRIER ();       // the LDS buffers of the previous sweep are no longer read
+      WV_BARRIER ();       // strips of steps 0 and 1 are in H
+
+      double prev = ghostL, first = 0., N = 0.;
+      double frontH = frontsrc[0], hJm = H[0][b], hJp = H[0][32 + b], hKp = H[0][48 + a];
+
+      for (int t0 = 0; t0 < T; t0 += WV_D) {
+#pragma unroll
+	for (int q = 0; q < WV_D; q++) {
+	  const int t = t0 + q;
+	  // values from outside the wave for the next step (written before the last barrier)
+	  const double nfrontH = frontsrc[((t + 1) & 3)*frontstride];
+	  const double * Hn = H[(t + 1) & 3];
+	  const double nJm = Hn[b], nJp = Hn[32 + b], nKp = Hn[48 + a];
+	  const double Rn = pR[q];               // own cell of row t - w + 1
+	  const int I = t - se;
+	  const bool act = I >= 0 && I < n;
+	  double front = (WV_KO & 16) ? N : bperm_f64 (up, N);
+	  front = p == 0 ? frontH : front;
+	  const double top = (WV_KO & 32) ? hJm : dpp_f64<0x111> (hJm, N);        /* row_shr:1, lane a = 0 keeps the strip */
+	  const double bot = (WV_KO & 32) ? hJp : dpp_f64<0x101> (hJp, Rn);       /* row_shl:1, lane a = 15 keeps the strip */
+	  const double back = lastB ? hKp : pB[q];
+	  // relax, src/poisson.c:507-530, unit weights, d = 0..5 = right,left,top,bottom,front,back
+	  const double Rv = (I + 1 < n) ? Rn : ghostR;
+	  double bb = 0.;
+	  bb += 1.*Rv;
+	  bb += 1.*prev;
+	  bb += 1.*top;
+	  bb += 1.*bot;
+	  bb += 1.*front;
+	  bb += 1.*back;
+	  const double v = divide_by_6 (bb - pRhs[q]);
+	  prev = act ? v : prev;
+	  first = I == 0 ? v : first;
+	  N = v;
+	  // for the next wave (two steps later) and the helper wave (next step)
+	  if (!(WV_KO & 2)) {
+	    double * const Ow = O[(t & 1) ^ 1];
+	    if (p == 3) {
+	      if (w == 3) Ow[16 + a] = v;
+	      else XW[w + 1][(t + 2) & 3][a] = v;
+	    }
+	    if (a == SK_T - 1) Ow[b] = v;
+	    if (a == 0) Ow[32 + b] = v;
+	    if (b == 0) Ow[48 + a] = v;
+	  }
+	  if (!(WV_KO & 4)) {
+	    pR[q] = qR[0]; pB[q] = qR[SK_T]; qR += SK_NL;
+	    pRhs[q] = *qRhs; qRhs += SK_NL;
+	    *wU = v; wU += SK_NL;
+	  }
+	  frontH = nfrontH; hJm = nJm; hJp = nJp; hKp = nKp;
+	  WV_STEP_BARRIER ();
+	}
+      }
+      if (A.stats && tid0 == 0)
+	A.stats[2*(tile*SK_MAXF + sw) + 1] = __builtin_amdgcn_s_memrealtime ();
+      // ghosts of the line for the next sweep: the periodic image, or the homogeneous BC of the side
+      {
+	const double last = prev;
+	ghostL = A.sgn[1] == 0. ? last : A.sgn[1]*first;
+	ghostR = A.sgn[0] == 0. ? first : A.sgn[0]*last;
+      }
+      if (write_ghosts) {
+	A.un[A.L.idx (n + 1, j, k)] = ghostR;
+	A.un[A.L.idx (0, j, k)] = ghostL;
+      }
+    }
+  }
+  else {
+    // =========================== helper wave ===========================
+    const int g = lane >> 4, m = lane & 15;        // strip g, line m of the strip
+    const int tJm = (P > 0 ? P - 1 : ntj - 1) + ntj*Q, tJp = (P + 1 < ntj ? P + 1 : 0) + ntj*Q;
+    const int tKm = P + ntj*(Q > 0 ? Q - 1 : ntj - 1), tKp = P + ntj*(Q + 1 < ntj ? Q + 1 : 0);
+    const int jm = n - (SK_T*P + m), km = n - (SK_T*Q + m);
+    // the wave that consumes / produces the line of this lane runs woff steps behind wave 0
+    const int wIn = g == 1 ? 0 : g == 3 ? 3 : m >> 2;
+    const int wOut = g == 1 ? 3 : g == 3 ? 0 : m >> 2;
+    const int hlag = (g < 2 ? m : m + SK_T - 1) + wIn;
+    bool failed = false;
+
+    for (int sw = 0; sw < A.nsweeps; sw++) {
+      const bool more = sw + 1 < A.nsweeps;
+      u64 * const hbJ = A.hb + sw*A.hb_sweep, * const hbK = hbJ + A.hb_words;
+      u64 * const snJ = hbK + A.hb_words, * const snK = snJ + A.hb_words;
+      const u64 * const hbJp = hbJ - A.hb_sweep, * const hbKp = hbK - A.hb_sweep;
+      const u64 * const snJp = snJ - A.hb_sweep, * const snKp = snK - A.hb_sweep;
+
+      // ---- incoming strips: same sources as in relax_skew_loop_kernel ----
+      const u64 * qH = A.dummy;
+      int hs = 0;
+      bool handoff = false;
+      double hsgn = 1.;
+      switch (g) {
+      case 0:
+	if (P > 0)       { qH = hbJ + (long) tJm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0 && A.sgn[2] == 0.) { qH = hbJp + (long) tJm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = snJp + (long) tile*hstride + m + (long) (SK_T - 1)*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[2]; }
+	else             { qH = (const u64 *) (A.un + A.L.idx (1 - m, n + 1, km)); hs = 1; }
+	break;
+      case 1:
+	if (Q > 0)       { qH = hbK + (long) tKm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0 && A.sgn[4] == 0.) { qH = hbKp + (long) tKm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = snKp + (long) tile*hstride + m + (long) (SK_T - 1)*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[4]; }
+	else             { qH = (const u64 *) (A.un + A.L.idx (1 - m, jm, n + 1)); hs = 1; }
+	break;
+      case 2:
+	if (sw > 0 && (P + 1 < ntj || A.sgn[3] == 0.)) { qH = snJp + (long) tJp*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = hbJp + (long) tile*hstride + m - (long) (SK_T - 1)*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[3]; }
+	else if (P + 1 < ntj) {
+	  qH = (const u64 *) (A.us + tJp*tstride + SK_FP*SK_NL - (long) (SK_T - 1)*SK_NL + SK_T*m);
+	  hs = SK_NL;
+	}
+	else { qH = (const u64 *) (A.un + A.L.idx (1 - (SK_T - 1 + m), 0, km)); hs = 1; }
+	break;
+      default:
+	if (sw > 0 && (Q + 1 < ntj || A.sgn[5] == 0.)) { qH = snKp + (long) tKp*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = hbKp + (long) tile*hstride + m - (long) (SK_T - 1)*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[5]; }
+	else if (Q + 1 < ntj) {
+	  qH = (const u64 *) (A.us + tKp*tstride + SK_FP*SK_NL - (long) (SK_T - 1)*SK_NL + m);
+	  hs = SK_NL;
+	}
+	else { qH = (const u64 *) (A.un + A.L.idx (1 - (m + SK_T - 1), jm, 0)); hs = 1; }
+      }
+      const u64 * const qH0 = qH;
+      // row of the stream for step t_ of wave 0: the consumer wave is at its step t_ - wIn (the rows
+      // in front of the first one are never used: clamped)
+#define WV_ROW(t_) (qH0 + (long) ((t_) - wIn > 0 ? (t_) - wIn : 0)*hs)
+
+      // ---- outgoing lines: granule of cell I of the line = row I + m (hand-off) / I + m + 15 (snapshot) ----
+      u64 * pS;
+      bool sOn;
+      switch (g) {
+      case 0: sOn = P + 1 < ntj || more; pS = hbJ + (long) tile*hstride + m; break;
+      case 1: sOn = Q + 1 < ntj || more; pS = hbK + (long) tile*hstride + m; break;
+      case 2: sOn = more; pS = snJ + (long) tile*hstride + m + (long) (SK_T - 1)*SK_T; break;
+      default: sOn = more; pS = snK + (long) tile*hstride + m + (long) (SK_T - 1)*SK_T;
+      }
+      const int sLag = (g < 2 ? SK_T - 1 + m : m) + wOut;   // I = t - 1 - sLag for the value in O[t & 1]
+      pS += (long) m*SK_T;                                   // row I + m
+
+      // strip value hv_ of step t_ into the ring (waits for a granule that is not there yet)
+#define WV_HALO_PUT(t_, hv_)						\
+      do {								\
+	double hv = (hv_);						\
+	bool wt = handoff && !failed && (unsigned) ((t_) - hlag) < (unsigned) n && \
+	  (u64) __double_as_longlong (hv) == SK_SENTINEL;		\
+	if (__builtin_expect (__any (wt), 0)) {				\
+	  unsigned spins = 0;						\
+	  _Pragma ("nounroll")						\
+	  while (__any (wt)) {						\
+	    __builtin_amdgcn_s_sleep (SK_POLL_SLEEP);			\
+	    if (wt) {							\
+	      hv = __longlong_as_double ((long long) load_sc1 (WV_ROW (t_))); \
+	      wt = (u64) __double_as_longlong (hv) == SK_SENTINEL;	\
+	    }								\
+	    if (++spins > (1u << 18)) { *A.err = 1; failed = true; break; } \
+	  }								\
+	}								\
+	H[(t_) & 3][lane] = hv*hsgn;					\
+      } while (0)
+
+      double pH[WV_DH];
+      const double h0 = __longlong_as_double ((long long) load_sc1 (WV_ROW (0)));
+      const double h1 = __longlong_as_double ((long long) load_sc1 (WV_ROW (1)));
+#pragma unroll
+      for (int q = 0; q < WV_DH; q++)
+	pH[q] = __longlong_as_double ((long long) load_sc1 (WV_ROW (2 + q)));
+      WV_BARRIER ();       // the LDS buffers of the previous sweep are no longer read
+      WV_HALO_PUT (0, h0);
+      WV_HALO_PUT (1, h1);
+      WV_BARRIER ();
+
+      for (int t0 = 0; t0 < T; t0 += WV_DH) {
+#pragma unroll
+	for (int q = 0; q < WV_DH; q++) {
+	  const int t = t0 + q;
+	  if (!(WV_KO & 1)) {
+	    // the value a line computed at step t - 1 sits in O[t & 1]
+	    const int I = t - 1 - sLag;
+	    if (sOn && I >= 0 && I < n)
+	      store_sc1 (pS + (long) I*SK_T, (u64) __double_as_longlong (O[t & 1][lane]));
+	    // strips of step t + 2
+	    WV_HALO_PUT (t + 2, pH[q]);
+	    pH[q] = __longlong_as_double ((long long) load_sc1 (WV_ROW (t + 2 + WV_DH)));
+	  }
+	  WV_STEP_BARRIER ();
+	}
+      }
+#undef WV_HALO_PUT
+#undef WV_ROW
+    }
+  }
+}
+
 // y and z ghost planes left by the last BC application of the loop = periodic images (or, at a
 // non-periodic side, +- the adjacent line) of the side cells after sweep nsweeps - 2, taken from
 // that sweep's granules:
@@ -452,14 +772,16 @@ bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool 
   // every tile waits on tiles of the previous sweep: all of them must be resident
   int ntj = dom->lay[level].n/SK_T, ntiles = ntj*ntj;
   if (dom->skew_resident < 0) {
-    int per_cu = 0, dev = 0;
+    int per_cu = 0, per_cu_w = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice (&dev) != hipSuccess || hipGetDeviceProperties (&prop, dev) != hipSuccess ||
 	hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_skew_loop_kernel<true>,
-						      SK_NTHREADS, 0) != hipSuccess)
+						      SK_NTHREADS, 0) != hipSuccess ||
+	hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu_w, relax_wave_loop_kernel,
+						      WV_NTHREADS, 0) != hipSuccess)
       dom->skew_resident = 0;
     else
-      dom->skew_resident = per_cu*prop.multiProcessorCount;
+      dom->skew_resident = (per_cu < per_cu_w ? per_cu : per_cu_w)*prop.multiProcessorCount;
   }
   return ntiles <= dom->skew_resident;
 }
@@ -479,7 +801,8 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
     GFSHIP_HIP (hipMalloc ((void **) &S->hbf, (size_t) SK_MAXF*hb_sweep*sizeof (u64)));
   }
   GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
-  /* a single sweep only uses the two hand-off arrays of its granule set */
+  /* a single sweep only uses the two hand-off arrays of its granule set.  (Arming the granules on a
+     side stream, with two sets used in turn, was tried: no gain, the stores compete for HBM.) */
   GFSHIP_HIP (hipMemsetAsync (S->hbf, 0xFF, (nrelax > 1 ? (size_t) nrelax*hb_sweep : (size_t) 2*hb_words)*
 			      sizeof (u64), dom->stream));
   SkewLoopArgs A;
@@ -510,7 +833,9 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
     A.stats = (u64 *) S->stats_loop;
   }
   if (ms) GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
-  if (has_dia)
+  if (dom->wave_loop && nrelax >= 2 && !has_dia)     /* one compute wave per tile */
+    hipLaunchKernelGGL (relax_wave_loop_kernel, dim3 (ntiles), dim3 (WV_NTHREADS), 0, dom->stream, A);
+  else if (has_dia)
     hipLaunchKernelGGL (relax_skew_loop_kernel<true>, dim3 (ntiles), dim3 (SK_NTHREADS), 0, dom->stream, A);
   else
     hipLaunchKernelGGL (relax_skew_loop_kernel<false>, dim3 (ntiles), dim3 (SK_NTHREADS), 0, dom->stream, A);
@@ -520,12 +845,14 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
     GFSHIP_HIP (hipEventSynchronize (dom->ev1));
     GFSHIP_HIP (hipEventElapsedTime (ms, dom->ev0, dom->ev1));
   }
+  if (nrelax >= 2) {
+    int block = L.n >= 256 ? 256 : L.n >= 128 ? 128 : 64;
+    hipLaunchKernelGGL (skew_loop_ghosts_kernel, dim3 ((L.n + block - 1)/block, L.n, 4), dim3 (block),
+			0, dom->stream, A);
+    GFSHIP_HIP (hipGetLastError ());
+  }
   if (nrelax < 2)
     return GFSHIP_OK;
-  int block = L.n >= 256 ? 256 : L.n >= 128 ? 128 : 64;
-  hipLaunchKernelGGL (skew_loop_ghosts_kernel, dim3 ((L.n + block - 1)/block, L.n, 4), dim3 (block),
-		      0, dom->stream, A);
-  GFSHIP_HIP (hipGetLastError ());
   if (A.stats && ms) {
     (void) hipStreamSynchronize (dom->stream);
     std::vector<u64> h ((size_t) ntiles*SK_MAXF*2);

@@ -465,3 +465,43 @@ def test_fused_relax_loop_non_periodic_sides_bit_exact(level, kind, component):
         assert _faces_equal(f["u"][0].leaf(), f["u"][1].download(), dim)
         assert np.array_equal(_interior(f["res"][0].leaf(), dim),
                               _interior(f["res"][1].download(), dim))
+
+
+@pytest.mark.parametrize("level,kind", [(6, "periodic"), (5, "mixed"), (7, "periodic")])
+def test_one_wave_per_tile_loop_kernel_bit_exact(monkeypatch, level, kind):
+    """GFSHIP_WAVE_LOOP=1 selects the experimental relax_wave_loop_kernel (one compute wave per tile,
+    neighbours through DPP / ds_bpermute instead of LDS + barrier) for the fused
+    loops with dia == 0: V-cycles against the oracle, interior, ghost layer and residual"""
+    monkeypatch.setenv("GFSHIP_WAVE_LOOP", "1")
+    L = O.lib()
+    dim = 3
+    side, bck = SIDES[kind]
+    rng = np.random.default_rng(6000 + level)
+    od, gd = _pair(dim, level, side)
+    L.go_poisson_coefficients(od.ptr)
+    gd.poisson_coefficients()
+    f = _rand_fields(od, gd, ["u", "rhs", "dia", "res"], rng)
+    for l in range(level + 1):
+        f["dia"][0].level(l)[...] = 0.
+        f["dia"][1].fill(0., l)
+    if kind != "periodic":
+        n = 1 << level
+        for d in range(2 * dim):
+            val = rng.standard_normal(n * n)
+            f["u"][0].set_bc(d, bck, val)
+            f["u"][1].set_bc(d, bck, val)
+    L.go_bc(f["u"][0].ptr, f["u"][0].ptr, level)
+    gd.bc(f["u"][1])
+    L.go_residual(od.ptr, dim, level, f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr,
+                  f["res"][0].ptr)
+    gd.residual(f["u"][1], f["rhs"][1], f["dia"][1], f["res"][1])
+    op, gp = od.params(), gd.params()
+    for p in (op, gp):
+        p.depth = level
+    for _ in range(2):
+        L.go_poisson_cycle(od.ptr, C.byref(op), f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr,
+                           f["res"][0].ptr)
+        gd.poisson_cycle(gp, f["u"][1], f["rhs"][1], f["dia"][1], f["res"][1])
+        assert _faces_equal(f["u"][0].leaf(), f["u"][1].download(), dim)
+        assert np.array_equal(_interior(f["res"][0].leaf(), dim),
+                              _interior(f["res"][1].download(), dim))
