@@ -48,6 +48,14 @@ struct gfship_particles {
   double * outbox = nullptr;          // device, 6 x out_cap records of 7 doubles
   unsigned * out_count = nullptr;     // device, 6 counters
   int out_cap = 0;
+  // GfsParticulate (modules/particulatecommon.h:35-48), indexed by the creation slot (`orig`):
+  // velocity, force, mass, volume, diameter; the list's forces in application order
+  bool particulate = false;
+  int np0 = 0;                        // particles at creation
+  double * vel[3] = {}, * force[3] = {}, * mass = nullptr, * volume = nullptr, * dia = nullptr;
+  int nforces = 0, forces[8] = {};
+  double gravity[3] = {};
+  gfship_field uold[3] = { -1, -1, -1 };   // Un, Vn, Wn of GfsForceCoeff
 };
 
 namespace gfship {
@@ -224,37 +232,15 @@ __device__ bool check_intersection (const double cellpos[3], const double p0[3],
   return false;
 }
 
+// gfs_particle_bc, modules/particulatecommon.c:3326-3395: a particle that left the box is taken
+// off the list (or marked for the box across a GfsBoundaryMpi side) unless a periodic side puts it
+// back; stores the position
 template <int DIM>
-__global__ void __launch_bounds__(256)
-particle_list_event_kernel (PartArgs A, int depth)
+__device__ void particle_bc_and_store (const PartArgs & A, int q, int depth, const int cell[3],
+				       double p[3], double po[3])
 {
-  int q = blockIdx.x*blockDim.x + threadIdx.x;
-  if (q >= A.n) return;
-  if (A.alive[q] != 1) return;
   const int n = A.L.n;
   const double h = 1./n;
-  double p[3] = { A.pos[0][q], A.pos[1][q], DIM == 3 ? A.pos[2][q] : 0. };
-  int cell[3];
-  // remove_particles_not_in_domain, modules/particulatecommon.c:955-969
-  if (!locate<DIM> (depth, p, cell)) {
-    A.alive[q] = 0;
-    return;
-  }
-  // gfs_particle_event (src/particle.c:31-44): pos_old = pos; gfs_domain_advect_point
-  double po[3] = { p[0], p[1], p[2] };
-  {
-    double p1[3] = { p[0], p[1], p[2] };
-#pragma unroll
-    for (int c = 0; c < DIM; c++)
-      p1[c] += A.dt*interpolate<DIM> (A.L, A.u[c], cell, po)/2.;
-    int cell1[3];
-    if (locate<DIM> (depth, p1, cell1)) {
-#pragma unroll
-      for (int c = 0; c < DIM; c++)
-	p[c] += A.dt*interpolate<DIM> (A.L, A.u[c], cell1, p1);
-    }
-  }
-  // gfs_particle_bc, modules/particulatecommon.c:3326-3395
   int cn[3];
   bool keep = true;
   int mig = 0;
@@ -298,6 +284,208 @@ particle_list_event_kernel (PartArgs A, int depth)
   else if (mig)
     A.alive[q] = (unsigned char) mig;
 }
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+particle_list_event_kernel (PartArgs A, int depth)
+{
+  int q = blockIdx.x*blockDim.x + threadIdx.x;
+  if (q >= A.n) return;
+  if (A.alive[q] != 1) return;
+  double p[3] = { A.pos[0][q], A.pos[1][q], DIM == 3 ? A.pos[2][q] : 0. };
+  int cell[3];
+  // remove_particles_not_in_domain, modules/particulatecommon.c:955-969
+  if (!locate<DIM> (depth, p, cell)) {
+    A.alive[q] = 0;
+    return;
+  }
+  // gfs_particle_event (src/particle.c:31-44): pos_old = pos; gfs_domain_advect_point
+  double po[3] = { p[0], p[1], p[2] };
+  {
+    double p1[3] = { p[0], p[1], p[2] };
+#pragma unroll
+    for (int c = 0; c < DIM; c++)
+      p1[c] += A.dt*interpolate<DIM> (A.L, A.u[c], cell, po)/2.;
+    int cell1[3];
+    if (locate<DIM> (depth, p1, cell1)) {
+#pragma unroll
+      for (int c = 0; c < DIM; c++)
+	p[c] += A.dt*interpolate<DIM> (A.L, A.u[c], cell1, p1);
+    }
+  }
+  particle_bc_and_store<DIM> (A, q, depth, cell, p, po);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GfsParticulate with forces (modules/particulatecommon.c:91-842): uniform box, alpha = NULL
+// (fluid_rho = 1.), constant viscosity (GfsSourceDiffusion on U), no user coefficient functions
+// (cm = cl = 0.5, the default drag law).  Same operand order as the reference; pow (Re, 0.5) of
+// the drag law is evaluated as sqrt (Re) (correctly rounded; glibc's pow is within 0.52 ulp of it).
+// ---------------------------------------------------------------------------------------------
+enum { FORCE_INERTIAL = GFSHIP_FORCE_INERTIAL, FORCE_ADDEDMASS = GFSHIP_FORCE_ADDEDMASS,
+       FORCE_LIFT = GFSHIP_FORCE_LIFT, FORCE_DRAG = GFSHIP_FORCE_DRAG, FORCE_BUOY = GFSHIP_FORCE_BUOY };
+
+struct ParticulateArgs {
+  PartArgs P;
+  const unsigned * orig;
+  double * vel[3], * force[3], * mass;
+  const double * volume, * dia;
+  const double * uold[3];
+  int nforces, forces[8];
+  double gravity[3], viscosity;
+};
+
+// gfs_center_gradient, src/fluid.c:434-475, both neighbours at the same level (x1 = x2 = 1.)
+__device__ __forceinline__ double center_gradient (const double * __restrict__ v, long idx, long off)
+{
+  const double v0 = v[idx], v1 = v[idx - off], v2 = v[idx + off];
+  return ((v2 - v0) + (v0 - v1))/2.;
+}
+
+// compute_inertial_force, :285-336
+template <int DIM>
+__device__ void inertial_force (const ParticulateArgs & A, const int cell[3], const double p[3],
+				long idx, double force[3])
+{
+  const Layout & L = A.P.L;
+  const long off[3] = { 1, (long) L.sy, (long) L.sz };
+  const double size = 1./L.n;
+  const double fluid_rho = 1.;
+  force[0] = force[1] = force[2] = 0.;
+  if (!(A.P.dt > 0.))
+    return;
+#pragma unroll
+  for (int c = 0; c < DIM; c++) {
+    const double fluid_vel = interpolate<DIM> (L, A.P.u[c], cell, p);
+    const double fluid_veln = interpolate<DIM> (L, A.uold[c], cell, p);
+    force[c] = fluid_rho*(fluid_vel - fluid_veln)/A.P.dt;
+  }
+#pragma unroll
+  for (int c = 0; c < DIM; c++)
+#pragma unroll
+    for (int c2 = 0; c2 < DIM; c2++)
+      force[c] += fluid_rho*center_gradient (A.P.u[c], idx, off[c2])*A.P.u[c2][idx]/size;
+}
+
+// gfs_particulate_event (:768-842) in a gfs_particle_list_event (:980-1015)
+template <int DIM>
+__global__ void __launch_bounds__(256)
+particulate_list_event_kernel (ParticulateArgs A, int depth)
+{
+  const PartArgs & P = A.P;
+  int q = blockIdx.x*blockDim.x + threadIdx.x;
+  if (q >= P.n) return;
+  if (P.alive[q] != 1) return;
+  const Layout & L = P.L;
+  double p[3] = { P.pos[0][q], P.pos[1][q], DIM == 3 ? P.pos[2][q] : 0. };
+  int cell[3];
+  // remove_particles_not_in_domain, :955-969
+  if (!locate<DIM> (depth, p, cell)) {
+    P.alive[q] = 0;
+    return;
+  }
+  const unsigned o = A.orig[q];
+  const long idx = L.idx (cell[0], cell[1], DIM == 3 ? cell[2] : 0);
+  const long off[3] = { 1, (long) L.sy, (long) L.sz };
+  const double size = 1./L.n;
+  const double fluid_rho = 1.;
+  const double dt = P.dt;
+  double po[3] = { p[0], p[1], p[2] };
+  double vel[3] = { A.vel[0][o], A.vel[1][o], A.vel[2][o] };
+  double mass = A.mass[o];
+  const double volume = A.volume[o];
+  double pf[3] = { 0., 0., 0. };
+  for (int f = 0; f < A.nforces; f++) {
+    double force[3] = { 0., 0., 0. };
+    switch (A.forces[f]) {
+    case FORCE_INERTIAL:
+      inertial_force<DIM> (A, cell, p, idx, force);
+      break;
+    case FORCE_ADDEDMASS: {     // compute_addedmass_force, :363-427
+      inertial_force<DIM> (A, cell, p, idx, force);
+      const double cm = 0.5;
+#pragma unroll
+      for (int c = 0; c < DIM; c++)
+	force[c] *= cm;
+      mass += fluid_rho*volume*cm;
+      break;
+    }
+    case FORCE_LIFT: {          // compute_lift_force, :455-524; vorticity_vector, :146-168
+      double rel[3] = { 0., 0., 0. }, vort[3];
+#pragma unroll
+      for (int c = 0; c < DIM; c++)
+	rel[c] = interpolate<DIM> (L, P.u[c], cell, p) - vel[c];
+      if (DIM == 2) {
+	vort[0] = 0.; vort[1] = 0.;
+	vort[2] = (center_gradient (P.u[1], idx, off[0]) - center_gradient (P.u[0], idx, off[1]))/size;
+      }
+      else {
+	vort[0] = (center_gradient (P.u[2], idx, off[1]) - center_gradient (P.u[1], idx, off[2]))/size;
+	vort[1] = (center_gradient (P.u[0], idx, off[2]) - center_gradient (P.u[2], idx, off[0]))/size;
+	vort[2] = (center_gradient (P.u[1], idx, off[0]) - center_gradient (P.u[0], idx, off[1]))/size;
+      }
+      const double cl = 0.5;
+      if (DIM == 2) {
+	force[0] = fluid_rho*cl*rel[1]*vort[2];
+	force[1] = -fluid_rho*cl*rel[0]*vort[2];
+      }
+      else {
+	force[0] = fluid_rho*cl*(rel[1]*vort[2] - rel[2]*vort[1]);
+	force[1] = fluid_rho*cl*(rel[2]*vort[0] - rel[0]*vort[2]);
+	force[2] = fluid_rho*cl*(rel[0]*vort[1] - rel[1]*vort[0]);
+      }
+      break;
+    }
+    case FORCE_DRAG: {          // compute_drag_force, :527-588
+      double rel[3] = { 0., 0., 0. };
+#pragma unroll
+      for (int c = 0; c < DIM; c++)
+	rel[c] = interpolate<DIM> (L, P.u[c], cell, p) - vel[c];
+      const double dia = A.dia[o];
+      const double norm = DIM == 3 ? sqrt (rel[0]*rel[0] + rel[1]*rel[1] + rel[2]*rel[2]) :
+	sqrt (rel[0]*rel[0] + rel[1]*rel[1]);
+      if (A.viscosity == 0)
+	break;
+      const double Re = norm*dia*fluid_rho/A.viscosity;
+      double cd;
+      if (Re < 1e-8)
+	break;
+      else if (Re < 50.0)
+	cd = 16.*(1. + 0.15*sqrt (Re))/Re;
+      else
+	cd = 48.*(1. - 2.21/sqrt (Re))/Re;
+#pragma unroll
+      for (int c = 0; c < DIM; c++)
+	force[c] += 3./(4.*dia)*cd*norm*rel[c]*fluid_rho;
+      break;
+    }
+    case FORCE_BUOY:            // compute_buoyancy_force, :619-653
+#pragma unroll
+      for (int c = 0; c < DIM; c++)
+	force[c] += (mass/volume - fluid_rho)*A.gravity[c];
+      break;
+    }
+    // compute_forces, :738-752
+#pragma unroll
+    for (int c = 0; c < DIM; c++)
+      pf[c] = force[c]*volume + pf[c];
+    if (DIM == 2) pf[2] = 0.;
+  }
+#pragma unroll
+  for (int c = 0; c < DIM; c++) {
+    p[c] += vel[c]*dt/2.;
+    vel[c] += pf[c]*dt/mass;
+    p[c] += vel[c]*dt/2.;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    A.vel[c][o] = vel[c];
+    A.force[c][o] = pf[c];
+  }
+  A.mass[o] = mass;
+  particle_bc_and_store<DIM> (P, q, depth, cell, p, po);
+}
+
 
 // mpi_send_particle (modules/particulatecommon.c:3218-3222): the particles marked 2 + d go into the
 // packet of side d (7 doubles: position and old position in the coordinates of the receiving
@@ -417,7 +605,7 @@ using namespace gfship;
 
 extern "C" {
 
-struct gfship_sim_view { gfship_domain * dom; const gfship_field * u; double dt; };
+struct gfship_sim_view { gfship_domain * dom; const gfship_field * u; double dt; double visc; };
 gfship_sim_view gfship_sim_view_get (gfship_sim * s);   /* simulation.hip */
 
 int gfship_particles_create (gfship_particles ** out, gfship_sim * sim, int np,
@@ -429,6 +617,7 @@ int gfship_particles_create (gfship_particles ** out, gfship_sim * sim, int np,
   pl->sim = sim;
   pl->dom = gfship_sim_view_get (sim).dom;
   pl->n = np;
+  pl->np0 = np;
   pl->cap = std::max (np, 1);
   size_t m = pl->cap;
   std::vector<double> tmp (m);
@@ -480,6 +669,14 @@ void gfship_particles_destroy (gfship_particles * pl)
 		     pl->alive2, pl->sort_tmp, pl->outbox, pl->out_count };
   for (void * a : extra)
     if (a) (void) hipFree (a);
+  for (int c = 0; c < 3; c++) {
+    if (pl->vel[c]) (void) hipFree (pl->vel[c]);
+    if (pl->force[c]) (void) hipFree (pl->force[c]);
+    if (pl->uold[c] >= 0) gfship_field_free (pl->dom, pl->uold[c]);
+  }
+  if (pl->mass) (void) hipFree (pl->mass);
+  if (pl->volume) (void) hipFree (pl->volume);
+  if (pl->dia) (void) hipFree (pl->dia);
   delete pl;
 }
 
@@ -695,6 +892,7 @@ static int particles_migrate (gfship_particles * pl)
 int gfship_particles_set_migrate (gfship_particles * pl, gfship_particle_migrate_fn fn, void * ctx)
 {
   GFSHIP_CHECK (pl != nullptr, GFSHIP_EINVAL, "null particle list");
+  GFSHIP_CHECK (!pl->particulate, GFSHIP_EINVAL, "particulates do not migrate between boxes yet");
   pl->migrate = fn;
   pl->migrate_ctx = ctx;
   return GFSHIP_OK;
@@ -704,6 +902,146 @@ int gfship_particles_slots (gfship_particles * pl)
 {
   GFSHIP_CHECK (pl != nullptr, GFSHIP_EINVAL, "null particle list");
   return pl->n;
+}
+
+// store_domain_previous_vel, modules/particulatecommon.c:100-114: copy on the leaves, then the BC
+// of the new variable (a scalar with the default BC)
+static int store_previous_vel (gfship_particles * pl)
+{
+  gfship_domain * dom = pl->dom;
+  gfship_sim_view v = gfship_sim_view_get (pl->sim);
+  const Layout & L = dom->lay[dom->depth];
+  for (int c = 0; c < dom->dim; c++) {
+    GFSHIP_HIP (hipMemcpyAsync (dom->fields[pl->uold[c]].lev[dom->depth],
+				dom->fields[v.u[c]].lev[dom->depth], L.total*sizeof (double),
+				hipMemcpyDeviceToDevice, dom->stream));
+    int r = gfship_bc (dom, pl->uold[c], pl->uold[c], dom->depth);
+    if (r) return r;
+  }
+  return GFSHIP_OK;
+}
+
+static int particulate_event (gfship_particles * pl, const PartArgs & P, double viscosity)
+{
+  gfship_domain * dom = pl->dom;
+  ParticulateArgs A;
+  A.P = P;
+  A.orig = pl->orig;
+  for (int c = 0; c < 3; c++) {
+    A.vel[c] = pl->vel[c];
+    A.force[c] = pl->force[c];
+    A.uold[c] = c < dom->dim && pl->uold[c] >= 0 ? dom->fields[pl->uold[c]].lev[dom->depth] : nullptr;
+    A.gravity[c] = pl->gravity[c];
+  }
+  A.mass = pl->mass; A.volume = pl->volume; A.dia = pl->dia;
+  A.nforces = pl->nforces;
+  for (int f = 0; f < 8; f++) A.forces[f] = pl->forces[f];
+  A.viscosity = viscosity;
+  int block = 256, grid = (pl->n + block - 1)/block;
+  if (dom->dim == 3)
+    hipLaunchKernelGGL (particulate_list_event_kernel<3>, dim3 (grid), dim3 (block), 0, dom->stream,
+			A, dom->depth);
+  else
+    hipLaunchKernelGGL (particulate_list_event_kernel<2>, dim3 (grid), dim3 (block), 0, dom->stream,
+			A, dom->depth);
+  GFSHIP_HIP (hipGetLastError ());
+  // the velocity of this step for the inertial force of the next one (:1003-1012: only for
+  // GfsForceInertial objects)
+  for (int f = 0; f < pl->nforces; f++)
+    if (pl->forces[f] == GFSHIP_FORCE_INERTIAL)
+      return store_previous_vel (pl);
+  return GFSHIP_OK;
+}
+
+int gfship_particles_set_particulate (gfship_particles * pl, const double * vel, const double * mass,
+				      const double * volume)
+{
+  GFSHIP_CHECK (pl && vel && mass && volume, GFSHIP_EINVAL, "null argument");
+  GFSHIP_CHECK (!pl->particulate, GFSHIP_EINVAL, "the list already holds particulates");
+  GFSHIP_CHECK (!pl->migrate, GFSHIP_EINVAL, "particulates do not migrate between boxes yet");
+  size_t m = (size_t) std::max (pl->np0, 1), np = (size_t) pl->np0;
+  std::vector<double> tmp (m, 0.);
+  for (int c = 0; c < 3; c++) {
+    GFSHIP_HIP (hipMalloc ((void **) &pl->vel[c], m*sizeof (double)));
+    GFSHIP_HIP (hipMalloc ((void **) &pl->force[c], m*sizeof (double)));
+    for (size_t q = 0; q < np; q++) tmp[q] = vel[3*q + c];
+    GFSHIP_HIP (hipMemcpy (pl->vel[c], tmp.data (), m*sizeof (double), hipMemcpyHostToDevice));
+    GFSHIP_HIP (hipMemset (pl->force[c], 0, m*sizeof (double)));
+  }
+  GFSHIP_HIP (hipMalloc ((void **) &pl->mass, m*sizeof (double)));
+  GFSHIP_HIP (hipMalloc ((void **) &pl->volume, m*sizeof (double)));
+  GFSHIP_HIP (hipMalloc ((void **) &pl->dia, m*sizeof (double)));
+  if (np) {
+    GFSHIP_HIP (hipMemcpy (pl->mass, mass, np*sizeof (double), hipMemcpyHostToDevice));
+    GFSHIP_HIP (hipMemcpy (pl->volume, volume, np*sizeof (double), hipMemcpyHostToDevice));
+    /* diameter of the sphere of that volume, on the host with the reference's expression
+       (compute_drag_force, :552) */
+    for (size_t q = 0; q < np; q++)
+      tmp[q] = 2.*pow (3.0*volume[q]/4.0/M_PI, 1./3.);
+    GFSHIP_HIP (hipMemcpy (pl->dia, tmp.data (), np*sizeof (double), hipMemcpyHostToDevice));
+  }
+  pl->particulate = true;
+  return GFSHIP_OK;
+}
+
+int gfship_particles_set_forces (gfship_particles * pl, int nforces, const int * kinds,
+				 const double gravity[3])
+{
+  GFSHIP_CHECK (pl && (nforces == 0 || kinds), GFSHIP_EINVAL, "null argument");
+  GFSHIP_CHECK (pl->particulate, GFSHIP_EINVAL, "forces act on particulates (gfship_particles_set_particulate)");
+  GFSHIP_CHECK (nforces >= 0 && nforces <= 8, GFSHIP_EINVAL, "at most 8 forces");
+  bool coeff = false;
+  for (int f = 0; f < nforces; f++) {
+    GFSHIP_CHECK (kinds[f] >= GFSHIP_FORCE_INERTIAL && kinds[f] <= GFSHIP_FORCE_BUOY, GFSHIP_EINVAL,
+		  "unknown force");
+    pl->forces[f] = kinds[f];
+    if (kinds[f] != GFSHIP_FORCE_BUOY) coeff = true;
+  }
+  pl->nforces = nforces;
+  for (int c = 0; c < 3; c++) pl->gravity[c] = gravity ? gravity[c] : 0.;
+  /* every GfsForceCoeff creates Un, Vn, Wn and stores the velocity when it is read (:181-187) */
+  if (coeff && pl->uold[0] < 0) {
+    for (int c = 0; c < pl->dom->dim; c++) {
+      pl->uold[c] = gfship_field_alloc (pl->dom, -1);
+      GFSHIP_CHECK (pl->uold[c] >= 0, GFSHIP_ENOMEM, "no field for the previous velocity");
+    }
+    return store_previous_vel (pl);
+  }
+  return GFSHIP_OK;
+}
+
+int gfship_particles_download_particulate (gfship_particles * pl, double * vel, double * mass,
+					   double * force)
+{
+  GFSHIP_CHECK (pl && pl->particulate, GFSHIP_EINVAL, "not a list of particulates");
+  if (pl->n == 0) return 0;
+  gfship_domain * dom = pl->dom;
+  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  size_t m = pl->n, m0 = pl->np0;
+  std::vector<unsigned> orig (m), where (m);
+  std::vector<unsigned char> al (m);
+  std::vector<double> v[3], f[3], ms (m0);
+  GFSHIP_HIP (hipMemcpy (orig.data (), pl->orig, m*sizeof (unsigned), hipMemcpyDeviceToHost));
+  GFSHIP_HIP (hipMemcpy (al.data (), pl->alive, m, hipMemcpyDeviceToHost));
+  for (int c = 0; c < 3; c++) {
+    v[c].resize (m0); f[c].resize (m0);
+    GFSHIP_HIP (hipMemcpy (v[c].data (), pl->vel[c], m0*sizeof (double), hipMemcpyDeviceToHost));
+    GFSHIP_HIP (hipMemcpy (f[c].data (), pl->force[c], m0*sizeof (double), hipMemcpyDeviceToHost));
+  }
+  GFSHIP_HIP (hipMemcpy (ms.data (), pl->mass, m0*sizeof (double), hipMemcpyDeviceToHost));
+  for (size_t q = 0; q < m; q++)
+    where[orig[q]] = (unsigned) q;
+  int k = 0;
+  for (size_t o = 0; o < m; o++)
+    if (al[where[o]] == 1) {
+      for (int c = 0; c < 3; c++) {
+	if (vel) vel[3*(size_t) k + c] = v[c][o];
+	if (force) force[3*(size_t) k + c] = f[c][o];
+      }
+      if (mass) mass[k] = ms[o];
+      k++;
+    }
+  return k;
 }
 
 int gfship_particle_list_event (gfship_particles * pl)
@@ -733,6 +1071,8 @@ int gfship_particle_list_event (gfship_particles * pl)
   A.count = pl->d_count;
   A.migrate = pl->migrate != nullptr;
   int block = 256, grid = (pl->n + block - 1)/block;
+  if (pl->n > 0 && pl->particulate && pl->nforces > 0)
+    return particulate_event (pl, A, v.visc);
   if (pl->n > 0) {
     if (dom->dim == 3)
       hipLaunchKernelGGL (particle_list_event_kernel<3>, dim3 (grid), dim3 (block), 0, dom->stream,

@@ -194,10 +194,10 @@ int advance_tracers (gfship_sim * s, double dt)
 extern "C" {
 
 /* internal view of a simulation for particles.hip */
-struct gfship_sim_view { gfship_domain * dom; const gfship_field * u; double dt; };
+struct gfship_sim_view { gfship_domain * dom; const gfship_field * u; double dt; double visc; };
 gfship_sim_view gfship_sim_view_get (gfship_sim * s)
 {
-  gfship_sim_view v = { s->dom, s->u, s->advection_params.dt };
+  gfship_sim_view v = { s->dom, s->u, s->advection_params.dt, s->visc[0] };
   return v;
 }
 

@@ -122,6 +122,9 @@ SIGNATURES = {
     "gfship_particles_sort": (_i, [_vp]),
     "gfship_particles_set_sort_interval": (_i, [_vp, _i]),
     "gfship_particles_download": (_i, [_vp, _pd, C.POINTER(C.c_uint)]),
+    "gfship_particles_set_particulate": (_i, [_vp, _pd, _pd, _pd]),
+    "gfship_particles_set_forces": (_i, [_vp, _i, C.POINTER(_i), _pd]),
+    "gfship_particles_download_particulate": (_i, [_vp, _pd, _pd, _pd]),
 }
 
 
@@ -410,6 +413,9 @@ class Simulation:
             pass
 
 
+FORCE_INERTIAL, FORCE_ADDEDMASS, FORCE_LIFT, FORCE_DRAG, FORCE_BUOY = 1, 2, 3, 4, 5
+
+
 class ParticleList:
     """GfsParticleList of GfsParticle tracers on the device."""
 
@@ -442,6 +448,28 @@ class ParticleList:
         k = _check(lib().gfship_particles_download(self.ptr, pos.ctypes.data_as(_pd),
                                                    ids.ctypes.data_as(C.POINTER(C.c_uint))))
         return pos[:k].copy(), ids[:k].copy()
+
+    # GfsParticulate: velocity, mass, volume and the list's forces (FORCE_* in application order)
+    def set_particulate(self, vel, mass, volume):
+        vel = np.ascontiguousarray(vel, dtype=np.float64).reshape(-1, 3)
+        mass = np.ascontiguousarray(mass, dtype=np.float64)
+        volume = np.ascontiguousarray(volume, dtype=np.float64)
+        _check(lib().gfship_particles_set_particulate(self.ptr, vel.ctypes.data_as(_pd),
+                                                      mass.ctypes.data_as(_pd),
+                                                      volume.ctypes.data_as(_pd)))
+
+    def set_forces(self, kinds, gravity=(0., 0., 0.)):
+        k = (_i * len(kinds))(*kinds)
+        g = (C.c_double * 3)(*gravity)
+        _check(lib().gfship_particles_set_forces(self.ptr, len(kinds), k, g))
+
+    def particulate_state(self):
+        """(vel, mass, force) of the particles on the list, in list order"""
+        m = max(_check(lib().gfship_particles_slots(self.ptr)), 1)
+        vel, mass, force = np.empty((m, 3)), np.empty(m), np.empty((m, 3))
+        k = _check(lib().gfship_particles_download_particulate(
+            self.ptr, vel.ctypes.data_as(_pd), mass.ctypes.data_as(_pd), force.ctypes.data_as(_pd)))
+        return vel[:k].copy(), mass[:k].copy(), force[:k].copy()
 
     def destroy(self):
         if self.ptr:

@@ -257,6 +257,29 @@ int  gfship_particles_count (gfship_particles * pl);
 /* positions and ids of the particles still on the list, in list order; returns their number */
 int  gfship_particles_download (gfship_particles * pl, double * pos, unsigned * id);
 
+/* GfsParticulate with forces (modules/particulatecommon.h:35-61, particulatecommon.c:91-842): the
+   particles of the list get a velocity (3*np), a mass and a volume (np each), and the list a set of
+   GfsParticleForce objects applied in the given order.  gfship_particle_list_event then runs
+   gfs_particulate_event (:768-842): forces per unit volume from the fields at the start of the
+   step -- GfsForceInertial Du/Dt (:285-336, with the velocity of the previous step kept in Un, Vn,
+   Wn), GfsForceAddedMass (:363-427, cm = 0.5, adds rho*volume*cm to the mass at every event like the
+   reference), GfsForceLift (:455-524, cl = 0.5), GfsForceDrag (:527-588, default law
+   cd = 16 (1 + 0.15 Re^0.5)/Re below Re = 50, 48 (1 - 2.21/Re^0.5)/Re above; no force without
+   viscosity), GfsForceBuoy (:619-653, gravity = the sum of the GfsSource intensities on U, V, W) --
+   then pos += vel*dt/2, vel += force*dt/mass, pos += vel*dt/2 and gfs_particle_bc.  fluid density 1
+   (alpha = NULL), viscosity = gfship_sim_set_viscosity of U; user coefficient functions
+   (GfsForceCoeff with a GfsFunction) and migration between boxes are not supported yet. */
+enum { GFSHIP_FORCE_INERTIAL = 1, GFSHIP_FORCE_ADDEDMASS = 2, GFSHIP_FORCE_LIFT = 3,
+       GFSHIP_FORCE_DRAG = 4, GFSHIP_FORCE_BUOY = 5 };
+int  gfship_particles_set_particulate (gfship_particles * pl, const double * vel, const double * mass,
+				       const double * volume);
+int  gfship_particles_set_forces (gfship_particles * pl, int nforces, const int * kinds,
+				  const double gravity[3]);
+/* velocity (3 per particle), mass and force of the particles still on the list, in list order (any
+   pointer may be NULL); returns their number */
+int  gfship_particles_download_particulate (gfship_particles * pl, double * vel, double * mass,
+					    double * force);
+
 /* ---- one box per GPU: GfsBoundaryMpi sides (src/mpi_boundary.c:78-246) ----------------------- */
 
 /* The library does not talk to a network itself: for every GFSHIP_SIDE_EXTERNAL side the caller

@@ -15,6 +15,10 @@
 #include "go_sim.h"
 #include "go_particles.h"
 
+#ifndef M_PI
+#define M_PI 3.14159265358979323846   /* math.h, as used by the reference */
+#endif
+
 /* ftt_cell_locate on the box root (unit box centred on the origin), max_depth = -1:
  * returns 0 if outside, else fills the 1-based cell coordinates of the leaf */
 int go_locate (const GoDomain * dom, const double target[3], int ijk[3])
@@ -231,6 +235,8 @@ void go_particles_destroy (GoParticles * pl)
 {
   if (!pl) return;
   free (pl->pos); free (pl->pos_old); free (pl->id);
+  free (pl->vel); free (pl->force); free (pl->mass); free (pl->volume);
+  for (int c = 0; c < 3; c++) if (pl->uold[c]) go_field_destroy (pl->uold[c]);
   for (int d = 0; d < 6; d++) free (pl->out[d]);
   free (pl);
 }
@@ -268,6 +274,234 @@ int go_particles_count (const GoParticles * pl) { return pl->n; }
 double * go_particles_pos (GoParticles * pl) { return pl->pos; }
 unsigned * go_particles_id (GoParticles * pl) { return pl->id; }
 
+static void move_particle (GoParticles * pl, int m, int q)
+{
+  memcpy (pl->pos + 3*m, pl->pos + 3*q, 3*sizeof (double));
+  memcpy (pl->pos_old + 3*m, pl->pos_old + 3*q, 3*sizeof (double));
+  pl->id[m] = pl->id[q];
+  if (pl->particulate) {
+    memcpy (pl->vel + 3*m, pl->vel + 3*q, 3*sizeof (double));
+    memcpy (pl->force + 3*m, pl->force + 3*q, 3*sizeof (double));
+    pl->mass[m] = pl->mass[q];
+    pl->volume[m] = pl->volume[q];
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * GfsParticulate with forces (modules/particulatecommon.c:91-842).  Uniform box, alpha = NULL
+ * (fluid_rho = 1.), constant viscosity (GfsSourceDiffusion on U), no user coefficient functions
+ * (cm = cl = 0.5, the default drag law).
+ * ------------------------------------------------------------------------------------------- */
+
+void go_particles_set_particulate (GoParticles * pl, const double * vel, const double * mass,
+				   const double * volume)
+{
+  size_t np = (size_t) pl->n;
+  pl->particulate = 1;
+  pl->vel = malloc (3*np*sizeof (double));
+  pl->force = calloc (3*np, sizeof (double));
+  pl->mass = malloc (np*sizeof (double));
+  pl->volume = malloc (np*sizeof (double));
+  memcpy (pl->vel, vel, 3*np*sizeof (double));
+  memcpy (pl->mass, mass, np*sizeof (double));
+  memcpy (pl->volume, volume, np*sizeof (double));
+}
+
+/* store_domain_previous_vel, particulatecommon.c:100-114: copy on the leaves, then the BC of the
+ * new variable (a scalar with the default BC) */
+static void store_previous_vel (GoSim * s, GoParticles * pl)
+{
+  GoDomain * dom = s->dom;
+  int L = dom->depth;
+  for (int c = 0; c < dom->dim; c++) {
+    double * un = pl->uold[c]->lev[L];
+    const double * u = s->u[c]->lev[L];
+    const int * order = go_order (dom, L);
+    size_t ncells = 1;
+    for (int q = 0; q < dom->dim; q++) ncells *= (size_t) dom->n[L];
+    for (size_t q = 0; q < ncells; q++)
+      un[order[q]] = u[order[q]];
+    go_bc (pl->uold[c], pl->uold[c], L);
+  }
+}
+
+/* the list's forces, in the order they are applied (gfs_particle_list_read :1034-1070); every
+ * GfsForceCoeff creates Un, Vn, Wn and stores the velocity when it is read (:181-187) */
+void go_particles_set_forces (GoParticles * pl, GoSim * s, int n, const int * kinds)
+{
+  assert (n <= 8);
+  pl->nforces = n;
+  int coeff = 0;
+  for (int q = 0; q < n; q++) {
+    pl->forces[q] = kinds[q];
+    if (kinds[q] != GO_FORCE_BUOY) coeff = 1;
+  }
+  if (coeff && !pl->uold[0]) {
+    for (int c = 0; c < s->dom->dim; c++)
+      pl->uold[c] = go_field_new (s->dom, -1);
+    store_previous_vel (s, pl);
+  }
+}
+
+void go_particles_set_gravity (GoParticles * pl, const double g[3])
+{
+  for (int c = 0; c < 3; c++) pl->gravity[c] = g[c];
+}
+
+double * go_particles_vel (GoParticles * pl) { return pl->vel; }
+double * go_particles_mass (GoParticles * pl) { return pl->mass; }
+double * go_particles_force (GoParticles * pl) { return pl->force; }
+
+/* gfs_center_gradient, fluid.c:434-475, both neighbours at the same level (x1 = x2 = 1.) */
+static double center_gradient (const GoDomain * dom, const double * v, size_t cell, int c)
+{
+  int L = dom->depth;
+  double v0 = v[cell];
+  double x1 = 1., v1 = v[cell + dom->off[L][2*c + 1]];
+  double x2 = 1., v2 = v[cell + dom->off[L][2*c]];
+  return (x1*x1*(v2 - v0) + x2*x2*(v0 - v1))/(x1*x2*(x2 + x1));
+}
+
+/* compute_inertial_force, :285-336 */
+static void inertial_force (GoSim * s, GoParticles * pl, const int cell[3], const double p[3],
+			    double force[3])
+{
+  GoDomain * dom = s->dom;
+  int dim = dom->dim, L = dom->depth;
+  for (int c = 0; c < 3; c++) force[c] = 0;
+  double size = 1./dom->n[L];
+  double fluid_rho = 1.;
+  double fluid_vel[3], fluid_veln[3];
+  for (int c = 0; c < dim; c++)
+    fluid_vel[c] = go_interpolate (dom, s->u[c]->lev[L], cell, p);
+  for (int c = 0; c < dim; c++)
+    fluid_veln[c] = go_interpolate (dom, pl->uold[c]->lev[L], cell, p);
+  double dt = s->advection_params.dt;
+  if (dt > 0.)
+    for (int c = 0; c < dim; c++)
+      force[c] = fluid_rho*(fluid_vel[c] - fluid_veln[c])/dt;
+  else
+    return;
+  size_t idx = go_index (dom, L, cell[0], cell[1], dim == 3 ? cell[2] : 0);
+  for (int c = 0; c < dim; c++)
+    for (int c2 = 0; c2 < dim; c2++)
+      force[c] += fluid_rho*center_gradient (dom, s->u[c]->lev[L], idx, c2)*
+	s->u[c2]->lev[L][idx]/size;
+}
+
+/* vorticity_vector, :146-168 */
+static void vorticity_vector (GoSim * s, size_t idx, double vort[3])
+{
+  GoDomain * dom = s->dom;
+  int L = dom->depth;
+  double size = 1./dom->n[L];
+  const double * u = s->u[0]->lev[L], * v = s->u[1]->lev[L];
+  if (dom->dim == 2) {
+    vort[0] = 0.;
+    vort[1] = 0.;
+    vort[2] = (center_gradient (dom, v, idx, 0) - center_gradient (dom, u, idx, 1))/size;
+  }
+  else {
+    const double * w = s->u[2]->lev[L];
+    vort[0] = (center_gradient (dom, w, idx, 1) - center_gradient (dom, v, idx, 2))/size;
+    vort[1] = (center_gradient (dom, u, idx, 2) - center_gradient (dom, w, idx, 0))/size;
+    vort[2] = (center_gradient (dom, v, idx, 0) - center_gradient (dom, u, idx, 1))/size;
+  }
+}
+
+/* gfs_particulate_event with forces, :768-842: forces from the state at the start of the step,
+ * then pos += vel*dt/2, vel += force*dt/mass, pos += vel*dt/2 */
+static void particulate_event (GoSim * s, GoParticles * pl, int q)
+{
+  GoDomain * dom = s->dom;
+  int dim = dom->dim, L = dom->depth;
+  double * p = pl->pos + 3*q, * vel = pl->vel + 3*q, * pf = pl->force + 3*q;
+  double dt = s->advection_params.dt;
+  double pos[3] = { p[0], p[1], p[2] };
+  memcpy (pl->pos_old + 3*q, p, 3*sizeof (double));
+  for (int c = 0; c < 3; c++) pf[c] = 0.;
+
+  int cell[3];
+  int inside = go_locate (dom, p, cell);
+  size_t idx = inside ? go_index (dom, L, cell[0], cell[1], dim == 3 ? cell[2] : 0) : 0;
+  double fluid_rho = 1.;
+  double viscosity = s->visc[0];
+  for (int f = 0; f < pl->nforces; f++) {
+    double force[3] = { 0., 0., 0. };
+    if (inside)
+      switch (pl->forces[f]) {
+      case GO_FORCE_INERTIAL:
+	inertial_force (s, pl, cell, p, force);
+	break;
+      case GO_FORCE_ADDEDMASS: {   /* compute_addedmass_force, :363-427 */
+	inertial_force (s, pl, cell, p, force);
+	double cm = 0.5;
+	for (int c = 0; c < dim; c++)
+	  force[c] *= cm;
+	pl->mass[q] += fluid_rho*pl->volume[q]*cm;
+	break;
+      }
+      case GO_FORCE_LIFT: {        /* compute_lift_force, :455-524 */
+	double relative_vel[3] = { 0., 0., 0. }, vorticity[3];
+	for (int c = 0; c < dim; c++)
+	  relative_vel[c] = go_interpolate (dom, s->u[c]->lev[L], cell, p) - vel[c];
+	if (dim == 2) relative_vel[2] = 0. - vel[2];
+	vorticity_vector (s, idx, vorticity);
+	double cl = 0.5;
+	if (dim == 2) {
+	  force[0] = fluid_rho*cl*relative_vel[1]*vorticity[2];
+	  force[1] = -fluid_rho*cl*relative_vel[0]*vorticity[2];
+	}
+	else {
+	  force[0] = fluid_rho*cl*(relative_vel[1]*vorticity[2] - relative_vel[2]*vorticity[1]);
+	  force[1] = fluid_rho*cl*(relative_vel[2]*vorticity[0] - relative_vel[0]*vorticity[2]);
+	  force[2] = fluid_rho*cl*(relative_vel[0]*vorticity[1] - relative_vel[1]*vorticity[0]);
+	}
+	break;
+      }
+      case GO_FORCE_DRAG: {        /* compute_drag_force, :552-588 */
+	double relative_vel[3] = { 0., 0., 0. };
+	for (int c = 0; c < dim; c++)
+	  relative_vel[c] = go_interpolate (dom, s->u[c]->lev[L], cell, p) - vel[c];
+	double dia = 2.*pow (3.0*pl->volume[q]/4.0/M_PI, 1./3.);
+	double norm_relative_vel = dim == 3 ?
+	  sqrt (relative_vel[0]*relative_vel[0] + relative_vel[1]*relative_vel[1] +
+		relative_vel[2]*relative_vel[2]) :
+	  sqrt (relative_vel[0]*relative_vel[0] + relative_vel[1]*relative_vel[1]);
+	double cd = 0., Re;
+	if (viscosity == 0)
+	  break;
+	Re = norm_relative_vel*dia*fluid_rho/viscosity;
+	if (Re < 1e-8)
+	  break;
+	else if (Re < 50.0)
+	  cd = 16.*(1. + 0.15*pow (Re, 0.5))/Re;
+	else
+	  cd = 48.*(1. - 2.21/pow (Re, 0.5))/Re;
+	for (int c = 0; c < dim; c++)
+	  force[c] += 3./(4.*dia)*cd*norm_relative_vel*relative_vel[c]*fluid_rho;
+	break;
+      }
+      case GO_FORCE_BUOY:          /* compute_buoyancy_force, :619-653 */
+	for (int c = 0; c < dim; c++)
+	  force[c] += (pl->mass[q]/pl->volume[q] - fluid_rho)*pl->gravity[c];
+	break;
+      }
+    /* compute_forces, :738-752 */
+    double total[3];
+    for (int c = 0; c < dim; c++)
+      total[c] = force[c]*pl->volume[q] + pf[c];
+    if (dim == 2) total[2] = 0.;
+    for (int c = 0; c < 3; c++) pf[c] = total[c];
+  }
+  for (int c = 0; c < dim; c++) {
+    pos[c] += vel[c]*dt/2.;
+    vel[c] += pf[c]*dt/pl->mass[q];
+    pos[c] += vel[c]*dt/2.;
+  }
+  p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
+}
+
 /* gfs_particle_list_event, particulatecommon.c:980-1015 (no forces):
  *   remove_particles_not_in_domain (:955-969)
  *   every particle: gfs_particle_event (src/particle.c:31-44)
@@ -283,15 +517,16 @@ void go_particle_list_event (GoSim * s, GoParticles * pl)
   int m = 0;
   for (int q = 0; q < pl->n; q++)
     if (go_locate (dom, pl->pos + 3*q, cell)) {
-      if (m != q) {
-	memcpy (pl->pos + 3*m, pl->pos + 3*q, 3*sizeof (double));
-	memcpy (pl->pos_old + 3*m, pl->pos_old + 3*q, 3*sizeof (double));
-	pl->id[m] = pl->id[q];
-      }
+      if (m != q)
+	move_particle (pl, m, q);
       m++;
     }
   pl->n = m;
   for (int q = 0; q < pl->n; q++) {
+    if (pl->particulate && pl->nforces > 0) {
+      particulate_event (s, pl, q);     /* gfs_particulate_event, :768-842 */
+      continue;
+    }
     double * p = pl->pos + 3*q, * po = pl->pos_old + 3*q;
     double pos[3] = { p[0], p[1], p[2] };
     po[0] = p[0]; po[1] = p[1]; po[2] = p[2];
@@ -337,13 +572,17 @@ void go_particle_list_event (GoSim * s, GoParticles * pl)
   m = 0;
   for (int q = 0; q < pl->n; q++)
     if (!drop[q]) {
-      if (m != q) {
-	memcpy (pl->pos + 3*m, pl->pos + 3*q, 3*sizeof (double));
-	memcpy (pl->pos_old + 3*m, pl->pos_old + 3*q, 3*sizeof (double));
-	pl->id[m] = pl->id[q];
-      }
+      if (m != q)
+	move_particle (pl, m, q);
       m++;
     }
   pl->n = m;
   free (drop);
+  /* the velocity of this step for the inertial force of the next one (:1003-1012: only for
+     GfsForceInertial objects) */
+  for (int f = 0; f < pl->nforces; f++)
+    if (pl->forces[f] == GO_FORCE_INERTIAL) {
+      store_previous_vel (s, pl);
+      break;
+    }
 }

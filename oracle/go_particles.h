@@ -12,7 +12,18 @@ typedef struct {
      the neighbour's coordinates */
   int nout[6];
   double * out[6];
+  /* GfsParticulate (modules/particulatecommon.h:35-48): mass, volume, velocity, force; the list's
+     forces (GfsParticleForce objects in the order they are applied) */
+  int particulate;
+  double * vel, * force;     /* 3 doubles per particle */
+  double * mass, * volume;
+  int nforces, forces[8];    /* GO_FORCE_* */
+  double gravity[3];         /* sum of the GfsSource intensities on U, V, W (compute_buoyancy_force) */
+  GoField * uold[3];         /* "Un", "Vn", "Wn" of GfsForceCoeff (particulatecommon.c:181-185) */
 } GoParticles;
+
+enum { GO_FORCE_INERTIAL = 1, GO_FORCE_ADDEDMASS = 2, GO_FORCE_LIFT = 3, GO_FORCE_DRAG = 4,
+       GO_FORCE_BUOY = 5 };
 
 int    go_locate (const GoDomain * dom, const double target[3], int ijk[3]);
 double go_interpolate (const GoDomain * dom, const double * v, const int cell[3], const double p[3]);
@@ -26,4 +37,11 @@ void   go_particles_append (GoParticles * pl, int n, const double * rec);
 double * go_particles_pos (GoParticles * pl);
 unsigned * go_particles_id (GoParticles * pl);
 void   go_particle_list_event (GoSim * s, GoParticles * pl);
+void   go_particles_set_particulate (GoParticles * pl, const double * vel, const double * mass,
+				     const double * volume);
+void   go_particles_set_forces (GoParticles * pl, GoSim * s, int n, const int * kinds);
+void   go_particles_set_gravity (GoParticles * pl, const double g[3]);
+double * go_particles_vel (GoParticles * pl);
+double * go_particles_mass (GoParticles * pl);
+double * go_particles_force (GoParticles * pl);
 #endif

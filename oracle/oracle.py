@@ -313,6 +313,9 @@ class Sim:
 # GfsParticleList (oracle/go_particles.c)
 # ---------------------------------------------------------------------------------------------
 
+FORCE_INERTIAL, FORCE_ADDEDMASS, FORCE_LIFT, FORCE_DRAG, FORCE_BUOY = 1, 2, 3, 4, 5
+
+
 class Particles:
     def __init__(self, sim, pos, ids):
         L = lib()
@@ -330,6 +333,12 @@ class Particles:
                 "go_particles_outbox": (i, [vp, i, C.POINTER(pd)]),
                 "go_particles_clear_outbox": (None, [vp]),
                 "go_particles_append": (None, [vp, i, pd]),
+                "go_particles_set_particulate": (None, [vp, pd, pd, pd]),
+                "go_particles_set_forces": (None, [vp, vp, i, C.POINTER(i)]),
+                "go_particles_set_gravity": (None, [vp, pd]),
+                "go_particles_vel": (pd, [vp]),
+                "go_particles_mass": (pd, [vp]),
+                "go_particles_force": (pd, [vp]),
             }.items():
                 f = getattr(L, name)
                 f.restype, f.argtypes = res, args
@@ -361,6 +370,31 @@ class Particles:
         rec = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, 7)
         if len(rec):
             lib().go_particles_append(self.ptr, len(rec), rec.ctypes.data_as(C.POINTER(C.c_double)))
+
+    # GfsParticulate: velocity, mass, volume and the list's forces (FORCE_* in application order)
+    def set_particulate(self, vel, mass, volume):
+        pd = C.POINTER(C.c_double)
+        vel = np.ascontiguousarray(vel, dtype=np.float64).reshape(-1, 3)
+        mass = np.ascontiguousarray(mass, dtype=np.float64)
+        volume = np.ascontiguousarray(volume, dtype=np.float64)
+        assert len(vel) == len(mass) == len(volume) == self.count()
+        lib().go_particles_set_particulate(self.ptr, vel.ctypes.data_as(pd), mass.ctypes.data_as(pd),
+                                           volume.ctypes.data_as(pd))
+
+    def set_forces(self, kinds, gravity=(0., 0., 0.)):
+        k = (C.c_int * len(kinds))(*kinds)
+        g = (C.c_double * 3)(*gravity)
+        lib().go_particles_set_gravity(self.ptr, g)
+        lib().go_particles_set_forces(self.ptr, self.sim.ptr, len(kinds), k)
+
+    def particulate_state(self):
+        """(vel, mass, force) of the particles on the list, in list order"""
+        n = self.count()
+        L = lib()
+        vel = np.ctypeslib.as_array(L.go_particles_vel(self.ptr), shape=(max(n, 1), 3))[:n].copy()
+        mass = np.ctypeslib.as_array(L.go_particles_mass(self.ptr), shape=(max(n, 1),))[:n].copy()
+        force = np.ctypeslib.as_array(L.go_particles_force(self.ptr), shape=(max(n, 1), 3))[:n].copy()
+        return vel, mass, force
 
     def state(self):
         n = self.count()

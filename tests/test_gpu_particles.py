@@ -200,3 +200,130 @@ def test_particles_migrate_between_two_boxes_on_one_gpu():
             assert np.array_equal(gi[a], oi[b]), (rank, k)
             assert np.array_equal(gp[a], op[b]), (rank, k, np.abs(gp[a] - op[b]).max())
     del ohooks
+
+
+# ---------------------------------------------------------------------------------------------
+# GfsParticulate with forces: modules/particulatecommon.c:91-842
+# ---------------------------------------------------------------------------------------------
+
+ALL_FORCES = [O.FORCE_INERTIAL, O.FORCE_ADDEDMASS, O.FORCE_LIFT, O.FORCE_DRAG, O.FORCE_BUOY]
+
+
+def _rel_err(a, b):
+    scale = max(np.abs(a).max(), 1e-300)
+    return np.abs(a - b).max() / scale
+
+
+def _run_particulates(osim, side, pos, ids, vel, mass, vol, forces, gravity, nsteps, nu, sort_every=None,
+                      end=None):
+    gd, gs = _device_sim(osim, side)
+    if end is not None:
+        gs.set_time(end=end)
+    for c in range(osim.dim):
+        if nu:
+            gs.set_viscosity(c, nu)
+    osim.start()
+    gs.start()
+    opl = O.Particles(osim, pos, ids)
+    gpl = gfship.ParticleList(gs, pos, ids)
+    if sort_every is not None:
+        gpl.set_sort_interval(sort_every)
+    opl.set_particulate(vel, mass, vol)
+    gpl.set_particulate(vel, mass, vol)
+    opl.set_forces(forces, gravity)
+    gpl.set_forces(forces, gravity)
+    worst = 0.
+    for k in range(nsteps):
+        opl.event()
+        gpl.event()
+        op, oi = opl.state()
+        gp, gi = gpl.download()
+        # same survivors in the same order; positions, velocities, forces within 1e-12 relative
+        # L-infinity (the only operation not bit-reproducible is pow (Re, 0.5) of the drag law,
+        # sqrt on the device)
+        assert np.array_equal(oi, gi), k
+        ov, om, of = opl.particulate_state()
+        gv, gm, gf = gpl.particulate_state()
+        for a, b, what in ((op, gp, "pos"), (ov, gv, "vel"), (of, gf, "force"), (om, gm, "mass")):
+            e = _rel_err(a, b)
+            worst = max(worst, e)
+            assert e <= 1e-12, (k, what, e)
+        # cell indices bit-identical
+        for q in range(0, len(gi), 37):
+            assert opl.locate(gp[q]) == opl.locate(op[q])
+        osim.step()
+        gs.step()
+    return worst, opl, gpl
+
+
+def _particulate_case(n, dim, seed):
+    rng = np.random.default_rng(seed)
+    pos, ids = lcg_positions(n, dim=dim)
+    vel = 0.3 * rng.standard_normal((n, 3))
+    if dim == 2:
+        vel[:, 2] = 0.
+    vol = 1e-3 * (0.5 + rng.random(n))
+    mass = vol * (0.5 + 2.5 * rng.random(n))
+    return pos, ids, vel, mass, vol
+
+
+@pytest.mark.parametrize("sort_every", [0, 2])
+def test_particulates_all_forces_taylor_green_3d(sort_every):
+    nu = 1e-2
+    osim = oracle_taylor_green(4)
+    for c in range(3):
+        osim.set_viscosity(c, nu)
+    pos, ids, vel, mass, vol = _particulate_case(1500, 3, 11)
+    worst, opl, gpl = _run_particulates(osim, PERIODIC, pos, ids, vel, mass, vol, ALL_FORCES,
+                                        (0., 0.5, 0.), 6, nu, sort_every=sort_every)
+    # the added mass accumulates at every event (:424), on both sides alike
+    om = opl.particulate_state()[1]
+    idx = np.searchsorted(ids, opl.state()[1])
+    assert np.allclose(om, mass[idx] + 6 * 0.5 * vol[idx], rtol=1e-13)
+    assert worst <= 1e-12
+
+
+def test_particulates_2d_periodic():
+    nu = 1e-3
+    osim = oracle_reynolds(5)
+    for c in range(2):
+        osim.set_viscosity(c, nu)
+    pos, ids, vel, mass, vol = _particulate_case(800, 2, 12)
+    _run_particulates(osim, PERIODIC, pos, ids, vel, mass, vol,
+                      [O.FORCE_DRAG, O.FORCE_LIFT, O.FORCE_INERTIAL], (0., 0., 0.), 6, nu, end=2.)
+
+
+def test_particulates_sediment_out_of_a_closed_box():
+    """lid-driven cavity: heavy particulates fall through the bottom wall and leave the list (no
+    periodic side puts them back); drag + buoyancy only"""
+    from flow_cases import oracle_lid
+    osim = oracle_lid(level=5, nu=1e-2)
+    n = 300
+    pos, ids, vel, mass, vol = _particulate_case(n, 2, 13)
+    pos[:, 1] = -0.5 + 0.1 * (pos[:, 1] + 0.5)          # near the bottom wall
+    vel[...] = 0.
+    mass = 5. * vol
+    from test_gpu_timestep import _device_lid
+    gd, gs = _device_lid(osim, 5, 1e-2)
+    gs.set_time(end=300.)
+    osim.start()
+    gs.start()
+    opl = O.Particles(osim, pos, ids)
+    gpl = gfship.ParticleList(gs, pos, ids)
+    for pl in (opl, gpl):
+        pl.set_particulate(vel, mass, vol)
+        pl.set_forces([O.FORCE_DRAG, O.FORCE_BUOY], (0., -20., 0.))
+    counts = []
+    for k in range(12):
+        opl.event()
+        gpl.event()
+        op, oi = opl.state()
+        gp, gi = gpl.download()
+        assert np.array_equal(oi, gi), k
+        if len(oi):
+            assert _rel_err(op, gp) <= 1e-12
+            assert _rel_err(opl.particulate_state()[0], gpl.particulate_state()[0]) <= 1e-12
+        counts.append(len(oi))
+        osim.step()
+        gs.step()
+    assert counts[-1] < counts[0]
