@@ -13,9 +13,12 @@
 // coefficient on U, V, W), VariableTracer, EventStop, EventScript, GModule (ignored: the device
 // solver replaces hypre/agmg), OutputTime, OutputProjectionStats, OutputDiffusionStats,
 // OutputScalarNorm, OutputScalarSum, OutputScalarStats, OutputErrorNorm, OutputLocation,
-// OutputSimulation (text format).  Anything else fails loudly with the line number.
+// OutputSimulation (text format), GfsParticleList of GfsParticle / GfsParticulate objects with
+// GfsForce{Inertial,AddedMass,Lift,Drag,Buoy} (`GModule particulates`; --particles FILE writes the
+// lists at the end of the run the way the reference prints them).  Anything else fails loudly with
+// the line number.
 //
-//   gfship2D [-D NAME=VALUE ...] [--device N] file.gfs     (gfship3D for three dimensions)
+//   gfship2D [-D NAME=VALUE ...] [--device N] [--particles FILE] file.gfs     (gfship3D for three dimensions)
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
@@ -92,6 +95,16 @@ struct Output {                    // GfsOutput, src/output.c:143-212
 
 struct BcSpec { int kind = GFSHIP_BC_SYMMETRY; Function * val = nullptr; };
 
+// GfsParticleList (modules/particulatecommon.c:980-1093) of GfsParticle (src/particle.c:46-99) or
+// GfsParticulate (:844-905) objects, with the list's GfsParticleForce objects
+struct ParticleSpec {
+  bool particulate = false;
+  std::vector<unsigned> id;
+  std::vector<double> pos, vel, mass, volume;    // 3 per particle for pos / vel
+  std::vector<int> forces;                       // GFSHIP_FORCE_* in file order
+  gfship_particles * pl = nullptr;
+};
+
 struct Run {
   int dim = 2, level = 0, device = 0;
   std::string sim_class = "Simulation";
@@ -109,6 +122,8 @@ struct Run {
   std::vector<Variable> vars;
   std::vector<std::unique_ptr<Event>> events;
   std::vector<std::unique_ptr<Output>> outputs;
+  std::vector<std::unique_ptr<ParticleSpec>> plists;
+  std::string particles_out;                     // --particles FILE: the lists at the end of the run
   FunctionSet functions;
   gfship_domain * dom = nullptr;
   gfship_sim * sim = nullptr;
@@ -424,8 +439,11 @@ void parse_object (Run & R, Reader & r)
   else if (cls == "GModule") {
     std::string name = r.word (false);
     if (r.peek (false) == '{') r.braces ();
-    fprintf (stderr, "gfship: GModule %s ignored (the Poisson and diffusion solvers are libgfship's)\n",
-	     name.c_str ());
+    if (name == "particulates")
+      ;   /* GfsParticleList / GfsParticulate / GfsForce* are built in (libgfship) */
+    else
+      fprintf (stderr, "gfship: GModule %s ignored (the Poisson and diffusion solvers are libgfship's)\n",
+	       name.c_str ());
   }
   else if (cls == "ApproxProjectionParams") read_multilevel (r, R.approx_set);
   else if (cls == "ProjectionParams") read_multilevel (r, R.proj_set);
@@ -507,6 +525,73 @@ void parse_object (Run & R, Reader & r)
       }
       *oldv = cur;
       *last = R.t;
+    };
+    add_event (R, e, cls, line);
+  }
+  else if (cls == "ParticleList") {
+    // gfs_event_list_read (src/event.c:2446-2506) + gfs_particle_list_read
+    // (modules/particulatecommon.c:1022-1093):
+    //   GfsParticleList { event } [GfsParticle|GfsParticulate] { objects } [{ forces }] [idlast]
+    Event * e = new Event;
+    read_event_params (r, *e);
+    R.plists.emplace_back (new ParticleSpec);
+    ParticleSpec * ps = R.plists.back ().get ();
+    auto strip = [] (std::string w) { return w.compare (0, 3, "Gfs") == 0 ? w.substr (3) : w; };
+    std::string item;
+    if (r.peek (false) != '{') item = strip (r.word (false));
+    auto numeric = [] (char c) { return (c >= '0' && c <= '9') || c == '-' || c == '+' || c == '.'; };
+    {
+      int l0 = r.line ();
+      Reader b (r.braces (), "simulation file", l0);
+      bool first = true;
+      while (!b.eof ()) {
+	// every object starts with its class (gfs_event_read, src/event.c:171-196)
+	std::string k = strip (b.word ());
+	if (k != "Particle" && k != "Particulate")
+	  b.fail ("expecting GfsParticle or GfsParticulate in a GfsParticleList (got `" + k + "')");
+	if (!item.empty () && k != item)
+	  b.fail ("the list holds Gfs" + item + " objects");
+	bool particulate = k == "Particulate";
+	if (!first && particulate != ps->particulate)
+	  b.fail ("mixed lists of GfsParticle and GfsParticulate are not supported");
+	ps->particulate = particulate;
+	first = false;
+	if (b.peek (false) == '{') b.braces ();          /* per-object event parameters: the list's apply */
+	ps->id.push_back ((unsigned) b.number ());
+	for (int c = 0; c < 3; c++) ps->pos.push_back (b.number ());
+	if (particulate) {
+	  ps->mass.push_back (b.number ());
+	  ps->volume.push_back (b.number ());           /* physical_params.L = 1 */
+	  for (int c = 0; c < 3; c++) ps->vel.push_back (b.number ());
+	  for (int c = 0; c < 3 && numeric (b.peek (false)); c++)
+	    b.number ();                                 /* force: recomputed at every event */
+	}
+      }
+    }
+    if (r.peek (false) == '{') {
+      int l0 = r.line ();
+      Reader b (r.braces (), "simulation file", l0);
+      while (!b.eof ()) {
+	std::string k = strip (b.word ());
+	int kind = k == "ForceInertial" ? GFSHIP_FORCE_INERTIAL : k == "ForceAddedMass" ? GFSHIP_FORCE_ADDEDMASS :
+	  k == "ForceLift" ? GFSHIP_FORCE_LIFT : k == "ForceDrag" ? GFSHIP_FORCE_DRAG :
+	  k == "ForceBuoy" ? GFSHIP_FORCE_BUOY : 0;
+	if (!kind) b.fail ("unsupported GfsParticleForce `" + k + "'");
+	char c = b.peek (false);
+	if (c != 0 && c != '\n')
+	  b.fail ("coefficient functions of a GfsForceCoeff are not supported");
+	ps->forces.push_back (kind);
+      }
+      if (!ps->forces.empty () && !ps->particulate)
+	r.fail ("GfsParticleForce objects act on GfsParticulate objects");
+      if (ps->forces.size () > 8) r.fail ("at most 8 forces");
+    }
+    if (numeric (r.peek (false))) r.number ();           /* idlast */
+    e->action = [ps] () {
+      if (ps->pl && gfship_particle_list_event (ps->pl) != GFSHIP_OK) {
+	fprintf (stderr, "gfship: %s\n", gfship_last_error ());
+	exit (1);
+      }
     };
     add_event (R, e, cls, line);
   }
@@ -1112,6 +1197,18 @@ int run (Run & R)
       CHECK (gfship_sim_set_viscosity (R.sim, c, R.visc[c]));
       apply_multilevel (gfship_sim_diffusion_params (R.sim, c), R.diff_set[c]);
     }
+  // the particle lists: created (and the previous velocity of the GfsForceCoeff objects stored)
+  // while the fields still hold the zeros of a fresh simulation, like the reference, which reads
+  // the list before any GfsInit event runs (gfs_force_coeff_read, :181-187)
+  for (auto & ps : R.plists) {
+    int np = (int) ps->id.size ();
+    CHECK (gfship_particles_create (&ps->pl, R.sim, np, ps->pos.data (), ps->id.data ()));
+    if (ps->particulate) {
+      CHECK (gfship_particles_set_particulate (ps->pl, ps->vel.data (), ps->mass.data (), ps->volume.data ()));
+      /* gravity = the GfsSource objects on U, V, W: none can be declared here */
+      CHECK (gfship_particles_set_forces (ps->pl, (int) ps->forces.size (), ps->forces.data (), nullptr));
+    }
+  }
   set_boundary_conditions (R);
   apply_init (R);
   events_init (R);
@@ -1163,6 +1260,37 @@ int run (Run & R)
     }
     events_do (R);
   }
+  if (!R.particles_out.empty ()) {
+    // the lists as gfs_event_list_write / gfs_particle_write / gfs_particulate_write print them
+    // (src/event.c:2508-2524, src/particle.c:88-99, modules/particulatecommon.c:907-921)
+    FILE * fp = fopen (R.particles_out.c_str (), "w");
+    if (!fp) { fprintf (stderr, "gfship: cannot open `%s'\n", R.particles_out.c_str ()); return 1; }
+    for (auto & ps : R.plists) {
+      int m = gfship_particles_slots (ps->pl);
+      CHECK (m);
+      std::vector<double> pos (3*(size_t) std::max (m, 1)), vel (pos.size ()), force (pos.size ()), mass (std::max (m, 1));
+      std::vector<unsigned> id (std::max (m, 1));
+      int k = gfship_particles_download (ps->pl, pos.data (), id.data ());
+      CHECK (k);
+      if (ps->particulate)
+	CHECK (gfship_particles_download_particulate (ps->pl, vel.data (), mass.data (), force.data ()));
+      std::map<unsigned, double> volume;
+      for (size_t q = 0; q < ps->id.size () && ps->particulate; q++) volume[ps->id[q]] = ps->volume[q];
+      fprintf (fp, "GfsParticleList %s {\n", ps->particulate ? "GfsParticulate" : "GfsParticle");
+      for (int q = 0; q < k; q++) {
+	fprintf (fp, "    %s %d %g %g %g", ps->particulate ? "GfsParticulate" : "GfsParticle", (int) id[q],
+		 pos[3*q], pos[3*q + 1], pos[3*q + 2]);
+	if (ps->particulate) {
+	  fprintf (fp, " %g %g %g %g %g", mass[q], volume[id[q]], vel[3*q], vel[3*q + 1], vel[3*q + 2]);
+	  fprintf (fp, " %g %g %g", force[3*q], force[3*q + 1], force[3*q + 2]);
+	}
+	fputc ('\n', fp);
+      }
+      fputs ("}\n", fp);
+    }
+    fclose (fp);
+  }
+  for (auto & ps : R.plists) gfship_particles_destroy (ps->pl);
   for (auto & o : R.outputs) o->close ();
   gfship_sim_destroy (R.sim);
   gfship_domain_destroy (R.dom);
@@ -1216,6 +1344,7 @@ int main (int argc, char ** argv)
     else if (s == "-3") R.dim = 3;
     else if (s == "--device" && a + 1 < argc) R.device = atoi (argv[++a]);
     else if (s == "--check") check_only = true;
+    else if (s == "--particles" && a + 1 < argc) R.particles_out = argv[++a];
     else if (s.compare (0, 2, "-D") == 0) {
       std::string d = s.size () > 2 ? s.substr (2) : (a + 1 < argc ? argv[++a] : "");
       size_t eq = d.find ('=');
@@ -1223,7 +1352,7 @@ int main (int argc, char ** argv)
       else defs[d.substr (0, eq)] = d.substr (eq + 1);
     }
     else if (s == "-h" || s == "--help") {
-      printf ("Usage: %s [-2|-3] [-DNAME=VALUE] [--device N] file.gfs\n", argv[0]);
+      printf ("Usage: %s [-2|-3] [-DNAME=VALUE] [--device N] [--particles FILE] file.gfs\n", argv[0]);
       return 0;
     }
     else file = s;

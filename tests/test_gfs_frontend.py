@@ -145,3 +145,60 @@ def test_vortex_translation_case_matches_r0_ref(golden_dir):
         err = [l.split() for l in out.splitlines() if l.startswith("U time:")][-1]
         # periodic.sh: awk '{print LEVEL, $7, $9}': second, infty
         assert [err[6], err[8]] == row[1:3], (row, err)
+
+
+# ---------------------------------------------------------------------------------------------
+# GfsParticleList of GfsParticulate objects with forces (modules/particulates)
+# ---------------------------------------------------------------------------------------------
+
+def test_check_particulates_case():
+    out = _run("particulates.gfs", {"LEVEL": 5, "NSTEPS": 8}, check=True)
+    ev = [l.split()[1] for l in out.splitlines() if l.startswith("event ")]
+    assert ev == ["ParticleList", "OutputTime"]
+    assert "viscosity 0 0.001" in out and "iend 8" in out
+
+
+@pytest.mark.gpu
+def test_particulates_case_matches_the_oracle(tmp_path):
+    """the list of the case file after 8 steps, as the reference would write it (%g), against the
+    oracle driven from Python with the same set-up (previous velocity of the GfsForceCoeff objects
+    stored while the fields are still zero, like the reference reading the file)"""
+    from oracle import oracle as O
+    from flow_cases import PERIODIC, reynolds_init
+    level, nsteps = 5, 8
+    outp = tmp_path / "plist.txt"
+    cmd = [BIN, "--particles", str(outp), "-DLEVEL=%d" % level, "-DNSTEPS=%d" % nsteps,
+           os.path.join(CASES, "particulates.gfs")]
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    rows = [l.split() for l in open(outp) if l.strip().startswith("GfsParticulate")]
+    got = np.array([[float(x) for x in row[1:]] for row in rows])
+
+    s = O.Sim(2, level, PERIODIC)
+    for c in range(2):
+        s.set_viscosity(c, 1e-3)
+    s.approx_projection_params.tolerance = 1e-6
+    s.projection_params.tolerance = 1e-6
+    s.set_time(end=2.)
+    pos = np.array([[0.11, 0.23, 0], [-0.31, 0.07, 0], [0.4, -0.4, 0], [-0.05, -0.27, 0], [0.25, 0.25, 0]])
+    vel = np.array([[0, 0, 0], [0.1, -0.2, 0], [0, 0.3, 0], [-0.1, 0, 0], [0, 0, 0]], dtype=float)
+    mass = np.array([2e-3, 1.5e-3, 0.5e-3, 3e-3, 1e-3])
+    vol = np.array([1e-3, 1e-3, 1e-3, 2e-3, 0.5e-3])
+    pl = O.Particles(s, pos, np.arange(1, 6, dtype=np.uint32))
+    pl.set_particulate(vel, mass, vol)
+    pl.set_forces([O.FORCE_DRAG, O.FORCE_LIFT, O.FORCE_INERTIAL])      # Un = Vn = 0 here
+    x, y = s.dom.centres()
+    u, v = reynolds_init(x, y)
+    s.u[0].interior()[...] = u
+    s.u[1].interior()[...] = v
+    s.start()
+    for k in range(nsteps):
+        pl.event()
+        s.step()
+    pl.event()
+    op, oi = pl.state()
+    ov, om, of = pl.particulate_state()
+    assert [int(g) for g in got[:, 0]] == list(oi)
+    idx = np.array(oi) - 1
+    want = np.column_stack([oi, op, om, vol[idx], ov, of])
+    assert np.allclose(got, want, rtol=2e-5, atol=1e-9)
