@@ -13,7 +13,7 @@
 // coefficient on U, V, W), VariableTracer, EventStop, EventScript, GModule (ignored: the device
 // solver replaces hypre/agmg), OutputTime, OutputProjectionStats, OutputDiffusionStats,
 // OutputScalarNorm, OutputScalarSum, OutputScalarStats, OutputErrorNorm, OutputLocation,
-// OutputSimulation (text format), GfsParticleList of GfsParticle / GfsParticulate objects with
+// OutputSimulation (text format), OutputEnergySpectra (`GModule fft`), GfsParticleList of GfsParticle / GfsParticulate objects with
 // GfsForce{Inertial,AddedMass,Lift,Drag,Buoy} (`GModule particulates`; --particles FILE writes the
 // lists at the end of the run the way the reference prints them).  Anything else fails loudly with
 // the line number.
@@ -439,7 +439,7 @@ void parse_object (Run & R, Reader & r)
   else if (cls == "GModule") {
     std::string name = r.word (false);
     if (r.peek (false) == '{') r.braces ();
-    if (name == "particulates")
+    if (name == "particulates" || name == "fft")
       ;   /* GfsParticleList / GfsParticulate / GfsForce* are built in (libgfship) */
     else
       fprintf (stderr, "gfship: GModule %s ignored (the Poisson and diffusion solvers are libgfship's)\n",
@@ -592,6 +592,38 @@ void parse_object (Run & R, Reader & r)
 	fprintf (stderr, "gfship: %s\n", gfship_last_error ());
 	exit (1);
       }
+    };
+    add_event (R, e, cls, line);
+  }
+  else if (cls == "OutputEnergySpectra") {
+    // GfsOutputEnergySpectra (modules/fft.c:1360-1530): file { x0 = .. x1 = .. ... } [level]; the box
+    // is transformed whole at the finest level
+    Event * e = new Event;
+    read_event_params (r, *e);
+    Output * o = read_output (R, r);
+    if (r.peek (false) == '{') r.braces ();
+    auto digit = [] (char c) { return c >= '0' && c <= '9'; };
+    if (digit (r.peek (false))) r.number ();
+    Run * pr = &R;
+    e->action = [pr, o] () {
+      Run & R = *pr;
+      int nk = gfship_energy_spectra_bins (R.dom);
+      std::vector<double> Ek ((size_t) std::max (nk, 1));
+      gfship_field u[3];
+      const char * un[3] = { "U", "V", "W" };
+      for (int c = 0; c < R.dim; c++) u[c] = R.vars[R.var_index (un[c])].dev;
+      double Etot = 0., deltak = 0.;
+      if (nk < 0 || gfship_energy_spectra (R.dom, R.dim, u, Ek.data (), &Etot, &deltak) != GFSHIP_OK) {
+	fprintf (stderr, "gfship: %s\n", gfship_last_error ());
+	exit (1);
+      }
+      // write_energy_spectra, modules/fft.c:1340-1348
+      FILE * fp = o->open ();
+      fprintf (fp, "# Total energy = %g \n", Etot);
+      fputs ("# 1:k 2:Ek \n", fp);
+      for (int i = 1; i < nk; i++)
+	fprintf (fp, "%g %g \n", deltak*sqrt ((double) i), Ek[i]);
+      fflush (fp);
     };
     add_event (R, e, cls, line);
   }

@@ -122,6 +122,9 @@ SIGNATURES = {
     "gfship_particles_sort": (_i, [_vp]),
     "gfship_particles_set_sort_interval": (_i, [_vp, _i]),
     "gfship_particles_download": (_i, [_vp, _pd, C.POINTER(C.c_uint)]),
+    "gfship_energy_spectra_bins": (_i, [_vp]),
+    "gfship_energy_spectra": (_i, [_vp, _i, C.POINTER(_i), _pd, C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double)]),
     "gfship_particles_set_particulate": (_i, [_vp, _pd, _pd, _pd]),
     "gfship_particles_set_forces": (_i, [_vp, _i, C.POINTER(_i), _pd]),
     "gfship_particles_download_particulate": (_i, [_vp, _pd, _pd, _pd]),
@@ -281,6 +284,18 @@ class Domain:
         _check(lib().gfship_time_relax_loop(self.ptr, level, u.h, rhs.h, dia.h, nrelax, reps,
                                             C.byref(ms), C.byref(fused)))
         return ms.value, bool(fused.value)
+
+    def energy_spectra(self, comps):
+        """GfsOutputEnergySpectra of the variables comps (U, V[, W]): (k, Ek, Etot) as the reference
+        prints them (modules/fft.c:1340-1348)"""
+        nk = _check(lib().gfship_energy_spectra_bins(self.ptr))
+        Ek = np.empty(nk)
+        etot, dk = C.c_double(), C.c_double()
+        h = (_i * len(comps))(*[c.h for c in comps])
+        _check(lib().gfship_energy_spectra(self.ptr, len(comps), h, Ek.ctypes.data_as(_pd),
+                                           C.byref(etot), C.byref(dk)))
+        i = np.arange(1, nk)
+        return dk.value * np.sqrt(i.astype(float)), Ek[1:].copy(), etot.value
 
     def interpolate(self, v, points):
         """GfsOutputLocation sampling: (values, inside) of variable v at points (np x 3)"""

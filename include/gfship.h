@@ -222,6 +222,18 @@ int  gfship_sim_download_un (gfship_sim * sim, int c, double * host);
 int  gfship_field_interpolate (gfship_domain * dom, gfship_field v, int np, const double * pos,
 			       double * out, unsigned char * inside);
 
+/* ---- energy spectra (modules/fft.c) ------------------------------------------------------------ */
+
+/* GfsOutputEnergySpectra (modules/fft.c:1340-1474) of the whole box at the finest level: for each of
+   the ncomp variables (U, V[, W]) the real-to-complex DFT of (u - <u>)/ntot (fill_cartesian_matrix,
+   :966-1001), |F|^2 summed into Ek[knx^2 + kny^2 + kz^2] with the weights of :1409-1448.  Ek has
+   gfship_energy_spectra_bins() entries; the reference prints "deltak*sqrt(i) Ek[i]" for i >= 1 and
+   "# Total energy = Etot" (write_energy_spectra, :1340-1348).  The DFT is rocFFT's through hipFFT
+   (FFTW in the reference): same definition, not the same rounding. */
+int  gfship_energy_spectra_bins (gfship_domain * dom);
+int  gfship_energy_spectra (gfship_domain * dom, int ncomp, const gfship_field * comps, double * Ek,
+			    double * Etot, double * deltak);
+
 /* ---- Lagrangian tracers (src/particle.c, modules/particulatecommon.c) ------------------------ */
 
 typedef struct gfship_particles gfship_particles;   /* GfsParticleList of GfsParticle */

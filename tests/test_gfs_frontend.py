@@ -202,3 +202,43 @@ def test_particulates_case_matches_the_oracle(tmp_path):
     idx = np.array(oi) - 1
     want = np.column_stack([oi, op, om, vol[idx], ov, of])
     assert np.allclose(got, want, rtol=2e-5, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------
+# GfsOutputEnergySpectra (modules/fft)
+# ---------------------------------------------------------------------------------------------
+
+def test_check_spectra_case():
+    out = _run("spectra.gfs", {"LEVEL": 5, "NSTEPS": 3}, check=True, exe=BIN.replace("2D", "3D"))
+    ev = [l.split()[1] for l in out.splitlines() if l.startswith("event ")]
+    assert ev == ["OutputEnergySpectra", "OutputEnergySpectra"]
+
+
+@pytest.mark.gpu
+def test_spectra_case_taylor_green(tmp_path):
+    """the spectrum files in the reference's format: all the energy of the initial field in
+    |k|^2 = 3, the total equal to the kinetic energy; three steps later it is still there (the
+    flow has barely evolved) and nothing sits beyond the grid's resolved shells"""
+    level = 5
+    r = subprocess.run([BIN.replace("2D", "3D"), "-DLEVEL=%d" % level, "-DNSTEPS=3",
+                        os.path.join(CASES, "spectra.gfs")], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    n = 1 << level
+    for name in ("spectrum-0", "spectrum-end"):
+        lines = open(tmp_path / name).read().splitlines()
+        assert lines[0].startswith("# Total energy = ") and lines[1].strip() == "# 1:k 2:Ek"
+        etot = float(lines[0].split("=")[1])
+        rows = np.array([[float(x) for x in l.split()] for l in lines[2:]])
+        assert len(rows) == 4 * (n // 2 + 1) ** 2 - 1
+        dk = 2 * np.pi / ((n - 1) / n)
+        assert np.isclose(rows[2, 0], dk * np.sqrt(3.), rtol=1e-5)
+        x = (np.arange(n) + 0.5) / n - 0.5
+        Z, Y, X = np.meshgrid(x, x, x, indexing="ij")
+        ke = 0.5 * 2 * np.mean((np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) * np.cos(2 * np.pi * Z)) ** 2)
+        if name == "spectrum-0":
+            assert np.isclose(etot, ke, rtol=1e-5)
+            assert np.isclose(rows[2, 1], ke, rtol=1e-5)
+        else:
+            assert 0.9 * ke < etot <= ke * (1 + 1e-6)
+            assert rows[2, 1] > 0.9 * etot

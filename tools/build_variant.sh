@@ -16,5 +16,5 @@ for f in "$SRC"/*.hip; do
   esac
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgfship_$NAME.so" $OBJS
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgfship_$NAME.so" $OBJS -L/opt/rocm/lib -lhipfft
 echo "built $OUT/libgfship_$NAME.so"
