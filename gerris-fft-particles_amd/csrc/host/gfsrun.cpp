@@ -13,7 +13,8 @@
 // coefficient on U, V, W), VariableTracer, EventStop, EventScript, GModule (ignored: the device
 // solver replaces hypre/agmg), OutputTime, OutputProjectionStats, OutputDiffusionStats,
 // OutputScalarNorm, OutputScalarSum, OutputScalarStats, OutputErrorNorm, OutputLocation,
-// OutputSimulation (text format), OutputEnergySpectra (`GModule fft`), GfsParticleList of GfsParticle / GfsParticulate objects with
+// OutputSimulation (text format), OutputEnergySpectra (`GModule fft`), InitSpectra (`GModule
+// turbulence`), GfsParticleList of GfsParticle / GfsParticulate objects with
 // GfsForce{Inertial,AddedMass,Lift,Drag,Buoy} (`GModule particulates`; --particles FILE writes the
 // lists at the end of the run the way the reference prints them).  Anything else fails loudly with
 // the line number.
@@ -123,6 +124,7 @@ struct Run {
   std::vector<std::unique_ptr<Event>> events;
   std::vector<std::unique_ptr<Output>> outputs;
   std::vector<std::unique_ptr<ParticleSpec>> plists;
+  std::vector<std::pair<gfship_init_spectra_params, std::vector<std::string>>> init_spectra;
   std::string particles_out;                     // --particles FILE: the lists at the end of the run
   FunctionSet functions;
   gfship_domain * dom = nullptr;
@@ -439,7 +441,7 @@ void parse_object (Run & R, Reader & r)
   else if (cls == "GModule") {
     std::string name = r.word (false);
     if (r.peek (false) == '{') r.braces ();
-    if (name == "particulates" || name == "fft")
+    if (name == "particulates" || name == "fft" || name == "turbulence")
       ;   /* GfsParticleList / GfsParticulate / GfsForce* are built in (libgfship) */
     else
       fprintf (stderr, "gfship: GModule %s ignored (the Poisson and diffusion solvers are libgfship's)\n",
@@ -626,6 +628,37 @@ void parse_object (Run & R, Reader & r)
       fflush (fp);
     };
     add_event (R, e, cls, line);
+  }
+  else if (cls == "InitSpectra") {
+    // gfs_init_spectra_read, modules/turbulence.c:277-346:
+    //   GfsInitSpectra { event } { x0 y0 z0 L E } { alpha epsilon c1 c2 c3 [ReL kmax seed] } [level] U V W
+    Event e;
+    read_event_params (r, e);
+    gfship_init_spectra_params p;
+    memset (&p, 0, sizeof (p));
+    p.kmax = DBL_MAX; p.ReL = 0.; p.seed = 0.;
+    auto m1 = r.assignments ();
+    for (auto & kv : m1) {
+      double v = atof (kv.second.c_str ());
+      if (kv.first == "x0") p.x0 = v; else if (kv.first == "y0") p.y0 = v; else if (kv.first == "z0") p.z0 = v;
+      else if (kv.first == "L") p.L = v; else if (kv.first == "E") p.E = v;
+      else r.fail ("unknown GfsInitSpectra keyword `" + kv.first + "'");
+    }
+    auto m2 = r.assignments ();
+    for (auto & kv : m2) {
+      double v = atof (kv.second.c_str ());
+      if (kv.first == "alpha") p.alpha = v; else if (kv.first == "epsilon") p.epsilon = v;
+      else if (kv.first == "c1") p.c1 = v; else if (kv.first == "c2") p.c2 = v; else if (kv.first == "c3") p.c3 = v;
+      else if (kv.first == "ReL") p.ReL = v; else if (kv.first == "kmax") p.kmax = v; else if (kv.first == "seed") p.seed = v;
+      else r.fail ("unknown GfsInitSpectra keyword `" + kv.first + "'");
+    }
+    p.level = -1;                                   /* default: the depth of the domain */
+    char c0 = r.peek (false);
+    if (c0 >= '0' && c0 <= '9') p.level = (int) r.number ();
+    std::vector<std::string> names;
+    for (int c = 0; c < 3; c++) names.push_back (r.word (false));
+    if (R.dim != 3) r.fail ("GfsInitSpectra only works in 3-D (modules/turbulence.c:747)");
+    R.init_spectra.emplace_back (p, names);
   }
   else if (cls == "EventScript") {
     Event * e = new Event;
@@ -1243,6 +1276,21 @@ int run (Run & R)
   }
   set_boundary_conditions (R);
   apply_init (R);
+  for (auto & is : R.init_spectra) {
+    gfship_init_spectra_params p = is.first;
+    if (p.level < 0) p.level = R.level;
+    gfship_field v[3];
+    for (int c = 0; c < 3; c++) {
+      int q = R.var_index (is.second[c]);
+      if (q < 0 || R.vars[q].dev < 0) {
+	fprintf (stderr, "gfship: GfsInitSpectra: `%s' is not a variable of the simulation\n", is.second[c].c_str ());
+	return 1;
+      }
+      v[c] = R.vars[q].dev;
+      R.vars[q].host_time = -1.;
+    }
+    CHECK (gfship_init_spectra (R.dom, &p, v));
+  }
   events_init (R);
 
   if (R.sim_class == "Poisson") {

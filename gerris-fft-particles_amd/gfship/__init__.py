@@ -125,6 +125,7 @@ SIGNATURES = {
     "gfship_energy_spectra_bins": (_i, [_vp]),
     "gfship_energy_spectra": (_i, [_vp, _i, C.POINTER(_i), _pd, C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
+    "gfship_init_spectra": (_i, [_vp, _vp, C.POINTER(_i)]),
     "gfship_particles_set_particulate": (_i, [_vp, _pd, _pd, _pd]),
     "gfship_particles_set_forces": (_i, [_vp, _i, C.POINTER(_i), _pd]),
     "gfship_particles_download_particulate": (_i, [_vp, _pd, _pd, _pd]),
@@ -297,6 +298,15 @@ class Domain:
         i = np.arange(1, nk)
         return dk.value * np.sqrt(i.astype(float)), Ek[1:].copy(), etot.value
 
+    def init_spectra(self, par, fields):
+        """GfsInitSpectra (modules/turbulence.c): par = dict with the keywords of the .gfs object
+        (x0 y0 z0 L E alpha epsilon c1 c2 c3 ReL kmax seed level)"""
+        p = InitSpectraParams()
+        for k, v in par.items():
+            setattr(p, k, v)
+        h = (_i * 3)(*[f.h for f in fields])
+        _check(lib().gfship_init_spectra(self.ptr, C.byref(p), h))
+
     def interpolate(self, v, points):
         """GfsOutputLocation sampling: (values, inside) of variable v at points (np x 3)"""
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
@@ -429,6 +439,11 @@ class Simulation:
 
 
 FORCE_INERTIAL, FORCE_ADDEDMASS, FORCE_LIFT, FORCE_DRAG, FORCE_BUOY = 1, 2, 3, 4, 5
+
+
+class InitSpectraParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("x0", "y0", "z0", "L", "E", "alpha", "epsilon", "c1", "c2",
+                                           "c3", "ReL", "kmax", "seed")] + [("level", C.c_int)]
 
 
 class ParticleList:

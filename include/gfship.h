@@ -234,6 +234,20 @@ int  gfship_energy_spectra_bins (gfship_domain * dom);
 int  gfship_energy_spectra (gfship_domain * dom, int ncomp, const gfship_field * comps, double * Ek,
 			    double * Etot, double * deltak);
 
+/* GfsInitSpectra (modules/turbulence.c:270-901), 3-D: fills the variables v[0..2] with a synthetic
+   solenoidal velocity field whose shell energies follow Pope's model spectrum (ReL != 0:
+   alpha epsilon^(2/3) k^(-5/3) fL feta with c1, c2, c3) or k^2 (ReL = 0) below kmax, rescaled to the
+   total energy E, on a periodic cube of side L centred on (x0, y0, z0) with 2^level points per side,
+   interpolated at the cell centres.  The phases follow the reference: srand (seed) before every
+   rand(), i.e. one value for all modes.  Field names in the struct = keywords of the .gfs object. */
+typedef struct {
+  double x0, y0, z0, L, E;
+  double alpha, epsilon, c1, c2, c3, ReL, kmax, seed;
+  int level;
+} gfship_init_spectra_params;
+int  gfship_init_spectra (gfship_domain * dom, const gfship_init_spectra_params * par,
+			  const gfship_field v[3]);
+
 /* ---- Lagrangian tracers (src/particle.c, modules/particulatecommon.c) ------------------------ */
 
 typedef struct gfship_particles gfship_particles;   /* GfsParticleList of GfsParticle */

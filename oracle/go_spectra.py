@@ -50,3 +50,81 @@ def energy_spectra(comps):
     deltak = 2. * np.pi / ((n - 1) * dx)
     i = np.arange(1, nk)
     return deltak * np.sqrt(i.astype(float)), Ek[1:].copy(), Etot
+
+
+def init_spectra(par, n):
+    """GfsInitSpectra (modules/turbulence.c:545-901) restated with numpy for an n^3 box of unit size:
+    par = dict(x0, y0, z0, L, E, alpha, epsilon, c1, c2, c3, ReL, kmax, seed, level).  Returns the
+    three components indexed [k][j][i].  Same steps as the reference (see spectra.hip for the list);
+    sums in numpy's order, the DFT is pocketfft's: agreement with the device to ~1e-12, not bit for
+    bit.  rand() is the C library's (the reference calls srand (seed) before every rand())."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.srand(ctypes.c_uint(int(par["seed"])))
+    c = 100. * (0.5 - libc.rand() / (2147483647. + 1.))
+    m = 1 << par["level"]
+    nh = m // 2 + 1
+    deltak = 2. * np.pi / par["L"]
+    sg = np.zeros((m, m, nh), dtype=np.int8)
+    sg[:, :, 1:] = 1
+    sg[1:nh, 1:, 0] = 1
+    img = [(m - i, m - j) for i in range(1, nh) for j in range(1, m)]
+    for j in range(1, nh):
+        sg[0, j, 0] = 1
+        sg[0, m - j, 0] = -1
+    sg[1:nh, 0, 0] = 1
+    img += [(m - i, 0) for i in range(1, nh)]
+    for i, j in img:
+        sg[i, j, 0] = -1
+    idx = np.arange(m)
+    kx = np.where(idx < nh, idx, idx - m) * deltak
+    KX, KY, KZ = kx[:, None, None], kx[None, :, None], (np.arange(nh) * deltak)[None, None, :]
+    k2 = KX ** 2 + KY ** 2 + KZ ** 2
+    k2s = np.where(k2 != 0., k2, 1.)
+    u = (1. + 1j * c * sg).astype(np.complex128)
+    us = [(1. - KX ** 2 / k2s) * u - KX * KY / k2s * u - KX * KZ / k2s * u,
+          - KY * KX / k2s * u + (1. - KY ** 2 / k2s) * u - KY * KZ / k2s * u,
+          - KZ * KX / k2s * u - KY * KZ / k2s * u + (1. - KZ ** 2 / k2s) * u]
+    us = [np.where(k2 != 0., a, 0.) for a in us]
+    kn = np.where(idx < nh, idx, m - idx)
+    bins = kn[:, None, None] ** 2 + kn[None, :, None] ** 2 + (np.arange(nh) ** 2)[None, None, :]
+    w = np.where(np.arange(nh) == 0, 0.5, 1.)[None, None, :]
+    nk = 3 * nh * nh
+    Ek = np.zeros(nk)
+    for a in us:
+        np.add.at(Ek, bins.ravel(), (w * (a.real ** 2 + a.imag ** 2)).ravel())
+    i = np.arange(nk)
+    kwave = deltak * np.sqrt(i.astype(float))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if par["ReL"] != 0:
+            Lint = par["E"] ** 1.5 / par["epsilon"]
+            fl = (Lint * kwave / np.sqrt((Lint * kwave) ** 2 + par["c1"])) ** (11. / 3.)
+            feta = np.exp(-par["c2"] * (((Lint * kwave * par["ReL"] ** (-0.75)) ** 4 + par["c3"] ** 4) ** 0.25
+                                        - par["c3"]))
+            Ei = par["alpha"] * par["epsilon"] ** (2. / 3.) * kwave ** (-5. / 3.) * fl * feta
+        else:
+            Ei = kwave ** 2
+    Ei = np.where(kwave < par["kmax"], Ei, 0.)
+    on = (Ek != 0.) & (i >= 1)
+    Ei = np.where(on, Ei, 0.)
+    cscale = np.where(on, np.sqrt(Ei / np.where(on, Ek, 1.)), 0.)
+    cscale2 = np.sqrt(par["E"] / Ei.sum())
+    out = []
+    gx = [par[k] + par["L"] * (np.arange(m) / (m - 1.) - 0.5) for k in ("x0", "y0", "z0")]
+    pc = (np.arange(n) + 0.5) / n - 0.5
+    for a in us:
+        a = a * (cscale2 * cscale[bins])
+        g = np.fft.irfftn(a, s=(m, m, m), axes=(0, 1, 2)) * float(m) ** 3        # unnormalised c2r, [ix][iy][iz]
+        # gfs_cartesian_grid_interpolate at the cell centres: z innermost, x outermost
+        def interp(arr, axis, x, p):
+            lo = np.clip(np.searchsorted(x, p, side="left") - 1, 0, len(x) - 2)
+            v1, v2 = np.take(arr, lo, axis=axis), np.take(arr, lo + 1, axis=axis)
+            shape = [1] * arr.ndim
+            shape[axis] = len(p)
+            t = ((p - x[lo]) / (x[lo + 1] - x[lo])).reshape(shape)
+            return v1 + (v2 - v1) * t
+        v = interp(g, 2, gx[2], pc)
+        v = interp(v, 1, gx[1], pc)
+        v = interp(v, 0, gx[0], pc)
+        out.append(np.ascontiguousarray(np.transpose(v)))        # -> [k][j][i]
+    return out
