@@ -57,6 +57,7 @@ struct SkewPlan {
   void * ctl = nullptr;           // { ticket, err }
   unsigned long long * stats = nullptr; // optional per-tile timing (debug)
   unsigned short * order = nullptr;
+  unsigned short * xorder = nullptr;   // tiles by XCD block (relax_skew_loop.hip)
 };
 
 // cell update of the exact-order sweeps: kind 0 = Poisson relax (unit weights), kind 1 =
@@ -94,6 +95,7 @@ struct gfship_domain {
   gfship_field dp_cache = -1;     // the `dp` temporary of gfs_poisson_cycle, kept between cycles
   int skew_resident = -1;         // workgroups of the fused relax loop that fit on the device
   bool wave_loop = false;         // fused relax loops by the experimental one-wave-per-tile kernel (GFSHIP_WAVE_LOOP=1)
+  bool xcd_place = false;         // XCD-aware tile placement in the loop kernel (experiment, GFSHIP_XCD_PLACE=1)
   bool skew_old = false;          // single sweeps by the older four-wave kernel (GFSHIP_SKEW_OLD)
   bool no_fused_godunov = false;  // face-value arrays + separate kernels even on periodic boxes
   bool no_fused_loop = false;     // one launch per sweep even where the fused loop applies

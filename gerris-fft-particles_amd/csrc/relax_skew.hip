@@ -364,6 +364,19 @@ static int skew_plan (gfship_domain * dom, int level, SkewPlan ** out)
     GFSHIP_HIP (hipMalloc ((void **) &S.order, order.size ()*sizeof (unsigned short)));
     GFSHIP_HIP (hipMemcpy (S.order, order.data (), order.size ()*sizeof (unsigned short),
 			   hipMemcpyHostToDevice));
+    if (ntiles >= 8 && S.ntj % 4 == 0) {
+      // blocks of (ntj/2) x (ntj/4) tiles, one per XCD, each in anti-diagonal order
+      int bw = S.ntj/2, bh = S.ntj/4;
+      std::vector<unsigned short> xo;
+      for (int x = 0; x < 8; x++)
+	for (unsigned short t : order) {
+	  int P = t % S.ntj, Q = t / S.ntj;
+	  if ((P/bw) + 2*(Q/bh) == x) xo.push_back (t);
+	}
+      GFSHIP_HIP (hipMalloc ((void **) &S.xorder, xo.size ()*sizeof (unsigned short)));
+      GFSHIP_HIP (hipMemcpy (S.xorder, xo.data (), xo.size ()*sizeof (unsigned short),
+			     hipMemcpyHostToDevice));
+    }
     GFSHIP_HIP (hipMemsetAsync (S.ctl, 0, 64, dom->stream));
   }
   *out = &S;
@@ -384,6 +397,7 @@ void skew_free (gfship_domain * dom)
     if (S.ctl) (void) hipFree (S.ctl);
     if (S.stats) (void) hipFree (S.stats);
     if (S.order) (void) hipFree (S.order);
+    if (S.xorder) (void) hipFree (S.xorder);
     S = SkewPlan ();
   }
 }

@@ -72,7 +72,34 @@ struct SkewLoopArgs {
   unsigned * ticket, * err;
   const u64 * dummy;
   u64 * stats;             // optional [tile][sweep]{start, end} (debug, GFSHIP_SKEW_STATS)
+  // XCD-aware placement (all tiles resident): the tiles are split into 8 blocks, one per XCD, and
+  // a workgroup claims a tile of the block of the XCD it runs on (any other block once its own is
+  // exhausted): most hand-offs then stay inside one L2
+  const unsigned short * xorder;   // [8][per_xcd] tiles of each block, anti-diagonal order
+  unsigned * xticket;              // [8] ticket counters (zeroed before the launch)
+  int per_xcd;                     // 0: placement by the single ticket counter
 };
+
+__device__ __forceinline__ unsigned skew_xcc_id ()
+{
+  unsigned v;
+  asm volatile ("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s" (v));
+  return v & 7;
+}
+
+__device__ __forceinline__ unsigned skew_claim_tile (const SkewLoopArgs & A)
+{
+  if (A.per_xcd == 0)
+    return A.order[atomicAdd (A.ticket, 1u)];
+  const unsigned x = skew_xcc_id ();
+  for (unsigned q = 0; q < 8; q++) {
+    const unsigned xx = (x + q) & 7;
+    const unsigned k = atomicAdd (&A.xticket[xx], 1u);
+    if (k < (unsigned) A.per_xcd)
+      return A.xorder[xx*A.per_xcd + k];
+  }
+  return 0;     /* not reached: as many workgroups as tiles */
+}
 
 // Workgroup = 4 compute waves (256 lines) + 1 halo wave + 1 store wave.  The halo wave streams
 // the four halo strips into LDS (and polls the granules that are not there yet); the store wave
@@ -106,7 +133,7 @@ relax_skew_loop_kernel (SkewLoopArgs A)
   const long hstride = (long) SK_HROWS (n)*SK_T;
 
   if (tid0 == 0)
-    s_tile = A.order[atomicAdd (A.ticket, 1u)];
+    s_tile = skew_claim_tile (A);
   __syncthreads ();
   const int tile = s_tile;
   const int P = tile % ntj, Q = tile / ntj;
@@ -763,14 +790,9 @@ skew_loop_ghosts_kernel (SkewLoopArgs A)
 // host side
 // ---------------------------------------------------------------------------------------------
 
-bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool bc)
+// workgroups of the loop kernels that are resident at once on the device
+static int skew_loop_resident (gfship_domain * dom)
 {
-  if (!bc || nrelax < 2 || nrelax > SK_MAXF) return false;
-  if (!skew_supported (dom, level)) return false;
-  for (int d = 0; d < 6; d++)
-    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL) return false;   /* the exchange comes between the sweeps */
-  // every tile waits on tiles of the previous sweep: all of them must be resident
-  int ntj = dom->lay[level].n/SK_T, ntiles = ntj*ntj;
   if (dom->skew_resident < 0) {
     int per_cu = 0, per_cu_w = 0, dev = 0;
     hipDeviceProp_t prop;
@@ -783,7 +805,18 @@ bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool 
     else
       dom->skew_resident = (per_cu < per_cu_w ? per_cu : per_cu_w)*prop.multiProcessorCount;
   }
-  return ntiles <= dom->skew_resident;
+  return dom->skew_resident;
+}
+
+bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool bc)
+{
+  if (!bc || nrelax < 2 || nrelax > SK_MAXF) return false;
+  if (!skew_supported (dom, level)) return false;
+  for (int d = 0; d < 6; d++)
+    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL) return false;   /* the exchange comes between the sweeps */
+  // every tile waits on tiles of the previous sweep: all of them must be resident
+  int ntj = dom->lay[level].n/SK_T, ntiles = ntj*ntj;
+  return ntiles <= skew_loop_resident (dom);
 }
 
 // nrelax >= 2: the fused loop of a periodic level.  nrelax == 1: one sweep of any level the
@@ -823,6 +856,13 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   A.un = u_nat;
   A.hb = (u64 *) S->hbf; A.hb_sweep = hb_sweep; A.hb_words = hb_words;
   A.order = S->order;
+  A.xorder = S->xorder;
+  A.xticket = (unsigned *) S->ctl + 6;
+  A.per_xcd = 0;
+  if (dom->xcd_place && S->xorder && ntiles >= 8 && skew_loop_resident (dom) >= ntiles) {
+    A.per_xcd = ntiles/8;
+    GFSHIP_HIP (hipMemsetAsync ((unsigned *) S->ctl + 6, 0, 8*sizeof (unsigned), dom->stream));
+  }
   A.ticket = (unsigned *) S->ctl;
   A.err = (unsigned *) S->ctl + 1;
   A.dummy = (const u64 *) S->ctl + 2;
