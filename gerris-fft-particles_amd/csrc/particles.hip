@@ -492,12 +492,14 @@ particulate_list_event_kernel (ParticulateArgs A, int depth)
 // box -- the same point of space, one box size less along the normal -- and the id) and leave
 // the list
 struct OutboxArgs {
-  int n, out_cap;
+  int n, out_cap, rs;          // rs doubles per record: 7, or 15 for particulates
   const double * pos[3], * old[3];
   const unsigned * id;
   unsigned char * alive;
   double * outbox;
   unsigned * out_count;
+  const unsigned * orig;       // particulates: state indexed by the creation slot
+  const double * vel[3], * force[3], * mass, * volume;
 };
 
 __global__ void __launch_bounds__(256)
@@ -511,13 +513,20 @@ particle_outbox_kernel (OutboxArgs A)
   A.alive[q] = 0;
   unsigned k = atomicAdd (A.out_count + d, 1u);
   if (k >= (unsigned) A.out_cap) return;      /* the host sees the count and reports the overflow */
-  double * r = A.outbox + 7*((size_t) d*A.out_cap + k);
+  double * r = A.outbox + (size_t) A.rs*((size_t) d*A.out_cap + k);
   double normal = (double) (d ^ 1) - (double) d;
 #pragma unroll
   for (int c = 0; c < 3; c++) { r[c] = A.pos[c][q]; r[3 + c] = A.old[c][q]; }
   r[d/2] -= normal*1.;
   r[3 + d/2] -= normal*1.;
   r[6] = (double) A.id[q];
+  if (A.rs > 7) {
+    const unsigned o = A.orig[q];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { r[7 + c] = A.vel[c][o]; r[12 + c] = A.force[c][o]; }
+    r[10] = A.mass[o];
+    r[11] = A.volume[o];
+  }
 }
 
 // key = linear index of the containing leaf cell, dead or outside particles last
@@ -807,6 +816,15 @@ static int particles_reserve (gfship_particles * pl, int need)
   for (unsigned ** a : scratch)
     GFSHIP_HIP (grow ((void **) a, sizeof (unsigned), false));
   GFSHIP_HIP (grow ((void **) &pl->alive2, 1, false));
+  if (pl->particulate) {
+    for (int c = 0; c < 3; c++) {
+      GFSHIP_HIP (grow ((void **) &pl->vel[c], sizeof (double), true));
+      GFSHIP_HIP (grow ((void **) &pl->force[c], sizeof (double), true));
+    }
+    GFSHIP_HIP (grow ((void **) &pl->mass, sizeof (double), true));
+    GFSHIP_HIP (grow ((void **) &pl->volume, sizeof (double), true));
+    GFSHIP_HIP (grow ((void **) &pl->dia, sizeof (double), true));
+  }
   pl->cap = (int) m;
   return GFSHIP_OK;
 }
@@ -816,18 +834,21 @@ static int particles_reserve (gfship_particles * pl, int need)
 static int particles_migrate (gfship_particles * pl)
 {
   gfship_domain * dom = pl->dom;
+  const int rs = pl->particulate ? 15 : 7;
   const int want = std::max (4096, pl->n/4);
   if (pl->out_cap < want) {
     if (pl->outbox) GFSHIP_HIP (hipFree (pl->outbox));
     pl->outbox = nullptr;
-    GFSHIP_HIP (hipMalloc ((void **) &pl->outbox, 6*(size_t) want*7*sizeof (double)));
+    GFSHIP_HIP (hipMalloc ((void **) &pl->outbox, 6*(size_t) want*15*sizeof (double)));
     pl->out_cap = want;
   }
   if (!pl->out_count)
     GFSHIP_HIP (hipMalloc ((void **) &pl->out_count, 6*sizeof (unsigned)));
   GFSHIP_HIP (hipMemsetAsync (pl->out_count, 0, 6*sizeof (unsigned), dom->stream));
   OutboxArgs O;
-  O.n = pl->n; O.out_cap = pl->out_cap;
+  O.n = pl->n; O.out_cap = pl->out_cap; O.rs = rs;
+  O.orig = pl->orig; O.mass = pl->mass; O.volume = pl->volume;
+  for (int c = 0; c < 3; c++) { O.vel[c] = pl->vel[c]; O.force[c] = pl->force[c]; }
   for (int c = 0; c < 3; c++) { O.pos[c] = pl->pos[c]; O.old[c] = pl->old[c]; }
   O.id = pl->id; O.alive = pl->alive; O.outbox = pl->outbox; O.out_count = pl->out_count;
   if (pl->n > 0) {
@@ -845,17 +866,17 @@ static int particles_migrate (gfship_particles * pl)
 		  "%u particles leave through side %d in one step: more than the %d the packet holds",
 		  cnt[d], d, pl->out_cap);
     nsend[d] = (int) cnt[d];
-    send[d].resize (7*(size_t) cnt[d]);
+    send[d].resize ((size_t) rs*cnt[d]);
     if (cnt[d])
-      GFSHIP_HIP (hipMemcpy (send[d].data (), pl->outbox + 7*(size_t) d*pl->out_cap,
-			     7*(size_t) cnt[d]*sizeof (double), hipMemcpyDeviceToHost));
+      GFSHIP_HIP (hipMemcpy (send[d].data (), pl->outbox + (size_t) rs*d*pl->out_cap,
+			     (size_t) rs*cnt[d]*sizeof (double), hipMemcpyDeviceToHost));
     /* the device fills the packet in no particular order: sort it by id */
     std::vector<size_t> o (cnt[d]);
     std::iota (o.begin (), o.end (), (size_t) 0);
-    std::sort (o.begin (), o.end (), [&] (size_t a, size_t b) { return send[d][7*a + 6] < send[d][7*b + 6]; });
+    std::sort (o.begin (), o.end (), [&] (size_t a, size_t b) { return send[d][rs*a + 6] < send[d][rs*b + 6]; });
     std::vector<double> sorted (send[d].size ());
     for (size_t q = 0; q < o.size (); q++)
-      memcpy (&sorted[7*q], &send[d][7*o[q]], 7*sizeof (double));
+      memcpy (&sorted[rs*q], &send[d][rs*o[q]], rs*sizeof (double));
     send[d].swap (sorted);
     sp[d] = send[d].data ();
   }
@@ -872,19 +893,33 @@ static int particles_migrate (gfship_particles * pl)
     size_t k = 0;
     for (int d = 0; d < 6; d++)             /* box_rcv_bc: side by side, in packet order */
       for (int q = 0; q < nrecv[d]; q++)
-	col[k++] = rp[d][7*(size_t) q + c];
+	col[k++] = rp[d][(size_t) rs*q + c];
     GFSHIP_HIP (hipMemcpy ((c < 3 ? pl->pos[c] : pl->old[c - 3]) + pl->n, col.data (),
 			   total*sizeof (double), hipMemcpyHostToDevice));
   }
   size_t k = 0;
   for (int d = 0; d < 6; d++)
     for (int q = 0; q < nrecv[d]; q++, k++) {
-      ids[k] = (unsigned) rp[d][7*(size_t) q + 6];
+      ids[k] = (unsigned) rp[d][(size_t) rs*q + 6];
       orig[k] = (unsigned) (pl->n + k);
     }
   GFSHIP_HIP (hipMemcpy (pl->id + pl->n, ids.data (), total*sizeof (unsigned), hipMemcpyHostToDevice));
   GFSHIP_HIP (hipMemcpy (pl->orig + pl->n, orig.data (), total*sizeof (unsigned), hipMemcpyHostToDevice));
   GFSHIP_HIP (hipMemcpy (pl->alive + pl->n, one.data (), total, hipMemcpyHostToDevice));
+  if (pl->particulate) {
+    /* the state of the newcomers lives at their creation slots pl->n .. pl->n + total - 1 */
+    for (int c = 0; c < 9; c++) {      /* record columns 7 .. 14: vel, mass, volume, force; then dia */
+      size_t kk = 0;
+      for (int d = 0; d < 6; d++)
+	for (int q = 0; q < nrecv[d]; q++) {
+	  const double * r = rp[d] + (size_t) rs*q;
+	  col[kk++] = c < 8 ? r[7 + c] : 2.*pow (3.0*r[11]/4.0/M_PI, 1./3.);
+	}
+      double * dst = c < 3 ? pl->vel[c] : c == 3 ? pl->mass : c == 4 ? pl->volume :
+	c < 8 ? pl->force[c - 5] : pl->dia;
+      GFSHIP_HIP (hipMemcpy (dst + pl->n, col.data (), total*sizeof (double), hipMemcpyHostToDevice));
+    }
+  }
   pl->n += total;
   return GFSHIP_OK;
 }
@@ -892,10 +927,15 @@ static int particles_migrate (gfship_particles * pl)
 int gfship_particles_set_migrate (gfship_particles * pl, gfship_particle_migrate_fn fn, void * ctx)
 {
   GFSHIP_CHECK (pl != nullptr, GFSHIP_EINVAL, "null particle list");
-  GFSHIP_CHECK (!pl->particulate, GFSHIP_EINVAL, "particulates do not migrate between boxes yet");
   pl->migrate = fn;
   pl->migrate_ctx = ctx;
   return GFSHIP_OK;
+}
+
+int gfship_particles_record_size (gfship_particles * pl)
+{
+  GFSHIP_CHECK (pl != nullptr, GFSHIP_EINVAL, "null particle list");
+  return pl->particulate ? 15 : 7;
 }
 
 int gfship_particles_slots (gfship_particles * pl)
@@ -958,8 +998,8 @@ int gfship_particles_set_particulate (gfship_particles * pl, const double * vel,
 {
   GFSHIP_CHECK (pl && vel && mass && volume, GFSHIP_EINVAL, "null argument");
   GFSHIP_CHECK (!pl->particulate, GFSHIP_EINVAL, "the list already holds particulates");
-  GFSHIP_CHECK (!pl->migrate, GFSHIP_EINVAL, "particulates do not migrate between boxes yet");
-  size_t m = (size_t) std::max (pl->np0, 1), np = (size_t) pl->np0;
+  size_t m = (size_t) pl->cap, np = (size_t) pl->n;
+  GFSHIP_CHECK (pl->n == pl->np0, GFSHIP_EINVAL, "set the particulate state before the first migration");
   std::vector<double> tmp (m, 0.);
   for (int c = 0; c < 3; c++) {
     GFSHIP_HIP (hipMalloc ((void **) &pl->vel[c], m*sizeof (double)));
@@ -1017,7 +1057,7 @@ int gfship_particles_download_particulate (gfship_particles * pl, double * vel, 
   if (pl->n == 0) return 0;
   gfship_domain * dom = pl->dom;
   GFSHIP_HIP (hipStreamSynchronize (dom->stream));
-  size_t m = pl->n, m0 = pl->np0;
+  size_t m = pl->n, m0 = pl->n;      /* creation slots = slots in use */
   std::vector<unsigned> orig (m), where (m);
   std::vector<unsigned char> al (m);
   std::vector<double> v[3], f[3], ms (m0);
@@ -1071,8 +1111,11 @@ int gfship_particle_list_event (gfship_particles * pl)
   A.count = pl->d_count;
   A.migrate = pl->migrate != nullptr;
   int block = 256, grid = (pl->n + block - 1)/block;
-  if (pl->n > 0 && pl->particulate && pl->nforces > 0)
-    return particulate_event (pl, A, v.visc);
+  if (pl->n > 0 && pl->particulate && pl->nforces > 0) {
+    int r = particulate_event (pl, A, v.visc);
+    if (r) return r;
+    return pl->migrate ? particles_migrate (pl) : GFSHIP_OK;
+  }
   if (pl->n > 0) {
     if (dom->dim == 3)
       hipLaunchKernelGGL (particle_list_event_kernel<3>, dim3 (grid), dim3 (block), 0, dom->stream,

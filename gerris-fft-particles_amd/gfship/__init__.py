@@ -119,6 +119,7 @@ SIGNATURES = {
     "gfship_particles_count": (_i, [_vp]),
     "gfship_particles_set_migrate": (_i, [_vp, _vp, _vp]),
     "gfship_particles_slots": (_i, [_vp]),
+    "gfship_particles_record_size": (_i, [_vp]),
     "gfship_particles_sort": (_i, [_vp]),
     "gfship_particles_set_sort_interval": (_i, [_vp, _i]),
     "gfship_particles_download": (_i, [_vp, _pd, C.POINTER(C.c_uint)]),

@@ -126,8 +126,8 @@ class Transport:
         for q in dist.batch_isend_irecv(ops):
             q.wait()
 
-    def exchange_records(self, out):
-        """out[s]: (n, 7) records leaving through my MPI side s; returns {r: records arriving
+    def exchange_records(self, out, rs=7):
+        """out[s]: (n, rs) records leaving through my MPI side s; returns {r: records arriving
         through my side r}.  Counts first, then the payloads, matched like the halo messages."""
         t, dist = self.torch, self.dist
         sides = sorted(out)
@@ -145,7 +145,7 @@ class Transport:
             self.exchange(sides, cnt_s, sides, cnt_r)
         snd = {s: t.from_numpy(np.ascontiguousarray(out[s]).ravel()).to(dev)
                for s in sides if len(out[s])}
-        rcv = {r: t.empty(7 * int(cnt_r[r].item()), dtype=t.float64, device=dev)
+        rcv = {r: t.empty(rs * int(cnt_r[r].item()), dtype=t.float64, device=dev)
                for r in sides if int(cnt_r[r].item())}
         # every box knows which of its messages are empty on both ends: only the others are posted
         ops = []
@@ -156,7 +156,7 @@ class Transport:
         if ops:
             for q in dist.batch_isend_irecv(ops):
                 q.wait()
-        return {r: rcv[r].cpu().numpy().reshape(-1, 7) for r in rcv}
+        return {r: rcv[r].cpu().numpy().reshape(-1, rs) for r in rcv}
 
     def allreduce(self, vals, op):
         t, dist = self.torch, self.dist
@@ -274,12 +274,14 @@ class ParticleMigration:
 
     def _migrate(self, ctx, nsend, send, nrecv, recv):
         try:
+            import gfship
+            rs = gfship.lib().gfship_particles_record_size(self.pl.ptr)   # 7, particulates 15
             out = {}
             for d in self.tr.grid.external_sides():
                 n = nsend[d]
-                out[d] = (np.ctypeslib.as_array(send[d], shape=(n, 7)).copy() if n
-                          else np.empty((0, 7)))
-            inc = self.tr.exchange_records(out)
+                out[d] = (np.ctypeslib.as_array(send[d], shape=(n, rs)).copy() if n
+                          else np.empty((0, rs)))
+            inc = self.tr.exchange_records(out, rs)
             self._keep = {}
             for d in range(6):
                 a = inc.get(d)
@@ -392,7 +394,7 @@ class LocalTransport:
             self.torch.cuda.current_stream().synchronize()     # my copies are complete
         f.barrier.wait()
 
-    def exchange_records(self, out):
+    def exchange_records(self, out, rs=7):
         f = self.fabric
         f.posted[self.rank] = out
         f.barrier.wait()

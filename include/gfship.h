@@ -277,6 +277,9 @@ typedef int (* gfship_particle_migrate_fn) (void * ctx, const int nsend[6],
 					    const double * const send[6], int nrecv[6],
 					    const double * recv[6]);
 int  gfship_particles_set_migrate (gfship_particles * pl, gfship_particle_migrate_fn fn, void * ctx);
+/* doubles per record of the migration packets: 7, or 15 for particulates (+ velocity, mass, volume,
+   force) */
+int  gfship_particles_record_size (gfship_particles * pl);
 /* slots in use (alive or not): upper bound of the count, size of the download buffers */
 int  gfship_particles_slots (gfship_particles * pl);
 int  gfship_particles_count (gfship_particles * pl);
@@ -294,7 +297,8 @@ int  gfship_particles_download (gfship_particles * pl, double * pos, unsigned * 
    viscosity), GfsForceBuoy (:619-653, gravity = the sum of the GfsSource intensities on U, V, W) --
    then pos += vel*dt/2, vel += force*dt/mass, pos += vel*dt/2 and gfs_particle_bc.  fluid density 1
    (alpha = NULL), viscosity = gfship_sim_set_viscosity of U; user coefficient functions
-   (GfsForceCoeff with a GfsFunction) and migration between boxes are not supported yet. */
+   (GfsForceCoeff with a GfsFunction) are not supported yet.  Particulates migrate between boxes like
+   tracers, with 15-double records. */
 enum { GFSHIP_FORCE_INERTIAL = 1, GFSHIP_FORCE_ADDEDMASS = 2, GFSHIP_FORCE_LIFT = 3,
        GFSHIP_FORCE_DRAG = 4, GFSHIP_FORCE_BUOY = 5 };
 int  gfship_particles_set_particulate (gfship_particles * pl, const double * vel, const double * mass,

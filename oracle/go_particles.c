@@ -241,7 +241,10 @@ void go_particles_destroy (GoParticles * pl)
   free (pl);
 }
 
-/* the packet of particles sent through side d (7 doubles per particle) */
+/* doubles per migrating particle: pos, pos_old, id (+ vel, mass, volume, force for particulates) */
+int go_particles_record_size (const GoParticles * pl) { return pl->particulate ? 15 : 7; }
+
+/* the packet of particles sent through side d (go_particles_record_size doubles per particle) */
 int go_particles_outbox (GoParticles * pl, int d, double ** rec)
 {
   *rec = pl->out[d];
@@ -256,16 +259,31 @@ void go_particles_clear_outbox (GoParticles * pl)
 /* mpi_rcv_particle, particulatecommon.c:3224-3245: the received particles join the list */
 void go_particles_append (GoParticles * pl, int n, const double * rec)
 {
+  int rs = go_particles_record_size (pl);
   if (pl->n + n > pl->cap) {
     pl->cap = 2*(pl->n + n);
     pl->pos = realloc (pl->pos, 3*(size_t) pl->cap*sizeof (double));
     pl->pos_old = realloc (pl->pos_old, 3*(size_t) pl->cap*sizeof (double));
     pl->id = realloc (pl->id, (size_t) pl->cap*sizeof (unsigned));
+    if (pl->particulate) {
+      pl->vel = realloc (pl->vel, 3*(size_t) pl->cap*sizeof (double));
+      pl->force = realloc (pl->force, 3*(size_t) pl->cap*sizeof (double));
+      pl->mass = realloc (pl->mass, (size_t) pl->cap*sizeof (double));
+      pl->volume = realloc (pl->volume, (size_t) pl->cap*sizeof (double));
+    }
   }
   for (int q = 0; q < n; q++) {
-    memcpy (pl->pos + 3*(pl->n + q), rec + 7*q, 3*sizeof (double));
-    memcpy (pl->pos_old + 3*(pl->n + q), rec + 7*q + 3, 3*sizeof (double));
-    pl->id[pl->n + q] = (unsigned) rec[7*q + 6];
+    const double * r = rec + (size_t) rs*q;
+    int m = pl->n + q;
+    memcpy (pl->pos + 3*m, r, 3*sizeof (double));
+    memcpy (pl->pos_old + 3*m, r + 3, 3*sizeof (double));
+    pl->id[m] = (unsigned) r[6];
+    if (pl->particulate) {
+      memcpy (pl->vel + 3*m, r + 7, 3*sizeof (double));
+      pl->mass[m] = r[10];
+      pl->volume[m] = r[11];
+      memcpy (pl->force + 3*m, r + 12, 3*sizeof (double));
+    }
   }
   pl->n += n;
 }
@@ -296,12 +314,12 @@ static void move_particle (GoParticles * pl, int m, int q)
 void go_particles_set_particulate (GoParticles * pl, const double * vel, const double * mass,
 				   const double * volume)
 {
-  size_t np = (size_t) pl->n;
+  size_t np = (size_t) pl->n, cap = (size_t) (pl->cap > 0 ? pl->cap : 1);
   pl->particulate = 1;
-  pl->vel = malloc (3*np*sizeof (double));
-  pl->force = calloc (3*np, sizeof (double));
-  pl->mass = malloc (np*sizeof (double));
-  pl->volume = malloc (np*sizeof (double));
+  pl->vel = malloc (3*cap*sizeof (double));
+  pl->force = calloc (3*cap, sizeof (double));
+  pl->mass = malloc (cap*sizeof (double));
+  pl->volume = malloc (cap*sizeof (double));
   memcpy (pl->vel, vel, 3*np*sizeof (double));
   memcpy (pl->mass, mass, np*sizeof (double));
   memcpy (pl->volume, volume, np*sizeof (double));
@@ -546,12 +564,18 @@ void go_particle_list_event (GoSim * s, GoParticles * pl)
 	 (send_particles :3247-3268); its position is the same point of space, i.e. one box size
 	 less along the normal in the coordinates of the receiving box */
       double normal = (double) (d ^ 1) - (double) d;
-      pl->out[d] = realloc (pl->out[d], 7*(size_t) (pl->nout[d] + 1)*sizeof (double));
-      double * r = pl->out[d] + 7*(size_t) pl->nout[d]++;
+      int rs = go_particles_record_size (pl);
+      pl->out[d] = realloc (pl->out[d], (size_t) rs*(pl->nout[d] + 1)*sizeof (double));
+      double * r = pl->out[d] + (size_t) rs*pl->nout[d]++;
       for (int c = 0; c < 3; c++) { r[c] = p[c]; r[3 + c] = po[c]; }
       r[d/2] -= normal*1.;
       r[3 + d/2] -= normal*1.;
       r[6] = (double) pl->id[q];
+      if (pl->particulate) {
+	for (int c = 0; c < 3; c++) { r[7 + c] = pl->vel[3*q + c]; r[12 + c] = pl->force[3*q + c]; }
+	r[10] = pl->mass[q];
+	r[11] = pl->volume[q];
+      }
       drop[q] = 1;
     }
     else if (dom->side[d] != GO_SIDE_PERIODIC)

@@ -9,7 +9,7 @@ typedef struct {
   unsigned * id;
   /* particles that left through a GfsBoundaryMpi side d, as sent to the neighbour
      (mpi_send_particle, particulatecommon.c:3218-3222): 7 doubles each (pos, pos_old, id) in
-     the neighbour's coordinates */
+     the neighbour's coordinates, 15 for particulates (+ vel, mass, volume, force) */
   int nout[6];
   double * out[6];
   /* GfsParticulate (modules/particulatecommon.h:35-48): mass, volume, velocity, force; the list's
@@ -31,6 +31,7 @@ void   go_advect_point (GoSim * s, double p[3], double dt);
 GoParticles * go_particles_new (int np, const double * pos, const unsigned * id);
 void   go_particles_destroy (GoParticles * pl);
 int    go_particles_count (const GoParticles * pl);
+int    go_particles_record_size (const GoParticles * pl);
 int    go_particles_outbox (GoParticles * pl, int d, double ** rec);
 void   go_particles_clear_outbox (GoParticles * pl);
 void   go_particles_append (GoParticles * pl, int n, const double * rec);

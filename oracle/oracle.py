@@ -331,6 +331,7 @@ class Particles:
                 "go_particle_list_event": (None, [vp, vp]),
                 "go_locate": (i, [vp, pd, C.POINTER(C.c_int)]),
                 "go_particles_outbox": (i, [vp, i, C.POINTER(pd)]),
+                "go_particles_record_size": (i, [vp]),
                 "go_particles_clear_outbox": (None, [vp]),
                 "go_particles_append": (None, [vp, i, pd]),
                 "go_particles_set_particulate": (None, [vp, pd, pd, pd]),
@@ -356,18 +357,20 @@ class Particles:
         return lib().go_particles_count(self.ptr)
 
     def outbox(self, d):
-        """records (n x 7: pos, pos_old, id) of the particles sent through MPI side d"""
+        """records (n x 7: pos, pos_old, id; n x 15 for particulates: + vel, mass, volume, force) of
+        the particles sent through MPI side d"""
+        rs = lib().go_particles_record_size(self.ptr)
         rec = C.POINTER(C.c_double)()
         n = lib().go_particles_outbox(self.ptr, d, C.byref(rec))
         if n == 0:
-            return np.empty((0, 7))
-        return np.ctypeslib.as_array(rec, shape=(n, 7)).copy()
+            return np.empty((0, rs))
+        return np.ctypeslib.as_array(rec, shape=(n, rs)).copy()
 
     def clear_outbox(self):
         lib().go_particles_clear_outbox(self.ptr)
 
     def append(self, rec):
-        rec = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, 7)
+        rec = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, lib().go_particles_record_size(self.ptr))
         if len(rec):
             lib().go_particles_append(self.ptr, len(rec), rec.ctypes.data_as(C.POINTER(C.c_double)))
 

@@ -114,7 +114,7 @@ class _MirrorTransport:
         a = np.array(vals, dtype=np.float64)
         return a + a if op == 0 else a
 
-    def exchange_records(self, out):
+    def exchange_records(self, out, rs=7):
         return {r: out[r ^ 1] for r in out if len(out[r ^ 1])}
 
 
@@ -327,3 +327,96 @@ def test_particulates_sediment_out_of_a_closed_box():
         osim.step()
         gs.step()
     assert counts[-1] < counts[0]
+
+
+def test_particulates_migrate_between_two_boxes_on_one_gpu():
+    """particulates crossing a GfsBoundaryMpi side carry their velocity, mass, volume and force with
+    them (15-double records): two device boxes in one process against the oracle run of one box
+    of the same lattice and its mirror image; drag + lift + buoyancy in a viscous through-flow"""
+    import threading
+    import torch
+    from gfship import distributed as D
+    level, nsteps, npart, nu = 4, 5, 1200, 1e-2
+    grid = D.BoxGrid(2, 3)
+    pos, ids, vel, mass, vol = _particulate_case(npart, 3, 21)
+    pos[:150, 0] = 0.5 - 3e-4 * (1 + np.arange(150))          # a crowd next to the +x MPI side
+    vel[:150, 0] = 0.6
+    forces, gravity = [O.FORCE_DRAG, O.FORCE_LIFT, O.FORCE_BUOY], (0., 0.3, 0.)
+
+    def init(sim_u, x, y, z):
+        from flow_cases import taylor_green_3d
+        for c, a in enumerate(taylor_green_3d(x, y, z)):
+            sim_u[c][...] = a + (0.7 if c == 0 else 0.)
+
+    osim = O.Sim(3, level, grid.sides(0))
+    for c in range(3):
+        osim.set_viscosity(c, nu)
+    mt = _MirrorTransport(grid)
+    ohooks = D.OracleHooks(O.lib(), osim.dom.ptr, 3, mt)
+    init([osim.u[c].interior() for c in range(3)], *osim.dom.centres())
+    opl = O.Particles(osim, pos, ids)
+    opl.set_particulate(vel, mass, vol)
+    opl.set_forces(forces, gravity)
+    osim.start()
+    ostates, moved = [], 0
+    for _ in range(nsteps):
+        opl.event()
+        out = {d: opl.outbox(d) for d in grid.external_sides()}
+        moved += sum(len(a) for a in out.values())
+        assert all(a.shape[1] == 15 for a in out.values())
+        opl.clear_outbox()
+        for d, a in sorted(mt.exchange_records(out).items()):
+            opl.append(a)
+        ostates.append(opl.state() + opl.particulate_state())
+        osim.step()
+    assert moved > 30
+
+    fabric = D.LocalFabric(2)
+    dev = torch.device("cuda", 0)
+    results, errors = [None, None], []
+    u0 = [osim.dom.field() for _ in range(3)]
+    init([f.interior() for f in u0], *osim.dom.centres())
+
+    def worker(rank):
+        try:
+            gd = gfship.Domain(3, level, grid.sides(rank))
+            gs = gfship.Simulation(gd)
+            for c in range(3):
+                gs.set_viscosity(c, nu)
+            tr = D.LocalTransport(grid, rank, fabric, dev)
+            hooks = D.DeviceHooks(gd, tr)
+            for c in range(3):
+                gs.u[c].upload(u0[c].leaf())
+            gpl = gfship.ParticleList(gs, pos, ids)
+            gpl.set_sort_interval(2)
+            gpl.set_particulate(vel, mass, vol)
+            gpl.set_forces(forces, gravity)
+            mig = D.ParticleMigration(gpl, tr)
+            gs.start()
+            states = []
+            for _ in range(nsteps):
+                gpl.event()
+                states.append(gpl.download() + gpl.particulate_state())
+                gs.step()
+            gd.synchronize()
+            results[rank] = (states, gd, gs, hooks, mig, gpl)
+        except Exception as e:       # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            errors.append(e)
+            fabric.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=180)
+    assert not errors, errors
+    for rank in range(2):
+        for k, (gp, gi, gv, gm, gf) in enumerate(results[rank][0]):
+            op, oi, ov, om, of = ostates[k]
+            assert len(oi) == len(gi), (rank, k)
+            a, b = np.argsort(gi, kind="stable"), np.argsort(oi, kind="stable")
+            assert np.array_equal(gi[a], oi[b]), (rank, k)
+            for x, y, what in ((gp, op, "pos"), (gv, ov, "vel"), (gm, om, "mass"), (gf, of, "force")):
+                assert _rel_err(y[b], x[a]) <= 1e-12, (rank, k, what)
