@@ -13,7 +13,7 @@
 // coefficient on U, V, W), VariableTracer, EventStop, EventScript, GModule (ignored: the device
 // solver replaces hypre/agmg), OutputTime, OutputProjectionStats, OutputDiffusionStats,
 // OutputScalarNorm, OutputScalarSum, OutputScalarStats, OutputErrorNorm, OutputLocation,
-// OutputSimulation (text format), OutputEnergySpectra (`GModule fft`), InitSpectra (`GModule
+// GfsAdvection with a VariableStreamFunction, OutputSimulation (text format), OutputEnergySpectra (`GModule fft`), InitSpectra (`GModule
 // turbulence`), GfsParticleList of GfsParticle / GfsParticulate objects with
 // GfsForce{Inertial,AddedMass,Lift,Drag,Buoy} (`GModule particulates`; --particles FILE writes the
 // lists at the end of the run the way the reference prints them).  Anything else fails loudly with
@@ -119,6 +119,8 @@ struct Run {
   double visc[3] = { 0., 0., 0. };
   std::map<std::string, std::string> diff_set[3];
   std::vector<std::string> tracers;
+  std::vector<int> tracer_gradient;              // 0 gfs_center_gradient, 1 van Leer (default)
+  Function * stream_function = nullptr;          // GfsVariableStreamFunction (2-D, GfsAdvection)
   std::vector<std::pair<std::string, Function *>> init;   // Init {} { var = f }
   std::vector<Variable> vars;
   std::vector<std::unique_ptr<Event>> events;
@@ -491,14 +493,27 @@ void parse_object (Run & R, Reader & r)
   }
   else if (cls == "VariableTracer") {
     std::string name = r.word (false);
+    int gradient = 1;
     if (r.peek (false) == '{') {
       auto m = r.assignments ();
       for (auto & kv : m)
-	if (!(kv.first == "gradient" && kv.second == "gfs_center_van_leer_gradient"))
-	  r.fail ("tracers use the default van Leer limiter only (got " + kv.first + " = " + kv.second + ")");
+	if (kv.first == "gradient" && kv.second == "gfs_center_van_leer_gradient") gradient = 1;
+	else if (kv.first == "gradient" && kv.second == "gfs_center_gradient") gradient = 0;
+	else
+	  r.fail ("unsupported GfsVariableTracer parameter " + kv.first + " = " + kv.second);
     }
     R.tracers.push_back (name);
+    R.tracer_gradient.push_back (gradient);
     R.get_or_add_variable (name);
+  }
+  else if (cls == "VariableStreamFunction") {
+    // GfsVariableStreamFunction name function (2-D; src/variable.c:905-1120)
+    if (R.dim != 2) r.fail ("GfsVariableStreamFunction is 2-D only");
+    Event e;
+    if (r.peek (false) == '{') read_event_params (r, e);
+    std::string name = r.word (false);
+    R.get_or_add_variable (name);
+    R.stream_function = R.functions.add (r.function (), r.line ());
   }
   else if (cls == "EventStop") {
     // gfs_event_stop_read / _event, src/event.c:1737-1835
@@ -1009,7 +1024,7 @@ void parse_file (Run & R, const std::string & text, const std::string & name)
   if (nboxes != 1)
     r.fail ("one GfsBox per process: multi-box files map to one box per GPU through "
 	    "gfship/distributed.py, not through this front end");
-  if (R.sim_class != "Simulation" && R.sim_class != "Poisson")
+  if (R.sim_class != "Simulation" && R.sim_class != "Poisson" && R.sim_class != "Advection")
     r.fail ("unsupported simulation class Gfs" + R.sim_class);
   // default variables of gfs_simulation_init (src/simulation.c:958-985)
   R.get_or_add_variable ("P");
@@ -1236,6 +1251,7 @@ int run (Run & R)
     int k = gfship_sim_add_tracer (R.sim);
     CHECK (k);
     R.vars[R.var_index (t)].dev = gfship_sim_variable (R.sim, GFSHIP_VAR_TRACER, k);
+    CHECK (gfship_sim_set_tracer_gradient (R.sim, k, R.tracer_gradient[(size_t) k]));
   }
   gfship_field div = -1;
   if (R.sim_class == "Poisson") {
@@ -1323,6 +1339,61 @@ int run (Run & R)
       R.i++;
       events_do (R);
     }
+  }
+  else if (R.sim_class == "Advection") {
+    // advection_run, src/simulation.c:2061-2116, with the velocity of a GfsVariableStreamFunction
+    // (variable_stream_function_event, src/variable.c:1041-1086: psi at the four corners of every
+    // leaf -> MAC velocities, centred velocities = means of the two faces, BC)
+    if (!R.stream_function) {
+      fprintf (stderr, "gfship: GfsAdvection needs a GfsVariableStreamFunction (prescribed velocity)\n");
+      return 1;
+    }
+    {
+      const int n = R.n ();
+      std::vector<double> un[2], uc[2];
+      for (int c = 0; c < 2; c++) { un[c].assign (R.total (), 0.); uc[c].assign (R.total (), 0.); }
+      for (int j = 1; j <= n; j++)
+	for (int i = 1; i <= n; i++) {
+	  double o[3], p[3] = { 0., 0., 0. };
+	  cell_pos (R, i, j, 0, o);
+	  double h = (1./n)/2.;
+	  p[0] = o[0] - h; p[1] = o[1] - h; double psi0 = eval (R, R.stream_function, p, -1);
+	  p[0] = o[0] + h; p[1] = o[1] - h; double psi1 = eval (R, R.stream_function, p, -1);
+	  p[0] = o[0] + h; p[1] = o[1] + h; double psi2 = eval (R, R.stream_function, p, -1);
+	  p[0] = o[0] - h; p[1] = o[1] + h; double psi3 = eval (R, R.stream_function, p, -1);
+	  double hh = 2.*h;
+	  double f0 = (psi2 - psi1)*1./hh, f1 = (psi3 - psi0)*1./hh;
+	  double f2 = (psi3 - psi2)*1./hh, f3 = (psi0 - psi1)*1./hh;
+	  un[0][R.idx (i, j, 0)] = f0;
+	  if (i == 1) un[0][R.idx (0, j, 0)] = f1;
+	  un[1][R.idx (i, j, 0)] = f2;
+	  if (j == 1) un[1][R.idx (i, 0, 0)] = f3;
+	  uc[0][R.idx (i, j, 0)] = (f0 + f1)/2.;
+	  uc[1][R.idx (i, j, 0)] = (f2 + f3)/2.;
+	}
+      const char * unames[2] = { "U", "V" };
+      for (int c = 0; c < 2; c++) {
+	gfship_field fu = R.vars[R.var_index (unames[c])].dev;
+	CHECK (gfship_field_upload (R.dom, gfship_sim_variable (R.sim, GFSHIP_VAR_UN, c), R.level, un[c].data ()));
+	CHECK (gfship_field_upload (R.dom, fu, R.level, uc[c].data ()));
+	CHECK (gfship_bc (R.dom, fu, fu, R.level));
+	R.vars[R.var_index (unames[c])].host_time = -1.;
+      }
+    }
+    CHECK (gfship_sim_set_time (R.sim, R.end, R.dtmax));
+    CHECK (gfship_sim_set_next_event (R.sim, next_event_hook, &R));
+    for (const std::string & t : R.tracers) {
+      gfship_field ft = R.vars[R.var_index (t)].dev;
+      CHECK (gfship_bc (R.dom, ft, ft, R.level));
+    }
+    while (R.t < R.end && R.i < R.iend) {
+      events_do (R);
+      CHECK (gfship_sim_set_time (R.sim, R.end, R.dtmax));
+      CHECK (gfship_sim_advection_step (R.sim));
+      R.t = gfship_sim_time (R.sim);
+      R.i = gfship_sim_iter (R.sim);
+    }
+    events_do (R);
   }
   else {
     // simulation_run, src/simulation.c:432-557

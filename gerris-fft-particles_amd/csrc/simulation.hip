@@ -13,6 +13,7 @@ struct gfship_sim {
   gfship_domain * dom = nullptr;
   gfship_field p = -1, pmac = -1, u[3] = {-1, -1, -1}, g[3] = {-1, -1, -1}, gmac[3] = {-1, -1, -1};
   std::vector<gfship_field> tracers;
+  std::vector<int> tracer_gradient;    // GfsVariableTracer { gradient = }: 0 centred, 1 van Leer
   gfship_field un[3] = {-1, -1, -1};   // face normal velocities (see timestep_kernels.hip)
   gfship_field fv[6] = {-1, -1, -1, -1, -1, -1};
   gfship_field dia = -1, div = -1, res = -1, tmp = -1; // temporaries of mac_projection
@@ -267,6 +268,7 @@ gfship_field gfship_sim_variable (gfship_sim * s, int which, int c)
   case GFSHIP_VAR_TRACER:
     GFSHIP_CHECK ((size_t) c < s->tracers.size (), GFSHIP_EINVAL, "no tracer %d", c);
     return s->tracers[c];
+  case GFSHIP_VAR_UN: return s->un[c];
   }
   set_error ("unknown variable kind %d", which);
   return GFSHIP_EINVAL;
@@ -316,6 +318,7 @@ int gfship_sim_add_tracer (gfship_sim * s)
   gfship_field t = gfship_field_alloc (s->dom, -1);
   if (t < 0) return t;
   s->tracers.push_back (t);
+  s->tracer_gradient.push_back (1);      /* gfs_center_van_leer_gradient, src/variable.c:429 */
   return (int) s->tracers.size () - 1;
 }
 
@@ -389,8 +392,12 @@ int gfship_tracer_advection (gfship_sim * s, gfship_field t, double dt)
 {
   GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
   if (!get_field (s->dom, t)) return GFSHIP_EINVAL;
-  /* tracers: van Leer gradient + gfs_face_advection_flux (src/variable.c:427-431) */
-  TRY (variable_sources (s, t, t, 1, false, dt, nullptr, nullptr));
+  /* tracers: van Leer gradient unless the file says otherwise + gfs_face_advection_flux
+     (src/variable.c:427-431) */
+  int gradient = 1;
+  for (size_t q = 0; q < s->tracers.size (); q++)
+    if (s->tracers[q] == t) gradient = s->tracer_gradient[q];
+  TRY (variable_sources (s, t, t, gradient, false, dt, nullptr, nullptr));
   TRY (bc_leaf (s, t));
   return GFSHIP_OK;
 }
@@ -480,6 +487,15 @@ static void sim_variables (gfship_sim * s, std::vector<Field *> & v)
     v.push_back (get_field (dom, t));
 }
 
+int gfship_sim_set_tracer_gradient (gfship_sim * s, int t, int gradient)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  GFSHIP_CHECK (t >= 0 && (size_t) t < s->tracers.size (), GFSHIP_EINVAL, "no tracer %d", t);
+  GFSHIP_CHECK (gradient == 0 || gradient == 1, GFSHIP_EINVAL, "gradient: 0 centred, 1 van Leer");
+  s->tracer_gradient[t] = gradient;
+  return GFSHIP_OK;
+}
+
 int gfship_coarse_init (gfship_sim * s)
 {
   GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
@@ -511,6 +527,20 @@ int gfship_sim_start (gfship_sim * s)
     TRY (set_timestep (s, true));
     TRY (advance_tracers (s, s->advection_params.dt/2.));
   }
+  return GFSHIP_OK;
+}
+
+// loop body of advection_run (src/simulation.c:2078-2111) of a GfsAdvection simulation whose MAC
+// velocities are given (GfsVariableStreamFunction: uploaded through GFSHIP_VAR_UN and kept as they
+// are): coarse values, time step, tracers
+int gfship_sim_advection_step (gfship_sim * s)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  TRY (gfship_coarse_init (s));
+  TRY (set_timestep (s, false));
+  TRY (advance_tracers (s, s->advection_params.dt));
+  s->t = s->tnext;
+  s->i++;
   return GFSHIP_OK;
 }
 

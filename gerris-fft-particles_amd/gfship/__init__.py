@@ -96,6 +96,8 @@ SIGNATURES = {
     "gfship_sim_diffusion_params": (C.POINTER(MultilevelParams), [_vp, _i]),
     "gfship_sim_start": (_i, [_vp]),
     "gfship_sim_step": (_i, [_vp]),
+    "gfship_sim_advection_step": (_i, [_vp]),
+    "gfship_sim_set_tracer_gradient": (_i, [_vp, _i, _i]),
     "gfship_predicted_face_velocities": (_i, [_vp]),
     "gfship_mac_projection": (_i, [_vp, C.POINTER(MultilevelParams), _d, _i, _pi]),
     "gfship_approximate_projection": (_i, [_vp, C.POINTER(MultilevelParams), _d, _i, _pi]),
@@ -349,7 +351,7 @@ class _SimVariable(Variable):
 
 class Simulation:
     """GfsSimulation on one box: the simulation_run loop (src/simulation.c:432-557)."""
-    VAR_P, VAR_PMAC, VAR_U, VAR_G, VAR_GMAC, VAR_TRACER = range(6)
+    VAR_P, VAR_PMAC, VAR_U, VAR_G, VAR_GMAC, VAR_TRACER, VAR_UN = range(7)
 
     def __init__(self, dom):
         self.dom = dom
@@ -378,9 +380,20 @@ class Simulation:
     def diffusion_params(self, c):
         return lib().gfship_sim_diffusion_params(self.ptr, c).contents
 
-    def add_tracer(self):
+    def add_tracer(self, gradient=None):
+        """GfsVariableTracer; gradient 0 = gfs_center_gradient, 1 = van Leer (the default)"""
         t = _check(lib().gfship_sim_add_tracer(self.ptr))
+        if gradient is not None:
+            _check(lib().gfship_sim_set_tracer_gradient(self.ptr, t, gradient))
         return self._var(self.VAR_TRACER, t)
+
+    def mac_velocity(self, c):
+        """MAC velocity of the + face of every cell along c (GFSHIP_VAR_UN)"""
+        return self._var(self.VAR_UN, c)
+
+    def advection_step(self):
+        """loop body of advection_run (GfsAdvection) with the MAC velocities as they are"""
+        _check(lib().gfship_sim_advection_step(self.ptr))
 
     def set_time(self, end=1.7976931348623157e308, dtmax=1.7976931348623157e308):
         self.end = end

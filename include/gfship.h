@@ -168,7 +168,9 @@ typedef struct {           /* the fields of GfsAdvectionParams used here, src/ad
 } gfship_advection_params;
 
 enum { GFSHIP_VAR_P = 0, GFSHIP_VAR_PMAC = 1, GFSHIP_VAR_U = 2, GFSHIP_VAR_G = 3,
-       GFSHIP_VAR_GMAC = 4, GFSHIP_VAR_TRACER = 5 };
+       GFSHIP_VAR_GMAC = 4, GFSHIP_VAR_TRACER = 5,
+       GFSHIP_VAR_UN = 6 /* MAC velocity of the + face of every cell along c (ghost cell 0: the - face of
+			    the first cell), GFS_STATE (cell)->f[2c].un */ };
 
 /* gfs_simulation_new + simulation_init (src/simulation.c:910-1015): allocates P, Pmac, U, V(, W),
    the gradient vectors g[], gmac[] of simulation_run (:432-456) and the face state */
@@ -188,6 +190,8 @@ int      gfship_sim_set_next_event (gfship_sim * sim, gfship_next_event_fn fn, v
 double   gfship_sim_time (gfship_sim * sim);
 unsigned gfship_sim_iter (gfship_sim * sim);
 int      gfship_sim_add_tracer (gfship_sim * sim);       /* GfsVariableTracer, src/variable.c:427-431 */
+/* GfsVariableTracer { gradient = gfs_center_gradient | gfs_center_van_leer_gradient }: 0 | 1 (default) */
+int      gfship_sim_set_tracer_gradient (gfship_sim * sim, int tracer, int gradient);
 /* GfsSourceDiffusion {} U|V|W nu (src/source.c:933-1160): constant implicit viscosity of
    velocity component c (0. removes it), and the GfsMultilevelParams of its solver
    (tolerance 1e-6, beta 1: diffusion_init, src/source.c:966-974) */
@@ -198,6 +202,10 @@ gfship_multilevel_params * gfship_sim_diffusion_params (gfship_sim * sim, int c)
 int  gfship_sim_start (gfship_sim * sim);
 /* one iteration of the simulation_run loop body (src/simulation.c:479-548) */
 int  gfship_sim_step (gfship_sim * sim);
+/* loop body of advection_run (GfsAdvection, src/simulation.c:2078-2111) with given MAC velocities
+   (GfsVariableStreamFunction, src/variable.c:931-1086: upload them through GFSHIP_VAR_UN and the
+   centred ones through GFSHIP_VAR_U): coarse values, time step, tracers */
+int  gfship_sim_advection_step (gfship_sim * sim);
 /* the pieces, callable on their own: */
 int  gfship_predicted_face_velocities (gfship_sim * sim);      /* src/timestep.c:681-717 */
 int  gfship_mac_projection (gfship_sim * sim, gfship_multilevel_params * par, double dt,

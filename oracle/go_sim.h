@@ -11,6 +11,7 @@ typedef struct GoSim {
   GoField * p, * pmac, * u[3], * g[3], * gmac[3];
   GoField * tracer[GO_MAXTRACERS];
   int ntracers;
+  int tracer_gradient[GO_MAXTRACERS];   /* GfsVariableTracer { gradient = }: 0 centred, 1 van Leer (default) */
   double * un[6];   /* GFS_STATE (cell)->f[d].un on leaves, ghosts included */
   double * fv[6];   /* GFS_STATE (cell)->f[d].v  on leaves, ghosts included */
   GoMultilevelParams projection_params, approx_projection_params;
@@ -34,6 +35,7 @@ double  go_sim_time (GoSim * s);
 unsigned go_sim_iter (GoSim * s);
 void    go_sim_set_time (GoSim * s, double end, double dtmax);
 int     go_sim_add_tracer (GoSim * s);
+void    go_sim_set_tracer_gradient (GoSim * s, int t, int gradient);
 void    go_approximate_projection (GoSim * s, GoMultilevelParams * par, double dt, GoField * p,
 				   GoField ** g);
 void    go_mac_projection (GoSim * s, GoMultilevelParams * par, double dt, GoField * p,
@@ -46,6 +48,7 @@ void    go_set_timestep (GoSim * s);
 void    go_coarse_init (GoSim * s);
 void    go_sim_start (GoSim * s);
 void    go_sim_step (GoSim * s);
+void    go_advection_step (GoSim * s);
 void    go_divergence (GoSim * s, GoField * out);
 void    go_sim_set_viscosity (GoSim * s, int c, double nu);
 GoMultilevelParams * go_sim_diffusion_params (GoSim * s, int c);

@@ -145,7 +145,14 @@ int go_sim_add_tracer (GoSim * s)
 {
   assert (s->ntracers < GO_MAXTRACERS);
   s->tracer[s->ntracers] = go_field_new (s->dom, -1);
+  s->tracer_gradient[s->ntracers] = 1;     /* gfs_center_van_leer_gradient, variable.c:429 */
   return s->ntracers++;
+}
+
+void go_sim_set_tracer_gradient (GoSim * s, int t, int gradient)
+{
+  assert (t >= 0 && t < s->ntracers);
+  s->tracer_gradient[t] = gradient;
 }
 
 /* ---- K12: MAC velocities from centred velocities ---------------------------------------- */
@@ -574,7 +581,10 @@ void go_centered_velocity_advection (GoSim * s, GoField ** gmac, GoField ** g)
    tracers default to the van Leer gradient and gfs_face_advection_flux (variable.c:427-431) */
 void go_tracer_advection (GoSim * s, GoField * t, double dt)
 {
-  variable_sources (s, t, t, 1, 0, dt, NULL, NULL);
+  int gradient = 1;
+  for (int q = 0; q < s->ntracers; q++)
+    if (s->tracer[q] == t) gradient = s->tracer_gradient[q];
+  variable_sources (s, t, t, gradient, 0, dt, NULL, NULL);
   go_bc (t, t, s->dom->depth);
 }
 
@@ -750,6 +760,18 @@ void go_sim_step (GoSim * s)
 
   go_set_timestep (s);
   advance_tracers (s, s->advection_params.dt);
+}
+
+/* loop body of advection_run (simulation.c:2078-2111) for a GfsAdvection simulation whose velocity
+ * comes from a GfsVariableStreamFunction (the MAC velocities un are kept as they are): coarse
+ * values, time step, tracers */
+void go_advection_step (GoSim * s)
+{
+  go_coarse_init (s);
+  go_set_timestep (s);
+  advance_tracers (s, s->advection_params.dt);
+  s->t = s->tnext;
+  s->i++;
 }
 
 /* gfs_divergence (fluid.c:2357-2376) on every leaf: derived variable "Divergence" */

@@ -176,6 +176,8 @@ def _sim_sigs(L):
         "go_predicted_face_velocities": (None, [vp]),
         "go_domain_cfl": (d, [vp]),
         "go_set_timestep": (None, [vp]),
+        "go_advection_step": (None, [vp]),
+        "go_sim_set_tracer_gradient": (None, [vp, i, i]),
         "go_coarse_init": (None, [vp]),
         "go_sim_start": (None, [vp]),
         "go_sim_step": (None, [vp]),
@@ -233,13 +235,43 @@ class Sim:
     def field(self, which, c=0):
         return _FieldView(self.dom, lib().go_sim_field(self.ptr, which, c))
 
-    def add_tracer(self):
+    def add_tracer(self, gradient=None):
+        """GfsVariableTracer; gradient 0 = gfs_center_gradient, 1 = van Leer (the default)"""
         t = lib().go_sim_add_tracer(self.ptr)
+        if gradient is not None:
+            lib().go_sim_set_tracer_gradient(self.ptr, t, gradient)
         return self.field(self.TRACER, t)
 
     def un(self, d):
         n = (1 << self.depth) + 2
         return np.ctypeslib.as_array(lib().go_sim_un(self.ptr, d), shape=(n,) * self.dim)
+
+    def stream_function(self, psi):
+        """GfsVariableStreamFunction (2-D, src/variable.c:931-944,1041-1086): MAC velocities of every
+        leaf from psi(x, y) at its four corners, centred velocities = means of the two faces, BC"""
+        assert self.dim == 2
+        n = 1 << self.depth
+        h = 1. / n
+        xv = -0.5 + np.arange(n + 1) * h
+        # corner positions exactly as init_streamfunction computes them: cell centre -+ h/2
+        xc = -0.5 + (np.arange(n) + 0.5) * h
+        xm, xp = xc - h / 2., xc + h / 2.
+        Y0, X0 = np.meshgrid(xm, xm, indexing="ij")
+        Y1, X1 = np.meshgrid(xm, xp, indexing="ij")
+        Y2, X2 = np.meshgrid(xp, xp, indexing="ij")
+        Y3, X3 = np.meshgrid(xp, xm, indexing="ij")
+        p0, p1, p2, p3 = psi(X0, Y0), psi(X1, Y1), psi(X2, Y2), psi(X3, Y3)
+        hh = 2. * (h / 2.)
+        un = [(p2 - p1) * 1. / hh, (p3 - p0) * 1. / hh, (p3 - p2) * 1. / hh, (p0 - p1) * 1. / hh]
+        for d in range(4):
+            self.un(d)[1:-1, 1:-1] = un[d]
+        self.u[0].interior()[...] = (un[0] + un[1]) / 2.
+        self.u[1].interior()[...] = (un[2] + un[3]) / 2.
+        for c in range(2):
+            lib().go_bc(self.u[c].ptr, self.u[c].ptr, self.depth)
+
+    def advection_step(self):
+        lib().go_advection_step(self.ptr)
 
     def fv(self, d):
         n = (1 << self.depth) + 2

@@ -266,3 +266,34 @@ def test_isotropic_case_init_spectra(tmp_path):
     assert 0.5 * e["spectrum-0"] < e["spectrum-end"] <= e["spectrum-0"]
     div = [l for l in open(tmp_path / "div").read().splitlines() if l.strip()]
     assert len(div) == 4
+
+
+# ---------------------------------------------------------------------------------------------
+# GfsAdvection + GfsVariableStreamFunction (test/advection)
+# ---------------------------------------------------------------------------------------------
+
+def test_check_rotation_case():
+    out = _run("rotation.gfs", {"LEVEL": 5}, check=True)
+    assert "class GfsAdvection dim 2 level 5" in out
+    ev = [l.split()[1] for l in out.splitlines() if l.startswith("event ")]
+    assert ev == ["OutputErrorNorm", "OutputScalarSum"]
+
+
+@pytest.mark.gpu
+def test_rotation_case_matches_error_ref(golden_dir, tmp_path):
+    """test/advection/advection.sh: error norms of the tracer after one revolution for levels 5..7
+    against error.ref -- second and maximum norm to the last digit or so of the file, the first norm to 1 %
+    (the reference box has no ghost cells at its walls, see tests/test_oracle_golden_timestep.py)
+    -- and the tracer sum (OutputScalarSum)"""
+    ref = {int(r[0]): r[1:] for r in _rows(golden_dir, "advection_error.ref")}
+    for level in (5, 6, 7):
+        _run("rotation.gfs", {"LEVEL": level}, cwd=str(tmp_path))
+        err = open(tmp_path / ("error-%d" % level)).read().split()
+        # awk '{ print LEVEL " " $5 " " $7 " " $9}'
+        first, second, infty = err[4], err[6], err[8]
+        assert np.allclose([float(second), float(infty)], [float(v) for v in ref[level][1:3]],
+                           rtol=2e-3), (level, err, ref[level])
+        assert abs(float(first) / float(ref[level][0]) - 1.) < 0.01
+        sums = [float(l.split()[4]) for l in open(tmp_path / ("t-%d" % level)) if l.strip()]
+        # the rotation crosses the walls of the square box: the sum is only nearly conserved
+        assert abs(sums[-1] - sums[0]) < 1e-3 * abs(sums[0])

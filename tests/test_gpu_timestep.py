@@ -392,3 +392,59 @@ def test_fused_periodic_paths_equal_general_paths(dim, level):
     for a, b in zip(*res):
         assert np.array_equal(_interior(a, dim) if a.ndim == dim else a,
                               _interior(b, dim) if b.ndim == dim else b)
+
+
+# ---------------------------------------------------------------------------------------------
+# GfsAdvection with a GfsVariableStreamFunction (test/advection): tracer in solid rotation
+# ---------------------------------------------------------------------------------------------
+
+def _blob(x, y):
+    r2 = x * x + y * y
+    coeff = 20. + 20000. * r2 * r2 * r2 * r2
+    return (1. + np.cos(20. * x) * np.cos(20. * y)) * np.exp(-coeff * r2) / 2.
+
+
+@pytest.mark.parametrize("level,gradient", [(5, 0), (6, 0), (5, 1)])
+def test_advection_run_stream_function_bit_exact(level, gradient, golden_dir):
+    """advection_run (src/simulation.c:2061-2116): MAC velocities from the stream function
+    -4 (x^2 + y^2), one revolution of the tracer blob of test/advection; the device against the
+    oracle bit for bit at every step, and (centred gradient, 64^2) the error norms of error.ref"""
+    import os
+    side = [O.SIDE_BOUNDARY] * 6
+    osim = O.Sim(2, level, side)
+    T = osim.add_tracer(gradient=gradient)
+    x, y = osim.dom.centres()
+    T.interior()[...] = _blob(x, y)
+    O.lib().go_bc(T.ptr, T.ptr, level)
+    osim.stream_function(lambda X, Y: -4. * (X * X + Y * Y))
+    osim.set_time(end=0.785398)
+
+    gd = gfship.Domain(2, level, side)
+    gs = gfship.Simulation(gd)
+    gs.set_time(end=0.785398)
+    gT = gs.add_tracer(gradient=gradient)
+    gT.upload(T.leaf())
+    for c in range(2):
+        gs.u[c].upload(osim.u[c].leaf())
+        # + face of every cell; ghost cell 0 holds the - face of the first cell
+        a = osim.un(2 * c).copy()
+        lo = osim.un(2 * c + 1)
+        if c == 0:
+            a[:, 0] = lo[:, 1]
+        else:
+            a[0, :] = lo[1, :]
+        gs.mac_velocity(c).upload(a)
+    k = 0
+    while osim.t < 0.785398:
+        osim.advection_step()
+        gs.advection_step()
+        assert osim.dt == gs.dt and osim.t == gs.t, k
+        if k % 16 == 0:
+            assert np.array_equal(T.interior(), _interior(gT.download(), 2)), k
+        k += 1
+    assert np.array_equal(T.interior(), _interior(gT.download(), 2))
+    if gradient == 0 and level == 6:
+        e = _interior(gT.download(), 2) - _blob(x, y)
+        rows = [l.split() for l in open(os.path.join(golden_dir, "reference", "advection_error.ref"))]
+        ref = {int(r[0]): [float(v) for v in r[1:]] for r in rows}[level]
+        assert np.allclose([np.sqrt((e * e).mean()), np.abs(e).max()], ref[1:], rtol=2e-3)
