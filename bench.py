@@ -207,6 +207,26 @@ def main():
                      "combined_mcell_steps_per_s": n ** 3 / t_both / 1e6,
                      "alive": pl.count()}
         pl.destroy()
+        # the same particles as GfsParticulate objects with the list's forces (inertial, added mass,
+        # lift, drag -- inactive without viscosity --, buoyancy): the event alone
+        rng = np.random.default_rng(1)
+        vol = 1e-6 * (0.5 + rng.random(args.particles))
+        pp = gfship.ParticleList(sim, pos, ids)
+        pp.set_particulate(np.zeros((args.particles, 3)), 2. * vol, vol)
+        pp.set_forces([gfship.FORCE_INERTIAL, gfship.FORCE_ADDEDMASS, gfship.FORCE_LIFT,
+                       gfship.FORCE_DRAG, gfship.FORCE_BUOY], (0., 1., 0.))
+        pp.event()
+        dom.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nev):
+            pp.event()
+        dom.synchronize()
+        t_part = (time.perf_counter() - t0) / nev
+        particles["particulates"] = {"forces": "inertial, added mass, lift, drag, buoyancy",
+                                     "value": args.particles / t_part / 1e6,
+                                     "unit": "Mparticle-steps/s", "ms_per_event": t_part * 1e3,
+                                     "alive": pp.count()}
+        pp.destroy()
 
     if rank == 0:
         value = world * n ** 3 * args.steps / elapsed / 1e6
