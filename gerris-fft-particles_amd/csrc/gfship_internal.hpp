@@ -51,7 +51,6 @@ struct SkewPlan {
   double * us = nullptr, * rs = nullptr, * ds = nullptr;
   void * hb = nullptr;            // hand-off granules (J side then K side)
   void * hbf = nullptr;           // granules of the fused relax loop (relax_skew_loop.hip)
-  unsigned * prog = nullptr;      // per-tile progress words of the fused relax loop
   bool loop_checked = false;      // the trial run of the fused loop has been made on this level
   void * stats_loop = nullptr;    // optional per-tile, per-sweep timing of the fused loop (debug)
   void * ctl = nullptr;           // { ticket, err }

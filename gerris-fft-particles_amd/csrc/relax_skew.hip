@@ -392,7 +392,6 @@ void skew_free (gfship_domain * dom)
     if (S.ds) (void) hipFree (S.ds);
     if (S.hb) (void) hipFree (S.hb);
     if (S.hbf) (void) hipFree (S.hbf);
-    if (S.prog) (void) hipFree (S.prog);
     if (S.stats_loop) (void) hipFree (S.stats_loop);
     if (S.ctl) (void) hipFree (S.ctl);
     if (S.stats) (void) hipFree (S.stats);

@@ -277,7 +277,8 @@ int  gfship_particles_set_sort_interval (gfship_particles * pl, int every);
 /* particles crossing a GFSHIP_SIDE_EXTERNAL side go to the box across it (send_particles /
    rcv_particles, modules/particulatecommon.c:3218-3312).  Without a hook they are dropped like at any
    non-periodic side.  The hook is called once per event by every box: nsend[d] records leave
-   through side d (send[d]: 7 doubles each -- position, old position, id -- already in the
+   through side d (send[d]: gfship_particles_record_size doubles each -- position, old position, id,
+   for particulates also velocity, mass, volume, force -- already in the
    coordinates of the receiving box, sorted by id); it returns in nrecv[d] / recv[d] the records
    that arrive through side d (host memory owned by the hook until its next call); they join the
    list in side order */
