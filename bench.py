@@ -146,10 +146,12 @@ def main():
     rhs.upload(rng.standard_normal((n + 2,) * 3))
     dom.poisson_coefficients()
     nrelax = 4
-    ms_sweep = dom.time_relax(u, rhs, dia, reps=5)            # one sweep launched on its own
+    # medians of 20 single measurements (HIP events on the library's stream around the kernel)
+    ms_sweep = float(np.median([dom.time_relax(u, rhs, dia, reps=1) for _ in range(20)]))
     roofline = None
     if args.mode == "exact":
-        ms_loop, fused = dom.time_relax_loop(u, rhs, dia, nrelax=nrelax, reps=5)
+        runs = [dom.time_relax_loop(u, rhs, dia, nrelax=nrelax, reps=1) for _ in range(20)]
+        ms_loop, fused = float(np.median([r[0] for r in runs])), runs[0][1]
         bytes_loop = RELAX_BYTES_PER_CELL * n ** 3 * nrelax
         achieved = bytes_loop / (ms_loop * 1e-3) / 1e9
         # HBM bytes per launch from rocprofv3 PMC passes of the same kernel at the same size
