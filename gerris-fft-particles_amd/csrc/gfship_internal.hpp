@@ -188,7 +188,7 @@ int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, d
 bool skew_supported (const gfship_domain * dom, int level);
 int  launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * ubc,
 			     const double * rhs, const double * dia, bool dia_zero,
-			     unsigned nrelax, bool bc);
+			     unsigned nrelax, bool bc, double * correct_into = nullptr);
 void skew_free (gfship_domain * dom);
 bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool bc);
 int  skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia,

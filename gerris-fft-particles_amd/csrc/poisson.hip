@@ -27,15 +27,21 @@ static int relax_level (gfship_domain * dom, unsigned dimension, int level, doub
 }
 
 // relax_loop, src/poisson.c:1070-1089
+// correct_into: the caller's next operation is `correct' (u += dp on this level, src/poisson.c:998-
+// 1003) and dp is not read again: where the level runs on the pipelined sweep the addition is done
+// while the skewed copy is unpacked (*corrected set), dp's natural array is then left as it was
 static int relax_loop (gfship_domain * dom, Field * dp, Field * u, unsigned dimension, int level,
-		       double omega, Field * rhs, Field * dia, unsigned nrelax)
+		       double omega, Field * rhs, Field * dia, unsigned nrelax,
+		       double * correct_into = nullptr, bool * corrected = nullptr)
 {
   int r;
   dp->zero[level] = false;
   if (dom->relax_mode == GFSHIP_RELAX_EXACT && dimension == 3 && skew_supported (dom, level) &&
-      !dom->force_hyperplane)
+      !dom->force_hyperplane) {
+    if (corrected) *corrected = correct_into != nullptr;
     return launch_relax_loop_skew (dom, level, dp, u, rhs->lev[level], dia->lev[level],
-				   dia->zero[level], nrelax, true);
+				   dia->zero[level], nrelax, true, correct_into);
+  }
   if (dom->relax_mode == GFSHIP_RELAX_EXACT) {
     bool done = false;
     if ((r = launch_relax_loop_small (dom, dimension, level, omega, dp, u, rhs->lev[level],
@@ -238,6 +244,7 @@ static int poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
   Field * U = get_field (dom, u), * R = get_field (dom, rhs), * D = get_field (dom, dia),
     * S = get_field (dom, res), * DP = get_field (dom, dpf);
   int r = GFSHIP_OK;
+  bool corrected = false;      /* u += dp already done while the finest level was unpacked */
   if (!U || !R || !D || !S) return GFSHIP_EINVAL;
   const int L = dom->depth;
   unsigned minlevel = p->minlevel; /* MAX (domain->rootlevel, p->minlevel), rootlevel = 0 */
@@ -280,11 +287,13 @@ static int poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
     for (unsigned l = first; l <= p->depth; l++) {
       /* get initial guess from coarser grid */
       TRY (launch_prolongate (dom, l - 1, DP->lev[l - 1], DP->lev[l]));
-      TRY (relax_loop (dom, DP, U, p->dimension, l, p->omega, S, D, nrl[l]));
+      TRY (relax_loop (dom, DP, U, p->dimension, l, p->omega, S, D, nrl[l],
+		       (int) l == L ? U->lev[L] : nullptr, &corrected));
     }
   }
   /* correct on leaf cells, then BC on u (gfs_traverse_and_bc ... correct, u, u) */
-  TRY (launch_correct (dom, L, U->lev[L], DP->lev[L]));
+  if (!corrected)
+    TRY (launch_correct (dom, L, U->lev[L], DP->lev[L]));
   TRY (launch_bc (dom, U, U, L, 0));
   /* compute new residual on leaf cells */
   if (norm)

@@ -262,6 +262,7 @@ struct PackArgs {
   const double * src[3];
   double * dst[3];
   int narr;
+  double * add;            // unpack: add the values to this natural array instead of storing them
 };
 
 __global__ void __launch_bounds__(SK_NL)
@@ -320,7 +321,11 @@ skew_unpack_kernel (PackArgs A)
   }
   __syncthreads ();
   const int j = n - (SK_T*P + hi);
-  A.dst[0][A.L.idx (I0 + lo + 1, j, k)] = tile_[hi][lo];
+  const long c = A.L.idx (I0 + lo + 1, j, k);
+  if (A.add)
+    A.add[c] += tile_[hi][lo];     /* correct (src/poisson.c:998-1003) fused into the unpack */
+  else
+    A.dst[0][c] = tile_[hi][lo];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -405,6 +410,7 @@ static int skew_pack (gfship_domain * dom, int level, SkewPlan * S, const double
 		      const double * rhs, const double * dia)
 {
   PackArgs A;
+  A.add = nullptr;
   A.L = dom->lay[level]; A.ntj = S->ntj; A.RT = S->RT;
   A.narr = 0;
   A.src[A.narr] = u;   A.dst[A.narr++] = S->us;
@@ -416,12 +422,13 @@ static int skew_pack (gfship_domain * dom, int level, SkewPlan * S, const double
   return GFSHIP_OK;
 }
 
-static int skew_unpack (gfship_domain * dom, int level, SkewPlan * S, double * u)
+static int skew_unpack (gfship_domain * dom, int level, SkewPlan * S, double * u,
+			double * add_into = nullptr)
 {
   PackArgs A;
   A.L = dom->lay[level]; A.ntj = S->ntj; A.RT = S->RT;
   A.narr = 1;
-  A.src[0] = S->us; A.dst[0] = u;
+  A.src[0] = S->us; A.dst[0] = u; A.add = add_into;
   dim3 grid (A.L.n/SK_T, SK_T, S->ntj*S->ntj);
   hipLaunchKernelGGL (skew_unpack_kernel, grid, dim3 (SK_NL), 0, dom->stream, A);
   GFSHIP_HIP (hipGetLastError ());
@@ -466,7 +473,7 @@ static int skew_sweep (gfship_domain * dom, int level, SkewPlan * S, double * u_
 // nrelax = 1 and bc = false it is a single gfs_relax sweep
 int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * ubc,
 			    const double * rhs, const double * dia, bool dia_zero,
-			    unsigned nrelax, bool bc)
+			    unsigned nrelax, bool bc, double * correct_into)
 {
   SkewPlan * S;
   int r;
@@ -503,13 +510,13 @@ int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * 
   if (!dom->no_fused_loop && skew_loop_supported (dom, level, nrelax, bc)) {
     /* the sweeps of the loop pipelined in one launch (relax_skew_loop.hip) */
     if ((r = skew_loop_run (dom, level, S, u, !dia_zero, nrelax, nullptr, ubc))) return r;
-    return skew_unpack (dom, level, S, u);
+    return skew_unpack (dom, level, S, u, correct_into);
   }
   for (unsigned q = 0; q < nrelax; q++) {
     if ((r = skew_sweep (dom, level, S, u, !dia_zero))) return r;
     if (bc && q + 1 < nrelax && (r = launch_bc (dom, ubc, dp, level, 1))) return r;
   }
-  return skew_unpack (dom, level, S, u);
+  return skew_unpack (dom, level, S, u, correct_into);
 }
 
 // debug: print per-tile timing of the last sweep of `level` (GFSHIP_SKEW_STATS=1)
