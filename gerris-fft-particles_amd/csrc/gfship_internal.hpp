@@ -150,6 +150,7 @@ int launch_prolongate (gfship_domain * dom, int level_coarse, const double * v_c
 		       double * v_fine);
 int launch_correct (gfship_domain * dom, int level, double * u, const double * dp);
 int launch_fill (gfship_domain * dom, int level, double * a, double value);
+int launch_norm_async (gfship_domain * dom, int level, const double * a, double scale, double weight);
 int launch_norm (gfship_domain * dom, int level, const double * a, double scale, double weight,
 		 double out[5] /* bias(sum of scaled), first, second, infty, raw sum */);
 

@@ -328,15 +328,35 @@ int gfship_poisson_solve (gfship_domain * dom, gfship_multilevel_params * par,
   par->depth = L;
   par->niter = 0;
 
-  /* calculates the initial residual and its norm */
-  if ((r = residual_and_norm (dom, dt, U, R, D, S, &par->residual))) return r;
-  par->residual_before = par->residual;
+  /* calculates the initial residual and its norm.  With nitermin >= 1 the first cycle runs whatever
+     that norm is: it is then enqueued before the host waits for the norm, and both norms are read
+     after the one synchronisation at the end of the cycle */
+  bool deferred = par->nitermin >= 1 && par->nitermax >= 1;
+  if (deferred) {
+    const Layout & Ly = dom->lay[L];
+    double size = 1./Ly.n;
+    S->zero[L] = false;
+    if ((r = launch_residual (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L]))) return r;
+    if ((r = launch_norm_async (dom, L, S->lev[L], 1.*size*size, 1.))) return r;
+  }
+  else {
+    if ((r = residual_and_norm (dom, dt, U, R, D, S, &par->residual))) return r;
+    par->residual_before = par->residual;
+  }
 
   double res_max_before = par->residual.infty;
 
   while (par->niter < par->nitermin ||
 	 (par->residual.infty > par->tolerance && par->niter < par->nitermax)) {
     if ((r = poisson_cycle (dom, par, lhs, rhs, dia, res, dt, &par->residual))) break;
+    if (deferred) {
+      /* the stream has been synchronised by the norm of the cycle: the first norm is there */
+      deferred = false;
+      double s0[5];
+      memcpy (s0, dom->h_pinned + 8, sizeof (s0));
+      if ((r = norm_residual_finish (dom, dt, s0, &par->residual_before))) break;
+      res_max_before = par->residual_before.infty;
+    }
     if (par->residual.infty == res_max_before) /* convergence has stopped!! */
       break;
     if (par->residual.infty > res_max_before/1.1 && par->minlevel < par->depth)

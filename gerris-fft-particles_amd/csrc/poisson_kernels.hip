@@ -750,6 +750,27 @@ norm_final_kernel (const double * __restrict__ partial, int nblocks, double * __
   }
 }
 
+// the same without waiting for the result: it lands in dom->h_pinned[8 .. 12] once the stream has
+// passed this point (the caller synchronises later anyway)
+int launch_norm_async (gfship_domain * dom, int level, const double * a, double scale, double weight)
+{
+  const Layout & L = dom->lay[level];
+  long nc = ncells (L);
+  int block = 256;
+  int nblocks = (int) ((nc + block - 1)/block);
+  if (nblocks > 1024) nblocks = 1024;
+  double * partial = dom->d_scratch;
+  double * result = dom->d_scratch + 5*1024;
+  hipLaunchKernelGGL (norm_partial_kernel, dim3 (nblocks), dim3 (block), 0, dom->stream,
+		      L, a, scale, weight, partial);
+  hipLaunchKernelGGL (norm_final_kernel, dim3 (1), dim3 (256), 0, dom->stream,
+		      partial, nblocks, result);
+  GFSHIP_HIP (hipGetLastError ());
+  GFSHIP_HIP (hipMemcpyAsync (dom->h_pinned + 8, result, 5*sizeof (double), hipMemcpyDeviceToHost,
+			      dom->stream));
+  return GFSHIP_OK;
+}
+
 int launch_norm (gfship_domain * dom, int level, const double * a, double scale, double weight,
 		 double out[5])
 {
