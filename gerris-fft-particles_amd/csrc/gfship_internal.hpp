@@ -118,6 +118,16 @@ int  hip_fail (hipError_t e, const char * what, const char * file, int line);
 #define GFSHIP_HIP(call) do { hipError_t e_ = (call); \
     if (e_ != hipSuccess) return gfship::hip_fail (e_, #call, __FILE__, __LINE__); } while (0)
 
+// wait for the stream by polling it: the small results the host needs in the middle of a step
+// (norms, CFL) come back a few microseconds sooner than through a blocking synchronisation
+inline hipError_t stream_wait_spin (hipStream_t st)
+{
+  hipError_t e;
+  while ((e = hipStreamQuery (st)) == hipErrorNotReady)
+    ;
+  return e;
+}
+
 #define GFSHIP_CHECK(cond, code, ...) do { if (!(cond)) { \
     gfship::set_error (__VA_ARGS__); return (code); } } while (0)
 

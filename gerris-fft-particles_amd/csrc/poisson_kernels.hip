@@ -788,7 +788,7 @@ int launch_norm (gfship_domain * dom, int level, const double * a, double scale,
   GFSHIP_HIP (hipGetLastError ());
   GFSHIP_HIP (hipMemcpyAsync (dom->h_pinned, result, 5*sizeof (double), hipMemcpyDeviceToHost,
 			      dom->stream));
-  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  GFSHIP_HIP (stream_wait_spin (dom->stream));
   memcpy (out, dom->h_pinned, 5*sizeof (double));
   return GFSHIP_OK;
 }

@@ -1124,7 +1124,7 @@ int launch_cfl_from_max (gfship_domain * dom, double * cfl2)
   GFSHIP_HIP (hipGetLastError ());
   GFSHIP_HIP (hipMemcpyAsync (dom->h_pinned, result, sizeof (double), hipMemcpyDeviceToHost,
 			      dom->stream));
-  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  GFSHIP_HIP (stream_wait_spin (dom->stream));
   *cfl2 = dom->h_pinned[0];
   return call_reduce (dom, cfl2, 1, 2);
 }
@@ -1206,7 +1206,7 @@ int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3],
   GFSHIP_HIP (hipGetLastError ());
   GFSHIP_HIP (hipMemcpyAsync (dom->h_pinned, result, sizeof (double), hipMemcpyDeviceToHost,
 			      dom->stream));
-  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  GFSHIP_HIP (stream_wait_spin (dom->stream));
   *cfl2 = dom->h_pinned[0];
   return call_reduce (dom, cfl2, 1, 2);   /* gfs_all_reduce (..., MPI_MIN), src/domain.c:2921 */
 }
