@@ -760,14 +760,12 @@ int launch_norm_async (gfship_domain * dom, int level, const double * a, double 
   int nblocks = (int) ((nc + block - 1)/block);
   if (nblocks > 1024) nblocks = 1024;
   double * partial = dom->d_scratch;
-  double * result = dom->d_scratch + 5*1024;
+  double * result = dom->h_pinned + 8;     /* host memory mapped on the device */
   hipLaunchKernelGGL (norm_partial_kernel, dim3 (nblocks), dim3 (block), 0, dom->stream,
 		      L, a, scale, weight, partial);
   hipLaunchKernelGGL (norm_final_kernel, dim3 (1), dim3 (256), 0, dom->stream,
 		      partial, nblocks, result);
   GFSHIP_HIP (hipGetLastError ());
-  GFSHIP_HIP (hipMemcpyAsync (dom->h_pinned + 8, result, 5*sizeof (double), hipMemcpyDeviceToHost,
-			      dom->stream));
   return GFSHIP_OK;
 }
 
@@ -780,14 +778,12 @@ int launch_norm (gfship_domain * dom, int level, const double * a, double scale,
   int nblocks = (int) ((nc + block - 1)/block);
   if (nblocks > 1024) nblocks = 1024;
   double * partial = dom->d_scratch;     // 5*1024 doubles
-  double * result = dom->d_scratch + 5*1024;
+  double * result = dom->h_pinned;       // host memory mapped on the device: no copy kernel
   hipLaunchKernelGGL (norm_partial_kernel, dim3 (nblocks), dim3 (block), 0, dom->stream,
 		      L, a, scale, weight, partial);
   hipLaunchKernelGGL (norm_final_kernel, dim3 (1), dim3 (256), 0, dom->stream,
 		      partial, nblocks, result);
   GFSHIP_HIP (hipGetLastError ());
-  GFSHIP_HIP (hipMemcpyAsync (dom->h_pinned, result, 5*sizeof (double), hipMemcpyDeviceToHost,
-			      dom->stream));
   GFSHIP_HIP (stream_wait_spin (dom->stream));
   memcpy (out, dom->h_pinned, 5*sizeof (double));
   return GFSHIP_OK;

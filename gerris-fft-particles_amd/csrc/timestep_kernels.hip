@@ -1117,13 +1117,11 @@ int launch_project_correct (gfship_domain * dom, const double * p, double * cons
 int launch_cfl_from_max (gfship_domain * dom, double * cfl2)
 {
   const Layout & L = dom->lay[dom->depth];
-  double * result = dom->d_scratch + 5*1024;
+  double * result = dom->h_pinned;      /* host memory mapped on the device: no copy kernel */
   hipLaunchKernelGGL (cfl_from_max_kernel, dim3 (1), dim3 (256), 0, dom->stream, dom->cfl_partial,
 		      (int) dom->cfl_used, 1./L.n, result);
   dom->cfl_dirty = false;
   GFSHIP_HIP (hipGetLastError ());
-  GFSHIP_HIP (hipMemcpyAsync (dom->h_pinned, result, sizeof (double), hipMemcpyDeviceToHost,
-			      dom->stream));
   GFSHIP_HIP (stream_wait_spin (dom->stream));
   *cfl2 = dom->h_pinned[0];
   return call_reduce (dom, cfl2, 1, 2);
@@ -1200,12 +1198,10 @@ int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3],
   int nblocks = (int) ((next + block - 1)/block);
   if (nblocks > 1024) nblocks = 1024;
   double * partial = dom->d_scratch;
-  double * result = dom->d_scratch + 5*1024;
+  double * result = dom->h_pinned;      /* host memory mapped on the device: no copy kernel */
   DISPATCH (dom, cfl_partial_kernel, dim3 (nblocks), dim3 (block), L, c3 (u), c3 (un), vs, partial);
   hipLaunchKernelGGL (min_final_kernel, dim3 (1), dim3 (256), 0, dom->stream, partial, nblocks, result);
   GFSHIP_HIP (hipGetLastError ());
-  GFSHIP_HIP (hipMemcpyAsync (dom->h_pinned, result, sizeof (double), hipMemcpyDeviceToHost,
-			      dom->stream));
   GFSHIP_HIP (stream_wait_spin (dom->stream));
   *cfl2 = dom->h_pinned[0];
   return call_reduce (dom, cfl2, 1, 2);   /* gfs_all_reduce (..., MPI_MIN), src/domain.c:2921 */
