@@ -98,6 +98,7 @@ int gfship_domain_create (gfship_domain ** out, int dim, int depth, const int si
   dom->scratch_doubles = 5*1024 + 64;
   if (e == hipSuccess) e = hipMalloc ((void **) &dom->d_scratch, dom->scratch_doubles*sizeof (double));
   if (e == hipSuccess) e = hipHostMalloc ((void **) &dom->h_pinned, 64*sizeof (double), hipHostMallocDefault);
+  if (e == hipSuccess) memset (dom->h_pinned, 0, 64*sizeof (double));
   if (e != hipSuccess) {
     int r = hip_fail (e, "domain resources", __FILE__, __LINE__);
     gfship_domain_destroy (dom);

@@ -341,6 +341,13 @@ bool skew_supported (const gfship_domain * dom, int level)
   return true;
 }
 
+// the "a bounded wait gave up" flag of a level lives in host memory mapped on the device (written
+// by a kernel only when it happens): the host checks it without a copy
+static unsigned * skew_err_word (gfship_domain * dom, int level)
+{
+  return (unsigned *) (dom->h_pinned + 32) + level;
+}
+
 static int skew_plan (gfship_domain * dom, int level, SkewPlan ** out)
 {
   SkewPlan & S = dom->skew[level];
@@ -444,7 +451,7 @@ static int skew_launch (gfship_domain * dom, int level, SkewPlan * S, double * u
   A.hbJ = (u64 *) S->hb; A.hbK = (u64 *) S->hb + S->hb_words;
   A.order = S->order;
   A.ticket = (unsigned *) S->ctl;
-  A.err = (unsigned *) S->ctl + 1;
+  A.err = skew_err_word (dom, level);
   A.dummy = (const u64 *) S->ctl + 2;
   A.stats = S->stats;
   int ntiles = S->ntj*S->ntj;
@@ -494,16 +501,13 @@ int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * 
     GFSHIP_HIP (hipMemsetAsync (S->us, 0, doubles*sizeof (double), dom->stream));
     GFSHIP_HIP (hipMemsetAsync (S->rs, 0, doubles*sizeof (double), dom->stream));
     r = skew_loop_run (dom, level, S, zero_nat, false, 2);
-    unsigned e[2] = { 0, 0 };
-    if (r == GFSHIP_OK) {
-      GFSHIP_HIP (hipMemcpyAsync (e, S->ctl, sizeof (e), hipMemcpyDeviceToHost, dom->stream));
+    if (r == GFSHIP_OK)
       GFSHIP_HIP (hipStreamSynchronize (dom->stream));
-    }
     (void) hipFree (zero_nat);
     if (r != GFSHIP_OK) return r;
-    if (e[1]) {
+    if (*skew_err_word (dom, level)) {
       dom->no_fused_loop = true;
-      GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, 2*sizeof (unsigned), dom->stream));
+      *skew_err_word (dom, level) = 0;
     }
   }
   if ((r = skew_pack (dom, level, S, u, rhs, dia_zero ? nullptr : dia))) return r;
@@ -621,9 +625,7 @@ int skew_check_error (gfship_domain * dom)
 {
   for (int l = 0; l <= dom->depth; l++)
     if (dom->skew[l].ctl) {
-      unsigned e[2];
-      GFSHIP_HIP (hipMemcpy (e, dom->skew[l].ctl, sizeof (e), hipMemcpyDeviceToHost));
-      GFSHIP_CHECK (e[1] == 0, GFSHIP_EHIP,
+      GFSHIP_CHECK (*skew_err_word (dom, l) == 0, GFSHIP_EHIP,
 		    "relax_skew_kernel: a hand-off wait timed out on level %d", l);
     }
   return GFSHIP_OK;

@@ -864,7 +864,7 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
     GFSHIP_HIP (hipMemsetAsync ((unsigned *) S->ctl + 6, 0, 8*sizeof (unsigned), dom->stream));
   }
   A.ticket = (unsigned *) S->ctl;
-  A.err = (unsigned *) S->ctl + 1;
+  A.err = (unsigned *) (dom->h_pinned + 32) + level;     /* skew_err_word, relax_skew.hip */
   A.dummy = (const u64 *) S->ctl + 2;
   A.stats = nullptr;
   if (getenv ("GFSHIP_SKEW_STATS")) {
