@@ -58,10 +58,50 @@ def cpu_baseline(level=7, steps=3):
     for _ in range(steps):
         s.step()
     dt = time.perf_counter() - t0
-    return {"value": n ** 3 * steps / dt / 1e6, "unit": "Mcell-steps/s", "cores": 1,
-            "kind": "port",
-            "sample": "%d^3 Taylor-Green, %d steps, CPU oracle (reference algorithm, "
-                      "reference traversal order)" % (n, steps)}
+    out = {"value": n ** 3 * steps / dt / 1e6, "unit": "Mcell-steps/s", "cores": 1,
+           "kind": "port",
+           "sample": "%d^3 Taylor-Green, %d steps, CPU oracle (reference algorithm, "
+                     "reference traversal order)" % (n, steps)}
+    out["relax_sweep"] = cpu_relax_layouts(level)
+    return out
+
+
+def cpu_relax_layouts(level=7, sweeps=4):
+    """Where the CPU time goes: the same relax sweeps on the oracle's flat arrays and on
+    a reference-like tree of FttCell / FttOct records with ftt_cell_neighbor lookups and one callback
+    per cell (oracle/go_aos.c; both give the same bits, tests/test_oracle_aos_baseline.py)."""
+    import ctypes as C
+    from oracle import oracle as O
+    L = O.lib()
+    vp, pd, i = C.c_void_p, C.POINTER(C.c_double), C.c_int
+    L.go_aos_new.restype, L.go_aos_new.argtypes = vp, [i]
+    L.go_aos_destroy.restype, L.go_aos_destroy.argtypes = None, [vp]
+    L.go_aos_load.restype, L.go_aos_load.argtypes = None, [vp, vp, pd, pd, pd]
+    L.go_aos_relax.restype, L.go_aos_relax.argtypes = None, [vp, i]
+    L.go_aos_bytes_per_cell.restype = C.c_size_t
+    n = 1 << level
+    dom = O.Domain(3, level, [O.SIDE_PERIODIC] * 6)
+    L.go_poisson_coefficients(dom.ptr)
+    u, rhs, dia = dom.field(), dom.field(), dom.field()
+    rng = np.random.default_rng(0)
+    u.interior()[...] = rng.standard_normal(u.interior().shape)
+    rhs.interior()[...] = rng.standard_normal(u.interior().shape)
+    lev = lambda f: C.cast(L.go_field_level(f.ptr, level), pd)   # noqa: E731
+    tree = L.go_aos_new(level)
+    L.go_aos_load(tree, dom.ptr, lev(u), lev(rhs), lev(dia))
+    t0 = time.perf_counter()
+    L.go_aos_relax(tree, sweeps)
+    t_aos = time.perf_counter() - t0
+    L.go_aos_destroy(tree)
+    t0 = time.perf_counter()
+    for _ in range(sweeps):
+        L.go_homogeneous_bc(u.ptr, u.ptr, level)
+        L.go_relax(dom.ptr, 3, level, 1., u.ptr, rhs.ptr, dia.ptr)
+    t_soa = time.perf_counter() - t0
+    return {"unit": "Mcell-sweeps/s", "cores": 1, "sample": "%d sweeps at %d^3" % (sweeps, n),
+            "flat_arrays": n ** 3 * sweeps / t_soa / 1e6,
+            "pointer_tree_aos": n ** 3 * sweeps / t_aos / 1e6,
+            "aos_bytes_per_cell": int(L.go_aos_bytes_per_cell())}
 
 
 def main():
