@@ -694,23 +694,30 @@ __device__ __forceinline__ double wave_max (double v)
   return v;
 }
 
+// rows of cells per workgroup (grid-stride), lanes along x: no per-cell index arithmetic.  EXACT_INV:
+// scale is a power of two (h*h), the division raw/scale is the exact multiplication by 1/scale.
+template <bool EXACT_INV>
 __global__ void __launch_bounds__(256)
 norm_partial_kernel (Layout L, const double * __restrict__ a, double scale, double weight,
 		     double * __restrict__ partial)
 {
-  long nc = L.dim == 3 ? (long) L.n*L.n*L.n : (long) L.n*L.n;
+  const int n = L.n;
+  const long nrows = L.dim == 3 ? (long) n*n : n;
+  const double inv = 1./scale;
   double s0 = 0., s1 = 0., s2 = 0., s3 = 0., s4 = 0.;
-  for (long q = (long) blockIdx.x*blockDim.x + threadIdx.x; q < nc;
-       q += (long) gridDim.x*blockDim.x) {
-    int i = q % L.n + 1, j = (q / L.n) % L.n + 1, k = L.dim == 3 ? q / ((long) L.n*L.n) + 1 : 0;
-    double raw = a[L.idx (i, j, k)];
-    double val = raw/scale;
-    s0 += weight*val;
-    val = fabs (val);
-    s3 = fmax (s3, val);
-    s1 += weight*val;
-    s2 += weight*val*val;
-    s4 += raw;
+  for (long r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const int j = (int) (r % n) + 1, k = L.dim == 3 ? (int) (r / n) + 1 : 0;
+    const double * row = a + L.idx (1, j, k);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      double raw = row[i];
+      double val = EXACT_INV ? raw*inv : raw/scale;
+      s0 += weight*val;
+      val = fabs (val);
+      s3 = fmax (s3, val);
+      s1 += weight*val;
+      s2 += weight*val*val;
+      s4 += raw;
+    }
   }
   __shared__ double sh[5][4];
   s0 = wave_sum (s0); s1 = wave_sum (s1); s2 = wave_sum (s2); s3 = wave_max (s3); s4 = wave_sum (s4);
@@ -750,19 +757,32 @@ norm_final_kernel (const double * __restrict__ partial, int nblocks, double * __
   }
 }
 
+// 1/scale is exact when scale is a power of two (the h*h of the residual norms, 1. elsewhere)
+static bool power_of_two (double x)
+{
+  int e;
+  return x > 0. && frexp (x, &e) == 0.5;
+}
+#define NORM_PARTIAL_LAUNCH() do {					\
+    if (power_of_two (scale))						\
+      hipLaunchKernelGGL (norm_partial_kernel<true>, dim3 (nblocks), dim3 (block), 0, dom->stream, \
+			  L, a, scale, weight, partial);		\
+    else								\
+      hipLaunchKernelGGL (norm_partial_kernel<false>, dim3 (nblocks), dim3 (block), 0, dom->stream, \
+			  L, a, scale, weight, partial);		\
+  } while (0)
+
 // the same without waiting for the result: it lands in dom->h_pinned[8 .. 12] once the stream has
 // passed this point (the caller synchronises later anyway)
 int launch_norm_async (gfship_domain * dom, int level, const double * a, double scale, double weight)
 {
   const Layout & L = dom->lay[level];
-  long nc = ncells (L);
-  int block = 256;
-  int nblocks = (int) ((nc + block - 1)/block);
-  if (nblocks > 1024) nblocks = 1024;
+  long nrows = L.dim == 3 ? (long) L.n*L.n : L.n;
+  int block = L.n >= 256 ? 256 : L.n >= 128 ? 128 : 64;
+  int nblocks = (int) (nrows > 1024 ? 1024 : nrows);
   double * partial = dom->d_scratch;
   double * result = dom->h_pinned + 8;     /* host memory mapped on the device */
-  hipLaunchKernelGGL (norm_partial_kernel, dim3 (nblocks), dim3 (block), 0, dom->stream,
-		      L, a, scale, weight, partial);
+  NORM_PARTIAL_LAUNCH ();
   hipLaunchKernelGGL (norm_final_kernel, dim3 (1), dim3 (256), 0, dom->stream,
 		      partial, nblocks, result);
   GFSHIP_HIP (hipGetLastError ());
@@ -773,14 +793,12 @@ int launch_norm (gfship_domain * dom, int level, const double * a, double scale,
 		 double out[5])
 {
   const Layout & L = dom->lay[level];
-  long nc = ncells (L);
-  int block = 256;
-  int nblocks = (int) ((nc + block - 1)/block);
-  if (nblocks > 1024) nblocks = 1024;
+  long nrows = L.dim == 3 ? (long) L.n*L.n : L.n;
+  int block = L.n >= 256 ? 256 : L.n >= 128 ? 128 : 64;
+  int nblocks = (int) (nrows > 1024 ? 1024 : nrows);
   double * partial = dom->d_scratch;     // 5*1024 doubles
   double * result = dom->h_pinned;       // host memory mapped on the device: no copy kernel
-  hipLaunchKernelGGL (norm_partial_kernel, dim3 (nblocks), dim3 (block), 0, dom->stream,
-		      L, a, scale, weight, partial);
+  NORM_PARTIAL_LAUNCH ();
   hipLaunchKernelGGL (norm_final_kernel, dim3 (1), dim3 (256), 0, dom->stream,
 		      partial, nblocks, result);
   GFSHIP_HIP (hipGetLastError ());
