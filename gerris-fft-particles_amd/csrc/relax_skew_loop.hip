@@ -836,7 +836,9 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
   /* a single sweep only uses the two hand-off arrays of its granule set.  (Arming the granules on a
      side stream, with two sets used in turn, was tried: no gain, the stores compete for HBM.) */
-  GFSHIP_HIP (hipMemsetAsync (S->hbf, 0xFF, (nrelax > 1 ? (size_t) nrelax*hb_sweep : (size_t) 2*hb_words)*
+  /* (the snapshots of the last sweep are neither written nor read: its two hand-off arrays end the
+     armed range) */
+  GFSHIP_HIP (hipMemsetAsync (S->hbf, 0xFF, ((size_t) (nrelax - 1)*hb_sweep + (size_t) 2*hb_words)*
 			      sizeof (u64), dom->stream));
   SkewLoopArgs A;
   A.L = L; A.ntj = S->ntj; A.RT = S->RT; A.nsweeps = (int) nrelax;
