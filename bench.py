@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 RELAX_BYTES_PER_CELL = 24.0    # read u, read rhs, write u
+PMC_SUMMARY = "r01_pmc_relax_loop_256.json"
 
 
 def taylor_green(n):
@@ -47,7 +48,8 @@ def with_ghosts(a):
 
 
 def cpu_baseline(level=7, steps=3):
-    """The oracle on a bounded sample of the same workload (64^3, same parameters), 1 core."""
+    """The oracle on a bounded sample of the same workload (2^level cells per side, same
+    parameters), 1 core."""
     from oracle import oracle as O
     n = 1 << level
     s = O.Sim(3, level, [O.SIDE_PERIODIC] * 6)
@@ -104,82 +106,7 @@ def cpu_relax_layouts(level=7, sweeps=4):
             "aos_bytes_per_cell": int(L.go_aos_bytes_per_cell())}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--level", type=int, default=8, help="Refine level (8 = 256^3)")
-    ap.add_argument("--mode", default="exact", choices=["exact", "redblack"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--particles", type=int, default=2000000,
-                    help="tracers of the config D line (0 = skip)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # GFSHIP_DIST_BACKEND=gloo: rehearsal of the N > 1 path with several ranks on one GPU
-        # (halos staged through the host, gfship/distributed.py); never used for reported numbers
-        backend = os.environ.get("GFSHIP_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            local_rank = local_rank % max(1, torch.cuda.device_count())
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend)
-
-    import gfship
-    n = 1 << args.level
-    hooks = None
-    if world > 1:
-        # one 256^3 GfsBox per GPU on a periodic lattice of boxes (2x1x1, 2x2x1, 2x2x2): the sides
-        # with a neighbour box are GfsBoundaryMpi sides served over RCCL (gfship/distributed.py)
-        from gfship import distributed as D
-        grid = D.BoxGrid(world, 3)
-        dom = gfship.Domain(3, args.level, grid.sides(rank), device=local_rank)
-        hooks = D.DeviceHooks(dom, D.Transport(grid, rank, torch.device("cuda", local_rank)))
-    else:
-        dom = gfship.Domain(3, args.level, [gfship.SIDE_PERIODIC] * 6, device=local_rank)
-    if args.mode == "redblack":
-        dom.set_relax_mode(gfship.RELAX_REDBLACK)
-    sim = gfship.Simulation(dom)
-    for c, a in enumerate(taylor_green(n)):
-        sim.u[c].upload(with_ghosts(a))
-    sim.start()
-    for _ in range(args.warmup):
-        sim.step()
-    dom.synchronize()
-
-    def barrier():
-        dom.synchronize()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sim.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # roofline of the dominant kernel: the exact-order relax loop of the 256^3 level (nrelax = 4
-    # sweeps with the homogeneous BC between them, src/poisson.c:1070-1089) -- on a periodic box one
-    # launch of relax_skew_loop_kernel with the sweeps pipelined behind each other; timed with HIP
-    # events on the library's stream.  Algorithmic traffic: 24 B per cell and sweep.
+def measure_roofline(dom, args, n):
     u, rhs, dia = dom.variable(), dom.variable(), dom.variable()
     rng = np.random.default_rng(0)
     u.upload(rng.standard_normal((n + 2,) * 3))
@@ -198,12 +125,15 @@ def main():
         # (FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes): counters cannot
         # be read from inside this process, so the committed summary is reported
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_relax_loop_256.json")
+        pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
         if args.level == 8 and fused and os.path.exists(pmc):
             with open(pmc) as f:
                 traffic = json.load(f)["kernels"]["relax_skew_loop_kernel"]["hbm_bytes_per_launch_guide_corrected"]
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": None if traffic is None else
+                    "profiles/%s: rocprofv3 --pmc passes of this kernel at this size, committed; "
+                    "not collected in this run" % PMC_SUMMARY,
                     "algorithmic_bytes_per_launch": bytes_loop,
                     "kernel": "relax loop (%d sweeps%s), level %d (%d^3), mode exact"
                               % (nrelax, ", one pipelined launch" if fused else
@@ -218,6 +148,130 @@ def main():
                     "algorithmic_bytes_per_launch": RELAX_BYTES_PER_CELL * n ** 3,
                     "kernel": "relax sweep, level %d (%d^3), mode %s" % (args.level, n, args.mode),
                     "ms_per_launch": ms_sweep}
+
+    return roofline
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--level", type=int, default=8, help="Refine level (8 = 256^3)")
+    ap.add_argument("--mode", default="exact", choices=["exact", "redblack"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--particles", type=int, default=2000000,
+                    help="tracers of the config D line (0 = skip)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand as `python bench.py --gpus N`: start the N ranks as a fresh child under
+        # torch.distributed.run BEFORE anything here touches the GPU (this process never does), and
+        # relay its output and exit code
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        r = subprocess.run(cmd, env=env)
+        sys.exit(r.returncode)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE = %d\n" % (args.gpus, world))
+        sys.exit(2)
+    dist = None
+    backend = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # torch.distributed is the launcher's channel only (rendezvous, the 128 bytes of the RCCL
+        # unique id, the barriers around the timed region): a CPU process group.  The halos and
+        # reductions of the time step go through the library's own RCCL communicator.
+        # GFSHIP_DIST_BACKEND=gloo-staged: rehearsal of the N > 1 path with several ranks on one GPU
+        # (RCCL refuses that): halos staged through the host by the hook transport
+        # (gfship/distributed.py); never used for reported numbers
+        backend = os.environ.get("GFSHIP_DIST_BACKEND", "rccl")
+        dist.init_process_group("gloo")
+        if backend != "rccl":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+
+    import gfship
+    n = 1 << args.level
+    hooks = None
+    rccl_world = 0
+    if world > 1:
+        # one 256^3 GfsBox per GPU on a periodic lattice of boxes (2x1x1, 2x2x1, 2x2x2): the sides
+        # with a neighbour box are GfsBoundaryMpi sides
+        from gfship import distributed as D
+        grid = D.BoxGrid(world, 3)
+        dom = gfship.Domain(3, args.level, grid.sides(rank), device=local_rank)
+        if backend == "rccl":
+            import torch
+            uid = torch.zeros(gfship.UNIQUE_ID_BYTES, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(gfship.comm_unique_id()), dtype=torch.uint8).clone()
+            dist.broadcast(uid, 0)
+            dom.comm_init(bytes(uid.numpy().tobytes()), rank, world, grid.b)
+            rccl_world = dom.comm_size()
+        else:
+            import torch
+            torch.cuda.set_device(local_rank)
+            hooks = D.DeviceHooks(dom, D.Transport(grid, rank, torch.device("cuda", local_rank)))
+    else:
+        dom = gfship.Domain(3, args.level, [gfship.SIDE_PERIODIC] * 6, device=local_rank)
+    if args.mode == "redblack":
+        dom.set_relax_mode(gfship.RELAX_REDBLACK)
+    sim = gfship.Simulation(dom)
+    for c, a in enumerate(taylor_green(n)):
+        sim.u[c].upload(with_ghosts(a))
+    sim.start()
+    for _ in range(args.warmup):
+        sim.step()
+    dom.synchronize()
+
+    def barrier():
+        dom.synchronize()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize(local_rank)
+            dist.barrier()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # roofline of the dominant kernel: the exact-order relax loop of the 256^3 level (nrelax = 4
+    # sweeps with the homogeneous BC between them, src/poisson.c:1070-1089) -- on a periodic box one
+    # launch of relax_skew_loop_kernel with the sweeps pipelined behind each other; timed with HIP
+    # events on the library's stream.  Algorithmic traffic: 24 B per cell and sweep.
+    # (with several boxes the relax loop of a box has the halo exchange between its sweeps: the kernel
+    # entry is then measured by rank 0 on a periodic box of its own, after the timed region)
+    roofline = None
+    rdom = dom if world == 1 else (
+        gfship.Domain(3, args.level, [gfship.SIDE_PERIODIC] * 6, device=local_rank) if rank == 0
+        else None)
+    if rdom is not None:
+        roofline = measure_roofline(rdom, args, n)
 
     # config D: the same box with 2e6 GfsParticle tracers (positions from the
     # fixed-seed LCG, ids 1..Np): the particle event alone, and the step with the event in it
@@ -273,7 +327,7 @@ def main():
     if rank == 0:
         value = world * n ** 3 * args.steps / elapsed / 1e6
         out = {
-            "metric": "Mcell-steps/s (projection+advection), 3D 256^3 uniform",
+            "metric": "Mcell-steps/s (projection+advection), 3D %d^3 uniform" % n,
             "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -283,8 +337,11 @@ def main():
                        "relax_mode": args.mode,
                        "parallelism": "1 box" if world == 1 else
                                       "%d boxes of %d^3, lattice %s, one per GPU, halo exchange "
-                                      "over RCCL p2p (reference semantics: overlap = 0)"
-                                      % (world, n, "x".join(map(str, grid.b))),
+                                      "%s (reference semantics: overlap = 0)"
+                                      % (world, n, "x".join(map(str, grid.b)),
+                                         "by ncclSend/ncclRecv inside libgfship" if backend == "rccl"
+                                         else "staged through the host (rehearsal)"),
+                       "rccl_world_size": rccl_world,
                        "poisson_niter": [int(sim.projection_params.niter),
                                          int(sim.approx_projection_params.niter)]},
             "roofline": roofline,

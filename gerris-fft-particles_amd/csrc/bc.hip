@@ -79,9 +79,11 @@ int call_exchange (gfship_domain * dom, double * ptr, int level, int kind)
 {
   if (!dom->has_external)
     return GFSHIP_OK;
+  if (dom->comm)
+    return comm_exchange (dom, ptr, level, kind);
   GFSHIP_CHECK (dom->exchange != nullptr, GFSHIP_EINVAL,
-		"the domain has GFSHIP_SIDE_EXTERNAL sides but no exchange hook "
-		"(gfship_domain_set_exchange)");
+		"the domain has GFSHIP_SIDE_EXTERNAL sides but neither a communicator "
+		"(gfship_domain_comm_init) nor an exchange hook (gfship_domain_set_exchange)");
   int r = (* dom->exchange) (dom->exchange_ctx, ptr, level, kind);
   GFSHIP_CHECK (r == 0, GFSHIP_EHIP, "the exchange hook failed (%d)", r);
   return GFSHIP_OK;
@@ -91,12 +93,29 @@ int call_reduce (gfship_domain * dom, double * vals, int n, int op)
 {
   if (!dom->has_external)
     return GFSHIP_OK;
+  if (dom->comm)
+    return op == 0 ? comm_reduce (dom, vals, n, nullptr, 0, nullptr, 0) :
+      op == 1 ? comm_reduce (dom, nullptr, 0, vals, n, nullptr, 0) :
+      comm_reduce (dom, nullptr, 0, nullptr, 0, vals, n);
   GFSHIP_CHECK (dom->reduce != nullptr, GFSHIP_EINVAL,
-		"the domain has GFSHIP_SIDE_EXTERNAL sides but no reduce hook "
-		"(gfship_domain_set_reduce)");
+		"the domain has GFSHIP_SIDE_EXTERNAL sides but neither a communicator "
+		"(gfship_domain_comm_init) nor a reduce hook (gfship_domain_set_reduce)");
   int r = (* dom->reduce) (dom->reduce_ctx, vals, n, op);
   GFSHIP_CHECK (r == 0, GFSHIP_EHIP, "the reduce hook failed (%d)", r);
   return GFSHIP_OK;
+}
+
+// domain_norm_reduce (src/domain.c:2135-2166): nsum sums and one maximum; one collective with the
+// in-library transport, one hook call per operation otherwise
+int call_reduce_norm (gfship_domain * dom, double * sums, int nsum, double * mx)
+{
+  if (!dom->has_external)
+    return GFSHIP_OK;
+  if (dom->comm)
+    return comm_reduce (dom, sums, nsum, mx, 1, nullptr, 0);
+  int r;
+  if ((r = call_reduce (dom, sums, nsum, 0))) return r;
+  return call_reduce (dom, mx, 1, 1);
 }
 
 // sndbuf / rcvbuf of the periodic and MPI boundaries (src/boundary.c:1240-1258,1333-1347):

@@ -16,7 +16,7 @@ for f in "$HERE"/*.hip; do
   OBJS="$OBJS $o"
 done
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgfship.so" $OBJS -L/opt/rocm/lib -lhipfft
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgfship.so" $OBJS -L/opt/rocm/lib -lhipfft -ldl
 echo "built $OUT/libgfship.so"
 # host front end: the reference's gerris2D / gerris3D command, on libgfship (C ABI only)
 BIN="$HERE/../bin"

@@ -119,6 +119,7 @@ void gfship_domain_destroy (gfship_domain * dom)
   for (size_t f = 0; f < dom->fields.size (); f++)
     if (dom->fields[f].used)
       gfship_field_free (dom, (gfship_field) f);
+  comm_free (dom);
   skew_free (dom);
   if (dom->d_scratch) (void) hipFree (dom->d_scratch);
   if (dom->cfl_partial) (void) hipFree (dom->cfl_partial);

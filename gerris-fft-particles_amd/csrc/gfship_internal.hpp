@@ -91,6 +91,7 @@ struct gfship_domain {
   gfship_exchange_fn exchange = nullptr; void * exchange_ctx = nullptr;  // GfsBoundaryMpi hooks
   gfship_reduce_fn reduce = nullptr;     void * reduce_ctx = nullptr;
   bool has_external = false;
+  void * comm = nullptr;          // in-library RCCL transport (transport.hip), replaces the hooks
   gfship_field dp_cache = -1;     // the `dp` temporary of gfs_poisson_cycle, kept between cycles
   int skew_resident = -1;         // workgroups of the fused relax loop that fit on the device
   bool wave_loop = false;         // fused relax loops by the experimental one-wave-per-tile kernel (GFSHIP_WAVE_LOOP=1)
@@ -141,6 +142,12 @@ inline long ncells (const Layout & L) {
 int launch_bc (gfship_domain * dom, Field * v, Field * v1, int level, int homogeneous);
 int call_exchange (gfship_domain * dom, double * ptr, int level, int kind);
 int call_reduce (gfship_domain * dom, double * vals, int n, int op);
+int call_reduce_norm (gfship_domain * dom, double * sums, int nsum, double * mx);
+// transport.hip
+int comm_exchange (gfship_domain * dom, double * a, int level, int kind);
+int comm_reduce (gfship_domain * dom, double * sums, int nsum, double * maxs, int nmax,
+		 double * mins, int nmin);
+void comm_free (gfship_domain * dom);
 int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, double omega,
 			double * u, const double * rhs, const double * dia,
 			const RelaxOp * op = nullptr);

@@ -1240,6 +1240,10 @@ void apply_init (Run & R)
 int run (Run & R)
 {
   R.clock0 = std::chrono::steady_clock::now ();
+  /* the functions of the file are compiled (a child `cc') before anything touches the GPU: a file
+     whose functions do not compile exits here without a device context or handles left behind */
+  add_derived (R);
+  R.functions.resolve (R.var_names ());
   CHECK (gfship_domain_create (&R.dom, R.dim, R.level, R.side, R.device));
   CHECK (gfship_sim_create (&R.sim, R.dom));
   R.vars[R.var_index ("P")].dev = gfship_sim_variable (R.sim, GFSHIP_VAR_P, 0);
@@ -1258,9 +1262,6 @@ int run (Run & R)
     div = gfship_field_alloc (R.dom, -1);     /* the temporary `div` of poisson_run */
     CHECK (div);
   }
-  add_derived (R);
-  R.functions.resolve (R.var_names ());
-
   apply_multilevel (gfship_sim_projection_params (R.sim), R.proj_set);
   apply_multilevel (gfship_sim_approx_projection_params (R.sim), R.approx_set);
   gfship_advection_params * adv = gfship_sim_advection_params (R.sim);

@@ -101,11 +101,9 @@ static int norm_residual_finish (gfship_domain * dom, double dt, double s[5], gf
   double w = (double) ncells (L);
   if (dom->has_external) {
     /* domain_norm_reduce + gfs_all_reduce (bias), src/domain.c:2135-2166,2279 */
-    double sums[4] = { s[0], s[1], s[2], w }, mx[1] = { s[3] }, raw[1] = { s[4] };
-    if ((r = call_reduce (dom, sums, 4, 0))) return r;
-    if ((r = call_reduce (dom, mx, 1, 1))) return r;
-    if ((r = call_reduce (dom, raw, 1, 0))) return r;
-    s[0] = sums[0]; s[1] = sums[1]; s[2] = sums[2]; w = sums[3]; s[3] = mx[0]; s[4] = raw[0];
+    double sums[5] = { s[0], s[1], s[2], w, s[4] }, mx[1] = { s[3] };
+    if ((r = call_reduce_norm (dom, sums, 5, mx))) return r;
+    s[0] = sums[0]; s[1] = sums[1]; s[2] = sums[2]; w = sums[3]; s[3] = mx[0]; s[4] = sums[4];
   }
   gfship_norm n;
   n.bias = s[0]; n.first = s[1]; n.second = s[2]; n.infty = s[3]; n.w = w;
@@ -206,8 +204,7 @@ int gfship_norm_variable (gfship_domain * dom, gfship_field v, gfship_norm * out
   double wv = vol*(double) ncells (L);
   if (dom->has_external) {
     double sums[4] = { s[0], s[1], s[2], wv }, mx[1] = { s[3] };
-    if ((r = call_reduce (dom, sums, 4, 0))) return r;
-    if ((r = call_reduce (dom, mx, 1, 1))) return r;
+    if ((r = call_reduce_norm (dom, sums, 4, mx))) return r;
     s[0] = sums[0]; s[1] = sums[1]; s[2] = sums[2]; wv = sums[3]; s[3] = mx[0];
   }
   n.bias = s[0]; n.first = s[1]; n.second = s[2]; n.infty = s[3];
@@ -348,7 +345,23 @@ int gfship_poisson_solve (gfship_domain * dom, gfship_multilevel_params * par,
 
   while (par->niter < par->nitermin ||
 	 (par->residual.infty > par->tolerance && par->niter < par->nitermax)) {
-    if ((r = poisson_cycle (dom, par, lhs, rhs, dia, res, dt, &par->residual))) break;
+    if ((r = poisson_cycle (dom, par, lhs, rhs, dia, res, dt, &par->residual))) {
+      if (deferred) {
+	/* the cycle failed after the first norm was enqueued: callers that print the statistics
+	   still get residual_before (and no stale residual) */
+	deferred = false;
+	double s0[5];
+	if (hipStreamSynchronize (dom->stream) == hipSuccess) {
+	  memcpy (s0, dom->h_pinned + 8, sizeof (s0));
+	  if (norm_residual_finish (dom, dt, s0, &par->residual_before) == GFSHIP_OK)
+	    par->residual = par->residual_before;
+	}
+	else
+	  memset (&par->residual_before, 0, sizeof (par->residual_before)),
+	    memset (&par->residual, 0, sizeof (par->residual));
+      }
+      break;
+    }
     if (deferred) {
       /* the stream has been synchronised by the norm of the cycle: the first norm is there */
       deferred = false;

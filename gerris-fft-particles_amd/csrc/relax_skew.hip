@@ -624,9 +624,16 @@ int skew_time_loop (gfship_domain * dom, int level, Field * u, const double * rh
 int skew_check_error (gfship_domain * dom)
 {
   for (int l = 0; l <= dom->depth; l++)
-    if (dom->skew[l].ctl) {
-      GFSHIP_CHECK (*skew_err_word (dom, l) == 0, GFSHIP_EHIP,
-		    "relax_skew_kernel: a hand-off wait timed out on level %d", l);
+    if (dom->skew[l].ctl && *skew_err_word (dom, l) != 0) {
+      /* the word is not sticky: this solve is lost (its tiles computed on values that never
+	 arrived), but the domain keeps working -- from now on with one launch per sweep, whose
+	 tiles only ever wait on tiles claimed before them (no residency assumption) */
+      *skew_err_word (dom, l) = 0;
+      dom->no_fused_loop = true;
+      set_error ("relax_skew_kernel: a hand-off wait timed out on level %d (CUs held by another "
+		 "process or stream?); this solve failed, the domain falls back to one launch "
+		 "per sweep", l);
+      return GFSHIP_EHIP;
     }
   return GFSHIP_OK;
 }

@@ -1,0 +1,287 @@
+// transport.hip -- GfsBoundaryMpi over RCCL, inside the library: the halo exchange of every BC
+// application and the all-reduces of norms / CFL of a domain that is one GfsBox of a periodic
+// lattice of boxes, one box per GPU (src/mpi_boundary.c:78-246, src/domain.c:2135-2166,2921).
+//
+// One exchange = pack kernel (all sides, one launch) -> one ncclGroupStart/End with an ncclSend per
+// MPI side and the matching ncclRecv -> unpack kernel, all enqueued on the domain's stream: no
+// host synchronisation, no Python, no callback.  Reductions are one ncclAllGather of the operands
+// of every rank followed by the same rank-ordered reduction on every rank (identical results
+// everywhere, so that all boxes take the same branches of the solve loop), read back through
+// pinned host memory.
+//
+// RCCL is opened at run time (dlopen librccl.so.1): a single-box run never loads it, and a process
+// that already holds an RCCL (PyTorch's) shares that copy.
+#include "gfship_internal.hpp"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace gfship {
+
+struct RcclApi {
+  void * handle = nullptr;
+  ncclResult_t (* GetUniqueId) (ncclUniqueId *) = nullptr;
+  ncclResult_t (* CommInitRank) (ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (* CommDestroy) (ncclComm_t) = nullptr;
+  ncclResult_t (* CommCount) (const ncclComm_t, int *) = nullptr;
+  ncclResult_t (* GroupStart) () = nullptr;
+  ncclResult_t (* GroupEnd) () = nullptr;
+  ncclResult_t (* Send) (const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (* Recv) (void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (* AllGather) (const void *, void *, size_t, ncclDataType_t, ncclComm_t,
+			      hipStream_t) = nullptr;
+  const char * (* GetErrorString) (ncclResult_t) = nullptr;
+};
+
+static RcclApi g_rccl;
+
+static int rccl_load ()
+{
+  if (g_rccl.handle) return GFSHIP_OK;
+  const char * names[] = { "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" };
+  void * h = nullptr;
+  for (const char * nm : names)
+    if ((h = dlopen (nm, RTLD_NOW | RTLD_GLOBAL)))
+      break;
+  GFSHIP_CHECK (h != nullptr, GFSHIP_EUNSUPPORTED, "cannot open librccl.so.1: %s", dlerror ());
+#define SYM(field, name) do { \
+    *(void **) &g_rccl.field = dlsym (h, name); \
+    GFSHIP_CHECK (g_rccl.field != nullptr, GFSHIP_EUNSUPPORTED, "librccl: no symbol %s", name); \
+  } while (0)
+  SYM (GetUniqueId, "ncclGetUniqueId");
+  SYM (CommInitRank, "ncclCommInitRank");
+  SYM (CommDestroy, "ncclCommDestroy");
+  SYM (CommCount, "ncclCommCount");
+  SYM (GroupStart, "ncclGroupStart");
+  SYM (GroupEnd, "ncclGroupEnd");
+  SYM (Send, "ncclSend");
+  SYM (Recv, "ncclRecv");
+  SYM (AllGather, "ncclAllGather");
+  SYM (GetErrorString, "ncclGetErrorString");
+#undef SYM
+  g_rccl.handle = h;
+  return GFSHIP_OK;
+}
+
+#define GFSHIP_NCCL(call) do { ncclResult_t e_ = (call); \
+    if (e_ != ncclSuccess) { \
+      gfship::set_error ("RCCL error %d (%s) in %s at %s:%d", (int) e_, \
+			 g_rccl.GetErrorString (e_), #call, __FILE__, __LINE__); \
+      return GFSHIP_EHIP; } } while (0)
+
+#define COMM_MAXRED 8     /* doubles per rank in one reduction */
+
+struct Comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+  int b[3] = { 1, 1, 1 };           // lattice of boxes; rank r sits at (r % bx, (r/bx) % by, r/(bx by))
+  int peer[6] = { 0, 0, 0, 0, 0, 0 }; // rank of the box across side d
+  double * sbuf[6] = {}, * rbuf[6] = {}; // sndbuf / rcvbuf of the leaf level (coarser levels use a part)
+  double * dred = nullptr;          // [COMM_MAXRED] operands, then [nranks*COMM_MAXRED] gathered
+  double * hred = nullptr;          // pinned host mirror of dred
+  unsigned long long messages = 0, bytes = 0;   // domain->mpi_messages / mpi_size, mpi_boundary.c:113,128
+};
+
+static int comm_rank_of (const Comm * C, int cx, int cy, int cz)
+{
+  const int bx = C->b[0], by = C->b[1], bz = C->b[2];
+  cx = (cx % bx + bx) % bx; cy = (cy % by + by) % by; cz = (cz % bz + bz) % bz;
+  return cx + bx*(cy + by*cz);
+}
+
+// gfs_domain_copy_bc on GfsBoundaryMpi sides: kind 0 = every MPI side of a cell-centred variable;
+// kind 1 + e = the face values fv[e] of gfs_domain_face_bc: my layer along side e goes out, the
+// ghost layer of side e^1 comes in
+int comm_exchange (gfship_domain * dom, double * a, int level, int kind)
+{
+  Comm * C = (Comm *) dom->comm;
+  const Layout & L = dom->lay[level];
+  const size_t nface = dom->dim == 3 ? (size_t) L.n*L.n : (size_t) L.n;
+  int send[6], recv[6], ns = 0, nr = 0;
+  if (kind == 0) {
+    for (int d = 0; d < 2*dom->dim; d++)
+      if (dom->side[d] == GFSHIP_SIDE_EXTERNAL) send[ns++] = d;
+    /* receives in increasing order of the SENDER's side index (r^1): with two boxes along an
+       axis both messages of a pair of ranks travel between the same two peers, and RCCL matches
+       the sends and receives of a pair in posting order (the reference tags them with the side,
+       src/mpi_boundary.c:78-83) */
+    for (int q = 0; q < ns; q++) recv[nr++] = send[q] ^ 1;
+  }
+  else {
+    const int e = kind - 1;
+    if (e >= 0 && e < 2*dom->dim && dom->side[e] == GFSHIP_SIDE_EXTERNAL) {
+      send[ns++] = e;
+      recv[nr++] = e ^ 1;
+    }
+  }
+  if (ns == 0) return GFSHIP_OK;
+  void * sb[6], * rb[6];
+  for (int q = 0; q < ns; q++) sb[q] = C->sbuf[send[q]];
+  for (int q = 0; q < nr; q++) rb[q] = C->rbuf[recv[q]];
+  int r = gfship_halo_pack_sides (dom, a, level, ns, send, sb);
+  if (r) return r;
+  GFSHIP_NCCL (g_rccl.GroupStart ());
+  for (int q = 0; q < ns; q++)
+    GFSHIP_NCCL (g_rccl.Send (sb[q], nface, ncclDouble, C->peer[send[q]], C->comm, dom->stream));
+  for (int q = 0; q < nr; q++)
+    GFSHIP_NCCL (g_rccl.Recv (rb[q], nface, ncclDouble, C->peer[recv[q]], C->comm, dom->stream));
+  GFSHIP_NCCL (g_rccl.GroupEnd ());
+  C->messages += ns;
+  C->bytes += ns*nface*sizeof (double);
+  return gfship_halo_unpack_sides (dom, a, level, nr, recv, rb);
+}
+
+// MPI_Allreduce of nsum sums, nmax maxima and nmin minima in one collective: every rank gathers
+// the operands of all ranks and reduces them in rank order
+int comm_reduce (gfship_domain * dom, double * sums, int nsum, double * maxs, int nmax,
+		 double * mins, int nmin)
+{
+  Comm * C = (Comm *) dom->comm;
+  const int n = nsum + nmax + nmin;
+  GFSHIP_CHECK (n > 0 && n <= COMM_MAXRED, GFSHIP_EINVAL, "at most %d operands per reduction",
+		COMM_MAXRED);
+  double * h = C->hred;
+  for (int q = 0; q < nsum; q++) h[q] = sums[q];
+  for (int q = 0; q < nmax; q++) h[nsum + q] = maxs[q];
+  for (int q = 0; q < nmin; q++) h[nsum + nmax + q] = mins[q];
+  GFSHIP_HIP (hipMemcpyAsync (C->dred, h, n*sizeof (double), hipMemcpyHostToDevice, dom->stream));
+  GFSHIP_NCCL (g_rccl.AllGather (C->dred, C->dred + COMM_MAXRED, (size_t) n, ncclDouble, C->comm,
+				 dom->stream));
+  GFSHIP_HIP (hipMemcpyAsync (h + COMM_MAXRED, C->dred + COMM_MAXRED,
+			      (size_t) C->nranks*n*sizeof (double), hipMemcpyDeviceToHost, dom->stream));
+  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  const double * g = h + COMM_MAXRED;
+  for (int q = 0; q < n; q++) {
+    double v = g[q];
+    for (int rk = 1; rk < C->nranks; rk++) {
+      const double x = g[(size_t) rk*n + q];
+      if (q < nsum) v += x;
+      else if (q < nsum + nmax) v = x > v ? x : v;
+      else v = x < v ? x : v;
+    }
+    if (q < nsum) sums[q] = v;
+    else if (q < nsum + nmax) maxs[q - nsum] = v;
+    else mins[q - nsum - nmax] = v;
+  }
+  return GFSHIP_OK;
+}
+
+void comm_free (gfship_domain * dom)
+{
+  Comm * C = (Comm *) dom->comm;
+  if (!C) return;
+  if (dom->stream) (void) hipStreamSynchronize (dom->stream);
+  if (C->comm && g_rccl.CommDestroy) (void) g_rccl.CommDestroy (C->comm);
+  for (int d = 0; d < 6; d++) {
+    if (C->sbuf[d]) (void) hipFree (C->sbuf[d]);
+    if (C->rbuf[d]) (void) hipFree (C->rbuf[d]);
+  }
+  if (C->dred) (void) hipFree (C->dred);
+  if (C->hred) (void) hipHostFree (C->hred);
+  delete C;
+  dom->comm = nullptr;
+}
+
+} // namespace gfship
+
+using namespace gfship;
+
+extern "C" {
+
+int gfship_comm_unique_id (void * id)
+{
+  GFSHIP_CHECK (id != nullptr, GFSHIP_EINVAL, "null pointer");
+  int r = rccl_load ();
+  if (r) return r;
+  ncclUniqueId u;
+  GFSHIP_NCCL (g_rccl.GetUniqueId (&u));
+  memcpy (id, &u, GFSHIP_UNIQUE_ID_BYTES);
+  return GFSHIP_OK;
+}
+
+int gfship_domain_comm_init (gfship_domain * dom, const void * unique_id, int rank, int nranks,
+			     const int lattice[3])
+{
+  GFSHIP_CHECK (dom && unique_id && lattice, GFSHIP_EINVAL, "null argument");
+  GFSHIP_CHECK (dom->comm == nullptr, GFSHIP_EINVAL, "the domain already has a communicator");
+  GFSHIP_CHECK (nranks >= 1 && rank >= 0 && rank < nranks, GFSHIP_EINVAL, "rank %d of %d", rank,
+		nranks);
+  long nb = 1;
+  for (int c = 0; c < 3; c++) {
+    GFSHIP_CHECK (lattice[c] >= 1 && (c < dom->dim || lattice[c] == 1), GFSHIP_EINVAL,
+		  "lattice[%d] = %d", c, lattice[c]);
+    nb *= lattice[c];
+  }
+  GFSHIP_CHECK (nb == nranks, GFSHIP_EINVAL, "a lattice of %d x %d x %d boxes needs %ld ranks, not %d",
+		lattice[0], lattice[1], lattice[2], nb, nranks);
+  for (int d = 0; d < 2*dom->dim; d++)
+    GFSHIP_CHECK (lattice[d/2] == 1 || dom->side[d] == GFSHIP_SIDE_EXTERNAL, GFSHIP_EINVAL,
+		  "side %d faces another box of the lattice: it must be GFSHIP_SIDE_EXTERNAL", d);
+  int r = rccl_load ();
+  if (r) return r;
+  GFSHIP_HIP (hipSetDevice (dom->device));
+  Comm * C = new Comm;
+  dom->comm = C;
+  C->rank = rank; C->nranks = nranks;
+  for (int c = 0; c < 3; c++) C->b[c] = lattice[c];
+  const int cx = rank % C->b[0], cy = (rank/C->b[0]) % C->b[1], cz = rank/(C->b[0]*C->b[1]);
+  for (int d = 0; d < 6; d++) {
+    int cc[3] = { cx, cy, cz };
+    cc[d/2] += (d & 1) ? -1 : 1;
+    C->peer[d] = comm_rank_of (C, cc[0], cc[1], cc[2]);
+  }
+  ncclUniqueId u;
+  memcpy (&u, unique_id, GFSHIP_UNIQUE_ID_BYTES);
+  ncclResult_t e = g_rccl.CommInitRank (&C->comm, nranks, u, rank);
+  if (e != ncclSuccess) {
+    set_error ("ncclCommInitRank failed: %d (%s)", (int) e, g_rccl.GetErrorString (e));
+    C->comm = nullptr;
+    comm_free (dom);
+    return GFSHIP_EHIP;
+  }
+  const Layout & L = dom->lay[dom->depth];
+  const size_t nface = dom->dim == 3 ? (size_t) L.n*L.n : (size_t) L.n;
+  hipError_t he = hipSuccess;
+  for (int d = 0; d < 2*dom->dim && he == hipSuccess; d++)
+    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL) {
+      he = hipMalloc ((void **) &C->sbuf[d], nface*sizeof (double));
+      if (he == hipSuccess) he = hipMalloc ((void **) &C->rbuf[d], nface*sizeof (double));
+    }
+  if (he == hipSuccess)
+    he = hipMalloc ((void **) &C->dred, (size_t) (nranks + 1)*COMM_MAXRED*sizeof (double));
+  if (he == hipSuccess)
+    he = hipHostMalloc ((void **) &C->hred, (size_t) (nranks + 1)*COMM_MAXRED*sizeof (double),
+			hipHostMallocDefault);
+  if (he != hipSuccess) {
+    int rr = hip_fail (he, "communicator buffers", __FILE__, __LINE__);
+    comm_free (dom);
+    return rr;
+  }
+  return GFSHIP_OK;
+}
+
+int gfship_domain_comm_size (gfship_domain * dom)
+{
+  GFSHIP_CHECK (dom != nullptr, GFSHIP_EINVAL, "null domain");
+  if (!dom->comm) return 0;
+  int n = 0;
+  GFSHIP_NCCL (g_rccl.CommCount (((Comm *) dom->comm)->comm, &n));
+  return n;
+}
+
+int gfship_domain_comm_stats (gfship_domain * dom, unsigned long long * messages,
+			      unsigned long long * bytes)
+{
+  GFSHIP_CHECK (dom && dom->comm, GFSHIP_EINVAL, "the domain has no communicator");
+  if (messages) *messages = ((Comm *) dom->comm)->messages;
+  if (bytes) *bytes = ((Comm *) dom->comm)->bytes;
+  return GFSHIP_OK;
+}
+
+int gfship_domain_comm_destroy (gfship_domain * dom)
+{
+  GFSHIP_CHECK (dom != nullptr, GFSHIP_EINVAL, "null domain");
+  comm_free (dom);
+  return GFSHIP_OK;
+}
+
+} // extern "C"

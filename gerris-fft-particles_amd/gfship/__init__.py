@@ -110,6 +110,11 @@ SIGNATURES = {
     "gfship_sim_download_un": (_i, [_vp, _i, _pd]),
     "gfship_domain_set_exchange": (_i, [_vp, _vp, _vp]),
     "gfship_domain_set_reduce": (_i, [_vp, _vp, _vp]),
+    "gfship_comm_unique_id": (_i, [_vp]),
+    "gfship_domain_comm_init": (_i, [_vp, _vp, _i, _i, _pi]),
+    "gfship_domain_comm_size": (_i, [_vp]),
+    "gfship_domain_comm_stats": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "gfship_domain_comm_destroy": (_i, [_vp]),
     "gfship_halo_pack": (_i, [_vp, _vp, _i, _i, _vp]),
     "gfship_halo_unpack": (_i, [_vp, _vp, _i, _i, _vp]),
     "gfship_halo_pack_sides": (_i, [_vp, _vp, _i, _i, _pi, C.POINTER(_vp)]),
@@ -133,6 +138,16 @@ SIGNATURES = {
     "gfship_particles_set_forces": (_i, [_vp, _i, C.POINTER(_i), _pd]),
     "gfship_particles_download_particulate": (_i, [_vp, _pd, _pd, _pd]),
 }
+
+
+UNIQUE_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (gfship_comm_unique_id): bytes for Domain.comm_init"""
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    _check(lib().gfship_comm_unique_id(buf))
+    return buf.raw
 
 
 def lib():
@@ -223,6 +238,20 @@ class Domain:
         par = MultilevelParams()
         lib().gfship_multilevel_params_init(C.byref(par), self.dim)
         return par
+
+    def comm_init(self, unique_id, rank, nranks, lattice):
+        """in-library RCCL transport: this box is rank `rank` of a periodic lattice of boxes, one
+        per GPU (gfship_domain_comm_init); unique_id = comm_unique_id() of one rank"""
+        buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        _check(lib().gfship_domain_comm_init(self.ptr, buf, rank, nranks, (C.c_int * 3)(*lattice)))
+
+    def comm_size(self):
+        return _check(lib().gfship_domain_comm_size(self.ptr))
+
+    def comm_stats(self):
+        m, b = C.c_ulonglong(), C.c_ulonglong()
+        _check(lib().gfship_domain_comm_stats(self.ptr, C.byref(m), C.byref(b)))
+        return int(m.value), int(b.value)
 
     def set_relax_mode(self, mode):
         _check(lib().gfship_domain_set_relax_mode(self.ptr, mode))

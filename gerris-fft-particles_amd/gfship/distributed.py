@@ -10,8 +10,10 @@ Mirrors the reference's parallel model (src/mpi_boundary.c:78-246, src/domain.c:
     (the reference uses a tag built from the side, :78-83);
   * norms and the CFL time step are all-reduced (sum / max / min).
 
-The same classes drive the CPU oracle (numpy views, gloo) in the CPU tests and libgfship
-(device buffers, RCCL) in bench.py: the transport logic is tested without GPUs.
+bench.py uses the library's own RCCL transport (gfship_domain_comm_init, csrc/transport.hip); the
+hook classes here serve the tests (tests/multibox.py drives the CPU oracle and several device boxes
+of one process with the same BoxGrid / Transport) and the host-staged rehearsal of several ranks on
+one GPU.
 """
 import ctypes as C
 
@@ -297,121 +299,3 @@ class ParticleMigration:
             import traceback
             traceback.print_exc()
             return 1
-
-
-# ---------------------------------------------------------------------------------------------
-# hooks for the CPU oracle (numpy views) -- used by the CPU tests only
-# ---------------------------------------------------------------------------------------------
-
-GO_EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
-GO_REDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
-
-
-def layer_slices(dim, n, side, ghost):
-    """numpy index of the interior layer (ghost=False) or ghost layer (ghost=True) along `side`
-    of an (n+2)^dim array indexed [k, j, i]"""
-    sl = [slice(1, n + 1)] * dim
-    axis = dim - 1 - side // 2
-    if ghost:
-        sl[axis] = 0 if side & 1 else n + 1
-    else:
-        sl[axis] = 1 if side & 1 else n
-    return tuple(sl)
-
-
-class OracleHooks:
-    def __init__(self, oracle_lib, dom_ptr, dim, transport):
-        self.dim, self.tr = dim, transport
-        self._ex = GO_EXCHANGE_FN(self._exchange)
-        self._red = GO_REDUCE_FN(self._reduce)
-        oracle_lib.go_domain_set_hooks.restype = None
-        oracle_lib.go_domain_set_hooks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
-                                                   C.c_void_p, C.c_void_p]
-        oracle_lib.go_domain_set_hooks(dom_ptr, C.cast(self._ex, C.c_void_p), None,
-                                       C.cast(self._red, C.c_void_p), None)
-
-    def _exchange(self, ctx, a, level, kind):
-        torch = self.tr.torch
-        n = 1 << level
-        arr = np.ctypeslib.as_array(a, shape=(n + 2,) * self.dim)
-        sides = _kind_sides(self.tr.grid, kind)
-        if not sides:
-            return
-        nface = n ** (self.dim - 1)
-        snd, rcv = self.tr.buffers("cpu", nface)
-        for s in sides:
-            # tangential order: first tangential axis fastest = C order of the [k, j, i] slice
-            snd[s].copy_(torch.from_numpy(np.ascontiguousarray(
-                arr[layer_slices(self.dim, n, s, False)]).ravel()))
-        recv_sides = [x ^ 1 for x in sides] if kind else sides
-        self.tr.exchange(sides, snd, recv_sides, rcv)
-        for s in recv_sides:
-            sl = layer_slices(self.dim, n, s, True)
-            arr[sl] = rcv[s].numpy().reshape(arr[sl].shape)
-
-    def _reduce(self, ctx, vals, n, op):
-        a = np.ctypeslib.as_array(vals, shape=(n,))
-        a[...] = self.tr.allreduce(a.copy(), op)
-
-
-# ---------------------------------------------------------------------------------------------
-# in-process transport: several boxes of one process (threads), used to exercise the
-# GFSHIP_SIDE_EXTERNAL path of libgfship on a single GPU
-# ---------------------------------------------------------------------------------------------
-
-class LocalFabric:
-    """shared state of the LocalTransports of one process"""
-
-    def __init__(self, nboxes):
-        import threading
-        self.n = nboxes
-        self.barrier = threading.Barrier(nboxes)
-        self.posted = [None] * nboxes
-        self.values = [None] * nboxes
-
-
-class LocalTransport:
-    def __init__(self, grid, rank, fabric, device=None):
-        import torch
-        self.torch = torch
-        self.grid, self.rank, self.fabric = grid, rank, fabric
-        self.device = device if device is not None else torch.device("cpu")
-        self._bufs = {}
-        self.stream = None      # set by DeviceHooks users that want stream synchronisation
-
-    buffers = Transport.buffers
-
-    def exchange(self, send_sides, snd, recv_sides, rcv):
-        f = self.fabric
-        if self.device.type == "cuda":
-            self.torch.cuda.current_stream().synchronize()     # my packs are complete
-        f.posted[self.rank] = {s: snd[s] for s in send_sides}
-        f.barrier.wait()
-        for r in recv_sides:
-            peer = self.grid.neighbour(self.rank, r)
-            rcv[r].copy_(f.posted[peer][r ^ 1])
-        if self.device.type == "cuda":
-            self.torch.cuda.current_stream().synchronize()     # my copies are complete
-        f.barrier.wait()
-
-    def exchange_records(self, out, rs=7):
-        f = self.fabric
-        f.posted[self.rank] = out
-        f.barrier.wait()
-        inc = {}
-        for r in self.grid.external_sides():
-            peer = self.grid.neighbour(self.rank, r)
-            a = f.posted[peer].get(r ^ 1)
-            if a is not None and len(a):
-                inc[r] = np.array(a, copy=True)
-        f.barrier.wait()
-        return inc
-
-    def allreduce(self, vals, op):
-        f = self.fabric
-        f.values[self.rank] = np.array(vals, dtype=np.float64)
-        f.barrier.wait()
-        stack = np.stack(f.values)
-        out = (stack.sum(0), stack.max(0), stack.min(0))[op]
-        f.barrier.wait()
-        return out

@@ -321,9 +321,9 @@ int  gfship_particles_download_particulate (gfship_particles * pl, double * vel,
 
 /* ---- one box per GPU: GfsBoundaryMpi sides (src/mpi_boundary.c:78-246) ----------------------- */
 
-/* The library does not talk to a network itself: for every GFSHIP_SIDE_EXTERNAL side the caller
-   installs the two hooks below (bench.py and the tests implement them over torch.distributed:
-   RCCL on GPUs, gloo in the CPU tests).  Semantics are the reference's parallel run with the
+/* Either the in-library RCCL transport below (gfship_domain_comm_init: what bench.py uses), or two
+   hooks of the caller for every GFSHIP_SIDE_EXTERNAL side (the tests implement them in-process and
+   over gloo).  Semantics are the reference's parallel run with the
    domain parameter `overlap = 0` (src/domain.c:225,1104,1183): plain traversal order, ghost cells
    of MPI sides refreshed by every BC application, i.e. lagged by one sweep exactly like the
    periodic and MPI boundaries of the reference (send src/mpi_boundary.c:89-130, receive
@@ -339,6 +339,28 @@ typedef int (* gfship_exchange_fn) (void * ctx, void * dev_ptr, int level, int k
 typedef int (* gfship_reduce_fn) (void * ctx, double * vals, int n, int op);
 int  gfship_domain_set_exchange (gfship_domain * dom, gfship_exchange_fn fn, void * ctx);
 int  gfship_domain_set_reduce (gfship_domain * dom, gfship_reduce_fn fn, void * ctx);
+/* The same boundary served inside the library over RCCL (xGMI on one node), no hooks: the domain
+   is one GfsBox of a periodic lattice of lattice[0] x lattice[1] x lattice[2] boxes, one box per
+   rank / GPU, rank r at (r % bx, (r / bx) % by, r / (bx by)) (gfs_domain_split, src/domain.c:2576-2599,
+   one box per PE).  Every BC application becomes: pack kernel -> ncclSend / ncclRecv of the packed
+   layers in one group (MPI_Isend / MPI_Recv of sndbuf / rcvbuf, src/mpi_boundary.c:89-222) -> unpack
+   kernel, on the domain's stream; norms and the CFL minimum are reduced over the boxes
+   (src/domain.c:2135-2166,2921) in one collective each.  Sides facing another box must be
+   GFSHIP_SIDE_EXTERNAL; a communicator takes precedence over the hooks above.
+     gfship_comm_unique_id: ncclGetUniqueId (GFSHIP_UNIQUE_ID_BYTES bytes): called by one rank, the
+       bytes are then given to every rank (through the launcher's own channel: a file, a TCP store);
+     gfship_domain_comm_init: ncclCommInitRank on the domain's device, collective over the ranks;
+     gfship_domain_comm_size: ncclCommCount (0 without a communicator);
+     gfship_domain_comm_stats: messages and bytes sent so far (domain->mpi_messages, mpi_size). */
+#define GFSHIP_UNIQUE_ID_BYTES 128
+int  gfship_comm_unique_id (void * id);
+int  gfship_domain_comm_init (gfship_domain * dom, const void * unique_id, int rank, int nranks,
+			      const int lattice[3]);
+int  gfship_domain_comm_size (gfship_domain * dom);
+int  gfship_domain_comm_stats (gfship_domain * dom, unsigned long long * messages,
+			       unsigned long long * bytes);
+int  gfship_domain_comm_destroy (gfship_domain * dom);
+
 /* pack the interior layer adjacent to `side` of a level array into n^(dim-1) contiguous doubles
    (first tangential axis fastest) / unpack such a buffer into the ghost layer of `side`
    (the sndbuf / rcvbuf of src/boundary.c:1240-1258,1333-1347); device pointers, asynchronous on

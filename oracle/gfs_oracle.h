@@ -121,6 +121,7 @@ void       go_bc (GoField * v, GoField * v1, int level);              /* gfs_dom
 void       go_homogeneous_bc (GoField * ov, GoField * v, int level);  /* gfs_domain_homogeneous_bc */
 void       go_domain_set_hooks (GoDomain * dom, GoExchangeFunc ex, void * ex_ctx,
 				GoReduceFunc red, void * red_ctx);
+void       go_domain_set_overlap (GoDomain * dom, int overlap);
 void       go_cell_pos (const GoDomain * dom, int level, int i, int j, int k, double pos[3]);
 
 /* ---- Poisson (go_poisson.c) ---- */

@@ -108,6 +108,13 @@ void go_domain_set_hooks (GoDomain * dom, GoExchangeFunc ex, void * ex_ctx,
   dom->reduce = red; dom->reduce_ctx = red_ctx;
 }
 
+/* the domain parameter `overlap' of a parallel run (domain.c:225,682; default 1 there, 0 here):
+   the sweeps of relax_loop visit the cells along GO_SIDE_EXTERNAL sides first */
+void go_domain_set_overlap (GoDomain * dom, int overlap)
+{
+  dom->mpi_order = overlap != 0;
+}
+
 GoField * go_field_new (GoDomain * dom, int component)
 {
   GoField * f = calloc (1, sizeof (GoField));

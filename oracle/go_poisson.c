@@ -121,18 +121,22 @@ static inline void relax_cell (const GoDomain * dom, unsigned dimension, int lev
   }
 }
 
-void go_relax (GoDomain * dom, unsigned d, int level, double omega,
-	       GoField * u, GoField * rhs, GoField * dia)
+/* one in-place sweep of a level.  mpi_first = 0: gfs_domain_cell_traverse (traversal order).
+   mpi_first = 1: the cell order of gfs_traverse_and_homogeneous_bc in a parallel run with the
+   domain parameter overlap = 1, the reference's default (domain.c:682,1093-1125) */
+static void relax_sweep (GoDomain * dom, unsigned d, int level, double omega,
+			 GoField * u, GoField * rhs, GoField * dia, int mpi_first)
 {
   int n = dom->n[level];
   size_t ncell = dom->dim == 3 ? (size_t) n*n*n : (size_t) n*n;
   double * pu = u->lev[level];
   const double * prhs = rhs->lev[level], * pdia = dia->lev[level];
   const int * order = dom->order[level];
-  if (dom->mpi_order) {
+  if (mpi_first) {
     /* parallel runs (domain.c:1093-1125): cells along GfsBoundaryMpi sides first
-       (update_mpi_boundaries, d = 0..5, each in traversal order, a cell only once),
-       then the remaining cells in traversal order */
+       (update_mpi_boundaries :1024-1049: d = 0..5, ftt_cell_traverse_boundary in traversal
+       order, a cell only once -- GFS_FLAG_USED), then the remaining cells in traversal order
+       (update_other_cell :1016-1022) */
     char * used = calloc (dom->size[level], 1);
     for (int s = 0; s < 2*dom->dim; s++)
       if (dom->side[s] == GO_SIDE_EXTERNAL)
@@ -151,6 +155,13 @@ void go_relax (GoDomain * dom, unsigned d, int level, double omega,
   }
   for (size_t q = 0; q < ncell; q++)
     relax_cell (dom, d, level, omega, pu, prhs, pdia, order[q]);
+}
+
+/* gfs_relax, poisson.c:604-632: gfs_domain_cell_traverse, i.e. always the plain traversal order */
+void go_relax (GoDomain * dom, unsigned d, int level, double omega,
+	       GoField * u, GoField * rhs, GoField * dia)
+{
+  relax_sweep (dom, d, level, omega, u, rhs, dia, 0);
 }
 
 /* Same sweep but in lexicographic order x increasing, y decreasing, z decreasing.
@@ -345,11 +356,14 @@ static void relax_loop (GoDomain * dom, GoField * dp, GoField * u, unsigned dime
 			int level, double omega, GoField * rhs, GoField * dia, unsigned nrelax)
 {
   go_homogeneous_bc (dp, u, level);
+  /* the first nrelax - 1 sweeps go through gfs_traverse_and_homogeneous_bc (MPI-side cells
+     first when the run is parallel with overlap = 1), the last one through a plain
+     gfs_domain_cell_traverse (poisson.c:1080-1086) */
   for (unsigned n = 0; n < nrelax - 1; n++) {
-    go_relax (dom, dimension, level, omega, dp, rhs, dia);
+    relax_sweep (dom, dimension, level, omega, dp, rhs, dia, dom->mpi_order);
     go_homogeneous_bc (dp, u, level);
   }
-  go_relax (dom, dimension, level, omega, dp, rhs, dia);
+  relax_sweep (dom, dimension, level, omega, dp, rhs, dia, 0);
 }
 
 /* gfs_poisson_cycle, poisson.c:1109-1178 (rootlevel = 0 for a single box) */

@@ -127,6 +127,12 @@ class Domain:
         lib().go_multilevel_params_init(C.byref(p), self.dim)
         return p
 
+    def set_overlap(self, overlap):
+        """the domain parameter `overlap' of a parallel run (src/domain.c:225,682)"""
+        f = lib().go_domain_set_overlap
+        f.restype, f.argtypes = None, [C.c_void_p, C.c_int]
+        f(self.ptr, int(overlap))
+
     def centres(self, l=None):
         """cell-centre coordinate arrays (x, y[, z]) of the interior of level l, broadcastable
         against interior() views."""

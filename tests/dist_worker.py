@@ -15,16 +15,34 @@ def main():
     import torch
     import torch.distributed as dist
     from gfship import distributed as D
+    import multibox as M
     from oracle import oracle as O
     from flow_cases import taylor_green_3d
 
     out, level, nsteps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    field = sys.argv[4] if len(sys.argv) > 4 else "period"
+    overlap = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     grid = D.BoxGrid(world, 3)
     sim = O.Sim(3, level, grid.sides(rank))
+    sim.dom.set_overlap(overlap)
     tr = D.Transport(grid, rank)
-    hooks = D.OracleHooks(O.lib(), sim.dom.ptr, 3, tr)   # keep alive
+    hooks = M.OracleHooks(O.lib(), sim.dom.ptr, 3, tr)   # keep alive
+    if field == "lattice":
+        # every box holds ITS part of a flow with one period over the whole lattice
+        X, Y, Z = M.global_centres(grid, rank, 1 << level)
+        for c, a in enumerate(M.lattice_velocity(X, Y, Z)):
+            sim.u[c].interior()[...] = a
+        sim.start()
+        for _ in range(nsteps):
+            sim.step()
+        np.savez(os.path.join(out, "rank%d.npz" % rank),
+                 u=sim.u[0].interior(), v=sim.u[1].interior(), w=sim.u[2].interior(),
+                 p=sim.p.interior(), dt=sim.dt, t=sim.t)
+        del hooks
+        dist.destroy_process_group()
+        return
     # every box holds one period of the Taylor-Green field: the global field is continuous
     x, y, z = sim.dom.centres()
     for c, a in enumerate(taylor_green_3d(x, y, z)):

@@ -1,0 +1,109 @@
+"""Domains of several GfsBoxes on the device against the oracle WITH THE SAME BOX LAYOUT, bit for bit
+(multi-box results depend on the partition: ghosts of GfsBoundaryMpi sides are lagged by one sweep,
+SURVEY.md hard part 2).  Every box holds its own part of a flow with one period over the whole
+lattice, so a swapped peer, a wrong rank_of or a left/right mix-up changes the result.
+
+Several device boxes share the one GPU of the test box (one thread per box, the in-process
+transport of tests/multibox.py behind the exchange / reduce hooks: RCCL refuses two ranks on one
+device).  The library's own RCCL transport (csrc/transport.hip: what bench.py --gpus N uses) is
+exercised on the same GPU through a one-rank communicator whose MPI sides face the box itself:
+ncclSend / ncclRecv to self and a one-rank all-gather must reproduce the periodic box bit for bit.
+"""
+import numpy as np
+import pytest
+
+import gfship
+from gfship import distributed as D
+import multibox as M
+from oracle import oracle as O
+from flow_cases import PERIODIC, oracle_taylor_green
+from test_gpu_timestep import _assert_same_state, _device_sim
+from test_multibox_cpu import run_lattice_flow_threads
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_lattice_flow(nboxes, level, nsteps, overlap):
+    import torch
+    n = 1 << level
+    grid = D.BoxGrid(nboxes, 3)
+    dev = torch.device("cuda", 0)
+
+    def worker(rank, fabric):
+        gd = gfship.Domain(3, level, grid.sides(rank))
+        if overlap:
+            gd.set_overlap(overlap)
+        gs = gfship.Simulation(gd)
+        hooks = D.DeviceHooks(gd, M.LocalTransport(grid, rank, fabric, dev))
+        X, Y, Z = M.global_centres(grid, rank, n)
+        for c, a in enumerate(M.lattice_velocity(X, Y, Z)):
+            b = np.zeros((n + 2,) * 3)
+            b[1:-1, 1:-1, 1:-1] = a
+            gs.u[c].upload(b)
+        gs.start()
+        for _ in range(nsteps):
+            gs.step()
+        gd.synchronize()
+        i3 = (slice(1, -1),) * 3
+        out = dict(u=gs.u[0].download()[i3], v=gs.u[1].download()[i3], w=gs.u[2].download()[i3],
+                   p=gs.p.download()[i3], pmac=gs.pmac.download()[i3],
+                   g=[gs.g[c].download()[i3] for c in range(3)], dt=gs.dt, t=gs.t,
+                   niter=(gs.projection_params.niter, gs.approx_projection_params.niter),
+                   res=gs.approx_projection_params.residual.infty)
+        del hooks
+        gs.destroy()
+        gd.destroy()
+        return out
+
+    return M.run_boxes(nboxes, worker)
+
+
+def _same(dev, ora, what):
+    for rank, (d, o) in enumerate(zip(dev, ora)):
+        for name in ("u", "v", "w", "p", "pmac"):
+            assert np.array_equal(d[name], o[name]), (what, rank, name)
+        for c in range(3):
+            assert np.array_equal(d["g"][c], o["g"][c]), (what, rank, "g", c)
+        assert d["dt"] == o["dt"] and d["t"] == o["t"], (what, rank)
+        assert tuple(d["niter"]) == tuple(o["niter"]), (what, rank)
+        assert d["res"] == o["res"], (what, rank)
+
+
+@pytest.mark.parametrize("nboxes,level", [(2, 5), (8, 4), (8, 5)])
+def test_lattice_flow_device_boxes_equal_oracle_boxes(nboxes, level):
+    """overlap = 0 (plain traversal order in every sweep): 2 x 1 x 1 and 2 x 2 x 2 boxes; at 32^3
+    the sweeps of the three finest levels run on the pipelined tile kernel with MPI ghost streams"""
+    nsteps = 2
+    ora = run_lattice_flow_threads(nboxes, level, nsteps, 0)
+    dev = _device_lattice_flow(nboxes, level, nsteps, 0)
+    _same(dev, ora, "%d boxes" % nboxes)
+    assert not np.array_equal(dev[0]["u"], dev[1]["u"])      # the boxes really differ
+
+
+def test_rccl_transport_on_one_rank_reproduces_the_periodic_box():
+    """gfship_domain_comm_init with one rank: the x and z sides are GfsBoundaryMpi sides whose peer is
+    the box itself, y stays a local periodic side.  pack -> ncclSend/ncclRecv (self) -> unpack and
+    the all-gather reduction, on the real RCCL, must give the periodic single box bit for bit."""
+    level, nsteps = 5, 2
+    osim = oracle_taylor_green(level)
+    osim.u[0].interior()[...] += 0.3          # something crosses the sides
+    side = [gfship.SIDE_EXTERNAL, gfship.SIDE_EXTERNAL, gfship.SIDE_PERIODIC, gfship.SIDE_PERIODIC,
+            gfship.SIDE_EXTERNAL, gfship.SIDE_EXTERNAL]
+    gd, gs = _device_sim(osim, side)
+    gd.comm_init(gfship.comm_unique_id(), 0, 1, (1, 1, 1))
+    assert gd.comm_size() == 1
+    osim.start()
+    gs.start()
+    _assert_same_state(osim, gs, "start")
+    for k in range(nsteps):
+        osim.step()
+        gs.step()
+        _assert_same_state(osim, gs, "step %d" % k)
+    assert gs.approx_projection_params.residual.infty == osim.approx_projection_params.residual.infty
+    for k in ("first", "second"):
+        assert getattr(gs.approx_projection_params.residual, k) == pytest.approx(
+            getattr(osim.approx_projection_params.residual, k), rel=1e-12)
+    msgs, nbytes = gd.comm_stats()
+    assert msgs > 100 and nbytes > msgs * 8
+    gs.destroy()
+    gd.destroy()

@@ -104,6 +104,7 @@ class _MirrorTransport:
 
     def buffers(self, key, nface):
         from gfship import distributed as D
+        import multibox as M
         return D.Transport.buffers(self, key, nface)
 
     def exchange(self, send_sides, snd, recv_sides, rcv):
@@ -125,6 +126,7 @@ def test_particles_migrate_between_two_boxes_on_one_gpu():
     import threading
     import torch
     from gfship import distributed as D
+    import multibox as M
     level, nsteps, npart = 5, 4, 3000
     grid = D.BoxGrid(2, 3)
     pos, ids = lcg_positions(npart)
@@ -139,7 +141,7 @@ def test_particles_migrate_between_two_boxes_on_one_gpu():
     # oracle reference: one box + its mirror image
     osim = O.Sim(3, level, grid.sides(0))
     mt = _MirrorTransport(grid)
-    ohooks = D.OracleHooks(O.lib(), osim.dom.ptr, 3, mt)
+    ohooks = M.OracleHooks(O.lib(), osim.dom.ptr, 3, mt)
     init([osim.u[c].interior() for c in range(3)], *osim.dom.centres())
     opl = O.Particles(osim, pos, ids)
     osim.start()
@@ -155,7 +157,7 @@ def test_particles_migrate_between_two_boxes_on_one_gpu():
         osim.step()
     assert moved > 50
 
-    fabric = D.LocalFabric(2)
+    fabric = M.LocalFabric(2)
     dev = torch.device("cuda", 0)
     results, errors = [None, None], []
     u0 = [osim.dom.field() for _ in range(3)]
@@ -165,7 +167,7 @@ def test_particles_migrate_between_two_boxes_on_one_gpu():
         try:
             gd = gfship.Domain(3, level, grid.sides(rank))
             gs = gfship.Simulation(gd)
-            tr = D.LocalTransport(grid, rank, fabric, dev)
+            tr = M.LocalTransport(grid, rank, fabric, dev)
             hooks = D.DeviceHooks(gd, tr)
             for c in range(3):
                 gs.u[c].upload(u0[c].leaf())
@@ -336,6 +338,7 @@ def test_particulates_migrate_between_two_boxes_on_one_gpu():
     import threading
     import torch
     from gfship import distributed as D
+    import multibox as M
     level, nsteps, npart, nu = 4, 5, 1200, 1e-2
     grid = D.BoxGrid(2, 3)
     pos, ids, vel, mass, vol = _particulate_case(npart, 3, 21)
@@ -352,7 +355,7 @@ def test_particulates_migrate_between_two_boxes_on_one_gpu():
     for c in range(3):
         osim.set_viscosity(c, nu)
     mt = _MirrorTransport(grid)
-    ohooks = D.OracleHooks(O.lib(), osim.dom.ptr, 3, mt)
+    ohooks = M.OracleHooks(O.lib(), osim.dom.ptr, 3, mt)
     init([osim.u[c].interior() for c in range(3)], *osim.dom.centres())
     opl = O.Particles(osim, pos, ids)
     opl.set_particulate(vel, mass, vol)
@@ -371,7 +374,7 @@ def test_particulates_migrate_between_two_boxes_on_one_gpu():
         osim.step()
     assert moved > 30
 
-    fabric = D.LocalFabric(2)
+    fabric = M.LocalFabric(2)
     dev = torch.device("cuda", 0)
     results, errors = [None, None], []
     u0 = [osim.dom.field() for _ in range(3)]
@@ -383,7 +386,7 @@ def test_particulates_migrate_between_two_boxes_on_one_gpu():
             gs = gfship.Simulation(gd)
             for c in range(3):
                 gs.set_viscosity(c, nu)
-            tr = D.LocalTransport(grid, rank, fabric, dev)
+            tr = M.LocalTransport(grid, rank, fabric, dev)
             hooks = D.DeviceHooks(gd, tr)
             for c in range(3):
                 gs.u[c].upload(u0[c].leaf())

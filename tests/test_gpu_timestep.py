@@ -202,10 +202,11 @@ def test_two_boxes_with_mpi_sides_on_one_gpu_reproduce_single_box():
     import threading
     import torch
     from gfship import distributed as D
+    import multibox as M
     level, nsteps = 5, 2
     osim = oracle_taylor_green(level)
     grid = D.BoxGrid(2, 3)
-    fabric = D.LocalFabric(2)
+    fabric = M.LocalFabric(2)
     dev = torch.device("cuda", 0)
     sims, errors = [None, None], []
 
@@ -213,7 +214,7 @@ def test_two_boxes_with_mpi_sides_on_one_gpu_reproduce_single_box():
         try:
             gd = gfship.Domain(3, level, grid.sides(rank))
             gs = gfship.Simulation(gd)
-            hooks = D.DeviceHooks(gd, D.LocalTransport(grid, rank, fabric, dev))
+            hooks = D.DeviceHooks(gd, M.LocalTransport(grid, rank, fabric, dev))
             for c in range(3):
                 gs.u[c].upload(osim.u[c].leaf())
             gs.start()

@@ -8,18 +8,20 @@ sys.path.insert(0, os.path.join(ROOT, "gerris-fft-particles_amd"))
 import torch
 import gfship
 from gfship import distributed as D
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import multibox as M
 
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 grid = D.BoxGrid(8, 3)
 
 
-class NullTransport(D.LocalTransport):
+class NullTransport(M.LocalTransport):
     def exchange(self, send_sides, snd, recv_sides, rcv):
         pass
 
 
 dom = gfship.Domain(3, level, grid.sides(0))
-tr = NullTransport(grid, 0, D.LocalFabric(1), torch.device("cuda", 0))
+tr = NullTransport(grid, 0, M.LocalFabric(1), torch.device("cuda", 0))
 hooks = D.DeviceHooks(dom, tr)
 v = dom.variable()
 for lev in (level, 4, 0):
