@@ -22,9 +22,13 @@ echo "built $OUT/libgfship.so"
 BIN="$HERE/../bin"
 mkdir -p "$BIN"
 CXX="${CXX:-g++}"
-if [ ! -f "$BIN/gfship2D" ] || [ "$HERE/host/gfsrun.cpp" -nt "$BIN/gfship2D" ] || [ "$HERE/host/gfs_text.hpp" -nt "$BIN/gfship2D" ] || [ "$HERE/host/gfs_function.hpp" -nt "$BIN/gfship2D" ] || [ "$HERE/../../include/gfship.h" -nt "$BIN/gfship2D" ]; then
+if [ ! -f "$BIN/gfship2D" ] || [ "$HERE/host/gfsrun.cpp" -nt "$BIN/gfship2D" ] || [ "$HERE/host/gfs_text.hpp" -nt "$BIN/gfship2D" ] || [ "$HERE/host/gfs_snapshot.hpp" -nt "$BIN/gfship2D" ] || [ "$HERE/host/gfs_function.hpp" -nt "$BIN/gfship2D" ] || [ "$HERE/../../include/gfship.h" -nt "$BIN/gfship2D" ]; then
   "$CXX" -O2 -std=c++17 -Wall -I"$HERE/../../include" -I"$HERE/host" "$HERE/host/gfsrun.cpp" \
     -o "$BIN/gfship2D" -L"$OUT" -lgfship -ldl -Wl,-rpath,'$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
   cp "$BIN/gfship2D" "$BIN/gfship3D"
 fi
-echo "built $BIN/gfship2D $BIN/gfship3D"
+if [ ! -f "$BIN/gfshipcompare2D" ] || [ "$HERE/host/gfscompare.cpp" -nt "$BIN/gfshipcompare2D" ] || [ "$HERE/host/gfs_snapshot.hpp" -nt "$BIN/gfshipcompare2D" ] || [ "$HERE/host/gfs_text.hpp" -nt "$BIN/gfshipcompare2D" ]; then
+  "$CXX" -O2 -std=c++17 -Wall -I"$HERE/host" "$HERE/host/gfscompare.cpp" -o "$BIN/gfshipcompare2D"
+  cp "$BIN/gfshipcompare2D" "$BIN/gfshipcompare3D"
+fi
+echo "built $BIN/gfship2D $BIN/gfship3D $BIN/gfshipcompare2D $BIN/gfshipcompare3D"

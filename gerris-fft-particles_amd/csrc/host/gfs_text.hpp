@@ -39,6 +39,7 @@ public:
 
   bool eof () { skip_space (true); return p_ >= s_.size (); }
   int line () const { return line_; }
+  size_t offset () const { return p_; }        // position in the text (for callers that cut it)
 
   [[noreturn]] void fail (const std::string & msg) const {
     throw ParseError (name_ + ":" + std::to_string (line_) + ": " + msg);

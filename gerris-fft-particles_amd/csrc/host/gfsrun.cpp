@@ -32,6 +32,7 @@
 #include <sstream>
 #include "gfship.h"
 #include "gfs_text.hpp"
+#include "gfs_snapshot.hpp"
 #include "gfs_function.hpp"
 
 using namespace gfs;
@@ -128,6 +129,12 @@ struct Run {
   std::vector<std::unique_ptr<ParticleSpec>> plists;
   std::vector<std::pair<gfship_init_spectra_params, std::vector<std::string>>> init_spectra;
   std::string particles_out;                     // --particles FILE: the lists at the end of the run
+  // the text of the file, kept to write it back (GfsOutputSimulation): objects of the body, the
+  // parameters of the GfsBox, the edges; and the cell data the file came with (a snapshot)
+  std::vector<std::pair<std::string, std::string>> object_texts;   // class, text
+  std::string box_text, edges_text;
+  int nedges = 0;
+  gfs::SimulationFile snapshot;
   FunctionSet functions;
   gfship_domain * dom = nullptr;
   gfship_sim * sim = nullptr;
@@ -414,6 +421,58 @@ void add_event (Run & R, Event * e, const std::string & cls, int line)
   e->cls = cls;
   e->line = line;
   R.events.emplace_back (e);
+}
+
+// gfs_simulation_write (src/simulation.c:1343-1361): the file this run was read from, with the
+// current GfsTime, without the objects that have done their work (GfsInit, GfsInitSpectra: events
+// with t >= end are not written, simulation_write :125-137; GfsRefine: the tree follows, :113-123),
+// and the cell data of the variables `list' between the braces of the GfsBox (gfs_box_write
+// src/boundary.c:1819-1851).  The time is written with 17 significant digits (the reference prints
+// %g, gfs_time_write src/simulation.c:1642-1660, and so cannot restart at exactly the same t).
+void write_simulation (Run & R, FILE * fp, const std::vector<int> & list, bool binary)
+{
+  fprintf (fp, "# Gerris Flow Solver %dD version 1.3.2 (gfship)\n", R.dim);
+  fprintf (fp, "1 %d GfsSimulation GfsBox GfsGEdge { version = 120812 variables = ", R.nedges);
+  for (size_t q = 0; q < list.size (); q++)
+    fprintf (fp, "%s%s", q ? "," : "", R.vars[list[q]].name.c_str ());
+  fprintf (fp, " %s} {\n", binary ? "binary = 1 " : "");
+  fprintf (fp, "  GfsTime { i = %u t = %.17g ", R.i, R.t);
+  if (R.end < DBL_MAX) fprintf (fp, "end = %.17g ", R.end);
+  if (R.iend < INT_MAX) fprintf (fp, "iend = %u ", R.iend);
+  if (R.dtmax < DBL_MAX) fprintf (fp, "dtmax = %.17g ", R.dtmax);
+  fputs ("}\n", fp);
+  for (auto & ot : R.object_texts) {
+    const std::string & c = ot.first;
+    if (c == "Time" || c == "Refine" || c == "Init" || c == "InitSpectra") continue;
+    fprintf (fp, "  %s\n", ot.second.c_str ());
+  }
+  fputs ("}\n", fp);
+  // the cell data: device variables straight from the device image; host-only variables (Div of a
+  // GfsPoisson file ...) go through a temporary device variable
+  std::vector<gfship_field> f, tmp;
+  for (int q : list) {
+    if (R.vars[q].dev >= 0) f.push_back (R.vars[q].dev);
+    else {
+      gfship_field t = gfship_field_alloc (R.dom, -1);
+      CHECK (t);
+      CHECK (gfship_field_upload (R.dom, t, R.level, host_of (R, q).data ()));
+      f.push_back (t);
+      tmp.push_back (t);
+    }
+  }
+  std::string image (gfship_snapshot_tree_bytes (R.dom, (int) f.size ()), '\0');
+  CHECK (gfship_snapshot_tree_write (R.dom, (int) f.size (), f.data (), &image[0], image.size ()));
+  for (gfship_field t : tmp) gfship_field_free (R.dom, t);
+  size_t leaves = 1;
+  for (int l = 0; l < R.level; l++) leaves *= R.dim == 3 ? 8 : 4;
+  fprintf (fp, "GfsBox { id = 1 pid = -1 size = %zu x = 0 y = 0 z = 0%s%s } {\n", leaves,
+	   R.box_text.empty () ? "" : " ", R.box_text.c_str ());
+  if (binary)
+    fwrite (image.data (), 1, image.size (), fp);
+  else
+    gfs::tree_write_text (fp, image, f.size ());
+  fputs ("}\n", fp);
+  fputs (R.edges_text.c_str (), fp);
 }
 
 void parse_object (Run & R, Reader & r)
@@ -911,28 +970,59 @@ void parse_object (Run & R, Reader & r)
     add_event (R, e, cls, line);
   }
   else if (cls == "OutputSimulation") {
-    // text format of gfs_output_simulation_event (format = text), src/output.c:1330-1350
+    // gfs_output_simulation (src/output.c:1354-1470, parameters :1480-1555): format = gfs (the
+    // default: a simulation file with the cell data, text or `binary = 1') or text (columns)
     Event * e = new Event;
     read_event_params (r, *e);
     Output * o = read_output (R, r);
-    if (r.peek (false) == '{') r.braces ();
+    std::string format = "gfs", variables;
+    bool binary = false;
+    if (r.peek (false) == '{') {
+      int l0 = r.line ();
+      Reader b (r.braces (), "simulation file", l0);
+      while (!b.eof ()) {
+	std::string k = b.word ();
+	b.expect ('=');
+	std::string v = b.word ();
+	if (k == "format") format = v;
+	else if (k == "binary") binary = atoi (v.c_str ()) != 0;
+	else if (k == "variables") variables = v;
+	else if (k == "depth" || k == "solid" || k == "precision") ;
+	else b.fail ("unknown GfsOutputSimulation keyword `" + k + "'");
+      }
+      if (format != "gfs" && format != "text")
+	r.fail ("GfsOutputSimulation: format `" + format + "' is not produced (gfs and text are)");
+    }
     Run * pr = &R;
-    e->action = [pr, o] () {
+    e->action = [pr, o, format, binary, variables] () {
       Run & R = *pr;
       FILE * fp = o->open ();
-      fputs ("# 1:x 2:y 3:z", fp);
-      int nv = 4;
       std::vector<int> list;
-      for (size_t q = 0; q < R.vars.size (); q++)
-	if (!R.vars[q].derive) { fprintf (fp, " %d:%s", nv++, R.vars[q].name.c_str ()); list.push_back ((int) q); }
-      fputc ('\n', fp);
-      for_each_cell (R, [&] (int i, int j, int k, size_t c) {
-	double p[3];
-	cell_pos (R, i, j, k, p);
-	fprintf (fp, "%g %g %g", p[0], p[1], p[2]);
-	for (int q : list) fprintf (fp, " %g", host_of (R, q)[c]);
+      if (variables.empty ()) {
+	for (size_t q = 0; q < R.vars.size (); q++)
+	  if (!R.vars[q].derive) list.push_back ((int) q);
+      }
+      else
+	for (const std::string & nm : gfs::split_commas (variables)) {
+	  int q = R.var_index (nm);
+	  if (q < 0) { fprintf (stderr, "gfship: GfsOutputSimulation: unknown variable `%s'\n", nm.c_str ()); exit (1); }
+	  list.push_back (q);
+	}
+      if (format == "text") {
+	fputs ("# 1:x 2:y 3:z", fp);
+	int nv = 4;
+	for (int q : list) fprintf (fp, " %d:%s", nv++, R.vars[q].name.c_str ());
 	fputc ('\n', fp);
-      });
+	for_each_cell (R, [&] (int i, int j, int k, size_t c) {
+	  double p[3];
+	  cell_pos (R, i, j, k, p);
+	  fprintf (fp, "%g %g %g", p[0], p[1], p[2]);
+	  for (int q : list) fprintf (fp, " %g", host_of (R, q)[c]);
+	  fputc ('\n', fp);
+	});
+      }
+      else
+	write_simulation (R, fp, list, binary);
       o->close ();
     };
     add_event (R, e, cls, line);
@@ -961,8 +1051,11 @@ void parse_box (Run & R, Reader & r)
   std::string cls = strip_gfs (r.word ());
   if (cls != "Box") r.fail ("expecting GfsBox");
   int l0 = r.line ();
-  Reader b (r.braces (), "simulation file", l0);
+  const std::string raw = r.braces ();
+  Reader b (raw, "simulation file", l0);
   while (!b.eof ()) {
+    b.peek ();
+    const size_t o0 = b.offset ();
     std::string k = b.word ();
     b.expect ('=');
     int d = side_from_name (k);
@@ -974,20 +1067,25 @@ void parse_box (Run & R, Reader & r)
     std::string bcls = strip_gfs (b.word ());
     if (bcls != "Boundary") b.fail ("unsupported boundary class `" + bcls + "'");
     R.side[d] = GFSHIP_SIDE_BOUNDARY;
-    if (b.peek (false) != '{') continue;
-    int l1 = b.line ();
-    Reader c (b.braces (), "simulation file", l1);
-    while (!c.eof ()) {
-      // gfs_bc_value_read, src/boundary.c:130-180
-      std::string bc = strip_gfs (c.word ());
-      BcSpec spec;
-      if (bc == "BcDirichlet") spec.kind = GFSHIP_BC_DIRICHLET;
-      else if (bc == "BcNeumann") spec.kind = GFSHIP_BC_NEUMANN;
-      else c.fail ("unsupported boundary condition `" + bc + "'");
-      std::string v = c.word ();
-      spec.val = R.functions.add (c.function (), c.line ());
-      R.bc[d][v] = spec;
+    if (b.peek (false) == '{') {
+      int l1 = b.line ();
+      Reader c (b.braces (), "simulation file", l1);
+      while (!c.eof ()) {
+	// gfs_bc_value_read, src/boundary.c:130-180
+	std::string bc = strip_gfs (c.word ());
+	BcSpec spec;
+	if (bc == "BcDirichlet") spec.kind = GFSHIP_BC_DIRICHLET;
+	else if (bc == "BcNeumann") spec.kind = GFSHIP_BC_NEUMANN;
+	else c.fail ("unsupported boundary condition `" + bc + "'");
+	std::string v = c.word ();
+	spec.val = R.functions.add (c.function (), c.line ());
+	R.bc[d][v] = spec;
+      }
     }
+    // kept for GfsOutputSimulation: the boundaries as the file has them (new lines folded)
+    std::string piece = raw.substr (o0, b.offset () - o0);
+    for (char & ch : piece) if (ch == '\n') ch = ' ';
+    R.box_text += (R.box_text.empty () ? "" : " ") + piece;
   }
 }
 
@@ -1035,17 +1133,26 @@ void parse_file (Run & R, const std::string & text, const std::string & name)
   if (R.sim_class == "Poisson") R.get_or_add_variable ("Div");
   {
     int l0 = r.line ();
-    Reader body (r.braces (), name, l0);
-    while (!body.eof ())
+    const std::string body_text = r.braces ();
+    Reader body (body_text, name, l0);
+    while (!body.eof ()) {
+      const size_t o0 = body.offset ();      /* eof () has skipped the space in front */
       parse_object (R, body);
+      std::string text = body_text.substr (o0, body.offset () - o0);
+      std::string cls = strip_gfs (Reader (text, name).word ());
+      R.object_texts.emplace_back (cls, text);
+    }
   }
   parse_box (R, r);
+  R.nedges = nedges;
   for (int e = 0; e < nedges; e++) {
     int a = (int) r.number (), b = (int) r.number ();
-    int d = side_from_name (r.word ());
+    std::string dn = r.word ();
+    int d = side_from_name (dn);
     if (a != 1 || b != 1 || d < 0 || d >= 2*R.dim || (d & 1))
       r.fail ("expecting a periodic self edge `1 1 right|top|front'");
     R.side[d] = R.side[d + 1] = GFSHIP_SIDE_PERIODIC;
+    R.edges_text += "1 1 " + dn + "\n";
   }
 }
 
@@ -1308,6 +1415,37 @@ int run (Run & R)
     }
     CHECK (gfship_init_spectra (R.dom, &p, v));
   }
+  if (R.snapshot.has_tree) {
+    // the cell data the file came with (gfs_box_read -> ftt_cell_read_binary / ftt_cell_read +
+    // gfs_cell_read*, src/boundary.c:1925-1944): all levels of the variables of `variables = ...'
+    if (R.snapshot.depth != R.level) {
+      fprintf (stderr, "gfship: the cell data of the file is refined to level %d\n", R.snapshot.depth);
+      return 1;
+    }
+    std::vector<gfship_field> f, tmp;
+    std::vector<int> host_only;
+    for (const std::string & nm : R.snapshot.variables) {
+      int q = R.get_or_add_variable (nm);
+      if (R.vars[q].dev >= 0) { f.push_back (R.vars[q].dev); R.vars[q].host_time = -1.; host_only.push_back (-1); }
+      else {
+	gfship_field t = gfship_field_alloc (R.dom, -1);
+	CHECK (t);
+	f.push_back (t); tmp.push_back (t); host_only.push_back (q);
+      }
+    }
+    CHECK (gfship_snapshot_tree_read (R.dom, (int) f.size (), f.data (), R.snapshot.tree.data (),
+				      R.snapshot.tree.size ()));
+    for (size_t k = 0; k < f.size (); k++)
+      if (host_only[k] >= 0) {
+	Variable & V = R.vars[host_only[k]];
+	V.host.assign (R.total (), 0.);
+	CHECK (gfship_field_download (R.dom, f[k], R.level, V.host.data ()));
+      }
+    for (gfship_field t : tmp) gfship_field_free (R.dom, t);
+    R.snapshot.tree.clear ();
+    if (R.sim_class == "Simulation")
+      CHECK (gfship_sim_restart (R.sim, R.t, R.i));
+  }
   events_init (R);
 
   if (R.sim_class == "Poisson") {
@@ -1515,7 +1653,15 @@ int main (int argc, char ** argv)
   std::stringstream ss;
   ss << in.rdbuf ();
   try {
-    parse_file (R, substitute (ss.str (), defs), file);
+    // a file with cell data (a snapshot written by GfsOutputSimulation): the data is cut out
+    // before the text is parsed
+    R.snapshot = gfs::split_simulation_file (ss.str (), file, R.dim);
+    parse_file (R, substitute (R.snapshot.text, defs), file);
+    R.snapshot.text.clear ();
+    for (const std::string & nm : R.snapshot.variables)
+      R.get_or_add_variable (nm);        /* gfs_domain_add_variable of domain_read, src/domain.c:283-293 */
+    if (R.snapshot.has_tree && R.level == 0 && R.snapshot.depth > 0)
+      R.level = R.snapshot.depth;        /* no GfsRefine in a file that carries its tree */
     return check_only ? check (R) : run (R);
   }
   catch (const ParseError & e) {

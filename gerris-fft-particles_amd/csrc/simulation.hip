@@ -527,6 +527,28 @@ int gfship_sim_start (gfship_sim * s)
     TRY (set_timestep (s, true));
     TRY (advance_tracers (s, s->advection_params.dt/2.));
   }
+  else {
+    /* a simulation read back from a snapshot (time.i > 0): gfs_update_gradients
+       (src/simulation.c:474-475, src/timestep.c:306-322) rebuilds the centred pressure gradient g
+       from P -- gfs_correct_normal_velocities with dt = 0 leaves the face velocities alone and
+       accumulates the same face differences as the approximate projection that ended the step the
+       snapshot was taken after, then gfs_scale_gradients -- so the restarted run continues bit for
+       bit */
+    double * gp[3];
+    ptrs3 (s, s->g, gp);
+    TRY (gfship_poisson_coefficients (s->dom));
+    TRY (launch_centered_gradient (s->dom, leaf (s, s->p), gp));
+    for (int c = 0; c < s->dom->dim; c++)
+      TRY (bc_leaf (s, s->g[c]));
+  }
+  return GFSHIP_OK;
+}
+
+int gfship_sim_restart (gfship_sim * s, double t, unsigned i)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  s->t = s->tnext = t;
+  s->i = i;
   return GFSHIP_OK;
 }
 

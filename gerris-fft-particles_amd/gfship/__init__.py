@@ -110,6 +110,10 @@ SIGNATURES = {
     "gfship_sim_download_un": (_i, [_vp, _i, _pd]),
     "gfship_domain_set_exchange": (_i, [_vp, _vp, _vp]),
     "gfship_domain_set_reduce": (_i, [_vp, _vp, _vp]),
+    "gfship_sim_restart": (_i, [_vp, _d, _u]),
+    "gfship_snapshot_tree_bytes": (C.c_size_t, [_vp, _i]),
+    "gfship_snapshot_tree_write": (_i, [_vp, _i, _pi, _vp, C.c_size_t]),
+    "gfship_snapshot_tree_read": (_i, [_vp, _i, _pi, _vp, C.c_size_t]),
     "gfship_comm_unique_id": (_i, [_vp]),
     "gfship_domain_comm_init": (_i, [_vp, _vp, _i, _i, _pi]),
     "gfship_domain_comm_size": (_i, [_vp]),
@@ -252,6 +256,21 @@ class Domain:
         m, b = C.c_ulonglong(), C.c_ulonglong()
         _check(lib().gfship_domain_comm_stats(self.ptr, C.byref(m), C.byref(b)))
         return int(m.value), int(b.value)
+
+    def snapshot_tree(self, variables):
+        """the binary cell data of a GfsBox (gfship_snapshot_tree_write) as bytes"""
+        n = len(variables)
+        h = (C.c_int * n)(*[v.h for v in variables])
+        size = lib().gfship_snapshot_tree_bytes(self.ptr, n)
+        buf = C.create_string_buffer(size)
+        _check(lib().gfship_snapshot_tree_write(self.ptr, n, h, buf, size))
+        return buf.raw
+
+    def snapshot_tree_read(self, variables, data):
+        n = len(variables)
+        h = (C.c_int * n)(*[v.h for v in variables])
+        buf = C.create_string_buffer(bytes(data), len(data))
+        _check(lib().gfship_snapshot_tree_read(self.ptr, n, h, buf, len(data)))
 
     def set_relax_mode(self, mode):
         _check(lib().gfship_domain_set_relax_mode(self.ptr, mode))
@@ -439,6 +458,9 @@ class Simulation:
     @property
     def dt(self):
         return self.advection_params.dt
+
+    def restart(self, t, i):
+        _check(lib().gfship_sim_restart(self.ptr, t, i))
 
     def start(self):
         _check(lib().gfship_sim_start(self.ptr))

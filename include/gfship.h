@@ -200,6 +200,11 @@ gfship_multilevel_params * gfship_sim_diffusion_params (gfship_sim * sim, int c)
 /* simulation_run before its loop (src/simulation.c:458-476): BCs, first time step, initial
    approximate projection */
 int  gfship_sim_start (gfship_sim * sim);
+/* GfsTime { i = .. t = .. } of a simulation file that is a snapshot of a running simulation
+   (gfs_time_read, src/simulation.c:1687-1725): call it before gfship_sim_start, which then takes
+   simulation_run's `time.i > 0' branch (no initial projection; gfs_update_gradients,
+   src/simulation.c:474-475) */
+int  gfship_sim_restart (gfship_sim * sim, double t, unsigned i);
 /* one iteration of the simulation_run loop body (src/simulation.c:479-548) */
 int  gfship_sim_step (gfship_sim * sim);
 /* loop body of advection_run (GfsAdvection, src/simulation.c:2078-2111) with given MAC velocities
@@ -229,6 +234,27 @@ int  gfship_sim_download_un (gfship_sim * sim, int c, double * host);
    the point is outside the domain (out[q] is then 0) */
 int  gfship_field_interpolate (gfship_domain * dom, gfship_field v, int np, const double * pos,
 			       double * out, unsigned char * inside);
+
+/* ---- snapshots: the cell data of a binary simulation file (GfsOutputSimulation { binary = 1 }) ---- */
+
+/* What gfs_box_write / gfs_box_read put between the braces of the GfsBox when the domain parameter
+   `binary = 1' is set (src/boundary.c:1819-1851,1853-2014): ftt_cell_write_binary
+   (src/ftt.c:1771-1799) -- the tree in pre-order, children 0..7 in the order of src/ftt.c:301-316, per
+   cell `guint flags' = child id | FTT_FLAG_LEAF on the deepest level -- with gfs_cell_write_binary
+   (src/domain.c:3176-3207) as the per-cell function: a double -1. (no solid fractions), then one
+   double per variable of `variables = ...'.  Every level of every variable is written / read (the
+   non-leaf values are whatever gfs_cell_coarse_init left); ghost cells are not part of the file
+   (apply the BCs after reading, as gfs_simulation_init does).
+     gfship_snapshot_tree_bytes: size of that byte image for nvars variables;
+     gfship_snapshot_tree_write: builds it on the device and copies it into host_buf;
+     gfship_snapshot_tree_read: takes it apart into the variables; fails if the child ids, the leaf
+       flags (the tree must be the uniform tree of this domain) or the -1. markers do not match
+       (cell_read_binary src/ftt.c:1915-1945, gfs_cell_read_binary src/domain.c:3219-3270). */
+size_t gfship_snapshot_tree_bytes (gfship_domain * dom, int nvars);
+int  gfship_snapshot_tree_write (gfship_domain * dom, int nvars, const gfship_field * vars,
+				 void * host_buf, size_t bytes);
+int  gfship_snapshot_tree_read (gfship_domain * dom, int nvars, const gfship_field * vars,
+				const void * host_buf, size_t bytes);
 
 /* ---- energy spectra (modules/fft.c) ------------------------------------------------------------ */
 

@@ -122,6 +122,8 @@ void       go_homogeneous_bc (GoField * ov, GoField * v, int level);  /* gfs_dom
 void       go_domain_set_hooks (GoDomain * dom, GoExchangeFunc ex, void * ex_ctx,
 				GoReduceFunc red, void * red_ctx);
 void       go_domain_set_overlap (GoDomain * dom, int overlap);
+size_t     go_snapshot_tree_bytes (const GoDomain * dom, int nvars);
+size_t     go_snapshot_tree_write (const GoDomain * dom, int nvars, GoField ** f, unsigned char * buf);
 void       go_cell_pos (const GoDomain * dom, int level, int i, int j, int k, double pos[3]);
 
 /* ---- Poisson (go_poisson.c) ---- */

@@ -232,3 +232,47 @@ void go_homogeneous_bc (GoField * ov, GoField * v, int level)
 {
   apply_bc (v, ov, level, 1);
 }
+
+/* ---- binary cell data of a simulation file ---------------------------------------------------
+ * ftt_cell_write_binary (ftt.c:1771-1799) with gfs_cell_write_binary (domain.c:3176-3207) as the
+ * per-cell function, on the implicit uniform tree: pre-order, children n = 0..7 at
+ * (x, y, z) = coords[n] (x:+ for bit 0, y:- for bit 1, z:- for bit 2, ftt.c:301-316); per cell
+ * `guint flags' (child id | FTT_FLAG_LEAF = 1 << 4 on the deepest level), a double -1. (no
+ * solid), one double per variable. */
+static unsigned char * snapshot_cell (const GoDomain * dom, int nvars, GoField ** f,
+				      unsigned char * p, int level, int i, int j, int k,
+				      unsigned id)
+{
+  unsigned flags = id | (level == dom->depth ? 16u : 0u);
+  memcpy (p, &flags, sizeof (unsigned)); p += sizeof (unsigned);
+  double a = -1.;
+  memcpy (p, &a, sizeof (double)); p += sizeof (double);
+  size_t c = go_index (dom, level, i, j, dom->dim == 3 ? k : 0);
+  for (int v = 0; v < nvars; v++) {
+    a = f[v]->lev[level][c];
+    memcpy (p, &a, sizeof (double)); p += sizeof (double);
+  }
+  if (level < dom->depth) {
+    int nc = dom->dim == 3 ? 8 : 4;
+    for (int n = 0; n < nc; n++) {
+      /* child n of cell (i,j,k): 1-based coordinates on the finer level */
+      int ci = 2*i - 1 + (n & 1);
+      int cj = 2*j - ((n >> 1) & 1);
+      int ck = dom->dim == 3 ? 2*k - ((n >> 2) & 1) : 0;
+      p = snapshot_cell (dom, nvars, f, p, level + 1, ci, cj, ck, (unsigned) n);
+    }
+  }
+  return p;
+}
+
+size_t go_snapshot_tree_bytes (const GoDomain * dom, int nvars)
+{
+  size_t cells = 0, c = 1;
+  for (int l = 0; l <= dom->depth; l++) { cells += c; c *= dom->dim == 3 ? 8 : 4; }
+  return cells*(sizeof (unsigned) + sizeof (double)*(1 + (size_t) nvars));
+}
+
+size_t go_snapshot_tree_write (const GoDomain * dom, int nvars, GoField ** f, unsigned char * buf)
+{
+  return (size_t) (snapshot_cell (dom, nvars, f, buf, 0, 1, 1, dom->dim == 3 ? 1 : 0, 0) - buf);
+}

@@ -47,6 +47,7 @@ double  go_domain_cfl (GoSim * s);
 void    go_set_timestep (GoSim * s);
 void    go_coarse_init (GoSim * s);
 void    go_sim_start (GoSim * s);
+void    go_sim_restart (GoSim * s, double t, unsigned i);
 void    go_sim_step (GoSim * s);
 void    go_advection_step (GoSim * s);
 void    go_divergence (GoSim * s, GoField * out);

@@ -728,6 +728,24 @@ void go_sim_start (GoSim * s)
     go_set_timestep (s);
     advance_tracers (s, s->advection_params.dt/2.);
   }
+  else {
+    /* gfs_update_gradients, timestep.c:306-322 (simulation.c:474-475: a simulation read back
+       from a snapshot, time.i > 0) */
+    GoField ** g = s->g;
+    LEAF_LOOP (s, cell)                         /* gfs_reset_gradients */
+      for (int c = 0; c < dim; c++)
+	g[c]->lev[L][cell] = 0.;
+    go_poisson_coefficients (s->dom);           /* gfs_poisson_coefficients (alpha = NULL) */
+    correct_normal_velocities (s, s->p, g, 0.); /* dt = 0.: un -= dp*0., g += dp */
+    scale_gradients (s, g);
+  }
+}
+
+/* GfsTime { i = .. t = .. } of a snapshot, gfs_time_read simulation.c:1687-1725 */
+void go_sim_restart (GoSim * s, double t, unsigned i)
+{
+  s->t = s->tnext = t;
+  s->i = i;
 }
 
 /* one iteration of the while loop, simulation.c:479-548 (events are the caller's business) */

@@ -127,6 +127,19 @@ class Domain:
         lib().go_multilevel_params_init(C.byref(p), self.dim)
         return p
 
+    def snapshot_tree(self, fields):
+        """ftt_cell_write_binary + gfs_cell_write_binary of the box (bytes)"""
+        L = lib()
+        L.go_snapshot_tree_bytes.restype, L.go_snapshot_tree_bytes.argtypes = C.c_size_t, [C.c_void_p, C.c_int]
+        L.go_snapshot_tree_write.restype = C.c_size_t
+        L.go_snapshot_tree_write.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]
+        n = len(fields)
+        size = L.go_snapshot_tree_bytes(self.ptr, n)
+        buf = C.create_string_buffer(size)
+        arr = (C.c_void_p * n)(*[f.ptr for f in fields])
+        assert L.go_snapshot_tree_write(self.ptr, n, arr, buf) == size
+        return buf.raw
+
     def set_overlap(self, overlap):
         """the domain parameter `overlap' of a parallel run (src/domain.c:225,682)"""
         f = lib().go_domain_set_overlap
@@ -309,6 +322,11 @@ class Sim:
     @property
     def dt(self):
         return self.advection_params.dt
+
+    def restart(self, t, i):
+        f = lib().go_sim_restart
+        f.restype, f.argtypes = None, [C.c_void_p, C.c_double, C.c_uint]
+        f(self.ptr, t, i)
 
     def start(self):
         lib().go_sim_start(self.ptr)
