@@ -49,7 +49,37 @@ bc_kernel (Layout L, BcDesc bc, double * __restrict__ a)
   a[nb + o] = v;
 }
 
+static int launch_bc_kernel (gfship_domain * dom, Field * v, Field * v1, int level, int homogeneous);
+
 int launch_bc (gfship_domain * dom, Field * v, Field * v1, int level, int homogeneous)
+{
+  int r = launch_bc_kernel (dom, v, v1, level, homogeneous);
+  if (r) return r;
+  /* GfsBoundaryMpi sides: ghost layer from the neighbour boxes */
+  return call_exchange (dom, v1->lev[level], level, 0);
+}
+
+// the two halves of a BC application around the bulk of a sweep (overlap = 1): the exchange of the
+// MPI sides starts after the cells along them have been swept; the local sides are filled and the
+// arrivals unpacked after the bulk.  With the hooks of the caller instead of the library's
+// communicator nothing can run beside the sweep: the whole exchange happens in the second half
+// (same values: the layers do not change after the first half).
+int bc_mpi_begin (gfship_domain * dom, Field * v1, int level)
+{
+  if (!dom->has_external || !dom->comm) return GFSHIP_OK;
+  return comm_exchange_begin (dom, v1->lev[level], level);
+}
+
+int bc_mpi_end (gfship_domain * dom, Field * v, Field * v1, int level, int homogeneous)
+{
+  int r = launch_bc_kernel (dom, v, v1, level, homogeneous);
+  if (r) return r;
+  if (!dom->has_external) return GFSHIP_OK;
+  if (dom->comm) return comm_exchange_end (dom, v1->lev[level], level);
+  return call_exchange (dom, v1->lev[level], level, 0);
+}
+
+static int launch_bc_kernel (gfship_domain * dom, Field * v, Field * v1, int level, int homogeneous)
 {
   const Layout & L = dom->lay[level];
   BcDesc bc;
@@ -71,8 +101,7 @@ int launch_bc (gfship_domain * dom, Field * v, Field * v1, int level, int homoge
   dim3 grid ((nface + block - 1)/block, 2*dom->dim);
   hipLaunchKernelGGL (bc_kernel, grid, dim3 (block), 0, dom->stream, L, bc, v1->lev[level]);
   GFSHIP_HIP (hipGetLastError ());
-  /* GfsBoundaryMpi sides: ghost layer from the neighbour boxes */
-  return call_exchange (dom, v1->lev[level], level, 0);
+  return GFSHIP_OK;
 }
 
 int call_exchange (gfship_domain * dom, double * ptr, int level, int kind)

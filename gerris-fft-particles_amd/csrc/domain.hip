@@ -120,6 +120,7 @@ void gfship_domain_destroy (gfship_domain * dom)
     if (dom->fields[f].used)
       gfship_field_free (dom, (gfship_field) f);
   comm_free (dom);
+  mpi_order_free (dom);
   skew_free (dom);
   if (dom->d_scratch) (void) hipFree (dom->d_scratch);
   if (dom->cfl_partial) (void) hipFree (dom->cfl_partial);
@@ -140,6 +141,13 @@ int gfship_domain_set_relax_mode (gfship_domain * dom, int mode)
   dom->no_fused_loop = (mode == GFSHIP_RELAX_EXACT_PER_SWEEP);
   dom->no_fused_godunov = (mode == GFSHIP_RELAX_EXACT_PER_SWEEP);   /* the unfused reference paths */
   dom->relax_mode = mode == GFSHIP_RELAX_REDBLACK ? GFSHIP_RELAX_REDBLACK : GFSHIP_RELAX_EXACT;
+  return GFSHIP_OK;
+}
+
+int gfship_domain_set_overlap (gfship_domain * dom, int overlap)
+{
+  GFSHIP_CHECK (dom != nullptr, GFSHIP_EINVAL, "null domain");
+  dom->overlap = overlap != 0;
   return GFSHIP_OK;
 }
 

@@ -92,6 +92,8 @@ struct gfship_domain {
   gfship_reduce_fn reduce = nullptr;     void * reduce_ctx = nullptr;
   bool has_external = false;
   void * comm = nullptr;          // in-library RCCL transport (transport.hip), replaces the hooks
+  int overlap = 0;                // the domain parameter `overlap' of a parallel run (src/domain.c:225,682)
+  void * mpi_plan[GFSHIP_MAXLEVEL + 1] = {};  // MPI-sides-first sweep order of each level (poisson_kernels.hip)
   gfship_field dp_cache = -1;     // the `dp` temporary of gfs_poisson_cycle, kept between cycles
   int skew_resident = -1;         // workgroups of the fused relax loop that fit on the device
   bool wave_loop = false;         // fused relax loops by the experimental one-wave-per-tile kernel (GFSHIP_WAVE_LOOP=1)
@@ -141,16 +143,24 @@ inline long ncells (const Layout & L) {
 // kernels launchers (poisson_kernels.hip, bc.hip)
 int launch_bc (gfship_domain * dom, Field * v, Field * v1, int level, int homogeneous);
 int call_exchange (gfship_domain * dom, double * ptr, int level, int kind);
+int bc_mpi_begin (gfship_domain * dom, Field * v1, int level);
+int bc_mpi_end (gfship_domain * dom, Field * v, Field * v1, int level, int homogeneous);
 int call_reduce (gfship_domain * dom, double * vals, int n, int op);
 int call_reduce_norm (gfship_domain * dom, double * sums, int nsum, double * mx);
 // transport.hip
 int comm_exchange (gfship_domain * dom, double * a, int level, int kind);
+int comm_exchange_begin (gfship_domain * dom, double * a, int level);
+int comm_exchange_end (gfship_domain * dom, double * a, int level);
 int comm_reduce (gfship_domain * dom, double * sums, int nsum, double * maxs, int nmax,
 		 double * mins, int nmin);
 void comm_free (gfship_domain * dom);
 int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, double omega,
 			double * u, const double * rhs, const double * dia,
 			const RelaxOp * op = nullptr);
+int launch_relax_mpi_first (gfship_domain * dom, unsigned dimension, int level, double omega,
+			    double * u, const double * rhs, const double * dia, const RelaxOp * op,
+			    int (* after_shell) (void *), void * ctx);
+void mpi_order_free (gfship_domain * dom);
 int launch_relax_loop_small (gfship_domain * dom, unsigned dimension, int level, double omega,
 			     Field * dp, Field * ubc, const double * rhs, const double * dia,
 			     unsigned nrelax, bool * done, const RelaxOp * op = nullptr);

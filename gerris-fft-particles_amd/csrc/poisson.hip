@@ -36,6 +36,29 @@ static int relax_loop (gfship_domain * dom, Field * dp, Field * u, unsigned dime
 {
   int r;
   dp->zero[level] = false;
+  if (dom->relax_mode == GFSHIP_RELAX_EXACT && dom->has_external && dom->overlap && nrelax > 1) {
+    /* a parallel run with the domain parameter overlap = 1 (the reference's default): the first
+       nrelax - 1 sweeps go through gfs_traverse_and_homogeneous_bc -- cells along the MPI sides
+       first, their layers sent beside the bulk of the sweep, src/domain.c:1093-1125 -- and the
+       last one is a plain gfs_domain_cell_traverse (src/poisson.c:1080-1086) */
+    struct Ctx { gfship_domain * dom; Field * dp; int level; } ctx = { dom, dp, level };
+    auto after_shell = [] (void * p) -> int {
+      Ctx * c = (Ctx *) p;
+      return bc_mpi_begin (c->dom, c->dp, c->level);
+    };
+    if ((r = launch_bc (dom, u, dp, level, 1))) return r;
+    for (unsigned n = 0; n < nrelax - 1; n++) {
+      if ((r = launch_relax_mpi_first (dom, dimension, level, omega, dp->lev[level], rhs->lev[level],
+				       dia->lev[level], nullptr, after_shell, &ctx)))
+	return r;
+      if ((r = bc_mpi_end (dom, u, dp, level, 1))) return r;
+    }
+    bool done = false;
+    if ((r = launch_relax_loop_small (dom, dimension, level, omega, dp, u, rhs->lev[level],
+				      dia->lev[level], 1, &done)))
+      return r;
+    return done ? GFSHIP_OK : relax_level (dom, dimension, level, omega, dp, rhs, dia);
+  }
   if (dom->relax_mode == GFSHIP_RELAX_EXACT && dimension == 3 && skew_supported (dom, level) &&
       !dom->force_hyperplane) {
     if (corrected) *corrected = correct_into != nullptr;

@@ -5,6 +5,7 @@
 // exact-mode results are bit-identical to the CPU algorithm.  Unit face weights
 // (gfs_poisson_coefficients with alpha = NULL on a uniform single box: every f[d].v == 1.).
 #include "gfship_internal.hpp"
+#include <algorithm>
 
 namespace gfship {
 
@@ -804,6 +805,186 @@ int launch_norm (gfship_domain * dom, int level, const double * a, double scale,
   GFSHIP_HIP (hipGetLastError ());
   GFSHIP_HIP (stream_wait_spin (dom->stream));
   memcpy (out, dom->h_pinned, 5*sizeof (double));
+  return GFSHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The cell order of gfs_traverse_and_homogeneous_bc in a parallel run with the domain parameter
+// `overlap = 1', the reference's default (src/domain.c:682,1093-1125): the cells along the
+// GfsBoundaryMpi sides first (update_mpi_boundaries :1024-1049: sides d = 0..5 in turn,
+// ftt_cell_traverse_boundary in traversal order, a cell only once -- GFS_FLAG_USED), so that their
+// new values can travel while the bulk is swept, then the remaining cells in traversal order
+// (update_other_cell :1016-1022).
+//
+// On the device the sweep runs as the levels of the dependency graph of that sequence: cell c
+// must follow those of its six neighbours that come before it in the sequence and precede the
+// others; every topological order of that relation gives the same bits.  step (c) = 1 + max over
+// the earlier neighbours, computed once per level on the host by walking the sequence; the cells
+// sorted by step are kept on the device and one launch relaxes the cells of one step.  The steps
+// up to `shell_steps' hold every cell along an MPI side (and nothing that depends on the bulk):
+// after them the halo layers are final and the exchange can start beside the bulk.
+// ---------------------------------------------------------------------------------------------
+struct MpiOrderPlan {
+  int * cells = nullptr;             // device: linear indices into the level array, sorted by step
+  std::vector<int> first;            // first[s] .. first[s+1]: the cells of step s
+  int shell_steps = 0;               // steps after which every cell along an MPI side is done
+};
+
+template <int DIM, int OP>
+__global__ void __launch_bounds__(256)
+relax_listed_kernel (const int * __restrict__ cells, int count, long sy, long sz,
+		     unsigned dimension, double omega, double w, double h2,
+		     double * __restrict__ u, const double * __restrict__ rhs,
+		     const double * __restrict__ dia)
+{
+  const int q = blockIdx.x*blockDim.x + threadIdx.x;
+  if (q >= count) return;
+  const long c = cells[q];
+  u[c] = relax_value<DIM, OP> (u, c, sy, sz, rhs[c], dia[c], dimension, omega, w, h2);
+}
+
+// pre-order position of cell (I, J, K) of a level (oriented coordinates: I = i - 1, J = n - j,
+// K = n - k): child n of every ancestor = bit 0 from I, bit 1 from J, bit 2 from K
+static inline unsigned long long morton_key (int dim, int level, int I, int J, int K)
+{
+  unsigned long long m = 0;
+  for (int b = level - 1; b >= 0; b--) {
+    unsigned n = ((I >> b) & 1) | (((J >> b) & 1) << 1) | (dim == 3 ? ((K >> b) & 1) << 2 : 0);
+    m = (m << (dim == 3 ? 3 : 2)) | n;
+  }
+  return m;
+}
+
+void mpi_order_free (gfship_domain * dom)
+{
+  for (int l = 0; l <= GFSHIP_MAXLEVEL; l++)
+    if (dom->mpi_plan[l]) {
+      MpiOrderPlan * P = (MpiOrderPlan *) dom->mpi_plan[l];
+      if (P->cells) (void) hipFree (P->cells);
+      delete P;
+      dom->mpi_plan[l] = nullptr;
+    }
+}
+
+static int mpi_order_plan (gfship_domain * dom, int level, MpiOrderPlan ** out)
+{
+  if (dom->mpi_plan[level]) { *out = (MpiOrderPlan *) dom->mpi_plan[level]; return GFSHIP_OK; }
+  const Layout & L = dom->lay[level];
+  const int n = L.n, dim = dom->dim;
+  const size_t ncell = (size_t) ncells (L);
+  // the sequence: cells along the MPI sides, side by side, each in traversal order; then the rest
+  std::vector<int> seq;               // linear indices in sequence order
+  seq.reserve (ncell);
+  std::vector<int> step (L.total, 0); // 0 = not visited yet (ghost cells stay 0)
+  std::vector<char> used (L.total, 0);
+  size_t nshell = 0;
+  for (int s = 0; s < 2*dim; s++) {
+    if (dom->side[s] != GFSHIP_SIDE_EXTERNAL) continue;
+    // the face: axis c fixed at its first / last cell; sorted by pre-order position
+    const int c = s/2, fixed = (s & 1) ? 1 : n;
+    std::vector<std::pair<unsigned long long, int>> face;
+    const int nb = dim == 3 ? n*n : n;
+    face.reserve (nb);
+    for (int t = 0; t < nb; t++) {
+      int ijk[3] = { 1, 1, dim == 3 ? 1 : 0 };
+      int ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
+      ijk[c] = fixed;
+      ijk[ta] = t % n + 1;
+      if (dim == 3) ijk[tb] = t / n + 1;
+      const long idx = L.idx (ijk[0], ijk[1], ijk[2]);
+      if (used[idx]) continue;
+      face.emplace_back (morton_key (dim, level, ijk[0] - 1, n - ijk[1], dim == 3 ? n - ijk[2] : 0),
+			 (int) idx);
+    }
+    std::sort (face.begin (), face.end ());
+    for (auto & f : face) { used[f.second] = 1; seq.push_back (f.second); }
+  }
+  nshell = seq.size ();
+  {
+    // the remaining cells in traversal order: walk the pre-order positions
+    const int bits = dim == 3 ? 3 : 2;
+    for (unsigned long long m = 0; m < (unsigned long long) ncell; m++) {
+      int I = 0, J = 0, K = 0;
+      for (int b = 0; b < level; b++) {
+	const unsigned nn = (unsigned) ((m >> (bits*b)) & ((1u << bits) - 1));
+	I |= (nn & 1) << b; J |= ((nn >> 1) & 1) << b; K |= ((nn >> 2) & 1) << b;
+      }
+      const long idx = L.idx (I + 1, n - J, dim == 3 ? n - K : 0);
+      if (!used[idx]) seq.push_back ((int) idx);
+    }
+  }
+  GFSHIP_CHECK (seq.size () == ncell, GFSHIP_EHIP, "internal error: sweep sequence of %zu cells for %zu",
+		seq.size (), ncell);
+  // step of every cell: after its earlier neighbours
+  const long off[6] = { 1, -1, L.sy, - L.sy, L.sz, - L.sz };
+  int nsteps = 0, shell_steps = 0;
+  for (size_t q = 0; q < ncell; q++) {
+    const int c = seq[q];
+    int st = 0;
+    for (int d = 0; d < 2*dim; d++) {
+      const int sn = step[c + off[d]];
+      if (sn > st) st = sn;
+    }
+    step[c] = st + 1;
+    if (st + 1 > nsteps) nsteps = st + 1;
+    if (q < nshell && st + 1 > shell_steps) shell_steps = st + 1;
+  }
+  MpiOrderPlan * P = new MpiOrderPlan;
+  P->first.assign (nsteps + 1, 0);
+  for (size_t q = 0; q < ncell; q++) P->first[step[seq[q]]]++;    /* counts at [1..nsteps] */
+  {
+    int acc = 0;
+    for (int s = 1; s <= nsteps; s++) { int cnt = P->first[s]; P->first[s] = acc; acc += cnt; }
+    /* now first[s] = start of step s (1-based); shift to 0-based */
+    for (int s = 0; s < nsteps; s++) P->first[s] = P->first[s + 1];
+    P->first[nsteps] = acc;
+  }
+  std::vector<int> sorted (ncell), fill (P->first.begin (), P->first.end () - 1);
+  for (size_t q = 0; q < ncell; q++) {
+    const int c = seq[q];
+    sorted[fill[step[c] - 1]++] = c;
+  }
+  P->shell_steps = shell_steps;
+  hipError_t e = hipMalloc ((void **) &P->cells, ncell*sizeof (int));
+  if (e == hipSuccess)
+    e = hipMemcpy (P->cells, sorted.data (), ncell*sizeof (int), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (P->cells) (void) hipFree (P->cells);
+    delete P;
+    return hip_fail (e, "sweep order", __FILE__, __LINE__);
+  }
+  dom->mpi_plan[level] = P;
+  *out = P;
+  return GFSHIP_OK;
+}
+
+// one sweep in that order; after the steps that hold the cells along the MPI sides `after_shell'
+// is called (the caller starts the halo exchange there)
+int launch_relax_mpi_first (gfship_domain * dom, unsigned dimension, int level, double omega,
+			    double * u, const double * rhs, const double * dia, const RelaxOp * op,
+			    int (* after_shell) (void *), void * ctx)
+{
+  MpiOrderPlan * P;
+  int r = mpi_order_plan (dom, level, &P);
+  if (r) return r;
+  const int kind = op ? op->kind : 0;
+  const double w = op ? op->w : 1., h2 = op ? op->h2 : 1.;
+  const Layout & L = dom->lay[level];
+  const int nsteps = (int) P->first.size () - 1;
+  for (int s = 0; s < nsteps; s++) {
+    const int count = P->first[s + 1] - P->first[s];
+    const int * cells = P->cells + P->first[s];
+    const int block = 256, grid = (count + block - 1)/block;
+#define LS_LAUNCH(D, O) hipLaunchKernelGGL ((relax_listed_kernel<D, O>), dim3 (grid), dim3 (block), 0, \
+					    dom->stream, cells, count, L.sy, L.sz, dimension, omega, \
+					    w, h2, u, rhs, dia)
+    if (dom->dim == 3) { if (kind) LS_LAUNCH (3, 1); else LS_LAUNCH (3, 0); }
+    else               { if (kind) LS_LAUNCH (2, 1); else LS_LAUNCH (2, 0); }
+#undef LS_LAUNCH
+    if (s + 1 == P->shell_steps && after_shell && (r = (* after_shell) (ctx)))
+      return r;
+  }
+  GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
 }
 

@@ -8,10 +8,12 @@ namespace gfship {
 #define SK_NL  (SK_T*SK_T)   /* lines = threads per tile */
 #define SK_PAD (2*SK_T - 2)  /* extra rows of a tile: max skew */
 #ifndef SK_D
-#define SK_D   16            /* prefetch distance (steps) */
+#define SK_D   6             /* prefetch distance (steps) of the own streams: 16 was 12 % slower at */
+                             /* 256^3 (round 2, tools/lab/knobs.sh: 4, 6, 8, 12, 16 tried): what is */
+                             /* in flight in a CU is what a hand-off poll of that CU queues behind  */
 #endif
 #ifndef SK_DH
-#define SK_DH  4             /* prefetch distance of the halo streams (divides SK_D): the lag */
+#define SK_DH  3             /* prefetch distance of the halo streams (divides SK_D): the lag */
                              /* between neighbouring tiles grows with it                     */
 #endif
 /* rows of padding in front of and behind every tile, so that prefetch addresses never need
@@ -20,7 +22,7 @@ namespace gfship {
 #define SK_FP  48
 /* rows of a tile's hand-off / snapshot granule array: n + 30 used, the streams read ahead by up
    to SK_D (rounding of T) + SK_DH + 1 rows */
-#define SK_HROWS(n_) ((n_) + 2*SK_T + SK_D + SK_DH + 16)
+#define SK_HROWS(n_) ((n_) + 2*SK_T + 36)   /* 36 = 16 + 4 + 16: the largest read-ahead of any of the kernels */
 
 typedef unsigned long long u64;
 #define SK_SENTINEL 0xFFFFFFFFFFFFFFFFull

@@ -40,7 +40,7 @@
 
 #define SK_MAXF 8    /* sweeps per launch */
 #ifndef SK_POLL_SLEEP
-#define SK_POLL_SLEEP 2   /* s_sleep argument between two polls of a hand-off granule */
+#define SK_POLL_SLEEP 0   /* s_sleep argument between two polls of a hand-off granule */
 #endif
 #ifndef SK_EXP
 #define SK_EXP 0    /* timing experiments: 1 plain halo prefetch loads, 2 plain granule stores */

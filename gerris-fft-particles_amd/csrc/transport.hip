@@ -79,6 +79,9 @@ struct Comm {
   double * dred = nullptr;          // [COMM_MAXRED] operands, then [nranks*COMM_MAXRED] gathered
   double * hred = nullptr;          // pinned host mirror of dred
   unsigned long long messages = 0, bytes = 0;   // domain->mpi_messages / mpi_size, mpi_boundary.c:113,128
+  // overlap = 1: the exchange of a sweep runs on a stream of its own beside the bulk of the sweep
+  hipStream_t side = nullptr;
+  hipEvent_t packed = nullptr, arrived = nullptr;
 };
 
 static int comm_rank_of (const Comm * C, int cx, int cy, int cz)
@@ -130,6 +133,60 @@ int comm_exchange (gfship_domain * dom, double * a, int level, int kind)
   return gfship_halo_unpack_sides (dom, a, level, nr, recv, rb);
 }
 
+// The same exchange (kind 0) in two halves, for the sweeps of a parallel relax loop with the domain
+// parameter overlap = 1 (gfs_traverse_and_homogeneous_bc, src/domain.c:1109-1123): `begin' after the
+// cells along the MPI sides have been swept -- their layers are packed on the domain's stream, sent
+// and received on a stream of the communicator's own, beside the bulk of the sweep that goes on on
+// the domain's stream (gfs_boundary_send inside update_mpi_boundaries :1024-1049) -- and `end' after
+// the bulk: the domain's stream waits for the arrivals and unpacks them into the ghost layer
+// (box_receive_bc / box_synchronize :1119-1122).
+static int comm_sides (gfship_domain * dom, int send[6], int recv[6])
+{
+  int ns = 0;
+  for (int d = 0; d < 2*dom->dim; d++)
+    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL) send[ns++] = d;
+  for (int q = 0; q < ns; q++) recv[q] = send[q] ^ 1;
+  return ns;
+}
+
+int comm_exchange_begin (gfship_domain * dom, double * a, int level)
+{
+  Comm * C = (Comm *) dom->comm;
+  const Layout & L = dom->lay[level];
+  const size_t nface = dom->dim == 3 ? (size_t) L.n*L.n : (size_t) L.n;
+  int send[6], recv[6];
+  const int ns = comm_sides (dom, send, recv);
+  if (ns == 0) return GFSHIP_OK;
+  void * sb[6];
+  for (int q = 0; q < ns; q++) sb[q] = C->sbuf[send[q]];
+  int r = gfship_halo_pack_sides (dom, a, level, ns, send, sb);
+  if (r) return r;
+  GFSHIP_HIP (hipEventRecord (C->packed, dom->stream));
+  GFSHIP_HIP (hipStreamWaitEvent (C->side, C->packed, 0));
+  GFSHIP_NCCL (g_rccl.GroupStart ());
+  for (int q = 0; q < ns; q++)
+    GFSHIP_NCCL (g_rccl.Send (sb[q], nface, ncclDouble, C->peer[send[q]], C->comm, C->side));
+  for (int q = 0; q < ns; q++)
+    GFSHIP_NCCL (g_rccl.Recv (C->rbuf[recv[q]], nface, ncclDouble, C->peer[recv[q]], C->comm, C->side));
+  GFSHIP_NCCL (g_rccl.GroupEnd ());
+  GFSHIP_HIP (hipEventRecord (C->arrived, C->side));
+  C->messages += ns;
+  C->bytes += ns*nface*sizeof (double);
+  return GFSHIP_OK;
+}
+
+int comm_exchange_end (gfship_domain * dom, double * a, int level)
+{
+  Comm * C = (Comm *) dom->comm;
+  int send[6], recv[6];
+  const int ns = comm_sides (dom, send, recv);
+  if (ns == 0) return GFSHIP_OK;
+  void * rb[6];
+  for (int q = 0; q < ns; q++) rb[q] = C->rbuf[recv[q]];
+  GFSHIP_HIP (hipStreamWaitEvent (dom->stream, C->arrived, 0));
+  return gfship_halo_unpack_sides (dom, a, level, ns, recv, rb);
+}
+
 // MPI_Allreduce of nsum sums, nmax maxima and nmin minima in one collective: every rank gathers
 // the operands of all ranks and reduces them in rank order
 int comm_reduce (gfship_domain * dom, double * sums, int nsum, double * maxs, int nmax,
@@ -170,7 +227,11 @@ void comm_free (gfship_domain * dom)
   Comm * C = (Comm *) dom->comm;
   if (!C) return;
   if (dom->stream) (void) hipStreamSynchronize (dom->stream);
+  if (C->side) (void) hipStreamSynchronize (C->side);
   if (C->comm && g_rccl.CommDestroy) (void) g_rccl.CommDestroy (C->comm);
+  if (C->packed) (void) hipEventDestroy (C->packed);
+  if (C->arrived) (void) hipEventDestroy (C->arrived);
+  if (C->side) (void) hipStreamDestroy (C->side);
   for (int d = 0; d < 6; d++) {
     if (C->sbuf[d]) (void) hipFree (C->sbuf[d]);
     if (C->rbuf[d]) (void) hipFree (C->rbuf[d]);
@@ -246,6 +307,9 @@ int gfship_domain_comm_init (gfship_domain * dom, const void * unique_id, int ra
       he = hipMalloc ((void **) &C->sbuf[d], nface*sizeof (double));
       if (he == hipSuccess) he = hipMalloc ((void **) &C->rbuf[d], nface*sizeof (double));
     }
+  if (he == hipSuccess) he = hipStreamCreateWithFlags (&C->side, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipEventCreateWithFlags (&C->packed, hipEventDisableTiming);
+  if (he == hipSuccess) he = hipEventCreateWithFlags (&C->arrived, hipEventDisableTiming);
   if (he == hipSuccess)
     he = hipMalloc ((void **) &C->dred, (size_t) (nranks + 1)*COMM_MAXRED*sizeof (double));
   if (he == hipSuccess)

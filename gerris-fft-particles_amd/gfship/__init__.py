@@ -108,6 +108,7 @@ SIGNATURES = {
     "gfship_coarse_init": (_i, [_vp]),
     "gfship_divergence_norm": (_i, [_vp, C.POINTER(Norm)]),
     "gfship_sim_download_un": (_i, [_vp, _i, _pd]),
+    "gfship_domain_set_overlap": (_i, [_vp, _i]),
     "gfship_domain_set_exchange": (_i, [_vp, _vp, _vp]),
     "gfship_domain_set_reduce": (_i, [_vp, _vp, _vp]),
     "gfship_sim_restart": (_i, [_vp, _d, _u]),
@@ -271,6 +272,9 @@ class Domain:
         h = (C.c_int * n)(*[v.h for v in variables])
         buf = C.create_string_buffer(bytes(data), len(data))
         _check(lib().gfship_snapshot_tree_read(self.ptr, n, h, buf, len(data)))
+
+    def set_overlap(self, overlap):
+        _check(lib().gfship_domain_set_overlap(self.ptr, int(overlap)))
 
     def set_relax_mode(self, mode):
         _check(lib().gfship_domain_set_relax_mode(self.ptr, mode))

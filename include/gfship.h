@@ -361,6 +361,16 @@ int  gfship_particles_download_particulate (gfship_particles * pl, double * vel,
      Work must be ordered after everything already enqueued on gfship_domain_stream().
    reduce: MPI_Allreduce of vals[0..n-1] over all boxes, op = 0 sum, 1 max, 2 min
      (norms src/domain.c:2135-2166, CFL :2921). */
+/* The domain parameter `overlap' of a parallel run (src/domain.c:225,682; "overlap = 0" in the
+   graph parameters of the simulation file).  0 (the default here): every sweep of a relax loop in
+   plain traversal order, BC application after it.  1 (the reference's default): the first
+   nrelax - 1 sweeps of a relax loop in the order of gfs_traverse_and_homogeneous_bc
+   (src/domain.c:1093-1125) -- the cells along the GfsBoundaryMpi sides first, side by side in
+   traversal order, then the rest -- with the halo layers travelling beside the bulk of the sweep
+   when the library's own communicator is used; the last sweep in plain order (src/poisson.c:1080-
+   1086).  The two orders give different iterates of the same solution: a multi-box run must be
+   compared with a reference run of the same setting.  No effect on a box without MPI sides. */
+int  gfship_domain_set_overlap (gfship_domain * dom, int overlap);
 typedef int (* gfship_exchange_fn) (void * ctx, void * dev_ptr, int level, int kind);
 typedef int (* gfship_reduce_fn) (void * ctx, double * vals, int n, int op);
 int  gfship_domain_set_exchange (gfship_domain * dom, gfship_exchange_fn fn, void * ctx);

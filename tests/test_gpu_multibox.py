@@ -80,6 +80,63 @@ def test_lattice_flow_device_boxes_equal_oracle_boxes(nboxes, level):
     assert not np.array_equal(dev[0]["u"], dev[1]["u"])      # the boxes really differ
 
 
+@pytest.mark.parametrize("nboxes,level", [(2, 4), (8, 4), (8, 5)])
+def test_lattice_flow_with_the_reference_default_overlap_order(nboxes, level):
+    """overlap = 1, the reference's default for parallel runs (src/domain.c:682): the first
+    nrelax - 1 sweeps of every relax loop visit the cells along the MPI sides first
+    (src/domain.c:1093-1125), the last one is a plain traversal (src/poisson.c:1080-1086).  Device
+    boxes against oracle boxes of the same lattice, bit for bit; and the iterates do differ from
+    the overlap = 0 ones."""
+    nsteps = 2
+    ora = run_lattice_flow_threads(nboxes, level, nsteps, 1)
+    dev = _device_lattice_flow(nboxes, level, nsteps, 1)
+    _same(dev, ora, "%d boxes, overlap" % nboxes)
+    plain = run_lattice_flow_threads(nboxes, level, nsteps, 0)
+    assert not np.array_equal(plain[0]["p"], ora[0]["p"])
+
+
+def test_rccl_transport_with_overlap_on_one_rank():
+    """the split exchange of overlap = 1 (layers sent on the communicator's own stream beside the
+    bulk of the sweep) through the real RCCL on a one-rank communicator, against the oracle box with
+    the same MPI sides served by a mirror transport (the box is its own neighbour)"""
+    from test_gpu_particles import _MirrorTransport
+    level, nsteps = 5, 2
+    side = [gfship.SIDE_EXTERNAL, gfship.SIDE_EXTERNAL, gfship.SIDE_PERIODIC, gfship.SIDE_PERIODIC,
+            gfship.SIDE_EXTERNAL, gfship.SIDE_EXTERNAL]
+    osim = O.Sim(3, level, side)
+    x, y, z = osim.dom.centres()
+    from flow_cases import taylor_green_3d
+    for c, a in enumerate(taylor_green_3d(x, y, z)):
+        osim.u[c].interior()[...] = a + (0.3 if c == 0 else 0.)
+    osim.dom.set_overlap(1)
+
+    class SelfTransport(_MirrorTransport):
+        def __init__(self):
+            import torch
+            self.torch, self.rank = torch, 0
+            self.device = torch.device("cpu")
+            self._bufs = {}
+            self.grid = type("G", (), {"external_sides": lambda s: [0, 1, 4, 5]})()
+
+        def allreduce(self, vals, op):
+            return np.array(vals, dtype=np.float64)
+
+    ohooks = M.OracleHooks(O.lib(), osim.dom.ptr, 3, SelfTransport())
+    gd, gs = _device_sim(osim, side)
+    gd.set_overlap(1)
+    gd.comm_init(gfship.comm_unique_id(), 0, 1, (1, 1, 1))
+    osim.start()
+    gs.start()
+    _assert_same_state(osim, gs, "start")
+    for k in range(nsteps):
+        osim.step()
+        gs.step()
+        _assert_same_state(osim, gs, "step %d" % k)
+    del ohooks
+    gs.destroy()
+    gd.destroy()
+
+
 def test_rccl_transport_on_one_rank_reproduces_the_periodic_box():
     """gfship_domain_comm_init with one rank: the x and z sides are GfsBoundaryMpi sides whose peer is
     the box itself, y stays a local periodic side.  pack -> ncclSend/ncclRecv (self) -> unpack and

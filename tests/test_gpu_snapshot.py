@@ -41,7 +41,7 @@ def test_tree_image_equals_the_oracle_walk_and_reads_back(dim, level):
     with pytest.raises(gfship.GfshipError):
         gd.snapshot_tree_read(back, got[:-20])
     bad = bytearray(got)
-    bad[20 + 8 * len(gfs)] ^= 1          # the child id of the second record
+    bad[12 + 8 * len(gfs)] ^= 1          # the child id (flags) of the second record
     with pytest.raises(gfship.GfshipError, match="FTT_CELL_ID"):
         gd.snapshot_tree_read(back, bytes(bad))
     gd.destroy()

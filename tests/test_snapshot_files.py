@@ -89,7 +89,7 @@ def test_front_end_restart_from_its_own_snapshot(tmp_path, binary):
     extra = ("  OutputSimulation { istart = 4 istep = 100 } mid.gfs { binary = %d }\n"
              "  OutputSimulation { start = end } end.gfs { binary = 1 }\n" % binary)
     # put the outputs in front of the closing brace of the simulation body
-    k = case.rindex("}", 0, case.index("GfsBox"))
+    k = case.rindex("}", 0, case.rindex("GfsBox"))
     text = (case[:k] + extra + case[k:]).replace("Time { end = 2 }", "Time { end = 2 iend = 8 }")
     (tmp_path / "run.gfs").write_text(text)
     r = subprocess.run([exe, "-DLEVEL=5", "run.gfs"], cwd=str(tmp_path),
