@@ -28,6 +28,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <fstream>
+#include <iostream>
 #include <functional>
 #include <sstream>
 #include "gfship.h"
@@ -129,6 +130,8 @@ struct Run {
   std::vector<std::unique_ptr<ParticleSpec>> plists;
   std::vector<std::pair<gfship_init_spectra_params, std::vector<std::string>>> init_spectra;
   std::string particles_out;                     // --particles FILE: the lists at the end of the run
+  Function * refine_fn = nullptr;                // GfsRefine given as a function
+  int refine_line = 0;
   // the text of the file, kept to write it back (GfsOutputSimulation): objects of the body, the
   // parameters of the GfsBox, the edges; and the cell data the file came with (a snapshot)
   std::vector<std::pair<std::string, std::string>> object_texts;   // class, text
@@ -495,9 +498,18 @@ void parse_object (Run & R, Reader & r)
     FunctionText t = r.function ();
     char * endp;
     long l = strtol (t.text.c_str (), &endp, 10);
-    if (t.block || *endp != '\0' || l < 0 || l > GFSHIP_MAXLEVEL)
-      r.fail ("only a uniform `Refine <integer>` is supported (got `" + t.text + "')");
-    R.level = (int) l;
+    if (t.block || *endp != '\0') {
+      // GfsRefine with a function of the position (refine_maxlevel, src/refine.c:34-43): accepted
+      // when it asks for the same level everywhere (resolve_refine: e.g. test/periodic/periodic.gfs
+      // with BOX = 0)
+      R.refine_fn = R.functions.add (t, line);
+      R.refine_line = line;
+    }
+    else {
+      if (l < 0 || l > GFSHIP_MAXLEVEL)
+	r.fail ("Refine: level out of range (got `" + t.text + "')");
+      R.level = (int) l;
+    }
   }
   else if (cls == "GModule") {
     std::string name = r.word (false);
@@ -1344,6 +1356,35 @@ void apply_init (Run & R)
   }
 }
 
+// gfs_refine_refine (src/refine.c:45-60): a cell of level l is refined while l < f (x, y, z) at its
+// centre.  Only uniform trees exist here: at every level all cells must agree.
+void resolve_refine (Run & R)
+{
+  if (!R.refine_fn) return;
+  int level = 0;
+  for (;;) {
+    const int n = 1 << level;
+    int yes = 0, no = 0;
+    for (int k = 1; k <= (R.dim == 3 ? n : 1); k++)
+      for (int j = 1; j <= n; j++)
+	for (int i = 1; i <= n; i++) {
+	  double p[3] = { -0.5 + (i - 0.5)/n, -0.5 + (j - 0.5)/n, R.dim == 3 ? -0.5 + (k - 0.5)/n : 0. };
+	  if (level < eval (R, R.refine_fn, p, -1)) yes++; else no++;
+	}
+    if (yes && no) {
+      fprintf (stderr, "gfship: line %d: the Refine function asks for a non-uniform tree at level %d "
+	       "(adaptive refinement is not supported)\n", R.refine_line, level);
+      exit (1);
+    }
+    if (!yes) break;
+    if (++level > GFSHIP_MAXLEVEL) {
+      fprintf (stderr, "gfship: line %d: Refine: more than %d levels\n", R.refine_line, GFSHIP_MAXLEVEL);
+      exit (1);
+    }
+  }
+  R.level = level;
+}
+
 int run (Run & R)
 {
   R.clock0 = std::chrono::steady_clock::now ();
@@ -1351,6 +1392,7 @@ int run (Run & R)
      whose functions do not compile exits here without a device context or handles left behind */
   add_derived (R);
   R.functions.resolve (R.var_names ());
+  resolve_refine (R);
   CHECK (gfship_domain_create (&R.dom, R.dim, R.level, R.side, R.device));
   CHECK (gfship_sim_create (&R.sim, R.dom));
   R.vars[R.var_index ("P")].dev = gfship_sim_variable (R.sim, GFSHIP_VAR_P, 0);
@@ -1594,6 +1636,7 @@ int check (Run & R)
 {
   add_derived (R);
   R.functions.resolve (R.var_names ());
+  resolve_refine (R);
   printf ("class Gfs%s dim %d level %d\n", R.sim_class.c_str (), R.dim, R.level);
   printf ("sides");
   for (int d = 0; d < 2*R.dim; d++)
@@ -1648,10 +1691,14 @@ int main (int argc, char ** argv)
     else file = s;
   }
   if (file.empty ()) { fprintf (stderr, "gfship: no simulation file given\n"); return 1; }
-  std::ifstream in (file);
-  if (!in) { fprintf (stderr, "gfship: cannot open `%s'\n", file.c_str ()); return 1; }
   std::stringstream ss;
-  ss << in.rdbuf ();
+  if (file == "-")                       /* `gerris2D -': the simulation file on standard input */
+    ss << std::cin.rdbuf ();
+  else {
+    std::ifstream in (file);
+    if (!in) { fprintf (stderr, "gfship: cannot open `%s'\n", file.c_str ()); return 1; }
+    ss << in.rdbuf ();
+  }
   try {
     // a file with cell data (a snapshot written by GfsOutputSimulation): the data is cut out
     // before the text is parsed
