@@ -100,6 +100,7 @@ struct gfship_domain {
   bool xcd_place = false;         // XCD-aware tile placement in the loop kernel (experiment, GFSHIP_XCD_PLACE=1)
   bool skew_old = false;          // single sweeps by the older four-wave kernel (GFSHIP_SKEW_OLD)
   bool no_fused_godunov = false;  // face-value arrays + separate kernels even on periodic boxes
+  bool no_fused_godunov3 = false; // one launch per velocity component instead of the three at once (GFSHIP_NO_ADVECT3)
   bool no_fused_loop = false;     // one launch per sweep even where the fused loop applies
   bool force_hyperplane = false;  // debug/bench: per-hyperplane launches instead of relax_skew
   bool unit_weights = false;      // gfship_poisson_coefficients called with alpha = NULL
@@ -177,6 +178,9 @@ int launch_prolongate (gfship_domain * dom, int level_coarse, const double * v_c
 		       double * v_fine);
 int launch_correct (gfship_domain * dom, int level, double * u, const double * dp);
 int launch_fill (gfship_domain * dom, int level, double * a, double value);
+int launch_residual_norm (gfship_domain * dom, int level, const double * u, const double * rhs,
+			  const double * dia, double * res, double scale, double weight,
+			  double * out /* 5 values, or nullptr: left in h_pinned[8..12], not waited for */);
 int launch_norm_async (gfship_domain * dom, int level, const double * a, double scale, double weight);
 int launch_norm (gfship_domain * dom, int level, const double * a, double scale, double weight,
 		 double out[5] /* bias(sum of scaled), first, second, infty, raw sum */);
@@ -207,6 +211,9 @@ int launch_face_interp_div (gfship_domain * dom, double * const u[3], double * c
 			    double * div, double dt);
 int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt, int gradient,
 			     const double visc[3], double * const un[3]);
+int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * const out[3],
+			  double * const un[3], double * const gm[3], double * const gc[3],
+			  double dt, int gradient);
 int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, double * out,
 			 double * const un[3], const double * gm, const double * gc, double dt,
 			 int gradient, double visc);

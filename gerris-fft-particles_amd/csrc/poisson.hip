@@ -105,16 +105,19 @@ static int norm_residual (gfship_domain * dom, double dt, Field * res, gfship_no
   return norm_residual_finish (dom, dt, s, out);
 }
 
-// the leaf residual, then its norm (a single-pass kernel with per-row partial sums was tried:
-// 190 us against 118 + 66 us for the two kernels at 256^3, so they stay separate)
+// the leaf residual and its norm in one pass over the cells (rows of cells per workgroup, 1024
+// workgroups; round 1's first attempt at this, one partial record per row, was slower than the two
+// kernels)
 static int residual_and_norm (gfship_domain * dom, double dt, Field * U, Field * R, Field * D,
 			      Field * S, gfship_norm * out)
 {
   const int L = dom->depth;
   S->zero[L] = false;
-  int r = launch_residual (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L]);
+  const double size = 1./dom->lay[L].n;
+  double s[5];
+  int r = launch_residual_norm (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L], 1.*size*size, 1., s);
   if (r) return r;
-  return norm_residual (dom, dt, S, out);
+  return norm_residual_finish (dom, dt, s, out);
 }
 
 static int norm_residual_finish (gfship_domain * dom, double dt, double s[5], gfship_norm * out)
@@ -356,8 +359,9 @@ int gfship_poisson_solve (gfship_domain * dom, gfship_multilevel_params * par,
     const Layout & Ly = dom->lay[L];
     double size = 1./Ly.n;
     S->zero[L] = false;
-    if ((r = launch_residual (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L]))) return r;
-    if ((r = launch_norm_async (dom, L, S->lev[L], 1.*size*size, 1.))) return r;
+    if ((r = launch_residual_norm (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L], 1.*size*size,
+				   1., nullptr)))
+      return r;
   }
   else {
     if ((r = residual_and_norm (dom, dt, U, R, D, S, &par->residual))) return r;

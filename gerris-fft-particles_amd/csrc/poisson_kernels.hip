@@ -808,6 +808,95 @@ int launch_norm (gfship_domain * dom, int level, const double * a, double scale,
   return GFSHIP_OK;
 }
 
+// K2 + K7 in one pass: the residual of the leaves and the partial sums of its norm
+// (gfs_residual src/poisson.c:721-747 followed by gfs_domain_norm_residual src/domain.c:2264-2288:
+// the solve loop always asks for both).  Rows of cells per workgroup as in norm_partial_kernel, the
+// residual arithmetic of residual_kernel; the residual is stored and accumulated from the register.
+// scale = h*h is a power of two: the division by it is the exact multiplication by 1/scale.
+template <int DIM>
+__global__ void __launch_bounds__(256)
+residual_norm_kernel (Layout L, const double * __restrict__ u, const double * __restrict__ rhs,
+		      const double * __restrict__ dia, double * __restrict__ res, double inv,
+		      double weight, double * __restrict__ partial)
+{
+  const int n = L.n;
+  const long nrows = DIM == 3 ? (long) n*n : n;
+  double s0 = 0., s1 = 0., s2 = 0., s3 = 0., s4 = 0.;
+  for (long r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const int j = (int) (r % n) + 1, k = DIM == 3 ? (int) (r / n) + 1 : 0;
+    const long row = L.idx (1, j, k);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const long c = row + i;
+      double a = dia[c], b = 0.;
+      a += 1.; b += 1.*u[c + 1];
+      a += 1.; b += 1.*u[c - 1];
+      a += 1.; b += 1.*u[c + L.sy];
+      a += 1.; b += 1.*u[c - L.sy];
+      if (DIM == 3) {
+	a += 1.; b += 1.*u[c + L.sz];
+	a += 1.; b += 1.*u[c - L.sz];
+      }
+      const double raw = rhs[c] - (b - u[c]*a);
+      res[c] = raw;
+      double val = raw*inv;
+      s0 += weight*val;
+      val = fabs (val);
+      s3 = fmax (s3, val);
+      s1 += weight*val;
+      s2 += weight*val*val;
+      s4 += raw;
+    }
+  }
+  __shared__ double sh[5][4];
+  s0 = wave_sum (s0); s1 = wave_sum (s1); s2 = wave_sum (s2); s3 = wave_max (s3); s4 = wave_sum (s4);
+  int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { sh[0][w] = s0; sh[1][w] = s1; sh[2][w] = s2; sh[3][w] = s3; sh[4][w] = s4; }
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    int nw = blockDim.x >> 6;
+    double r0 = 0., r1 = 0., r2 = 0., r3 = 0., r4 = 0.;
+    for (int q = 0; q < nw; q++) {
+      r0 += sh[0][q]; r1 += sh[1][q]; r2 += sh[2][q]; r3 = fmax (r3, sh[3][q]); r4 += sh[4][q];
+    }
+    double * p = partial + 5*(size_t) blockIdx.x;
+    p[0] = r0; p[1] = r1; p[2] = r2; p[3] = r3; p[4] = r4;
+  }
+}
+
+// result_slot: 0 = dom->h_pinned (waited for, copied to out), 8 = dom->h_pinned + 8 (not waited for:
+// the caller synchronises later, launch_norm_async's convention)
+int launch_residual_norm (gfship_domain * dom, int level, const double * u, const double * rhs,
+			  const double * dia, double * res, double scale, double weight,
+			  double * out)
+{
+  const Layout & L = dom->lay[level];
+  if (!power_of_two (scale)) {
+    int r = launch_residual (dom, level, u, rhs, dia, res);
+    if (r) return r;
+    return out ? launch_norm (dom, level, res, scale, weight, out) :
+      launch_norm_async (dom, level, res, scale, weight);
+  }
+  long nrows = L.dim == 3 ? (long) L.n*L.n : L.n;
+  int block = L.n >= 256 ? 256 : L.n >= 128 ? 128 : 64;
+  int nblocks = (int) (nrows > 1024 ? 1024 : nrows);   /* d_scratch holds 5*1024 partials */
+  double * partial = dom->d_scratch;
+  double * result = out ? dom->h_pinned : dom->h_pinned + 8;
+  if (dom->dim == 3)
+    hipLaunchKernelGGL (residual_norm_kernel<3>, dim3 (nblocks), dim3 (block), 0, dom->stream, L, u,
+			rhs, dia, res, 1./scale, weight, partial);
+  else
+    hipLaunchKernelGGL (residual_norm_kernel<2>, dim3 (nblocks), dim3 (block), 0, dom->stream, L, u,
+			rhs, dia, res, 1./scale, weight, partial);
+  hipLaunchKernelGGL (norm_final_kernel, dim3 (1), dim3 (256), 0, dom->stream,
+		      partial, nblocks, result);
+  GFSHIP_HIP (hipGetLastError ());
+  if (out) {
+    GFSHIP_HIP (stream_wait_spin (dom->stream));
+    memcpy (out, dom->h_pinned, 5*sizeof (double));
+  }
+  return GFSHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The cell order of gfs_traverse_and_homogeneous_bc in a parallel run with the domain parameter
 // `overlap = 1', the reference's default (src/domain.c:682,1093-1125): the cells along the

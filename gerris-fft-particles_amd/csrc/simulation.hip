@@ -26,6 +26,7 @@ struct gfship_sim {
   gfship_field drhs = -1, rhoc = -1;   // temporaries of variable_diffusion
   bool cfl_ready = false;              // maxima for the CFL condition left by the last projection
   gfship_field adv_tmp = -1;           // output of the fused advection kernel (swapped with v)
+  gfship_field adv_tmp3[3] = {-1, -1, -1};   // the same for the three-component kernel
   gfship_next_event_fn next_event = nullptr; void * next_event_ctx = nullptr;
 };
 
@@ -250,6 +251,7 @@ void gfship_sim_destroy (gfship_sim * s)
   for (int c = 0; c < 3; c++) { fr (s->u[c]); fr (s->g[c]); fr (s->gmac[c]); fr (s->un[c]); }
   for (int d = 0; d < 6; d++) fr (s->fv[d]);
   fr (s->dia); fr (s->div); fr (s->res); fr (s->drhs); fr (s->rhoc); fr (s->adv_tmp);
+  for (int c = 0; c < 3; c++) fr (s->adv_tmp3[c]);
   for (gfship_field t : s->tracers) fr (t);
   delete s;
 }
@@ -364,6 +366,33 @@ int gfship_centered_velocity_advection (gfship_sim * s, const gfship_field gmac[
 					const gfship_field g[3])
 {
   GFSHIP_CHECK (s && gmac, GFSHIP_EINVAL, "null argument");
+  if (s->dom->dim == 3 && godunov_fused_supported (s->dom) && !s->dom->no_fused_godunov3 &&
+      s->visc[0] == 0. && s->visc[1] == 0. && s->visc[2] == 0.) {
+    /* the three components in one pass over the box (same MAC velocities, nothing of one component
+       feeds another): into scratch leaf levels, then the storage is swapped */
+    gfship_domain * dom = s->dom;
+    const int L = dom->depth;
+    double * v[3], * out[3], * un[3], * gm[3], * gc[3];
+    for (int c = 0; c < 3; c++) {
+      if (s->adv_tmp3[c] < 0)
+	s->adv_tmp3[c] = gfship_field_alloc (dom, -1);
+      if (s->adv_tmp3[c] < 0) return s->adv_tmp3[c];
+    }
+    ptrs3 (s, s->u, v);
+    ptrs3 (s, s->adv_tmp3, out);
+    ptrs3 (s, s->un, un);
+    ptrs3 (s, gmac, gm);
+    if (g) ptrs3 (s, g, gc);
+    TRY (launch_advect3_fused (dom, v, out, un, gm, g ? gc : nullptr, s->advection_params.dt,
+			       s->advection_params.gradient));
+    for (int c = 0; c < 3; c++) {
+      std::swap (dom->fields[s->u[c]].lev[L], dom->fields[s->adv_tmp3[c]].lev[L]);
+      dom->fields[s->u[c]].zero[L] = false;
+    }
+    for (int c = 0; c < 3; c++)
+      TRY (bc_leaf (s, s->u[c]));
+    return GFSHIP_OK;
+  }
   for (int c = 0; c < s->dom->dim; c++) {
     if (s->visc[c] != 0.) {
       /* source_diffusion (v[c]): rhs = copy of v on the leaves, sources into rhs, implicit

@@ -816,6 +816,236 @@ advect_tiled_kernel (Layout L, const double * __restrict__ v, double * __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// The three velocity components in ONE pass (gfs_centered_velocity_advection_diffusion without
+// viscosity, src/timestep.c:976-1016: variable_sources of U, V, W with the same MAC velocities).
+// advect_tiled_kernel is issue-bound, and most of what it issues does not depend on the advected
+// variable: the MAC velocities of the cell and their sums (tangential velocities and CFL numbers of
+// gfs_cell_advected_face_values), the upwind neighbours, the periodic images and addresses of the
+// halo cells, the flux velocities un*dt/h of the faces, the gather order.  Here all of that is
+// done once per cell for the three components.  Two more changes against the one-component kernel:
+//   * only the `right' face values travel through LDS (the + face of a cell needs its own left
+//     state and the right state of the cell after it);
+//   * every face flux is computed once, by the cell on its - side, and handed to the cell on its
+//     + side through LDS (same expression, same operands: the same bits the two cells used to
+//     compute twice); the faces on the - sides of the tile are computed by the cells along them
+//     from the left state of the cell before the tile.
+// Same arithmetic and gather order as advect_tiled_kernel / flux_update_kernel: bit-identical.
+// ---------------------------------------------------------------------------------------------
+struct AdvShared {          // what gfs_cell_advected_face_values derives from the MAC velocities of a cell
+  double vtan[3];           // (f[2c].un + f[2c+1].un)/2.
+  double unorm[3];          // dt*(f[2c].un + f[2c+1].un)/(2.*size)
+};
+
+__device__ __forceinline__ AdvShared adv_shared (const Layout & L, const CPtr3 & un, int c, double dt)
+{
+  const int off[3] = { 1, (int) L.sy, (int) L.sz };
+  const double rsize2 = (double) L.n/2.;
+  AdvShared S;
+#pragma unroll
+  for (int cc = 0; cc < 3; cc++) {
+    const double a = un.p[cc][c], b = un.p[cc][c - off[cc]];
+    S.vtan[cc] = (a + b)/2.;
+    S.unorm[cc] = dt*(a + b)*rsize2;
+  }
+  return S;
+}
+
+// transverse term of direction cc (transverse_term, src/advection.c:27-47)
+__device__ __forceinline__ double adv_transverse (const double * __restrict__ v, int c, int o,
+						  double v0, double vtan, double dt, double rsize2)
+{
+  const int nb = vtan > 0. ? c - o : c + o;
+  double g = v[nb] - 1.*v0;
+  if (vtan > 0.) g = - g;
+  return dt*vtan*g*rsize2;
+}
+
+// the two face values of direction D given the transverse terms ta, tb of the other two directions
+// (in increasing order of direction): face_values_dir with CEN = false, VS = false
+template <int D, bool VL>
+__device__ __forceinline__ FacePair adv_face_values (const double * __restrict__ v, int c, int o,
+						     double v0, double unorm, double ta, double tb,
+						     double dt)
+{
+  const double v1 = v[c - o], v2 = v[c + o];
+  const double g = VL ? van_leer_gradient (v0, v1, v2) : center_gradient (v0, v1, v2);
+  const double vl = v0 + GMIN ((1. - unorm)/2., 0.5)*g;
+  const double vr = v0 + GMAX ((- 1. - unorm)/2., -0.5)*g;
+  const double msrc = 0.;                /* gfs_variable_mac_source: no source */
+  const double src = dt*msrc/2.;
+  double dv = ta;
+  dv += tb;
+  FacePair f;
+  f.l = vl + src - dv;
+  f.r = vr + src - dv;
+  return f;
+}
+
+template <bool VL>
+__global__ void __launch_bounds__(GN)
+advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt)
+{
+  // R: right face values, then (after they have been read) the fluxes of the + faces
+  __shared__ double R[3][3][GN];
+  __shared__ double hm[3][3][GX*GZ], hp[3][3][GX*GZ];   // l of the cell before / r of the cell after the tile
+  const TileIdx T;
+  const int n = L.n;
+  const double rn = (double) n, rsize2 = (double) n/2.;
+  const int c = (int) L.idx (T.i, T.j, T.k);
+  const int off[3] = { 1, (int) L.sy, (int) L.sz };
+  const int own = T.own ();
+  double v0[3], fl[3][3], fr[3][3];
+  {
+    const AdvShared S = adv_shared (L, un, c, dt);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const double * vq = v.p[q];
+      v0[q] = vq[c];
+      double t[3];
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++)
+	t[cc] = adv_transverse (vq, c, off[cc], v0[q], S.vtan[cc], dt, rsize2);
+      FacePair f = adv_face_values<0, VL> (vq, c, off[0], v0[q], S.unorm[0], t[1], t[2], dt);
+      fl[q][0] = f.l; fr[q][0] = f.r;
+      f = adv_face_values<1, VL> (vq, c, off[1], v0[q], S.unorm[1], t[0], t[2], dt);
+      fl[q][1] = f.l; fr[q][1] = f.r;
+      f = adv_face_values<2, VL> (vq, c, off[2], v0[q], S.unorm[2], t[0], t[1], dt);
+      fl[q][2] = f.l; fr[q][2] = f.r;
+#pragma unroll
+      for (int d = 0; d < 3; d++)
+	R[q][d][own] = fr[q][d];
+    }
+  }
+  // halo cells, one direction each: waves 0-1 y minus, 2-3 y plus, 4-5 z minus, 6-7 z plus (one cell
+  // per lane); the first 32 lanes also take the x halos
+  {
+    const int h = threadIdx.x;
+    const int grp = h / (GX*GZ), idx = h % (GX*GZ), p = idx % GX, qq = idx / GX;
+    if (grp < 2) {
+      const int ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + (grp ? GY + 1 : 0), blockIdx.z*GZ + qq + 1);
+      const AdvShared S = adv_shared (L, un, ci, dt);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	const double * vq = v.p[q];
+	const double w0 = vq[ci];
+	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
+	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
+	const FacePair f = adv_face_values<1, VL> (vq, ci, off[1], w0, S.unorm[1], ta, tb, dt);
+	if (grp) hp[q][1][idx] = f.r; else hm[q][1][idx] = f.l;
+      }
+    }
+    else {
+      const int ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + qq + 1, blockIdx.z*GZ + (grp == 3 ? GZ + 1 : 0));
+      const AdvShared S = adv_shared (L, un, ci, dt);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	const double * vq = v.p[q];
+	const double w0 = vq[ci];
+	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
+	const double tb = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
+	const FacePair f = adv_face_values<2, VL> (vq, ci, off[2], w0, S.unorm[2], ta, tb, dt);
+	if (grp == 3) hp[q][2][idx] = f.r; else hm[q][2][idx] = f.l;
+      }
+    }
+    if (h < 2*GY*GZ) {
+      const int plus = h >= GY*GZ, hh = h % (GY*GZ), py = hh % GY, qz = hh / GY;
+      const int ci = image<3> (L, blockIdx.x*GX + (plus ? GX + 1 : 0), blockIdx.y*GY + py + 1, blockIdx.z*GZ + qz + 1);
+      const AdvShared S = adv_shared (L, un, ci, dt);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	const double * vq = v.p[q];
+	const double w0 = vq[ci];
+	const double ta = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
+	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
+	const FacePair f = adv_face_values<0, VL> (vq, ci, off[0], w0, S.unorm[0], ta, tb, dt);
+	if (plus) hp[q][0][hh] = f.r; else hm[q][0][hh] = f.l;
+      }
+    }
+  }
+  __syncthreads ();
+  const int t3[3] = { T.tx, T.ty, T.tz }, g3[3] = { GX, GY, GZ };
+  const int so[3] = { 1, GX, GX*GY };
+  const int hi[3] = { T.ty + GY*T.tz, T.tx + GX*T.tz, T.tx + GX*T.ty };
+  // fluxes through the + faces of the own cell (gfs_face_velocity_advection_flux,
+  // src/advection.c:398-435): flux = 1.*un*dt/h; flux *= upwinded value - interpolated g*dt/2.
+  double Fp[3][3], rnb[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; d++)
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+      rnb[q][d] = t3[d] + 1 < g3[d] ? R[q][d][own + so[d]] : hp[q][d][hi[d]];
+  __syncthreads ();          // every right value has been read: R now takes the fluxes
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const double unf = un.p[d][c];
+    const double fu = 1.*unf*dt*rn;          /* /h, h = 1/n a power of two: exact scaling */
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const double upw = upwinded (unf, fl[q][d], rnb[q][d]);
+      double f = fu;
+      f *= upw - face_interp (gm.p[q][c], gm.p[q][c + off[d]])*dt/2.;
+      Fp[q][d] = f;
+      R[q][d][own] = f;
+    }
+  }
+  __syncthreads ();
+  // fluxes through the - faces: from the cell before, or computed here along the - sides of the tile
+  double Fm[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    if (t3[d] > 0) {
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+	Fm[q][d] = R[q][d][own - so[d]];
+    }
+    else {
+      const int a = c - off[d];
+      const double unf = un.p[d][a];
+      const double fu = 1.*unf*dt*rn;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	const double upw = upwinded (unf, hm[q][d][hi[d]], fr[q][d]);
+	double f = fu;
+	f *= upw - face_interp (gm.p[q][a], gm.p[q][c])*dt/2.;
+	Fm[q][d] = f;
+      }
+    }
+  }
+  // the gather in the reference's scatter order (flux_update_kernel)
+  const int i = T.i, j = T.j, k = T.k;
+  const unsigned J = n - j, K = n - k;
+  const bool back_first = __ffs (~J) > __ffs (~K);
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    double acc = 0.;
+    if (i > 1)
+      acc += Fm[q][0];
+    acc -= Fp[q][0];
+    acc -= Fp[q][1];
+    acc -= Fp[q][2];
+    if (back_first) {
+      if (k > 1) acc += Fm[q][2];
+      if (j > 1) acc += Fm[q][1];
+    }
+    else {
+      if (j > 1) acc += Fm[q][1];
+      if (k > 1) acc += Fm[q][2];
+    }
+    if (i == 1)
+      acc += Fm[q][0];
+    if (j == 1)
+      acc += Fm[q][1];
+    if (k == 1)
+      acc += Fm[q][2];
+    double val = v0[q];
+    val += acc/1.;
+    if (gc.p[q])
+      val -= gc.p[q][c]*dt;
+    out.p[q][c] = val;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K19: minimum_mac_cfl / minimum_cfl, src/domain.c:2824-2923: min of (h/|un|)^2 and (h/|u|)^2
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_min (double v)
@@ -1182,6 +1412,25 @@ int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, d
     else          { if (vs) AK (false, false, true); else AK (false, false, false); }
   }
 #undef AK
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// the three velocity components at once (periodic 3-D box, no viscosity)
+int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * const out[3],
+			  double * const un[3], double * const gm[3], double * const gc[3],
+			  double dt, int gradient)
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid (L.n/GX, L.n/GY, L.n/GZ);
+  CPtr3 gcp;
+  for (int c = 0; c < 3; c++) gcp.p[c] = gc ? gc[c] : nullptr;
+  if (gradient)
+    hipLaunchKernelGGL (advect3_tiled_kernel<true>, grid, dim3 (GN), 0, dom->stream, L, c3 (v), m3 (out),
+			c3 (un), c3 (gm), gcp, dt);
+  else
+    hipLaunchKernelGGL (advect3_tiled_kernel<false>, grid, dim3 (GN), 0, dom->stream, L, c3 (v), m3 (out),
+			c3 (un), c3 (gm), gcp, dt);
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
 }
