@@ -95,7 +95,7 @@ int gfship_domain_create (gfship_domain ** out, int dim, int depth, const int si
   hipError_t e = hipStreamCreateWithFlags (&dom->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate (&dom->ev0);
   if (e == hipSuccess) e = hipEventCreate (&dom->ev1);
-  dom->scratch_doubles = 5*1024 + 64;
+  dom->scratch_doubles = 5*8192 + 64;
   if (e == hipSuccess) e = hipMalloc ((void **) &dom->d_scratch, dom->scratch_doubles*sizeof (double));
   if (e == hipSuccess) e = hipHostMalloc ((void **) &dom->h_pinned, 64*sizeof (double), hipHostMallocDefault);
   if (e == hipSuccess) memset (dom->h_pinned, 0, 64*sizeof (double));

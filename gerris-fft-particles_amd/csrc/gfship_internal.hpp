@@ -62,8 +62,9 @@ struct SkewPlan {
 // cell update of the exact-order sweeps: kind 0 = Poisson relax (unit weights), kind 1 =
 // diffusion_relax with the level's uniform face weight w and h2 = h*h
 struct RelaxOp {
-  int kind = 0;
+  int kind = 0;                  // 2: Poisson relax with the face weights f[d].v of the level (wf)
   double w = 1., h2 = 1.;
+  const double * wf[6] = {};
 };
 
 // device-side description of the six sides for the BC kernel
@@ -104,6 +105,8 @@ struct gfship_domain {
   bool no_fused_loop = false;     // one launch per sweep even where the fused loop applies
   bool force_hyperplane = false;  // debug/bench: per-hyperplane launches instead of relax_skew
   bool unit_weights = false;      // gfship_poisson_coefficients called with alpha = NULL
+  bool weighted = false;          // gfship_poisson_coefficients_alpha: the face weights live in wf[]
+  gfship_field wf[6] = {-1, -1, -1, -1, -1, -1};   // GFS_STATE (cell)->f[d].v as Poisson weights, all levels
   gfship::SkewPlan skew[GFSHIP_MAXLEVEL + 1];
   double diff_w[GFSHIP_MAXLEVEL + 1] = {};  // diffusion face weight of each level
   double * cfl_partial = nullptr;   // per-block max |un|, |u| of the fused projection update
@@ -172,6 +175,10 @@ int launch_relax_redblack (gfship_domain * dom, unsigned dimension, int level, d
 			   double * u, const double * rhs, const double * dia);
 int launch_residual (gfship_domain * dom, int level, const double * u, const double * rhs,
 		     const double * dia, double * res);
+int launch_residual_weighted (gfship_domain * dom, int level, const double * u, const double * rhs,
+			      const double * dia, double * res);
+int launch_poisson_weights (gfship_domain * dom, double * const alpha[3]);
+RelaxOp weighted_op (gfship_domain * dom, int level);
 int launch_restrict (gfship_domain * dom, unsigned dimension, int level_coarse, double * v_coarse,
 		     const double * v_fine);
 int launch_prolongate (gfship_domain * dom, int level_coarse, const double * v_coarse,

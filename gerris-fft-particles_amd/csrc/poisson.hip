@@ -16,6 +16,13 @@ static int relax_level (gfship_domain * dom, unsigned dimension, int level, doub
 			Field * u, Field * rhs, Field * dia)
 {
   u->zero[level] = false;
+  if (dom->weighted) {
+    /* face weights from a GfsFunction alpha: the exact-order sweep with the six weights of every
+       cell, one launch per hyperplane (the pipelined kernels carry the constant weight 1) */
+    RelaxOp op = weighted_op (dom, level);
+    return launch_relax_exact (dom, dimension, level, omega, u->lev[level], rhs->lev[level],
+			       dia->lev[level], &op);
+  }
   if (dom->relax_mode == GFSHIP_RELAX_REDBLACK)
     return launch_relax_redblack (dom, dimension, level, omega, u->lev[level], rhs->lev[level],
 				  dia->lev[level]);
@@ -36,6 +43,14 @@ static int relax_loop (gfship_domain * dom, Field * dp, Field * u, unsigned dime
 {
   int r;
   dp->zero[level] = false;
+  if (dom->weighted) {
+    if ((r = launch_bc (dom, u, dp, level, 1))) return r;
+    for (unsigned n = 0; n < nrelax - 1; n++) {
+      if ((r = relax_level (dom, dimension, level, omega, dp, rhs, dia))) return r;
+      if ((r = launch_bc (dom, u, dp, level, 1))) return r;
+    }
+    return relax_level (dom, dimension, level, omega, dp, rhs, dia);
+  }
   if (dom->relax_mode == GFSHIP_RELAX_EXACT && dom->has_external && dom->overlap && nrelax > 1) {
     /* a parallel run with the domain parameter overlap = 1 (the reference's default): the first
        nrelax - 1 sweeps go through gfs_traverse_and_homogeneous_bc -- cells along the MPI sides
@@ -113,6 +128,11 @@ static int residual_and_norm (gfship_domain * dom, double dt, Field * U, Field *
 {
   const int L = dom->depth;
   S->zero[L] = false;
+  if (dom->weighted) {
+    int rr = launch_residual_weighted (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L]);
+    if (rr) return rr;
+    return norm_residual (dom, dt, S, out);
+  }
   const double size = 1./dom->lay[L].n;
   double s[5];
   int r = launch_residual_norm (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L], 1.*size*size, 1., s);
@@ -169,9 +189,45 @@ void gfship_multilevel_params_init (gfship_multilevel_params * par, int dim)
   par->function  = 0;
 }
 
+int gfship_poisson_coefficients_alpha (gfship_domain * dom, const gfship_field alpha[3])
+{
+  GFSHIP_CHECK (dom != nullptr, GFSHIP_EINVAL, "null domain");
+  if (!alpha)
+    return gfship_poisson_coefficients (dom);
+  double * a[3] = { nullptr, nullptr, nullptr };
+  for (int c = 0; c < dom->dim; c++) {
+    Field * F = get_field (dom, alpha[c]);
+    if (!F) return GFSHIP_EINVAL;
+    a[c] = F->lev[dom->depth];
+  }
+  for (int d = 0; d < 2*dom->dim; d++)
+    if (dom->wf[d] < 0) {
+      dom->wf[d] = gfship_field_alloc (dom, -1);
+      if (dom->wf[d] < 0) return dom->wf[d];
+    }
+  for (int d = 0; d < 2*dom->dim; d++)
+    for (int l = 0; l <= dom->depth; l++)
+      dom->fields[dom->wf[d]].zero[l] = false;
+  int r = launch_poisson_weights (dom, a);
+  if (r) return r;
+  dom->weighted = true;
+  dom->unit_weights = true;     /* "coefficients have been set" for the checks of the entry points */
+  return GFSHIP_OK;
+}
+
+int gfship_poisson_weights (gfship_domain * dom, int d, gfship_field * w)
+{
+  GFSHIP_CHECK (dom && w, GFSHIP_EINVAL, "null argument");
+  GFSHIP_CHECK (d >= 0 && d < 2*dom->dim, GFSHIP_EINVAL, "direction %d out of range", d);
+  GFSHIP_CHECK (dom->weighted, GFSHIP_EINVAL, "call gfship_poisson_coefficients_alpha first");
+  *w = dom->wf[d];
+  return GFSHIP_OK;
+}
+
 int gfship_poisson_coefficients (gfship_domain * dom)
 {
   GFSHIP_CHECK (dom != nullptr, GFSHIP_EINVAL, "null domain");
+  dom->weighted = false;
   // alpha = NULL on one uniform box: every leaf face weight is 1.*1.*1./1. (poisson_coeff,
   // src/poisson.c:769-797), every coarse weight the mean of four/two ones, and no cell has
   // exactly one non-boundary neighbour (face_coeff_from_below :826-853), so f[d].v == 1.
@@ -205,6 +261,9 @@ int gfship_residual (gfship_domain * dom, unsigned d, int level,
   for (Field * F : { U, R, D, S })
     if (int r = coarse_flush (dom, F, level)) return r;
   S->zero[level] = false;
+  if (dom->weighted)
+    return launch_residual_weighted (dom, level, U->lev[level], R->lev[level], D->lev[level],
+				     S->lev[level]);
   return launch_residual (dom, level, U->lev[level], R->lev[level], D->lev[level], S->lev[level]);
 }
 
@@ -291,7 +350,7 @@ static int poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
       DP->zero[l] = false;
     /* the coarse end of the cycle (restrictions, relax loops and prolongations of the levels that
        fit in LDS together) in one launch where that applies */
-    const int ctop = coarse_cycle_top (dom, (int) minlevel);
+    const int ctop = dom->weighted ? -1 : coarse_cycle_top (dom, (int) minlevel);
     /* compute residual on non-leafs cells (get_from_below, post-order: finest parents first) */
     for (int l = L - 1; l >= (ctop >= 0 ? ctop + 1 : 0); l--)
       TRY (launch_restrict (dom, p->dimension, l, S->lev[l], S->lev[l + 1]));
@@ -321,6 +380,8 @@ static int poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
   /* compute new residual on leaf cells */
   if (norm)
     TRY (residual_and_norm (dom, dt, U, R, D, S, norm));
+  else if (dom->weighted)
+    TRY (launch_residual_weighted (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L]));
   else
     TRY (launch_residual (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L]));
 #undef TRY
@@ -359,8 +420,12 @@ int gfship_poisson_solve (gfship_domain * dom, gfship_multilevel_params * par,
     const Layout & Ly = dom->lay[L];
     double size = 1./Ly.n;
     S->zero[L] = false;
-    if ((r = launch_residual_norm (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L], 1.*size*size,
-				   1., nullptr)))
+    if (dom->weighted) {
+      if ((r = launch_residual_weighted (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L]))) return r;
+      if ((r = launch_norm_async (dom, L, S->lev[L], 1.*size*size, 1.))) return r;
+    }
+    else if ((r = launch_residual_norm (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L], 1.*size*size,
+					1., nullptr)))
       return r;
   }
   else {

@@ -6,6 +6,7 @@
 // (gfs_poisson_coefficients with alpha = NULL on a uniform single box: every f[d].v == 1.).
 #include "gfship_internal.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace gfship {
 
@@ -17,11 +18,29 @@ namespace gfship {
 // same-level branch (src/fluid.c:1361-1366: g->a = w; g->b = w*u_nb) for the uniform face
 // weight w of the level and h2 = h*h:  a = dia*h*h ; g.a = 1. + g.a/a ; u = (g.b/a + res)/g.a.
 // ---------------------------------------------------------------------------------------------
+struct W6 { const double * p[6]; };   // the six face weights f[d].v of a level (OP == 2)
+
 template <int DIM, int OP>
 __device__ __forceinline__ double relax_value (const double * __restrict__ u, long c, long sy, long sz,
 					       double rhs, double dia, unsigned dimension,
-					       double omega, double w, double h2)
+					       double omega, double w, double h2, const W6 * wf = nullptr)
 {
+  if (OP == 2) {
+    // relax / relax2D with the face weights of the cell (src/poisson.c:507-557, gfs_face_weighted_
+    // gradient's same-level branch src/fluid.c:858-864: g.a = w, g.b = w*u_nb)
+    double a = dia, b = 0.;
+    { const double g = wf->p[0][c]; a += g; b += g*u[c + 1]; }
+    { const double g = wf->p[1][c]; a += g; b += g*u[c - 1]; }
+    { const double g = wf->p[2][c]; a += g; b += g*u[c + sy]; }
+    { const double g = wf->p[3][c]; a += g; b += g*u[c - sy]; }
+    if (DIM == 3) {
+      { const double g = wf->p[4][c]; a += g; b += g*u[c + sz]; }
+      { const double g = wf->p[5][c]; a += g; b += g*u[c - sz]; }
+    }
+    if (dimension == 2)
+      return a != 0. ? (1. - omega)*u[c] + omega*(b - rhs)/a : 0.;
+    return a != 0. ? (b - rhs)/a : 0.;
+  }
   if (OP == 1) {
     double ga = 0., gb = 0.;
     ga += w; gb += w*u[c + 1];
@@ -61,7 +80,7 @@ template <int DIM, int OP>
 __global__ void __launch_bounds__(256)
 relax_hyperplane_kernel (Layout L, int plane, unsigned dimension, double omega, double w, double h2,
 			 double * __restrict__ u, const double * __restrict__ rhs,
-			 const double * __restrict__ dia)
+			 const double * __restrict__ dia, W6 wf)
 {
   int n = L.n;
   int t = blockIdx.x*blockDim.x + threadIdx.x;
@@ -78,7 +97,7 @@ relax_hyperplane_kernel (Layout L, int plane, unsigned dimension, double omega, 
   }
   if (I < 0 || I >= n) return;
   long c = L.idx (I + 1, n - J, DIM == 3 ? n - K : 0);
-  u[c] = relax_value<DIM, OP> (u, c, L.sy, L.sz, rhs[c], dia[c], dimension, omega, w, h2);
+  u[c] = relax_value<DIM, OP> (u, c, L.sy, L.sz, rhs[c], dia[c], dimension, omega, w, h2, &wf);
 }
 
 int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, double omega,
@@ -92,11 +111,13 @@ int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, doub
   int nthreads = dom->dim == 3 ? n*n : n;
   int block = 256;
   int grid = (nthreads + block - 1)/block;
+  W6 wf;
+  for (int d = 0; d < 6; d++) wf.p[d] = op ? op->wf[d] : nullptr;
   for (int p = 0; p < nplanes; p++) {
 #define HP_LAUNCH(D, O) hipLaunchKernelGGL ((relax_hyperplane_kernel<D, O>), dim3 (grid), dim3 (block), \
-					    0, dom->stream, L, p, dimension, omega, w, h2, u, rhs, dia)
-    if (dom->dim == 3) { if (kind) HP_LAUNCH (3, 1); else HP_LAUNCH (3, 0); }
-    else               { if (kind) HP_LAUNCH (2, 1); else HP_LAUNCH (2, 0); }
+					    0, dom->stream, L, p, dimension, omega, w, h2, u, rhs, dia, wf)
+    if (dom->dim == 3) { if (kind == 2) HP_LAUNCH (3, 2); else if (kind) HP_LAUNCH (3, 1); else HP_LAUNCH (3, 0); }
+    else               { if (kind == 2) HP_LAUNCH (2, 2); else if (kind) HP_LAUNCH (2, 1); else HP_LAUNCH (2, 0); }
 #undef HP_LAUNCH
   }
   GFSHIP_HIP (hipGetLastError ());
@@ -559,6 +580,146 @@ int launch_residual (gfship_domain * dom, int level, const double * u, const dou
   return GFSHIP_OK;
 }
 
+// K2 with the face weights of the cells (residual_set, src/poisson.c:634-655)
+template <int DIM>
+__global__ void __launch_bounds__(256)
+residual_weighted_kernel (Layout L, const double * __restrict__ u, const double * __restrict__ rhs,
+			  const double * __restrict__ dia, double * __restrict__ res, W6 wf)
+{
+  CELL_LOOP_PROLOGUE (L);
+  double a = dia[c], b = 0.;
+  { const double g = wf.p[0][c]; a += g; b += g*u[c + 1]; }
+  { const double g = wf.p[1][c]; a += g; b += g*u[c - 1]; }
+  { const double g = wf.p[2][c]; a += g; b += g*u[c + L.sy]; }
+  { const double g = wf.p[3][c]; a += g; b += g*u[c - L.sy]; }
+  if (DIM == 3) {
+    { const double g = wf.p[4][c]; a += g; b += g*u[c + L.sz]; }
+    { const double g = wf.p[5][c]; a += g; b += g*u[c - L.sz]; }
+  }
+  res[c] = rhs[c] - (b - u[c]*a);
+}
+
+RelaxOp weighted_op (gfship_domain * dom, int level)
+{
+  RelaxOp op;
+  op.kind = 2;
+  for (int d = 0; d < 2*dom->dim; d++)
+    op.wf[d] = dom->fields[dom->wf[d]].lev[level];
+  return op;
+}
+
+int launch_residual_weighted (gfship_domain * dom, int level, const double * u, const double * rhs,
+			      const double * dia, double * res)
+{
+  const Layout & L = dom->lay[level];
+  dim3 grid, block;
+  cell_grid (L, &grid, &block);
+  RelaxOp op = weighted_op (dom, level);
+  W6 wf;
+  for (int d = 0; d < 6; d++) wf.p[d] = op.wf[d];
+  if (dom->dim == 3)
+    hipLaunchKernelGGL (residual_weighted_kernel<3>, grid, block, 0, dom->stream, L, u, rhs, dia, res, wf);
+  else
+    hipLaunchKernelGGL (residual_weighted_kernel<2>, grid, block, 0, dom->stream, L, u, rhs, dia, res, wf);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// K8: gfs_poisson_coefficients (src/poisson.c:856-901) with a GfsFunction alpha given at the faces.
+//   leaves (reset_coeff :756-767 + poisson_coeff :769-797): every face adds v = lambda2*alpha*
+//     face_fraction/metric = 1.*alpha*1./1. once to f[d].v of the cells on both sides, i.e.
+//     f[d].v = 0. + v; alpha[c] holds the face values in the layout of a level array (entry of a
+//     cell = its + face along c, the entry in front of the first cell = its - face);
+//   non-leaf cells, finest first (face_coeff_from_below :826-853): the mean over the children on
+//     side d in child-id order (ftt_cell_children_direction, src/ftt.h:322-341), then all six
+//     zeroed if exactly one direction has a non-zero weight towards a cell of the box.
+struct A3 { const double * p[3]; };
+struct M6 { double * p[6]; };
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+weights_leaf_kernel (Layout L, A3 alpha, M6 w)
+{
+  CELL_LOOP_PROLOGUE (L);
+  const long off[3] = { 1, L.sy, L.sz };
+#pragma unroll
+  for (int cc = 0; cc < DIM; cc++) {
+    double v = 1.*alpha.p[cc][c]*1./1.;
+    double f = 0.;
+    f += v;
+    w.p[2*cc][c] = f;
+    v = 1.*alpha.p[cc][c - off[cc]]*1./1.;
+    f = 0.;
+    f += v;
+    w.p[2*cc + 1][c] = f;
+  }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+weights_coarse_kernel (Layout Lc, Layout Lf, M6 wc, W6 wfine)
+{
+  CELL_LOOP_PROLOGUE (Lc);
+  constexpr int ND = DIM == 3 ? 4 : 2;
+  const int cdir3[6][4] = {{1,3,5,7},{0,2,4,6},{0,1,4,5},{2,3,6,7},{0,1,2,3},{4,5,6,7}};
+  const int cdir2[4][2] = {{1,3},{0,2},{0,1},{2,3}};
+  const int n = Lc.n;
+  const int ijk[3] = { i, j, k };
+  double s6[6];
+  unsigned neighbors = 0;
+#pragma unroll
+  for (int d = 0; d < 2*DIM; d++) {
+    double s = 0.;
+#pragma unroll
+    for (int m = 0; m < ND; m++) {
+      const int id = DIM == 3 ? cdir3[d][m] : cdir2[d][m];
+      const int ci = 2*i - 1 + (id & 1);
+      const int cj = 2*j - 1 + ((id & 2) ? 0 : 1);
+      const int ck = DIM == 3 ? 2*k - 1 + ((id & 4) ? 0 : 1) : 0;
+      s += wfine.p[d][Lf.idx (ci, cj, ck)];
+    }
+    s /= ND;
+    s6[d] = s;
+    const bool at_side = (d & 1) ? ijk[d/2] == 1 : ijk[d/2] == n;
+    if (s != 0. && !at_side)
+      neighbors++;
+  }
+#pragma unroll
+  for (int d = 0; d < 2*DIM; d++)
+    wc.p[d][c] = neighbors == 1 ? 0. : s6[d];
+}
+
+int launch_poisson_weights (gfship_domain * dom, double * const alpha[3])
+{
+  const int Ld = dom->depth;
+  {
+    const Layout & L = dom->lay[Ld];
+    dim3 grid, block;
+    cell_grid (L, &grid, &block);
+    A3 a;
+    M6 w;
+    for (int c = 0; c < 3; c++) a.p[c] = c < dom->dim ? alpha[c] : nullptr;
+    for (int d = 0; d < 6; d++) w.p[d] = d < 2*dom->dim ? dom->fields[dom->wf[d]].lev[Ld] : nullptr;
+    if (dom->dim == 3) hipLaunchKernelGGL (weights_leaf_kernel<3>, grid, block, 0, dom->stream, L, a, w);
+    else               hipLaunchKernelGGL (weights_leaf_kernel<2>, grid, block, 0, dom->stream, L, a, w);
+  }
+  for (int l = Ld - 1; l >= 0; l--) {
+    const Layout & Lc = dom->lay[l], & Lf = dom->lay[l + 1];
+    dim3 grid, block;
+    cell_grid (Lc, &grid, &block);
+    M6 wc;
+    W6 wfine;
+    for (int d = 0; d < 6; d++) {
+      wc.p[d] = d < 2*dom->dim ? dom->fields[dom->wf[d]].lev[l] : nullptr;
+      wfine.p[d] = d < 2*dom->dim ? dom->fields[dom->wf[d]].lev[l + 1] : nullptr;
+    }
+    if (dom->dim == 3) hipLaunchKernelGGL (weights_coarse_kernel<3>, grid, block, 0, dom->stream, Lc, Lf, wc, wfine);
+    else               hipLaunchKernelGGL (weights_coarse_kernel<2>, grid, block, 0, dom->stream, Lc, Lf, wc, wfine);
+  }
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
 // K3: get_from_below_3D / _2D, src/poisson.c:1044-1068: sum of the children in child-id order
 // (child id bit0 -> +x, bit1 -> -y, bit2 -> -z), halved when dimension == 3.
 template <int DIM>
@@ -878,7 +1039,15 @@ int launch_residual_norm (gfship_domain * dom, int level, const double * u, cons
   }
   long nrows = L.dim == 3 ? (long) L.n*L.n : L.n;
   int block = L.n >= 256 ? 256 : L.n >= 128 ? 128 : 64;
-  int nblocks = (int) (nrows > 1024 ? 1024 : nrows);   /* d_scratch holds 5*1024 partials */
+  /* d_scratch holds 5*8192 partials; GFSHIP_RN_BLOCKS: tuning knob (4096 = 16 workgroups per CU:
+     the 7-point reads of a row keep more rows in flight than the norm alone needs) */
+  static int rn_blocks = 0;
+  if (!rn_blocks) {
+    const char * e = getenv ("GFSHIP_RN_BLOCKS");
+    rn_blocks = e ? atoi (e) : 4096;
+    if (rn_blocks < 64 || rn_blocks > 8192) rn_blocks = 4096;
+  }
+  int nblocks = (int) (nrows > rn_blocks ? rn_blocks : nrows);
   double * partial = dom->d_scratch;
   double * result = out ? dom->h_pinned : dom->h_pinned + 8;
   if (dom->dim == 3)

@@ -68,6 +68,8 @@ SIGNATURES = {
     "gfship_homogeneous_bc": (_i, [_vp, _i, _i, _i]),
     "gfship_multilevel_params_init": (None, [C.POINTER(MultilevelParams), _i]),
     "gfship_poisson_coefficients": (_i, [_vp]),
+    "gfship_poisson_coefficients_alpha": (_i, [_vp, _pi]),
+    "gfship_poisson_weights": (_i, [_vp, _i, _pi]),
     "gfship_relax": (_i, [_vp, _u, _i, _d, _i, _i, _i]),
     "gfship_residual": (_i, [_vp, _u, _i, _i, _i, _i, _i]),
     "gfship_norm_residual": (_i, [_vp, _d, _i, C.POINTER(Norm)]),
@@ -292,6 +294,21 @@ class Domain:
 
     def poisson_coefficients(self):
         _check(lib().gfship_poisson_coefficients(self.ptr))
+
+    def poisson_coefficients_alpha(self, alpha):
+        """alpha: dim Variables holding the face values of the GfsFunction alpha"""
+        h = (C.c_int * 3)(*([v.h for v in alpha] + [-1] * (3 - len(alpha))))
+        _check(lib().gfship_poisson_coefficients_alpha(self.ptr, h))
+
+    def poisson_weight(self, d, level=None):
+        """f[d].v of the cells of a level (host array with ghosts)"""
+        w = C.c_int()
+        _check(lib().gfship_poisson_weights(self.ptr, d, C.byref(w)))
+        v = Variable.__new__(Variable)
+        v.dom, v.h = self, w.value
+        a = v.download(level)
+        v.h = None
+        return a
 
     def relax(self, u, rhs, dia, level=None, omega=1., d=None):
         level = self.depth if level is None else level

@@ -116,6 +116,17 @@ void gfship_multilevel_params_init (gfship_multilevel_params * par, int dim);
 						/* gfs_multilevel_params_init, src/poisson.c:70-89 */
 /* gfs_poisson_coefficients (src/poisson.c:856-901) with alpha = NULL */
 int  gfship_poisson_coefficients (gfship_domain * dom);
+/* gfs_poisson_coefficients (src/poisson.c:856-901) with a GfsFunction alpha (the inverse of the
+   density: the equation is div (alpha grad p) = ...): alpha[c] holds gfs_function_face_value (alpha,
+   face) of the leaf faces normal to c in the layout of a variable (the entry of a cell is its + face
+   along c, the ghost entry in front of the first cell its - face).  Sets f[d].v of every cell of
+   every level (poisson_coeff :769-797, face_coeff_from_below :826-853 with its one-neighbour rule);
+   relax, residual, cycle and solve then use them (exact sweep order, one launch per hyperplane: the
+   pipelined kernels are for the constant-density case).  alpha = NULL: gfship_poisson_coefficients.
+   The projections of a gfship_sim keep alpha = NULL (GfsPhysicalParams { alpha = ... } is not
+   supported at that level).  gfship_poisson_weights: the variable holding f[d].v, d = 0 .. 2 dim - 1. */
+int  gfship_poisson_coefficients_alpha (gfship_domain * dom, const gfship_field alpha[3]);
+int  gfship_poisson_weights (gfship_domain * dom, int d, gfship_field * w);
 /* gfs_relax, src/poisson.c:604-632: one in-place sweep of level `level` */
 int  gfship_relax (gfship_domain * dom, unsigned d, int level, double omega,
 		   gfship_field u, gfship_field rhs, gfship_field dia);

@@ -122,6 +122,7 @@ void       go_homogeneous_bc (GoField * ov, GoField * v, int level);  /* gfs_dom
 void       go_domain_set_hooks (GoDomain * dom, GoExchangeFunc ex, void * ex_ctx,
 				GoReduceFunc red, void * red_ctx);
 void       go_domain_set_overlap (GoDomain * dom, int overlap);
+double *   go_domain_weight (GoDomain * dom, int d, int level);
 size_t     go_snapshot_tree_bytes (const GoDomain * dom, int nvars);
 size_t     go_snapshot_tree_write (const GoDomain * dom, int nvars, GoField ** f, unsigned char * buf);
 void       go_cell_pos (const GoDomain * dom, int level, int i, int j, int k, double pos[3]);
@@ -129,6 +130,7 @@ void       go_cell_pos (const GoDomain * dom, int level, int i, int j, int k, do
 /* ---- Poisson (go_poisson.c) ---- */
 void   go_multilevel_params_init (GoMultilevelParams * par, int dim);
 void   go_poisson_coefficients (GoDomain * dom);                      /* alpha = NULL (unity) */
+void   go_poisson_coefficients_alpha (GoDomain * dom, double * const alpha[3]);
 void   go_relax (GoDomain * dom, unsigned d, int level, double omega,
 		 GoField * u, GoField * rhs, GoField * dia);
 void   go_residual (GoDomain * dom, unsigned d, int level,

@@ -108,6 +108,12 @@ void go_domain_set_hooks (GoDomain * dom, GoExchangeFunc ex, void * ex_ctx,
   dom->reduce = red; dom->reduce_ctx = red_ctx;
 }
 
+/* GFS_STATE (cell)->f[d].v of the cells of a level, as set by go_poisson_coefficients* */
+double * go_domain_weight (GoDomain * dom, int d, int level)
+{
+  return dom->w[d][level];
+}
+
 /* the domain parameter `overlap' of a parallel run (domain.c:225,682; default 1 there, 0 here):
    the sweeps of relax_loop visit the cells along GO_SIDE_EXTERNAL sides first */
 void go_domain_set_overlap (GoDomain * dom, int overlap)

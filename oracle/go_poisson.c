@@ -35,6 +35,14 @@ void go_multilevel_params_init (GoMultilevelParams * par, int dim)
  * its d = 0,2,4 faces, then the cells along sides d = 1,3,5 with their d face. */
 void go_poisson_coefficients (GoDomain * dom)
 {
+  go_poisson_coefficients_alpha (dom, NULL);
+}
+
+/* The same with a GfsFunction alpha: alpha[c] holds gfs_function_face_value (alpha, face) of the
+ * leaf faces normal to c, one array per component in the layout of a level array: the entry of
+ * cell (i,j,k) is its + face along c, the ghost entry in front of the first cell its - face. */
+void go_poisson_coefficients_alpha (GoDomain * dom, double * const alpha[3])
+{
   int dim = dom->dim, L = dom->depth;
   for (int l = 0; l <= L; l++)
     for (int d = 0; d < 2*dim; d++)
@@ -45,7 +53,8 @@ void go_poisson_coefficients (GoDomain * dom)
   for (size_t q = 0; q < ncell; q++) {
     int c = order[q];
     for (int d = 0; d < 2*dim; d += 2) {
-      double v = 1.*1.*1./1.;
+      double a = alpha ? alpha[d/2][c] : 1.;
+      double v = 1.*a*1./1.;
       dom->w[d][L][c] += v;
       dom->w[d + 1][L][c + dom->off[L][d]] += v;
     }
@@ -53,7 +62,8 @@ void go_poisson_coefficients (GoDomain * dom)
   for (int d = 1; d < 2*dim; d += 2)
     for (int q = 0; q < dom->nborder[L]; q++) {
       int c = dom->border[L][d][q];
-      double v = 1.*1.*1./1.;
+      double a = alpha ? alpha[d/2][c + dom->off[L][d]] : 1.;
+      double v = 1.*a*1./1.;
       dom->w[d][L][c] += v;
       dom->w[d - 1][L][c + dom->off[L][d]] += v;
     }

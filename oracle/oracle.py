@@ -140,6 +140,23 @@ class Domain:
         assert L.go_snapshot_tree_write(self.ptr, n, arr, buf) == size
         return buf.raw
 
+    def poisson_coefficients_alpha(self, alpha):
+        """gfs_poisson_coefficients with a GfsFunction alpha given as face values: alpha = dim Fields"""
+        f = lib().go_poisson_coefficients_alpha
+        f.restype, f.argtypes = None, [C.c_void_p, C.POINTER(C.POINTER(C.c_double))]
+        arr = (C.POINTER(C.c_double) * 3)()
+        for c, a in enumerate(alpha):
+            arr[c] = lib().go_field_level(a.ptr, self.depth)
+        f(self.ptr, arr)
+
+    def weight(self, d, l=None):
+        """f[d].v of the cells of level l (array with ghosts)"""
+        l = self.depth if l is None else l
+        f = lib().go_domain_weight
+        f.restype, f.argtypes = C.POINTER(C.c_double), [C.c_void_p, C.c_int, C.c_int]
+        n = (1 << l) + 2
+        return np.ctypeslib.as_array(f(self.ptr, d, l), shape=(n,) * self.dim)
+
     def set_overlap(self, overlap):
         """the domain parameter `overlap' of a parallel run (src/domain.c:225,682)"""
         f = lib().go_domain_set_overlap

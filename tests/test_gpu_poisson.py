@@ -505,3 +505,88 @@ def test_one_wave_per_tile_loop_kernel_bit_exact(monkeypatch, level, kind):
         assert _faces_equal(f["u"][0].leaf(), f["u"][1].download(), dim)
         assert np.array_equal(_interior(f["res"][0].leaf(), dim),
                               _interior(f["res"][1].download(), dim))
+
+
+# ---------------------------------------------------------------------------------------------
+# K8: gfs_poisson_coefficients with a GfsFunction alpha (variable density), src/poisson.c:756-901
+# ---------------------------------------------------------------------------------------------
+
+def _alpha_pair(od, gd, rng, kind):
+    """face values of alpha as oracle Fields and device Variables (same arrays, ghosts included:
+    the ghost entry in front of the first cell is its - face)"""
+    dim, level = od.dim, od.depth
+    oa, ga = [], []
+    for c in range(dim):
+        of, gf = od.field(), gd.variable()
+        a = 0.5 + rng.random(of.leaf().shape)
+        if kind == "periodic":
+            # a periodic alpha: the - face of the first cell is the + face of the last one
+            ax = dim - 1 - c
+            sl0, sln = [slice(None)] * dim, [slice(None)] * dim
+            sl0[ax], sln[ax] = 0, -2
+            a[tuple(sl0)] = a[tuple(sln)]
+        of.leaf()[...] = a
+        gf.upload(a)
+        oa.append(of)
+        ga.append(gf)
+    return oa, ga
+
+
+@pytest.mark.parametrize("dim,level,kind", [(2, 5, "dirichlet"), (2, 4, "periodic"), (3, 4, "dirichlet"),
+                                            (3, 4, "periodic"), (3, 3, "mixed")])
+def test_poisson_coefficients_with_alpha_bit_exact(dim, level, kind):
+    """the face weights of every level (leaf faces from alpha, coarser cells by face_coeff_from_below),
+    then sweeps, residual, V-cycles and a solve with them: everything equal to the oracle's bits"""
+    L = O.lib()
+    side, bck = SIDES[kind]
+    rng = np.random.default_rng(77 + 10 * dim + level)
+    od, gd = _pair(dim, level, side)
+    oa, ga = _alpha_pair(od, gd, rng, kind)
+    od.poisson_coefficients_alpha(oa)
+    gd.poisson_coefficients_alpha(ga)
+    inner = (slice(1, -1),) * dim
+    for l in range(level + 1):
+        for d in range(2 * dim):
+            assert np.array_equal(od.weight(d, l)[inner], gd.poisson_weight(d, l)[inner]), (l, d)
+    assert not np.array_equal(od.weight(0, level)[inner], np.ones_like(od.weight(0, level)[inner]))
+    f = _rand_fields(od, gd, ["u", "rhs", "dia", "res"], rng)
+    f["dia"][0].leaf()[...] = 0.
+    f["dia"][1].fill(0.)
+    n = 1 << level
+    for d in range(2 * dim):
+        val = rng.standard_normal(n ** (dim - 1))
+        f["u"][0].set_bc(d, bck, val)
+        f["u"][1].set_bc(d, bck, val)
+    L.go_bc(f["u"][0].ptr, f["u"][0].ptr, level)
+    gd.bc(f["u"][1])
+    for _ in range(2):
+        L.go_relax(od.ptr, dim, level, 1., f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr)
+        gd.relax(f["u"][1], f["rhs"][1], f["dia"][1])
+        assert np.array_equal(f["u"][0].leaf()[inner], f["u"][1].download()[inner])
+    L.go_residual(od.ptr, dim, level, f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr,
+                  f["res"][0].ptr)
+    gd.residual(f["u"][1], f["rhs"][1], f["dia"][1], f["res"][1])
+    assert np.array_equal(f["res"][0].leaf()[inner], f["res"][1].download()[inner])
+    op, gp = od.params(), gd.params()
+    for p in (op, gp):
+        p.depth = level
+    for _ in range(2):
+        L.go_poisson_cycle(od.ptr, C.byref(op), f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr,
+                           f["res"][0].ptr)
+        gd.poisson_cycle(gp, f["u"][1], f["rhs"][1], f["dia"][1], f["res"][1])
+        assert _faces_equal(f["u"][0].leaf(), f["u"][1].download(), dim)
+        assert np.array_equal(f["res"][0].leaf()[inner], f["res"][1].download()[inner])
+    op.tolerance = gp.tolerance = 1e-30
+    op.nitermin = gp.nitermin = op.nitermax = gp.nitermax = 3
+    L.go_poisson_solve(od.ptr, C.byref(op), f["u"][0].ptr, f["rhs"][0].ptr, f["res"][0].ptr,
+                       f["dia"][0].ptr, 0.7)
+    gd.poisson_solve(gp, f["u"][1], f["rhs"][1], f["res"][1], f["dia"][1], 0.7)
+    assert gp.niter == op.niter == 3
+    assert gp.residual.infty == op.residual.infty
+    assert np.array_equal(f["u"][0].leaf()[inner], f["u"][1].download()[inner])
+    # back to alpha = NULL: the unit-weight kernels again
+    L.go_poisson_coefficients(od.ptr)
+    gd.poisson_coefficients()
+    L.go_relax(od.ptr, dim, level, 1., f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr)
+    gd.relax(f["u"][1], f["rhs"][1], f["dia"][1])
+    assert np.array_equal(f["u"][0].leaf()[inner], f["u"][1].download()[inner])
