@@ -237,7 +237,7 @@ int  skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat
 		    unsigned nrelax, float * ms = nullptr, const Field * ubc = nullptr);
 int  skew_time_loop (gfship_domain * dom, int level, Field * u, const double * rhs,
 		     const double * dia, bool dia_zero, unsigned nrelax, int reps,
-		     double * ms_per_loop, int * fused);
+		     double * ms_per_loop, int * fused, double * ms_inclusive = nullptr);
 int  skew_check_error (gfship_domain * dom);
 void skew_dump_stats (gfship_domain * dom, int level);
 int  skew_time_sweeps (gfship_domain * dom, int level, Field * u, const double * rhs,

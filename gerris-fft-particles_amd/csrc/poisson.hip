@@ -511,6 +511,14 @@ int gfship_time_relax_loop (gfship_domain * dom, int level, gfship_field u, gfsh
 			    gfship_field dia, unsigned nrelax, int reps, double * ms_per_loop,
 			    int * fused)
 {
+  return gfship_time_relax_loop_inclusive (dom, level, u, rhs, dia, nrelax, reps, ms_per_loop, fused,
+					   nullptr);
+}
+
+int gfship_time_relax_loop_inclusive (gfship_domain * dom, int level, gfship_field u, gfship_field rhs,
+				      gfship_field dia, unsigned nrelax, int reps,
+				      double * ms_per_loop, int * fused, double * ms_inclusive)
+{
   Field * U = get_field (dom, u), * R = get_field (dom, rhs), * D = get_field (dom, dia);
   if (!U || !R || !D || !ms_per_loop || !fused || reps <= 0 || nrelax == 0) return GFSHIP_EINVAL;
   GFSHIP_CHECK (level >= 0 && level <= dom->depth, GFSHIP_EINVAL, "level %d out of range", level);
@@ -519,7 +527,7 @@ int gfship_time_relax_loop (gfship_domain * dom, int level, gfship_field u, gfsh
 		"the pipelined sweep does not run on this level / in this mode");
   U->zero[level] = false;
   int r = skew_time_loop (dom, level, U, R->lev[level], D->lev[level], D->zero[level], nrelax,
-			  reps, ms_per_loop, fused);
+			  reps, ms_per_loop, fused, ms_inclusive);
   if (r == GFSHIP_OK)
     r = skew_check_error (dom);
   return r;

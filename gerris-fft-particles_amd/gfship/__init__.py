@@ -83,6 +83,7 @@ SIGNATURES = {
     "gfship_diffusion": (_i, [_vp, C.POINTER(MultilevelParams), _i, _i, _i]),
     "gfship_time_relax": (_i, [_vp, _u, _i, _i, _i, _i, _i, _pd]),
     "gfship_time_relax_loop": (_i, [_vp, _i, _i, _i, _i, _u, _i, _pd, _pi]),
+    "gfship_time_relax_loop_inclusive": (_i, [_vp, _i, _i, _i, _i, _u, _i, _pd, _pi, _pd]),
     "gfship_sim_create": (_i, [C.POINTER(_vp), _vp]),
     "gfship_sim_destroy": (None, [_vp]),
     "gfship_sim_variable": (_i, [_vp, _i, _i]),
@@ -357,6 +358,14 @@ class Domain:
         _check(lib().gfship_time_relax_loop(self.ptr, level, u.h, rhs.h, dia.h, nrelax, reps,
                                             C.byref(ms), C.byref(fused)))
         return ms.value, bool(fused.value)
+
+    def time_relax_loop_inclusive(self, u, rhs, dia, nrelax=4, level=None, reps=5):
+        """(ms of the sweep kernels alone, fused?, ms of the whole loop as a V-cycle pays for it)"""
+        level = self.depth if level is None else level
+        ms, fused, incl = C.c_double(), C.c_int(), C.c_double()
+        _check(lib().gfship_time_relax_loop_inclusive(self.ptr, level, u.h, rhs.h, dia.h, nrelax, reps,
+                                                      C.byref(ms), C.byref(fused), C.byref(incl)))
+        return ms.value, bool(fused.value), incl.value
 
     def energy_spectra(self, comps):
         """GfsOutputEnergySpectra of the variables comps (U, V[, W]): (k, Ek, Etot) as the reference

@@ -435,6 +435,13 @@ int  gfship_time_relax_loop (gfship_domain * dom, int level, gfship_field u, gfs
 			     gfship_field dia, unsigned nrelax, int reps, double * ms_per_loop,
 			     int * fused);
 
+/* the same, and in *ms_inclusive the time of everything such a loop costs inside a V-cycle: BC
+   kernel, copy into the skewed layout, arming of the hand-off granules, the sweeps, the ghost planes
+   of the last BC application, copy back (HIP events on the domain's stream around all of it) */
+int  gfship_time_relax_loop_inclusive (gfship_domain * dom, int level, gfship_field u, gfship_field rhs,
+				       gfship_field dia, unsigned nrelax, int reps,
+				       double * ms_per_loop, int * fused, double * ms_inclusive);
+
 #ifdef __cplusplus
 }
 #endif
