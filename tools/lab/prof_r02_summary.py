@@ -47,7 +47,7 @@ by_level = {}
 for r in csv.DictReader(open(trace)):
     if "relax_skew_loop_kernel" not in r["Kernel_Name"]:
         continue
-    grid = int(r["Grid_Size"])
+    grid = int(r["Grid_Size_X"])
     tiles = grid // 384
     n = int(round(tiles ** 0.5)) * 16
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
