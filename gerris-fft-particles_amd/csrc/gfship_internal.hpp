@@ -100,6 +100,7 @@ struct gfship_domain {
   bool wave_loop = false;         // fused relax loops by the experimental one-wave-per-tile kernel (GFSHIP_WAVE_LOOP=1)
   bool xcd_place = false;         // XCD-aware tile placement in the loop kernel (experiment, GFSHIP_XCD_PLACE=1)
   bool skew_old = false;          // single sweeps by the older four-wave kernel (GFSHIP_SKEW_OLD)
+  bool patch = true;              // 2 x 2 lines per lane (relax_patch_loop.hip); GFSHIP_SKEW_LINES=1: one line per thread
   bool no_fused_godunov = false;  // face-value arrays + separate kernels even on periodic boxes
   bool no_fused_godunov3 = false; // one launch per velocity component instead of the three at once (GFSHIP_NO_ADVECT3)
   bool no_fused_loop = false;     // one launch per sweep even where the fused loop applies
@@ -239,6 +240,11 @@ int  skew_time_loop (gfship_domain * dom, int level, Field * u, const double * r
 		     const double * dia, bool dia_zero, unsigned nrelax, int reps,
 		     double * ms_per_loop, int * fused, double * ms_inclusive = nullptr);
 int  skew_check_error (gfship_domain * dom);
+// relax_patch_loop.hip
+int  patch_resident_per_cu ();
+int  patch_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u, const double * rhs,
+		 const double * dia);
+int  patch_unpack (gfship_domain * dom, int level, SkewPlan * S, double * u, double * add_into);
 void skew_dump_stats (gfship_domain * dom, int level);
 int  skew_time_sweeps (gfship_domain * dom, int level, Field * u, const double * rhs,
 		       const double * dia, bool dia_zero, int reps, double * ms_per_sweep);

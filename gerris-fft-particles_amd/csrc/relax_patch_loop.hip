@@ -1,0 +1,602 @@
+// relax_patch_loop.hip -- the pipelined exact-order relax loop with 2 x 2 lines per lane.
+//
+// Same schedule, same granule protocol and same arithmetic per cell as relax_skew_loop.hip (read
+// that file first); what changes is who owns what inside a tile.  There a tile of 16 x 16 lines is
+// 256 threads, one line each, and line (a, b) runs a + b steps behind line (0, 0): a tile's own
+// skew is 30 steps, and every hop of the chain of tiles across the box -- which is what the loop
+// waits for, tools/lab + DESIGN.md 5 -- carries 16 of them.  Here ONE wave computes the tile: lane
+// (A, B), A, B = 0..7, owns the lines (2A + da, 2B + db), da, db = 0, 1, and computes their four
+// cells of one I per step, in the order (0,0), (1,0), (0,1), (1,1): inside the patch the new values
+// it needs are the ones it has just computed, in registers.  Lane (A, B) runs A + B steps behind
+// lane (0, 0): the tile's skew is 14 steps, a hop carries 8.  A step costs about what it cost before
+// (it is bounded by what one CU streams, 6 KB per step, and by the issue of one wave; the four
+// SIMDs no longer meet at a barrier with a quarter of the work each), so the chain is nearly twice
+// as fast.  The memory side gains too: a lane's four cells of a row are 32 contiguous bytes
+// (two 16-byte accesses per array and step instead of four 8-byte ones: rows are 2 KB as before).
+//
+// Layout (patch-skewed): element (I, a, b) of tile T sits at
+//     T*tstride + SK_FP*256 + (I + (a >> 1) + (b >> 1))*256 + 4*((a >> 1) + 8*(b >> 1)) + (a & 1) + 2*(b & 1)
+// so that at step t lane (A, B) reads and writes the 32 bytes at column 4*(A + 8 B) of row t
+// (t + 1 for the old values one cell ahead).
+//
+// Workgroup = the compute wave + the halo wave + the store wave of relax_skew_loop.hip; the LDS
+// exchange grids X (new values of the previous step) and Y (old values one cell ahead) are indexed
+// by line as before, so the strips of the halo wave and the lines of the store wave keep their LDS
+// positions; their lags in steps change with the skew:
+//     line (-1, m) / (m, -1) is read by lane (0, m >> 1) / (m >> 1, 0)     at I = t - (m >> 1)
+//     line (16, m) / (m, 16) is read by lane (7, m >> 1) / (m >> 1, 7)     at I = t - 7 - (m >> 1)
+//     hand-off granule of cell I of line (15, m) / (m, 15): row I + (m >> 1)       (consumer's step)
+//     snapshot granule of cell I of line (0, m) / (m, 0):   row I + (m >> 1) + 7
+#include "relax_skew.hpp"
+#include <cstdlib>
+#include <vector>
+
+#ifndef PK_D
+#define PK_D 6       /* prefetch distance (steps) of the compute wave's streams */
+#endif
+#ifndef PK_DH
+#define PK_DH 3      /* prefetch distance of the halo strips (divides PK_D) */
+#endif
+#define PK_NTHREADS 192
+#define PK_SKEW 14   /* largest A + B */
+
+namespace gfship {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned patch_claim_tile (const SkewLoopArgs & A)
+{
+  return A.order[atomicAdd (A.ticket, 1u)];
+}
+
+// one cell: relax, src/poisson.c:507-530, unit weights, d = 0..5 = right, left, top, bottom, front, back
+template <bool HAS_DIA>
+__device__ __forceinline__ double patch_cell (double right, double left, double top, double bottom,
+					      double front, double back, double rhs, double dia)
+{
+  double aa = HAS_DIA ? dia : 0., bb = 0.;
+  aa += 1.; bb += 1.*right;
+  aa += 1.; bb += 1.*left;
+  aa += 1.; bb += 1.*top;
+  aa += 1.; bb += 1.*bottom;
+  aa += 1.; bb += 1.*front;
+  aa += 1.; bb += 1.*back;
+  return HAS_DIA ? (aa != 0. ? (bb - rhs)/aa : 0.) : divide_by_6 (bb - rhs);
+}
+
+template <bool HAS_DIA>
+__global__ void __launch_bounds__(PK_NTHREADS)
+relax_patch_loop_kernel (SkewLoopArgs A)
+{
+  constexpr int XS = SK_T + 1;
+  __shared__ double X[2][XS*XS];
+  __shared__ double Y[2][XS*XS];
+  __shared__ unsigned s_tile;
+
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane (tid0 >> 6);
+  const int lane = tid0 & 63;
+  const bool compute = wave == 0, loader = wave == 1, storer = wave == 2;
+  const int n = A.L.n;
+  const int ntj = A.ntj;
+  const long tstride = (long) (A.RT + 2*SK_FP)*SK_NL;
+  const long hstride = (long) SK_HROWS (n)*SK_T;
+
+  if (tid0 == 0)
+    s_tile = patch_claim_tile (A);
+  __syncthreads ();
+  const int tile = s_tile;
+  const int P = tile % ntj, Q = tile / ntj;
+  // periodic neighbours of the tile
+  const int tJm = (P > 0 ? P - 1 : ntj - 1) + ntj*Q, tJp = (P + 1 < ntj ? P + 1 : 0) + ntj*Q;
+  const int tKm = P + ntj*(Q > 0 ? Q - 1 : ntj - 1), tKp = P + ntj*(Q + 1 < ntj ? Q + 1 : 0);
+
+  double * const ut = A.us + tile*tstride + SK_FP*SK_NL;
+  const double * const rt = A.rs + tile*tstride + SK_FP*SK_NL;
+  const double * const dt_ = HAS_DIA ? A.ds + tile*tstride + SK_FP*SK_NL : nullptr;
+
+  // compute lane (PA, PB); helper lanes: strip / line g = 0..3, position m = 0..15
+  const int PA = lane & 7, PB = lane >> 3;
+  const int s = PA + PB;
+  const int g = (lane >> 4) & 3, m = lane & 15, mh = m >> 1;
+  const int jm = n - (SK_T*P + m), km = n - (SK_T*Q + m);
+  bool failed = false;
+
+  // steps of a sweep: the lanes are active at t = s .. s + n - 1, the store wave one step later
+  const int T = (n + PK_SKEW + 1 + PK_D)/PK_D*PK_D;
+
+  // LDS indices of the compute lane (line coordinates: X at (a + 1) + XS (b + 1), Y at a + XS b)
+  const int a0 = 2*PA, b0 = 2*PB;
+  const int xT = a0 + XS*(b0 + 1);           // new (a0 - 1, b0); + XS: (a0 - 1, b0 + 1)
+  const int xF = (a0 + 1) + XS*b0;           // new (a0, b0 - 1); + 1: (a0 + 1, b0 - 1)
+  const int yBo = (a0 + 2) + XS*b0;          // old (a0 + 2, b0); + XS: (a0 + 2, b0 + 1)
+  const int yBk = a0 + XS*(b0 + 2);          // old (a0, b0 + 2); + 1: (a0 + 1, b0 + 2)
+  const int xOwn = (a0 + 1) + XS*(b0 + 1);   // own new values: + 0, + 1, + XS, + XS + 1
+  const int yOwn = a0 + XS*b0;               // own old values one cell ahead
+
+  // natural coordinates of the four lines of the lane: p = da + 2 db
+  int jl[4], kl[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    jl[p] = n - (SK_T*P + a0 + (p & 1));
+    kl[p] = n - (SK_T*Q + b0 + (p >> 1));
+  }
+  // ghost cells at the two ends of the lines: natural ghosts for the first sweep, then the periodic
+  // images (or the homogeneous BC of the side) kept in registers
+  double ghostL[4] = { 0., 0., 0., 0. }, ghostR[4] = { 0., 0., 0., 0. };
+  if (compute) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      ghostL[p] = A.un[A.L.idx (0, jl[p], kl[p])];
+      ghostR[p] = A.un[A.L.idx (n + 1, jl[p], kl[p])];
+    }
+  }
+
+  for (int sw = 0; sw < A.nsweeps; sw++) {
+    const bool more = sw + 1 < A.nsweeps;
+    const bool write_ghosts = sw + 2 == A.nsweeps;
+    u64 * const hbJ = A.hb + sw*A.hb_sweep, * const hbK = hbJ + A.hb_words;
+    u64 * const snJ = hbK + A.hb_words, * const snK = snJ + A.hb_words;
+    const u64 * const hbJp = hbJ - A.hb_sweep, * const hbKp = hbK - A.hb_sweep;   // previous sweep
+    const u64 * const snJp = snJ - A.hb_sweep, * const snKp = snK - A.hb_sweep;
+
+    if (A.stats && tid0 == 0)
+      A.stats[2*(tile*SK_MAXF + sw)] = __builtin_amdgcn_s_memrealtime ();
+
+    __syncthreads ();      // the LDS grids of the previous sweep are no longer read
+    for (int q = tid0; q < 2*XS*XS; q += PK_NTHREADS) {
+      (&X[0][0])[q] = 0.;
+      (&Y[0][0])[q] = 0.;
+    }
+    __syncthreads ();
+
+    if (loader) {
+      // =========================== halo wave ===========================
+      const u64 * qH = A.dummy;
+      int hs = 0;
+      bool handoff = false;       // sentinel-guarded granule stream
+      double hsgn = 1.;           // sign of a homogeneous BC whose ghost this stream carries
+      int xy_halo = 0;
+      switch (g) {
+      case 0: // new values of line (-1, m), row t
+	if (P > 0)       { qH = hbJ + (long) tJm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0 && A.sgn[2] == 0.) { qH = hbJp + (long) tJm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = snJp + (long) tile*hstride + m + (long) 7*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[2]; }      /* own line a = 0: snapshot row I + mh + 7 = t + 7 */
+	else             { qH = (const u64 *) (A.un + A.L.idx (1 - mh, n + 1, km)); hs = 1; }
+	xy_halo = 0 + XS*(m + 1);
+	break;
+      case 1: // new values of line (m, -1)
+	if (Q > 0)       { qH = hbK + (long) tKm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0 && A.sgn[4] == 0.) { qH = hbKp + (long) tKm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = snKp + (long) tile*hstride + m + (long) 7*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[4]; }      /* own line b = 0, row t + 7 */
+	else             { qH = (const u64 *) (A.un + A.L.idx (1 - mh, jm, n + 1)); hs = 1; }
+	xy_halo = (m + 1) + XS*0;
+	break;
+      case 2: // old values of line (16, m) = line (0, m) of tile (P + 1, Q) at I = t - 7 - mh
+	if (sw > 0 && (P + 1 < ntj || A.sgn[3] == 0.)) { qH = snJp + (long) tJp*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = hbJp + (long) tile*hstride + m - (long) 7*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[3]; }      /* own line a = 15: hand-off row I + mh = t - 7 */
+	else if (P + 1 < ntj) {
+	  // element (I, 0, m) of the next tile: row I + mh = t - 7, column 32 mh + 2 (m & 1)
+	  qH = (const u64 *) (A.us + tJp*tstride + SK_FP*SK_NL - (long) 7*SK_NL + 32*mh + 2*(m & 1));
+	  hs = SK_NL;
+	}
+	else { qH = (const u64 *) (A.un + A.L.idx (1 - (7 + mh), 0, km)); hs = 1; }
+	xy_halo = SK_T + XS*m;
+	break;
+      default: // old values of line (m, 16) = line (m, 0) of tile (P, Q + 1) at I = t - 7 - mh
+	if (sw > 0 && (Q + 1 < ntj || A.sgn[5] == 0.)) { qH = snKp + (long) tKp*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = hbKp + (long) tile*hstride + m - (long) 7*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[5]; }      /* own line b = 15 */
+	else if (Q + 1 < ntj) {
+	  // element (I, m, 0) of the tile behind: row t - 7, column 4 mh + (m & 1)
+	  qH = (const u64 *) (A.us + tKp*tstride + SK_FP*SK_NL - (long) 7*SK_NL + 4*mh + (m & 1));
+	  hs = SK_NL;
+	}
+	else { qH = (const u64 *) (A.un + A.L.idx (1 - (7 + mh), jm, 0)); hs = 1; }
+	xy_halo = m + XS*SK_T;
+      }
+      double * const halo_dst0 = (g < 2 ? &X[0][0] : &Y[0][0]) + xy_halo;
+      const u64 * const qH0 = qH;
+      // a granule stream is awaited only at the steps at which its consumer lane is active
+      const int hlag = g < 2 ? mh : 7 + mh;
+      double pH[PK_DH];
+
+#define PK_HALO(t_, q_, refill_)					\
+      do {								\
+	double hv = pH[q_];						\
+	bool w = handoff && !failed && (unsigned) ((t_) - hlag) < (unsigned) n && \
+	  (u64) __double_as_longlong (hv) == SK_SENTINEL;		\
+	if (__builtin_expect (__any (w), 0)) {				\
+	  unsigned spins = 0;						\
+	  _Pragma ("nounroll")						\
+	  while (__any (w)) {						\
+	    __builtin_amdgcn_s_sleep (SK_POLL_SLEEP);			\
+	    if (w) {							\
+	      hv = __longlong_as_double ((long long) load_sc1 (qH0 + (long) (t_)*hs)); \
+	      w = (u64) __double_as_longlong (hv) == SK_SENTINEL;	\
+	    }								\
+	    if (++spins > (1u << 18)) { *A.err = 1; failed = true; break; } \
+	  }								\
+	}								\
+	halo_dst0[((t_) & 1)*(XS*XS)] = hv*hsgn;			\
+	if (refill_) {							\
+	  pH[q_] = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs; \
+	}								\
+      } while (0)
+
+      // strip values of step 0, then the ring holds steps 1 .. PK_DH
+      {
+	pH[0] = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs;
+	PK_HALO (0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < PK_DH; q++) {
+	pH[q] = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs;
+      }
+      __syncthreads ();
+      // the value of step t + 1 is put into LDS during step t: slot (t mod PK_DH) holds step t + 1
+      for (int t0 = 0; t0 < T; t0 += PK_D) {
+#pragma unroll
+	for (int q = 0; q < PK_D; q++) {
+	  const int t = t0 + q;
+	  PK_HALO (t + 1, q % PK_DH, 1);
+	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	}
+      }
+#undef PK_HALO
+    }
+    else if (storer) {
+      // =========================== store wave ===========================
+      // lane (g, m) owns one outgoing line; the value the compute wave produced at step t - 1 sits
+      // in X[t & 1]
+      //   g = 0  line (15, m)  hand-off to tile (P + 1, Q), also its periodic image when a sweep follows
+      //   g = 1  line (m, 15)  hand-off to tile (P, Q + 1)
+      //   g = 2  line (0, m)   snapshot for the next sweep of tile (P - 1, Q)
+      //   g = 3  line (m, 0)   snapshot for the next sweep of tile (P, Q - 1)
+      u64 * pS = (u64 *) A.dummy;
+      bool sOn = false;
+      int sX = 0, sLag = 0;       // LDS index of the line's new value; I = t - 1 - sLag
+      double * pNat = nullptr;    // mirror mode: the line lies along a box side: natural address of cell i = t - sLag
+      switch (g) {
+      case 0: sOn = P + 1 < ntj || more; pS = hbJ + (long) tile*hstride + m - (long) 8*SK_T;   /* row t - 8 */
+	sX = SK_T + XS*(m + 1); sLag = 7 + mh;
+	if (A.mirror && P == ntj - 1) pNat = A.un + A.L.idx (0, 1, km) - sLag;
+	break;
+      case 1: sOn = Q + 1 < ntj || more; pS = hbK + (long) tile*hstride + m - (long) 8*SK_T;
+	sX = (m + 1) + XS*SK_T; sLag = 7 + mh;
+	if (A.mirror && Q == ntj - 1) pNat = A.un + A.L.idx (0, jm, 1) - sLag;
+	break;
+      case 2: sOn = more; pS = snJ + (long) tile*hstride + m + (long) 6*SK_T;                   /* row t + 6 */
+	sX = 1 + XS*(m + 1); sLag = mh;
+	if (A.mirror && P == 0) pNat = A.un + A.L.idx (0, n, km) - sLag;
+	break;
+      default: sOn = more; pS = snK + (long) tile*hstride + m + (long) 6*SK_T;
+	sX = (m + 1) + XS*1; sLag = mh;
+	if (A.mirror && Q == 0) pNat = A.un + A.L.idx (0, jm, n) - sLag;
+      }
+      __syncthreads ();
+      for (int t0 = 0; t0 < T; t0 += PK_D) {
+#pragma unroll
+	for (int q = 0; q < PK_D; q++) {
+	  const int t = t0 + q;
+	  const int I = t - 1 - sLag;
+	  if (I >= 0 && I < n) {
+	    const double v = X[t & 1][sX];
+	    if (pNat) pNat[t] = v;
+	    if (sOn) store_sc1 (pS, (u64) __double_as_longlong (v));
+	  }
+	  pS += SK_T;
+	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	}
+      }
+    }
+    else {
+      // =========================== compute wave ===========================
+      const double * qR = ut + SK_NL + 4*lane;        // old values one cell ahead: row t + 1
+      const double * qRhs = rt + 4*lane;              // row t
+      const double * qDia = HAS_DIA ? dt_ + 4*lane : nullptr;
+      double * wU = ut + 4*lane;                      // own row t
+      d2 pRa[PK_D], pRb[PK_D], pHa[PK_D], pHb[PK_D], pDa[PK_D], pDb[PK_D];
+#define PK_PREFETCH(q_)							\
+      do {								\
+	pRa[q_] = *(const d2 *) qR; pRb[q_] = *(const d2 *) (qR + 2); qR += SK_NL; \
+	pHa[q_] = *(const d2 *) qRhs; pHb[q_] = *(const d2 *) (qRhs + 2); qRhs += SK_NL; \
+	if (HAS_DIA) { pDa[q_] = *(const d2 *) qDia; pDb[q_] = *(const d2 *) (qDia + 2); qDia += SK_NL; } \
+      } while (0)
+      // old values of the own cells at I = 0 - s ... : row t of the first step
+      d2 c01 = *(const d2 *) (ut + 4*lane), c23 = *(const d2 *) (ut + 4*lane + 2);
+#pragma unroll
+      for (int q = 0; q < PK_D; q++)
+	PK_PREFETCH (q);
+      // the old values one cell ahead that the neighbours read at step 0
+      Y[0][yOwn] = pRa[0].x; Y[0][yOwn + 1] = pRa[0].y;
+      Y[0][yOwn + XS] = pRb[0].x; Y[0][yOwn + XS + 1] = pRb[0].y;
+      __syncthreads ();
+
+      double prev[4] = { ghostL[0], ghostL[1], ghostL[2], ghostL[3] };
+      double first[4] = { 0., 0., 0., 0. };
+      double cur[4] = { c01.x, c01.y, c23.x, c23.y };
+
+      for (int t0 = 0; t0 < T; t0 += PK_D) {
+#pragma unroll
+	for (int q = 0; q < PK_D; q++) {
+	  const int t = t0 + q;
+	  const int I = t - s;
+	  const bool act = I >= 0 && I < n;
+	  const int Bf = t & 1;
+	  const double * Xb = X[Bf], * Yb = Y[Bf];
+	  const double Tn0 = Xb[xT], Tn1 = Xb[xT + XS];
+	  const double Fn0 = Xb[xF], Fn1 = Xb[xF + 1];
+	  const double Bo0 = Yb[yBo], Bo1 = Yb[yBo + XS];
+	  const double Bk0 = Yb[yBk], Bk1 = Yb[yBk + 1];
+	  const double nx[4] = { pRa[q].x, pRa[q].y, pRb[q].x, pRb[q].y };   // old values at I + 1
+	  const bool last = I + 1 >= n;
+	  const double R0 = last ? ghostR[0] : nx[0], R1 = last ? ghostR[1] : nx[1];
+	  const double R2 = last ? ghostR[2] : nx[2], R3 = last ? ghostR[3] : nx[3];
+	  const double d0 = HAS_DIA ? pDa[q].x : 0., d1 = HAS_DIA ? pDa[q].y : 0.;
+	  const double d2_ = HAS_DIA ? pDb[q].x : 0., d3 = HAS_DIA ? pDb[q].y : 0.;
+	  // (a0, b0): top and front from the neighbour lanes, bottom and back the lane's own old values
+	  const double v0 = patch_cell<HAS_DIA> (R0, prev[0], Tn0, cur[1], Fn0, cur[2], pHa[q].x, d0);
+	  // (a0 + 1, b0): top = the new (a0, b0)
+	  const double v1 = patch_cell<HAS_DIA> (R1, prev[1], v0, Bo0, Fn1, cur[3], pHa[q].y, d1);
+	  // (a0, b0 + 1): front = the new (a0, b0)
+	  const double v2 = patch_cell<HAS_DIA> (R2, prev[2], Tn1, cur[3], v0, Bk0, pHb[q].x, d2_);
+	  // (a0 + 1, b0 + 1)
+	  const double v3 = patch_cell<HAS_DIA> (R3, prev[3], v2, Bo1, v1, Bk1, pHb[q].y, d3);
+	  prev[0] = act ? v0 : prev[0]; prev[1] = act ? v1 : prev[1];
+	  prev[2] = act ? v2 : prev[2]; prev[3] = act ? v3 : prev[3];
+	  const bool isfirst = I == 0;
+	  first[0] = isfirst ? v0 : first[0]; first[1] = isfirst ? v1 : first[1];
+	  first[2] = isfirst ? v2 : first[2]; first[3] = isfirst ? v3 : first[3];
+	  // publish for step t + 1: new values, and the old values one cell ahead of step t + 1
+	  double * Xn = X[Bf ^ 1], * Yn = Y[Bf ^ 1];
+	  Xn[xOwn] = v0; Xn[xOwn + 1] = v1; Xn[xOwn + XS] = v2; Xn[xOwn + XS + 1] = v3;
+	  {
+	    const int qn = (q + 1) % PK_D;
+	    Yn[yOwn] = pRa[qn].x; Yn[yOwn + 1] = pRa[qn].y;
+	    Yn[yOwn + XS] = pRb[qn].x; Yn[yOwn + XS + 1] = pRb[qn].y;
+	  }
+	  cur[0] = nx[0]; cur[1] = nx[1]; cur[2] = nx[2]; cur[3] = nx[3];
+	  PK_PREFETCH (q);
+	  // own row of the skewed copy (read back by the same lane only): stored unconditionally, for an
+	  // inactive lane the slot is padding that nothing reads
+	  {
+	    d2 o01, o23;
+	    o01.x = v0; o01.y = v1; o23.x = v2; o23.y = v3;
+	    *(d2 *) wU = o01; *(d2 *) (wU + 2) = o23;
+	  }
+	  wU += SK_NL;
+	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	}
+      }
+#undef PK_PREFETCH
+      // ghosts of the lines for the next sweep: the periodic image, or the homogeneous BC of the side
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+	const double lastv = prev[p];                               // value at I = n - 1
+	ghostL[p] = A.sgn[1] == 0. ? lastv : A.sgn[1]*first[p];     // I = -1 (left side)
+	ghostR[p] = A.sgn[0] == 0. ? first[p] : A.sgn[0]*lastv;     // I = n  (right side)
+      }
+      if (A.mirror) {
+#pragma unroll
+	for (int p = 0; p < 4; p++) {
+	  A.un[A.L.idx (1, jl[p], kl[p])] = first[p];
+	  A.un[A.L.idx (n, jl[p], kl[p])] = prev[p];
+	}
+      }
+      if (write_ghosts) {
+	// x ghosts of the last BC application (the y and z ghost planes: patch_loop_ghosts_kernel)
+#pragma unroll
+	for (int p = 0; p < 4; p++) {
+	  A.un[A.L.idx (n + 1, jl[p], kl[p])] = ghostR[p];
+	  A.un[A.L.idx (0, jl[p], kl[p])] = ghostL[p];
+	}
+      }
+    }
+    if (A.stats && tid0 == 0)
+      A.stats[2*(tile*SK_MAXF + sw) + 1] = __builtin_amdgcn_s_memrealtime ();
+  }
+}
+
+// y and z ghost planes left by the last BC application of the loop, from the granules of sweep
+// nsweeps - 2 (see skew_loop_ghosts_kernel); rows in this file's convention
+__global__ void __launch_bounds__(256)
+patch_loop_ghosts_kernel (SkewLoopArgs A)
+{
+  const int n = A.L.n, ntj = A.ntj;
+  const long hstride = (long) SK_HROWS (n)*SK_T;
+  const int sw = A.nsweeps - 2;
+  const u64 * hbJ = A.hb + sw*A.hb_sweep, * hbK = hbJ + A.hb_words;
+  const u64 * snJ = hbK + A.hb_words, * snK = snJ + A.hb_words;
+  const int I = blockIdx.x*blockDim.x + threadIdx.x;     // 0 .. n-1
+  const int c = blockIdx.y;                               // the other tangential index, 0 .. n-1
+  const int plane = blockIdx.z;
+  if (I >= n) return;
+  const int T_ = c / SK_T, l = c % SK_T, lh = l >> 1;
+  const long lastJ = (long) ((ntj - 1) + ntj*T_)*hstride, firstJ = (long) (0 + ntj*T_)*hstride;
+  const long lastK = (long) (T_ + ntj*(ntj - 1))*hstride, firstK = (long) (T_ + ntj*0)*hstride;
+  const long rowHb = (long) (I + lh)*SK_T + l, rowSn = (long) (I + lh + 7)*SK_T + l;
+  u64 bits;
+  long dst;
+  double sg;
+  switch (plane) {
+  case 0: sg = A.sgn[2]; bits = sg == 0. ? hbJ[lastJ + rowHb] : snJ[firstJ + rowSn];     // ghost j = n + 1
+    dst = A.L.idx (I + 1, n + 1, n - c); break;
+  case 1: sg = A.sgn[3]; bits = sg == 0. ? snJ[firstJ + rowSn] : hbJ[lastJ + rowHb];     // ghost j = 0
+    dst = A.L.idx (I + 1, 0, n - c); break;
+  case 2: sg = A.sgn[4]; bits = sg == 0. ? hbK[lastK + rowHb] : snK[firstK + rowSn];     // ghost k = n + 1
+    dst = A.L.idx (I + 1, n - c, n + 1); break;
+  default: sg = A.sgn[5]; bits = sg == 0. ? snK[firstK + rowSn] : hbK[lastK + rowHb];    // ghost k = 0
+    dst = A.L.idx (I + 1, n - c, 0);
+  }
+  const double v = __longlong_as_double ((long long) bits);
+  A.un[dst] = sg == 0. ? v : sg*v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// natural <-> patch-skewed copies.  One block = one tile, one pair of K planes (b = 2 PB, 2 PB + 1)
+// and a chunk of 16 rows: on the skewed side the block moves 16 rows x 256 B (8 lanes x 32 B), on
+// the natural side 32 lines x (16 + 7) cells; the transposition goes through LDS.
+// ---------------------------------------------------------------------------------------------
+struct PatchPackArgs {
+  Layout L;
+  int ntj, RT;
+  const double * src[3];
+  double * dst[3];
+  int narr;
+  double * add;            // unpack: add the values to this natural array instead of storing them
+};
+
+#define PP_ROWS 16
+#define PP_SPAN (PP_ROWS + 7)     /* cells along I touched by 16 rows of the 8 lanes of a B */
+
+__global__ void __launch_bounds__(256)
+patch_pack_kernel (PatchPackArgs A)
+{
+  // [array][line: a + 16 db][cell along I], padded
+  __shared__ double buf[3][32][PP_SPAN + 1];
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.z, PB = blockIdx.y, r0 = blockIdx.x*PP_ROWS;
+  const int P = tile % A.ntj, Q = tile / A.ntj;
+  const int n = A.L.n;
+  const long tbase = (long) tile*(A.RT + 2*SK_FP)*SK_NL + SK_FP*SK_NL;
+  // natural cells needed: I = rho - PA - PB, rho = r0 .. r0 + 15, PA = 0..7  =>  I0 = r0 - 7 - PB .. r0 + 15 - PB
+  const int I0 = r0 - 7 - PB;
+  for (int e = tid; e < 32*PP_SPAN; e += 256) {
+    const int line = e / PP_SPAN, di = e % PP_SPAN;
+    const int a = line & 15, db = line >> 4;
+    const int I = I0 + di;
+    if (I >= 0 && I < n) {
+      const int j = n - (SK_T*P + a), k = n - (SK_T*Q + 2*PB + db);
+      const long nidx = A.L.idx (I + 1, j, k);
+      for (int q = 0; q < A.narr; q++)
+	buf[q][line][di] = A.src[q][nidx];
+    }
+  }
+  __syncthreads ();
+  // skewed side: 16 rows x 32 doubles (8 lanes x 4 cells) = 512 elements, 2 per thread
+  for (int e = tid; e < PP_ROWS*32; e += 256) {
+    const int row = e / 32, col = e % 32;
+    const int PA = col >> 2, p = col & 3;
+    const int a = 2*PA + (p & 1), db = p >> 1;
+    const int rho = r0 + row;
+    const int I = rho - PA - PB;
+    if (I >= 0 && I < n) {
+      const long sidx = tbase + (long) rho*SK_NL + 4*(PA + 8*PB) + p;
+      for (int q = 0; q < A.narr; q++)
+	A.dst[q][sidx] = buf[q][a + 16*db][I - I0];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+patch_unpack_kernel (PatchPackArgs A)
+{
+  __shared__ double buf[32][PP_SPAN + 1];
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.z, PB = blockIdx.y, r0 = blockIdx.x*PP_ROWS;
+  const int P = tile % A.ntj, Q = tile / A.ntj;
+  const int n = A.L.n;
+  const long tbase = (long) tile*(A.RT + 2*SK_FP)*SK_NL + SK_FP*SK_NL;
+  // the natural cells this block owns: I = r0 - PB .. r0 + 15 - PB for lane PA = 0 ... every cell
+  // (I, a, b) belongs to exactly one row rho = I + PA + PB, hence to exactly one block
+  const int I0 = r0 - 7 - PB;
+  for (int e = tid; e < PP_ROWS*32; e += 256) {
+    const int row = e / 32, col = e % 32;
+    const int PA = col >> 2, p = col & 3;
+    const int a = 2*PA + (p & 1), db = p >> 1;
+    const int rho = r0 + row;
+    const int I = rho - PA - PB;
+    if (I >= 0 && I < n)
+      buf[a + 16*db][I - I0] = A.src[0][tbase + (long) rho*SK_NL + 4*(PA + 8*PB) + p];
+  }
+  __syncthreads ();
+  for (int e = tid; e < 32*PP_SPAN; e += 256) {
+    const int line = e / PP_SPAN, di = e % PP_SPAN;
+    const int a = line & 15, db = line >> 4;
+    const int I = I0 + di;
+    // the cell is in this block's rows iff r0 <= I + (a >> 1) + PB < r0 + 16
+    const int rho = I + (a >> 1) + PB;
+    if (I >= 0 && I < n && rho >= r0 && rho < r0 + PP_ROWS) {
+      const int j = n - (SK_T*P + a), k = n - (SK_T*Q + 2*PB + db);
+      const long c = A.L.idx (I + 1, j, k);
+      if (A.add)
+	A.add[c] += buf[line][di];     /* correct (src/poisson.c:998-1003) fused into the unpack */
+      else
+	A.dst[0][c] = buf[line][di];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int patch_resident_per_cu ()
+{
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_patch_loop_kernel<true>,
+						    PK_NTHREADS, 0) != hipSuccess)
+    return 0;
+  return per_cu;
+}
+
+int patch_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u, const double * rhs,
+		const double * dia)
+{
+  PatchPackArgs A;
+  A.add = nullptr;
+  A.L = dom->lay[level]; A.ntj = S->ntj; A.RT = S->RT;
+  A.narr = 0;
+  A.src[A.narr] = u;   A.dst[A.narr++] = S->us;
+  A.src[A.narr] = rhs; A.dst[A.narr++] = S->rs;
+  if (dia) { A.src[A.narr] = dia; A.dst[A.narr++] = S->ds; }
+  const int rows = A.L.n + PK_SKEW + 1;
+  dim3 grid ((rows + PP_ROWS - 1)/PP_ROWS, 8, S->ntj*S->ntj);
+  hipLaunchKernelGGL (patch_pack_kernel, grid, dim3 (256), 0, dom->stream, A);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+int patch_unpack (gfship_domain * dom, int level, SkewPlan * S, double * u, double * add_into)
+{
+  PatchPackArgs A;
+  A.L = dom->lay[level]; A.ntj = S->ntj; A.RT = S->RT;
+  A.narr = 1;
+  A.src[0] = S->us; A.dst[0] = u; A.add = add_into;
+  const int rows = A.L.n + PK_SKEW + 1;
+  dim3 grid ((rows + PP_ROWS - 1)/PP_ROWS, 8, S->ntj*S->ntj);
+  hipLaunchKernelGGL (patch_unpack_kernel, grid, dim3 (256), 0, dom->stream, A);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// launches the loop kernel (and the ghost planes for nrelax >= 2) with the arguments the caller has
+// prepared (skew_loop_run, relax_skew_loop.hip: granules armed, ticket zeroed)
+int patch_loop_launch (gfship_domain * dom, const SkewLoopArgs & A, int ntiles, bool has_dia,
+		       unsigned nrelax, float * ms)
+{
+  if (ms) GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
+  if (has_dia)
+    hipLaunchKernelGGL (relax_patch_loop_kernel<true>, dim3 (ntiles), dim3 (PK_NTHREADS), 0, dom->stream, A);
+  else
+    hipLaunchKernelGGL (relax_patch_loop_kernel<false>, dim3 (ntiles), dim3 (PK_NTHREADS), 0, dom->stream, A);
+  GFSHIP_HIP (hipGetLastError ());
+  if (ms) {
+    GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));
+    GFSHIP_HIP (hipEventSynchronize (dom->ev1));
+    GFSHIP_HIP (hipEventElapsedTime (ms, dom->ev0, dom->ev1));
+  }
+  if (nrelax >= 2) {
+    const Layout & L = A.L;
+    int block = L.n >= 256 ? 256 : L.n >= 128 ? 128 : 64;
+    hipLaunchKernelGGL (patch_loop_ghosts_kernel, dim3 ((L.n + block - 1)/block, L.n, 4), dim3 (block),
+			0, dom->stream, A);
+    GFSHIP_HIP (hipGetLastError ());
+  }
+  return GFSHIP_OK;
+}
+
+} // namespace gfship

@@ -44,6 +44,47 @@ struct SkewArgs {
   u64 * stats;             // optional per-tile { start, end, spins, slow entries } (debug)
 };
 
+#define SK_MAXF 8    /* sweeps per launch */
+#ifndef SK_POLL_SLEEP
+#define SK_POLL_SLEEP 0   /* s_sleep argument between two polls of a hand-off granule */
+#endif
+#ifndef SK_EXP
+#define SK_EXP 0    /* timing experiments: 1 plain halo prefetch loads, 2 plain granule stores */
+#endif
+#define SK_HLOAD(p_) ((SK_EXP & 1) ? *(p_) : load_sc1 (p_))
+#ifndef SK_KO
+#define SK_KO 0      /* timing experiments only: knock out parts of the step (wrong results) */
+#endif
+
+
+struct SkewLoopArgs {
+  Layout L;
+  int ntj, RT, nsweeps;
+  // homogeneous BC of the sides d = 0..5 (right, left, top, bottom, front, back) between the sweeps
+  // of a fused loop: sgn[d] = 0 periodic; otherwise ghost = sgn[d] * adjacent interior value (-1
+  // Dirichlet and the normal component at a symmetry side, +1 Neumann and symmetry otherwise)
+  double sgn[6];
+  int mirror;              // single sweep with the BC kernel around it: cells next to the box sides
+                           // are also written to the natural array (any kind of side)
+  double * us;             // skewed u (in place)
+  const double * rs;       // skewed rhs
+  const double * ds;       // skewed dia (or nullptr)
+  double * un;             // natural u: ghosts of sweep 0 are read, ghosts of the last BC written
+  u64 * hb;                // per sweep: [J hand-off | K hand-off | J snapshot | K snapshot]
+  long hb_sweep;           // granules per sweep
+  long hb_words;           // granules of one hand-off array (ntiles*hstride)
+  const unsigned short * order;
+  unsigned * ticket, * err;
+  const u64 * dummy;
+  u64 * stats;             // optional [tile][sweep]{start, end} (debug, GFSHIP_SKEW_STATS)
+  // XCD-aware placement (all tiles resident): the tiles are split into 8 blocks, one per XCD, and
+  // a workgroup claims a tile of the block of the XCD it runs on (any other block once its own is
+  // exhausted): most hand-offs then stay inside one L2
+  const unsigned short * xorder;   // [8][per_xcd] tiles of each block, anti-diagonal order
+  unsigned * xticket;              // [8] ticket counters (zeroed before the launch)
+  int per_xcd;                     // 0: placement by the single ticket counter
+};
+
 typedef __attribute__((address_space(1))) u64 gu64;
 
 __device__ __forceinline__ u64 load_sc1 (const u64 * p)
@@ -80,5 +121,8 @@ __device__ __forceinline__ double divide_by_6 (double x)
     q2 = x/6.;
   return q2;
 }
+
+int patch_loop_launch (gfship_domain * dom, const SkewLoopArgs & A, int ntiles, bool has_dia,
+		       unsigned nrelax, float * ms);
 
 } // namespace gfship

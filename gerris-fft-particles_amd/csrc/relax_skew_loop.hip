@@ -38,47 +38,8 @@
 #include <cstdlib>
 #include <vector>
 
-#define SK_MAXF 8    /* sweeps per launch */
-#ifndef SK_POLL_SLEEP
-#define SK_POLL_SLEEP 0   /* s_sleep argument between two polls of a hand-off granule */
-#endif
-#ifndef SK_EXP
-#define SK_EXP 0    /* timing experiments: 1 plain halo prefetch loads, 2 plain granule stores */
-#endif
-#define SK_HLOAD(p_) ((SK_EXP & 1) ? *(p_) : load_sc1 (p_))
-#ifndef SK_KO
-#define SK_KO 0      /* timing experiments only: knock out parts of the step (wrong results) */
-#endif
-
 namespace gfship {
 
-struct SkewLoopArgs {
-  Layout L;
-  int ntj, RT, nsweeps;
-  // homogeneous BC of the sides d = 0..5 (right, left, top, bottom, front, back) between the sweeps
-  // of a fused loop: sgn[d] = 0 periodic; otherwise ghost = sgn[d] * adjacent interior value (-1
-  // Dirichlet and the normal component at a symmetry side, +1 Neumann and symmetry otherwise)
-  double sgn[6];
-  int mirror;              // single sweep with the BC kernel around it: cells next to the box sides
-                           // are also written to the natural array (any kind of side)
-  double * us;             // skewed u (in place)
-  const double * rs;       // skewed rhs
-  const double * ds;       // skewed dia (or nullptr)
-  double * un;             // natural u: ghosts of sweep 0 are read, ghosts of the last BC written
-  u64 * hb;                // per sweep: [J hand-off | K hand-off | J snapshot | K snapshot]
-  long hb_sweep;           // granules per sweep
-  long hb_words;           // granules of one hand-off array (ntiles*hstride)
-  const unsigned short * order;
-  unsigned * ticket, * err;
-  const u64 * dummy;
-  u64 * stats;             // optional [tile][sweep]{start, end} (debug, GFSHIP_SKEW_STATS)
-  // XCD-aware placement (all tiles resident): the tiles are split into 8 blocks, one per XCD, and
-  // a workgroup claims a tile of the block of the XCD it runs on (any other block once its own is
-  // exhausted): most hand-offs then stay inside one L2
-  const unsigned short * xorder;   // [8][per_xcd] tiles of each block, anti-diagonal order
-  unsigned * xticket;              // [8] ticket counters (zeroed before the launch)
-  int per_xcd;                     // 0: placement by the single ticket counter
-};
 
 __device__ __forceinline__ unsigned skew_xcc_id ()
 {
@@ -802,6 +763,8 @@ static int skew_loop_resident (gfship_domain * dom)
 	hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu_w, relax_wave_loop_kernel,
 						      WV_NTHREADS, 0) != hipSuccess)
       dom->skew_resident = 0;
+    else if (dom->patch)
+      dom->skew_resident = patch_resident_per_cu ()*prop.multiProcessorCount;
     else
       dom->skew_resident = (per_cu < per_cu_w ? per_cu : per_cu_w)*prop.multiProcessorCount;
   }
@@ -874,6 +837,13 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
       GFSHIP_HIP (hipMalloc ((void **) &S->stats_loop, (size_t) ntiles*SK_MAXF*2*sizeof (u64)));
     A.stats = (u64 *) S->stats_loop;
   }
+  if (dom->patch) {
+    int r = patch_loop_launch (dom, A, ntiles, has_dia, nrelax, ms);
+    if (r) return r;
+    if (nrelax >= 2 && A.stats && ms)
+      goto dump_stats;
+    return GFSHIP_OK;
+  }
   if (ms) GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
   if (dom->wave_loop && nrelax >= 2 && !has_dia)     /* one compute wave per tile */
     hipLaunchKernelGGL (relax_wave_loop_kernel, dim3 (ntiles), dim3 (WV_NTHREADS), 0, dom->stream, A);
@@ -895,6 +865,7 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   }
   if (nrelax < 2)
     return GFSHIP_OK;
+ dump_stats:
   if (A.stats && ms) {
     (void) hipStreamSynchronize (dom->stream);
     std::vector<u64> h ((size_t) ntiles*SK_MAXF*2);
