@@ -15,9 +15,10 @@
 // (two 16-byte accesses per array and step instead of four 8-byte ones: rows are 2 KB as before).
 //
 // Layout (patch-skewed): element (I, a, b) of tile T sits at
-//     T*tstride + SK_FP*256 + (I + (a >> 1) + (b >> 1))*256 + 4*((a >> 1) + 8*(b >> 1)) + (a & 1) + 2*(b & 1)
-// so that at step t lane (A, B) reads and writes the 32 bytes at column 4*(A + 8 B) of row t
-// (t + 1 for the old values one cell ahead).
+//     T*tstride + SK_FP*256 + (I + (a >> 1) + (b >> 1))*256 + 128*(b & 1) + 2*((a >> 1) + 8*(b >> 1)) + (a & 1)
+// so that at step t lane (A, B) = lane l reads and writes 16 bytes at column 2 l of each half of
+// row t (t + 1 for the old values one cell ahead): the lines with even b in the first KB of the row,
+// those with odd b in the second, and every 16-byte access of the wave covers one contiguous KB.
 //
 // Workgroup = the compute wave + the halo wave + the store wave of relax_skew_loop.hip; the LDS
 // exchange grids X (new values of the previous step) and Y (old values one cell ahead) are indexed
@@ -32,10 +33,13 @@
 #include <vector>
 
 #ifndef PK_D
-#define PK_D 6       /* prefetch distance (steps) of the compute wave's streams */
+#define PK_D 9       /* prefetch distance (steps) of the compute wave's streams (6, 8, 9, 10, 12, 15 tried) */
 #endif
 #ifndef PK_DH
 #define PK_DH 3      /* prefetch distance of the halo strips (divides PK_D) */
+#endif
+#ifndef PK_KO
+#define PK_KO 0      /* timing experiments only (wrong results): 1 no streaming loads, 2 no row stores, 4 no LDS publish */
 #endif
 #define PK_NTHREADS 192
 #define PK_SKEW 14   /* largest A + B */
@@ -49,10 +53,16 @@ __device__ __forceinline__ unsigned patch_claim_tile (const SkewLoopArgs & A)
   return A.order[atomicAdd (A.ticket, 1u)];
 }
 
-// one cell: relax, src/poisson.c:507-530, unit weights, d = 0..5 = right, left, top, bottom, front, back
+// one cell: relax, src/poisson.c:507-530, unit weights, d = 0..5 = right, left, top, bottom, front, back.
+// Without dia the quotient by 6 comes from divide_by_6's reciprocal sequence (relax_skew.hpp), whose
+// guard -- operands so small that the sequence could meet subnormals -- is only recorded here: the
+// four cells of a step form one dependent chain, a branch per cell would cut it into basic blocks
+// that the scheduler cannot interleave.  The step tests the four flags once and, in the (never
+// observed) case that one is set, recomputes its cells with true divisions.
 template <bool HAS_DIA>
 __device__ __forceinline__ double patch_cell (double right, double left, double top, double bottom,
-					      double front, double back, double rhs, double dia)
+					      double front, double back, double rhs, double dia,
+					      bool & tiny, bool exact)
 {
   double aa = HAS_DIA ? dia : 0., bb = 0.;
   aa += 1.; bb += 1.*right;
@@ -61,7 +71,16 @@ __device__ __forceinline__ double patch_cell (double right, double left, double 
   aa += 1.; bb += 1.*bottom;
   aa += 1.; bb += 1.*front;
   aa += 1.; bb += 1.*back;
-  return HAS_DIA ? (aa != 0. ? (bb - rhs)/aa : 0.) : divide_by_6 (bb - rhs);
+  if (HAS_DIA)
+    return aa != 0. ? (bb - rhs)/aa : 0.;
+  const double x = bb - rhs;
+  if (exact)
+    return x/6.;
+  const double r = 0x1.5555555555555p-3;
+  const double q = x*r;
+  const double rem = __builtin_fma (- q, 6., x);
+  tiny = tiny || __builtin_amdgcn_frexp_exp (x) < -999;
+  return __builtin_fma (rem, r, q);
 }
 
 template <bool HAS_DIA>
@@ -179,8 +198,8 @@ relax_patch_loop_kernel (SkewLoopArgs A)
 	else if (sw > 0) { qH = hbJp + (long) tile*hstride + m - (long) 7*SK_T; hs = SK_T;
 			   handoff = true; hsgn = A.sgn[3]; }      /* own line a = 15: hand-off row I + mh = t - 7 */
 	else if (P + 1 < ntj) {
-	  // element (I, 0, m) of the next tile: row I + mh = t - 7, column 32 mh + 2 (m & 1)
-	  qH = (const u64 *) (A.us + tJp*tstride + SK_FP*SK_NL - (long) 7*SK_NL + 32*mh + 2*(m & 1));
+	  // element (I, 0, m) of the next tile: row I + mh = t - 7, column 128 (m & 1) + 16 mh
+	  qH = (const u64 *) (A.us + tJp*tstride + SK_FP*SK_NL - (long) 7*SK_NL + 128*(m & 1) + 16*mh);
 	  hs = SK_NL;
 	}
 	else { qH = (const u64 *) (A.un + A.L.idx (1 - (7 + mh), 0, km)); hs = 1; }
@@ -191,8 +210,8 @@ relax_patch_loop_kernel (SkewLoopArgs A)
 	else if (sw > 0) { qH = hbKp + (long) tile*hstride + m - (long) 7*SK_T; hs = SK_T;
 			   handoff = true; hsgn = A.sgn[5]; }      /* own line b = 15 */
 	else if (Q + 1 < ntj) {
-	  // element (I, m, 0) of the tile behind: row t - 7, column 4 mh + (m & 1)
-	  qH = (const u64 *) (A.us + tKp*tstride + SK_FP*SK_NL - (long) 7*SK_NL + 4*mh + (m & 1));
+	  // element (I, m, 0) of the tile behind: row t - 7, column 2 mh + (m & 1)
+	  qH = (const u64 *) (A.us + tKp*tstride + SK_FP*SK_NL - (long) 7*SK_NL + 2*mh + (m & 1));
 	  hs = SK_NL;
 	}
 	else { qH = (const u64 *) (A.un + A.L.idx (1 - (7 + mh), jm, 0)); hs = 1; }
@@ -277,14 +296,25 @@ relax_patch_loop_kernel (SkewLoopArgs A)
 	sX = (m + 1) + XS*1; sLag = mh;
 	if (A.mirror && Q == 0) pNat = A.un + A.L.idx (0, jm, n) - sLag;
       }
+      // ... and every lane writes the row of the skewed copy that the compute lane of the same number
+      // produced in the previous step (its four new values are in X): the stores of the rows stay out
+      // of the compute wave's in-order memory queue, whose prefetched loads would wait behind them
+      double * wRow = ut + 2*lane - SK_NL;            // row t - 1
       __syncthreads ();
       for (int t0 = 0; t0 < T; t0 += PK_D) {
 #pragma unroll
 	for (int q = 0; q < PK_D; q++) {
 	  const int t = t0 + q;
 	  const int I = t - 1 - sLag;
+	  const double * Xb = X[t & 1];
+	  if (!(PK_KO & 2) && t > 0) {
+	    d2 o01, o23;
+	    o01.x = Xb[xOwn]; o01.y = Xb[xOwn + 1]; o23.x = Xb[xOwn + XS]; o23.y = Xb[xOwn + XS + 1];
+	    *(d2 *) wRow = o01; *(d2 *) (wRow + 128) = o23;
+	  }
+	  wRow += SK_NL;
 	  if (I >= 0 && I < n) {
-	    const double v = X[t & 1][sX];
+	    const double v = Xb[sX];
 	    if (pNat) pNat[t] = v;
 	    if (sOn) store_sc1 (pS, (u64) __double_as_longlong (v));
 	  }
@@ -295,19 +325,18 @@ relax_patch_loop_kernel (SkewLoopArgs A)
     }
     else {
       // =========================== compute wave ===========================
-      const double * qR = ut + SK_NL + 4*lane;        // old values one cell ahead: row t + 1
-      const double * qRhs = rt + 4*lane;              // row t
-      const double * qDia = HAS_DIA ? dt_ + 4*lane : nullptr;
-      double * wU = ut + 4*lane;                      // own row t
+      const double * qR = ut + SK_NL + 2*lane;        // old values one cell ahead: row t + 1
+      const double * qRhs = rt + 2*lane;              // row t
+      const double * qDia = HAS_DIA ? dt_ + 2*lane : nullptr;
       d2 pRa[PK_D], pRb[PK_D], pHa[PK_D], pHb[PK_D], pDa[PK_D], pDb[PK_D];
 #define PK_PREFETCH(q_)							\
       do {								\
-	pRa[q_] = *(const d2 *) qR; pRb[q_] = *(const d2 *) (qR + 2); qR += SK_NL; \
-	pHa[q_] = *(const d2 *) qRhs; pHb[q_] = *(const d2 *) (qRhs + 2); qRhs += SK_NL; \
-	if (HAS_DIA) { pDa[q_] = *(const d2 *) qDia; pDb[q_] = *(const d2 *) (qDia + 2); qDia += SK_NL; } \
+	pRa[q_] = *(const d2 *) qR; pRb[q_] = *(const d2 *) (qR + 128); qR += SK_NL; \
+	pHa[q_] = *(const d2 *) qRhs; pHb[q_] = *(const d2 *) (qRhs + 128); qRhs += SK_NL; \
+	if (HAS_DIA) { pDa[q_] = *(const d2 *) qDia; pDb[q_] = *(const d2 *) (qDia + 128); qDia += SK_NL; } \
       } while (0)
       // old values of the own cells at I = 0 - s ... : row t of the first step
-      d2 c01 = *(const d2 *) (ut + 4*lane), c23 = *(const d2 *) (ut + 4*lane + 2);
+      d2 c01 = *(const d2 *) (ut + 2*lane), c23 = *(const d2 *) (ut + 2*lane + 128);
 #pragma unroll
       for (int q = 0; q < PK_D; q++)
 	PK_PREFETCH (q);
@@ -317,7 +346,7 @@ relax_patch_loop_kernel (SkewLoopArgs A)
       __syncthreads ();
 
       double prev[4] = { ghostL[0], ghostL[1], ghostL[2], ghostL[3] };
-      double first[4] = { 0., 0., 0., 0. };
+      double first[4] = { 0., 0., 0., 0. }, lastv[4] = { 0., 0., 0., 0. };
       double cur[4] = { c01.x, c01.y, c23.x, c23.y };
 
       for (int t0 = 0; t0 < T; t0 += PK_D) {
@@ -325,32 +354,49 @@ relax_patch_loop_kernel (SkewLoopArgs A)
 	for (int q = 0; q < PK_D; q++) {
 	  const int t = t0 + q;
 	  const int I = t - s;
-	  const bool act = I >= 0 && I < n;
 	  const int Bf = t & 1;
 	  const double * Xb = X[Bf], * Yb = Y[Bf];
 	  const double Tn0 = Xb[xT], Tn1 = Xb[xT + XS];
 	  const double Fn0 = Xb[xF], Fn1 = Xb[xF + 1];
 	  const double Bo0 = Yb[yBo], Bo1 = Yb[yBo + XS];
 	  const double Bk0 = Yb[yBk], Bk1 = Yb[yBk + 1];
-	  const double nx[4] = { pRa[q].x, pRa[q].y, pRb[q].x, pRb[q].y };   // old values at I + 1
-	  const bool last = I + 1 >= n;
-	  const double R0 = last ? ghostR[0] : nx[0], R1 = last ? ghostR[1] : nx[1];
-	  const double R2 = last ? ghostR[2] : nx[2], R3 = last ? ghostR[3] : nx[3];
+	  double nx[4] = { pRa[q].x, pRa[q].y, pRb[q].x, pRb[q].y };   // old values at I + 1
+	  const double keep[4] = { nx[0], nx[1], nx[2], nx[3] };
+	  // the two ends of the lines (one step each per lane and sweep: a rarely entered block instead
+	  // of selects in every step): left ghost at I = 0, right ghost at I = n - 1
+	  if (__builtin_expect (I == 0 || I == n - 1, 0)) {
+#pragma unroll
+	    for (int p = 0; p < 4; p++) {
+	      prev[p] = I == 0 ? ghostL[p] : prev[p];
+	      nx[p] = I == n - 1 ? ghostR[p] : nx[p];
+	    }
+	  }
 	  const double d0 = HAS_DIA ? pDa[q].x : 0., d1 = HAS_DIA ? pDa[q].y : 0.;
 	  const double d2_ = HAS_DIA ? pDb[q].x : 0., d3 = HAS_DIA ? pDb[q].y : 0.;
+	  bool tiny = false;
 	  // (a0, b0): top and front from the neighbour lanes, bottom and back the lane's own old values
-	  const double v0 = patch_cell<HAS_DIA> (R0, prev[0], Tn0, cur[1], Fn0, cur[2], pHa[q].x, d0);
+	  double v0 = patch_cell<HAS_DIA> (nx[0], prev[0], Tn0, cur[1], Fn0, cur[2], pHa[q].x, d0, tiny, false);
 	  // (a0 + 1, b0): top = the new (a0, b0)
-	  const double v1 = patch_cell<HAS_DIA> (R1, prev[1], v0, Bo0, Fn1, cur[3], pHa[q].y, d1);
+	  double v1 = patch_cell<HAS_DIA> (nx[1], prev[1], v0, Bo0, Fn1, cur[3], pHa[q].y, d1, tiny, false);
 	  // (a0, b0 + 1): front = the new (a0, b0)
-	  const double v2 = patch_cell<HAS_DIA> (R2, prev[2], Tn1, cur[3], v0, Bk0, pHb[q].x, d2_);
+	  double v2 = patch_cell<HAS_DIA> (nx[2], prev[2], Tn1, cur[3], v0, Bk0, pHb[q].x, d2_, tiny, false);
 	  // (a0 + 1, b0 + 1)
-	  const double v3 = patch_cell<HAS_DIA> (R3, prev[3], v2, Bo1, v1, Bk1, pHb[q].y, d3);
-	  prev[0] = act ? v0 : prev[0]; prev[1] = act ? v1 : prev[1];
-	  prev[2] = act ? v2 : prev[2]; prev[3] = act ? v3 : prev[3];
-	  const bool isfirst = I == 0;
-	  first[0] = isfirst ? v0 : first[0]; first[1] = isfirst ? v1 : first[1];
-	  first[2] = isfirst ? v2 : first[2]; first[3] = isfirst ? v3 : first[3];
+	  double v3 = patch_cell<HAS_DIA> (nx[3], prev[3], v2, Bo1, v1, Bk1, pHb[q].y, d3, tiny, false);
+	  if (!HAS_DIA && __builtin_expect (__builtin_amdgcn_ballot_w64 (tiny) != 0, 0)) {
+	    v0 = patch_cell<HAS_DIA> (nx[0], prev[0], Tn0, cur[1], Fn0, cur[2], pHa[q].x, d0, tiny, true);
+	    v1 = patch_cell<HAS_DIA> (nx[1], prev[1], v0, Bo0, Fn1, cur[3], pHa[q].y, d1, tiny, true);
+	    v2 = patch_cell<HAS_DIA> (nx[2], prev[2], Tn1, cur[3], v0, Bk0, pHb[q].x, d2_, tiny, true);
+	    v3 = patch_cell<HAS_DIA> (nx[3], prev[3], v2, Bo1, v1, Bk1, pHb[q].y, d3, tiny, true);
+	  }
+	  prev[0] = v0; prev[1] = v1; prev[2] = v2; prev[3] = v3;
+	  if (__builtin_expect (I == 0 || I == n - 1, 0)) {
+	    const double vv[4] = { v0, v1, v2, v3 };
+#pragma unroll
+	    for (int p = 0; p < 4; p++) {
+	      first[p] = I == 0 ? vv[p] : first[p];
+	      lastv[p] = I == n - 1 ? vv[p] : lastv[p];
+	    }
+	  }
 	  // publish for step t + 1: new values, and the old values one cell ahead of step t + 1
 	  double * Xn = X[Bf ^ 1], * Yn = Y[Bf ^ 1];
 	  Xn[xOwn] = v0; Xn[xOwn + 1] = v1; Xn[xOwn + XS] = v2; Xn[xOwn + XS + 1] = v3;
@@ -359,16 +405,10 @@ relax_patch_loop_kernel (SkewLoopArgs A)
 	    Yn[yOwn] = pRa[qn].x; Yn[yOwn + 1] = pRa[qn].y;
 	    Yn[yOwn + XS] = pRb[qn].x; Yn[yOwn + XS + 1] = pRb[qn].y;
 	  }
-	  cur[0] = nx[0]; cur[1] = nx[1]; cur[2] = nx[2]; cur[3] = nx[3];
-	  PK_PREFETCH (q);
-	  // own row of the skewed copy (read back by the same lane only): stored unconditionally, for an
-	  // inactive lane the slot is padding that nothing reads
-	  {
-	    d2 o01, o23;
-	    o01.x = v0; o01.y = v1; o23.x = v2; o23.y = v3;
-	    *(d2 *) wU = o01; *(d2 *) (wU + 2) = o23;
-	  }
-	  wU += SK_NL;
+	  cur[0] = keep[0]; cur[1] = keep[1]; cur[2] = keep[2]; cur[3] = keep[3];
+	  if (!(PK_KO & 1))
+	    PK_PREFETCH (q);
+	  // (the own row of the skewed copy is written by the store wave, from X, one step later)
 	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 	}
       }
@@ -376,15 +416,14 @@ relax_patch_loop_kernel (SkewLoopArgs A)
       // ghosts of the lines for the next sweep: the periodic image, or the homogeneous BC of the side
 #pragma unroll
       for (int p = 0; p < 4; p++) {
-	const double lastv = prev[p];                               // value at I = n - 1
-	ghostL[p] = A.sgn[1] == 0. ? lastv : A.sgn[1]*first[p];     // I = -1 (left side)
-	ghostR[p] = A.sgn[0] == 0. ? first[p] : A.sgn[0]*lastv;     // I = n  (right side)
+	ghostL[p] = A.sgn[1] == 0. ? lastv[p] : A.sgn[1]*first[p];     // I = -1 (left side)
+	ghostR[p] = A.sgn[0] == 0. ? first[p] : A.sgn[0]*lastv[p];     // I = n  (right side)
       }
       if (A.mirror) {
 #pragma unroll
 	for (int p = 0; p < 4; p++) {
 	  A.un[A.L.idx (1, jl[p], kl[p])] = first[p];
-	  A.un[A.L.idx (n, jl[p], kl[p])] = prev[p];
+	  A.un[A.L.idx (n, jl[p], kl[p])] = lastv[p];
 	}
       }
       if (write_ghosts) {
@@ -485,7 +524,7 @@ patch_pack_kernel (PatchPackArgs A)
     const int rho = r0 + row;
     const int I = rho - PA - PB;
     if (I >= 0 && I < n) {
-      const long sidx = tbase + (long) rho*SK_NL + 4*(PA + 8*PB) + p;
+      const long sidx = tbase + (long) rho*SK_NL + 128*(p >> 1) + 2*(PA + 8*PB) + (p & 1);
       for (int q = 0; q < A.narr; q++)
 	A.dst[q][sidx] = buf[q][a + 16*db][I - I0];
     }
@@ -511,7 +550,7 @@ patch_unpack_kernel (PatchPackArgs A)
     const int rho = r0 + row;
     const int I = rho - PA - PB;
     if (I >= 0 && I < n)
-      buf[a + 16*db][I - I0] = A.src[0][tbase + (long) rho*SK_NL + 4*(PA + 8*PB) + p];
+      buf[a + 16*db][I - I0] = A.src[0][tbase + (long) rho*SK_NL + 128*(p >> 1) + 2*(PA + 8*PB) + (p & 1)];
   }
   __syncthreads ();
   for (int e = tid; e < 32*PP_SPAN; e += 256) {
