@@ -440,6 +440,419 @@ relax_patch_loop_kernel (SkewLoopArgs A)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same with the rows streamed through LDS by a fourth wave (LDS-DMA), so that the compute wave
+// issues no vector-memory instruction at all: with one wave computing the tile the step is bound by
+// what that wave issues (4 cycles per instruction), and the four 16-byte loads of a step, their
+// address arithmetic and the waits for them cost a quarter of it (PK_KO experiments: 63 us per
+// tile-sweep without them, 85 us with them at 256^3).  The stream wave puts row t + 1 + RK_DS of u and
+// row t + RK_DS of rhs (dia) into a ring of RK_R slots in LDS at step t (global_load_lds, 1 KB per
+// instruction, no registers), retiring them with a counted s_waitcnt one step before they are read.
+// The compute lane reads its own cells of row t + 1 from the ring -- and the old values of the
+// lines after its patch from the same row (they are its neighbour lanes' cells): the Y grid and
+// its four LDS writes per step are gone; the `old' strips of the halo wave sit next to the row in
+// the slot.  Everything else (X grid, store wave, granules, layout) is as above.
+// ---------------------------------------------------------------------------------------------
+#ifndef RK_R
+#define RK_R 12      /* ring slots = unroll factor of the step loop (slot numbers are compile-time) */
+#endif
+#ifndef RK_DS
+#define RK_DS 9      /* steps the stream wave runs ahead (<= RK_R - 2) */
+#endif
+#define RK_NTHREADS 256
+
+template <bool HAS_DIA>
+__global__ void __launch_bounds__(RK_NTHREADS)
+relax_ring_loop_kernel (SkewLoopArgs A)
+{
+  constexpr int XS = SK_T + 1;
+  // doubles per ring slot: the u row, the rhs row (the dia row), and the two `old' halo strips
+  constexpr int SS = (HAS_DIA ? 3 : 2)*SK_NL + 32;
+  constexpr int oRhs = SK_NL, oDia = 2*SK_NL, oHalo = (HAS_DIA ? 3 : 2)*SK_NL;
+  __shared__ double X[2][XS*XS];
+  __shared__ __attribute__((aligned(16))) double ring[RK_R*SS];
+  __shared__ unsigned s_tile;
+
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane (tid0 >> 6);
+  const int lane = tid0 & 63;
+  const bool compute = wave == 0, loader = wave == 1, storer = wave == 2;   // wave 3: the stream wave
+  const int n = A.L.n;
+  const int ntj = A.ntj;
+  const long tstride = (long) (A.RT + 2*SK_FP)*SK_NL;
+  const long hstride = (long) SK_HROWS (n)*SK_T;
+
+  if (tid0 == 0)
+    s_tile = patch_claim_tile (A);
+  __syncthreads ();
+  const int tile = s_tile;
+  const int P = tile % ntj, Q = tile / ntj;
+  // periodic neighbours of the tile
+  const int tJm = (P > 0 ? P - 1 : ntj - 1) + ntj*Q, tJp = (P + 1 < ntj ? P + 1 : 0) + ntj*Q;
+  const int tKm = P + ntj*(Q > 0 ? Q - 1 : ntj - 1), tKp = P + ntj*(Q + 1 < ntj ? Q + 1 : 0);
+
+  double * const ut = A.us + tile*tstride + SK_FP*SK_NL;
+  const double * const rt = A.rs + tile*tstride + SK_FP*SK_NL;
+  const double * const dt_ = HAS_DIA ? A.ds + tile*tstride + SK_FP*SK_NL : nullptr;
+
+  // compute lane (PA, PB); helper lanes: strip / line g = 0..3, position m = 0..15
+  const int PA = lane & 7, PB = lane >> 3;
+  const int s = PA + PB;
+  const int g = (lane >> 4) & 3, m = lane & 15, mh = m >> 1;
+  const int jm = n - (SK_T*P + m), km = n - (SK_T*Q + m);
+  bool failed = false;
+
+  // steps of a sweep: the lanes are active at t = s .. s + n - 1, the store wave one step later
+  const int T = (n + PK_SKEW + 1 + RK_R)/RK_R*RK_R;
+
+  // LDS indices of the compute lane (line coordinates: X at (a + 1) + XS (b + 1), Y at a + XS b)
+  const int a0 = 2*PA, b0 = 2*PB;
+  const int xT = a0 + XS*(b0 + 1);           // new (a0 - 1, b0); + XS: (a0 - 1, b0 + 1)
+  const int xF = (a0 + 1) + XS*b0;           // new (a0, b0 - 1); + 1: (a0 + 1, b0 - 1)
+  const int xOwn = (a0 + 1) + XS*(b0 + 1);   // own new values: + 0, + 1, + XS, + XS + 1
+  // the old values at I of the lines after the patch are elements of row t + 1 of the lanes PA + 1 /
+  // PB + 1 -- in the ring, where the stream wave has put that row -- or, along the + sides of the
+  // tile, the strip values the halo wave puts next to it (slot offsets in doubles):
+  //   (a0 + 2, b0), (a0 + 2, b0 + 1): lane + 1, its cells p = 0 (first half) and p = 2 (second half)
+  //   (a0, b0 + 2), (a0 + 1, b0 + 2): lane + 8, its cells p = 0, 1 (16 contiguous bytes)
+  const int rOwn = 2*lane;
+  const int rBo0 = PA < 7 ? 2*(lane + 1) : oHalo + b0;
+  const int rBo1 = PA < 7 ? 128 + 2*(lane + 1) : oHalo + b0 + 1;
+  const int rBk = PB < 7 ? 2*(lane + 8) : oHalo + 16 + a0;
+
+  // natural coordinates of the four lines of the lane: p = da + 2 db
+  int jl[4], kl[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    jl[p] = n - (SK_T*P + a0 + (p & 1));
+    kl[p] = n - (SK_T*Q + b0 + (p >> 1));
+  }
+  // ghost cells at the two ends of the lines: natural ghosts for the first sweep, then the periodic
+  // images (or the homogeneous BC of the side) kept in registers
+  double ghostL[4] = { 0., 0., 0., 0. }, ghostR[4] = { 0., 0., 0., 0. };
+  if (compute) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      ghostL[p] = A.un[A.L.idx (0, jl[p], kl[p])];
+      ghostR[p] = A.un[A.L.idx (n + 1, jl[p], kl[p])];
+    }
+  }
+
+  for (int sw = 0; sw < A.nsweeps; sw++) {
+    const bool more = sw + 1 < A.nsweeps;
+    const bool write_ghosts = sw + 2 == A.nsweeps;
+    u64 * const hbJ = A.hb + sw*A.hb_sweep, * const hbK = hbJ + A.hb_words;
+    u64 * const snJ = hbK + A.hb_words, * const snK = snJ + A.hb_words;
+    const u64 * const hbJp = hbJ - A.hb_sweep, * const hbKp = hbK - A.hb_sweep;   // previous sweep
+    const u64 * const snJp = snJ - A.hb_sweep, * const snKp = snK - A.hb_sweep;
+
+    if (A.stats && tid0 == 0)
+      A.stats[2*(tile*SK_MAXF + sw)] = __builtin_amdgcn_s_memrealtime ();
+
+    __syncthreads ();      // the LDS grids of the previous sweep are no longer read
+    for (int q = tid0; q < 2*XS*XS; q += RK_NTHREADS)
+      (&X[0][0])[q] = 0.;
+    __syncthreads ();
+
+    if (loader) {
+      // =========================== halo wave ===========================
+      const u64 * qH = A.dummy;
+      int hs = 0;
+      bool handoff = false;       // sentinel-guarded granule stream
+      double hsgn = 1.;           // sign of a homogeneous BC whose ghost this stream carries
+      int xy_halo = 0;
+      switch (g) {
+      case 0: // new values of line (-1, m), row t
+	if (P > 0)       { qH = hbJ + (long) tJm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0 && A.sgn[2] == 0.) { qH = hbJp + (long) tJm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = snJp + (long) tile*hstride + m + (long) 7*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[2]; }      /* own line a = 0: snapshot row I + mh + 7 = t + 7 */
+	else             { qH = (const u64 *) (A.un + A.L.idx (1 - mh, n + 1, km)); hs = 1; }
+	xy_halo = 0 + XS*(m + 1);
+	break;
+      case 1: // new values of line (m, -1)
+	if (Q > 0)       { qH = hbK + (long) tKm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0 && A.sgn[4] == 0.) { qH = hbKp + (long) tKm*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = snKp + (long) tile*hstride + m + (long) 7*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[4]; }      /* own line b = 0, row t + 7 */
+	else             { qH = (const u64 *) (A.un + A.L.idx (1 - mh, jm, n + 1)); hs = 1; }
+	xy_halo = (m + 1) + XS*0;
+	break;
+      case 2: // old values of line (16, m) = line (0, m) of tile (P + 1, Q) at I = t - 7 - mh
+	if (sw > 0 && (P + 1 < ntj || A.sgn[3] == 0.)) { qH = snJp + (long) tJp*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = hbJp + (long) tile*hstride + m - (long) 7*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[3]; }      /* own line a = 15: hand-off row I + mh = t - 7 */
+	else if (P + 1 < ntj) {
+	  // element (I, 0, m) of the next tile: row I + mh = t - 7, column 128 (m & 1) + 16 mh
+	  qH = (const u64 *) (A.us + tJp*tstride + SK_FP*SK_NL - (long) 7*SK_NL + 128*(m & 1) + 16*mh);
+	  hs = SK_NL;
+	}
+	else { qH = (const u64 *) (A.un + A.L.idx (1 - (7 + mh), 0, km)); hs = 1; }
+	xy_halo = SK_T + XS*m;
+	break;
+      default: // old values of line (m, 16) = line (m, 0) of tile (P, Q + 1) at I = t - 7 - mh
+	if (sw > 0 && (Q + 1 < ntj || A.sgn[5] == 0.)) { qH = snKp + (long) tKp*hstride + m; hs = SK_T; handoff = true; }
+	else if (sw > 0) { qH = hbKp + (long) tile*hstride + m - (long) 7*SK_T; hs = SK_T;
+			   handoff = true; hsgn = A.sgn[5]; }      /* own line b = 15 */
+	else if (Q + 1 < ntj) {
+	  // element (I, m, 0) of the tile behind: row t - 7, column 2 mh + (m & 1)
+	  qH = (const u64 *) (A.us + tKp*tstride + SK_FP*SK_NL - (long) 7*SK_NL + 2*mh + (m & 1));
+	  hs = SK_NL;
+	}
+	else { qH = (const u64 *) (A.un + A.L.idx (1 - (7 + mh), jm, 0)); hs = 1; }
+	xy_halo = m + XS*SK_T;
+      }
+      // new values go into the X grid of the step's parity; old values into the slot of row t + 1
+      double * const halo_x = &X[0][0] + xy_halo;
+      double * const halo_y = ring + oHalo + (g == 2 ? m : 16 + m);
+      const u64 * const qH0 = qH;
+      // a granule stream is awaited only at the steps at which its consumer lane is active
+      const int hlag = g < 2 ? mh : 7 + mh;
+      double pH[PK_DH];
+
+#define PK_HALO(t_, q_, refill_)					\
+      do {								\
+	double hv = pH[q_];						\
+	bool w = handoff && !failed && (unsigned) ((t_) - hlag) < (unsigned) n && \
+	  (u64) __double_as_longlong (hv) == SK_SENTINEL;		\
+	if (__builtin_expect (__any (w), 0)) {				\
+	  unsigned spins = 0;						\
+	  _Pragma ("nounroll")						\
+	  while (__any (w)) {						\
+	    __builtin_amdgcn_s_sleep (SK_POLL_SLEEP);			\
+	    if (w) {							\
+	      hv = __longlong_as_double ((long long) load_sc1 (qH0 + (long) (t_)*hs)); \
+	      w = (u64) __double_as_longlong (hv) == SK_SENTINEL;	\
+	    }								\
+	    if (++spins > (1u << 18)) { *A.err = 1; failed = true; break; } \
+	  }								\
+	}								\
+	if (g < 2) halo_x[((t_) & 1)*(XS*XS)] = hv*hsgn;		\
+	else halo_y[(((t_) + 1) % RK_R)*SS] = hv*hsgn;			\
+	if (refill_) {							\
+	  pH[q_] = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs; \
+	}								\
+      } while (0)
+
+      // strip values of step 0, then the ring holds steps 1 .. PK_DH
+      {
+	pH[0] = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs;
+	PK_HALO (0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < PK_DH; q++) {
+	pH[q] = __longlong_as_double ((long long) load_sc1 (qH)); qH += hs;
+      }
+      __syncthreads ();
+      // the value of step t + 1 is put into LDS during step t: slot (t mod PK_DH) holds step t + 1
+      for (int t0 = 0; t0 < T; t0 += RK_R) {
+#pragma unroll
+	for (int q = 0; q < RK_R; q++) {
+	  const int t = t0 + q;
+	  PK_HALO (t + 1, q % PK_DH, 1);
+	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	}
+      }
+#undef PK_HALO
+    }
+    else if (storer) {
+      // =========================== store wave ===========================
+      // lane (g, m) owns one outgoing line; the value the compute wave produced at step t - 1 sits
+      // in X[t & 1]
+      //   g = 0  line (15, m)  hand-off to tile (P + 1, Q), also its periodic image when a sweep follows
+      //   g = 1  line (m, 15)  hand-off to tile (P, Q + 1)
+      //   g = 2  line (0, m)   snapshot for the next sweep of tile (P - 1, Q)
+      //   g = 3  line (m, 0)   snapshot for the next sweep of tile (P, Q - 1)
+      u64 * pS = (u64 *) A.dummy;
+      bool sOn = false;
+      int sX = 0, sLag = 0;       // LDS index of the line's new value; I = t - 1 - sLag
+      double * pNat = nullptr;    // mirror mode: the line lies along a box side: natural address of cell i = t - sLag
+      switch (g) {
+      case 0: sOn = P + 1 < ntj || more; pS = hbJ + (long) tile*hstride + m - (long) 8*SK_T;   /* row t - 8 */
+	sX = SK_T + XS*(m + 1); sLag = 7 + mh;
+	if (A.mirror && P == ntj - 1) pNat = A.un + A.L.idx (0, 1, km) - sLag;
+	break;
+      case 1: sOn = Q + 1 < ntj || more; pS = hbK + (long) tile*hstride + m - (long) 8*SK_T;
+	sX = (m + 1) + XS*SK_T; sLag = 7 + mh;
+	if (A.mirror && Q == ntj - 1) pNat = A.un + A.L.idx (0, jm, 1) - sLag;
+	break;
+      case 2: sOn = more; pS = snJ + (long) tile*hstride + m + (long) 6*SK_T;                   /* row t + 6 */
+	sX = 1 + XS*(m + 1); sLag = mh;
+	if (A.mirror && P == 0) pNat = A.un + A.L.idx (0, n, km) - sLag;
+	break;
+      default: sOn = more; pS = snK + (long) tile*hstride + m + (long) 6*SK_T;
+	sX = (m + 1) + XS*1; sLag = mh;
+	if (A.mirror && Q == 0) pNat = A.un + A.L.idx (0, jm, n) - sLag;
+      }
+      // ... and every lane writes the row of the skewed copy that the compute lane of the same number
+      // produced in the previous step (its four new values are in X): the stores of the rows stay out
+      // of the compute wave's in-order memory queue, whose prefetched loads would wait behind them
+      double * wRow = ut + 2*lane - SK_NL;            // row t - 1
+      __syncthreads ();
+      for (int t0 = 0; t0 < T; t0 += RK_R) {
+#pragma unroll
+	for (int q = 0; q < RK_R; q++) {
+	  const int t = t0 + q;
+	  const int I = t - 1 - sLag;
+	  const double * Xb = X[t & 1];
+	  if (!(PK_KO & 2) && t > 0) {
+	    d2 o01, o23;
+	    o01.x = Xb[xOwn]; o01.y = Xb[xOwn + 1]; o23.x = Xb[xOwn + XS]; o23.y = Xb[xOwn + XS + 1];
+	    *(d2 *) wRow = o01; *(d2 *) (wRow + 128) = o23;
+	  }
+	  wRow += SK_NL;
+	  if (I >= 0 && I < n) {
+	    const double v = Xb[sX];
+	    if (pNat) pNat[t] = v;
+	    if (sOn) store_sc1 (pS, (u64) __double_as_longlong (v));
+	  }
+	  pS += SK_T;
+	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	}
+      }
+    }
+    else if (wave == 3) {
+      // =========================== stream wave ===========================
+      // LDS-DMA (global_load_lds, no register destination) of the rows into the ring: RK_DS steps
+      // ahead, one KB per instruction.  At step t: the u row t + 1 + RK_DS and the rhs (dia) row
+      // t + RK_DS are issued; the counted wait then retires what was issued RK_DS - 1 steps ago, i.e.
+      // the rows of step t + 1, before the barrier in front of that step.
+      const double * gU = ut + 2*lane, * gR = rt + 2*lane, * gD = HAS_DIA ? dt_ + 2*lane : nullptr;
+      constexpr int NI = HAS_DIA ? 6 : 4;
+#define RK_LOAD_ROW(src_, row_, dst_)						\
+      do {									\
+	__builtin_amdgcn_global_load_lds ((const void *) ((src_) + (long) (row_)*SK_NL),	\
+					  (__attribute__((address_space(3))) void *) (dst_), 16, 0, 0); \
+	__builtin_amdgcn_global_load_lds ((const void *) ((src_) + (long) (row_)*SK_NL + 128),	\
+					  (__attribute__((address_space(3))) void *) ((dst_) + 128), 16, 0, 0); \
+      } while (0)
+      // prologue: u rows 0 .. RK_DS, rhs rows 0 .. RK_DS - 1
+#pragma unroll
+      for (int r = 0; r <= RK_DS; r++)
+	RK_LOAD_ROW (gU, r, ring + (r % RK_R)*SS);
+#pragma unroll
+      for (int r = 0; r < RK_DS; r++) {
+	RK_LOAD_ROW (gR, r, ring + (r % RK_R)*SS + oRhs);
+	if (HAS_DIA) RK_LOAD_ROW (gD, r, ring + (r % RK_R)*SS + oDia);
+      }
+      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads ();
+      for (int t0 = 0; t0 < T; t0 += RK_R) {
+#pragma unroll
+	for (int q = 0; q < RK_R; q++) {
+	  const int t = t0 + q;
+	  if (!(PK_KO & 1)) {
+	    RK_LOAD_ROW (gU, t + 1 + RK_DS, ring + ((q + 1 + RK_DS) % RK_R)*SS);
+	    RK_LOAD_ROW (gR, t + RK_DS, ring + ((q + RK_DS) % RK_R)*SS + oRhs);
+	    if (HAS_DIA) RK_LOAD_ROW (gD, t + RK_DS, ring + ((q + RK_DS) % RK_R)*SS + oDia);
+	    {
+	      // s_waitcnt vmcnt (NI*(RK_DS - 1)) alone: gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]
+	      constexpr int N = NI*(RK_DS - 1);
+	      static_assert (N < 64, "the vmcnt counter holds 63");
+	      __builtin_amdgcn_s_waitcnt ((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+	    }
+	  }
+	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	}
+      }
+#undef RK_LOAD_ROW
+    }
+    else {
+      // =========================== compute wave ===========================
+      __syncthreads ();
+      // old values of the own cells at the I of step 0: row 0
+      const d2 c01 = *(const d2 *) (ring + rOwn), c23 = *(const d2 *) (ring + rOwn + 128);
+      double prev[4] = { ghostL[0], ghostL[1], ghostL[2], ghostL[3] };
+      double first[4] = { 0., 0., 0., 0. }, lastv[4] = { 0., 0., 0., 0. };
+      double cur[4] = { c01.x, c01.y, c23.x, c23.y };
+
+      for (int t0 = 0; t0 < T; t0 += RK_R) {
+#pragma unroll
+	for (int q = 0; q < RK_R; q++) {
+	  const int t = t0 + q;
+	  const int I = t - s;
+	  const int Bf = t & 1;
+	  const double * Xb = X[Bf];
+	  const double * const su = ring + ((q + 1) % RK_R)*SS;      // slot of the u row t + 1
+	  const double * const sr = ring + (q % RK_R)*SS;            // slot of the rhs (dia) row t
+	  const double Tn0 = Xb[xT], Tn1 = Xb[xT + XS];
+	  const double Fn0 = Xb[xF], Fn1 = Xb[xF + 1];
+	  const double Bo0 = su[rBo0], Bo1 = su[rBo1];
+	  const d2 bk = *(const d2 *) (su + rBk);
+	  const double Bk0 = bk.x, Bk1 = bk.y;
+	  const d2 n01 = *(const d2 *) (su + rOwn), n23 = *(const d2 *) (su + rOwn + 128);
+	  const d2 h01 = *(const d2 *) (sr + oRhs + rOwn), h23 = *(const d2 *) (sr + oRhs + rOwn + 128);
+	  d2 e01 = { 0., 0. }, e23 = { 0., 0. };
+	  if (HAS_DIA) { e01 = *(const d2 *) (sr + oDia + rOwn); e23 = *(const d2 *) (sr + oDia + rOwn + 128); }
+	  double nx[4] = { n01.x, n01.y, n23.x, n23.y };   // old values at I + 1
+	  const double keep[4] = { nx[0], nx[1], nx[2], nx[3] };
+	  // the two ends of the lines (one step each per lane and sweep: a rarely entered block instead
+	  // of selects in every step): left ghost at I = 0, right ghost at I = n - 1
+	  if (__builtin_expect (I == 0 || I == n - 1, 0)) {
+#pragma unroll
+	    for (int p = 0; p < 4; p++) {
+	      prev[p] = I == 0 ? ghostL[p] : prev[p];
+	      nx[p] = I == n - 1 ? ghostR[p] : nx[p];
+	    }
+	  }
+	  bool tiny = false;
+	  // (a0, b0): top and front from the neighbour lanes, bottom and back the lane's own old values
+	  double v0 = patch_cell<HAS_DIA> (nx[0], prev[0], Tn0, cur[1], Fn0, cur[2], h01.x, e01.x, tiny, false);
+	  // (a0 + 1, b0): top = the new (a0, b0)
+	  double v1 = patch_cell<HAS_DIA> (nx[1], prev[1], v0, Bo0, Fn1, cur[3], h01.y, e01.y, tiny, false);
+	  // (a0, b0 + 1): front = the new (a0, b0)
+	  double v2 = patch_cell<HAS_DIA> (nx[2], prev[2], Tn1, cur[3], v0, Bk0, h23.x, e23.x, tiny, false);
+	  // (a0 + 1, b0 + 1)
+	  double v3 = patch_cell<HAS_DIA> (nx[3], prev[3], v2, Bo1, v1, Bk1, h23.y, e23.y, tiny, false);
+	  if (!HAS_DIA && __builtin_expect (__builtin_amdgcn_ballot_w64 (tiny) != 0, 0)) {
+	    v0 = patch_cell<HAS_DIA> (nx[0], prev[0], Tn0, cur[1], Fn0, cur[2], h01.x, e01.x, tiny, true);
+	    v1 = patch_cell<HAS_DIA> (nx[1], prev[1], v0, Bo0, Fn1, cur[3], h01.y, e01.y, tiny, true);
+	    v2 = patch_cell<HAS_DIA> (nx[2], prev[2], Tn1, cur[3], v0, Bk0, h23.x, e23.x, tiny, true);
+	    v3 = patch_cell<HAS_DIA> (nx[3], prev[3], v2, Bo1, v1, Bk1, h23.y, e23.y, tiny, true);
+	  }
+	  prev[0] = v0; prev[1] = v1; prev[2] = v2; prev[3] = v3;
+	  if (__builtin_expect (I == 0 || I == n - 1, 0)) {
+	    const double vv[4] = { v0, v1, v2, v3 };
+#pragma unroll
+	    for (int p = 0; p < 4; p++) {
+	      first[p] = I == 0 ? vv[p] : first[p];
+	      lastv[p] = I == n - 1 ? vv[p] : lastv[p];
+	    }
+	  }
+	  // publish the new values for step t + 1 (the row itself is written by the store wave)
+	  double * Xn = X[Bf ^ 1];
+	  Xn[xOwn] = v0; Xn[xOwn + 1] = v1; Xn[xOwn + XS] = v2; Xn[xOwn + XS + 1] = v3;
+	  cur[0] = keep[0]; cur[1] = keep[1]; cur[2] = keep[2]; cur[3] = keep[3];
+	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	}
+      }
+      // ghosts of the lines for the next sweep: the periodic image, or the homogeneous BC of the side
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+	ghostL[p] = A.sgn[1] == 0. ? lastv[p] : A.sgn[1]*first[p];     // I = -1 (left side)
+	ghostR[p] = A.sgn[0] == 0. ? first[p] : A.sgn[0]*lastv[p];     // I = n  (right side)
+      }
+      if (A.mirror) {
+#pragma unroll
+	for (int p = 0; p < 4; p++) {
+	  A.un[A.L.idx (1, jl[p], kl[p])] = first[p];
+	  A.un[A.L.idx (n, jl[p], kl[p])] = lastv[p];
+	}
+      }
+      if (write_ghosts) {
+	// x ghosts of the last BC application (the y and z ghost planes: patch_loop_ghosts_kernel)
+#pragma unroll
+	for (int p = 0; p < 4; p++) {
+	  A.un[A.L.idx (n + 1, jl[p], kl[p])] = ghostR[p];
+	  A.un[A.L.idx (0, jl[p], kl[p])] = ghostL[p];
+	}
+      }
+    }
+    if (A.stats && tid0 == 0)
+      A.stats[2*(tile*SK_MAXF + sw) + 1] = __builtin_amdgcn_s_memrealtime ();
+  }
+}
+
 // y and z ghost planes left by the last BC application of the loop, from the granules of sweep
 // nsweeps - 2 (see skew_loop_ghosts_kernel); rows in this file's convention
 __global__ void __launch_bounds__(256)
@@ -573,13 +986,20 @@ patch_unpack_kernel (PatchPackArgs A)
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+static bool patch_regs ()
+{
+  static int v = -1;
+  if (v < 0) v = getenv ("GFSHIP_PATCH_REGS") != nullptr;
+  return v != 0;
+}
+
 int patch_resident_per_cu ()
 {
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_patch_loop_kernel<true>,
-						    PK_NTHREADS, 0) != hipSuccess)
-    return 0;
-  return per_cu;
+  hipError_t e = patch_regs () ?
+    hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_patch_loop_kernel<true>, PK_NTHREADS, 0) :
+    hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_ring_loop_kernel<true>, RK_NTHREADS, 0);
+  return e == hipSuccess ? per_cu : 0;
 }
 
 int patch_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u, const double * rhs,
@@ -618,10 +1038,16 @@ int patch_loop_launch (gfship_domain * dom, const SkewLoopArgs & A, int ntiles, 
 		       unsigned nrelax, float * ms)
 {
   if (ms) GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
-  if (has_dia)
-    hipLaunchKernelGGL (relax_patch_loop_kernel<true>, dim3 (ntiles), dim3 (PK_NTHREADS), 0, dom->stream, A);
+  if (patch_regs ()) {      /* the variant that streams through registers (GFSHIP_PATCH_REGS=1) */
+    if (has_dia)
+      hipLaunchKernelGGL (relax_patch_loop_kernel<true>, dim3 (ntiles), dim3 (PK_NTHREADS), 0, dom->stream, A);
+    else
+      hipLaunchKernelGGL (relax_patch_loop_kernel<false>, dim3 (ntiles), dim3 (PK_NTHREADS), 0, dom->stream, A);
+  }
+  else if (has_dia)
+    hipLaunchKernelGGL (relax_ring_loop_kernel<true>, dim3 (ntiles), dim3 (RK_NTHREADS), 0, dom->stream, A);
   else
-    hipLaunchKernelGGL (relax_patch_loop_kernel<false>, dim3 (ntiles), dim3 (PK_NTHREADS), 0, dom->stream, A);
+    hipLaunchKernelGGL (relax_ring_loop_kernel<false>, dim3 (ntiles), dim3 (RK_NTHREADS), 0, dom->stream, A);
   GFSHIP_HIP (hipGetLastError ());
   if (ms) {
     GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));
