@@ -106,6 +106,7 @@ int gfship_domain_create (gfship_domain ** out, int dim, int depth, const int si
   }
   dom->skew_old = getenv ("GFSHIP_SKEW_OLD") != nullptr;
   dom->patch = getenv ("GFSHIP_SKEW_LINES") == nullptr && !dom->skew_old;
+  { const char * w = getenv ("GFSHIP_PATCH_MIN_N"); if (w) dom->patch_min_n = atoi (w); }
   dom->no_fused_godunov3 = getenv ("GFSHIP_NO_ADVECT3") != nullptr;
   { const char * w = getenv ("GFSHIP_XCD_PLACE"); dom->xcd_place = w && w[0] == '1'; }
   { const char * w = getenv ("GFSHIP_WAVE_LOOP"); dom->wave_loop = w && w[0] == '1'; }

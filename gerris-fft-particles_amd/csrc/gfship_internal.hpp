@@ -97,10 +97,12 @@ struct gfship_domain {
   void * mpi_plan[GFSHIP_MAXLEVEL + 1] = {};  // MPI-sides-first sweep order of each level (poisson_kernels.hip)
   gfship_field dp_cache = -1;     // the `dp` temporary of gfs_poisson_cycle, kept between cycles
   int skew_resident = -1;         // workgroups of the fused relax loop that fit on the device
+  int patch_resident = 0;         // the same for the kernels of relax_patch_loop.hip
   bool wave_loop = false;         // fused relax loops by the experimental one-wave-per-tile kernel (GFSHIP_WAVE_LOOP=1)
   bool xcd_place = false;         // XCD-aware tile placement in the loop kernel (experiment, GFSHIP_XCD_PLACE=1)
   bool skew_old = false;          // single sweeps by the older four-wave kernel (GFSHIP_SKEW_OLD)
-  bool patch = true;              // 2 x 2 lines per lane (relax_patch_loop.hip); GFSHIP_SKEW_LINES=1: one line per thread
+  bool patch = true;              // 2 x 2 lines per lane (relax_patch_loop.hip) on the levels where it wins; GFSHIP_SKEW_LINES=1: one line per thread everywhere
+  int patch_min_n = 128;          // ... i.e. n >= 128 (GFSHIP_PATCH_MIN_N): on 64^3 and 32^3 (16 and 4 tiles) one line per thread is a few us faster
   bool no_fused_godunov = false;  // face-value arrays + separate kernels even on periodic boxes
   bool no_fused_godunov3 = false; // one launch per velocity component instead of the three at once (GFSHIP_NO_ADVECT3)
   bool no_fused_loop = false;     // one launch per sweep even where the fused loop applies
@@ -242,6 +244,7 @@ int  skew_time_loop (gfship_domain * dom, int level, Field * u, const double * r
 int  skew_check_error (gfship_domain * dom);
 // relax_patch_loop.hip
 int  patch_resident_per_cu ();
+inline bool patch_level (const gfship_domain * dom, int level) { return dom->patch && dom->lay[level].n >= dom->patch_min_n; }
 int  patch_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u, const double * rhs,
 		 const double * dia);
 int  patch_unpack (gfship_domain * dom, int level, SkewPlan * S, double * u, double * add_into);

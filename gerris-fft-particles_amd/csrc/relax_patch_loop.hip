@@ -988,9 +988,7 @@ patch_unpack_kernel (PatchPackArgs A)
 // ---------------------------------------------------------------------------------------------
 static bool patch_regs ()
 {
-  static int v = -1;
-  if (v < 0) v = getenv ("GFSHIP_PATCH_REGS") != nullptr;
-  return v != 0;
+  return getenv ("GFSHIP_PATCH_REGS") != nullptr;
 }
 
 int patch_resident_per_cu ()

@@ -416,7 +416,7 @@ void skew_free (gfship_domain * dom)
 static int skew_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u,
 		      const double * rhs, const double * dia)
 {
-  if (dom->patch)
+  if (patch_level (dom, level))
     return patch_pack (dom, level, S, u, rhs, dia);
   PackArgs A;
   A.add = nullptr;
@@ -434,7 +434,7 @@ static int skew_pack (gfship_domain * dom, int level, SkewPlan * S, const double
 static int skew_unpack (gfship_domain * dom, int level, SkewPlan * S, double * u,
 			double * add_into = nullptr)
 {
-  if (dom->patch)
+  if (patch_level (dom, level))
     return patch_unpack (dom, level, S, u, add_into);
   PackArgs A;
   A.L = dom->lay[level]; A.ntj = S->ntj; A.RT = S->RT;

@@ -751,8 +751,8 @@ skew_loop_ghosts_kernel (SkewLoopArgs A)
 // host side
 // ---------------------------------------------------------------------------------------------
 
-// workgroups of the loop kernels that are resident at once on the device
-static int skew_loop_resident (gfship_domain * dom)
+// workgroups of the loop kernel of a level that are resident at once on the device
+static int skew_loop_resident (gfship_domain * dom, int level)
 {
   if (dom->skew_resident < 0) {
     int per_cu = 0, per_cu_w = 0, dev = 0;
@@ -761,14 +761,16 @@ static int skew_loop_resident (gfship_domain * dom)
 	hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_skew_loop_kernel<true>,
 						      SK_NTHREADS, 0) != hipSuccess ||
 	hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu_w, relax_wave_loop_kernel,
-						      WV_NTHREADS, 0) != hipSuccess)
+						      WV_NTHREADS, 0) != hipSuccess) {
       dom->skew_resident = 0;
-    else if (dom->patch)
-      dom->skew_resident = patch_resident_per_cu ()*prop.multiProcessorCount;
-    else
+      dom->patch_resident = 0;
+    }
+    else {
       dom->skew_resident = (per_cu < per_cu_w ? per_cu : per_cu_w)*prop.multiProcessorCount;
+      dom->patch_resident = patch_resident_per_cu ()*prop.multiProcessorCount;
+    }
   }
-  return dom->skew_resident;
+  return patch_level (dom, level) ? dom->patch_resident : dom->skew_resident;
 }
 
 bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool bc)
@@ -779,7 +781,7 @@ bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool 
     if (dom->side[d] == GFSHIP_SIDE_EXTERNAL) return false;   /* the exchange comes between the sweeps */
   // every tile waits on tiles of the previous sweep: all of them must be resident
   int ntj = dom->lay[level].n/SK_T, ntiles = ntj*ntj;
-  return ntiles <= skew_loop_resident (dom);
+  return ntiles <= skew_loop_resident (dom, level);
 }
 
 // nrelax >= 2: the fused loop of a periodic level.  nrelax == 1: one sweep of any level the
@@ -824,7 +826,7 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   A.xorder = S->xorder;
   A.xticket = (unsigned *) S->ctl + 6;
   A.per_xcd = 0;
-  if (dom->xcd_place && S->xorder && ntiles >= 8 && skew_loop_resident (dom) >= ntiles) {
+  if (dom->xcd_place && S->xorder && ntiles >= 8 && skew_loop_resident (dom, level) >= ntiles) {
     A.per_xcd = ntiles/8;
     GFSHIP_HIP (hipMemsetAsync ((unsigned *) S->ctl + 6, 0, 8*sizeof (unsigned), dom->stream));
   }
@@ -837,7 +839,7 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
       GFSHIP_HIP (hipMalloc ((void **) &S->stats_loop, (size_t) ntiles*SK_MAXF*2*sizeof (u64)));
     A.stats = (u64 *) S->stats_loop;
   }
-  if (dom->patch) {
+  if (patch_level (dom, level)) {
     int r = patch_loop_launch (dom, A, ntiles, has_dia, nrelax, ms);
     if (r) return r;
     if (nrelax >= 2 && A.stats && ms)

@@ -590,3 +590,70 @@ def test_poisson_coefficients_with_alpha_bit_exact(dim, level, kind):
     L.go_relax(od.ptr, dim, level, 1., f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr)
     gd.relax(f["u"][1], f["rhs"][1], f["dia"][1])
     assert np.array_equal(f["u"][0].leaf()[inner], f["u"][1].download()[inner])
+
+
+# ---------------------------------------------------------------------------------------------
+# the three implementations of the pipelined sweep (one line per thread; 2 x 2 lines per lane with
+# the rows streamed through registers, or through an LDS ring by a fourth wave) on every size and
+# kind of side, whatever the default choice per level is
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("impl", ["lines", "patch_regs", "patch_ring"])
+@pytest.mark.parametrize("level,kind,use_dia", [(5, "periodic", False), (6, "dirichlet", False),
+                                                (6, "mixed", True), (6, "periodic", True),
+                                                (7, "neumann", False)])
+def test_every_sweep_implementation_bit_exact(impl, level, kind, use_dia, monkeypatch):
+    monkeypatch.delenv("GFSHIP_SKEW_LINES", raising=False)
+    monkeypatch.delenv("GFSHIP_PATCH_REGS", raising=False)
+    monkeypatch.setenv("GFSHIP_PATCH_MIN_N", "32")
+    if impl == "lines":
+        monkeypatch.setenv("GFSHIP_SKEW_LINES", "1")
+    elif impl == "patch_regs":
+        monkeypatch.setenv("GFSHIP_PATCH_REGS", "1")
+    L = O.lib()
+    dim = 3
+    side, bck = SIDES[kind]
+    rng = np.random.default_rng(9000 + level)
+    od, gd = _pair(dim, level, side)
+    L.go_poisson_coefficients(od.ptr)
+    gd.poisson_coefficients()
+    f = _rand_fields(od, gd, ["u", "rhs", "dia", "res"], rng)
+    for l in range(level + 1):
+        if use_dia:
+            a = np.abs(rng.standard_normal(f["dia"][0].level(l).shape)) + 0.5
+            f["dia"][0].level(l)[...] = a
+            f["dia"][1].upload(a, l)
+        else:
+            f["dia"][0].level(l)[...] = 0.
+            f["dia"][1].fill(0., l)
+    n = 1 << level
+    for d in range(2 * dim):
+        val = rng.standard_normal(n * n)
+        f["u"][0].set_bc(d, bck, val)
+        f["u"][1].set_bc(d, bck, val)
+    L.go_bc(f["u"][0].ptr, f["u"][0].ptr, level)
+    gd.bc(f["u"][1])
+    # single sweeps with the BC kernel around them (mirror mode) ...
+    for _ in range(2):
+        L.go_homogeneous_bc(f["u"][0].ptr, f["u"][0].ptr, level)
+        gd.homogeneous_bc(f["u"][1], f["u"][1])
+        L.go_relax(od.ptr, dim, level, 1., f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr)
+        gd.relax(f["u"][1], f["rhs"][1], f["dia"][1])
+        assert _faces_equal(f["u"][0].leaf(), f["u"][1].download(), dim)
+    # ... and V-cycles (fused loops where the sides allow it)
+    L.go_bc(f["u"][0].ptr, f["u"][0].ptr, level)
+    gd.bc(f["u"][1])
+    L.go_residual(od.ptr, dim, level, f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr,
+                  f["res"][0].ptr)
+    gd.residual(f["u"][1], f["rhs"][1], f["dia"][1], f["res"][1])
+    op, gp = od.params(), gd.params()
+    for p in (op, gp):
+        p.depth = level
+    for _ in range(2):
+        L.go_poisson_cycle(od.ptr, C.byref(op), f["u"][0].ptr, f["rhs"][0].ptr, f["dia"][0].ptr,
+                           f["res"][0].ptr)
+        gd.poisson_cycle(gp, f["u"][1], f["rhs"][1], f["dia"][1], f["res"][1])
+        assert _faces_equal(f["u"][0].leaf(), f["u"][1].download(), dim)
+        assert np.array_equal(_interior(f["res"][0].leaf(), dim),
+                              _interior(f["res"][1].download(), dim))
+    gd.destroy()
