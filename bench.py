@@ -129,7 +129,8 @@ def measure_roofline(dom, args, n):
         pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
         if args.level == 8 and fused and os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f)["kernels"]["relax_skew_loop_kernel"]["hbm_bytes_per_launch_guide_corrected"]
+                kernels = json.load(f)["kernels"]
+                traffic = next(iter(kernels.values()))["hbm_bytes_per_launch_guide_corrected"]
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": None if traffic is None else

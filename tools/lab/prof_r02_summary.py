@@ -43,26 +43,39 @@ def avg_us(prefix):
 
 
 # relax loops by level from the trace (grid size = tiles x 384 threads)
+# threads per tile: six-wave kernel 384, ring kernel (2 x 2 lines per lane + stream wave) 256,
+# register variant of it 192
+LOOPS = {"relax_skew_loop_kernel": 384, "relax_ring_loop_kernel": 256, "relax_patch_loop_kernel": 192}
+
+
+def loop_kernel(name):
+    for k in LOOPS:
+        if k in name:
+            return k
+    return None
+
+
 by_level = {}
 for r in csv.DictReader(open(trace)):
-    if "relax_skew_loop_kernel" not in r["Kernel_Name"]:
+    k = loop_kernel(r["Kernel_Name"])
+    if k is None:
         continue
     grid = int(r["Grid_Size_X"])
-    tiles = grid // 384
+    tiles = grid // LOOPS[k]
     n = int(round(tiles ** 0.5)) * 16
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    by_level.setdefault(n, []).append(d)
+    by_level.setdefault((n, k), []).append(d)
 lev = {}
-for n, ds in sorted(by_level.items()):
+for (n, k), ds in sorted(by_level.items()):
     ds.sort()
-    lev["level_n%d" % n] = {"tiles": (n // 16) ** 2, "dispatches": len(ds), "median_us": ds[len(ds) // 2],
-                            "min_us": ds[0], "max_us": ds[-1]}
+    lev["level_n%d" % n] = {"kernel": k, "tiles": (n // 16) ** 2, "dispatches": len(ds),
+                            "median_us": ds[len(ds) // 2], "min_us": ds[0], "max_us": ds[-1]}
 json.dump({"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 "
                       "--warmup 1 --no-cpu-baseline",
-           "note": "relax_skew_loop_kernel dispatches of the kernel trace grouped by level; at 256^3 the "
-                   "4-sweep loops of the steps and of the roofline entry plus single-sweep launches "
-                   "(hence min << median)",
-           "relax_skew_loop_kernel": lev}, open(os.path.join(DST, "r02_relax_loop_by_level_from_trace.json"), "w"),
+           "note": "dispatches of the sweep-loop kernels in the kernel trace grouped by level (ring kernel "
+                   "for n >= 128, six-wave kernel below); at 256^3 the 4-sweep loops of the steps and of "
+                   "the roofline entry plus single-sweep launches (hence min << median)",
+           "relax_loops": lev}, open(os.path.join(DST, "r02_relax_loop_by_level_from_trace.json"), "w"),
           indent=1)
 
 # PMC: FETCH_SIZE / WRITE_SIZE (KB) of relax_skew_loop_kernel over tools/relax_only.py 8
@@ -73,7 +86,8 @@ for key, pat in (("FETCH_SIZE", "pmc_fetch/**/f_counter_collection.csv"),
     shutil.copy(f, os.path.join(DST, "r02_pmc_%s_relax_loop_256.csv" % key))
     tot, launches = 0., 0
     for r in csv.DictReader(open(f)):
-        if "relax_skew_loop_kernel" in r["Kernel_Name"] and r["Counter_Name"] == key:
+        if loop_kernel(r["Kernel_Name"]) and r["Counter_Name"] == key:
+            pmc_kernel = loop_kernel(r["Kernel_Name"])
             tot += float(r["Counter_Value"])
             launches += 1
     pm[key] = (tot, launches)
@@ -85,11 +99,11 @@ raw = (fetch_kb + write_kb) * 1024
 corr = (2 * fetch_kb + write_kb) * 1024
 json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 "
                       "tools/relax_only.py 8 (separate passes)",
-           "note": "level 8 (256^3); counters summed over the %d launches of relax_skew_loop_kernel (= %d "
+           "note": "level 8 (256^3); counters summed over the %d launches of the sweep-loop kernel (= %d "
                    "sweeps) and divided by the sweeps; correction per MI355X_MICROARCH.md (FETCH_SIZE x 2 "
-                   "for wide coalesced reads; 8-byte-per-lane loads are uncalibrated there: the raw sum is "
-                   "kept beside it)" % (pm["FETCH_SIZE"][1], sweeps),
-           "kernels": {"relax_skew_loop_kernel": {
+                   "for wide coalesced reads: the ring kernel streams its rows with 16-byte LDS-DMA loads; "
+                   "the raw sum is kept beside it)" % (pm["FETCH_SIZE"][1], sweeps),
+           "kernels": {pmc_kernel: {
                "launches": pm["FETCH_SIZE"][1], "sweeps": sweeps,
                "FETCH_SIZE_KB_per_sweep": fetch_kb, "WRITE_SIZE_KB_per_sweep": write_kb,
                "hbm_bytes_per_sweep_raw": raw, "hbm_bytes_per_sweep_guide_corrected": corr,
