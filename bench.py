@@ -230,9 +230,20 @@ def main():
             if rank == 0:
                 uid = torch.frombuffer(bytearray(gfship.comm_unique_id()), dtype=torch.uint8).clone()
             dist.broadcast(uid, 0)
-            dom.comm_init(bytes(uid.numpy().tobytes()), rank, world, grid.b)
-            rccl_world = dom.comm_size()
-        else:
+            ok = torch.ones(1, dtype=torch.int32)
+            try:
+                dom.comm_init(bytes(uid.numpy().tobytes()), rank, world, grid.b)
+                rccl_world = dom.comm_size()
+            except Exception as e:      # reported, never silent: see "transport" in the line
+                sys.stderr.write("bench.py: rank %d: RCCL communicator failed: %s\n" % (rank, e))
+                ok[0] = 0
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                # every rank takes the same decision: host-staged hooks, and the line says so
+                backend = "gloo-staged (RCCL communicator failed on some rank)"
+                dom.destroy()
+                dom = gfship.Domain(3, args.level, grid.sides(rank), device=local_rank)
+        if backend != "rccl":
             import torch
             torch.cuda.set_device(local_rank)
             hooks = D.DeviceHooks(dom, D.Transport(grid, rank, torch.device("cuda", local_rank)))
@@ -347,7 +358,7 @@ def main():
                                       "%s (reference semantics: overlap = 0)"
                                       % (world, n, "x".join(map(str, grid.b)),
                                          "by ncclSend/ncclRecv inside libgfship" if backend == "rccl"
-                                         else "staged through the host (rehearsal)"),
+                                         else "staged through the host: " + backend),
                        "rccl_world_size": rccl_world,
                        "poisson_niter": [int(sim.projection_params.niter),
                                          int(sim.approx_projection_params.niter)]},
