@@ -176,6 +176,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--particles", type=int, default=2000000,
                     help="tracers of the config D line (0 = skip)")
+    ap.add_argument("--self-mpi", action="store_true",
+                    help="lab: one rank whose six sides are GfsBoundaryMpi sides facing the box itself "
+                         "(RCCL send / recv to self): the code path of a box in an N > 1 run, on one GPU")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -247,6 +250,10 @@ def main():
             import torch
             torch.cuda.set_device(local_rank)
             hooks = D.DeviceHooks(dom, D.Transport(grid, rank, torch.device("cuda", local_rank)))
+    elif args.self_mpi:
+        dom = gfship.Domain(3, args.level, [gfship.SIDE_EXTERNAL] * 6, device=local_rank)
+        dom.comm_init(gfship.comm_unique_id(), 0, 1, (1, 1, 1))
+        rccl_world = dom.comm_size()
     else:
         dom = gfship.Domain(3, args.level, [gfship.SIDE_PERIODIC] * 6, device=local_rank)
     if args.mode == "redblack":
@@ -285,7 +292,7 @@ def main():
     # (with several boxes the relax loop of a box has the halo exchange between its sweeps: the kernel
     # entry is then measured by rank 0 on a periodic box of its own, after the timed region)
     roofline = None
-    rdom = dom if world == 1 else (
+    rdom = dom if world == 1 and not args.self_mpi else (
         gfship.Domain(3, args.level, [gfship.SIDE_PERIODIC] * 6, device=local_rank) if rank == 0
         else None)
     if rdom is not None:
@@ -353,7 +360,8 @@ def main():
             "config": {"workload": "3-D periodic Taylor-Green, %d^3 per GPU, default "
                                    "projection/advection parameters (SURVEY 8d config C)" % n,
                        "relax_mode": args.mode,
-                       "parallelism": "1 box" if world == 1 else
+                       "parallelism": ("1 box" if not args.self_mpi else
+                                       "1 box, all sides GfsBoundaryMpi to itself (lab)") if world == 1 else
                                       "%d boxes of %d^3, lattice %s, one per GPU, halo exchange "
                                       "%s (reference semantics: overlap = 0)"
                                       % (world, n, "x".join(map(str, grid.b)),

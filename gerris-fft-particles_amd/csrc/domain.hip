@@ -108,6 +108,8 @@ int gfship_domain_create (gfship_domain ** out, int dim, int depth, const int si
   dom->patch = getenv ("GFSHIP_SKEW_LINES") == nullptr && !dom->skew_old;
   { const char * w = getenv ("GFSHIP_PATCH_MIN_N"); if (w) dom->patch_min_n = atoi (w); }
   dom->no_fused_godunov3 = getenv ("GFSHIP_NO_ADVECT3") != nullptr;
+  dom->no_lattice_cycle = getenv ("GFSHIP_NO_LATTICE_CYCLE") != nullptr;
+  dom->no_fused_mpi = getenv ("GFSHIP_NO_FUSED_MPI") != nullptr;
   { const char * w = getenv ("GFSHIP_XCD_PLACE"); dom->xcd_place = w && w[0] == '1'; }
   { const char * w = getenv ("GFSHIP_WAVE_LOOP"); dom->wave_loop = w && w[0] == '1'; }
   *out = dom;
@@ -127,6 +129,13 @@ void gfship_domain_destroy (gfship_domain * dom)
   skew_free (dom);
   if (dom->d_scratch) (void) hipFree (dom->d_scratch);
   if (dom->cfl_partial) (void) hipFree (dom->cfl_partial);
+  for (int d = 0; d < 6; d++) {
+    if (dom->gfv_send[d]) (void) hipFree (dom->gfv_send[d]);
+    if (dom->gfv_recv[d]) (void) hipFree (dom->gfv_recv[d]);
+  }
+  if (dom->lat_res) (void) hipFree (dom->lat_res);
+  if (dom->lat_xch) (void) hipFree (dom->lat_xch);
+  if (dom->lat_bar) (void) hipFree (dom->lat_bar);
   if (dom->h_pinned) (void) hipHostFree (dom->h_pinned);
   if (dom->ev0) (void) hipEventDestroy (dom->ev0);
   if (dom->ev1) (void) hipEventDestroy (dom->ev1);
@@ -167,6 +176,32 @@ int gfship_domain_set_reduce (gfship_domain * dom, gfship_reduce_fn fn, void * c
   GFSHIP_CHECK (dom != nullptr, GFSHIP_EINVAL, "null domain");
   dom->reduce = fn;
   dom->reduce_ctx = ctx;
+  return GFSHIP_OK;
+}
+
+int gfship_domain_set_gather (gfship_domain * dom, gfship_gather_fn fn, void * ctx, int rank,
+			      int nboxes, const int lattice[3])
+{
+  GFSHIP_CHECK (dom && lattice, GFSHIP_EINVAL, "null argument");
+  GFSHIP_CHECK (nboxes >= 1 && rank >= 0 && rank < nboxes &&
+		(long) lattice[0]*lattice[1]*lattice[2] == nboxes, GFSHIP_EINVAL,
+		"box %d of %d on a lattice of %d x %d x %d", rank, nboxes, lattice[0], lattice[1], lattice[2]);
+  for (int d = 0; d < 2*dom->dim; d++)
+    GFSHIP_CHECK (lattice[d/2] == 1 || dom->side[d] == GFSHIP_SIDE_EXTERNAL, GFSHIP_EINVAL,
+		  "side %d faces another box of the lattice: it must be GFSHIP_SIDE_EXTERNAL", d);
+  dom->gather = fn;
+  dom->gather_ctx = ctx;
+  dom->lat_rank = rank; dom->lat_n = nboxes;
+  for (int c = 0; c < 3; c++) dom->lat_b[c] = lattice[c];
+  return GFSHIP_OK;
+}
+
+int gfship_domain_path_counts (gfship_domain * dom, unsigned long long * lattice_cycles,
+			       unsigned long long * fused_mpi_launches)
+{
+  GFSHIP_CHECK (dom != nullptr, GFSHIP_EINVAL, "null domain");
+  if (lattice_cycles) *lattice_cycles = dom->n_lattice_cycles;
+  if (fused_mpi_launches) *fused_mpi_launches = dom->n_fused_mpi;
   return GFSHIP_OK;
 }
 

@@ -94,6 +94,19 @@ struct gfship_domain {
   bool has_external = false;
   void * comm = nullptr;          // in-library RCCL transport (transport.hip), replaces the hooks
   int overlap = 0;                // the domain parameter `overlap' of a parallel run (src/domain.c:225,682)
+  // the lattice of boxes this box belongs to (gfship_domain_comm_init or gfship_domain_set_gather)
+  int lat_rank = -1, lat_n = 0, lat_b[3] = { 1, 1, 1 };
+  gfship_gather_fn gather = nullptr; void * gather_ctx = nullptr;
+  // the coarse end of a V-cycle computed for every box of the lattice on every rank
+  // (lattice_cycle_kernel, poisson_kernels.hip): gathered residuals, layers between the boxes, barrier
+  double * lat_res = nullptr, * lat_xch = nullptr;
+  unsigned * lat_bar = nullptr;
+  size_t lat_res_doubles = 0, lat_xch_doubles = 0;
+  double * gfv_send[6] = {}, * gfv_recv[6] = {};   // states beyond the MPI sides of the tiled Godunov kernels
+  bool no_fused_mpi = false;      // GFSHIP_NO_FUSED_MPI=1: face-value arrays on boxes with MPI sides
+  unsigned long long n_lattice_cycles = 0, n_fused_mpi = 0;   // gfship_domain_path_counts
+  bool lattice_attr_set = false;  // dynamic-LDS limit of lattice_cycle_kernel raised
+  bool no_lattice_cycle = false;  // GFSHIP_NO_LATTICE_CYCLE=1: one exchange per sweep on every level
   void * mpi_plan[GFSHIP_MAXLEVEL + 1] = {};  // MPI-sides-first sweep order of each level (poisson_kernels.hip)
   gfship_field dp_cache = -1;     // the `dp` temporary of gfs_poisson_cycle, kept between cycles
   int skew_resident = -1;         // workgroups of the fused relax loop that fit on the device
@@ -156,6 +169,9 @@ int call_reduce (gfship_domain * dom, double * vals, int n, int op);
 int call_reduce_norm (gfship_domain * dom, double * sums, int nsum, double * mx);
 // transport.hip
 int comm_exchange (gfship_domain * dom, double * a, int level, int kind);
+int comm_exchange_raw (gfship_domain * dom, double * const send[6], double * const recv[6], size_t count);
+int comm_allgather (gfship_domain * dom, const double * send, double * recv, size_t count);
+int call_gather (gfship_domain * dom, const double * send, double * recv, size_t count);
 int comm_exchange_begin (gfship_domain * dom, double * a, int level);
 int comm_exchange_end (gfship_domain * dom, double * a, int level);
 int comm_reduce (gfship_domain * dom, double * sums, int nsum, double * maxs, int nmax,
@@ -172,6 +188,9 @@ int launch_relax_loop_small (gfship_domain * dom, unsigned dimension, int level,
 			     Field * dp, Field * ubc, const double * rhs, const double * dia,
 			     unsigned nrelax, bool * done, const RelaxOp * op = nullptr);
 int coarse_cycle_top (gfship_domain * dom, int minlevel);
+int lattice_cycle_top (gfship_domain * dom, int minlevel, Field * dia);
+int launch_lattice_cycle (gfship_domain * dom, unsigned dimension, double omega, int lmin, int ltop,
+			  const unsigned * nrelax, Field * dp, Field * ubc, Field * res);
 int launch_coarse_cycle (gfship_domain * dom, unsigned dimension, double omega, int lmin, int ltop,
 			 const unsigned * nrelax, Field * dp, Field * ubc, Field * res, Field * dia);
 int launch_relax_redblack (gfship_domain * dom, unsigned dimension, int level, double omega,
@@ -214,6 +233,7 @@ int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3],
 int launch_coarse_init (gfship_domain * dom, Field * const * v, int nf);
 int launch_velocity_divergence (gfship_domain * dom, double * const u[3], double * out);
 bool godunov_fused_supported (const gfship_domain * dom);
+bool godunov_fused_mpi_supported (const gfship_domain * dom);
 int launch_project_correct (gfship_domain * dom, const double * p, double * const un[3],
 			    double * const g[3], double * const u[3], double dt, bool want_max);
 int launch_cfl_from_max (gfship_domain * dom, double * cfl2);

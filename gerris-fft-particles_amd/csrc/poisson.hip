@@ -351,11 +351,18 @@ static int poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
     /* the coarse end of the cycle (restrictions, relax loops and prolongations of the levels that
        fit in LDS together) in one launch where that applies */
     const int ctop = dom->weighted ? -1 : coarse_cycle_top (dom, (int) minlevel);
+    /* ... or, on a box of a lattice of boxes, computed for all boxes on every rank after one
+       all-gather instead of one halo exchange per sweep and level (lattice_cycle_kernel) */
+    const int ltop = ctop >= 0 ? -1 : lattice_cycle_top (dom, (int) minlevel, D);
     /* compute residual on non-leafs cells (get_from_below, post-order: finest parents first) */
-    for (int l = L - 1; l >= (ctop >= 0 ? ctop + 1 : 0); l--)
+    for (int l = L - 1; l >= (ctop >= 0 ? ctop + 1 : ltop >= 0 ? ltop : 0); l--)
       TRY (launch_restrict (dom, p->dimension, l, S->lev[l], S->lev[l + 1]));
     unsigned first = minlevel;
-    if (ctop >= 0) {
+    if (ltop >= 0) {
+      TRY (launch_lattice_cycle (dom, p->dimension, p->omega, (int) minlevel, ltop, nrl, DP, U, S));
+      first = ltop + 1;
+    }
+    else if (ctop >= 0) {
       TRY (launch_coarse_cycle (dom, p->dimension, p->omega, (int) minlevel, ctop, nrl, DP, U, S, D));
       first = ctop + 1;
     }

@@ -490,6 +490,322 @@ int launch_coarse_cycle (gfship_domain * dom, unsigned dimension, double omega, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The coarse end of a V-cycle on a lattice of boxes (GfsBoundaryMpi sides): what costs the
+// reference -- and the per-level path here -- one halo exchange per sweep and level (20 exchanges
+// of a few hundred bytes on the levels up to 16^3, each a pack kernel, a send / receive pair and an
+// unpack kernel) is computed for EVERY box of the lattice on EVERY rank after one all-gather of the
+// residuals of the level ltop: workgroup b of the launch is box b, with its levels in LDS exactly
+// as coarse_cycle_kernel holds them; where the reference applies the BC (before every sweep) the
+// workgroups write the layers along their MPI sides to device memory, meet at a barrier and read
+// the layers of their neighbours into their ghost cells -- gfs_boundary_send / receive of
+// src/mpi_boundary.c:89-222 between workgroups.  Every rank performs the same operations in the
+// same order as the owners of the boxes would, so the values of its own box are the ones a run
+// with one exchange per sweep produces, bit for bit (tests/test_gpu_multibox.py).
+// The B <= 16 workgroups of 1024 threads are all resident (nothing else runs on the stream's
+// device at that point of the cycle), which the barrier needs.
+// ---------------------------------------------------------------------------------------------
+#define LAT_MAXBOXES 16
+
+struct LatticeCycleArgs {
+  Layout lay[GFSHIP_MAXLEVEL + 1];
+  int lmin, ltop;
+  unsigned nrelax[GFSHIP_MAXLEVEL + 1];
+  double * dp[GFSHIP_MAXLEVEL + 1];          // natural arrays of the own box, lmin..ltop are written
+  double * res[GFSHIP_MAXLEVEL + 1];         // natural arrays of the own box, lmin..ltop-1 are written
+  const double * gres;                       // res[ltop] of every box (natural layout), in rank order
+  unsigned long long * xch;                  // [2][B][6][nface (ltop)] layers between the boxes
+  unsigned * bar;                            // barrier counter, zero at launch
+  BcDesc bc;
+  unsigned dimension;
+  double omega;
+  int rank, nboxes, b[3];
+};
+
+typedef __attribute__((address_space(1))) unsigned long long lat_gu64;
+
+__device__ __forceinline__ void lattice_barrier (unsigned * bar, unsigned & target, int nboxes)
+{
+  __threadfence ();                  /* the layers of this workgroup are visible device-wide ... */
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    target += (unsigned) nboxes;
+    __hip_atomic_fetch_add (bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load (bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
+      __builtin_amdgcn_s_sleep (2);
+  }
+  __syncthreads ();
+  __threadfence ();                  /* ... and those of the others are read from memory */
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(1024)
+lattice_cycle_kernel (LatticeCycleArgs A)
+{
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int box = blockIdx.x;
+  const bool own = box == A.rank;
+  // the boxes across the six sides of this one
+  int nbox[6];
+  {
+    const int bx = A.b[0], by = A.b[1], bz = A.b[2];
+    const int cx = box % bx, cy = (box/bx) % by, cz = box/(bx*by);
+    for (int d = 0; d < 6; d++) {
+      int cc[3] = { cx, cy, cz };
+      cc[d/2] += (d & 1) ? -1 : 1;
+      cc[0] = (cc[0] + bx) % bx; cc[1] = (cc[1] + by) % by; cc[2] = (cc[2] + bz) % bz;
+      nbox[d] = cc[0] + bx*(cc[1] + by*cc[2]);
+    }
+  }
+  unsigned target = 0, parity = 0;
+  const size_t xface = DIM == 3 ? (size_t) A.lay[A.ltop].n*A.lay[A.ltop].n : (size_t) A.lay[A.ltop].n;
+  double * sdp[GFSHIP_MAXLEVEL + 1], * sres[GFSHIP_MAXLEVEL + 1];
+  {
+    size_t o = 0;
+    for (int l = A.lmin; l <= A.ltop; l++) {
+      size_t r = A.lay[l].n + 2, m = DIM == 3 ? r*r*r : r*r;
+      sdp[l] = lds + o; o += m;
+      sres[l] = lds + o; o += m;
+    }
+    for (size_t q = tid; q < o; q += nt)
+      lds[q] = 0.;
+  }
+  __syncthreads ();
+  // ---- the residual of the level ltop of this box, then the restrictions (restrict_kernel) ----
+  {
+    const Layout & L = A.lay[A.ltop];
+    const int n = L.n, r = n + 2;
+    const int ncell = DIM == 3 ? n*n*n : n*n;
+    const double * g = A.gres + (size_t) box*L.total;
+    for (int q = tid; q < ncell; q += nt) {
+      int i = q % n + 1, j = (q / n) % n + 1, k = DIM == 3 ? q / (n*n) + 1 : 0;
+      sres[A.ltop][i + r*(j + (DIM == 3 ? r*k : 0))] = g[L.idx (i, j, k)];
+    }
+    __syncthreads ();
+  }
+  for (int l = A.ltop - 1; l >= A.lmin; l--) {
+    const Layout & Lc = A.lay[l];
+    const int n = Lc.n, r = n + 2, rf = 2*n + 2;
+    const int ncell = DIM == 3 ? n*n*n : n*n;
+    for (int q = tid; q < ncell; q += nt) {
+      int i = q % n + 1, j = (q / n) % n + 1, k = DIM == 3 ? q / (n*n) + 1 : 0;
+      double val = 0.;
+#pragma unroll
+      for (int id = 0; id < (1 << DIM); id++) {
+	int ci = 2*i - 1 + (id & 1);
+	int cj = 2*j - 1 + ((id & 2) ? 0 : 1);
+	int ck = DIM == 3 ? 2*k - 1 + ((id & 4) ? 0 : 1) : 0;
+	val += sres[l + 1][ci + rf*(cj + (DIM == 3 ? rf*ck : 0))];
+      }
+      double v = A.dimension == 2 ? val : val/2.;
+      sres[l][i + r*(j + (DIM == 3 ? r*k : 0))] = v;
+      if (own) A.res[l][Lc.idx (i, j, k)] = v;
+    }
+    __syncthreads ();
+  }
+  // ---- relax loops from the coarsest level up ----
+  for (int l = A.lmin; l <= A.ltop; l++) {
+    const Layout & L = A.lay[l];
+    const int n = L.n, r = n + 2;
+    const long ssy = r, ssz = DIM == 3 ? (long) r*r : 0;
+    const int ncell = DIM == 3 ? n*n*n : n*n;
+    const int nface = DIM == 3 ? n*n : n;
+    double * s = sdp[l];
+    if (l > A.lmin) {
+      // get_from_above, src/poisson.c:1005-1042 (prolongate_kernel), one thread per fine cell
+      const int nc = n/2, rc = nc + 2;
+      const long cy = rc, cz = DIM == 3 ? (long) rc*rc : 0;
+      const double * vc = sdp[l - 1];
+      for (int q = tid; q < ncell; q += nt) {
+	int i = q % n + 1, j = (q / n) % n + 1, k = DIM == 3 ? q / (n*n) + 1 : 0;
+	int pi = (i + 1)/2, pj = (j + 1)/2, pk = DIM == 3 ? (k + 1)/2 : 0;
+	long p = pi + cy*pj + cz*pk;
+	double pv = vc[p];
+	double h[3];
+	const long off[3] = { 1, cy, cz };
+#pragma unroll
+	for (int cc = 0; cc < DIM; cc++) {
+	  double g1 = vc[p + off[cc]] - 1.*pv;
+	  double g2 = vc[p - off[cc]] - 1.*pv;
+	  h[cc] = (g1 - g2)/2.;
+	}
+	double rel[3] = { ((i & 1) ? -1. : 1.)/4., ((j & 1) ? -1. : 1.)/4., ((k & 1) ? -1. : 1.)/4. };
+	double val = pv;
+#pragma unroll
+	for (int cc = 0; cc < DIM; cc++)
+	  val += rel[cc]*h[cc];
+	s[i + ssy*j + ssz*k] = val;
+      }
+      __syncthreads ();
+    }
+    const double * rhs = sres[l];
+    for (unsigned sweep = 0; sweep < A.nrelax[l]; sweep++) {
+      // BC application: the layers along the MPI sides go out ...
+      unsigned long long * const out = A.xch + ((size_t) parity*A.nboxes + box)*6*xface;
+      for (int q = tid; q < 2*DIM*nface; q += nt) {
+	int d = q / nface, f = q % nface;
+	if (A.bc.side[d] != GFSHIP_SIDE_EXTERNAL) continue;
+	int c = d/2;
+	int t1 = f % n + 1, t2 = DIM == 3 ? f / n + 1 : 0;
+	int ijk[3] = { 0, 0, 0 };
+	int ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
+	ijk[c] = (d & 1) ? 1 : n;
+	ijk[ta] = t1;
+	if (DIM == 3) ijk[tb] = t2;
+	__hip_atomic_store ((lat_gu64 *) (out + d*xface + f),
+			    (unsigned long long) __double_as_longlong (s[ijk[0] + ssy*ijk[1] + ssz*ijk[2]]),
+			    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      lattice_barrier (A.bar, target, A.nboxes);
+      // ... and the ghost cells are filled: local sides as in bc_kernel, MPI sides from the layer the
+      // box across the side has just written (its side d ^ 1, same position on the face)
+      for (int q = tid; q < 2*DIM*nface; q += nt) {
+	int d = q / nface, f = q % nface;
+	int c = d/2;
+	int t1 = f % n + 1, t2 = DIM == 3 ? f / n + 1 : 0;
+	int ijk[3] = { 0, 0, 0 };
+	int ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
+	ijk[c] = (d & 1) ? 1 : n;
+	ijk[ta] = t1;
+	if (DIM == 3) ijk[tb] = t2;
+	long o = c == 0 ? 1 : c == 1 ? ssy : ssz;
+	if (d & 1) o = - o;
+	long nb = ijk[0] + ssy*ijk[1] + ssz*ijk[2];
+	double v;
+	if (A.bc.side[d] == GFSHIP_SIDE_PERIODIC)
+	  v = s[nb - (long) (n - 1)*o];
+	else if (A.bc.side[d] == GFSHIP_SIDE_EXTERNAL) {
+	  const unsigned long long * in = A.xch + ((size_t) parity*A.nboxes + nbox[d])*6*xface;
+	  v = __longlong_as_double ((long long)
+				    __hip_atomic_load ((lat_gu64 *) (in + (d ^ 1)*xface + f), __ATOMIC_RELAXED,
+						       __HIP_MEMORY_SCOPE_AGENT));
+	}
+	else
+	  v = ghost_value (A.bc.type[d], A.bc.component, c, s[nb], 1, 0., 0.);
+	s[nb + o] = v;
+      }
+      parity ^= 1;
+      __syncthreads ();
+      const int nplanes = DIM == 3 ? 3*n - 2 : 2*n - 1;
+      for (int plane = 0; plane < nplanes; plane++) {
+	for (int t = tid; t < nface; t += nt) {
+	  int J = t % n, K = DIM == 3 ? t / n : 0;
+	  int I = plane - J - K;
+	  if (I >= 0 && I < n) {
+	    int i = I + 1, j = n - J, k = DIM == 3 ? n - K : 0;
+	    long c = i + ssy*j + ssz*k;
+	    s[c] = relax_value<DIM, 0> (s, c, ssy, ssz, rhs[c], 0., A.dimension, A.omega, 1., 1.);
+	  }
+	}
+	__syncthreads ();
+      }
+    }
+    // natural copy of the own box with the ghost layer of the last BC application
+    if (own) {
+      const int nall = DIM == 3 ? r*r*r : r*r;
+      for (int q = tid; q < nall; q += nt) {
+	int i = q % r, j = (q / r) % r, k = DIM == 3 ? q / (r*r) : 0;
+	A.dp[l][L.idx (i, j, k)] = s[q];
+      }
+    }
+    __syncthreads ();
+  }
+}
+
+// highest level of the replicated coarse end (lmin .. ltop in LDS per box); -1 when it does not apply
+int lattice_cycle_top (gfship_domain * dom, int minlevel, Field * dia)
+{
+  if (!dom->has_external || dom->no_lattice_cycle || dom->overlap || dom->weighted)
+    return -1;
+  if (!(dom->comm || dom->gather) || dom->lat_rank < 0 || dom->lat_n < 1 || dom->lat_n > LAT_MAXBOXES)
+    return -1;
+  if (dom->relax_mode != GFSHIP_RELAX_EXACT || dom->force_hyperplane || dom->no_fused_loop)
+    return -1;
+  int top = -1;
+  size_t bytes = 0;
+  for (int l = minlevel; l < dom->depth; l++) {     /* the leaf level is never part of it */
+    if (dom->dim == 3 && skew_supported (dom, l)) break;
+    if (!dia->zero[l]) break;
+    size_t r = dom->lay[l].n + 2;
+    bytes += 2*(dom->dim == 3 ? r*r*r : r*r)*sizeof (double);
+    if (bytes > 150*1024) break;
+    top = l;
+  }
+  return top;
+}
+
+int launch_lattice_cycle (gfship_domain * dom, unsigned dimension, double omega, int lmin, int ltop,
+			  const unsigned * nrelax, Field * dp, Field * ubc, Field * res)
+{
+  LatticeCycleArgs A;
+  const int B = dom->lat_n;
+  const Layout & Lt = dom->lay[ltop];
+  const size_t xface = dom->dim == 3 ? (size_t) Lt.n*Lt.n : (size_t) Lt.n;
+  const size_t need_res = (size_t) B*Lt.total, need_xch = (size_t) 2*B*6*xface;
+  if (dom->lat_res_doubles < need_res) {
+    if (dom->lat_res) GFSHIP_HIP (hipFree (dom->lat_res));
+    dom->lat_res = nullptr; dom->lat_res_doubles = 0;
+    GFSHIP_HIP (hipMalloc ((void **) &dom->lat_res, need_res*sizeof (double)));
+    dom->lat_res_doubles = need_res;
+  }
+  if (dom->lat_xch_doubles < need_xch) {
+    if (dom->lat_xch) GFSHIP_HIP (hipFree (dom->lat_xch));
+    dom->lat_xch = nullptr; dom->lat_xch_doubles = 0;
+    GFSHIP_HIP (hipMalloc ((void **) &dom->lat_xch, need_xch*sizeof (double)));
+    dom->lat_xch_doubles = need_xch;
+  }
+  if (!dom->lat_bar)
+    GFSHIP_HIP (hipMalloc ((void **) &dom->lat_bar, 64));
+  // MPI_Allgather of the residual of the level ltop (whole arrays: contiguous, no pack kernel)
+  int r = call_gather (dom, res->lev[ltop], dom->lat_res, Lt.total);
+  if (r) return r;
+  GFSHIP_HIP (hipMemsetAsync (dom->lat_bar, 0, 64, dom->stream));
+  size_t bytes = 0;
+  for (int l = 0; l <= GFSHIP_MAXLEVEL; l++) {
+    A.lay[l] = dom->lay[l <= dom->depth ? l : dom->depth];
+    A.nrelax[l] = 0; A.dp[l] = nullptr; A.res[l] = nullptr;
+  }
+  for (int l = lmin; l <= ltop; l++) {
+    size_t rr = dom->lay[l].n + 2;
+    bytes += 2*(dom->dim == 3 ? rr*rr*rr : rr*rr)*sizeof (double);
+    A.nrelax[l] = nrelax[l];
+    A.dp[l] = dp->lev[l];
+    A.res[l] = res->lev[l];
+    dp->zero[l] = false;
+    res->zero[l] = false;
+  }
+  A.gres = dom->lat_res;
+  A.xch = (unsigned long long *) dom->lat_xch;
+  A.bar = dom->lat_bar;
+  A.lmin = lmin; A.ltop = ltop;
+  for (int d = 0; d < 6; d++) {
+    A.bc.side[d] = dom->side[d];
+    A.bc.type[d] = ubc->bc[d];
+    A.bc.val[d] = nullptr;
+  }
+  A.bc.component = ubc->component;
+  A.bc.homogeneous = 1;
+  A.dimension = dimension;
+  A.omega = omega;
+  A.rank = dom->lat_rank; A.nboxes = B;
+  for (int c = 0; c < 3; c++) A.b[c] = dom->lat_b[c];
+  if (!dom->lattice_attr_set) {
+    GFSHIP_HIP (hipFuncSetAttribute ((const void *) lattice_cycle_kernel<3>,
+				     hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
+    GFSHIP_HIP (hipFuncSetAttribute ((const void *) lattice_cycle_kernel<2>,
+				     hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
+    dom->lattice_attr_set = true;
+  }
+  if (dom->dim == 3)
+    hipLaunchKernelGGL (lattice_cycle_kernel<3>, dim3 (B), dim3 (1024), bytes, dom->stream, A);
+  else
+    hipLaunchKernelGGL (lattice_cycle_kernel<2>, dim3 (B), dim3 (1024), bytes, dom->stream, A);
+  GFSHIP_HIP (hipGetLastError ());
+  dom->n_lattice_cycles++;
+  return GFSHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Red-black Gauss-Seidel of the same operator (opt-in, not a reference algorithm): two colour
 // passes, each cell updated from the current values of its six neighbours.
 // ---------------------------------------------------------------------------------------------

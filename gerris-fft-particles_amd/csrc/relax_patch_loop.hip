@@ -50,7 +50,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned patch_claim_tile (const SkewLoopArgs & A)
 {
-  return A.order[atomicAdd (A.ticket, 1u)];
+  return A.order[atomicAdd (A.ticket, 1u) + 1u]   /* the ticket is armed with the granules: all ones */;
 }
 
 // one cell: relax, src/poisson.c:507-530, unit weights, d = 0..5 = right, left, top, bottom, front, back.

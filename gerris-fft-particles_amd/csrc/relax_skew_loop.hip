@@ -51,7 +51,7 @@ __device__ __forceinline__ unsigned skew_xcc_id ()
 __device__ __forceinline__ unsigned skew_claim_tile (const SkewLoopArgs & A)
 {
   if (A.per_xcd == 0)
-    return A.order[atomicAdd (A.ticket, 1u)];
+    return A.order[atomicAdd (A.ticket, 1u) + 1u]   /* the ticket is armed with the granules: all ones */;
   const unsigned x = skew_xcc_id ();
   for (unsigned q = 0; q < 8; q++) {
     const unsigned xx = (x + q) & 7;
@@ -461,7 +461,7 @@ relax_wave_loop_kernel (SkewLoopArgs A)
   const long hstride = (long) SK_HROWS (n)*SK_T;
 
   if (tid0 == 0)
-    s_tile = A.order[atomicAdd (A.ticket, 1u)];
+    s_tile = A.order[atomicAdd (A.ticket, 1u) + 1u]   /* the ticket is armed with the granules: all ones */;
   __syncthreads ();
   const int tile = s_tile;
   const int P = tile % ntj, Q = tile / ntj;
@@ -795,15 +795,17 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   long hstride = (long) SK_HROWS (L.n)*SK_T;
   long hb_words = (long) ntiles*hstride;
   long hb_sweep = 4*hb_words;
+  /* 8 words in front of the granules: the ticket counter, armed by the same fill (it then counts
+     from all ones: the claims add one) */
+  const size_t hdr = 8;
   if (!S->hbf) {
-    GFSHIP_HIP (hipMalloc ((void **) &S->hbf, (size_t) SK_MAXF*hb_sweep*sizeof (u64)));
+    GFSHIP_HIP (hipMalloc ((void **) &S->hbf, ((size_t) SK_MAXF*hb_sweep + hdr)*sizeof (u64)));
   }
-  GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
   /* a single sweep only uses the two hand-off arrays of its granule set.  (Arming the granules on a
      side stream, with two sets used in turn, was tried: no gain, the stores compete for HBM.) */
   /* (the snapshots of the last sweep are neither written nor read: its two hand-off arrays end the
      armed range) */
-  GFSHIP_HIP (hipMemsetAsync (S->hbf, 0xFF, ((size_t) (nrelax - 1)*hb_sweep + (size_t) 2*hb_words)*
+  GFSHIP_HIP (hipMemsetAsync (S->hbf, 0xFF, (hdr + (size_t) (nrelax - 1)*hb_sweep + (size_t) 2*hb_words)*
 			      sizeof (u64), dom->stream));
   SkewLoopArgs A;
   A.L = L; A.ntj = S->ntj; A.RT = S->RT; A.nsweeps = (int) nrelax;
@@ -821,7 +823,7 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   }
   A.us = S->us; A.rs = S->rs; A.ds = has_dia ? S->ds : nullptr;
   A.un = u_nat;
-  A.hb = (u64 *) S->hbf; A.hb_sweep = hb_sweep; A.hb_words = hb_words;
+  A.hb = (u64 *) S->hbf + hdr; A.hb_sweep = hb_sweep; A.hb_words = hb_words;
   A.order = S->order;
   A.xorder = S->xorder;
   A.xticket = (unsigned *) S->ctl + 6;
@@ -830,7 +832,7 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
     A.per_xcd = ntiles/8;
     GFSHIP_HIP (hipMemsetAsync ((unsigned *) S->ctl + 6, 0, 8*sizeof (unsigned), dom->stream));
   }
-  A.ticket = (unsigned *) S->ctl;
+  A.ticket = (unsigned *) S->hbf;
   A.err = (unsigned *) (dom->h_pinned + 32) + level;     /* skew_err_word, relax_skew.hip */
   A.dummy = (const u64 *) S->ctl + 2;
   A.stats = nullptr;

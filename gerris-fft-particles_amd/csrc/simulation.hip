@@ -331,7 +331,7 @@ int gfship_predicted_face_velocities (gfship_sim * s)
   ptrs6 (s, fv);
   /* the reset of every face (gfs_face_reset_normal_velocity) is implied: each component's
      faces are all overwritten below */
-  if (godunov_fused_supported (s->dom)) {
+  if (godunov_fused_supported (s->dom) || godunov_fused_mpi_supported (s->dom)) {
     double * u[3], * un[3];
     ptrs3 (s, s->u, u);
     ptrs3 (s, s->un, un);
@@ -366,7 +366,8 @@ int gfship_centered_velocity_advection (gfship_sim * s, const gfship_field gmac[
 					const gfship_field g[3])
 {
   GFSHIP_CHECK (s && gmac, GFSHIP_EINVAL, "null argument");
-  if (s->dom->dim == 3 && godunov_fused_supported (s->dom) && !s->dom->no_fused_godunov3 &&
+  if (s->dom->dim == 3 && (godunov_fused_supported (s->dom) || godunov_fused_mpi_supported (s->dom)) &&
+      !s->dom->no_fused_godunov3 &&
       s->visc[0] == 0. && s->visc[1] == 0. && s->visc[2] == 0.) {
     /* the three components in one pass over the box (same MAC velocities, nothing of one component
        feeds another): into scratch leaf levels, then the storage is swapped */

@@ -648,12 +648,24 @@ struct TileIdx {
   __device__ __forceinline__ int own () const { return tx + GX*(ty + GY*tz); }
 };
 
+struct GhostFv {
+  const double * r[6];     // received states beyond side d; nullptr: the side is not an MPI side
+  double * s[6];           // states to send across side d
+};
+
+// face position f of a ghost / layer cell of direction c: f = (x_a - 1) + n (x_b - 1) with a < b the
+// two directions other than c
+__device__ __forceinline__ int face_pos (int c, int n, int i, int j, int k)
+{
+  return c == 0 ? (j - 1) + n*(k - 1) : c == 1 ? (i - 1) + n*(k - 1) : (i - 1) + n*(j - 1);
+}
+
 // predictor of the three components in one pass: gfs_face_advected_normal_velocity
 // (src/advection.c:513-539) with the face values of u[c] along c computed in place
 // (use_centered_velocity = TRUE)
-template <bool VL, bool VS>
+template <bool VL, bool VS, bool MPI>
 __global__ void __launch_bounds__(GN)
-predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc)
+predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc, GhostFv G)
 {
   __shared__ double fl[3][GN], fr[3][GN];
   __shared__ double hp[3][GX*GZ];          // r of the cell beyond the + face of the tile
@@ -676,18 +688,33 @@ predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc)
     const int h = threadIdx.x;
     if (h < GX*GZ) {
       int p = h % GX, q = h / GX;
-      int ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + GY + 1, blockIdx.z*GZ + q + 1);
-      hp[1][h] = face_values_dir<3, 1, true, VL, VS> (L, u.p[1], u, none, ci, dt, visc.d[1]).r;
+      const int hi_ = blockIdx.x*GX + p + 1, hj = blockIdx.y*GY + GY + 1, hk = blockIdx.z*GZ + q + 1;
+      if (MPI && G.r[2] && hj > n)        /* beyond an MPI side: the state the box after this one sent */
+	hp[1][h] = G.r[2][face_pos (1, n, hi_, hj, hk)];
+      else {
+	int ci = image<3> (L, hi_, hj, hk);
+	hp[1][h] = face_values_dir<3, 1, true, VL, VS> (L, u.p[1], u, none, ci, dt, visc.d[1]).r;
+      }
     }
     else if (h < GX*GZ + GX*GY) {
       int hh = h - GX*GZ, p = hh % GX, q = hh / GX;
-      int ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + q + 1, blockIdx.z*GZ + GZ + 1);
-      hp[2][hh] = face_values_dir<3, 2, true, VL, VS> (L, u.p[2], u, none, ci, dt, visc.d[2]).r;
+      const int hi_ = blockIdx.x*GX + p + 1, hj = blockIdx.y*GY + q + 1, hk = blockIdx.z*GZ + GZ + 1;
+      if (MPI && G.r[4] && hk > n)
+	hp[2][hh] = G.r[4][face_pos (2, n, hi_, hj, hk)];
+      else {
+	int ci = image<3> (L, hi_, hj, hk);
+	hp[2][hh] = face_values_dir<3, 2, true, VL, VS> (L, u.p[2], u, none, ci, dt, visc.d[2]).r;
+      }
     }
     if (h < GY*GZ) {
       int p = h % GY, q = h / GY;
-      int ci = image<3> (L, blockIdx.x*GX + GX + 1, blockIdx.y*GY + p + 1, blockIdx.z*GZ + q + 1);
-      hp[0][h] = face_values_dir<3, 0, true, VL, VS> (L, u.p[0], u, none, ci, dt, visc.d[0]).r;
+      const int hi_ = blockIdx.x*GX + GX + 1, hj = blockIdx.y*GY + p + 1, hk = blockIdx.z*GZ + q + 1;
+      if (MPI && G.r[0] && hi_ > n)
+	hp[0][h] = G.r[0][face_pos (0, n, hi_, hj, hk)];
+      else {
+	int ci = image<3> (L, hi_, hj, hk);
+	hp[0][h] = face_values_dir<3, 0, true, VL, VS> (L, u.p[0], u, none, ci, dt, visc.d[0]).r;
+      }
     }
   }
   __syncthreads ();
@@ -705,8 +732,16 @@ predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc)
     double s_ = face_interp (ud[c], ud[c + off[d]]);
     double val = upwinded (s_, fl[d][T.own ()], r);
     un.p[d][c] = val;
+    if (MPI && G.r[2*d + 1]) {
+      // the face on the low side of the box: left state from the box before this one
+      if (ijk[d] == 1) {
+	const double gl = G.r[2*d + 1][face_pos (d, n, T.i, T.j, T.k)];
+	const double s0 = face_interp (ud[c - off[d]], ud[c]);
+	un.p[d][c - off[d]] = upwinded (s0, gl, fr[d][T.own ()]);
+      }
+    }
     // the face on the low side of the box is the periodic image of the one on the high side
-    if (ijk[d] == n)
+    else if (ijk[d] == n)
       un.p[d][c - n*off[d]] = val;
   }
 }
@@ -881,9 +916,82 @@ __device__ __forceinline__ FacePair adv_face_values (const double * __restrict__
   return f;
 }
 
-template <bool VL>
-__global__ void __launch_bounds__(GN)
-advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt)
+// ---------------------------------------------------------------------------------------------
+// The same kernels on a box with GfsBoundaryMpi sides.  The face value of a ghost cell beyond an MPI
+// side is what the neighbour box computed for its cell along that side (gfs_domain_face_bc over
+// gfs_boundary_send / receive): of everything the six face-value arrays hold, a box needs from its
+// neighbours one number per ghost cell and advected variable -- the left state of the layer n of the
+// box before it, the right state of the layer 1 of the box after it, in the direction of the side.
+// boundary_face_values_kernel computes exactly those for the own layers (the expressions of the
+// tiled kernels, hence the bits the neighbour would have found in the exchanged arrays), they
+// travel in ONE message per side (3 n^2 doubles for the three velocity components instead of the
+// six exchanges of whole-face arrays per component), and the tiled kernels take the states of the
+// cells before / after the box from the received buffers instead of recomputing periodic images.
+//   send[2c]   [q n^2 + f] = left state (direction c) of variable q in the cell of layer n at face position f
+//   send[2c+1] [q n^2 + f] = right state ........................................ layer 1
+//   recv[2c]: the right states of the layer 1 of the box across side 2c; recv[2c+1]: the left states
+//   of the layer n of the box across side 2c + 1
+// f = (x_a - 1) + n (x_b - 1) with a < b the two directions other than c.
+// ---------------------------------------------------------------------------------------------
+// CEN: the predictor (one variable per direction: u[c] along c, centred velocities); otherwise the
+// three velocity components with the MAC velocities (advect3_tiled_kernel)
+template <bool CEN, bool VL, bool VS>
+__global__ void __launch_bounds__(256)
+boundary_face_values_kernel (Layout L, CPtr3 v, CPtr3 un, double dt, Visc3 visc, GhostFv G)
+{
+  const int n = L.n;
+  const int f = blockIdx.x*blockDim.x + threadIdx.x;
+  const int d = blockIdx.y;
+  if (f >= n*n || !G.s[d]) return;
+  const int c = d/2;
+  const int t1 = f % n + 1, t2 = f / n + 1;
+  int ijk[3];
+  ijk[c] = (d & 1) ? 1 : n;
+  ijk[c == 0 ? 1 : 0] = t1;
+  ijk[c == 2 ? 1 : 2] = t2;
+  const int ci = (int) L.idx (ijk[0], ijk[1], ijk[2]);
+  const int off[3] = { 1, (int) L.sy, (int) L.sz };
+  const size_t nf = (size_t) n*n;
+  if (CEN) {
+    CPtr3 none = { { nullptr, nullptr, nullptr } };
+    FacePair p;
+    if (c == 0)      p = face_values_dir<3, 0, true, VL, VS> (L, v.p[0], v, none, ci, dt, visc.d[0]);
+    else if (c == 1) p = face_values_dir<3, 1, true, VL, VS> (L, v.p[1], v, none, ci, dt, visc.d[1]);
+    else             p = face_values_dir<3, 2, true, VL, VS> (L, v.p[2], v, none, ci, dt, visc.d[2]);
+    G.s[d][f] = (d & 1) ? p.r : p.l;
+  }
+  else {
+    const double rsize2 = (double) n/2.;
+    const AdvShared S = adv_shared (L, un, ci, dt);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const double * vq = v.p[q];
+      const double w0 = vq[ci];
+      FacePair p;
+      if (c == 0) {
+	const double ta = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
+	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
+	p = adv_face_values<0, VL> (vq, ci, off[0], w0, S.unorm[0], ta, tb, dt);
+      }
+      else if (c == 1) {
+	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
+	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
+	p = adv_face_values<1, VL> (vq, ci, off[1], w0, S.unorm[1], ta, tb, dt);
+      }
+      else {
+	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
+	const double tb = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
+	p = adv_face_values<2, VL> (vq, ci, off[2], w0, S.unorm[2], ta, tb, dt);
+      }
+      G.s[d][q*nf + f] = (d & 1) ? p.r : p.l;
+    }
+  }
+}
+
+template <bool VL, bool MPI>
+__device__ __forceinline__ void
+advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 & un, const CPtr3 & gm,
+	      const CPtr3 & gc, double dt, const GhostFv & G)
 {
   // R: right face values, then (after they have been read) the fluxes of the + faces
   __shared__ double R[3][3][GN];
@@ -921,8 +1029,19 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
   {
     const int h = threadIdx.x;
     const int grp = h / (GX*GZ), idx = h % (GX*GZ), p = idx % GX, qq = idx / GX;
+    const size_t nf = (size_t) n*n;
     if (grp < 2) {
-      const int ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + (grp ? GY + 1 : 0), blockIdx.z*GZ + qq + 1);
+      const int hi_ = blockIdx.x*GX + p + 1, hj = blockIdx.y*GY + (grp ? GY + 1 : 0), hk = blockIdx.z*GZ + qq + 1;
+      const double * gs = grp ? G.r[2] : G.r[3];     /* constant indices: G stays in scalar registers */
+      if (MPI && gs && (hj < 1 || hj > n)) {
+	// beyond an MPI side: the states the neighbour box sent
+	const double * g = gs + face_pos (1, n, hi_, hj, hk);
+#pragma unroll
+	for (int q = 0; q < 3; q++)
+	  if (grp) hp[q][1][idx] = g[q*nf]; else hm[q][1][idx] = g[q*nf];
+      }
+      else {
+      const int ci = image<3> (L, hi_, hj, hk);
       const AdvShared S = adv_shared (L, un, ci, dt);
 #pragma unroll
       for (int q = 0; q < 3; q++) {
@@ -933,9 +1052,19 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
 	const FacePair f = adv_face_values<1, VL> (vq, ci, off[1], w0, S.unorm[1], ta, tb, dt);
 	if (grp) hp[q][1][idx] = f.r; else hm[q][1][idx] = f.l;
       }
+      }
     }
     else {
-      const int ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + qq + 1, blockIdx.z*GZ + (grp == 3 ? GZ + 1 : 0));
+      const int hi_ = blockIdx.x*GX + p + 1, hj = blockIdx.y*GY + qq + 1, hk = blockIdx.z*GZ + (grp == 3 ? GZ + 1 : 0);
+      const double * gs = grp == 3 ? G.r[4] : G.r[5];
+      if (MPI && gs && (hk < 1 || hk > n)) {
+	const double * g = gs + face_pos (2, n, hi_, hj, hk);
+#pragma unroll
+	for (int q = 0; q < 3; q++)
+	  if (grp == 3) hp[q][2][idx] = g[q*nf]; else hm[q][2][idx] = g[q*nf];
+      }
+      else {
+      const int ci = image<3> (L, hi_, hj, hk);
       const AdvShared S = adv_shared (L, un, ci, dt);
 #pragma unroll
       for (int q = 0; q < 3; q++) {
@@ -946,10 +1075,20 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
 	const FacePair f = adv_face_values<2, VL> (vq, ci, off[2], w0, S.unorm[2], ta, tb, dt);
 	if (grp == 3) hp[q][2][idx] = f.r; else hm[q][2][idx] = f.l;
       }
+      }
     }
     if (h < 2*GY*GZ) {
       const int plus = h >= GY*GZ, hh = h % (GY*GZ), py = hh % GY, qz = hh / GY;
-      const int ci = image<3> (L, blockIdx.x*GX + (plus ? GX + 1 : 0), blockIdx.y*GY + py + 1, blockIdx.z*GZ + qz + 1);
+      const int hi_ = blockIdx.x*GX + (plus ? GX + 1 : 0), hj = blockIdx.y*GY + py + 1, hk = blockIdx.z*GZ + qz + 1;
+      const double * gs = plus ? G.r[0] : G.r[1];
+      if (MPI && gs && (hi_ < 1 || hi_ > n)) {
+	const double * g = gs + face_pos (0, n, hi_, hj, hk);
+#pragma unroll
+	for (int q = 0; q < 3; q++)
+	  if (plus) hp[q][0][hh] = g[q*nf]; else hm[q][0][hh] = g[q*nf];
+      }
+      else {
+      const int ci = image<3> (L, hi_, hj, hk);
       const AdvShared S = adv_shared (L, un, ci, dt);
 #pragma unroll
       for (int q = 0; q < 3; q++) {
@@ -959,6 +1098,7 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
 	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
 	const FacePair f = adv_face_values<0, VL> (vq, ci, off[0], w0, S.unorm[0], ta, tb, dt);
 	if (plus) hp[q][0][hh] = f.r; else hm[q][0][hh] = f.l;
+      }
       }
     }
   }
@@ -1043,6 +1183,23 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
       val -= gc.p[q][c]*dt;
     out.p[q][c] = val;
   }
+}
+
+// The centred-gradient kernel of a periodic box takes exactly 128 VGPRs (4 waves per SIMD = two tiles
+// per CU); the other variants would take 130-132 and lose a quarter of the occupancy: they are held
+// to 128 (a few dwords of scratch).
+template <bool VL, bool MPI>
+__global__ void __launch_bounds__(GN)
+advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt, GhostFv G)
+{
+  advect3_tile<VL, MPI> (L, v, out, un, gm, gc, dt, G);
+}
+
+template <bool VL, bool MPI>
+__global__ void __launch_bounds__(GN, 4)
+advect3_tiled_kernel_w4 (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt, GhostFv G)
+{
+  advect3_tile<VL, MPI> (L, v, out, un, gm, gc, dt, G);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1377,6 +1534,37 @@ bool godunov_fused_supported (const gfship_domain * dom)
   return true;
 }
 
+// boxes of a lattice (PERIODIC and GfsBoundaryMpi sides only) with the library's own communicator:
+// the tiled kernels with the states beyond the MPI sides exchanged in one message per side
+bool godunov_fused_mpi_supported (const gfship_domain * dom)
+{
+  if (dom->dim != 3 || dom->no_fused_godunov || dom->no_fused_mpi || !dom->comm) return false;
+  const int n = dom->lay[dom->depth].n;
+  if (n % GX) return false;
+  bool ext = false;
+  for (int d = 0; d < 6; d++) {
+    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL) ext = true;
+    else if (dom->side[d] != GFSHIP_SIDE_PERIODIC) return false;
+  }
+  return ext;
+}
+
+// send / receive buffers of the states beyond the MPI sides (3 n^2 doubles per side)
+static int ghost_fv (gfship_domain * dom, GhostFv * G)
+{
+  const Layout & L = dom->lay[dom->depth];
+  const size_t bytes = (size_t) 3*L.n*L.n*sizeof (double);
+  for (int d = 0; d < 6; d++) {
+    G->r[d] = nullptr; G->s[d] = nullptr;
+    if (dom->side[d] != GFSHIP_SIDE_EXTERNAL) continue;
+    if (!dom->gfv_send[d]) GFSHIP_HIP (hipMalloc ((void **) &dom->gfv_send[d], bytes));
+    if (!dom->gfv_recv[d]) GFSHIP_HIP (hipMalloc ((void **) &dom->gfv_recv[d], bytes));
+    G->s[d] = dom->gfv_send[d];
+    G->r[d] = dom->gfv_recv[d];
+  }
+  return GFSHIP_OK;
+}
+
 int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt, int gradient,
 			     const double visc[3], double * const un[3])
 {
@@ -1385,8 +1573,23 @@ int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt
   for (int c = 0; c < 3; c++) vs.d[c] = visc[c];
   const bool anyv = visc[0] != 0. || visc[1] != 0. || visc[2] != 0.;
   const dim3 grid (L.n/GX, L.n/GY, L.n/GZ);
-#define PK(VL_, VS_) hipLaunchKernelGGL ((predict_un_tiled_kernel<VL_, VS_>), grid, dim3 (GN), 0, \
-					 dom->stream, L, c3 (u), m3 (un), dt, vs)
+  GhostFv G;
+  for (int d = 0; d < 6; d++) { G.r[d] = nullptr; G.s[d] = nullptr; }
+  const bool mpi = dom->has_external;
+  if (mpi) {
+    int r = ghost_fv (dom, &G);
+    if (r) return r;
+    const dim3 bgrid ((L.n*L.n + 255)/256, 6);
+    CPtr3 none = { { nullptr, nullptr, nullptr } };
+#define BK(VL_, VS_) hipLaunchKernelGGL ((boundary_face_values_kernel<true, VL_, VS_>), bgrid, dim3 (256), 0, 					 dom->stream, L, c3 (u), none, dt, vs, G)
+    if (gradient) { if (anyv) BK (true, true); else BK (true, false); }
+    else          { if (anyv) BK (false, true); else BK (false, false); }
+#undef BK
+    GFSHIP_HIP (hipGetLastError ());
+    if ((r = comm_exchange_raw (dom, dom->gfv_send, dom->gfv_recv, (size_t) L.n*L.n))) return r;
+    dom->n_fused_mpi++;
+  }
+#define PK(VL_, VS_) do { if (mpi) hipLaunchKernelGGL ((predict_un_tiled_kernel<VL_, VS_, true>), grid, dim3 (GN), 0, 							dom->stream, L, c3 (u), m3 (un), dt, vs, G);     else hipLaunchKernelGGL ((predict_un_tiled_kernel<VL_, VS_, false>), grid, dim3 (GN), 0, 			     dom->stream, L, c3 (u), m3 (un), dt, vs, G); } while (0)
   if (gradient) { if (anyv) PK (true, true); else PK (true, false); }
   else          { if (anyv) PK (false, true); else PK (false, false); }
 #undef PK
@@ -1416,7 +1619,7 @@ int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, d
   return GFSHIP_OK;
 }
 
-// the three velocity components at once (periodic 3-D box, no viscosity)
+// the three velocity components at once (3-D box of periodic / MPI sides, no viscosity)
 int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * const out[3],
 			  double * const un[3], double * const gm[3], double * const gc[3],
 			  double dt, int gradient)
@@ -1425,12 +1628,27 @@ int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * con
   dim3 grid (L.n/GX, L.n/GY, L.n/GZ);
   CPtr3 gcp;
   for (int c = 0; c < 3; c++) gcp.p[c] = gc ? gc[c] : nullptr;
-  if (gradient)
-    hipLaunchKernelGGL (advect3_tiled_kernel<true>, grid, dim3 (GN), 0, dom->stream, L, c3 (v), m3 (out),
-			c3 (un), c3 (gm), gcp, dt);
-  else
-    hipLaunchKernelGGL (advect3_tiled_kernel<false>, grid, dim3 (GN), 0, dom->stream, L, c3 (v), m3 (out),
-			c3 (un), c3 (gm), gcp, dt);
+  GhostFv G;
+  for (int d = 0; d < 6; d++) { G.r[d] = nullptr; G.s[d] = nullptr; }
+  const bool mpi = dom->has_external;
+  if (mpi) {
+    int r = ghost_fv (dom, &G);
+    if (r) return r;
+    const dim3 bgrid ((L.n*L.n + 255)/256, 6);
+    Visc3 vs = { { 0., 0., 0. } };
+    if (gradient)
+      hipLaunchKernelGGL ((boundary_face_values_kernel<false, true, false>), bgrid, dim3 (256), 0, dom->stream,
+			  L, c3 (v), c3 (un), dt, vs, G);
+    else
+      hipLaunchKernelGGL ((boundary_face_values_kernel<false, false, false>), bgrid, dim3 (256), 0, dom->stream,
+			  L, c3 (v), c3 (un), dt, vs, G);
+    GFSHIP_HIP (hipGetLastError ());
+    if ((r = comm_exchange_raw (dom, dom->gfv_send, dom->gfv_recv, (size_t) 3*L.n*L.n))) return r;
+    dom->n_fused_mpi++;
+  }
+#define AK(VL_) do { if (mpi) hipLaunchKernelGGL ((advect3_tiled_kernel<VL_, true>), grid, dim3 (GN), 0, dom->stream, 						  L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, G);     else hipLaunchKernelGGL ((advect3_tiled_kernel<VL_, false>), grid, dim3 (GN), 0, dom->stream, 			     L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, G); } while (0)
+  if (gradient) AK (true); else AK (false);
+#undef AK
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
 }

@@ -222,6 +222,35 @@ int comm_reduce (gfship_domain * dom, double * sums, int nsum, double * maxs, in
   return GFSHIP_OK;
 }
 
+// `count' doubles per MPI side from caller's buffers: send[d] goes to the box across side d, recv[d]
+// receives what that box sent across its side d ^ 1 (same matching order as comm_exchange)
+int comm_exchange_raw (gfship_domain * dom, double * const send[6], double * const recv[6], size_t count)
+{
+  Comm * C = (Comm *) dom->comm;
+  int sd[6], rv[6];
+  const int ns = comm_sides (dom, sd, rv);
+  if (ns == 0) return GFSHIP_OK;
+  GFSHIP_NCCL (g_rccl.GroupStart ());
+  for (int q = 0; q < ns; q++)
+    GFSHIP_NCCL (g_rccl.Send (send[sd[q]], count, ncclDouble, C->peer[sd[q]], C->comm, dom->stream));
+  for (int q = 0; q < ns; q++)
+    GFSHIP_NCCL (g_rccl.Recv (recv[rv[q]], count, ncclDouble, C->peer[rv[q]], C->comm, dom->stream));
+  GFSHIP_NCCL (g_rccl.GroupEnd ());
+  C->messages += ns;
+  C->bytes += ns*count*sizeof (double);
+  return GFSHIP_OK;
+}
+
+// MPI_Allgather of `count' doubles per rank, in rank order, on the domain's stream
+int comm_allgather (gfship_domain * dom, const double * send, double * recv, size_t count)
+{
+  Comm * C = (Comm *) dom->comm;
+  GFSHIP_NCCL (g_rccl.AllGather (send, recv, count, ncclDouble, C->comm, dom->stream));
+  C->messages += 1;
+  C->bytes += count*sizeof (double);
+  return GFSHIP_OK;
+}
+
 void comm_free (gfship_domain * dom)
 {
   Comm * C = (Comm *) dom->comm;
@@ -284,6 +313,8 @@ int gfship_domain_comm_init (gfship_domain * dom, const void * unique_id, int ra
   dom->comm = C;
   C->rank = rank; C->nranks = nranks;
   for (int c = 0; c < 3; c++) C->b[c] = lattice[c];
+  dom->lat_rank = rank; dom->lat_n = nranks;
+  for (int c = 0; c < 3; c++) dom->lat_b[c] = lattice[c];
   const int cx = rank % C->b[0], cy = (rank/C->b[0]) % C->b[1], cz = rank/(C->b[0]*C->b[1]);
   for (int d = 0; d < 6; d++) {
     int cc[3] = { cx, cy, cz };

@@ -114,6 +114,8 @@ SIGNATURES = {
     "gfship_domain_set_overlap": (_i, [_vp, _i]),
     "gfship_domain_set_exchange": (_i, [_vp, _vp, _vp]),
     "gfship_domain_set_reduce": (_i, [_vp, _vp, _vp]),
+    "gfship_domain_set_gather": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(C.c_int)]),
+    "gfship_domain_path_counts": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "gfship_sim_restart": (_i, [_vp, _d, _u]),
     "gfship_snapshot_tree_bytes": (C.c_size_t, [_vp, _i]),
     "gfship_snapshot_tree_write": (_i, [_vp, _i, _pi, _vp, C.c_size_t]),
@@ -260,6 +262,12 @@ class Domain:
         m, b = C.c_ulonglong(), C.c_ulonglong()
         _check(lib().gfship_domain_comm_stats(self.ptr, C.byref(m), C.byref(b)))
         return int(m.value), int(b.value)
+
+    def path_counts(self):
+        """(coarse ends of V-cycles computed for the whole lattice, tiled Godunov launches with MPI sides)"""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        _check(lib().gfship_domain_path_counts(self.ptr, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def snapshot_tree(self, variables):
         """the binary cell data of a GfsBox (gfship_snapshot_tree_write) as bytes"""

@@ -182,6 +182,7 @@ def _kind_sides(grid, kind):
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
 REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 class DeviceHooks:
@@ -201,6 +202,14 @@ class DeviceHooks:
         self._red = REDUCE_FN(self._reduce)
         gfship._check(self.lib.gfship_domain_set_exchange(dom.ptr, C.cast(self._ex, C.c_void_p), None))
         gfship._check(self.lib.gfship_domain_set_reduce(dom.ptr, C.cast(self._red, C.c_void_p), None))
+        # a transport that can gather device memory of all boxes (gather_device (send, recv, nbytes,
+        # stream)) also serves the replicated coarse end of the V-cycle (include/gfship.h)
+        self._gat = None
+        if hasattr(transport, "gather_device"):
+            self._gat = GATHER_FN(self._gather)
+            g = transport.grid
+            gfship._check(self.lib.gfship_domain_set_gather(
+                dom.ptr, C.cast(self._gat, C.c_void_p), None, transport.rank, g.n, (C.c_int * 3)(*g.b)))
 
     def _plan(self, level, kind):
         """what one exchange of (level, kind) needs, built once: side lists, buffers and the
@@ -241,6 +250,15 @@ class DeviceHooks:
                     return rc
             return 0
         except Exception as e:     # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _gather(self, ctx, send, recv, nbytes):
+        try:
+            self.tr.gather_device(send, recv, nbytes, int(self.lib.gfship_domain_stream(self.dom.ptr)))
+            return 0
+        except Exception:
             import traceback
             traceback.print_exc()
             return 1

@@ -386,6 +386,28 @@ typedef int (* gfship_exchange_fn) (void * ctx, void * dev_ptr, int level, int k
 typedef int (* gfship_reduce_fn) (void * ctx, double * vals, int n, int op);
 int  gfship_domain_set_exchange (gfship_domain * dom, gfship_exchange_fn fn, void * ctx);
 int  gfship_domain_set_reduce (gfship_domain * dom, gfship_reduce_fn fn, void * ctx);
+/* Optional third hook, together with the place of the box on the periodic lattice of boxes (rank r
+   at (r % bx, (r / bx) % by, r / (bx by)), as for gfship_domain_comm_init below):
+   gather: MPI_Allgather of `bytes' bytes of device memory per box: dev_recv + r*bytes receives what
+     box r passed as dev_send; ordered after everything enqueued on gfship_domain_stream(), complete
+     (or enqueued on that stream) on return.
+   With it -- or with the library's own communicator -- the coarse end of a multigrid cycle (the
+   levels of at most 16^3 cells per box: restrictions, relax loops with the BC application between
+   their sweeps, prolongations; src/poisson.c:1131-1168) needs ONE collective instead of one halo
+   exchange per sweep and level: every rank gathers the residuals of all boxes on the finest of
+   those levels and runs the sweeps of every box of the lattice itself, handing the layers between
+   the boxes over in device memory exactly where the reference's BC application would -- the same
+   arithmetic in the same order on every rank, hence the same bits as one exchange per sweep.
+   GFSHIP_NO_LATTICE_CYCLE=1 in the environment keeps one exchange per sweep. */
+typedef int (* gfship_gather_fn) (void * ctx, const void * dev_send, void * dev_recv, size_t bytes);
+int  gfship_domain_set_gather (gfship_domain * dom, gfship_gather_fn fn, void * ctx, int rank,
+			       int nboxes, const int lattice[3]);
+/* Which of the multi-box fast paths have run on this domain (for tests and benchmarks: both are
+   bit-identical to the paths they replace): coarse ends of V-cycles computed for the whole lattice
+   after one gather; launches of the tiled Godunov kernels with the face states beyond the MPI sides
+   exchanged in one message per side (library communicator only, GFSHIP_NO_FUSED_MPI=1 disables). */
+int  gfship_domain_path_counts (gfship_domain * dom, unsigned long long * lattice_cycles,
+				unsigned long long * fused_mpi_launches);
 /* The same boundary served inside the library over RCCL (xGMI on one node), no hooks: the domain
    is one GfsBox of a periodic lattice of lattice[0] x lattice[1] x lattice[2] boxes, one box per
    rank / GPU, rank r at (r % bx, (r / bx) % by, r / (bx by)) (gfs_domain_split, src/domain.c:2576-2599,

@@ -72,6 +72,17 @@ class OracleHooks:
 # GFSHIP_SIDE_EXTERNAL path of libgfship on a single GPU
 # ---------------------------------------------------------------------------------------------
 
+_HIP = None
+
+
+def _hip():
+    global _HIP
+    if _HIP is None:
+        import ctypes as C
+        _HIP = C.CDLL("libamdhip64.so")
+    return _HIP
+
+
 class LocalFabric:
     """shared state of the LocalTransports of one process"""
 
@@ -105,6 +116,24 @@ class LocalTransport:
             rcv[r].copy_(f.posted[peer][r ^ 1])
         if self.device.type == "cuda":
             self.torch.cuda.current_stream().synchronize()     # my copies are complete
+        f.barrier.wait()
+
+    def gather_device(self, send, recv, nbytes, stream):
+        """MPI_Allgather of device memory between the boxes of this process (the gather hook of
+        include/gfship.h): device-to-device copies on the caller's stream"""
+        import ctypes as C
+        f = self.fabric
+        hip = _hip()
+        if hip.hipStreamSynchronize(C.c_void_p(stream)):       # what I send is complete
+            raise RuntimeError("hipStreamSynchronize")
+        f.posted[self.rank] = send
+        f.barrier.wait()
+        for r in range(f.n):
+            if hip.hipMemcpyAsync(C.c_void_p(recv + r * nbytes), C.c_void_p(f.posted[r]), C.c_size_t(nbytes),
+                                  3, C.c_void_p(stream)):
+                raise RuntimeError("hipMemcpyAsync")
+        if hip.hipStreamSynchronize(C.c_void_p(stream)):       # nobody overwrites what I still read
+            raise RuntimeError("hipStreamSynchronize")
         f.barrier.wait()
 
     def exchange_records(self, out, rs=7):

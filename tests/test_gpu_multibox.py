@@ -23,8 +23,12 @@ from test_multibox_cpu import run_lattice_flow_threads
 pytestmark = pytest.mark.gpu
 
 
+counts = []      # lattice-wide coarse cycles of the boxes of the last _device_lattice_flow
+
+
 def _device_lattice_flow(nboxes, level, nsteps, overlap):
     import torch
+    del counts[:]
     n = 1 << level
     grid = D.BoxGrid(nboxes, 3)
     dev = torch.device("cuda", 0)
@@ -45,6 +49,7 @@ def _device_lattice_flow(nboxes, level, nsteps, overlap):
             gs.step()
         gd.synchronize()
         i3 = (slice(1, -1),) * 3
+        counts.append(gd.path_counts()[0])
         out = dict(u=gs.u[0].download()[i3], v=gs.u[1].download()[i3], w=gs.u[2].download()[i3],
                    p=gs.p.download()[i3], pmac=gs.pmac.download()[i3],
                    g=[gs.g[c].download()[i3] for c in range(3)], dt=gs.dt, t=gs.t,
@@ -78,6 +83,18 @@ def test_lattice_flow_device_boxes_equal_oracle_boxes(nboxes, level):
     dev = _device_lattice_flow(nboxes, level, nsteps, 0)
     _same(dev, ora, "%d boxes" % nboxes)
     assert not np.array_equal(dev[0]["u"], dev[1]["u"])      # the boxes really differ
+    # ... and the coarse ends of the V-cycles were computed for the whole lattice on every box after
+    # one gather (lattice_cycle_kernel), not with one exchange per sweep
+    assert len(counts) == nboxes and min(counts) >= 2 * nsteps
+
+
+def test_lattice_flow_one_exchange_per_sweep_gives_the_same_bits(monkeypatch):
+    """GFSHIP_NO_LATTICE_CYCLE=1: the per-level path (one halo exchange per sweep on every level)"""
+    monkeypatch.setenv("GFSHIP_NO_LATTICE_CYCLE", "1")
+    ora = run_lattice_flow_threads(8, 4, 2, 0)
+    dev = _device_lattice_flow(8, 4, 2, 0)
+    _same(dev, ora, "8 boxes, per-level exchanges")
+    assert max(counts) == 0
 
 
 @pytest.mark.parametrize("nboxes,level", [(2, 4), (8, 4), (8, 5)])
@@ -93,6 +110,7 @@ def test_lattice_flow_with_the_reference_default_overlap_order(nboxes, level):
     _same(dev, ora, "%d boxes, overlap" % nboxes)
     plain = run_lattice_flow_threads(nboxes, level, nsteps, 0)
     assert not np.array_equal(plain[0]["p"], ora[0]["p"])
+    assert max(counts) == 0          # the lattice-wide coarse cycle is a plain-order (overlap = 0) path
 
 
 def test_rccl_transport_with_overlap_on_one_rank():
@@ -137,15 +155,21 @@ def test_rccl_transport_with_overlap_on_one_rank():
     gd.destroy()
 
 
-def test_rccl_transport_on_one_rank_reproduces_the_periodic_box():
-    """gfship_domain_comm_init with one rank: the x and z sides are GfsBoundaryMpi sides whose peer is
-    the box itself, y stays a local periodic side.  pack -> ncclSend/ncclRecv (self) -> unpack and
-    the all-gather reduction, on the real RCCL, must give the periodic single box bit for bit."""
+@pytest.mark.parametrize("axes,fast", [("xz", True), ("xyz", True), ("y", True), ("xyz", False)])
+def test_rccl_transport_on_one_rank_reproduces_the_periodic_box(axes, fast, monkeypatch):
+    """gfship_domain_comm_init with one rank: the sides of `axes' are GfsBoundaryMpi sides whose peer is
+    the box itself, the others stay local periodic sides.  pack -> ncclSend/ncclRecv (self) -> unpack
+    and the all-gather reduction, on the real RCCL, must give the periodic single box bit for bit --
+    with the multi-box fast paths (coarse end of the V-cycle after one all-gather; tiled Godunov
+    kernels with one message of face states per side) and without them."""
+    if not fast:
+        monkeypatch.setenv("GFSHIP_NO_LATTICE_CYCLE", "1")
+        monkeypatch.setenv("GFSHIP_NO_FUSED_MPI", "1")
     level, nsteps = 5, 2
     osim = oracle_taylor_green(level)
     osim.u[0].interior()[...] += 0.3          # something crosses the sides
-    side = [gfship.SIDE_EXTERNAL, gfship.SIDE_EXTERNAL, gfship.SIDE_PERIODIC, gfship.SIDE_PERIODIC,
-            gfship.SIDE_EXTERNAL, gfship.SIDE_EXTERNAL]
+    osim.u[1].interior()[...] -= 0.2
+    side = [gfship.SIDE_EXTERNAL if "xyz"[d // 2] in axes else gfship.SIDE_PERIODIC for d in range(6)]
     gd, gs = _device_sim(osim, side)
     gd.comm_init(gfship.comm_unique_id(), 0, 1, (1, 1, 1))
     assert gd.comm_size() == 1
@@ -162,5 +186,10 @@ def test_rccl_transport_on_one_rank_reproduces_the_periodic_box():
             getattr(osim.approx_projection_params.residual, k), rel=1e-12)
     msgs, nbytes = gd.comm_stats()
     assert msgs > 100 and nbytes > msgs * 8
+    cycles, fused = gd.path_counts()
+    if fast:
+        assert cycles >= 2 * nsteps and fused >= 2 * nsteps
+    else:
+        assert cycles == 0 and fused == 0
     gs.destroy()
     gd.destroy()
