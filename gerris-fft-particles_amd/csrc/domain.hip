@@ -318,6 +318,7 @@ int gfship_field_upload (gfship_domain * dom, gfship_field f, int level, const d
 				L.rows*sizeof (double), rows, hipMemcpyHostToDevice, dom->stream));
   GFSHIP_HIP (hipStreamSynchronize (dom->stream));
   F->zero[level] = false;
+  if (level < dom->depth) F->coarse_valid = true;
   return GFSHIP_OK;
 }
 

@@ -42,6 +42,8 @@ struct Field {
   // src/adaptive.c:43-58) the next time one of them is read or written (coarse_flush); the
   // simulation loop does not use it: its coarse values are a snapshot taken in mid-step
   bool coarse_stale = false;
+  // the non-leaf levels have been given values (gfs_cell_coarse_init, an upload, a snapshot)
+  bool coarse_valid = false;
 };
 
 // scratch of the skewed exact-order sweep of one level (relax_skew.hip)

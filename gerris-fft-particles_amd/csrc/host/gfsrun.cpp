@@ -125,6 +125,7 @@ struct Run {
   Function * stream_function = nullptr;          // GfsVariableStreamFunction (2-D, GfsAdvection)
   std::vector<std::pair<std::string, Function *>> init;   // Init {} { var = f }
   std::vector<Variable> vars;
+  std::vector<std::string> device_vars;   // variables of the file that live on the device (GfsVariableTurbulentViscosity)
   std::vector<std::unique_ptr<Event>> events;
   std::vector<std::unique_ptr<Output>> outputs;
   std::vector<std::unique_ptr<ParticleSpec>> plists;
@@ -712,6 +713,74 @@ void parse_object (Run & R, Reader & r)
       for (int i = 1; i < nk; i++)
 	fprintf (fp, "%g %g \n", deltak*sqrt ((double) i), Ek[i]);
       fflush (fp);
+    };
+    add_event (R, e, cls, line);
+  }
+  else if (cls == "OutputSpectra") {
+    // GfsOutputSpectra (modules/fft.c:1101-1226): file v { x0 = .. x1 = .. ... } [level]; the 3-D box is
+    // transformed whole at the finest level
+    Event * e = new Event;
+    read_event_params (r, *e);
+    Output * o = read_output (R, r);
+    std::string vname = r.word (false);
+    int v = R.var_index (vname);
+    if (v < 0) r.fail ("unknown variable `" + vname + "'");
+    if (r.peek (false) == '{') r.braces ();
+    auto digit = [] (char c) { return c >= '0' && c <= '9'; };
+    if (digit (r.peek (false))) r.number ();
+    if (R.dim != 3) r.fail ("GfsOutputSpectra: only the 3-D box is transformed (a plane is sampled through the tree)");
+    Run * pr = &R;
+    e->action = [pr, o, v] () {
+      Run & R = *pr;
+      const int N = gfship_output_spectra_side (R.dom);
+      if (N <= 0) { fprintf (stderr, "gfship: %s\n", gfship_last_error ()); exit (1); }
+      const int nh = N/2 + 1;
+      std::vector<double> F ((size_t) 2*N*N*nh);
+      double ks = 0.;
+      if (gfship_output_spectra (R.dom, R.vars[v].dev, F.data (), &ks) != GFSHIP_OK) {
+	fprintf (stderr, "gfship: %s\n", gfship_last_error ());
+	exit (1);
+      }
+      // write_spectra, modules/fft.c:1047-1085 (L = 1)
+      FILE * fp = o->open ();
+      fprintf (fp, "# %i \n", N*N*N);
+      fputs ("# 1:kx 2:ky 3:kz 4:real 5:img\n", fp);
+      for (int i = 0; i < N; i++) {
+	const double kx = ks*(i < nh ? i : i - N);
+	for (int j = 0; j < N; j++) {
+	  const double ky = ks*(j < nh ? j : j - N);
+	  for (int l = 0; l < nh; l++) {
+	    const size_t q = 2*(((size_t) i*N + j)*nh + l);
+	    fprintf (fp, "%g %g %g %g %g\n", kx, ky, ks*l, F[q]*1., F[q + 1]*1.);
+	  }
+	}
+      }
+      fflush (fp);
+    };
+    add_event (R, e, cls, line);
+  }
+  else if (cls == "VariableTurbulentViscosity") {
+    // GfsVariableTurbulentViscosity [{ event }] name Cs (modules/turbulence.c:1068-1084): the Smagorinsky
+    // eddy viscosity of the leaf cells, refreshed by its event (default: every step)
+    Event * e = new Event;
+    if (r.peek (false) == '{') read_event_params (r, *e);
+    else { e->istep = 1; e->start = 0.; }
+    std::string name = r.word (false);
+    const double Cs = r.number ();
+    const int v = R.get_or_add_variable (name);
+    R.device_vars.push_back (name);
+    Run * pr = &R;
+    e->action = [pr, v, Cs] () {
+      Run & R = *pr;
+      gfship_field u[3] = { -1, -1, -1 };
+      const char * un[3] = { "U", "V", "W" };
+      for (int c = 0; c < R.dim; c++) u[c] = R.vars[R.var_index (un[c])].dev;
+      if (R.dim == 2) u[2] = u[1];
+      if (gfship_turbulent_viscosity (R.dom, u, Cs, 1, R.vars[v].dev) != GFSHIP_OK) {
+	fprintf (stderr, "gfship: %s\n", gfship_last_error ());
+	exit (1);
+      }
+      R.vars[v].host_time = -1.;      /* the host copy, if any, is out of date */
     };
     add_event (R, e, cls, line);
   }
@@ -1405,6 +1474,11 @@ int run (Run & R)
     CHECK (k);
     R.vars[R.var_index (t)].dev = gfship_sim_variable (R.sim, GFSHIP_VAR_TRACER, k);
     CHECK (gfship_sim_set_tracer_gradient (R.sim, k, R.tracer_gradient[(size_t) k]));
+  }
+  for (const std::string & dv : R.device_vars) {
+    gfship_field f = gfship_field_alloc (R.dom, -1);
+    CHECK (f);
+    R.vars[R.var_index (dv)].dev = f;
   }
   gfship_field div = -1;
   if (R.sim_class == "Poisson") {

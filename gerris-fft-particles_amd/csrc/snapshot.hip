@@ -205,6 +205,7 @@ int gfship_snapshot_tree_read (gfship_domain * dom, int nvars, const gfship_fiel
     for (int l = 0; l <= dom->depth; l++)
       F->zero[l] = false;
     F->coarse_stale = false;
+    F->coarse_valid = true;
   }
   GFSHIP_CHECK (!(herr & 1), GFSHIP_EINVAL,
 		"FTT_CELL_ID (cell) != (flags & FTT_FLAG_ID): make sure the file has %d spatial "

@@ -38,25 +38,66 @@ spectra_sum_kernel (Layout L, const double * __restrict__ u, double * __restrict
   if (threadIdx.x == 0) atomicAdd (sum, sh[0]);
 }
 
-// a[ix][iy]([iz]) = (u - mean)/ntot
+// substract_average (modules/fft.c:897-908): the average is taken over the cells of ALL levels
+// (FTT_TRAVERSE_ALL) weighted by their volumes: sum_l h_l^dim sum_cells v / (number of levels)
+__global__ void spectra_mean_kernel (int dim, int depth, const double * __restrict__ sums,
+				     double * __restrict__ mean, double nboxes)
+{
+  if (threadIdx.x || blockIdx.x) return;
+  double val = 0., vol = 0.;
+  for (int l = 0; l <= depth; l++) {
+    const double h = 1./(double) (1 << l);
+    const double cv = dim == 3 ? h*h*h : h*h;
+    val += cv*sums[l];
+    vol += nboxes*cv*(double) (dim == 3 ? (1ull << (3*l)) : (1ull << (2*l)));
+  }
+  *mean = val/vol;
+}
+
+// get_data (modules/fft.c:399-417): a[ix][iy]([iz]) = (u - mean)/ntot on the grid of the whole
+// lattice of boxes (N = b n points per side; this box at offset o)
 __global__ void __launch_bounds__(256)
-spectra_fill_kernel (Layout L, const double * __restrict__ u, const double * __restrict__ sum,
-		     double * __restrict__ a)
+spectra_fill_kernel (Layout L, const double * __restrict__ u, const double * __restrict__ mean,
+		     double * __restrict__ a, double ntot_all)
 {
   const int n = L.n;
   const size_t ntot = L.dim == 3 ? (size_t) n*n*n : (size_t) n*n;
   const size_t q = (size_t) blockIdx.x*blockDim.x + threadIdx.x;
   if (q >= ntot) return;
   const int i = (int) (q % n), j = (int) ((q/n) % n), k = L.dim == 3 ? (int) (q/((size_t) n*n)) : 0;
-  const double mean = *sum/(double) ntot;
-  const double v = (u[L.idx (i + 1, j + 1, L.dim == 3 ? k + 1 : 0)] - mean)/(double) ntot;
+  const double v = (u[L.idx (i + 1, j + 1, L.dim == 3 ? k + 1 : 0)] - *mean)/ntot_all;
   const size_t dst = L.dim == 3 ? ((size_t) i*n + j)*n + k : (size_t) i*n + j;
   a[dst] = v;
+}
+
+// the blocks of the boxes of a lattice (gathered in rank order, each [ix][iy][iz]) into the grid of
+// the whole domain: what the slab redistribution of the reference (modules/fft.c:467-669) assembles
+__global__ void __launch_bounds__(256)
+spectra_assemble_kernel (int dim, int n, int bx, int by, int bz, const double * __restrict__ g,
+			 double * __restrict__ a)
+{
+  const size_t nloc = dim == 3 ? (size_t) n*n*n : (size_t) n*n;
+  const size_t total = nloc*bx*by*bz;
+  const size_t q = (size_t) blockIdx.x*blockDim.x + threadIdx.x;
+  if (q >= total) return;
+  const int box = (int) (q/nloc);
+  const size_t r = q % nloc;
+  const int cx = box % bx, cy = (box/bx) % by, cz = box/(bx*by);
+  const int Ny = by*n, Nz = bz*n;
+  if (dim == 3) {
+    const int k = (int) (r % n), j = (int) ((r/n) % n), i = (int) (r/((size_t) n*n));
+    a[((size_t) (cx*n + i)*Ny + (cy*n + j))*Nz + cz*n + k] = g[q];
+  }
+  else {
+    const int j = (int) (r % n), i = (int) (r/n);
+    a[(size_t) (cx*n + i)*Ny + cy*n + j] = g[q];
+  }
 }
 
 __global__ void __launch_bounds__(256)
 spectra_bin_kernel (int dim, int n, const double2 * __restrict__ F, double * __restrict__ Ek)
 {
+  // n: points per side of the (cubic) grid
   const int nh = n/2 + 1;
   const size_t total = dim == 3 ? (size_t) n*n*nh : (size_t) n*nh;
   const size_t q = (size_t) blockIdx.x*blockDim.x + threadIdx.x;
@@ -122,6 +163,93 @@ spectra_cells_kernel (Layout L, int np, const double * __restrict__ g, const dou
   u[L.idx (ci, cj, ck)] = vx[0] + (vx[1] - vx[0])*(p[0] - gx[i])/(gx[i + 1] - gx[i]);
 }
 
+// GfsVariableTurbulentViscosity (modules/turbulence.c:953-1062): eddy viscosity of the leaf cells from
+// the velocity gradients g[i][j] = gfs_cm_gradient of component i along j (src/fluid.c:3586-3617, the
+// branch of a variable that is not `centered': (g1.b - g2.b + (g2.a - g1.a)*val)/2. with g.a = 1.,
+// g.b = neighbour value).  model 1: Smagorinsky (:961-978, the only one a file can select: the read
+// method never changes model_type = 1); model 0: the sigma model of :980-1048.
+template <int DIM>
+__global__ void __launch_bounds__(256)
+turbulent_viscosity_kernel (Layout L, const double * __restrict__ u0, const double * __restrict__ u1,
+			    const double * __restrict__ u2, double Cs, int model, double * __restrict__ out)
+{
+  const int n = L.n;
+  const size_t ntot = DIM == 3 ? (size_t) n*n*n : (size_t) n*n;
+  const size_t q = (size_t) blockIdx.x*blockDim.x + threadIdx.x;
+  if (q >= ntot) return;
+  const int i = (int) (q % n) + 1, j = (int) ((q/n) % n) + 1, k = DIM == 3 ? (int) (q/((size_t) n*n)) + 1 : 0;
+  const long c = L.idx (i, j, k);
+  const long off[3] = { 1, L.sy, L.sz };
+  const double * u[3] = { u0, u1, u2 };
+  const double h = 1./n;
+  double g[3][3];
+#pragma unroll
+  for (int a = 0; a < DIM; a++)
+#pragma unroll
+    for (int b = 0; b < DIM; b++) {
+      const double val = u[a][c];
+      g[a][b] = (u[a][c + off[b]] - u[a][c - off[b]] + (1. - 1.)*val)/2.;
+    }
+  if (model == 1) {
+    double s = 0.;
+#pragma unroll
+    for (int a = 0; a < DIM; a++)
+#pragma unroll
+      for (int b = 0; b < DIM; b++) {
+	const double e = 0.5*(g[a][b] + g[b][a])/h;
+	s += e*e;                                       /* pow (x, 2) */
+      }
+    s = sqrt (2.*s);
+    out[c] = (Cs*h)*(Cs*h)*s;
+    return;
+  }
+  double g2[3][3], g22[3][3];
+#pragma unroll
+  for (int a = 0; a < DIM; a++)
+#pragma unroll
+    for (int b = 0; b < DIM; b++) {
+      g2[a][b] = 0.;
+      for (int m = 0; m < DIM; m++)
+	g2[a][b] += g[m][a]*g[m][b]/(h*h);
+    }
+#pragma unroll
+  for (int a = 0; a < DIM; a++)
+#pragma unroll
+    for (int b = 0; b < DIM; b++) {
+      g22[a][b] = 0.;
+      for (int m = 0; m < DIM; m++)
+	g22[a][b] += g2[a][m]*g2[m][b];
+    }
+  double inv1 = 0., inv2 = 0., inv3;
+  for (int a = 0; a < DIM; a++) { inv1 += g2[a][a]; inv2 += g22[a][a]; }
+  inv2 = (inv1*inv1 - inv2)/2;
+  if (DIM == 2)
+    inv3 = g2[0][0]*g2[1][1] - g2[0][1]*g2[1][0];
+  else {
+    inv3  = g2[0][0]*g2[1][1]*g2[2][2];
+    inv3 += g2[0][1]*g2[1][2]*g2[2][0];
+    inv3 += g2[0][2]*g2[1][0]*g2[2][1];
+    inv3 -= g2[0][2]*g2[1][1]*g2[2][0];
+    inv3 -= g2[0][1]*g2[1][0]*g2[2][2];
+    inv3 -= g2[0][0]*g2[1][2]*g2[2][1];
+  }
+  const double alpha1 = inv1*inv1/9. - inv2/3.;
+  const double alpha2 = inv1*inv1*inv1/27. - inv1*inv2/6. + inv3/2.;
+  if (alpha1 <= 0) { out[c] = 0.; return; }
+  const double a32 = pow (alpha1, 3./2.);
+  if (alpha2 >= a32) { out[c] = 0.; return; }
+  const double alpha3 = 1./3.*acos (alpha2/a32);
+  const double sigma1 = sqrt (inv1/3. + 2*sqrt (alpha1)*cos (alpha3));
+  const double sigma2 = sqrt (inv1/3. - 2*sqrt (alpha1)*cos (M_PI/3. + alpha3));
+  const double sigma3 = sqrt (inv1/3. - 2*sqrt (alpha1)*cos (M_PI/3. - alpha3));
+  double Dsigma;
+  if (sigma1 != 0.)
+    Dsigma = sigma3*(sigma1 - sigma2)*(sigma2 - sigma3)/(sigma1*sigma1);
+  else
+    Dsigma = 0.;
+  out[c] = (Cs*h)*(Cs*h)*Dsigma;
+}
+
 } // namespace gfship
 
 using namespace gfship;
@@ -131,64 +259,193 @@ using namespace gfship;
 
 extern "C" {
 
+// points per side of the grid of the whole domain; 0 when the lattice of boxes is not a cube
+static int spectra_side (const gfship_domain * dom)
+{
+  const int n = dom->lay[dom->depth].n;
+  if (!dom->has_external) return n;
+  for (int c = 1; c < dom->dim; c++)
+    if (dom->lat_b[c] != dom->lat_b[0]) return 0;
+  return n*dom->lat_b[0];
+}
+
 int gfship_energy_spectra_bins (gfship_domain * dom)
 {
   GFSHIP_CHECK (dom != nullptr, GFSHIP_EINVAL, "null domain");
-  int nh = dom->lay[dom->depth].n/2 + 1;
+  int nh = spectra_side (dom)/2 + 1;
   return (dom->dim + 1)*nh*nh;
 }
+
+namespace {
+
+// fill_cartesian_matrix + get_fftw_plan + fftw_execute for one variable: F = r2c DFT of
+// (v - <v>)/ntot on the grid of the whole domain.  On a box of a lattice every rank gathers the
+// blocks of all boxes and transforms the whole grid itself (replicated; the reference redistributes
+// slabs for FFTW-MPI).
+struct SpectraWork {
+  gfship_domain * dom = nullptr;
+  int N = 0;
+  size_t ntot = 0, nout = 0;
+  double * a = nullptr, * loc = nullptr, * gat = nullptr, * sums = nullptr, * mean = nullptr;
+  double2 * F = nullptr;
+  hipfftHandle plan = 0;
+  bool have_plan = false;
+  ~SpectraWork () {
+    if (have_plan) (void) hipfftDestroy (plan);
+    (void) hipFree (a); (void) hipFree (loc); (void) hipFree (gat); (void) hipFree (sums);
+    (void) hipFree (mean); (void) hipFree (F);
+  }
+};
+
+int spectra_prepare (gfship_domain * dom, SpectraWork * W)
+{
+  for (int d = 0; d < 2*dom->dim; d++)
+    GFSHIP_CHECK (dom->side[d] != GFSHIP_SIDE_EXTERNAL || dom->comm || dom->gather, GFSHIP_EINVAL,
+		  "spectra of a box of a lattice need the communicator or the gather hook");
+  const int dim = dom->dim;
+  W->dom = dom;
+  W->N = spectra_side (dom);
+  GFSHIP_CHECK (W->N > 0, GFSHIP_EUNSUPPORTED, "the lattice of boxes must have the same extent in every direction");
+  GFSHIP_CHECK (W->N >= 2, GFSHIP_EINVAL, "level too coarse for a spectrum");
+  const int N = W->N, nh = N/2 + 1;
+  W->ntot = dim == 3 ? (size_t) N*N*N : (size_t) N*N;
+  W->nout = dim == 3 ? (size_t) N*N*nh : (size_t) N*nh;
+  GFSHIP_HIP (hipMalloc ((void **) &W->a, W->ntot*sizeof (double)));
+  GFSHIP_HIP (hipMalloc ((void **) &W->F, W->nout*sizeof (double2)));
+  GFSHIP_HIP (hipMalloc ((void **) &W->sums, (GFSHIP_MAXLEVEL + 2)*sizeof (double)));
+  GFSHIP_HIP (hipMalloc ((void **) &W->mean, sizeof (double)));
+  if (dom->has_external) {
+    const int n = dom->lay[dom->depth].n;
+    const size_t nloc = dim == 3 ? (size_t) n*n*n : (size_t) n*n;
+    GFSHIP_HIP (hipMalloc ((void **) &W->loc, nloc*sizeof (double)));
+    GFSHIP_HIP (hipMalloc ((void **) &W->gat, W->ntot*sizeof (double)));
+  }
+  if (dim == 3) GFSHIP_FFT (hipfftPlan3d (&W->plan, N, N, N, HIPFFT_D2Z));
+  else GFSHIP_FFT (hipfftPlan2d (&W->plan, N, N, HIPFFT_D2Z));
+  W->have_plan = true;
+  GFSHIP_FFT (hipfftSetStream (W->plan, dom->stream));
+  return GFSHIP_OK;
+}
+
+int spectra_transform (SpectraWork * W, gfship_field v)
+{
+  gfship_domain * dom = W->dom;
+  Field * fc = get_field (dom, v);
+  GFSHIP_CHECK (fc != nullptr, GFSHIP_EINVAL, "invalid field");
+  const int dim = dom->dim, depth = dom->depth;
+  const Layout & L = dom->lay[depth];
+  const int n = L.n;
+  const size_t nloc = dim == 3 ? (size_t) n*n*n : (size_t) n*n;
+  /* the non-leaf values are the ones gfs_cell_coarse_init last gave the variable (for the variables
+     of a simulation: the state before the last approximate projection, as in the reference, whose
+     events run at the top of the loop); a field that never had any gets them from its leaves */
+  if (!fc->coarse_valid && depth > 0) {
+    Field * one[1] = { fc };
+    if (int r = launch_coarse_init (dom, one, 1)) return r;
+  }
+  // substract_average over the cells of all levels
+  GFSHIP_HIP (hipMemsetAsync (W->sums, 0, (GFSHIP_MAXLEVEL + 2)*sizeof (double), dom->stream));
+  for (int l = 0; l <= depth; l++) {
+    const Layout & Ll = dom->lay[l];
+    hipLaunchKernelGGL (spectra_sum_kernel, dim3 (Ll.n, dim == 3 ? Ll.n : 1), dim3 (256), 0, dom->stream,
+			Ll, (const double *) fc->lev[l], W->sums + l);
+  }
+  GFSHIP_HIP (hipGetLastError ());
+  double nboxes = 1.;
+  if (dom->has_external) {
+    /* gfs_all_reduce of the sums (modules/fft.c:902-903) */
+    std::vector<double> h (depth + 1);
+    GFSHIP_HIP (hipMemcpyAsync (h.data (), W->sums, (depth + 1)*sizeof (double), hipMemcpyDeviceToHost, dom->stream));
+    GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+    for (int l0 = 0; l0 <= depth; l0 += 8) {
+      int m = depth + 1 - l0 < 8 ? depth + 1 - l0 : 8;
+      if (int r = call_reduce (dom, h.data () + l0, m, 0)) return r;
+    }
+    GFSHIP_HIP (hipMemcpyAsync (W->sums, h.data (), (depth + 1)*sizeof (double), hipMemcpyHostToDevice, dom->stream));
+    GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+    nboxes = (double) dom->lat_n;
+  }
+  hipLaunchKernelGGL (spectra_mean_kernel, dim3 (1), dim3 (64), 0, dom->stream, dim, depth, W->sums, W->mean, nboxes);
+  double * dst = dom->has_external ? W->loc : W->a;
+  hipLaunchKernelGGL (spectra_fill_kernel, dim3 ((unsigned) ((nloc + 255)/256)), dim3 (256), 0, dom->stream,
+		      L, (const double *) fc->lev[depth], W->mean, dst, (double) W->ntot);
+  GFSHIP_HIP (hipGetLastError ());
+  if (dom->has_external) {
+    if (int r = call_gather (dom, W->loc, W->gat, nloc)) return r;
+    hipLaunchKernelGGL (spectra_assemble_kernel, dim3 ((unsigned) ((W->ntot + 255)/256)), dim3 (256), 0, dom->stream,
+			dim, n, dom->lat_b[0], dom->lat_b[1], dom->lat_b[2], W->gat, W->a);
+    GFSHIP_HIP (hipGetLastError ());
+  }
+  GFSHIP_FFT (hipfftExecD2Z (W->plan, W->a, (hipfftDoubleComplex *) W->F));
+  return GFSHIP_OK;
+}
+
+} // namespace
 
 int gfship_energy_spectra (gfship_domain * dom, int ncomp, const gfship_field * comps, double * Ek,
 			   double * Etot, double * deltak)
 {
   GFSHIP_CHECK (dom && comps && Ek && ncomp > 0, GFSHIP_EINVAL, "invalid argument");
-  for (int d = 0; d < 2*dom->dim; d++)
-    GFSHIP_CHECK (dom->side[d] == GFSHIP_SIDE_PERIODIC || dom->side[d] == GFSHIP_SIDE_BOUNDARY, GFSHIP_EINVAL,
-		  "spectra of a multi-box domain are not supported");
-  const Layout & L = dom->lay[dom->depth];
-  const int n = L.n, dim = dom->dim, nh = n/2 + 1;
-  GFSHIP_CHECK (n >= 2, GFSHIP_EINVAL, "level too coarse for a spectrum");
-  const size_t ntot = dim == 3 ? (size_t) n*n*n : (size_t) n*n;
-  const size_t nout = dim == 3 ? (size_t) n*n*nh : (size_t) n*nh;
+  SpectraWork W;
+  int r = spectra_prepare (dom, &W);
+  if (r) return r;
+  const int dim = dom->dim, N = W.N;
   const int nk = gfship_energy_spectra_bins (dom);
-  double * a = nullptr, * dEk = nullptr, * sum = nullptr;
-  double2 * F = nullptr;
-  GFSHIP_HIP (hipMalloc ((void **) &a, ntot*sizeof (double)));
-  GFSHIP_HIP (hipMalloc ((void **) &F, nout*sizeof (double2)));
+  double * dEk = nullptr;
   GFSHIP_HIP (hipMalloc ((void **) &dEk, (size_t) nk*sizeof (double)));
-  GFSHIP_HIP (hipMalloc ((void **) &sum, sizeof (double)));
-  GFSHIP_HIP (hipMemsetAsync (dEk, 0, (size_t) nk*sizeof (double), dom->stream));
-  hipfftHandle plan;
-  if (dim == 3) GFSHIP_FFT (hipfftPlan3d (&plan, n, n, n, HIPFFT_D2Z));
-  else GFSHIP_FFT (hipfftPlan2d (&plan, n, n, HIPFFT_D2Z));
-  GFSHIP_FFT (hipfftSetStream (plan, dom->stream));
-  for (int c = 0; c < ncomp; c++) {
-    Field * fc = get_field (dom, comps[c]);
-    GFSHIP_CHECK (fc != nullptr, GFSHIP_EINVAL, "invalid field");
-    const double * u = fc->lev[dom->depth];
-    GFSHIP_HIP (hipMemsetAsync (sum, 0, sizeof (double), dom->stream));
-    hipLaunchKernelGGL (spectra_sum_kernel, dim3 (n, dim == 3 ? n : 1), dim3 (256), 0, dom->stream, L, u, sum);
-    hipLaunchKernelGGL (spectra_fill_kernel, dim3 ((unsigned) ((ntot + 255)/256)), dim3 (256), 0, dom->stream,
-			L, u, sum, a);
-    GFSHIP_HIP (hipGetLastError ());
-    GFSHIP_FFT (hipfftExecD2Z (plan, a, (hipfftDoubleComplex *) F));
-    hipLaunchKernelGGL (spectra_bin_kernel, dim3 ((unsigned) ((nout + 255)/256)), dim3 (256), 0, dom->stream,
-			dim, n, F, dEk);
-    GFSHIP_HIP (hipGetLastError ());
+  hipError_t e = hipMemsetAsync (dEk, 0, (size_t) nk*sizeof (double), dom->stream);
+  for (int c = 0; c < ncomp && e == hipSuccess && r == GFSHIP_OK; c++) {
+    r = spectra_transform (&W, comps[c]);
+    if (r) break;
+    hipLaunchKernelGGL (spectra_bin_kernel, dim3 ((unsigned) ((W.nout + 255)/256)), dim3 (256), 0, dom->stream,
+			dim, N, W.F, dEk);
+    e = hipGetLastError ();
   }
-  GFSHIP_HIP (hipMemcpyAsync (Ek, dEk, (size_t) nk*sizeof (double), hipMemcpyDeviceToHost, dom->stream));
-  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
-  (void) hipfftDestroy (plan);
-  (void) hipFree (a); (void) hipFree (F); (void) hipFree (dEk); (void) hipFree (sum);
+  if (r == GFSHIP_OK && e == hipSuccess)
+    e = hipMemcpyAsync (Ek, dEk, (size_t) nk*sizeof (double), hipMemcpyDeviceToHost, dom->stream);
+  if (r == GFSHIP_OK && e == hipSuccess)
+    e = hipStreamSynchronize (dom->stream);
+  (void) hipFree (dEk);
+  if (r) return r;
+  GFSHIP_HIP (e);
   if (Etot) {
-    double e = 0.;
-    for (int q = 0; q < nk; q++) e += Ek[q];
-    *Etot = e;
+    double s = 0.;
+    for (int q = 0; q < nk; q++) s += Ek[q];
+    *Etot = s;
   }
   if (deltak) {
     /* x1 - x0 = distance between the first and the last cell centres (get_deep_level, :443-450) */
-    double dx = 1./n;
-    *deltak = 2.*M_PI/((n - 1)*dx);
+    double dx = 1./dom->lay[dom->depth].n;
+    *deltak = 2.*M_PI/((N - 1)*dx);
+  }
+  return GFSHIP_OK;
+}
+
+// GfsOutputSpectra (modules/fft.c:1101-1160) of the whole domain at the finest level, 3-D: the r2c
+// DFT of (v - <v>)/ntot; write_spectra (:1047-1085) prints, for ix, iy = 0 .. N-1 and iz = 0 .. N/2,
+// "kx ky kz re*L im*L" with k = 2 pi/(x1 - x0) times the signed index.
+int gfship_output_spectra_side (gfship_domain * dom)
+{
+  GFSHIP_CHECK (dom != nullptr, GFSHIP_EINVAL, "null domain");
+  return spectra_side (dom);
+}
+
+int gfship_output_spectra (gfship_domain * dom, gfship_field v, double * out, double * kstep)
+{
+  GFSHIP_CHECK (dom && out, GFSHIP_EINVAL, "null argument");
+  GFSHIP_CHECK (dom->dim == 3, GFSHIP_EUNSUPPORTED,
+		"GfsOutputSpectra of a plane interpolates through the tree (fill_interpolated_cartesian_matrix): "
+		"only the 3-D box is transformed here");
+  SpectraWork W;
+  int r = spectra_prepare (dom, &W);
+  if (r) return r;
+  if ((r = spectra_transform (&W, v))) return r;
+  GFSHIP_HIP (hipMemcpyAsync (out, W.F, W.nout*sizeof (double2), hipMemcpyDeviceToHost, dom->stream));
+  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  if (kstep) {
+    /* init_kmax (:1031-1045): 2 pi/L with L the distance between the first and last cell centres */
+    double dx = 1./dom->lay[dom->depth].n;
+    *kstep = 2.*M_PI/((W.N - 1)*dx);
   }
   return GFSHIP_OK;
 }
@@ -361,6 +618,36 @@ int gfship_init_spectra (gfship_domain * dom, const gfship_init_spectra_params *
   (void) hipFree (F); (void) hipFree (g); (void) hipFree (dgx); (void) hipFree (outside);
   GFSHIP_CHECK (nout == 0, GFSHIP_EINVAL,
 		"%u cells lie outside the spectral grid (the reference leaves them undefined)", nout);
+  return GFSHIP_OK;
+}
+
+// variable_turbulent_viscosity_event (modules/turbulence.c:1050-1066): leaf cells only; the velocity
+// ghost cells are those of the last BC application
+int gfship_turbulent_viscosity (gfship_domain * dom, const gfship_field u[3], double Cs, int model,
+				gfship_field out)
+{
+  GFSHIP_CHECK (dom && u, GFSHIP_EINVAL, "null argument");
+  GFSHIP_CHECK (model == 0 || model == 1, GFSHIP_EINVAL, "model: 1 Smagorinsky, 0 sigma");
+  const double * up[3] = { nullptr, nullptr, nullptr };
+  for (int c = 0; c < dom->dim; c++) {
+    Field * F = get_field (dom, u[c]);
+    if (!F) return GFSHIP_EINVAL;
+    up[c] = F->lev[dom->depth];
+  }
+  Field * O = get_field (dom, out);
+  if (!O) return GFSHIP_EINVAL;
+  const Layout & L = dom->lay[dom->depth];
+  const size_t ntot = dom->dim == 3 ? (size_t) L.n*L.n*L.n : (size_t) L.n*L.n;
+  const dim3 grid ((unsigned) ((ntot + 255)/256));
+  if (dom->dim == 3)
+    hipLaunchKernelGGL (turbulent_viscosity_kernel<3>, grid, dim3 (256), 0, dom->stream, L, up[0], up[1], up[2],
+			Cs, model, O->lev[dom->depth]);
+  else
+    hipLaunchKernelGGL (turbulent_viscosity_kernel<2>, grid, dim3 (256), 0, dom->stream, L, up[0], up[1], up[1],
+			Cs, model, O->lev[dom->depth]);
+  GFSHIP_HIP (hipGetLastError ());
+  O->zero[dom->depth] = false;
+  O->coarse_valid = false;
   return GFSHIP_OK;
 }
 

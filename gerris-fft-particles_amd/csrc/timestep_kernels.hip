@@ -1686,6 +1686,7 @@ int launch_coarse_init (gfship_domain * dom, Field * const * v, int nf)
 	A.vc[f] = v[f0 + f]->lev[l];
 	A.vf[f] = v[f0 + f]->lev[l + 1];
 	v[f0 + f]->zero[l] = false;
+	v[f0 + f]->coarse_valid = true;
       }
       dim3 grid, block;
       cell_grid (Lc, &grid, &block);

@@ -144,6 +144,9 @@ SIGNATURES = {
     "gfship_energy_spectra": (_i, [_vp, _i, C.POINTER(_i), _pd, C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
     "gfship_init_spectra": (_i, [_vp, _vp, C.POINTER(_i)]),
+    "gfship_output_spectra_side": (_i, [_vp]),
+    "gfship_output_spectra": (_i, [_vp, _i, _pd, C.POINTER(C.c_double)]),
+    "gfship_turbulent_viscosity": (_i, [_vp, C.POINTER(_i), C.c_double, _i, _i]),
     "gfship_particles_set_particulate": (_i, [_vp, _pd, _pd, _pd]),
     "gfship_particles_set_forces": (_i, [_vp, _i, C.POINTER(_i), _pd]),
     "gfship_particles_download_particulate": (_i, [_vp, _pd, _pd, _pd]),
@@ -386,6 +389,20 @@ class Domain:
                                            C.byref(etot), C.byref(dk)))
         i = np.arange(1, nk)
         return dk.value * np.sqrt(i.astype(float)), Ek[1:].copy(), etot.value
+
+    def output_spectra(self, v):
+        """GfsOutputSpectra of variable v on the whole 3-D domain: (F, kstep) with F the complex
+        array [ix][iy][iz <= N/2] of the r2c DFT of (v - <v>)/ntot (modules/fft.c:1101-1160)"""
+        N = _check(lib().gfship_output_spectra_side(self.ptr))
+        out = np.empty((N, N, N // 2 + 1), dtype=np.complex128)
+        ks = C.c_double()
+        _check(lib().gfship_output_spectra(self.ptr, v.h, out.ctypes.data_as(_pd), C.byref(ks)))
+        return out, ks.value
+
+    def turbulent_viscosity(self, u, Cs, out, model=1):
+        """GfsVariableTurbulentViscosity (modules/turbulence.c:953-1105): model 1 Smagorinsky, 0 sigma"""
+        h = (_i * 3)(*([c.h for c in u] + [u[-1].h] * (3 - len(u))))
+        _check(lib().gfship_turbulent_viscosity(self.ptr, h, float(Cs), int(model), out.h))
 
     def init_spectra(self, par, fields):
         """GfsInitSpectra (modules/turbulence.c): par = dict with the keywords of the .gfs object

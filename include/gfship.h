@@ -279,6 +279,25 @@ int  gfship_energy_spectra_bins (gfship_domain * dom);
 int  gfship_energy_spectra (gfship_domain * dom, int ncomp, const gfship_field * comps, double * Ek,
 			    double * Etot, double * deltak);
 
+/* GfsOutputSpectra (modules/fft.c:1101-1160) of the whole 3-D domain at the finest level: the r2c DFT
+   (FFTW's sign and normalisation: none) of (v - <v>)/ntot, with <v> the volume average over the
+   cells of all levels (substract_average, :897-908).  out receives N*N*(N/2 + 1) complex numbers
+   (re, im), index (ix*N + iy)*(N/2 + 1) + iz, N = gfship_output_spectra_side(); *kstep = 2 pi/(x1 - x0)
+   (init_kmax, :1031-1045): write_spectra prints "kx ky kz re*L im*L" with k = kstep times the
+   signed index.  On a box of a lattice (communicator or gather hook) every rank receives the
+   transform of the whole lattice -- the reference redistributes slabs for FFTW-MPI (:467-669) --
+   and gfship_energy_spectra likewise bins the whole domain.  Planes (realdim == 2) and
+   GfsOutputSpectraInterface sample through the tree / the VOF interface: not provided. */
+int  gfship_output_spectra_side (gfship_domain * dom);
+int  gfship_output_spectra (gfship_domain * dom, gfship_field v, double * out, double * kstep);
+
+/* GfsVariableTurbulentViscosity (modules/turbulence.c:953-1105): out = (Cs h)^2 |S| on the leaf cells
+   from the centred differences of u (gfs_cm_gradient); model 1 = Smagorinsky (what the reference's
+   files get: model_type is never read), model 0 = the sigma model of :980-1048 (libm calls: not
+   bit-identical across C libraries). */
+int  gfship_turbulent_viscosity (gfship_domain * dom, const gfship_field u[3], double Cs, int model,
+				 gfship_field out);
+
 /* GfsInitSpectra (modules/turbulence.c:270-901), 3-D: fills the variables v[0..2] with a synthetic
    solenoidal velocity field whose shell energies follow Pope's model spectrum (ReL != 0:
    alpha epsilon^(2/3) k^(-5/3) fL feta with c1, c2, c3) or k^2 (ReL = 0) below kmax, rescaled to the

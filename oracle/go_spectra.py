@@ -5,7 +5,8 @@ The FFT arithmetic of the reference lives in FFTW3 (>= 3, with fftw3_mpi; un-ven
 `modules/fft.h:26`, configure.ac:361-367) and the reference holds no test or golden data for its
 spectra: PARITY UNPINNED.  What is restated is the published algorithm of the call sites:
   fill_cartesian_matrix (:966-1001)  v = (u - <u>)/ntot on the np^dim grid of the finest level
-                                     (substract_average :897-908, get_data :399-417)
+                                     (substract_average :897-908: <u> over the cells of all levels;
+                                     get_data :399-417)
   get_fftw_plan (:1087-1098)          real-to-complex DFT over all dimensions (last one halved)
   output_energy_spectra_event (:1360-1474)
       3-D  Ek[knx^2 + kny^2 + k^2] += w |F[i][j][k]|^2, w = 1/2 for k = 0, 1 for k = 1 .. np/2,
@@ -21,18 +22,105 @@ Uses numpy's pocketfft; sums in the order of the loops above."""
 import numpy as np
 
 
-def energy_spectra(comps):
+def all_level_mean(u):
+    """substract_average (modules/fft.c:897-908): the volume-weighted average over the cells of ALL
+    levels (FTT_TRAVERSE_ALL), the non-leaf values being the averages of their children
+    (gfs_cell_coarse_init): sum_l h_l^dim sum_cells v / (number of levels).  u: the leaf level of one
+    box, or of a whole lattice of boxes of `n_box' cells per side (levels below a box do not exist)."""
+    return _all_level_mean(u, u.shape[0])
+
+
+def _all_level_mean(u, n_box):
+    dim = u.ndim
+    val, vol = 0., 0.
+    a = u
+    m = n_box
+    while True:
+        h = 1. / m
+        val += h ** dim * a.sum()
+        vol += h ** dim * a.size
+        if m == 1:
+            break
+        sh = []
+        for s in a.shape:
+            sh += [s // 2, 2]
+        a = a.reshape(sh).mean(axis=tuple(range(1, 2 * dim, 2)))
+        m //= 2
+    return val / vol
+
+
+def output_spectra(u, n_box=None):
+    """GfsOutputSpectra (modules/fft.c:1101-1160) of a 3-D variable given as [k][j][i] (leaf level of
+    the whole domain; n_box cells per side and box): the r2c DFT of (v - <v>)/ntot indexed
+    [ix][iy][iz <= N/2], and the k step 2 pi/(x1 - x0) of write_spectra / init_kmax (:1031-1085)."""
+    n = u.shape[0]
+    nb = n if n_box is None else n_box
+    a = np.transpose(u)
+    a = (a - _all_level_mean(u, nb)) / float(a.size)
+    dx = 1. / nb
+    return np.fft.rfftn(a), 2. * np.pi / ((n - 1) * dx)
+
+
+def turbulent_viscosity(u, Cs, model=1):
+    """GfsVariableTurbulentViscosity (modules/turbulence.c:953-1048) on a uniform box: u = components
+    WITH their ghost layer, [k][j][i]; returns the interior values.  g[i][j] = gfs_cm_gradient of
+    component i along j for a variable that is not `centered' (src/fluid.c:3601-3615)."""
+    dim = len(u)
+    n = u[0].shape[0] - 2
+    h = 1. / n
+    inner = (slice(1, -1),) * dim
+
+    def sh(a, axis, o):      # axis: 0 = x ... ; arrays are [k][j][i]
+        sl = [slice(1, -1)] * dim
+        ax = dim - 1 - axis
+        sl[ax] = slice(1 + o, a.shape[ax] - 1 + o)
+        return a[tuple(sl)]
+    g = [[(sh(u[a], b, 1) - sh(u[a], b, -1) + (1. - 1.) * u[a][inner]) / 2. for b in range(dim)]
+         for a in range(dim)]
+    if model == 1:
+        s = 0.
+        for a in range(dim):
+            for b in range(dim):
+                e = 0.5 * (g[a][b] + g[b][a]) / h
+                s = s + e * e
+        return (Cs * h) * (Cs * h) * np.sqrt(2. * s)
+    g2 = [[sum(g[m][a] * g[m][b] / (h * h) for m in range(dim)) for b in range(dim)] for a in range(dim)]
+    g22 = [[sum(g2[a][m] * g2[m][b] for m in range(dim)) for b in range(dim)] for a in range(dim)]
+    inv1 = sum(g2[a][a] for a in range(dim))
+    inv2 = sum(g22[a][a] for a in range(dim))
+    inv2 = (inv1 * inv1 - inv2) / 2
+    if dim == 2:
+        inv3 = g2[0][0] * g2[1][1] - g2[0][1] * g2[1][0]
+    else:
+        inv3 = (g2[0][0] * g2[1][1] * g2[2][2] + g2[0][1] * g2[1][2] * g2[2][0] + g2[0][2] * g2[1][0] * g2[2][1]
+                - g2[0][2] * g2[1][1] * g2[2][0] - g2[0][1] * g2[1][0] * g2[2][2] - g2[0][0] * g2[1][2] * g2[2][1])
+    alpha1 = inv1 * inv1 / 9. - inv2 / 3.
+    alpha2 = inv1 ** 3 / 27. - inv1 * inv2 / 6. + inv3 / 2.
+    with np.errstate(invalid="ignore", divide="ignore"):
+        a32 = np.where(alpha1 > 0, alpha1, 1.) ** 1.5
+        ok = (alpha1 > 0) & (alpha2 < a32)
+        alpha3 = 1. / 3. * np.arccos(np.clip(alpha2 / a32, -1., 1.))
+        sq = 2 * np.sqrt(np.where(alpha1 > 0, alpha1, 0.))
+        s1 = np.sqrt(inv1 / 3. + sq * np.cos(alpha3))
+        s2 = np.sqrt(inv1 / 3. - sq * np.cos(np.pi / 3. + alpha3))
+        s3 = np.sqrt(inv1 / 3. - sq * np.cos(np.pi / 3. - alpha3))
+        D = np.where(s1 != 0., s3 * (s1 - s2) * (s2 - s3) / np.where(s1 != 0., s1 * s1, 1.), 0.)
+    return np.where(ok, (Cs * h) * (Cs * h) * D, 0.)
+
+
+def energy_spectra(comps, n_box=None):
     """comps: interior arrays of the velocity components, indexed [k][j][i] (3-D) or [j][i] (2-D)
-    as oracle.Field.interior() returns them.  Returns (k, Ek, Etot): the printed lines and the
-    total energy."""
+    as oracle.Field.interior() returns them (the whole domain; n_box cells per side and box when it
+    is a lattice of boxes).  Returns (k, Ek, Etot): the printed lines and the total energy."""
     dim = comps[0].ndim
     n = comps[0].shape[0]
+    nb = n if n_box is None else n_box
     nk = (dim + 1) * (n // 2 + 1) ** 2
     Ek = np.zeros(nk)
     kn = np.where(np.arange(n) < n // 2 + 1, np.arange(n), n - np.arange(n))
     for u in comps:
         a = np.transpose(u)                       # [ix][iy]([iz])
-        a = (a - a.mean()) / float(n ** dim)
+        a = (a - _all_level_mean(u, nb)) / float(n ** dim)
         F = np.fft.rfftn(a)
         P = F.real ** 2 + F.imag ** 2
         if dim == 3:
@@ -46,7 +134,7 @@ def energy_spectra(comps):
             bins = kn[:, None] ** 2 + ky[None, :] ** 2
             np.add.at(Ek, bins.ravel(), P.ravel())
     Etot = float(Ek.sum())
-    dx = 1. / n
+    dx = 1. / nb
     deltak = 2. * np.pi / ((n - 1) * dx)
     i = np.arange(1, nk)
     return deltak * np.sqrt(i.astype(float)), Ek[1:].copy(), Etot

@@ -245,6 +245,40 @@ def test_spectra_case_taylor_green(tmp_path):
 
 
 @pytest.mark.gpu
+def test_output_spectra_and_turbulent_viscosity_case(tmp_path):
+    """GfsOutputSpectra in write_spectra's format (modules/fft.c:1047-1085): the Taylor-Green U has
+    eight modes (+-1, +-1, +1) of amplitude 1/8; GfsVariableTurbulentViscosity is refreshed every step
+    and its norms are those of (Cs h)^2 |S| of the same field"""
+    level = 4
+    r = subprocess.run([BIN.replace("2D", "3D"), "-DLEVEL=%d" % level, "-DNSTEPS=2",
+                        os.path.join(CASES, "spectra_variable.gfs")], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    n = 1 << level
+    lines = open(tmp_path / "spectra-U").read().splitlines()
+    assert lines[0].strip() == "# %d" % n ** 3 and lines[1] == "# 1:kx 2:ky 3:kz 4:real 5:img"
+    rows = np.array([[float(x) for x in l.split()] for l in lines[2:]])
+    assert len(rows) == n * n * (n // 2 + 1)
+    dk = 2 * np.pi / ((n - 1) / n)
+    amp = np.hypot(rows[:, 3], rows[:, 4])
+    big = rows[amp > 0.05]
+    assert len(big) == 4                                   # kz >= 0 half: (+-1, +-1, 1)
+    assert np.allclose(np.abs(big[:, :3]), dk, rtol=1e-5)
+    assert np.allclose(np.hypot(big[:, 3], big[:, 4]), 0.125, rtol=1e-3)
+    # the eddy viscosity against the numpy restatement on the initial field
+    from oracle.go_spectra import turbulent_viscosity
+    x = (np.arange(-1, n + 1) + 0.5) / n - 0.5
+    Z, Y, X = np.meshgrid(x, x, x, indexing="ij")
+    u = [np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) * np.cos(2 * np.pi * Z),
+         -np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y) * np.cos(2 * np.pi * Z), 0. * X]
+    nut = turbulent_viscosity(u, 0.17)
+    first = open(tmp_path / "nut").read().splitlines()[0].split()
+    vals = {k: float(first[first.index(k) + 1]) for k in ("first:", "infty:")}
+    assert np.isclose(vals["first:"], np.abs(nut).mean(), rtol=1e-3)
+    assert np.isclose(vals["infty:"], np.abs(nut).max(), rtol=1e-3)
+
+
+@pytest.mark.gpu
 def test_isotropic_case_init_spectra(tmp_path):
     """GfsInitSpectra + GfsOutputEnergySpectra from a .gfs file: the synthetic field has about the
     requested energy, a decaying spectrum, and survives three projection / advection steps"""

@@ -193,3 +193,44 @@ def test_rccl_transport_on_one_rank_reproduces_the_periodic_box(axes, fast, monk
         assert cycles == 0 and fused == 0
     gs.destroy()
     gd.destroy()
+
+
+def test_spectra_of_a_lattice_of_boxes_equal_those_of_the_whole_domain():
+    """GfsOutputEnergySpectra / GfsOutputSpectra on 2 x 2 x 2 boxes: every box gathers the blocks of all
+    boxes (the reference redistributes slabs, modules/fft.c:467-669) and transforms the grid of the
+    whole domain -- against the numpy restatement applied to the assembled field"""
+    import torch
+    from oracle.go_spectra import energy_spectra, output_spectra
+    nboxes, level = 8, 4
+    n = 1 << level
+    grid = D.BoxGrid(nboxes, 3)
+    dev = torch.device("cuda", 0)
+
+    def worker(rank, fabric):
+        gd = gfship.Domain(3, level, grid.sides(rank))
+        hooks = D.DeviceHooks(gd, M.LocalTransport(grid, rank, fabric, dev))
+        X, Y, Z = M.global_centres(grid, rank, n)
+        fields, parts = [], []
+        for a in M.lattice_velocity(X, Y, Z):
+            b = np.zeros((n + 2,) * 3)
+            b[1:-1, 1:-1, 1:-1] = a
+            f = gd.variable()
+            f.upload(b)
+            fields.append(f)
+            parts.append(np.array(a))
+        out = dict(parts=parts, es=gd.energy_spectra(fields), sp=gd.output_spectra(fields[0]))
+        del hooks
+        gd.destroy()
+        return out
+
+    res = M.run_boxes(nboxes, worker)
+    comps = [M.assemble(grid, [r["parts"][c] for r in res], n) for c in range(3)]
+    k0, Ek0, Etot0 = energy_spectra(comps, n_box=n)
+    F0, ks0 = output_spectra(comps[0], n_box=n)
+    for r in res:
+        k, Ek, Etot = r["es"]
+        assert np.array_equal(k, k0)
+        assert np.isclose(Etot, Etot0, rtol=1e-12)
+        assert np.abs(Ek - Ek0).max() <= 1e-12 * Etot0
+        F, ks = r["sp"]
+        assert ks == ks0 and np.abs(F - F0).max() <= 1e-13

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import gfship
-from oracle.go_spectra import energy_spectra
+from oracle.go_spectra import energy_spectra, output_spectra, turbulent_viscosity
 
 pytestmark = pytest.mark.gpu
 
@@ -103,7 +103,7 @@ def test_init_spectra_field_properties_128():
     feta = np.exp(-par["c2"] * (((Lint * kw * par["ReL"] ** (-0.75)) ** 4 + par["c3"] ** 4) ** 0.25 - par["c3"]))
     Ei = par["alpha"] * par["epsilon"] ** (2. / 3.) * kw ** (-5. / 3.) * fl * feta
     # shells that exist on the lattice (sums of three squares)
-    from oracle.go_spectra import energy_spectra  # noqa: F401  (restatement used by the other tests)
+    from oracle.go_spectra import energy_spectra, output_spectra, turbulent_viscosity  # noqa: F401  (restatement used by the other tests)
     exists = Ek[:len(i)] > 0
     Ei = np.where(exists[:len(Ei)], Ei, 0.)
     Ei *= par["E"] / Ei.sum()
@@ -112,3 +112,50 @@ def test_init_spectra_field_properties_128():
     # the modes are slightly stretched and leak between the integer shells; 25 % is what is left)
     assert np.allclose(Ek[low][exists[low]], Ei[low][exists[low]], rtol=0.25)
     assert np.all(np.diff(Ek[low][exists[low]]) < 0.)
+
+
+@pytest.mark.parametrize("level", [4, 6])
+def test_output_spectra_matches_the_restatement(level):
+    """GfsOutputSpectra (modules/fft.c:1101-1160): the r2c transform of one variable of the whole box"""
+    n = 1 << level
+    rng = np.random.default_rng(level)
+    x = (np.arange(n) + 0.5) / n - 0.5
+    Z, Y, X = np.meshgrid(x, x, x, indexing="ij")
+    a = 1.7 + 0.1 * rng.standard_normal((n, n, n)) + np.cos(2 * np.pi * 2 * X) + 0.5 * np.sin(2 * np.pi * 3 * Z)
+    gd = gfship.Domain(3, level, [gfship.SIDE_PERIODIC] * 6)
+    f = gd.variable()
+    f.upload(_with_ghosts(a))
+    F, ks = gd.output_spectra(f)
+    F0, ks0 = output_spectra(a)
+    assert ks == ks0
+    assert F.shape == F0.shape
+    assert np.abs(F - F0).max() <= 1e-13
+    assert np.isclose(abs(F[2, 0, 0]), 0.5, atol=1e-2) and np.isclose(abs(F[0, 0, 3]), 0.25, atol=1e-2)
+    gd.destroy()
+
+
+@pytest.mark.parametrize("dim,model", [(3, 1), (2, 1), (3, 0), (2, 0)])
+def test_turbulent_viscosity_matches_the_restatement(dim, model):
+    """GfsVariableTurbulentViscosity: Smagorinsky (what a simulation file gets) bit for bit up to the
+    square root; the sigma model through the device's acos / cos / pow within 1e-10 of its scale"""
+    level = 5
+    n = 1 << level
+    rng = np.random.default_rng(7 + dim)
+    gd = gfship.Domain(dim, level, [gfship.SIDE_PERIODIC] * 6)
+    u, fields = [], []
+    for c in range(dim):
+        a = _with_ghosts(rng.standard_normal((n,) * dim))
+        f = gd.variable()
+        f.upload(a)
+        u.append(a)
+        fields.append(f)
+    out = gd.variable()
+    gd.turbulent_viscosity(fields, 0.2, out, model=model)
+    got = out.download()[(slice(1, -1),) * dim]
+    want = turbulent_viscosity(u, 0.2, model=model)
+    if model == 1:
+        assert np.abs(got - want).max() <= 4e-16 * np.abs(want).max()
+    else:
+        assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+        assert (got > 0).any()
+    gd.destroy()

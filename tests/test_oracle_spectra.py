@@ -3,7 +3,7 @@ oracle/go_spectra.py.  The reference holds no golden data for its FFT outputs an
 parity UNPINNED; these are the analytic pins."""
 import numpy as np
 
-from oracle.go_spectra import energy_spectra
+from oracle.go_spectra import all_level_mean, energy_spectra, output_spectra, turbulent_viscosity
 
 
 def _grid(n, dim):
@@ -48,3 +48,42 @@ def test_2d_overweights_the_ky_zero_line_like_the_reference():
     _, Ey, _ = energy_spectra([uy])
     assert np.isclose(Ex[9 - 1], 3.0 * 0.5 * np.mean(ux ** 2), rtol=1e-13)
     assert np.isclose(Ey[9 - 1], 1.0 * 0.5 * np.mean(uy ** 2), rtol=1e-13)
+
+
+def test_output_spectra_single_mode_and_parseval():
+    """GfsOutputSpectra: a cosine along x and a sine along z land at their wave vectors with
+    amplitude 1/2 each (r2c of v/ntot), the mean is removed, Parseval holds for the half spectrum"""
+    n = 16
+    x = (np.arange(n) + 0.5) / n - 0.5
+    Z, Y, X = np.meshgrid(x, x, x, indexing="ij")
+    v = 3. + np.cos(2 * np.pi * 2 * X) + 0.5 * np.sin(2 * np.pi * 3 * Z)
+    F, ks = output_spectra(v)
+    assert F.shape == (n, n, n // 2 + 1)
+    assert np.isclose(ks, 2 * np.pi / (1. - 1. / n))
+    assert abs(F[0, 0, 0]) < 1e-15
+    assert np.isclose(abs(F[2, 0, 0]), 0.5) and np.isclose(abs(F[n - 2, 0, 0]), 0.5)
+    assert np.isclose(abs(F[0, 0, 3]), 0.25)
+    w = np.full(n // 2 + 1, 2.)
+    w[0] = w[-1] = 1.
+    assert np.isclose((w * (F.real ** 2 + F.imag ** 2)).sum(), ((v - v.mean()) ** 2).mean())
+
+
+def test_all_level_mean_weights_every_level_equally():
+    rng = np.random.default_rng(2)
+    v = rng.standard_normal((8, 8, 8))
+    assert np.isclose(all_level_mean(v), v.mean(), rtol=1e-14, atol=1e-16)
+
+
+def test_smagorinsky_of_a_pure_shear_and_sigma_of_solid_rotation():
+    """u = (S y, 0, 0): |S| = sqrt (2 S_ij S_ij) = S, nu = (Cs h)^2 S; the sigma model vanishes for
+    pure shear and for solid rotation (its defining property), Smagorinsky does not for shear"""
+    n, Cs, S = 8, 0.17, 2.5
+    x = (np.arange(-1, n + 1) + 0.5) / n - 0.5
+    Z, Y, X = np.meshgrid(x, x, x, indexing="ij")
+    u = [S * Y, 0. * X, 0. * X]
+    nu = turbulent_viscosity(u, Cs)
+    assert np.allclose(nu, (Cs / n) ** 2 * S, rtol=1e-13)
+    assert np.abs(turbulent_viscosity(u, Cs, model=0)).max() < 1e-12
+    rot = [-Y, X, 0. * X]
+    assert np.abs(turbulent_viscosity(rot, Cs, model=0)).max() < 1e-12
+    assert np.abs(turbulent_viscosity(rot, Cs)).max() < 1e-15       # S_ij = 0
