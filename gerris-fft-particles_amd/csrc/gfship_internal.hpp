@@ -105,6 +105,7 @@ struct gfship_domain {
   unsigned * lat_bar = nullptr;
   size_t lat_res_doubles = 0, lat_xch_doubles = 0;
   double * gfv_send[6] = {}, * gfv_recv[6] = {};   // states beyond the MPI sides of the tiled Godunov kernels
+  bool no_fused_prolongation = false;   // GFSHIP_NO_FUSED_PROLONGATION=1: prolongate_kernel, then the copy
   bool no_fused_mpi = false;      // GFSHIP_NO_FUSED_MPI=1: face-value arrays on boxes with MPI sides
   unsigned long long n_lattice_cycles = 0, n_fused_mpi = 0;   // gfship_domain_path_counts
   bool lattice_attr_set = false;  // dynamic-LDS limit of lattice_cycle_kernel raised
@@ -255,7 +256,8 @@ int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, d
 bool skew_supported (const gfship_domain * dom, int level);
 int  launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * ubc,
 			     const double * rhs, const double * dia, bool dia_zero,
-			     unsigned nrelax, bool bc, double * correct_into = nullptr);
+			     unsigned nrelax, bool bc, double * correct_into = nullptr,
+			     const double * prolong_from = nullptr);
 void skew_free (gfship_domain * dom);
 bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool bc);
 int  skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia,
@@ -266,9 +268,11 @@ int  skew_time_loop (gfship_domain * dom, int level, Field * u, const double * r
 int  skew_check_error (gfship_domain * dom);
 // relax_patch_loop.hip
 int  patch_resident_per_cu ();
+// the prolongation onto `level' can be done by the copy into the skewed layout of its relax loop
+bool prolongation_fused (gfship_domain * dom, unsigned dimension, int level, unsigned nrelax);
 inline bool patch_level (const gfship_domain * dom, int level) { return dom->patch && dom->lay[level].n >= dom->patch_min_n; }
 int  patch_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u, const double * rhs,
-		 const double * dia);
+		 const double * dia, const double * coarse = nullptr);
 int  patch_unpack (gfship_domain * dom, int level, SkewPlan * S, double * u, double * add_into);
 void skew_dump_stats (gfship_domain * dom, int level);
 int  skew_time_sweeps (gfship_domain * dom, int level, Field * u, const double * rhs,

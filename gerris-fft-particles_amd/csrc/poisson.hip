@@ -39,7 +39,8 @@ static int relax_level (gfship_domain * dom, unsigned dimension, int level, doub
 // while the skewed copy is unpacked (*corrected set), dp's natural array is then left as it was
 static int relax_loop (gfship_domain * dom, Field * dp, Field * u, unsigned dimension, int level,
 		       double omega, Field * rhs, Field * dia, unsigned nrelax,
-		       double * correct_into = nullptr, bool * corrected = nullptr)
+		       double * correct_into = nullptr, bool * corrected = nullptr,
+		       const double * prolong_from = nullptr)
 {
   int r;
   dp->zero[level] = false;
@@ -78,7 +79,7 @@ static int relax_loop (gfship_domain * dom, Field * dp, Field * u, unsigned dime
       !dom->force_hyperplane) {
     if (corrected) *corrected = correct_into != nullptr;
     return launch_relax_loop_skew (dom, level, dp, u, rhs->lev[level], dia->lev[level],
-				   dia->zero[level], nrelax, true, correct_into);
+				   dia->zero[level], nrelax, true, correct_into, prolong_from);
   }
   if (dom->relax_mode == GFSHIP_RELAX_EXACT) {
     bool done = false;
@@ -374,10 +375,13 @@ static int poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
     }
     /* relax from top to bottom */
     for (unsigned l = first; l <= p->depth; l++) {
-      /* get initial guess from coarser grid */
-      TRY (launch_prolongate (dom, l - 1, DP->lev[l - 1], DP->lev[l]));
+      /* get initial guess from coarser grid -- on the levels of the 2 x 2 sweep kernels while the
+	 level is copied into their layout */
+      const bool fp = prolongation_fused (dom, p->dimension, (int) l, nrl[l]);
+      if (!fp)
+	TRY (launch_prolongate (dom, l - 1, DP->lev[l - 1], DP->lev[l]));
       TRY (relax_loop (dom, DP, U, p->dimension, l, p->omega, S, D, nrl[l],
-		       (int) l == L ? U->lev[L] : nullptr, &corrected));
+		       (int) l == L ? U->lev[L] : nullptr, &corrected, fp ? DP->lev[l - 1] : nullptr));
     }
   }
   /* correct on leaf cells, then BC on u (gfs_traverse_and_bc ... correct, u, u) */

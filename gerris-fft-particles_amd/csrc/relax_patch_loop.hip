@@ -900,7 +900,36 @@ struct PatchPackArgs {
   double * dst[3];
   int narr;
   double * add;            // unpack: add the values to this natural array instead of storing them
+  // pack: array 0 is not read but prolongated from the next coarser level (get_from_above,
+  // src/poisson.c:1005-1042 = prolongate_kernel): the natural array of the level is then written
+  // only where the BC application that follows reads it (the cells along the six sides)
+  const double * coarse;
+  double * nat;
+  Layout Lc;
 };
+
+// get_from_above of fine cell (i, j, k): prolongate_kernel's expression (poisson_kernels.hip)
+__device__ __forceinline__ double patch_prolong (const Layout & Lc, const double * __restrict__ vc,
+						 int i, int j, int k)
+{
+  const int pi = (i + 1)/2, pj = (j + 1)/2, pk = (k + 1)/2;
+  const long p = Lc.idx (pi, pj, pk);
+  const double pv = vc[p];
+  double h[3];
+  const long off[3] = { 1, Lc.sy, Lc.sz };
+#pragma unroll
+  for (int cc = 0; cc < 3; cc++) {
+    double g1 = vc[p + off[cc]] - 1.*pv;
+    double g2 = vc[p - off[cc]] - 1.*pv;
+    h[cc] = (g1 - g2)/2.;
+  }
+  const double rel[3] = { ((i & 1) ? -1. : 1.)/4., ((j & 1) ? -1. : 1.)/4., ((k & 1) ? -1. : 1.)/4. };
+  double val = pv;
+#pragma unroll
+  for (int cc = 0; cc < 3; cc++)
+    val += rel[cc]*h[cc];
+  return val;
+}
 
 #define PP_ROWS 16
 #define PP_SPAN (PP_ROWS + 7)     /* cells along I touched by 16 rows of the 8 lanes of a B */
@@ -924,7 +953,15 @@ patch_pack_kernel (PatchPackArgs A)
     if (I >= 0 && I < n) {
       const int j = n - (SK_T*P + a), k = n - (SK_T*Q + 2*PB + db);
       const long nidx = A.L.idx (I + 1, j, k);
-      for (int q = 0; q < A.narr; q++)
+      int q0 = 0;
+      if (A.coarse) {
+	const double v = patch_prolong (A.Lc, A.coarse, I + 1, j, k);
+	buf[0][line][di] = v;
+	if (I == 0 || I == n - 1 || j == 1 || j == n || k == 1 || k == n)
+	  A.nat[nidx] = v;
+	q0 = 1;
+      }
+      for (int q = q0; q < A.narr; q++)
 	buf[q][line][di] = A.src[q][nidx];
     }
   }
@@ -1001,10 +1038,13 @@ int patch_resident_per_cu ()
 }
 
 int patch_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u, const double * rhs,
-		const double * dia)
+		const double * dia, const double * coarse)
 {
   PatchPackArgs A;
   A.add = nullptr;
+  A.coarse = coarse;
+  A.nat = const_cast<double *> (u);
+  A.Lc = dom->lay[level > 0 ? level - 1 : 0];
   A.L = dom->lay[level]; A.ntj = S->ntj; A.RT = S->RT;
   A.narr = 0;
   A.src[A.narr] = u;   A.dst[A.narr++] = S->us;
@@ -1020,6 +1060,7 @@ int patch_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u, 
 int patch_unpack (gfship_domain * dom, int level, SkewPlan * S, double * u, double * add_into)
 {
   PatchPackArgs A;
+  A.coarse = nullptr; A.nat = nullptr; A.Lc = dom->lay[level];
   A.L = dom->lay[level]; A.ntj = S->ntj; A.RT = S->RT;
   A.narr = 1;
   A.src[0] = S->us; A.dst[0] = u; A.add = add_into;

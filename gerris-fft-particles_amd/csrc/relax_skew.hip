@@ -414,10 +414,10 @@ void skew_free (gfship_domain * dom)
 }
 
 static int skew_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u,
-		      const double * rhs, const double * dia)
+		      const double * rhs, const double * dia, const double * coarse = nullptr)
 {
   if (patch_level (dom, level))
-    return patch_pack (dom, level, S, u, rhs, dia);
+    return patch_pack (dom, level, S, u, rhs, dia, coarse);
   PackArgs A;
   A.add = nullptr;
   A.L = dom->lay[level]; A.ntj = S->ntj; A.RT = S->RT;
@@ -482,15 +482,22 @@ static int skew_sweep (gfship_domain * dom, int level, SkewPlan * S, double * u_
 
 // the whole relax_loop (src/poisson.c:1070-1089) of one level in the skewed layout; for
 // nrelax = 1 and bc = false it is a single gfs_relax sweep
+bool prolongation_fused (gfship_domain * dom, unsigned dimension, int level, unsigned nrelax)
+{
+  if (dom->no_fused_prolongation || dom->weighted || level < 1) return false;
+  if (dom->relax_mode != GFSHIP_RELAX_EXACT || dimension != 3 || dom->force_hyperplane) return false;
+  if (dom->has_external && dom->overlap && nrelax > 1) return false;
+  return skew_supported (dom, level) && patch_level (dom, level);
+}
+
 int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * ubc,
 			    const double * rhs, const double * dia, bool dia_zero,
-			    unsigned nrelax, bool bc, double * correct_into)
+			    unsigned nrelax, bool bc, double * correct_into, const double * prolong_from)
 {
   SkewPlan * S;
   int r;
   if ((r = skew_plan (dom, level, &S))) return r;
   double * u = dp->lev[level];
-  if (bc && (r = launch_bc (dom, ubc, dp, level, 1))) return r;
   if (!dom->no_fused_loop && !S->loop_checked && skew_loop_supported (dom, level, nrelax, bc)) {
     /* Once per level: a trial run of the fused loop on zeros.  Its tiles wait on each other, so
        all of them must really be resident at the same time; the occupancy query says they are,
@@ -514,7 +521,14 @@ int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * 
       *skew_err_word (dom, level) = 0;
     }
   }
-  if ((r = skew_pack (dom, level, S, u, rhs, dia_zero ? nullptr : dia))) return r;
+  /* get_from_above fused into the copy into the skewed layout: the natural array gets the cells
+     along the box sides only (what the BC application reads), then the BC, then the loop */
+  const bool fusedp = prolong_from != nullptr && bc && patch_level (dom, level);
+  if (prolong_from && !fusedp)
+    if ((r = launch_prolongate (dom, level - 1, prolong_from, u))) return r;
+  if (fusedp && (r = skew_pack (dom, level, S, u, rhs, dia_zero ? nullptr : dia, prolong_from))) return r;
+  if (bc && (r = launch_bc (dom, ubc, dp, level, 1))) return r;
+  if (!fusedp && (r = skew_pack (dom, level, S, u, rhs, dia_zero ? nullptr : dia))) return r;
   if (!dom->no_fused_loop && skew_loop_supported (dom, level, nrelax, bc)) {
     /* the sweeps of the loop pipelined in one launch (relax_skew_loop.hip) */
     if ((r = skew_loop_run (dom, level, S, u, !dia_zero, nrelax, nullptr, ubc))) return r;

@@ -326,7 +326,7 @@ def test_skew_sweep_equals_hyperplane_sweep_256():
 # relax loop with its sweeps pipelined in one launch (relax_skew_loop.hip): periodic 3-D levels
 # ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("level,use_dia", [(5, False), (6, False), (6, True), (7, False)])
+@pytest.mark.parametrize("level,use_dia", [(5, False), (6, False), (6, True), (7, False), (7, True)])
 def test_fused_relax_loop_cycles_bit_exact_vs_oracle(level, use_dia):
     """V-cycles on a triply periodic box: the relax loops of the levels with n >= 32 run as one
     launch each (4 sweeps in flight behind each other, periodic images through the wrap
