@@ -256,6 +256,150 @@ static int halo_copy (gfship_domain * dom, double * a, int level, int side, doub
   return GFSHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The BC application of up to three variables at once (the velocity components, the components of
+// a pressure gradient: gfs_domain_bc is called for them one after the other, src/timestep.c:
+// 85,527): one launch for the local sides, and on MPI sides one pack kernel, ONE message per side
+// carrying the layers of all of them, one unpack kernel.
+// ---------------------------------------------------------------------------------------------
+struct BcMulti { BcDesc b[3]; double * a[3]; int nf; };
+
+__global__ void __launch_bounds__(256)
+bc_multi_kernel (Layout L, BcMulti M)
+{
+  const int n = L.n;
+  const int nface = L.dim == 3 ? n*n : n;
+  int f = blockIdx.x*blockDim.x + threadIdx.x;
+  int d = blockIdx.y;
+  const int q = blockIdx.z;
+  if (f >= nface) return;
+  const BcDesc & bc = M.b[q];
+  double * __restrict__ a = M.a[q];
+  if (bc.side[d] == GFSHIP_SIDE_EXTERNAL) return;
+  int c = d/2;
+  int t1 = f % n + 1, t2 = L.dim == 3 ? f / n + 1 : 0;
+  int ijk[3] = { 0, 0, 0 };
+  int ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
+  ijk[c] = (d & 1) ? 1 : n;
+  ijk[ta] = t1;
+  if (L.dim == 3) ijk[tb] = t2;
+  long o = c == 0 ? 1 : c == 1 ? L.sy : L.sz;
+  if (d & 1) o = - o;
+  long nb = L.idx (ijk[0], ijk[1], ijk[2]);
+  double v;
+  if (bc.side[d] == GFSHIP_SIDE_PERIODIC)
+    v = a[nb - (long) (n - 1)*o];
+  else {
+    double val = (!bc.homogeneous && bc.val[d]) ? bc.val[d][f] : 0.;
+    v = ghost_value_bc (bc.type[d], bc.component, c, a[nb], bc.homogeneous, val, 1./n);
+  }
+  a[nb + o] = v;
+}
+
+struct HaloMulti { int n; int side[6]; double * buf[6]; double * a[3]; int nf; };
+
+// blockIdx.y = entry of the side list, blockIdx.z = variable: its layer sits at buf + z nface
+__global__ void __launch_bounds__(256)
+halo_copy_multi_kernel (Layout L, HaloMulti H, int unpack)
+{
+  const int n = L.n;
+  const int nface = L.dim == 3 ? n*n : n;
+  int f = blockIdx.x*blockDim.x + threadIdx.x;
+  if (f >= nface) return;
+  const int side = H.side[blockIdx.y];
+  double * __restrict__ buf = H.buf[blockIdx.y] + (size_t) blockIdx.z*nface;
+  double * __restrict__ a = H.a[blockIdx.z];
+  int c = side/2;
+  int t1 = f % n + 1, t2 = L.dim == 3 ? f / n + 1 : 0;
+  int ijk[3] = { 0, 0, 0 };
+  int ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
+  ijk[c] = (side & 1) ? 1 : n;
+  ijk[ta] = t1;
+  if (L.dim == 3) ijk[tb] = t2;
+  long o = c == 0 ? 1 : c == 1 ? L.sy : L.sz;
+  if (side & 1) o = - o;
+  long nb = L.idx (ijk[0], ijk[1], ijk[2]);
+  if (unpack)
+    a[nb + o] = buf[f];
+  else
+    buf[f] = a[nb];
+}
+
+// send / receive buffers of 3 n^2 doubles per MPI side (leaf level): several variables in one
+// message, the face states of the tiled Godunov kernels
+int multi_buffers (gfship_domain * dom)
+{
+  const Layout & L = dom->lay[dom->depth];
+  const size_t bytes = (size_t) 3*(dom->dim == 3 ? (size_t) L.n*L.n : (size_t) L.n)*sizeof (double);
+  for (int d = 0; d < 2*dom->dim; d++) {
+    if (dom->side[d] != GFSHIP_SIDE_EXTERNAL) continue;
+    if (!dom->gfv_send[d]) GFSHIP_HIP (hipMalloc ((void **) &dom->gfv_send[d], bytes));
+    if (!dom->gfv_recv[d]) GFSHIP_HIP (hipMalloc ((void **) &dom->gfv_recv[d], bytes));
+  }
+  return GFSHIP_OK;
+}
+
+int launch_bc_multi (gfship_domain * dom, Field * const * v, int nf, int level, int homogeneous)
+{
+  GFSHIP_CHECK (nf >= 1 && nf <= 3, GFSHIP_EINVAL, "one to three variables");
+  const Layout & L = dom->lay[level];
+  const int nface = dom->dim == 3 ? L.n*L.n : L.n;
+  const int block = nface >= 256 ? 256 : 64;
+  bool local = false;
+  for (int d = 0; d < 2*dom->dim; d++)
+    if (dom->side[d] != GFSHIP_SIDE_EXTERNAL) local = true;
+  if (local) {
+    BcMulti M;
+    M.nf = nf;
+    for (int q = 0; q < nf; q++) {
+      for (int d = 0; d < 6; d++) {
+	M.b[q].side[d] = dom->side[d];
+	M.b[q].type[d] = v[q]->bc[d];
+	M.b[q].val[d] = (level == dom->depth) ? v[q]->bcval[d] : nullptr;
+      }
+      if (!homogeneous && level != dom->depth)
+	for (int d = 0; d < 2*dom->dim; d++)
+	  GFSHIP_CHECK (!(dom->side[d] == GFSHIP_SIDE_BOUNDARY && v[q]->bc[d] != GFSHIP_BC_SYMMETRY &&
+			  v[q]->bcval[d]),
+			GFSHIP_EUNSUPPORTED,
+			"non-homogeneous Dirichlet/Neumann values are held on the leaf level only");
+      M.b[q].component = v[q]->component;
+      M.b[q].homogeneous = homogeneous;
+      M.a[q] = v[q]->lev[level];
+    }
+    hipLaunchKernelGGL (bc_multi_kernel, dim3 ((nface + block - 1)/block, 2*dom->dim, nf), dim3 (block), 0,
+			dom->stream, L, M);
+    GFSHIP_HIP (hipGetLastError ());
+  }
+  if (!dom->has_external)
+    return GFSHIP_OK;
+  if (!dom->comm || nf == 1) {
+    for (int q = 0; q < nf; q++)
+      if (int r = call_exchange (dom, v[q]->lev[level], level, 0)) return r;
+    return GFSHIP_OK;
+  }
+  if (int r = multi_buffers (dom)) return r;
+  HaloMulti H;
+  H.n = 0; H.nf = nf;
+  for (int q = 0; q < nf; q++) H.a[q] = v[q]->lev[level];
+  for (int d = 0; d < 2*dom->dim; d++)
+    if (dom->side[d] == GFSHIP_SIDE_EXTERNAL) {
+      H.side[H.n] = d;
+      H.buf[H.n++] = dom->gfv_send[d];
+    }
+  hipLaunchKernelGGL (halo_copy_multi_kernel, dim3 ((nface + block - 1)/block, H.n, nf), dim3 (block), 0,
+		      dom->stream, L, H, 0);
+  GFSHIP_HIP (hipGetLastError ());
+  if (int r = comm_exchange_raw (dom, dom->gfv_send, dom->gfv_recv, (size_t) nf*nface)) return r;
+  /* the layer received across side d fills the ghost layer of side d */
+  for (int q = 0; q < H.n; q++)
+    H.buf[q] = dom->gfv_recv[H.side[q]];
+  hipLaunchKernelGGL (halo_copy_multi_kernel, dim3 ((nface + block - 1)/block, H.n, nf), dim3 (block), 0,
+		      dom->stream, L, H, 1);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
 } // namespace gfship
 
 extern "C" {

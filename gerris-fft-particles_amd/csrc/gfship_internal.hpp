@@ -174,6 +174,8 @@ int call_reduce_norm (gfship_domain * dom, double * sums, int nsum, double * mx)
 int comm_exchange (gfship_domain * dom, double * a, int level, int kind);
 int comm_exchange_raw (gfship_domain * dom, double * const send[6], double * const recv[6], size_t count);
 int comm_allgather (gfship_domain * dom, const double * send, double * recv, size_t count);
+int multi_buffers (gfship_domain * dom);
+int launch_bc_multi (gfship_domain * dom, Field * const * v, int nf, int level, int homogeneous);
 int call_gather (gfship_domain * dom, const double * send, double * recv, size_t count);
 int comm_exchange_begin (gfship_domain * dom, double * a, int level);
 int comm_exchange_end (gfship_domain * dom, double * a, int level);

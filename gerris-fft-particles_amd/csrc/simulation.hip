@@ -57,6 +57,16 @@ int bc_leaf (gfship_sim * s, gfship_field v)
   return launch_bc (s->dom, V, V, s->dom->depth, 0);
 }
 
+// gfs_domain_bc of the components of a vector, one after the other in the reference: one launch,
+// one message per MPI side
+int bc_leaf_vector (gfship_sim * s, const gfship_field v[3])
+{
+  Field * V[3];
+  for (int c = 0; c < s->dom->dim; c++)
+    if (!(V[c] = get_field (s->dom, v[c]))) return GFSHIP_EINVAL;
+  return launch_bc_multi (s->dom, V, s->dom->dim, s->dom->depth, 0);
+}
+
 // mac_projection, src/timestep.c:356-444.  `pdata` supplies the storage of the pressure and
 // `pbc` the boundary conditions (gfs_variables_swap swaps storage only, src/variable.c:234-243).
 int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, gfship_field p,
@@ -90,11 +100,9 @@ int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, g
     if (s->visc[c] != 0.) want_max = false;   /* the acceleration term needs the full kernel */
   TRY (launch_project_correct (dom, leaf (s, p), un, gp, approximate ? u : nullptr, dt, want_max));
   s->cfl_ready = want_max;
-  for (int c = 0; c < dom->dim; c++)
-    TRY (bc_leaf (s, g[c]));
+  TRY (bc_leaf_vector (s, g));
   if (approximate)
-    for (int c = 0; c < dom->dim; c++)
-      TRY (bc_leaf (s, s->u[c]));
+    TRY (bc_leaf_vector (s, s->u));
   return GFSHIP_OK;
 }
 
@@ -105,8 +113,7 @@ int correct_centered_velocities (gfship_sim * s, const gfship_field g[3], double
   ptrs3 (s, s->u, u);
   ptrs3 (s, g, gp);
   TRY (launch_correct_centered (s->dom, u, gp, dt));
-  for (int c = 0; c < s->dom->dim; c++)
-    TRY (bc_leaf (s, s->u[c]));
+  TRY (bc_leaf_vector (s, s->u));
   return GFSHIP_OK;
 }
 
@@ -390,8 +397,7 @@ int gfship_centered_velocity_advection (gfship_sim * s, const gfship_field gmac[
       std::swap (dom->fields[s->u[c]].lev[L], dom->fields[s->adv_tmp3[c]].lev[L]);
       dom->fields[s->u[c]].zero[L] = false;
     }
-    for (int c = 0; c < 3; c++)
-      TRY (bc_leaf (s, s->u[c]));
+    TRY (bc_leaf_vector (s, s->u));
     return GFSHIP_OK;
   }
   for (int c = 0; c < s->dom->dim; c++) {
@@ -413,8 +419,7 @@ int gfship_centered_velocity_advection (gfship_sim * s, const gfship_field gmac[
       TRY (variable_sources (s, s->u[c], s->u[c], s->advection_params.gradient, true,
 			     s->advection_params.dt, gmac, g));
   }
-  for (int c = 0; c < s->dom->dim; c++)
-    TRY (bc_leaf (s, s->u[c]));
+  TRY (bc_leaf_vector (s, s->u));
   return GFSHIP_OK;
 }
 

@@ -1552,13 +1552,10 @@ bool godunov_fused_mpi_supported (const gfship_domain * dom)
 // send / receive buffers of the states beyond the MPI sides (3 n^2 doubles per side)
 static int ghost_fv (gfship_domain * dom, GhostFv * G)
 {
-  const Layout & L = dom->lay[dom->depth];
-  const size_t bytes = (size_t) 3*L.n*L.n*sizeof (double);
+  if (int r = multi_buffers (dom)) return r;
   for (int d = 0; d < 6; d++) {
     G->r[d] = nullptr; G->s[d] = nullptr;
     if (dom->side[d] != GFSHIP_SIDE_EXTERNAL) continue;
-    if (!dom->gfv_send[d]) GFSHIP_HIP (hipMalloc ((void **) &dom->gfv_send[d], bytes));
-    if (!dom->gfv_recv[d]) GFSHIP_HIP (hipMalloc ((void **) &dom->gfv_recv[d], bytes));
     G->s[d] = dom->gfv_send[d];
     G->r[d] = dom->gfv_recv[d];
   }
