@@ -105,6 +105,7 @@ struct ParticleSpec {
   std::vector<unsigned> id;
   std::vector<double> pos, vel, mass, volume;    // 3 per particle for pos / vel
   std::vector<int> forces;                       // GFSHIP_FORCE_* in file order
+  std::vector<std::string> force_functions;      // the GfsFunction of a GfsForceCoeff ("" = none)
   gfship_particles * pl = nullptr;
 };
 
@@ -666,10 +667,18 @@ void parse_object (Run & R, Reader & r)
 	  k == "ForceLift" ? GFSHIP_FORCE_LIFT : k == "ForceDrag" ? GFSHIP_FORCE_DRAG :
 	  k == "ForceBuoy" ? GFSHIP_FORCE_BUOY : 0;
 	if (!kind) b.fail ("unsupported GfsParticleForce `" + k + "'");
+	// gfs_force_coeff_read, modules/particulatecommon.c:189-207: what follows on the line is the
+	// GfsFunction of the coefficient (variables Rep, Urelp, Vrelp, Wrelp, Pdia): compiled for the
+	// device when the list is created
+	std::string fn;
 	char c = b.peek (false);
-	if (c != 0 && c != '\n')
-	  b.fail ("coefficient functions of a GfsForceCoeff are not supported");
+	if (c != 0 && c != '\n') {
+	  if (kind == GFSHIP_FORCE_INERTIAL || kind == GFSHIP_FORCE_BUOY)
+	    b.fail ("Gfs" + k + " takes no coefficient");
+	  fn = b.function ().text;
+	}
 	ps->forces.push_back (kind);
+	ps->force_functions.push_back (fn);
       }
       if (!ps->forces.empty () && !ps->particulate)
 	r.fail ("GfsParticleForce objects act on GfsParticulate objects");
@@ -1512,6 +1521,9 @@ int run (Run & R)
       CHECK (gfship_particles_set_particulate (ps->pl, ps->vel.data (), ps->mass.data (), ps->volume.data ()));
       /* gravity = the GfsSource objects on U, V, W: none can be declared here */
       CHECK (gfship_particles_set_forces (ps->pl, (int) ps->forces.size (), ps->forces.data (), nullptr));
+      for (size_t f = 0; f < ps->force_functions.size (); f++)
+	if (!ps->force_functions[f].empty ())
+	  CHECK (gfship_particles_set_force_coefficient (ps->pl, (int) f, ps->force_functions[f].c_str ()));
     }
   }
   set_boundary_conditions (R);

@@ -25,6 +25,15 @@
 #include <algorithm>
 #include <numeric>
 
+namespace gfship {
+struct RtcKernel;
+int  rtc_compile_coefficient (gfship_domain * dom, const char * text, RtcKernel ** out);
+int  rtc_launch_coefficient (RtcKernel * k, hipStream_t stream, int n, const unsigned char * alive,
+			     const double * rep, const double * const rel[3], const double * pdia,
+			     double t, double * out);
+void rtc_free (RtcKernel * k);
+}
+
 struct gfship_particles {
   gfship_sim * sim = nullptr;
   gfship_domain * dom = nullptr;
@@ -56,6 +65,11 @@ struct gfship_particles {
   int nforces = 0, forces[8] = {};
   double gravity[3] = {};
   gfship_field uold[3] = { -1, -1, -1 };   // Un, Vn, Wn of GfsForceCoeff
+  // GfsFunction coefficients of the GfsForceCoeff objects, compiled for the device (rtc.hip): the
+  // variables Rep, Urelp, Vrelp, Wrelp, Pdia of every particle (slot order), and the values
+  gfship::RtcKernel * coef_fn[8] = {};
+  double * coef[8] = {}, * cin[5] = {};
+  int coef_cap = 0;
 };
 
 namespace gfship {
@@ -333,6 +347,8 @@ struct ParticulateArgs {
   const double * uold[3];
   int nforces, forces[8];
   double gravity[3], viscosity;
+  const double * coef[8];      // values of the GfsFunction of force f per slot; nullptr: the default
+  double * cin[5];             // Rep, Urelp, Vrelp, Wrelp, Pdia per slot (coefficient inputs)
 };
 
 // gfs_center_gradient, src/fluid.c:434-475, both neighbours at the same level (x1 = x2 = 1.)
@@ -365,6 +381,36 @@ __device__ void inertial_force (const ParticulateArgs & A, const int cell[3], co
 #pragma unroll
     for (int c2 = 0; c2 < DIM; c2++)
       force[c] += fluid_rho*center_gradient (A.P.u[c], idx, off[c2])*A.P.u[c2][idx]/size;
+}
+
+// the variables a GfsFunction of a GfsForceCoeff sees (:364-384,462-485,545-573): the particle
+// Reynolds number from the relative velocity (all three components of the FttVectors), the sphere
+// diameter and the viscosity (0.001 where the reference substitutes it for a zero viscosity in the
+// added-mass and lift coefficients; the drag is then zero whatever its coefficient)
+template <int DIM>
+__global__ void __launch_bounds__(256)
+particulate_coeff_inputs_kernel (ParticulateArgs A, int depth)
+{
+  const PartArgs & P = A.P;
+  int q = blockIdx.x*blockDim.x + threadIdx.x;
+  if (q >= P.n) return;
+  if (P.alive[q] != 1) return;
+  const Layout & L = P.L;
+  double p[3] = { P.pos[0][q], P.pos[1][q], DIM == 3 ? P.pos[2][q] : 0. };
+  int cell[3];
+  if (!locate<DIM> (depth, p, cell)) return;
+  const unsigned o = A.orig[q];
+  const double fluid_rho = 1.;
+  double rel[3] = { 0. - A.vel[0][o], 0. - A.vel[1][o], 0. - A.vel[2][o] };
+#pragma unroll
+  for (int c = 0; c < DIM; c++)
+    rel[c] = interpolate<DIM> (L, P.u[c], cell, p) - A.vel[c][o];
+  const double norm = sqrt (rel[0]*rel[0] + rel[1]*rel[1] + rel[2]*rel[2]);
+  const double dia = A.dia[o];
+  const double viscosity = A.viscosity == 0 ? 0.001 : A.viscosity;
+  A.cin[0][q] = norm*dia*fluid_rho/viscosity;
+  A.cin[1][q] = rel[0]; A.cin[2][q] = rel[1]; A.cin[3][q] = rel[2];
+  A.cin[4][q] = dia;
 }
 
 // gfs_particulate_event (:768-842) in a gfs_particle_list_event (:980-1015)
@@ -403,7 +449,7 @@ particulate_list_event_kernel (ParticulateArgs A, int depth)
       break;
     case FORCE_ADDEDMASS: {     // compute_addedmass_force, :363-427
       inertial_force<DIM> (A, cell, p, idx, force);
-      const double cm = 0.5;
+      const double cm = A.coef[f] ? A.coef[f][q] : 0.5;
 #pragma unroll
       for (int c = 0; c < DIM; c++)
 	force[c] *= cm;
@@ -424,7 +470,7 @@ particulate_list_event_kernel (ParticulateArgs A, int depth)
 	vort[1] = (center_gradient (P.u[0], idx, off[2]) - center_gradient (P.u[2], idx, off[0]))/size;
 	vort[2] = (center_gradient (P.u[1], idx, off[0]) - center_gradient (P.u[0], idx, off[1]))/size;
       }
-      const double cl = 0.5;
+      const double cl = A.coef[f] ? A.coef[f][q] : 0.5;
       if (DIM == 2) {
 	force[0] = fluid_rho*cl*rel[1]*vort[2];
 	force[1] = -fluid_rho*cl*rel[0]*vort[2];
@@ -448,7 +494,9 @@ particulate_list_event_kernel (ParticulateArgs A, int depth)
 	break;
       const double Re = norm*dia*fluid_rho/A.viscosity;
       double cd;
-      if (Re < 1e-8)
+      if (A.coef[f])
+	cd = A.coef[f][q];
+      else if (Re < 1e-8)
 	break;
       else if (Re < 50.0)
 	cd = 16.*(1. + 0.15*sqrt (Re))/Re;
@@ -686,6 +734,12 @@ void gfship_particles_destroy (gfship_particles * pl)
   if (pl->mass) (void) hipFree (pl->mass);
   if (pl->volume) (void) hipFree (pl->volume);
   if (pl->dia) (void) hipFree (pl->dia);
+  for (int f = 0; f < 8; f++) {
+    if (pl->coef[f]) (void) hipFree (pl->coef[f]);
+    gfship::rtc_free (pl->coef_fn[f]);
+  }
+  for (int q = 0; q < 5; q++)
+    if (pl->cin[q]) (void) hipFree (pl->cin[q]);
   delete pl;
 }
 
@@ -978,6 +1032,47 @@ static int particulate_event (gfship_particles * pl, const PartArgs & P, double 
   for (int f = 0; f < 8; f++) A.forces[f] = pl->forces[f];
   A.viscosity = viscosity;
   int block = 256, grid = (pl->n + block - 1)/block;
+  bool any = false;
+  for (int f = 0; f < 8; f++) {
+    A.coef[f] = nullptr;
+    if (f < pl->nforces && pl->coef_fn[f]) any = true;
+  }
+  for (int q = 0; q < 5; q++) A.cin[q] = nullptr;
+  if (any) {
+    /* the GfsFunction coefficients: inputs of every particle, then one compiled kernel per function */
+    if (pl->coef_cap < pl->cap) {
+      for (int q = 0; q < 5; q++) {
+	if (pl->cin[q]) GFSHIP_HIP (hipFree (pl->cin[q]));
+	pl->cin[q] = nullptr;
+	GFSHIP_HIP (hipMalloc ((void **) &pl->cin[q], (size_t) pl->cap*sizeof (double)));
+      }
+      for (int f = 0; f < 8; f++) {
+	if (pl->coef[f]) GFSHIP_HIP (hipFree (pl->coef[f]));
+	pl->coef[f] = nullptr;
+	if (pl->coef_fn[f])
+	  GFSHIP_HIP (hipMalloc ((void **) &pl->coef[f], (size_t) pl->cap*sizeof (double)));
+      }
+      pl->coef_cap = pl->cap;
+    }
+    for (int q = 0; q < 5; q++) A.cin[q] = pl->cin[q];
+    if (dom->dim == 3)
+      hipLaunchKernelGGL (particulate_coeff_inputs_kernel<3>, dim3 (grid), dim3 (block), 0, dom->stream,
+			  A, dom->depth);
+    else
+      hipLaunchKernelGGL (particulate_coeff_inputs_kernel<2>, dim3 (grid), dim3 (block), 0, dom->stream,
+			  A, dom->depth);
+    GFSHIP_HIP (hipGetLastError ());
+    const double * rel[3] = { pl->cin[1], pl->cin[2], pl->cin[3] };
+    for (int f = 0; f < pl->nforces; f++)
+      if (pl->coef_fn[f]) {
+	if (!pl->coef[f])
+	  GFSHIP_HIP (hipMalloc ((void **) &pl->coef[f], (size_t) pl->coef_cap*sizeof (double)));
+	int r = rtc_launch_coefficient (pl->coef_fn[f], dom->stream, pl->n, P.alive, pl->cin[0], rel, pl->cin[4],
+					gfship_sim_time (pl->sim), pl->coef[f]);
+	if (r) return r;
+	A.coef[f] = pl->coef[f];
+      }
+  }
   if (dom->dim == 3)
     hipLaunchKernelGGL (particulate_list_event_kernel<3>, dim3 (grid), dim3 (block), 0, dom->stream,
 			A, dom->depth);
@@ -1047,6 +1142,23 @@ int gfship_particles_set_forces (gfship_particles * pl, int nforces, const int *
     }
     return store_previous_vel (pl);
   }
+  return GFSHIP_OK;
+}
+
+int gfship_particles_set_force_coefficient (gfship_particles * pl, int force, const char * function)
+{
+  GFSHIP_CHECK (pl && function, GFSHIP_EINVAL, "null argument");
+  GFSHIP_CHECK (force >= 0 && force < pl->nforces, GFSHIP_EINVAL,
+		"force %d: the list has %d forces (gfship_particles_set_forces)", force, pl->nforces);
+  GFSHIP_CHECK (pl->forces[force] == GFSHIP_FORCE_ADDEDMASS || pl->forces[force] == GFSHIP_FORCE_LIFT ||
+		pl->forces[force] == GFSHIP_FORCE_DRAG, GFSHIP_EINVAL,
+		"only GfsForceAddedMass, GfsForceLift and GfsForceDrag read a coefficient");
+  gfship::RtcKernel * k = nullptr;
+  int r = gfship::rtc_compile_coefficient (pl->dom, function, &k);
+  if (r) return r;
+  GFSHIP_HIP (hipStreamSynchronize (pl->dom->stream));
+  gfship::rtc_free (pl->coef_fn[force]);
+  pl->coef_fn[force] = k;
   return GFSHIP_OK;
 }
 

@@ -436,6 +436,17 @@ int coarse_cycle_top (gfship_domain * dom, int minlevel)
   return top > minlevel ? top : -1;   /* a single level: the plain LDS loop does it */
 }
 
+static int coarse_threads ()
+{
+  static int n = 0;
+  if (!n) {
+    const char * e = getenv ("GFSHIP_COARSE_THREADS");
+    n = e ? atoi (e) : 1024;
+    if (n < 64 || n > 1024 || (n & 63)) n = 1024;
+  }
+  return n;
+}
+
 int launch_coarse_cycle (gfship_domain * dom, unsigned dimension, double omega, int lmin, int ltop,
 			 const unsigned * nrelax, Field * dp, Field * ubc, Field * res, Field * dia)
 {
@@ -475,7 +486,7 @@ int launch_coarse_cycle (gfship_domain * dom, unsigned dimension, double omega, 
 				       hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
       dom->coarse_attr_set = true;
     }
-    hipLaunchKernelGGL (coarse_cycle_kernel<3>, dim3 (1), dim3 (1024), bytes, dom->stream, A);
+    hipLaunchKernelGGL (coarse_cycle_kernel<3>, dim3 (1), dim3 (coarse_threads ()), bytes, dom->stream, A);
   }
   else {
     if (!dom->coarse_attr_set) {
@@ -483,7 +494,7 @@ int launch_coarse_cycle (gfship_domain * dom, unsigned dimension, double omega, 
 				       hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
       dom->coarse_attr_set = true;
     }
-    hipLaunchKernelGGL (coarse_cycle_kernel<2>, dim3 (1), dim3 (1024), bytes, dom->stream, A);
+    hipLaunchKernelGGL (coarse_cycle_kernel<2>, dim3 (1), dim3 (coarse_threads ()), bytes, dom->stream, A);
   }
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;

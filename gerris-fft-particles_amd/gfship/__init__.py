@@ -149,6 +149,7 @@ SIGNATURES = {
     "gfship_turbulent_viscosity": (_i, [_vp, C.POINTER(_i), C.c_double, _i, _i]),
     "gfship_particles_set_particulate": (_i, [_vp, _pd, _pd, _pd]),
     "gfship_particles_set_forces": (_i, [_vp, _i, C.POINTER(_i), _pd]),
+    "gfship_particles_set_force_coefficient": (_i, [_vp, _i, C.c_char_p]),
     "gfship_particles_download_particulate": (_i, [_vp, _pd, _pd, _pd]),
 }
 
@@ -612,6 +613,11 @@ class ParticleList:
         k = (_i * len(kinds))(*kinds)
         g = (C.c_double * 3)(*gravity)
         _check(lib().gfship_particles_set_forces(self.ptr, len(kinds), k, g))
+
+    def set_force_coefficient(self, force, function):
+        """the GfsFunction (C text of Rep, Urelp, Vrelp, Wrelp, Pdia, t) of force number `force' of the
+        list: compiled for the device with hipRTC"""
+        _check(lib().gfship_particles_set_force_coefficient(self.ptr, int(force), function.encode()))
 
     def particulate_state(self):
         """(vel, mass, force) of the particles on the list, in list order"""

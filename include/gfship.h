@@ -361,15 +361,23 @@ int  gfship_particles_download (gfship_particles * pl, double * pos, unsigned * 
    cd = 16 (1 + 0.15 Re^0.5)/Re below Re = 50, 48 (1 - 2.21/Re^0.5)/Re above; no force without
    viscosity), GfsForceBuoy (:619-653, gravity = the sum of the GfsSource intensities on U, V, W) --
    then pos += vel*dt/2, vel += force*dt/mass, pos += vel*dt/2 and gfs_particle_bc.  fluid density 1
-   (alpha = NULL), viscosity = gfship_sim_set_viscosity of U; user coefficient functions
-   (GfsForceCoeff with a GfsFunction) are not supported yet.  Particulates migrate between boxes like
-   tracers, with 15-double records. */
+   (alpha = NULL), viscosity = gfship_sim_set_viscosity of U.  Particulates migrate between boxes like
+   tracers, with 15-double records.
+   gfship_particles_set_force_coefficient: the GfsFunction a GfsForceAddedMass / GfsForceLift /
+   GfsForceDrag object of the list may carry (gfs_force_coeff_read, :166-210) -- C text as in the
+   simulation file, an expression or a { block } with a return, of the variables Rep, Urelp, Vrelp,
+   Wrelp, Pdia (set per particle as in :364-384,462-485,545-573) and t.  gerris compiles it with the
+   host compiler; here it is compiled for the GPU of the domain with hipRTC and evaluated for all
+   particles by a kernel of its own before the event kernel (same C arithmetic, the device's libm).
+   `force' is the index into the list given to gfship_particles_set_forces.  A text that does not
+   compile: GFSHIP_EINVAL with the compiler's messages in gfship_last_error(). */
 enum { GFSHIP_FORCE_INERTIAL = 1, GFSHIP_FORCE_ADDEDMASS = 2, GFSHIP_FORCE_LIFT = 3,
        GFSHIP_FORCE_DRAG = 4, GFSHIP_FORCE_BUOY = 5 };
 int  gfship_particles_set_particulate (gfship_particles * pl, const double * vel, const double * mass,
 				       const double * volume);
 int  gfship_particles_set_forces (gfship_particles * pl, int nforces, const int * kinds,
 				  const double gravity[3]);
+int  gfship_particles_set_force_coefficient (gfship_particles * pl, int force, const char * function);
 /* velocity (3 per particle), mass and force of the particles still on the list, in list order (any
    pointer may be NULL); returns their number */
 int  gfship_particles_download_particulate (gfship_particles * pl, double * vel, double * mass,

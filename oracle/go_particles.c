@@ -361,6 +361,13 @@ void go_particles_set_forces (GoParticles * pl, GoSim * s, int n, const int * ki
   }
 }
 
+void go_particles_set_coefficient (GoParticles * pl, int force,
+				   double (* fn) (double, double, double, double, double))
+{
+  assert (force >= 0 && force < 8);
+  pl->coefficient[force] = fn;
+}
+
 void go_particles_set_gravity (GoParticles * pl, const double g[3])
 {
   for (int c = 0; c < 3; c++) pl->gravity[c] = g[c];
@@ -427,6 +434,28 @@ static void vorticity_vector (GoSim * s, size_t idx, double vort[3])
   }
 }
 
+/* the coefficient of a GfsForceCoeff with a GfsFunction: Rep, Urelp, Vrelp, Wrelp, Pdia set in the
+ * cell, then gfs_function_value (compute_addedmass_force :354-384, compute_lift_force :462-485; the
+ * relative velocity is an FttVector: all three components enter the norm) */
+static double force_coefficient (GoSim * s, GoParticles * pl, int q, int f, const int cell[3],
+				 const double p[3], double fluid_rho, double viscosity)
+{
+  GoDomain * dom = s->dom;
+  int dim = dom->dim, L = dom->depth;
+  const double * vel = pl->vel + 3*q;
+  double relative_vel[3] = { 0. - vel[0], 0. - vel[1], 0. - vel[2] };
+  for (int c = 0; c < dim; c++)
+    relative_vel[c] = go_interpolate (dom, s->u[c]->lev[L], cell, p) - vel[c];
+  double norm_relative_vel = sqrt (relative_vel[0]*relative_vel[0] +
+				   relative_vel[1]*relative_vel[1] +
+				   relative_vel[2]*relative_vel[2]);
+  double dia = 2.*pow (3.0*pl->volume[q]/4.0/M_PI, 1./3.);
+  if (viscosity == 0)
+    viscosity = 0.001;
+  double Re = norm_relative_vel*dia*fluid_rho/viscosity;
+  return (* pl->coefficient[f]) (Re, relative_vel[0], relative_vel[1], relative_vel[2], dia);
+}
+
 /* gfs_particulate_event with forces, :768-842: forces from the state at the start of the step,
  * then pos += vel*dt/2, vel += force*dt/mass, pos += vel*dt/2 */
 static void particulate_event (GoSim * s, GoParticles * pl, int q)
@@ -454,6 +483,8 @@ static void particulate_event (GoSim * s, GoParticles * pl, int q)
       case GO_FORCE_ADDEDMASS: {   /* compute_addedmass_force, :363-427 */
 	inertial_force (s, pl, cell, p, force);
 	double cm = 0.5;
+	if (pl->coefficient[f])
+	  cm = force_coefficient (s, pl, q, f, cell, p, fluid_rho, viscosity);
 	for (int c = 0; c < dim; c++)
 	  force[c] *= cm;
 	pl->mass[q] += fluid_rho*pl->volume[q]*cm;
@@ -466,6 +497,8 @@ static void particulate_event (GoSim * s, GoParticles * pl, int q)
 	if (dim == 2) relative_vel[2] = 0. - vel[2];
 	vorticity_vector (s, idx, vorticity);
 	double cl = 0.5;
+	if (pl->coefficient[f])
+	  cl = force_coefficient (s, pl, q, f, cell, p, fluid_rho, viscosity);
 	if (dim == 2) {
 	  force[0] = fluid_rho*cl*relative_vel[1]*vorticity[2];
 	  force[1] = -fluid_rho*cl*relative_vel[0]*vorticity[2];
@@ -490,7 +523,9 @@ static void particulate_event (GoSim * s, GoParticles * pl, int q)
 	if (viscosity == 0)
 	  break;
 	Re = norm_relative_vel*dia*fluid_rho/viscosity;
-	if (Re < 1e-8)
+	if (pl->coefficient[f])      /* :565-574 */
+	  cd = (* pl->coefficient[f]) (Re, relative_vel[0], relative_vel[1], relative_vel[2], dia);
+	else if (Re < 1e-8)
 	  break;
 	else if (Re < 50.0)
 	  cd = 16.*(1. + 0.15*pow (Re, 0.5))/Re;

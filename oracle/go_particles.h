@@ -18,6 +18,9 @@ typedef struct {
   double * vel, * force;     /* 3 doubles per particle */
   double * mass, * volume;
   int nforces, forces[8];    /* GO_FORCE_* */
+  /* the GfsFunction of a GfsForceCoeff (particulatecommon.c:166-210): called with the variables
+     Rep, Urelp, Vrelp, Wrelp, Pdia as the reference sets them in the particle's cell; NULL: none */
+  double (* coefficient[8]) (double rep, double urel, double vrel, double wrel, double pdia);
   double gravity[3];         /* sum of the GfsSource intensities on U, V, W (compute_buoyancy_force) */
   GoField * uold[3];         /* "Un", "Vn", "Wn" of GfsForceCoeff (particulatecommon.c:181-185) */
 } GoParticles;
@@ -42,6 +45,8 @@ void   go_particles_set_particulate (GoParticles * pl, const double * vel, const
 				     const double * volume);
 void   go_particles_set_forces (GoParticles * pl, GoSim * s, int n, const int * kinds);
 void   go_particles_set_gravity (GoParticles * pl, const double g[3]);
+void   go_particles_set_coefficient (GoParticles * pl, int force,
+				     double (* fn) (double, double, double, double, double));
 double * go_particles_vel (GoParticles * pl);
 double * go_particles_mass (GoParticles * pl);
 double * go_particles_force (GoParticles * pl);

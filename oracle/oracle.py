@@ -410,6 +410,7 @@ class Particles:
                 "go_particles_set_particulate": (None, [vp, pd, pd, pd]),
                 "go_particles_set_forces": (None, [vp, vp, i, C.POINTER(i)]),
                 "go_particles_set_gravity": (None, [vp, pd]),
+                "go_particles_set_coefficient": (None, [vp, i, vp]),
                 "go_particles_vel": (pd, [vp]),
                 "go_particles_mass": (pd, [vp]),
                 "go_particles_force": (pd, [vp]),
@@ -462,6 +463,14 @@ class Particles:
         g = (C.c_double * 3)(*gravity)
         lib().go_particles_set_gravity(self.ptr, g)
         lib().go_particles_set_forces(self.ptr, self.sim.ptr, len(kinds), k)
+
+    COEFF_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double)
+
+    def set_coefficient(self, force, fn):
+        """the GfsFunction of force number `force' of the list: fn (Rep, Urelp, Vrelp, Wrelp, Pdia)"""
+        cb = Particles.COEFF_FN(fn)
+        self._keep = getattr(self, "_keep", []) + [cb]
+        lib().go_particles_set_coefficient(self.ptr, force, C.cast(cb, C.c_void_p))
 
     def particulate_state(self):
         """(vel, mass, force) of the particles on the list, in list order"""

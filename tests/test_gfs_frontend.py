@@ -159,16 +159,20 @@ def test_check_particulates_case():
 
 
 @pytest.mark.gpu
-def test_particulates_case_matches_the_oracle(tmp_path):
+@pytest.mark.parametrize("case", ["particulates.gfs", "particulates_coeff.gfs"])
+def test_particulates_case_matches_the_oracle(tmp_path, case):
     """the list of the case file after 8 steps, as the reference would write it (%g), against the
     oracle driven from Python with the same set-up (previous velocity of the GfsForceCoeff objects
-    stored while the fields are still zero, like the reference reading the file)"""
+    stored while the fields are still zero, like the reference reading the file); the second file
+    gives two of the forces a GfsFunction coefficient (compiled for the device by the front end's
+    library call, evaluated by the oracle as Python callbacks)"""
+    import math
     from oracle import oracle as O
     from flow_cases import PERIODIC, reynolds_init
     level, nsteps = 5, 8
     outp = tmp_path / "plist.txt"
     cmd = [BIN, "--particles", str(outp), "-DLEVEL=%d" % level, "-DNSTEPS=%d" % nsteps,
-           os.path.join(CASES, "particulates.gfs")]
+           os.path.join(CASES, case)]
     r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     rows = [l.split() for l in open(outp) if l.strip().startswith("GfsParticulate")]
@@ -187,6 +191,9 @@ def test_particulates_case_matches_the_oracle(tmp_path):
     pl = O.Particles(s, pos, np.arange(1, 6, dtype=np.uint32))
     pl.set_particulate(vel, mass, vol)
     pl.set_forces([O.FORCE_DRAG, O.FORCE_LIFT, O.FORCE_INERTIAL])      # Un = Vn = 0 here
+    if case == "particulates_coeff.gfs":
+        pl.set_coefficient(0, lambda rep, u, v, w, d: 24. / rep * (1. + 0.15 * math.pow(rep, 0.687)))
+        pl.set_coefficient(1, lambda rep, u, v, w, d: 0.3 + 0.1 * u)
     x, y = s.dom.centres()
     u, v = reynolds_init(x, y)
     s.u[0].interior()[...] = u

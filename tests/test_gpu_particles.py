@@ -217,7 +217,7 @@ def _rel_err(a, b):
 
 
 def _run_particulates(osim, side, pos, ids, vel, mass, vol, forces, gravity, nsteps, nu, sort_every=None,
-                      end=None):
+                      end=None, coefficients=None):
     gd, gs = _device_sim(osim, side)
     if end is not None:
         gs.set_time(end=end)
@@ -234,6 +234,9 @@ def _run_particulates(osim, side, pos, ids, vel, mass, vol, forces, gravity, nst
     gpl.set_particulate(vel, mass, vol)
     opl.set_forces(forces, gravity)
     gpl.set_forces(forces, gravity)
+    for f, (text, fn) in (coefficients or {}).items():
+        opl.set_coefficient(f, fn)
+        gpl.set_force_coefficient(f, text)
     worst = 0.
     for k in range(nsteps):
         opl.event()
@@ -283,6 +286,56 @@ def test_particulates_all_forces_taylor_green_3d(sort_every):
     idx = np.searchsorted(ids, opl.state()[1])
     assert np.allclose(om, mass[idx] + 6 * 0.5 * vol[idx], rtol=1e-13)
     assert worst <= 1e-12
+
+
+def test_particulates_with_coefficient_functions():
+    """GfsForceCoeff objects carrying a GfsFunction (modules/particulatecommon.c:166-210): the C text is
+    compiled for the device with hipRTC and evaluated per particle; the oracle calls the same
+    expressions on the host.  Schiller-Naumann drag, a lift coefficient given as a { block }, an
+    added-mass coefficient of the diameter and the relative velocity."""
+    import math
+    nu = 1e-2
+    osim = oracle_taylor_green(4)
+    for c in range(3):
+        osim.set_viscosity(c, nu)
+    pos, ids, vel, mass, vol = _particulate_case(1200, 3, 21)
+    forces = [O.FORCE_INERTIAL, O.FORCE_ADDEDMASS, O.FORCE_LIFT, O.FORCE_DRAG, O.FORCE_BUOY]
+    coefficients = {
+        1: ("0.5 + 0.1*Pdia + 0.01*fabs (Wrelp)",
+            lambda rep, u, v, w, d: 0.5 + 0.1 * d + 0.01 * abs(w)),
+        2: ("{ double a = 0.3 + 0.1*Urelp; if (Rep > 1.) a += 0.05*Vrelp; return a; }",
+            lambda rep, u, v, w, d: (0.3 + 0.1 * u) + (0.05 * v if rep > 1. else 0.)),
+        3: ("24./Rep*(1. + 0.15*pow (Rep, 0.687))",
+            lambda rep, u, v, w, d: 24. / rep * (1. + 0.15 * math.pow(rep, 0.687))),
+    }
+    worst, opl, gpl = _run_particulates(osim, PERIODIC, pos, ids, vel, mass, vol, forces, (0., 0.5, 0.), 5, nu,
+                                        sort_every=2, coefficients=coefficients)
+    assert worst <= 1e-12
+    # the coefficients are really used: the default laws give another state
+    w2, opl2, gpl2 = _run_particulates(_tg_with_nu(nu), PERIODIC, pos, ids, vel, mass, vol, forces,
+                                       (0., 0.5, 0.), 5, nu, sort_every=2)
+    v1, v2 = gpl.particulate_state()[0], gpl2.particulate_state()[0]
+    assert len(v1) != len(v2) or _rel_err(v1, v2) > 1e-6
+
+
+def _tg_with_nu(nu):
+    osim = oracle_taylor_green(4)
+    for c in range(3):
+        osim.set_viscosity(c, nu)
+    return osim
+
+
+def test_a_coefficient_function_that_does_not_compile_is_reported():
+    osim = oracle_taylor_green(3)
+    gd, gs = _device_sim(osim, PERIODIC)
+    pos, ids, vel, mass, vol = _particulate_case(10, 3, 5)
+    gpl = gfship.ParticleList(gs, pos, ids)
+    gpl.set_particulate(vel, mass, vol)
+    gpl.set_forces([O.FORCE_DRAG], (0., 0., 0.))
+    with pytest.raises(gfship.GfshipError, match="does not compile"):
+        gpl.set_force_coefficient(0, "24./Rep +* nonsense(")
+    with pytest.raises(gfship.GfshipError, match="coefficient"):
+        gpl.set_forces([O.FORCE_BUOY], (0., 0., 0.)) or gpl.set_force_coefficient(0, "1.")
 
 
 def test_particulates_2d_periodic():
