@@ -52,7 +52,13 @@ struct SkewPlan {
   size_t hb_words = 0;
   double * us = nullptr, * rs = nullptr, * ds = nullptr;
   void * hb = nullptr;            // hand-off granules (J side then K side)
-  void * hbf = nullptr;           // granules of the fused relax loop (relax_skew_loop.hip)
+  void * hbf = nullptr;           // granules of the fused relax loop (relax_skew_loop.hip): two sets
+  // the sets are used in turn: a loop kernel of relax_patch_loop.hip arms the OTHER set for the next
+  // loop of the level while its tiles wait for their first hand-off (armed = granules armed from
+  // the start of the set, 0 = to be armed by a fill before the launch)
+  int cur_set = 0;
+  size_t armed[2] = { 0, 0 };
+  unsigned * arm_cum = nullptr;   // share of each tile in that arming (cumulative weights)
   bool loop_checked = false;      // the trial run of the fused loop has been made on this level
   void * stats_loop = nullptr;    // optional per-tile, per-sweep timing of the fused loop (debug)
   void * ctl = nullptr;           // { ticket, err }
@@ -105,6 +111,7 @@ struct gfship_domain {
   unsigned * lat_bar = nullptr;
   size_t lat_res_doubles = 0, lat_xch_doubles = 0;
   double * gfv_send[6] = {}, * gfv_recv[6] = {};   // states beyond the MPI sides of the tiled Godunov kernels
+  bool no_kernel_arming = true;         // GFSHIP_KERNEL_ARMING=1: the loop kernels arm the other granule set (measured: no gain)
   bool no_fused_prolongation = false;   // GFSHIP_NO_FUSED_PROLONGATION=1: prolongate_kernel, then the copy
   bool no_fused_mpi = false;      // GFSHIP_NO_FUSED_MPI=1: face-value arrays on boxes with MPI sides
   unsigned long long n_lattice_cycles = 0, n_fused_mpi = 0;   // gfship_domain_path_counts

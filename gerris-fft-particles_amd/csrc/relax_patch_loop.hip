@@ -48,6 +48,20 @@ namespace gfship {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+// the tile's share of the arming of the other granule set (all threads of the workgroup; plain
+// stores: the set is read by a later launch)
+__device__ __forceinline__ void patch_arm_other_set (const SkewLoopArgs & A, int tile, int tid, int nt)
+{
+  if (A.arm_pairs == 0) return;
+  typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+  const unsigned long long W = A.arm_cum[A.ntj*A.ntj];
+  const unsigned long long lo = A.arm_pairs*A.arm_cum[tile]/W, hi = A.arm_pairs*A.arm_cum[tile + 1]/W;
+  ull2 * const p = (ull2 *) A.arm;
+  const ull2 ones = { ~0ull, ~0ull };
+  for (unsigned long long i = lo + tid; i < hi; i += nt)
+    __builtin_nontemporal_store (ones, p + i);
+}
+
 __device__ __forceinline__ unsigned patch_claim_tile (const SkewLoopArgs & A)
 {
   return A.order[atomicAdd (A.ticket, 1u) + 1u]   /* the ticket is armed with the granules: all ones */;
@@ -106,6 +120,7 @@ relax_patch_loop_kernel (SkewLoopArgs A)
   __syncthreads ();
   const int tile = s_tile;
   const int P = tile % ntj, Q = tile / ntj;
+  patch_arm_other_set (A, tile, tid0, blockDim.x);
   // periodic neighbours of the tile
   const int tJm = (P > 0 ? P - 1 : ntj - 1) + ntj*Q, tJp = (P + 1 < ntj ? P + 1 : 0) + ntj*Q;
   const int tKm = P + ntj*(Q > 0 ? Q - 1 : ntj - 1), tKp = P + ntj*(Q + 1 < ntj ? Q + 1 : 0);
@@ -487,6 +502,7 @@ relax_ring_loop_kernel (SkewLoopArgs A)
   __syncthreads ();
   const int tile = s_tile;
   const int P = tile % ntj, Q = tile / ntj;
+  patch_arm_other_set (A, tile, tid0, blockDim.x);
   // periodic neighbours of the tile
   const int tJm = (P > 0 ? P - 1 : ntj - 1) + ntj*Q, tJp = (P + 1 < ntj ? P + 1 : 0) + ntj*Q;
   const int tKm = P + ntj*(Q > 0 ? Q - 1 : ntj - 1), tKp = P + ntj*(Q + 1 < ntj ? Q + 1 : 0);

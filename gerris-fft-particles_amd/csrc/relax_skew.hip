@@ -404,6 +404,7 @@ void skew_free (gfship_domain * dom)
     if (S.ds) (void) hipFree (S.ds);
     if (S.hb) (void) hipFree (S.hb);
     if (S.hbf) (void) hipFree (S.hbf);
+    if (S.arm_cum) (void) hipFree (S.arm_cum);
     if (S.stats_loop) (void) hipFree (S.stats_loop);
     if (S.ctl) (void) hipFree (S.ctl);
     if (S.stats) (void) hipFree (S.stats);
@@ -667,6 +668,7 @@ int skew_check_error (gfship_domain * dom)
 	 arrived), but the domain keeps working -- from now on with one launch per sweep, whose
 	 tiles only ever wait on tiles claimed before them (no residency assumption) */
       *skew_err_word (dom, l) = 0;
+      dom->skew[l].armed[0] = dom->skew[l].armed[1] = 0;
       dom->no_fused_loop = true;
       set_error ("relax_skew_kernel: a hand-off wait timed out on level %d (CUs held by another "
 		 "process or stream?); this solve failed, the domain falls back to one launch "

@@ -83,6 +83,11 @@ struct SkewLoopArgs {
   const unsigned short * xorder;   // [8][per_xcd] tiles of each block, anti-diagonal order
   unsigned * xticket;              // [8] ticket counters (zeroed before the launch)
   int per_xcd;                     // 0: placement by the single ticket counter
+  // arming of the other granule set (relax_patch_loop.hip): arm_pairs 16-byte pairs from `arm',
+  // shared between the tiles by arm_cum[tile] .. arm_cum[tile + 1] of arm_cum[ntiles]
+  u64 * arm;
+  unsigned long long arm_pairs;
+  const unsigned * arm_cum;
 };
 
 typedef __attribute__((address_space(1))) u64 gu64;

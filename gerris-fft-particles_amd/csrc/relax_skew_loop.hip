@@ -795,18 +795,44 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   long hstride = (long) SK_HROWS (L.n)*SK_T;
   long hb_words = (long) ntiles*hstride;
   long hb_sweep = 4*hb_words;
-  /* 8 words in front of the granules: the ticket counter, armed by the same fill (it then counts
-     from all ones: the claims add one) */
+  /* 8 words in front of the granules: the ticket counter, armed with them (it then counts from all
+     ones: the claims add one).  Two sets of granules used in turn.  With GFSHIP_KERNEL_ARMING=1 the
+     2 x 2 loop kernels arm the other set for the next loop of this level themselves, while their
+     tiles wait for their first hand-off -- the fill before the launch (148 MB, 37 us at 256^3)
+     disappears, but measured on the same box the loop gets slower by about as much (the arming
+     stores delay the hand-offs of the pipeline's fill phase): off by default. */
   const size_t hdr = 8;
+  const size_t set_words = (size_t) SK_MAXF*hb_sweep + hdr;
   if (!S->hbf) {
-    GFSHIP_HIP (hipMalloc ((void **) &S->hbf, ((size_t) SK_MAXF*hb_sweep + hdr)*sizeof (u64)));
+    GFSHIP_HIP (hipMalloc ((void **) &S->hbf, 2*set_words*sizeof (u64)));
+    S->armed[0] = S->armed[1] = 0;
+    S->cur_set = 0;
   }
-  /* a single sweep only uses the two hand-off arrays of its granule set.  (Arming the granules on a
-     side stream, with two sets used in turn, was tried: no gain, the stores compete for HBM.) */
-  /* (the snapshots of the last sweep are neither written nor read: its two hand-off arrays end the
-     armed range) */
-  GFSHIP_HIP (hipMemsetAsync (S->hbf, 0xFF, (hdr + (size_t) (nrelax - 1)*hb_sweep + (size_t) 2*hb_words)*
-			      sizeof (u64), dom->stream));
+  /* a single sweep only uses the two hand-off arrays of its granule set; the snapshots of the last
+     sweep are neither written nor read: its two hand-off arrays end the armed range */
+  const size_t need = hdr + (size_t) (nrelax - 1)*hb_sweep + (size_t) 2*hb_words;
+  const int set = S->cur_set;
+  u64 * const base = (u64 *) S->hbf + (size_t) set*set_words;
+  u64 * const other = (u64 *) S->hbf + (size_t) (set ^ 1)*set_words;
+  if (S->armed[set] < need)
+    GFSHIP_HIP (hipMemsetAsync (base, 0xFF, need*sizeof (u64), dom->stream));
+  const bool arms = patch_level (dom, level) && !dom->no_kernel_arming;
+  if (arms && !S->arm_cum) {
+    /* tile (P, Q) starts about P + Q hops after the first: its share of the arming grows with that
+       slack, the tiles of the first diagonals get none */
+    std::vector<unsigned> cum (ntiles + 1, 0);
+    for (int t = 0; t < ntiles; t++) {
+      const int w = t % S->ntj + t / S->ntj - 3;
+      cum[t + 1] = cum[t] + (w > 0 ? w : 0);
+    }
+    if (cum[ntiles] == 0)
+      for (int t = 0; t < ntiles; t++) cum[t + 1] = t + 1;
+    GFSHIP_HIP (hipMalloc ((void **) &S->arm_cum, (ntiles + 1)*sizeof (unsigned)));
+    GFSHIP_HIP (hipMemcpy (S->arm_cum, cum.data (), (ntiles + 1)*sizeof (unsigned), hipMemcpyHostToDevice));
+  }
+  S->armed[set] = 0;
+  S->armed[set ^ 1] = arms ? need : 0;
+  S->cur_set = set ^ 1;
   SkewLoopArgs A;
   A.L = L; A.ntj = S->ntj; A.RT = S->RT; A.nsweeps = (int) nrelax;
   A.mirror = nrelax == 1;
@@ -823,7 +849,8 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   }
   A.us = S->us; A.rs = S->rs; A.ds = has_dia ? S->ds : nullptr;
   A.un = u_nat;
-  A.hb = (u64 *) S->hbf + hdr; A.hb_sweep = hb_sweep; A.hb_words = hb_words;
+  A.hb = base + hdr; A.hb_sweep = hb_sweep; A.hb_words = hb_words;
+  A.arm = other; A.arm_pairs = arms ? need/2 : 0; A.arm_cum = S->arm_cum;
   A.order = S->order;
   A.xorder = S->xorder;
   A.xticket = (unsigned *) S->ctl + 6;
@@ -832,7 +859,7 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
     A.per_xcd = ntiles/8;
     GFSHIP_HIP (hipMemsetAsync ((unsigned *) S->ctl + 6, 0, 8*sizeof (unsigned), dom->stream));
   }
-  A.ticket = (unsigned *) S->hbf;
+  A.ticket = (unsigned *) base;
   A.err = (unsigned *) (dom->h_pinned + 32) + level;     /* skew_err_word, relax_skew.hip */
   A.dummy = (const u64 *) S->ctl + 2;
   A.stats = nullptr;
