@@ -56,6 +56,7 @@ struct SkewPlan {
   // the sets are used in turn: a loop kernel of relax_patch_loop.hip arms the OTHER set for the next
   // loop of the level while its tiles wait for their first hand-off (armed = granules armed from
   // the start of the set, 0 = to be armed by a fill before the launch)
+  bool rs_ready = false;          // the skewed rhs already holds the residual of this cycle (launch_restrict_pack)
   int cur_set = 0;
   size_t armed[2] = { 0, 0 };
   unsigned * arm_cum = nullptr;   // share of each tile in that arming (cumulative weights)
@@ -111,6 +112,7 @@ struct gfship_domain {
   unsigned * lat_bar = nullptr;
   size_t lat_res_doubles = 0, lat_xch_doubles = 0;
   double * gfv_send[6] = {}, * gfv_recv[6] = {};   // states beyond the MPI sides of the tiled Godunov kernels
+  bool no_fused_restriction = false;    // GFSHIP_NO_FUSED_RESTRICTION=1: restrict_kernel, then the copy of the rhs
   bool no_kernel_arming = true;         // GFSHIP_KERNEL_ARMING=1: the loop kernels arm the other granule set (measured: no gain)
   bool no_fused_prolongation = false;   // GFSHIP_NO_FUSED_PROLONGATION=1: prolongate_kernel, then the copy
   bool no_fused_mpi = false;      // GFSHIP_NO_FUSED_MPI=1: face-value arrays on boxes with MPI sides
@@ -283,6 +285,12 @@ inline bool patch_level (const gfship_domain * dom, int level) { return dom->pat
 int  patch_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u, const double * rhs,
 		 const double * dia, const double * coarse = nullptr);
 int  patch_unpack (gfship_domain * dom, int level, SkewPlan * S, double * u, double * add_into);
+int  patch_restrict_pack (gfship_domain * dom, int level, SkewPlan * S, const double * res,
+			  double * res_coarse, SkewPlan * Sc, unsigned dimension);
+// restriction of the residual of `level' onto level - 1 together with the copy of the residual into
+// the skewed layout of the relax loop of `level' (and of level - 1 where that is a 2 x 2 level too)
+int  launch_restrict_pack (gfship_domain * dom, unsigned dimension, int level, Field * res,
+			   bool coarse_fused);
 void skew_dump_stats (gfship_domain * dom, int level);
 int  skew_time_sweeps (gfship_domain * dom, int level, Field * u, const double * rhs,
 		       const double * dia, bool dia_zero, int reps, double * ms_per_sweep);

@@ -356,8 +356,16 @@ static int poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
        all-gather instead of one halo exchange per sweep and level (lattice_cycle_kernel) */
     const int ltop = ctop >= 0 ? -1 : lattice_cycle_top (dom, (int) minlevel, D);
     /* compute residual on non-leafs cells (get_from_below, post-order: finest parents first) */
-    for (int l = L - 1; l >= (ctop >= 0 ? ctop + 1 : ltop >= 0 ? ltop : 0); l--)
-      TRY (launch_restrict (dom, p->dimension, l, S->lev[l], S->lev[l + 1]));
+    for (int l = L - 1; l >= (ctop >= 0 ? ctop + 1 : ltop >= 0 ? ltop : 0); l--) {
+      /* where level l + 1 runs its relax loop on the 2 x 2 kernels the residual is copied into their
+	 layout by the same pass that restricts it (and so is the restricted one, where level l does) */
+      if (!dom->no_fused_restriction && !dom->skew[l + 1].rs_ready &&
+	  prolongation_fused (dom, p->dimension, l + 1, nrl[l + 1]))
+	TRY (launch_restrict_pack (dom, p->dimension, l + 1, S,
+				   l > (int) minlevel && prolongation_fused (dom, p->dimension, l, nrl[l])));
+      else
+	TRY (launch_restrict (dom, p->dimension, l, S->lev[l], S->lev[l + 1]));
+    }
     unsigned first = minlevel;
     if (ltop >= 0) {
       TRY (launch_lattice_cycle (dom, p->dimension, p->omega, (int) minlevel, ltop, nrl, DP, U, S));
@@ -397,6 +405,8 @@ static int poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
     TRY (launch_residual (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L]));
 #undef TRY
  done:
+  for (int l = 0; l <= L; l++)
+    dom->skew[l].rs_ready = false;
   return r;
 }
 

@@ -997,6 +997,76 @@ patch_pack_kernel (PatchPackArgs A)
   }
 }
 
+// The residual of a level on its way down the V-cycle: get_from_below (src/poisson.c:1044-1068 =
+// restrict_kernel) onto the next coarser level AND the copy into the skewed layout of the level's
+// own relax loop, from one read of the natural array (the 2 x 2 lines of a lane and two consecutive
+// cells along I are the eight children of a coarse cell).  The coarse values go to the natural array
+// of the coarse level and, where that level runs on these kernels too, into its skewed rhs.
+struct PatchRestrictArgs {
+  Layout L, Lc;
+  int ntj, RT;
+  const double * src;      // natural residual of the fine level
+  double * dst;            // skewed rhs of the fine level
+  double * cnat;           // natural residual of the coarse level
+  double * cskew;          // skewed rhs of the coarse level, or nullptr
+  int cntj, cRT;
+  unsigned dimension;
+};
+
+__global__ void __launch_bounds__(256)
+patch_restrict_pack_kernel (PatchRestrictArgs A)
+{
+  __shared__ double buf[32][PP_SPAN + 2];
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.z, PB = blockIdx.y, r0 = blockIdx.x*PP_ROWS;
+  const int P = tile % A.ntj, Q = tile / A.ntj;
+  const int n = A.L.n;
+  const long tbase = (long) tile*(A.RT + 2*SK_FP)*SK_NL + SK_FP*SK_NL;
+  const int I0 = r0 - 7 - PB;
+  for (int e = tid; e < 32*(PP_SPAN + 1); e += 256) {
+    const int line = e / (PP_SPAN + 1), di = e % (PP_SPAN + 1);
+    const int a = line & 15, db = line >> 4;
+    const int I = I0 + di;
+    if (I >= 0 && I < n) {
+      const int j = n - (SK_T*P + a), k = n - (SK_T*Q + 2*PB + db);
+      buf[line][di] = A.src[A.L.idx (I + 1, j, k)];
+    }
+  }
+  __syncthreads ();
+  for (int e = tid; e < PP_ROWS*32; e += 256) {
+    const int row = e / 32, col = e % 32;
+    const int PA = col >> 2, p = col & 3;
+    const int a = 2*PA + (p & 1), db = p >> 1;
+    const int rho = r0 + row;
+    const int I = rho - PA - PB;
+    if (I >= 0 && I < n)
+      A.dst[tbase + (long) rho*SK_NL + 128*(p >> 1) + 2*(PA + 8*PB) + (p & 1)] = buf[a + 16*db][I - I0];
+  }
+  // the coarse cells whose first child (I = 2 m) sits in one of this block's rows
+  if (tid < 8*PP_ROWS) {
+    const int PA = tid & 7, row = tid >> 3;
+    const int I = r0 + row - PA - PB;
+    if (I >= 0 && I < n && !(I & 1)) {
+      const int di = I - I0;
+      double val = 0.;
+      // children in child-id order: bit 0 -> +x, bit 1 -> -y (da = 1), bit 2 -> -z (db = 1)
+#pragma unroll
+      for (int id = 0; id < 8; id++)
+	val += buf[2*PA + ((id >> 1) & 1) + 16*(id >> 2)][di + (id & 1)];
+      const double v = A.dimension == 2 ? val : val/2.;
+      const int m = I >> 1;
+      const int pj = (n - SK_T*P - 2*PA) >> 1, pk = (n - SK_T*Q - 2*PB) >> 1;
+      A.cnat[A.Lc.idx (m + 1, pj, pk)] = v;
+      if (A.cskew) {
+	const int ca = 8*(P & 1) + PA, cb = 8*(Q & 1) + PB;
+	const long ctile = (P >> 1) + (long) A.cntj*(Q >> 1);
+	A.cskew[ctile*(A.cRT + 2*SK_FP)*SK_NL + SK_FP*SK_NL +
+		(long) (m + (ca >> 1) + (cb >> 1))*SK_NL + 128*(cb & 1) + 2*((ca >> 1) + 8*(cb >> 1)) + (ca & 1)] = v;
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 patch_unpack_kernel (PatchPackArgs A)
 {
@@ -1064,11 +1134,29 @@ int patch_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u, 
   A.L = dom->lay[level]; A.ntj = S->ntj; A.RT = S->RT;
   A.narr = 0;
   A.src[A.narr] = u;   A.dst[A.narr++] = S->us;
-  A.src[A.narr] = rhs; A.dst[A.narr++] = S->rs;
+  if (rhs) { A.src[A.narr] = rhs; A.dst[A.narr++] = S->rs; }     /* nullptr: already there (patch_restrict_pack) */
   if (dia) { A.src[A.narr] = dia; A.dst[A.narr++] = S->ds; }
   const int rows = A.L.n + PK_SKEW + 1;
   dim3 grid ((rows + PP_ROWS - 1)/PP_ROWS, 8, S->ntj*S->ntj);
   hipLaunchKernelGGL (patch_pack_kernel, grid, dim3 (256), 0, dom->stream, A);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+int patch_restrict_pack (gfship_domain * dom, int level, SkewPlan * S, const double * res,
+			 double * res_coarse, SkewPlan * Sc, unsigned dimension)
+{
+  PatchRestrictArgs A;
+  A.L = dom->lay[level]; A.Lc = dom->lay[level - 1];
+  A.ntj = S->ntj; A.RT = S->RT;
+  A.src = res; A.dst = S->rs;
+  A.cnat = res_coarse;
+  A.cskew = Sc ? Sc->rs : nullptr;
+  A.cntj = Sc ? Sc->ntj : 0; A.cRT = Sc ? Sc->RT : 0;
+  A.dimension = dimension;
+  const int rows = A.L.n + PK_SKEW + 1;
+  dim3 grid ((rows + PP_ROWS - 1)/PP_ROWS, 8, S->ntj*S->ntj);
+  hipLaunchKernelGGL (patch_restrict_pack_kernel, grid, dim3 (256), 0, dom->stream, A);
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
 }

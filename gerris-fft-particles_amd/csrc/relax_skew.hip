@@ -483,27 +483,14 @@ static int skew_sweep (gfship_domain * dom, int level, SkewPlan * S, double * u_
 
 // the whole relax_loop (src/poisson.c:1070-1089) of one level in the skewed layout; for
 // nrelax = 1 and bc = false it is a single gfs_relax sweep
-bool prolongation_fused (gfship_domain * dom, unsigned dimension, int level, unsigned nrelax)
+// Once per level: a trial run of the fused loop on zeros.  Its tiles wait on each other, so all of
+// them must really be resident at the same time; the occupancy query says they are, but if the
+// device does not deliver (CUs in use by someone else ...) the bounded waits time out and report it
+// -- then this domain keeps to one launch per sweep.
+static int skew_loop_trial (gfship_domain * dom, int level, SkewPlan * S, unsigned nrelax, bool bc)
 {
-  if (dom->no_fused_prolongation || dom->weighted || level < 1) return false;
-  if (dom->relax_mode != GFSHIP_RELAX_EXACT || dimension != 3 || dom->force_hyperplane) return false;
-  if (dom->has_external && dom->overlap && nrelax > 1) return false;
-  return skew_supported (dom, level) && patch_level (dom, level);
-}
-
-int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * ubc,
-			    const double * rhs, const double * dia, bool dia_zero,
-			    unsigned nrelax, bool bc, double * correct_into, const double * prolong_from)
-{
-  SkewPlan * S;
   int r;
-  if ((r = skew_plan (dom, level, &S))) return r;
-  double * u = dp->lev[level];
   if (!dom->no_fused_loop && !S->loop_checked && skew_loop_supported (dom, level, nrelax, bc)) {
-    /* Once per level: a trial run of the fused loop on zeros.  Its tiles wait on each other, so
-       all of them must really be resident at the same time; the occupancy query says they are,
-       but if the device does not deliver (CUs in use by someone else ...) the bounded waits
-       time out and report it -- then this domain keeps to one launch per sweep. */
     S->loop_checked = true;
     const Layout & L = dom->lay[level];
     size_t doubles = (size_t) S->ntj*S->ntj*(S->RT + 2*SK_FP)*SK_NL;
@@ -522,14 +509,37 @@ int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * 
       *skew_err_word (dom, level) = 0;
     }
   }
+  return GFSHIP_OK;
+}
+
+bool prolongation_fused (gfship_domain * dom, unsigned dimension, int level, unsigned nrelax)
+{
+  if (dom->no_fused_prolongation || dom->weighted || level < 1) return false;
+  if (dom->relax_mode != GFSHIP_RELAX_EXACT || dimension != 3 || dom->force_hyperplane) return false;
+  if (dom->has_external && dom->overlap && nrelax > 1) return false;
+  return skew_supported (dom, level) && patch_level (dom, level);
+}
+
+int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * ubc,
+			    const double * rhs, const double * dia, bool dia_zero,
+			    unsigned nrelax, bool bc, double * correct_into, const double * prolong_from)
+{
+  SkewPlan * S;
+  int r;
+  if ((r = skew_plan (dom, level, &S))) return r;
+  double * u = dp->lev[level];
+  if ((r = skew_loop_trial (dom, level, S, nrelax, bc))) return r;
   /* get_from_above fused into the copy into the skewed layout: the natural array gets the cells
      along the box sides only (what the BC application reads), then the BC, then the loop */
   const bool fusedp = prolong_from != nullptr && bc && patch_level (dom, level);
+  /* the residual was copied into the skewed layout when it was restricted (launch_restrict_pack) */
+  const double * rhs_pack = S->rs_ready && patch_level (dom, level) ? nullptr : rhs;
+  S->rs_ready = false;
   if (prolong_from && !fusedp)
     if ((r = launch_prolongate (dom, level - 1, prolong_from, u))) return r;
-  if (fusedp && (r = skew_pack (dom, level, S, u, rhs, dia_zero ? nullptr : dia, prolong_from))) return r;
+  if (fusedp && (r = skew_pack (dom, level, S, u, rhs_pack, dia_zero ? nullptr : dia, prolong_from))) return r;
   if (bc && (r = launch_bc (dom, ubc, dp, level, 1))) return r;
-  if (!fusedp && (r = skew_pack (dom, level, S, u, rhs, dia_zero ? nullptr : dia))) return r;
+  if (!fusedp && (r = skew_pack (dom, level, S, u, rhs_pack, dia_zero ? nullptr : dia))) return r;
   if (!dom->no_fused_loop && skew_loop_supported (dom, level, nrelax, bc)) {
     /* the sweeps of the loop pipelined in one launch (relax_skew_loop.hip) */
     if ((r = skew_loop_run (dom, level, S, u, !dia_zero, nrelax, nullptr, ubc))) return r;
@@ -540,6 +550,24 @@ int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * 
     if (bc && q + 1 < nrelax && (r = launch_bc (dom, ubc, dp, level, 1))) return r;
   }
   return skew_unpack (dom, level, S, u, correct_into);
+}
+
+int launch_restrict_pack (gfship_domain * dom, unsigned dimension, int level, Field * res, bool coarse_fused)
+{
+  SkewPlan * S, * Sc = nullptr;
+  int r;
+  if ((r = skew_plan (dom, level, &S))) return r;
+  /* the trial run of the fused loop overwrites the skewed arrays: before they are filled */
+  if ((r = skew_loop_trial (dom, level, S, 4, true))) return r;
+  if (coarse_fused) {
+    if ((r = skew_plan (dom, level - 1, &Sc))) return r;
+    if ((r = skew_loop_trial (dom, level - 1, Sc, 4, true))) return r;
+  }
+  res->zero[level - 1] = false;
+  if ((r = patch_restrict_pack (dom, level, S, res->lev[level], res->lev[level - 1], Sc, dimension))) return r;
+  S->rs_ready = true;
+  if (Sc) Sc->rs_ready = true;
+  return GFSHIP_OK;
 }
 
 // debug: print per-tile timing of the last sweep of `level` (GFSHIP_SKEW_STATS=1)
