@@ -112,6 +112,7 @@ int gfship_domain_create (gfship_domain ** out, int dim, int depth, const int si
   dom->no_fused_mpi = getenv ("GFSHIP_NO_FUSED_MPI") != nullptr;
   dom->no_fused_prolongation = getenv ("GFSHIP_NO_FUSED_PROLONGATION") != nullptr;
   dom->no_kernel_arming = getenv ("GFSHIP_KERNEL_ARMING") == nullptr;
+  dom->no_xcd_scope = getenv ("GFSHIP_XCD_SCOPE") == nullptr;
   dom->no_fused_restriction = getenv ("GFSHIP_NO_FUSED_RESTRICTION") != nullptr;
   { const char * w = getenv ("GFSHIP_XCD_PLACE"); dom->xcd_place = w && w[0] == '1'; }
   { const char * w = getenv ("GFSHIP_WAVE_LOOP"); dom->wave_loop = w && w[0] == '1'; }

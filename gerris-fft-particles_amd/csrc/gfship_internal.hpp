@@ -112,6 +112,7 @@ struct gfship_domain {
   unsigned * lat_bar = nullptr;
   size_t lat_res_doubles = 0, lat_xch_doubles = 0;
   double * gfv_send[6] = {}, * gfv_recv[6] = {};   // states beyond the MPI sides of the tiled Godunov kernels
+  bool no_xcd_scope = true;             // GFSHIP_XCD_SCOPE=1: XCD blocks of tiles + narrower-scope stores towards same-XCD consumers (measured: no gain)
   bool no_fused_restriction = false;    // GFSHIP_NO_FUSED_RESTRICTION=1: restrict_kernel, then the copy of the rhs
   bool no_kernel_arming = true;         // GFSHIP_KERNEL_ARMING=1: the loop kernels arm the other granule set (measured: no gain)
   bool no_fused_prolongation = false;   // GFSHIP_NO_FUSED_PROLONGATION=1: prolongate_kernel, then the copy

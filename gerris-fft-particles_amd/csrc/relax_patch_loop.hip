@@ -62,9 +62,49 @@ __device__ __forceinline__ void patch_arm_other_set (const SkewLoopArgs & A, int
     __builtin_nontemporal_store (ones, p + i);
 }
 
+__device__ __forceinline__ unsigned patch_xcc_id ()
+{
+  unsigned v;
+  asm volatile ("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s" (v));
+  return v & 7;
+}
+
+// The tickets are armed with the granules: all ones, so the claims add one.  With per_xcd != 0 (all
+// tiles resident) the tiles are split into 8 blocks and a workgroup claims a tile of the block of
+// the XCD it runs on (any other block once its own is exhausted), and publishes the XCD it really
+// runs on: the producer of a granule stream whose consumer tile runs on the same XCD writes it
+// with plain stores -- they stop in the L2 the consumer's agent-scope polls hit (0.29 us on an idle
+// machine, tools/lab/xcd_lab.hip) instead of going through to memory, whose latency under the load
+// of 256 streaming tiles is most of what a hand-off costs.
 __device__ __forceinline__ unsigned patch_claim_tile (const SkewLoopArgs & A)
 {
-  return A.order[atomicAdd (A.ticket, 1u) + 1u]   /* the ticket is armed with the granules: all ones */;
+  if (A.per_xcd == 0)
+    return A.order[atomicAdd (A.ticket, 1u) + 1u];
+  const unsigned x = patch_xcc_id ();
+  unsigned tile = 0;
+  for (unsigned q = 0; q < 8; q++) {
+    const unsigned xx = (x + q) & 7;
+    const unsigned k = atomicAdd (&A.xticket[xx], 1u) + 1u;
+    if (k < (unsigned) A.per_xcd) {
+      tile = A.xorder[xx*A.per_xcd + k];
+      break;
+    }
+  }
+  __hip_atomic_store (&A.tile_xcd[tile], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return tile;
+}
+
+// does tile `t' run on the XCD of this workgroup?  (waits for the claim of t: all tiles are resident)
+__device__ __forceinline__ bool patch_same_xcd (const SkewLoopArgs & A, int t)
+{
+  if (A.per_xcd == 0) return false;
+  const unsigned x = patch_xcc_id ();
+  for (unsigned spins = 0; spins < (1u << 20); spins++) {
+    const unsigned v = __hip_atomic_load (&A.tile_xcd[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v != ~0u) return v == x;
+    __builtin_amdgcn_s_sleep (4);
+  }
+  return false;       /* never claimed: the hand-off waits will report it */
 }
 
 // one cell: relax, src/poisson.c:507-530, unit weights, d = 0..5 = right, left, top, bottom, front, back.
@@ -700,6 +740,8 @@ relax_ring_loop_kernel (SkewLoopArgs A)
 	sX = (m + 1) + XS*1; sLag = mh;
 	if (A.mirror && Q == 0) pNat = A.un + A.L.idx (0, jm, n) - sLag;
       }
+      // the consumer tile of the stream runs on this XCD: plain stores (they stay in the common L2)
+      const bool sNear = A.near_mode != 0 && patch_same_xcd (A, g == 0 ? tJp : g == 1 ? tKp : g == 2 ? tJm : tKm);
       // ... and every lane writes the row of the skewed copy that the compute lane of the same number
       // produced in the previous step (its four new values are in X): the stores of the rows stay out
       // of the compute wave's in-order memory queue, whose prefetched loads would wait behind them
@@ -720,7 +762,14 @@ relax_ring_loop_kernel (SkewLoopArgs A)
 	  if (I >= 0 && I < n) {
 	    const double v = Xb[sX];
 	    if (pNat) pNat[t] = v;
-	    if (sOn) store_sc1 (pS, (u64) __double_as_longlong (v));
+	    if (sOn) {
+	      if (sNear) {
+		if (A.near_mode == 1) *(volatile u64 *) pS = (u64) __double_as_longlong (v);
+		else __hip_atomic_store ((gu64 *) pS, (u64) __double_as_longlong (v), __ATOMIC_RELAXED,
+					 __HIP_MEMORY_SCOPE_WORKGROUP);
+	      }
+	      else store_sc1 (pS, (u64) __double_as_longlong (v));
+	    }
 	  }
 	  pS += SK_T;
 	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -88,6 +88,9 @@ struct SkewLoopArgs {
   u64 * arm;
   unsigned long long arm_pairs;
   const unsigned * arm_cum;
+  // XCD of the workgroup that claimed each tile (armed all ones with the granules; relax_patch_loop.hip)
+  unsigned * tile_xcd;
+  int near_mode;           // stores towards a consumer on the same XCD: 0 agent scope like the others, 1 plain, 2 workgroup scope
 };
 
 typedef __attribute__((address_space(1))) u64 gu64;

@@ -801,8 +801,9 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
      tiles wait for their first hand-off -- the fill before the launch (148 MB, 37 us at 256^3)
      disappears, but measured on the same box the loop gets slower by about as much (the arming
      stores delay the hand-offs of the pipeline's fill phase): off by default. */
-  const size_t hdr = 8;
-  const size_t set_words = (size_t) SK_MAXF*hb_sweep + hdr;
+  /* header: [0] ticket, [1..4] the 8 tickets of the XCD blocks, [8..] the XCD of each tile (32 bits each) */
+  const size_t hdr = 8 + ((size_t) ntiles + 1)/2 + 8;
+  const size_t set_words = (size_t) SK_MAXF*hb_sweep + hdr + (hdr & 1);
   if (!S->hbf) {
     GFSHIP_HIP (hipMalloc ((void **) &S->hbf, 2*set_words*sizeof (u64)));
     S->armed[0] = S->armed[1] = 0;
@@ -810,7 +811,7 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   }
   /* a single sweep only uses the two hand-off arrays of its granule set; the snapshots of the last
      sweep are neither written nor read: its two hand-off arrays end the armed range */
-  const size_t need = hdr + (size_t) (nrelax - 1)*hb_sweep + (size_t) 2*hb_words;
+  const size_t need = hdr + (hdr & 1) + (size_t) (nrelax - 1)*hb_sweep + (size_t) 2*hb_words;
   const int set = S->cur_set;
   u64 * const base = (u64 *) S->hbf + (size_t) set*set_words;
   u64 * const other = (u64 *) S->hbf + (size_t) (set ^ 1)*set_words;
@@ -849,13 +850,28 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   }
   A.us = S->us; A.rs = S->rs; A.ds = has_dia ? S->ds : nullptr;
   A.un = u_nat;
-  A.hb = base + hdr; A.hb_sweep = hb_sweep; A.hb_words = hb_words;
+  A.hb = base + hdr + (hdr & 1); A.hb_sweep = hb_sweep; A.hb_words = hb_words;
+  A.tile_xcd = (unsigned *) (base + 8);
   A.arm = other; A.arm_pairs = arms ? need/2 : 0; A.arm_cum = S->arm_cum;
   A.order = S->order;
   A.xorder = S->xorder;
   A.xticket = (unsigned *) S->ctl + 6;
   A.per_xcd = 0;
-  if (dom->xcd_place && S->xorder && ntiles >= 8 && skew_loop_resident (dom, level) >= ntiles) {
+  A.near_mode = 0;
+  if (patch_level (dom, level)) {
+    /* the 2 x 2 kernels, GFSHIP_XCD_SCOPE=1: XCD blocks + narrower-scope stores towards consumers on
+       the same XCD (tickets in the armed header).  Measured at 256^3 on one box: blocks alone 0.51-0.52
+       ms per loop against 0.505 without; + workgroup-scope stores (GFSHIP_XCD_NEAR_MODE=2) 0.485-0.52;
+       + plain stores (=1) 1.04 (they linger in the L1's write path): the hand-off latency is not
+       the store's way to memory.  Off by default. */
+    if (!dom->no_xcd_scope && S->xorder && ntiles >= 8 && ntiles % 8 == 0 &&
+	skew_loop_resident (dom, level) >= ntiles) {
+      A.per_xcd = ntiles/8;
+      A.xticket = (unsigned *) (base + 1);
+      { const char * e = getenv ("GFSHIP_XCD_NEAR_MODE"); A.near_mode = e ? atoi (e) : 2; }
+    }
+  }
+  else if (dom->xcd_place && S->xorder && ntiles >= 8 && skew_loop_resident (dom, level) >= ntiles) {
     A.per_xcd = ntiles/8;
     GFSHIP_HIP (hipMemsetAsync ((unsigned *) S->ctl + 6, 0, 8*sizeof (unsigned), dom->stream));
   }
