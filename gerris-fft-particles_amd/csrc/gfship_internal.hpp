@@ -112,6 +112,7 @@ struct gfship_domain {
   unsigned * lat_bar = nullptr;
   size_t lat_res_doubles = 0, lat_xch_doubles = 0;
   double * gfv_send[6] = {}, * gfv_recv[6] = {};   // states beyond the MPI sides of the tiled Godunov kernels
+  double src[3] = { 0., 0., 0. };       // GfsSource {} U/V/W: constant intensities (gfship_sim_set_source)
   bool no_xcd_scope = true;             // GFSHIP_XCD_SCOPE=1: XCD blocks of tiles + narrower-scope stores towards same-XCD consumers (measured: no gain)
   bool no_fused_restriction = false;    // GFSHIP_NO_FUSED_RESTRICTION=1: restrict_kernel, then the copy of the rhs
   bool no_kernel_arming = true;         // GFSHIP_KERNEL_ARMING=1: the loop kernels arm the other granule set (measured: no gain)
@@ -237,12 +238,13 @@ int launch_centered_gradient (gfship_domain * dom, const double * p, double * co
 int launch_correct_centered (gfship_domain * dom, double * const u[3], double * const g[3], double dt);
 int launch_advected_face_values (gfship_domain * dom, const double * v, double * const u[3],
 				 double * const un[3], double dt, int use_centered, int gradient,
-				 double * const fv[6], int cmask, double visc = 0.);
+				 double * const fv[6], int cmask, double visc = 0., double gsrc = 0.);
 int launch_face_bc (gfship_domain * dom, Field * v, double * const fv[6], int cmask);
 int launch_predict_un (gfship_domain * dom, int cc, const double * uc, double * const fv[6],
 		       double * unc);
 int launch_flux_update (gfship_domain * dom, bool velocity, double * v, double * const un[3],
-			double * const fv[6], const double * gm, const double * gc, double dt);
+			double * const fv[6], const double * gm, const double * gc, double dt,
+			double gsrc = 0.);
 int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3],
 		const double visc[3], double * cfl2);
 int launch_coarse_init (gfship_domain * dom, Field * const * v, int nf);
@@ -261,7 +263,7 @@ int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * con
 			  double dt, int gradient);
 int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, double * out,
 			 double * const un[3], const double * gm, const double * gc, double dt,
-			 int gradient, double visc);
+			 int gradient, double visc, double gsrc = 0.);
 
 
 // relax_skew.hip

@@ -125,6 +125,7 @@ struct Run {
   std::vector<int> tracer_gradient;              // 0 gfs_center_gradient, 1 van Leer (default)
   Function * stream_function = nullptr;          // GfsVariableStreamFunction (2-D, GfsAdvection)
   std::vector<std::pair<std::string, Function *>> init;   // Init {} { var = f }
+  double source[3] = { 0., 0., 0. };    // GfsSource intensities on U, V, W
   std::vector<Variable> vars;
   std::vector<std::string> device_vars;   // variables of the file that live on the device (GfsVariableTurbulentViscosity)
   std::vector<std::unique_ptr<Event>> events;
@@ -563,6 +564,19 @@ void parse_object (Run & R, Reader & r)
       R.visc[c] = atof (t.text.c_str ());
       R.diff_set[c] = par;
     }
+  }
+  else if (cls == "Source") {
+    // GfsSource [{ event }] U|V|W intensity (src/source.c:405-446): a constant intensity on a velocity
+    // component
+    Event e;
+    if (r.peek (false) == '{') read_event_params (r, e);
+    std::string v = r.word (false);
+    int c = v == "U" ? 0 : v == "V" ? 1 : (v == "W" && R.dim == 3) ? 2 : -1;
+    if (c < 0) r.fail ("GfsSource is supported on the velocity components only (got `" + v + "')");
+    FunctionText t = r.function ();
+    if (t.block || !Reader::is_number (t.text))
+      r.fail ("only a constant intensity is supported");
+    R.source[c] += atof (t.text.c_str ());        /* several sources on a variable add up */
   }
   else if (cls == "VariableTracer") {
     std::string name = r.word (false);
@@ -1507,6 +1521,9 @@ int run (Run & R)
     }
   }
   for (int c = 0; c < R.dim; c++)
+    if (R.source[c] != 0.)
+      CHECK (gfship_sim_set_source (R.sim, c, R.source[c]));
+  for (int c = 0; c < R.dim; c++)
     if (R.visc[c] != 0.) {
       CHECK (gfship_sim_set_viscosity (R.sim, c, R.visc[c]));
       apply_multilevel (gfship_sim_diffusion_params (R.sim, c), R.diff_set[c]);
@@ -1519,8 +1536,8 @@ int run (Run & R)
     CHECK (gfship_particles_create (&ps->pl, R.sim, np, ps->pos.data (), ps->id.data ()));
     if (ps->particulate) {
       CHECK (gfship_particles_set_particulate (ps->pl, ps->vel.data (), ps->mass.data (), ps->volume.data ()));
-      /* gravity = the GfsSource objects on U, V, W: none can be declared here */
-      CHECK (gfship_particles_set_forces (ps->pl, (int) ps->forces.size (), ps->forces.data (), nullptr));
+      /* gravity of GfsForceBuoy = the GfsSource intensities on U, V, W (compute_buoyancy_force) */
+      CHECK (gfship_particles_set_forces (ps->pl, (int) ps->forces.size (), ps->forces.data (), R.source));
       for (size_t f = 0; f < ps->force_functions.size (); f++)
 	if (!ps->force_functions[f].empty ())
 	  CHECK (gfship_particles_set_force_coefficient (ps->pl, (int) f, ps->force_functions[f].c_str ()));

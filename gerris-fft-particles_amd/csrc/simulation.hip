@@ -97,7 +97,7 @@ int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, g
   s->cfl_ready = false;
   bool want_max = approximate;
   for (int c = 0; c < dom->dim; c++)
-    if (s->visc[c] != 0.) want_max = false;   /* the acceleration term needs the full kernel */
+    if (s->visc[c] != 0. || dom->src[c] != 0.) want_max = false;   /* the acceleration term needs the full kernel */
   TRY (launch_project_correct (dom, leaf (s, p), un, gp, approximate ? u : nullptr, dt, want_max));
   s->cfl_ready = want_max;
   TRY (bc_leaf_vector (s, g));
@@ -126,12 +126,14 @@ int face_values_set (gfship_sim * s, gfship_field v, double dt, int use_centered
   ptrs3 (s, s->un, un);
   ptrs6 (s, fv);
   /* v->sources: the implicit diffusion of a velocity component acts as MAC source */
-  double visc = 0.;
+  double visc = 0., gsrc = 0.;
   for (int c = 0; c < s->dom->dim; c++)
-    if (v == s->u[c])
+    if (v == s->u[c]) {
       visc = s->visc[c];
+      gsrc = s->dom->src[c];     /* ... and the intensity of a GfsSource on it */
+    }
   TRY (launch_advected_face_values (s->dom, leaf (s, v), u, un, dt, use_centered, gradient, fv, cmask,
-				    visc));
+				    visc, gsrc));
   TRY (launch_face_bc (s->dom, get_field (s->dom, v), fv, cmask));
   return GFSHIP_OK;
 }
@@ -150,21 +152,23 @@ int variable_sources (gfship_sim * s, gfship_field v, gfship_field sv, int gradi
     const int L = dom->depth;
     const double * gm = velocity ? leaf (s, gmac[c]) : nullptr;
     const double * gc = (velocity && g) ? leaf (s, g[c]) : nullptr;
-    double visc = 0.;
+    double visc = 0., gsrc = 0.;
     for (int q = 0; q < dom->dim; q++)
-      if (v == s->u[q])
+      if (v == s->u[q]) {
 	visc = s->visc[q];
+	gsrc = dom->src[q];
+      }
     dom->fields[sv].zero[L] = false;
     if (sv != v)      /* sv holds a copy of v (source_diffusion): out = sv */
       return launch_advect_fused (dom, velocity, leaf (s, v), leaf (s, sv), un, gm, gc, dt,
-				  gradient, visc);
+				  gradient, visc, gsrc);
     /* in place in the reference: here into a scratch leaf level, then the storage is swapped
        (every cell reads the old values of its neighbours) */
     if (s->adv_tmp < 0)
       s->adv_tmp = gfship_field_alloc (dom, -1);
     if (s->adv_tmp < 0) return s->adv_tmp;
     TRY (launch_advect_fused (dom, velocity, leaf (s, v), leaf (s, s->adv_tmp), un, gm, gc, dt,
-			      gradient, visc));
+			      gradient, visc, gsrc));
     std::swap (dom->fields[v].lev[L], dom->fields[s->adv_tmp].lev[L]);
     return GFSHIP_OK;
   }
@@ -172,7 +176,11 @@ int variable_sources (gfship_sim * s, gfship_field v, gfship_field sv, int gradi
   const double * gm = velocity ? leaf (s, gmac[c]) : nullptr;
   const double * gc = (velocity && g) ? leaf (s, g[c]) : nullptr;
   s->dom->fields[sv].zero[s->dom->depth] = false;
-  TRY (launch_flux_update (s->dom, velocity, leaf (s, sv), un, fv, gm, gc, dt));
+  double gsrc = 0.;
+  for (int q = 0; q < s->dom->dim; q++)
+    if (v == s->u[q])
+      gsrc = s->dom->src[q];
+  TRY (launch_flux_update (s->dom, velocity, leaf (s, sv), un, fv, gm, gc, dt, gsrc));
   return GFSHIP_OK;
 }
 
@@ -300,6 +308,15 @@ int gfship_sim_set_time (gfship_sim * s, double end, double dtmax)
 
 double gfship_sim_time (gfship_sim * s) { return s ? s->t : 0.; }
 unsigned gfship_sim_iter (gfship_sim * s) { return s ? s->i : 0; }
+
+int gfship_sim_set_source (gfship_sim * s, int c, double intensity)
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  GFSHIP_CHECK (c >= 0 && c < s->dom->dim, GFSHIP_EINVAL, "component %d out of range", c);
+  s->dom->src[c] = intensity;
+  s->cfl_ready = false;
+  return GFSHIP_OK;
+}
 
 int gfship_sim_set_viscosity (gfship_sim * s, int c, double nu)
 {

@@ -50,7 +50,7 @@ struct Ptr3  { double * p[3]; };
 struct CPtr3 { const double * p[3]; };
 struct Ptr6  { double * p[6]; };
 struct CPtr6 { const double * p[6]; };
-struct Visc3 { double d[3]; };
+struct Visc3 { double d[3]; double g[3]; };   // diffusion coefficients and GfsSource intensities of U, V, W
 
 // gfs_face_interpolated_value, src/fluid.c:2186-2198, same-level neighbour (x1 = 1.)
 __device__ __forceinline__ double face_interp (double v0, double v1)
@@ -356,7 +356,7 @@ template <int DIM>
 __global__ void __launch_bounds__(256)
 advected_face_values_kernel (Layout L, const double * __restrict__ v, CPtr3 u, CPtr3 un,
 			     double dt, int use_centered_velocity, int gradient, Ptr6 fv, int cmask,
-			     double visc)
+			     double visc, double gsrc)
 {
   CELL_PROLOGUE (L);
   const long off[3] = { 1, L.sy, L.sz };
@@ -390,6 +390,7 @@ advected_face_values_kernel (Layout L, const double * __restrict__ v, CPtr3 u, C
     double msrc = 0.;
     if (visc != 0.)
       msrc = 0. + source_diffusion_value<DIM> (v, c, off, visc, L.n);
+    msrc += gsrc;               /* the intensity of a GfsSource (source_value, src/source.c:398-403) */
     double src = dt*msrc/2.;
     double dv;
     if (DIM == 2)
@@ -511,7 +512,7 @@ __device__ __forceinline__ double face_flux (const Layout & L, int cf, long a, c
 template <int DIM, bool VELOCITY>
 __global__ void __launch_bounds__(256)
 flux_update_kernel (Layout L, double * __restrict__ v, CPtr3 un, CPtr6 fv,
-		    const double * __restrict__ gm, const double * __restrict__ gc, double dt)
+		    const double * __restrict__ gm, const double * __restrict__ gc, double dt, double gsrc)
 {
   CELL_PROLOGUE (L);
   const int n = L.n;
@@ -546,6 +547,11 @@ flux_update_kernel (Layout L, double * __restrict__ v, CPtr3 un, CPtr6 fv,
   val += acc/1.;
   if (gc)
     val -= gc[c]*dt;
+  if (gsrc != 0.) {             /* gfs_domain_variable_centered_sources, src/source.c:62-108 */
+    double sum = 0;
+    sum += gsrc;
+    val += dt*sum;
+  }
   v[c] = val;
 }
 
@@ -572,7 +578,7 @@ struct FacePair { double l, r; };   // f[2*d].v ("left state" of the + face) and
 template <int DIM, int D, bool CEN, bool VL, bool VS>
 __device__ __forceinline__ FacePair face_values_dir (const Layout & L, const double * __restrict__ v,
 						     const CPtr3 & u, const CPtr3 & un, int c,
-						     double dt, double visc)
+						     double dt, double visc, double gsrc)
 {
   const int use_centered_velocity = CEN, gradient = VL;
   // 32-bit cell indices (a level has far fewer than 2^31 doubles): the loads take a uniform base
@@ -602,6 +608,7 @@ __device__ __forceinline__ FacePair face_values_dir (const Layout & L, const dou
     const long off64[3] = { 1, L.sy, L.sz };
     msrc = 0. + source_diffusion_value<DIM> (v, c, off64, visc, L.n);
   }
+  msrc += gsrc;                 /* the intensity of a GfsSource on the variable */
   double src = dt*msrc/2.;
   double dv;
   if (DIM == 2)
@@ -675,11 +682,11 @@ predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc, Ghos
   const int off[3] = { 1, (int) L.sy, (int) L.sz };
   CPtr3 none = { { nullptr, nullptr, nullptr } };
   {
-    FacePair f = face_values_dir<3, 0, true, VL, VS> (L, u.p[0], u, none, c, dt, visc.d[0]);
+    FacePair f = face_values_dir<3, 0, true, VL, VS> (L, u.p[0], u, none, c, dt, visc.d[0], visc.g[0]);
     fl[0][T.own ()] = f.l; fr[0][T.own ()] = f.r;
-    f = face_values_dir<3, 1, true, VL, VS> (L, u.p[1], u, none, c, dt, visc.d[1]);
+    f = face_values_dir<3, 1, true, VL, VS> (L, u.p[1], u, none, c, dt, visc.d[1], visc.g[1]);
     fl[1][T.own ()] = f.l; fr[1][T.own ()] = f.r;
-    f = face_values_dir<3, 2, true, VL, VS> (L, u.p[2], u, none, c, dt, visc.d[2]);
+    f = face_values_dir<3, 2, true, VL, VS> (L, u.p[2], u, none, c, dt, visc.d[2], visc.g[2]);
     fl[2][T.own ()] = f.l; fr[2][T.own ()] = f.r;
   }
   // halo: the cell beyond the + face of the tile in each direction.  Waves 0-3 take y, waves 4-7
@@ -693,7 +700,7 @@ predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc, Ghos
 	hp[1][h] = G.r[2][face_pos (1, n, hi_, hj, hk)];
       else {
 	int ci = image<3> (L, hi_, hj, hk);
-	hp[1][h] = face_values_dir<3, 1, true, VL, VS> (L, u.p[1], u, none, ci, dt, visc.d[1]).r;
+	hp[1][h] = face_values_dir<3, 1, true, VL, VS> (L, u.p[1], u, none, ci, dt, visc.d[1], visc.g[1]).r;
       }
     }
     else if (h < GX*GZ + GX*GY) {
@@ -703,7 +710,7 @@ predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc, Ghos
 	hp[2][hh] = G.r[4][face_pos (2, n, hi_, hj, hk)];
       else {
 	int ci = image<3> (L, hi_, hj, hk);
-	hp[2][hh] = face_values_dir<3, 2, true, VL, VS> (L, u.p[2], u, none, ci, dt, visc.d[2]).r;
+	hp[2][hh] = face_values_dir<3, 2, true, VL, VS> (L, u.p[2], u, none, ci, dt, visc.d[2], visc.g[2]).r;
       }
     }
     if (h < GY*GZ) {
@@ -713,7 +720,7 @@ predict_un_tiled_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc, Ghos
 	hp[0][h] = G.r[0][face_pos (0, n, hi_, hj, hk)];
       else {
 	int ci = image<3> (L, hi_, hj, hk);
-	hp[0][h] = face_values_dir<3, 0, true, VL, VS> (L, u.p[0], u, none, ci, dt, visc.d[0]).r;
+	hp[0][h] = face_values_dir<3, 0, true, VL, VS> (L, u.p[0], u, none, ci, dt, visc.d[0], visc.g[0]).r;
       }
     }
   }
@@ -752,7 +759,7 @@ template <bool VELOCITY, bool VL, bool VS>
 __global__ void __launch_bounds__(GN)
 advect_tiled_kernel (Layout L, const double * __restrict__ v, double * __restrict__ out, CPtr3 un,
 		     const double * __restrict__ gm, const double * __restrict__ gc, double dt,
-		     double visc)
+		     double visc, double gsrc)
 {
   __shared__ double fl[3][GN], fr[3][GN];
   __shared__ double hm[3][GX*GZ], hp[3][GX*GZ];   // l of the cell before / r of the cell after the tile
@@ -763,11 +770,11 @@ advect_tiled_kernel (Layout L, const double * __restrict__ v, double * __restric
   const int off[3] = { 1, (int) L.sy, (int) L.sz };
   CPtr3 none = { { nullptr, nullptr, nullptr } };
   {
-    FacePair f = face_values_dir<3, 0, false, VL, VS> (L, v, none, un, c, dt, visc);
+    FacePair f = face_values_dir<3, 0, false, VL, VS> (L, v, none, un, c, dt, visc, gsrc);
     fl[0][T.own ()] = f.l; fr[0][T.own ()] = f.r;
-    f = face_values_dir<3, 1, false, VL, VS> (L, v, none, un, c, dt, visc);
+    f = face_values_dir<3, 1, false, VL, VS> (L, v, none, un, c, dt, visc, gsrc);
     fl[1][T.own ()] = f.l; fr[1][T.own ()] = f.r;
-    f = face_values_dir<3, 2, false, VL, VS> (L, v, none, un, c, dt, visc);
+    f = face_values_dir<3, 2, false, VL, VS> (L, v, none, un, c, dt, visc, gsrc);
     fl[2][T.own ()] = f.l; fr[2][T.own ()] = f.r;
   }
   // halo cells: l of the cell before the tile (minus side), r of the cell after it (plus side).
@@ -778,18 +785,18 @@ advect_tiled_kernel (Layout L, const double * __restrict__ v, double * __restric
     const int grp = h / (GX*GZ), idx = h % (GX*GZ), p = idx % GX, q = idx / GX;
     if (grp < 2) {
       int ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + (grp ? GY + 1 : 0), blockIdx.z*GZ + q + 1);
-      FacePair f = face_values_dir<3, 1, false, VL, VS> (L, v, none, un, ci, dt, visc);
+      FacePair f = face_values_dir<3, 1, false, VL, VS> (L, v, none, un, ci, dt, visc, gsrc);
       if (grp) hp[1][idx] = f.r; else hm[1][idx] = f.l;
     }
     else {
       int ci = image<3> (L, blockIdx.x*GX + p + 1, blockIdx.y*GY + q + 1, blockIdx.z*GZ + (grp == 3 ? GZ + 1 : 0));
-      FacePair f = face_values_dir<3, 2, false, VL, VS> (L, v, none, un, ci, dt, visc);
+      FacePair f = face_values_dir<3, 2, false, VL, VS> (L, v, none, un, ci, dt, visc, gsrc);
       if (grp == 3) hp[2][idx] = f.r; else hm[2][idx] = f.l;
     }
     if (h < 2*GY*GZ) {
       const int plus = h >= GY*GZ, hh = h % (GY*GZ), py = hh % GY, qz = hh / GY;
       int ci = image<3> (L, blockIdx.x*GX + (plus ? GX + 1 : 0), blockIdx.y*GY + py + 1, blockIdx.z*GZ + qz + 1);
-      FacePair f = face_values_dir<3, 0, false, VL, VS> (L, v, none, un, ci, dt, visc);
+      FacePair f = face_values_dir<3, 0, false, VL, VS> (L, v, none, un, ci, dt, visc, gsrc);
       if (plus) hp[0][hh] = f.r; else hm[0][hh] = f.l;
     }
   }
@@ -847,6 +854,11 @@ advect_tiled_kernel (Layout L, const double * __restrict__ v, double * __restric
   val += acc/1.;
   if (gc)
     val -= gc[c]*dt;
+  if (gsrc != 0.) {             /* gfs_domain_variable_centered_sources, src/source.c:62-108 */
+    double sum = 0;
+    sum += gsrc;
+    val += dt*sum;
+  }
   out[c] = val;
 }
 
@@ -900,13 +912,14 @@ __device__ __forceinline__ double adv_transverse (const double * __restrict__ v,
 template <int D, bool VL>
 __device__ __forceinline__ FacePair adv_face_values (const double * __restrict__ v, int c, int o,
 						     double v0, double unorm, double ta, double tb,
-						     double dt)
+						     double dt, double gsrc)
 {
   const double v1 = v[c - o], v2 = v[c + o];
   const double g = VL ? van_leer_gradient (v0, v1, v2) : center_gradient (v0, v1, v2);
   const double vl = v0 + GMIN ((1. - unorm)/2., 0.5)*g;
   const double vr = v0 + GMAX ((- 1. - unorm)/2., -0.5)*g;
-  const double msrc = 0.;                /* gfs_variable_mac_source: no source */
+  double msrc = 0.;                      /* gfs_variable_mac_source: the intensity of a GfsSource, if any */
+  msrc += gsrc;
   const double src = dt*msrc/2.;
   double dv = ta;
   dv += tb;
@@ -955,9 +968,9 @@ boundary_face_values_kernel (Layout L, CPtr3 v, CPtr3 un, double dt, Visc3 visc,
   if (CEN) {
     CPtr3 none = { { nullptr, nullptr, nullptr } };
     FacePair p;
-    if (c == 0)      p = face_values_dir<3, 0, true, VL, VS> (L, v.p[0], v, none, ci, dt, visc.d[0]);
-    else if (c == 1) p = face_values_dir<3, 1, true, VL, VS> (L, v.p[1], v, none, ci, dt, visc.d[1]);
-    else             p = face_values_dir<3, 2, true, VL, VS> (L, v.p[2], v, none, ci, dt, visc.d[2]);
+    if (c == 0)      p = face_values_dir<3, 0, true, VL, VS> (L, v.p[0], v, none, ci, dt, visc.d[0], visc.g[0]);
+    else if (c == 1) p = face_values_dir<3, 1, true, VL, VS> (L, v.p[1], v, none, ci, dt, visc.d[1], visc.g[1]);
+    else             p = face_values_dir<3, 2, true, VL, VS> (L, v.p[2], v, none, ci, dt, visc.d[2], visc.g[2]);
     G.s[d][f] = (d & 1) ? p.r : p.l;
   }
   else {
@@ -971,17 +984,17 @@ boundary_face_values_kernel (Layout L, CPtr3 v, CPtr3 un, double dt, Visc3 visc,
       if (c == 0) {
 	const double ta = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
 	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
-	p = adv_face_values<0, VL> (vq, ci, off[0], w0, S.unorm[0], ta, tb, dt);
+	p = adv_face_values<0, VL> (vq, ci, off[0], w0, S.unorm[0], ta, tb, dt, visc.g[q]);
       }
       else if (c == 1) {
 	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
 	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
-	p = adv_face_values<1, VL> (vq, ci, off[1], w0, S.unorm[1], ta, tb, dt);
+	p = adv_face_values<1, VL> (vq, ci, off[1], w0, S.unorm[1], ta, tb, dt, visc.g[q]);
       }
       else {
 	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
 	const double tb = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
-	p = adv_face_values<2, VL> (vq, ci, off[2], w0, S.unorm[2], ta, tb, dt);
+	p = adv_face_values<2, VL> (vq, ci, off[2], w0, S.unorm[2], ta, tb, dt, visc.g[q]);
       }
       G.s[d][q*nf + f] = (d & 1) ? p.r : p.l;
     }
@@ -991,7 +1004,7 @@ boundary_face_values_kernel (Layout L, CPtr3 v, CPtr3 un, double dt, Visc3 visc,
 template <bool VL, bool MPI>
 __device__ __forceinline__ void
 advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 & un, const CPtr3 & gm,
-	      const CPtr3 & gc, double dt, const GhostFv & G)
+	      const CPtr3 & gc, double dt, const GhostFv & G, const Visc3 & src3)
 {
   // R: right face values, then (after they have been read) the fluxes of the + faces
   __shared__ double R[3][3][GN];
@@ -1013,11 +1026,11 @@ advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 &
 #pragma unroll
       for (int cc = 0; cc < 3; cc++)
 	t[cc] = adv_transverse (vq, c, off[cc], v0[q], S.vtan[cc], dt, rsize2);
-      FacePair f = adv_face_values<0, VL> (vq, c, off[0], v0[q], S.unorm[0], t[1], t[2], dt);
+      FacePair f = adv_face_values<0, VL> (vq, c, off[0], v0[q], S.unorm[0], t[1], t[2], dt, src3.g[q]);
       fl[q][0] = f.l; fr[q][0] = f.r;
-      f = adv_face_values<1, VL> (vq, c, off[1], v0[q], S.unorm[1], t[0], t[2], dt);
+      f = adv_face_values<1, VL> (vq, c, off[1], v0[q], S.unorm[1], t[0], t[2], dt, src3.g[q]);
       fl[q][1] = f.l; fr[q][1] = f.r;
-      f = adv_face_values<2, VL> (vq, c, off[2], v0[q], S.unorm[2], t[0], t[1], dt);
+      f = adv_face_values<2, VL> (vq, c, off[2], v0[q], S.unorm[2], t[0], t[1], dt, src3.g[q]);
       fl[q][2] = f.l; fr[q][2] = f.r;
 #pragma unroll
       for (int d = 0; d < 3; d++)
@@ -1049,7 +1062,7 @@ advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 &
 	const double w0 = vq[ci];
 	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
 	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
-	const FacePair f = adv_face_values<1, VL> (vq, ci, off[1], w0, S.unorm[1], ta, tb, dt);
+	const FacePair f = adv_face_values<1, VL> (vq, ci, off[1], w0, S.unorm[1], ta, tb, dt, src3.g[q]);
 	if (grp) hp[q][1][idx] = f.r; else hm[q][1][idx] = f.l;
       }
       }
@@ -1072,7 +1085,7 @@ advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 &
 	const double w0 = vq[ci];
 	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
 	const double tb = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
-	const FacePair f = adv_face_values<2, VL> (vq, ci, off[2], w0, S.unorm[2], ta, tb, dt);
+	const FacePair f = adv_face_values<2, VL> (vq, ci, off[2], w0, S.unorm[2], ta, tb, dt, src3.g[q]);
 	if (grp == 3) hp[q][2][idx] = f.r; else hm[q][2][idx] = f.l;
       }
       }
@@ -1096,7 +1109,7 @@ advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 &
 	const double w0 = vq[ci];
 	const double ta = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
 	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
-	const FacePair f = adv_face_values<0, VL> (vq, ci, off[0], w0, S.unorm[0], ta, tb, dt);
+	const FacePair f = adv_face_values<0, VL> (vq, ci, off[0], w0, S.unorm[0], ta, tb, dt, src3.g[q]);
 	if (plus) hp[q][0][hh] = f.r; else hm[q][0][hh] = f.l;
       }
       }
@@ -1181,6 +1194,11 @@ advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 &
     val += acc/1.;
     if (gc.p[q])
       val -= gc.p[q][c]*dt;
+    if (src3.g[q] != 0.) {        /* gfs_domain_variable_centered_sources, src/source.c:62-108 */
+      double sum = 0;
+      sum += src3.g[q];
+      val += dt*sum;
+    }
     out.p[q][c] = val;
   }
 }
@@ -1190,16 +1208,18 @@ advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 &
 // to 128 (a few dwords of scratch).
 template <bool VL, bool MPI>
 __global__ void __launch_bounds__(GN)
-advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt, GhostFv G)
+advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt, GhostFv G,
+		      Visc3 gs)
 {
-  advect3_tile<VL, MPI> (L, v, out, un, gm, gc, dt, G);
+  advect3_tile<VL, MPI> (L, v, out, un, gm, gc, dt, G, gs);
 }
 
 template <bool VL, bool MPI>
 __global__ void __launch_bounds__(GN, 4)
-advect3_tiled_kernel_w4 (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt, GhostFv G)
+advect3_tiled_kernel_w4 (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt, GhostFv G,
+			 Visc3 gs)
 {
-  advect3_tile<VL, MPI> (L, v, out, un, gm, gc, dt, G);
+  advect3_tile<VL, MPI> (L, v, out, un, gm, gc, dt, G, gs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1244,9 +1264,12 @@ cfl_partial_kernel (Layout L, CPtr3 u, CPtr3 un, Visc3 visc, double * __restrict
 	  double cflu = length/fabs (1.*uv);
 	  m = fmin (m, cflu*cflu);
 	}
-	if (visc.d[cc] != 0. && i <= n && j <= n && (DIM == 2 || k <= n)) {
-	  /* p->v[c]->sources: acceleration time scale, src/domain.c:2893-2901 */
-	  double g = 0. + source_diffusion_value<DIM> (u.p[cc], c, off, visc.d[cc], n);
+	if ((visc.d[cc] != 0. || visc.g[cc] != 0.) && i <= n && j <= n && (DIM == 2 || k <= n)) {
+	  /* p->v[c]->sources: acceleration time scale, src/domain.c:2893-2901 (gfs_variable_mac_source:
+	     the explicit diffusion term, then the intensity of a GfsSource) */
+	  double g = 0.;
+	  if (visc.d[cc] != 0.) g += source_diffusion_value<DIM> (u.p[cc], c, off, visc.d[cc], n);
+	  if (visc.g[cc] != 0.) g += visc.g[cc];
 	  if (g != 0.) {
 	    double cflg = 2.*length/fabs (1.*g);
 	    m = fmin (m, cflg);
@@ -1384,13 +1407,13 @@ int launch_correct_centered (gfship_domain * dom, double * const u[3], double * 
 
 int launch_advected_face_values (gfship_domain * dom, const double * v, double * const u[3],
 				 double * const un[3], double dt, int use_centered, int gradient,
-				 double * const fv[6], int cmask, double visc)
+				 double * const fv[6], int cmask, double visc, double gsrc)
 {
   const Layout & L = dom->lay[dom->depth];
   dim3 grid, block;
   cell_grid (L, &grid, &block);
   DISPATCH (dom, advected_face_values_kernel, grid, block, L, v, c3 (u), c3 (un), dt,
-	    use_centered, gradient, m6 (fv), cmask, visc);
+	    use_centered, gradient, m6 (fv), cmask, visc, gsrc);
   return GFSHIP_OK;
 }
 
@@ -1432,7 +1455,7 @@ int launch_predict_un (gfship_domain * dom, int cc, const double * uc, double * 
 }
 
 int launch_flux_update (gfship_domain * dom, bool velocity, double * v, double * const un[3],
-			double * const fv[6], const double * gm, const double * gc, double dt)
+			double * const fv[6], const double * gm, const double * gc, double dt, double gsrc)
 {
   const Layout & L = dom->lay[dom->depth];
   dim3 grid, block;
@@ -1440,18 +1463,18 @@ int launch_flux_update (gfship_domain * dom, bool velocity, double * v, double *
   if (dom->dim == 3) {
     if (velocity)
       hipLaunchKernelGGL ((flux_update_kernel<3, true>), grid, block, 0, dom->stream,
-			  L, v, c3 (un), c6 (fv), gm, gc, dt);
+			  L, v, c3 (un), c6 (fv), gm, gc, dt, gsrc);
     else
       hipLaunchKernelGGL ((flux_update_kernel<3, false>), grid, block, 0, dom->stream,
-			  L, v, c3 (un), c6 (fv), gm, gc, dt);
+			  L, v, c3 (un), c6 (fv), gm, gc, dt, gsrc);
   }
   else {
     if (velocity)
       hipLaunchKernelGGL ((flux_update_kernel<2, true>), grid, block, 0, dom->stream,
-			  L, v, c3 (un), c6 (fv), gm, gc, dt);
+			  L, v, c3 (un), c6 (fv), gm, gc, dt, gsrc);
     else
       hipLaunchKernelGGL ((flux_update_kernel<2, false>), grid, block, 0, dom->stream,
-			  L, v, c3 (un), c6 (fv), gm, gc, dt);
+			  L, v, c3 (un), c6 (fv), gm, gc, dt, gsrc);
   }
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
@@ -1567,7 +1590,7 @@ int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt
 {
   const Layout & L = dom->lay[dom->depth];
   Visc3 vs;
-  for (int c = 0; c < 3; c++) vs.d[c] = visc[c];
+  for (int c = 0; c < 3; c++) { vs.d[c] = visc[c]; vs.g[c] = dom->src[c]; }
   const bool anyv = visc[0] != 0. || visc[1] != 0. || visc[2] != 0.;
   const dim3 grid (L.n/GX, L.n/GY, L.n/GZ);
   GhostFv G;
@@ -1596,12 +1619,12 @@ int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt
 
 int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, double * out,
 			 double * const un[3], const double * gm, const double * gc, double dt,
-			 int gradient, double visc)
+			 int gradient, double visc, double gsrc)
 {
   const Layout & L = dom->lay[dom->depth];
   dim3 grid (L.n/GX, L.n/GY, L.n/GZ);
 #define AK(VE_, VL_, VS_) hipLaunchKernelGGL ((advect_tiled_kernel<VE_, VL_, VS_>), grid, dim3 (GN), 0, \
-					      dom->stream, L, v, out, c3 (un), gm, gc, dt, visc)
+					      dom->stream, L, v, out, c3 (un), gm, gc, dt, visc, gsrc)
   const bool vs = visc != 0.;
   if (velocity) {
     if (gradient) { if (vs) AK (true, true, true); else AK (true, true, false); }
@@ -1627,12 +1650,12 @@ int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * con
   for (int c = 0; c < 3; c++) gcp.p[c] = gc ? gc[c] : nullptr;
   GhostFv G;
   for (int d = 0; d < 6; d++) { G.r[d] = nullptr; G.s[d] = nullptr; }
+  Visc3 vs = { { 0., 0., 0. }, { dom->src[0], dom->src[1], dom->src[2] } };
   const bool mpi = dom->has_external;
   if (mpi) {
     int r = ghost_fv (dom, &G);
     if (r) return r;
     const dim3 bgrid ((L.n*L.n + 255)/256, 6);
-    Visc3 vs = { { 0., 0., 0. } };
     if (gradient)
       hipLaunchKernelGGL ((boundary_face_values_kernel<false, true, false>), bgrid, dim3 (256), 0, dom->stream,
 			  L, c3 (v), c3 (un), dt, vs, G);
@@ -1643,8 +1666,12 @@ int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * con
     if ((r = comm_exchange_raw (dom, dom->gfv_send, dom->gfv_recv, (size_t) 3*L.n*L.n))) return r;
     dom->n_fused_mpi++;
   }
-#define AK(VL_) do { if (mpi) hipLaunchKernelGGL ((advect3_tiled_kernel<VL_, true>), grid, dim3 (GN), 0, dom->stream, 						  L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, G);     else hipLaunchKernelGGL ((advect3_tiled_kernel<VL_, false>), grid, dim3 (GN), 0, dom->stream, 			     L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, G); } while (0)
-  if (gradient) AK (true); else AK (false);
+#define AK(K_, VL_, MPI_) hipLaunchKernelGGL ((K_<VL_, MPI_>), grid, dim3 (GN), 0, dom->stream, \
+					     L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, G, vs)
+  /* the variants that would take 130-132 VGPRs are held to 128 (two tiles per CU) */
+  if (mpi) { if (gradient) AK (advect3_tiled_kernel_w4, true, true); else AK (advect3_tiled_kernel_w4, false, true); }
+  else if (gradient) AK (advect3_tiled_kernel_w4, true, false);
+  else AK (advect3_tiled_kernel, false, false);
 #undef AK
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
@@ -1654,7 +1681,7 @@ int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3],
 		const double visc[3], double * cfl2)
 {
   Visc3 vs;
-  for (int c = 0; c < 3; c++) vs.d[c] = visc ? visc[c] : 0.;
+  for (int c = 0; c < 3; c++) { vs.d[c] = visc ? visc[c] : 0.; vs.g[c] = dom->src[c]; }
   const Layout & L = dom->lay[dom->depth];
   long r = L.n + 1;
   long next = dom->dim == 3 ? r*r*r : r*r;

@@ -96,6 +96,7 @@ SIGNATURES = {
     "gfship_sim_iter": (_u, [_vp]),
     "gfship_sim_add_tracer": (_i, [_vp]),
     "gfship_sim_set_viscosity": (_i, [_vp, _i, _d]),
+    "gfship_sim_set_source": (_i, [_vp, _i, _d]),
     "gfship_sim_diffusion_params": (C.POINTER(MultilevelParams), [_vp, _i]),
     "gfship_sim_start": (_i, [_vp]),
     "gfship_sim_step": (_i, [_vp]),
@@ -476,6 +477,10 @@ class Simulation:
 
     def _var(self, which, c=0):
         return _SimVariable(self.dom, _check(lib().gfship_sim_variable(self.ptr, which, c)))
+
+    def set_source(self, c, g):
+        """GfsSource {} U/V/W g: constant intensity"""
+        _check(lib().gfship_sim_set_source(self.ptr, c, float(g)))
 
     def set_viscosity(self, c, nu):
         """SourceDiffusion {} U|V|W nu"""

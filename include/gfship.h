@@ -207,6 +207,13 @@ int      gfship_sim_set_tracer_gradient (gfship_sim * sim, int tracer, int gradi
    velocity component c (0. removes it), and the GfsMultilevelParams of its solver
    (tolerance 1e-6, beta 1: diffusion_init, src/source.c:966-974) */
 int      gfship_sim_set_viscosity (gfship_sim * sim, int c, double nu);
+/* GfsSource {} U|V|W g (src/source.c:362-500) with a constant intensity g on velocity component c
+   (0. removes it): a body force per unit mass -- the MAC source of gfs_cell_advected_face_values
+   (src/advection.c:88, gfs_variable_mac_source), the centred source added at the end of
+   variable_sources (gfs_domain_variable_centered_sources, src/source.c:62-108), the acceleration
+   time scale of gfs_domain_cfl (src/domain.c:2893-2901), and the gravity GfsForceBuoy reads
+   (modules/particulatecommon.c:632-647).  Pinned by test/poiseuille (error.ref). */
+int      gfship_sim_set_source (gfship_sim * sim, int c, double intensity);
 gfship_multilevel_params * gfship_sim_diffusion_params (gfship_sim * sim, int c);
 /* simulation_run before its loop (src/simulation.c:458-476): BCs, first time step, initial
    approximate projection */

@@ -18,6 +18,7 @@ typedef struct GoSim {
   GoAdvectionParams advection_params;
   double t, end, dtmax, tnext;   /* GfsTime */
   double visc[3];                /* SourceDiffusion {} U nu: constant diffusion coefficient, 0 = none */
+  double src[3];                 /* GfsSource {} U g: constant intensity (src/source.c:398-403,476-481), 0 = none */
   GoMultilevelParams diffusion_params[3]; /* GfsDiffusion.par (source.c:966-974) */
   unsigned i, iend;
 } GoSim;
@@ -52,6 +53,7 @@ void    go_sim_step (GoSim * s);
 void    go_advection_step (GoSim * s);
 void    go_divergence (GoSim * s, GoField * out);
 void    go_sim_set_viscosity (GoSim * s, int c, double nu);
+void    go_sim_set_source (GoSim * s, int c, double g);
 GoMultilevelParams * go_sim_diffusion_params (GoSim * s, int c);
 /* go_diffusion.c */
 double  go_source_diffusion_value (GoSim * s, GoField * phi, int cell, double D);

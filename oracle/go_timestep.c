@@ -139,6 +139,26 @@ void go_sim_set_time (GoSim * s, double end, double dtmax)
 }
 
 void go_sim_set_viscosity (GoSim * s, int c, double nu) { s->visc[c] = nu; }
+void go_sim_set_source (GoSim * s, int c, double g) { s->src[c] = g; }
+
+/* gfs_variable_mac_source (source.c:38-59) of a velocity component: the sum over its sources that
+ * have a mac_value -- the explicit diffusion term of an implicit GfsSourceDiffusion
+ * (source_diffusion_value, source.c:1105-1144) and the intensity of a GfsSource (source_value,
+ * :398-403); *has = the variable has sources at all */
+static double variable_mac_source (GoSim * s, GoField * v, int cell, int * has)
+{
+  int c = v->component;
+  int present = c >= 0 && (s->visc[c] != 0. || s->src[c] != 0.);
+  if (has) *has = present;
+  if (!present)
+    return 0.;
+  double sum = 0.;
+  if (s->visc[c] != 0.)
+    sum += go_source_diffusion_value (s, v, cell, s->visc[c]);
+  if (s->src[c] != 0.)
+    sum += s->src[c];
+  return sum;
+}
 GoMultilevelParams * go_sim_diffusion_params (GoSim * s, int c) { return &s->diffusion_params[c]; }
 
 int go_sim_add_tracer (GoSim * s)
@@ -377,9 +397,7 @@ static void cell_advected_face_values (GoSim * s, const AdvPar * par, int cell)
     double vr = v[cell] + MAX ((- 1. - unorm)/2., -0.5)*g;
     /* gfs_variable_mac_source (source.c:38-59): the explicit diffusion term of an implicit
        GfsSourceDiffusion (source_diffusion_value, source.c:1105-1144) */
-    double msrc = 0.;
-    if (par->v->component >= 0 && s->visc[par->v->component] != 0.)
-      msrc = 0. + go_source_diffusion_value (s, par->v, cell, s->visc[par->v->component]);
+    double msrc = variable_mac_source (s, par->v, cell, NULL);
     double src = par->dt*msrc/2.;
     double dv;
     if (dim == 2)
@@ -550,6 +568,14 @@ static void variable_sources (GoSim * s, GoField * v, GoField * sv, int gradient
     /* add_pressure_gradient on sv, timestep.c:809-812 */
     LEAF_LOOP (s, cell)
       sv->lev[L][cell] -= g[v->component]->lev[L][cell]*dt;
+  /* gfs_domain_variable_centered_sources (source.c:62-108): the sources with a centered_value -- a
+     GfsSource, not the implicit diffusion */
+  if (v->component >= 0 && s->src[v->component] != 0.)
+    LEAF_LOOP (s, cell) {
+      double sum = 0;
+      sum += s->src[v->component];
+      sv->lev[L][cell] += dt*sum;
+    }
 }
 
 /* gfs_centered_velocity_advection_diffusion, timestep.c:976-1016 (no diffusion source) */
@@ -625,8 +651,9 @@ double go_domain_cfl (GoSim * s)
 	if (cflu*cflu < cfl)
 	  cfl = cflu*cflu;
       }
-      if (s->visc[c] != 0.) { /* p->v[c]->sources: acceleration scale, domain.c:2893-2901 */
-	double g = 0. + go_source_diffusion_value (s, s->u[c], cell, s->visc[c]);
+      int has;
+      double g = variable_mac_source (s, s->u[c], cell, &has);
+      if (has) { /* p->v[c]->sources: acceleration scale, domain.c:2893-2901 */
 	if (g != 0.) {
 	  double cflg = 2.*length/fabs (fm*g);
 	  if (cflg < cfl)

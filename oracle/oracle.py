@@ -220,6 +220,7 @@ def _sim_sigs(L):
         "go_divergence": (None, [vp, vp]),
         "go_tracer_advection": (None, [vp, vp, d]),
         "go_sim_set_viscosity": (None, [vp, i, d]),
+        "go_sim_set_source": (None, [vp, i, d]),
         "go_variable_diffusion": (None, [vp, vp, vp, d, d, C.POINTER(MultilevelParams)]),
         "go_sim_diffusion_params": (C.POINTER(MultilevelParams), [vp, i]),
     }
@@ -312,6 +313,10 @@ class Sim:
     def fv(self, d):
         n = (1 << self.depth) + 2
         return np.ctypeslib.as_array(lib().go_sim_fv(self.ptr, d), shape=(n,) * self.dim)
+
+    def set_source(self, c, g):
+        """GfsSource {} U/V/W g: constant intensity (a body force per unit mass)"""
+        lib().go_sim_set_source(self.ptr, c, g)
 
     def set_viscosity(self, c, nu):
         """SourceDiffusion {} U|V|W nu (implicit, Crank-Nicholson beta = 1 by default)"""

@@ -171,6 +171,8 @@ def test_rccl_transport_on_one_rank_reproduces_the_periodic_box(axes, fast, monk
     osim.u[1].interior()[...] -= 0.2
     side = [gfship.SIDE_EXTERNAL if "xyz"[d // 2] in axes else gfship.SIDE_PERIODIC for d in range(6)]
     gd, gs = _device_sim(osim, side)
+    osim.set_source(1, -0.8)                  # a GfsSource on V: MAC and centred sources on both paths
+    gs.set_source(1, -0.8)
     gd.comm_init(gfship.comm_unique_id(), 0, 1, (1, 1, 1))
     assert gd.comm_size() == 1
     osim.start()

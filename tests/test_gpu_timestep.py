@@ -449,3 +449,69 @@ def test_advection_run_stream_function_bit_exact(level, gradient, golden_dir):
         rows = [l.split() for l in open(os.path.join(golden_dir, "reference", "advection_error.ref"))]
         ref = {int(r[0]): [float(v) for v in r[1:]] for r in rows}[level]
         assert np.allclose([np.sqrt((e * e).mean()), np.abs(e).max()], ref[1:], rtol=2e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# GfsSource with a constant intensity on the velocity components (src/source.c:362-500)
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("level,nu", [(4, 0.), (5, 0.), (4, 1e-2)])
+def test_body_force_taylor_green_3d_bit_exact(level, nu):
+    """`Source U / V / W g' on the triply periodic box: the MAC source of the face values (the tiled
+    kernels at 32^3, the three-component kernel without viscosity, the one-component kernels with
+    it), the centred source, the acceleration time scale of the CFL condition; device against oracle
+    bit for bit, and the flow really accelerates"""
+    osim = oracle_taylor_green(level)
+    g = (0.7, -1.3, 0.4)
+    for c in range(3):
+        osim.set_source(c, g[c])
+        if nu:
+            osim.set_viscosity(c, nu)
+    gd, gs = _device_sim(osim, PERIODIC)
+    for c in range(3):
+        gs.set_source(c, g[c])
+        if nu:
+            gs.set_viscosity(c, nu)
+    osim.start()
+    gs.start()
+    _assert_same_state(osim, gs, "start")
+    assert gs.cfl() == O.lib().go_domain_cfl(osim.ptr)
+    for k in range(3):
+        osim.step()
+        gs.step()
+        _assert_same_state(osim, gs, "step %d" % k)
+        _assert_same_un(osim, gs, "step %d" % k)
+    assert gs.cfl() == O.lib().go_domain_cfl(osim.ptr)
+    assert abs(osim.u[1].interior().mean() - g[1] * osim.t) < 0.05 * abs(g[1] * osim.t)
+
+
+@pytest.mark.parametrize("level", [3, 5])
+def test_poiseuille_channel_steps_bit_exact(level):
+    """the set-up of test/poiseuille (periodic channel, Dirichlet walls, Source U 1, Source V 1,
+    SourceViscosity 1 { beta = 1 }): the general (face-value array) kernels with sources, 2-D"""
+    side = [O.SIDE_PERIODIC, O.SIDE_PERIODIC, O.SIDE_BOUNDARY, O.SIDE_BOUNDARY, O.SIDE_BOUNDARY, O.SIDE_BOUNDARY]
+    osim = O.Sim(2, level, side)
+    n = 1 << level
+    gd = gfship.Domain(2, level, side)
+    gs = gfship.Simulation(gd)
+    for d in (2, 3):
+        osim.u[0].set_bc(d, O.BC_DIRICHLET, np.zeros(n))
+        gs.u[0].set_bc(d, gfship.BC_DIRICHLET, np.zeros(n))
+    for c in range(2):
+        osim.set_viscosity(c, 1.)
+        osim.diffusion_params(c).beta = 1.
+        osim.set_source(c, 1.)
+        gs.set_viscosity(c, 1.)
+        gs.diffusion_params(c).beta = 1.
+        gs.set_source(c, 1.)
+    for sim in (osim, gs):
+        sim.projection_params.tolerance = 1e-6
+        sim.approx_projection_params.tolerance = 1e-6
+    osim.start()
+    gs.start()
+    _assert_same_state(osim, gs, "start")
+    for k in range(6):
+        osim.step()
+        gs.step()
+        _assert_same_state(osim, gs, "step %d" % k)
+    assert gs.dt == osim.dt and osim.u[0].interior().max() > 0.05

@@ -1,6 +1,7 @@
 """The reference's own simulation files, unmodified (tests/golden/reference_inputs/*.gfs are
 byte-identical copies of test/poisson/poisson.gfs, test/reynolds/reynolds.gfs,
-test/advection/advection.gfs, test/lid/lid.gfs and test/periodic/periodic.gfs: input data, like the
+test/advection/advection.gfs, test/lid/lid.gfs, test/periodic/periodic.gfs and
+test/poiseuille/poiseuille.gfs: input data, like the
 .ref files next to them), run through the front end with the macro definitions their driver
 scripts use (poisson.sh, reynolds.sh, advection.sh, lid.sh, periodic.sh).
 
@@ -58,6 +59,7 @@ def _rows(name):
     ("advection.gfs", {}, {"LEVEL": 6}, "class GfsAdvection dim 2 level 6"),
     ("lid.gfs", {}, None, "class GfsSimulation dim 2 level 6"),
     ("periodic.gfs", {}, {"LEVEL": 6, "BOX": 0}, "class GfsSimulation dim 2 level 6"),
+    ("poiseuille.gfs", {"LEVEL": 5}, None, "class GfsSimulation dim 2 level 5"),
 ])
 def test_reference_files_parse_unmodified(tmp_path, name, defs, sed, expect):
     _stage(tmp_path, name)
@@ -128,6 +130,20 @@ def test_advection_gfs_against_error_ref(tmp_path):
     want = [r for r in _rows("advection_error.ref") if r[0] == "5"][0]
     assert out[0] == "5"
     assert ["%.3e" % float(out[2]), "%.3e" % float(out[3])] == want[2:4]     # L2, Linf
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [3, 4, 5])
+def test_poiseuille_gfs_against_error_ref(tmp_path, level):
+    """test/poiseuille/poiseuille.gfs (Source U 1, Source V 1, SourceViscosity 1. { beta = 1 }, EventStop):
+    the line its OutputErrorNorm pipes through awk, against error.ref with the tolerance of
+    poiseuille.sh (1e-6 on the maximum norm)"""
+    _stage(tmp_path, "poiseuille.gfs")
+    out = _run(tmp_path, "poiseuille.gfs", {"LEVEL": level}).stdout.split()
+    want = [r for r in _rows("poiseuille_error.ref") if r[0] == str(level)][0]
+    assert out[0] == str(level)
+    assert abs(float(out[3]) - float(want[3])) <= 1e-6
+    assert abs(float(out[1]) - float(want[1])) <= 2e-6 and abs(float(out[2]) - float(want[2])) <= 2e-6
 
 
 @pytest.mark.gpu
