@@ -608,7 +608,7 @@ __device__ __forceinline__ FacePair face_values_dir (const Layout & L, const dou
     const long off64[3] = { 1, L.sy, L.sz };
     msrc = 0. + source_diffusion_value<DIM> (v, c, off64, visc, L.n);
   }
-  msrc += gsrc;                 /* the intensity of a GfsSource on the variable */
+  if (VS) msrc += gsrc;         /* the intensity of a GfsSource on the variable */
   double src = dt*msrc/2.;
   double dv;
   if (DIM == 2)
@@ -854,7 +854,7 @@ advect_tiled_kernel (Layout L, const double * __restrict__ v, double * __restric
   val += acc/1.;
   if (gc)
     val -= gc[c]*dt;
-  if (gsrc != 0.) {             /* gfs_domain_variable_centered_sources, src/source.c:62-108 */
+  if (VS && gsrc != 0.) {       /* gfs_domain_variable_centered_sources, src/source.c:62-108 */
     double sum = 0;
     sum += gsrc;
     val += dt*sum;
@@ -909,7 +909,7 @@ __device__ __forceinline__ double adv_transverse (const double * __restrict__ v,
 
 // the two face values of direction D given the transverse terms ta, tb of the other two directions
 // (in increasing order of direction): face_values_dir with CEN = false, VS = false
-template <int D, bool VL>
+template <int D, bool VL, bool SRC>
 __device__ __forceinline__ FacePair adv_face_values (const double * __restrict__ v, int c, int o,
 						     double v0, double unorm, double ta, double tb,
 						     double dt, double gsrc)
@@ -919,7 +919,7 @@ __device__ __forceinline__ FacePair adv_face_values (const double * __restrict__
   const double vl = v0 + GMIN ((1. - unorm)/2., 0.5)*g;
   const double vr = v0 + GMAX ((- 1. - unorm)/2., -0.5)*g;
   double msrc = 0.;                      /* gfs_variable_mac_source: the intensity of a GfsSource, if any */
-  msrc += gsrc;
+  if (SRC) msrc += gsrc;
   const double src = dt*msrc/2.;
   double dv = ta;
   dv += tb;
@@ -984,27 +984,29 @@ boundary_face_values_kernel (Layout L, CPtr3 v, CPtr3 un, double dt, Visc3 visc,
       if (c == 0) {
 	const double ta = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
 	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
-	p = adv_face_values<0, VL> (vq, ci, off[0], w0, S.unorm[0], ta, tb, dt, visc.g[q]);
+	p = adv_face_values<0, VL, VS> (vq, ci, off[0], w0, S.unorm[0], ta, tb, dt, visc.g[q]);
       }
       else if (c == 1) {
 	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
 	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
-	p = adv_face_values<1, VL> (vq, ci, off[1], w0, S.unorm[1], ta, tb, dt, visc.g[q]);
+	p = adv_face_values<1, VL, VS> (vq, ci, off[1], w0, S.unorm[1], ta, tb, dt, visc.g[q]);
       }
       else {
 	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
 	const double tb = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
-	p = adv_face_values<2, VL> (vq, ci, off[2], w0, S.unorm[2], ta, tb, dt, visc.g[q]);
+	p = adv_face_values<2, VL, VS> (vq, ci, off[2], w0, S.unorm[2], ta, tb, dt, visc.g[q]);
       }
       G.s[d][q*nf + f] = (d & 1) ? p.r : p.l;
     }
   }
 }
 
-template <bool VL, bool MPI>
-__device__ __forceinline__ void
-advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 & un, const CPtr3 & gm,
-	      const CPtr3 & gc, double dt, const GhostFv & G, const Visc3 & src3)
+// WPE: waves per SIMD the register allocation is held to (4 = 128 VGPRs = two tiles per CU: the
+// variants that would take a few more are held to it; 1 = no constraint)
+template <bool VL, bool MPI, bool SRC, int WPE>
+__global__ void __launch_bounds__(GN, WPE)
+advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt, GhostFv G,
+		      Visc3 src3)
 {
   // R: right face values, then (after they have been read) the fluxes of the + faces
   __shared__ double R[3][3][GN];
@@ -1026,11 +1028,11 @@ advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 &
 #pragma unroll
       for (int cc = 0; cc < 3; cc++)
 	t[cc] = adv_transverse (vq, c, off[cc], v0[q], S.vtan[cc], dt, rsize2);
-      FacePair f = adv_face_values<0, VL> (vq, c, off[0], v0[q], S.unorm[0], t[1], t[2], dt, src3.g[q]);
+      FacePair f = adv_face_values<0, VL, SRC> (vq, c, off[0], v0[q], S.unorm[0], t[1], t[2], dt, src3.g[q]);
       fl[q][0] = f.l; fr[q][0] = f.r;
-      f = adv_face_values<1, VL> (vq, c, off[1], v0[q], S.unorm[1], t[0], t[2], dt, src3.g[q]);
+      f = adv_face_values<1, VL, SRC> (vq, c, off[1], v0[q], S.unorm[1], t[0], t[2], dt, src3.g[q]);
       fl[q][1] = f.l; fr[q][1] = f.r;
-      f = adv_face_values<2, VL> (vq, c, off[2], v0[q], S.unorm[2], t[0], t[1], dt, src3.g[q]);
+      f = adv_face_values<2, VL, SRC> (vq, c, off[2], v0[q], S.unorm[2], t[0], t[1], dt, src3.g[q]);
       fl[q][2] = f.l; fr[q][2] = f.r;
 #pragma unroll
       for (int d = 0; d < 3; d++)
@@ -1062,7 +1064,7 @@ advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 &
 	const double w0 = vq[ci];
 	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
 	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
-	const FacePair f = adv_face_values<1, VL> (vq, ci, off[1], w0, S.unorm[1], ta, tb, dt, src3.g[q]);
+	const FacePair f = adv_face_values<1, VL, SRC> (vq, ci, off[1], w0, S.unorm[1], ta, tb, dt, src3.g[q]);
 	if (grp) hp[q][1][idx] = f.r; else hm[q][1][idx] = f.l;
       }
       }
@@ -1085,7 +1087,7 @@ advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 &
 	const double w0 = vq[ci];
 	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
 	const double tb = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
-	const FacePair f = adv_face_values<2, VL> (vq, ci, off[2], w0, S.unorm[2], ta, tb, dt, src3.g[q]);
+	const FacePair f = adv_face_values<2, VL, SRC> (vq, ci, off[2], w0, S.unorm[2], ta, tb, dt, src3.g[q]);
 	if (grp == 3) hp[q][2][idx] = f.r; else hm[q][2][idx] = f.l;
       }
       }
@@ -1109,7 +1111,7 @@ advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 &
 	const double w0 = vq[ci];
 	const double ta = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
 	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
-	const FacePair f = adv_face_values<0, VL> (vq, ci, off[0], w0, S.unorm[0], ta, tb, dt, src3.g[q]);
+	const FacePair f = adv_face_values<0, VL, SRC> (vq, ci, off[0], w0, S.unorm[0], ta, tb, dt, src3.g[q]);
 	if (plus) hp[q][0][hh] = f.r; else hm[q][0][hh] = f.l;
       }
       }
@@ -1194,32 +1196,13 @@ advect3_tile (const Layout & L, const CPtr3 & v, const Ptr3 & out, const CPtr3 &
     val += acc/1.;
     if (gc.p[q])
       val -= gc.p[q][c]*dt;
-    if (src3.g[q] != 0.) {        /* gfs_domain_variable_centered_sources, src/source.c:62-108 */
+    if (SRC && src3.g[q] != 0.) { /* gfs_domain_variable_centered_sources, src/source.c:62-108 */
       double sum = 0;
       sum += src3.g[q];
       val += dt*sum;
     }
     out.p[q][c] = val;
   }
-}
-
-// The centred-gradient kernel of a periodic box takes exactly 128 VGPRs (4 waves per SIMD = two tiles
-// per CU); the other variants would take 130-132 and lose a quarter of the occupancy: they are held
-// to 128 (a few dwords of scratch).
-template <bool VL, bool MPI>
-__global__ void __launch_bounds__(GN)
-advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt, GhostFv G,
-		      Visc3 gs)
-{
-  advect3_tile<VL, MPI> (L, v, out, un, gm, gc, dt, G, gs);
-}
-
-template <bool VL, bool MPI>
-__global__ void __launch_bounds__(GN, 4)
-advect3_tiled_kernel_w4 (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt, GhostFv G,
-			 Visc3 gs)
-{
-  advect3_tile<VL, MPI> (L, v, out, un, gm, gc, dt, G, gs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1591,7 +1574,9 @@ int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt
   const Layout & L = dom->lay[dom->depth];
   Visc3 vs;
   for (int c = 0; c < 3; c++) { vs.d[c] = visc[c]; vs.g[c] = dom->src[c]; }
-  const bool anyv = visc[0] != 0. || visc[1] != 0. || visc[2] != 0.;
+  /* VS: the velocity components may have MAC sources (implicit viscosity, GfsSource) */
+  const bool anyv = visc[0] != 0. || visc[1] != 0. || visc[2] != 0. ||
+    dom->src[0] != 0. || dom->src[1] != 0. || dom->src[2] != 0.;
   const dim3 grid (L.n/GX, L.n/GY, L.n/GZ);
   GhostFv G;
   for (int d = 0; d < 6; d++) { G.r[d] = nullptr; G.s[d] = nullptr; }
@@ -1625,7 +1610,7 @@ int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, d
   dim3 grid (L.n/GX, L.n/GY, L.n/GZ);
 #define AK(VE_, VL_, VS_) hipLaunchKernelGGL ((advect_tiled_kernel<VE_, VL_, VS_>), grid, dim3 (GN), 0, \
 					      dom->stream, L, v, out, c3 (un), gm, gc, dt, visc, gsrc)
-  const bool vs = visc != 0.;
+  const bool vs = visc != 0. || gsrc != 0.;
   if (velocity) {
     if (gradient) { if (vs) AK (true, true, true); else AK (true, true, false); }
     else          { if (vs) AK (true, false, true); else AK (true, false, false); }
@@ -1656,22 +1641,27 @@ int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * con
     int r = ghost_fv (dom, &G);
     if (r) return r;
     const dim3 bgrid ((L.n*L.n + 255)/256, 6);
-    if (gradient)
-      hipLaunchKernelGGL ((boundary_face_values_kernel<false, true, false>), bgrid, dim3 (256), 0, dom->stream,
-			  L, c3 (v), c3 (un), dt, vs, G);
-    else
-      hipLaunchKernelGGL ((boundary_face_values_kernel<false, false, false>), bgrid, dim3 (256), 0, dom->stream,
-			  L, c3 (v), c3 (un), dt, vs, G);
+    const bool bsrc = dom->src[0] != 0. || dom->src[1] != 0. || dom->src[2] != 0.;
+#define BK3(VL_, VS_) hipLaunchKernelGGL ((boundary_face_values_kernel<false, VL_, VS_>), bgrid, dim3 (256), 0, \
+					  dom->stream, L, c3 (v), c3 (un), dt, vs, G)
+    if (gradient) { if (bsrc) BK3 (true, true); else BK3 (true, false); }
+    else          { if (bsrc) BK3 (false, true); else BK3 (false, false); }
+#undef BK3
     GFSHIP_HIP (hipGetLastError ());
     if ((r = comm_exchange_raw (dom, dom->gfv_send, dom->gfv_recv, (size_t) 3*L.n*L.n))) return r;
     dom->n_fused_mpi++;
   }
-#define AK(K_, VL_, MPI_) hipLaunchKernelGGL ((K_<VL_, MPI_>), grid, dim3 (GN), 0, dom->stream, \
-					     L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, G, vs)
-  /* the variants that would take 130-132 VGPRs are held to 128 (two tiles per CU) */
-  if (mpi) { if (gradient) AK (advect3_tiled_kernel_w4, true, true); else AK (advect3_tiled_kernel_w4, false, true); }
-  else if (gradient) AK (advect3_tiled_kernel_w4, true, false);
-  else AK (advect3_tiled_kernel, false, false);
+#define AK(VL_, MPI_, SRC_, WPE_) hipLaunchKernelGGL ((advect3_tiled_kernel<VL_, MPI_, SRC_, WPE_>), grid, dim3 (GN), 0, \
+					    dom->stream, L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, G, vs)
+  const bool srcs = dom->src[0] != 0. || dom->src[1] != 0. || dom->src[2] != 0.;
+  if (srcs) {
+    if (mpi) { if (gradient) AK (true, true, true, 4); else AK (false, true, true, 4); }
+    else if (gradient) AK (true, false, true, 4);
+    else AK (false, false, true, 4);
+  }
+  else if (mpi) { if (gradient) AK (true, true, false, 4); else AK (false, true, false, 4); }
+  else if (gradient) AK (true, false, false, 4);
+  else AK (false, false, false, 1);
 #undef AK
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
