@@ -122,7 +122,12 @@ for key, prefix, bytes_, what in (
         ("residual_norm_kernel", "residual_norm_kernel", 32 * CELLS, "read u, rhs, dia, write res"),
         ("project_correct_kernel<3, true>", "project_correct_kernel<3, true>", 128 * CELLS,
          "approximate projection update: DESIGN.md 4"),
-        ("skew_pack_kernel", "skew_pack_kernel", None, "all levels mixed: see r02_relax_loop inclusive entry"),
+        ("patch_pack_kernel", "patch_pack_kernel", None,
+         "copy into the skewed layout of the 2 x 2 levels (u by prolongation inside the V-cycle, u and rhs "
+         "in the roofline entry), 256^3 and 128^3 mixed"),
+        ("patch_restrict_pack_kernel", "patch_restrict_pack_kernel", None,
+         "restriction of the residual + its copy into the skewed layout, 256^3 and 128^3 mixed"),
+        ("patch_unpack_kernel", "patch_unpack_kernel", None, "copy back (with the correction u += dp at 256^3)"),
         ("particle_list_event_kernel", "particle_list_event_kernel", (1296 + 48) * 2000000,
          "2e6 tracers: 2 stages x 27 cells x 3 components x 8 B gathered + 48 B of state per particle-step"),
         ("particulate_list_event_kernel", "particulate_list_event_kernel", None, "five forces; gather-bound")):
