@@ -137,6 +137,19 @@ int  gfship_residual (gfship_domain * dom, unsigned d, int level,
 int  gfship_norm_residual (gfship_domain * dom, double dt, gfship_field res, gfship_norm * out);
 /* gfs_domain_norm_variable on leaves, src/domain.c:2197-2232 */
 int  gfship_norm_variable (gfship_domain * dom, gfship_field v, gfship_norm * out);
+/* Two properties of the pipelined sweeps behind gfship_relax / _cycle / _solve on 3-D levels of 32^3
+   cells and more, stated here because a caller can run into them:
+   - their tiles hand lines over through 8-byte words in which the value itself is the flag: a word
+     of all ones (0xFFFFFFFFFFFFFFFF, a NaN with that particular payload, which no arithmetic of the
+     solver produces) means "not there yet".  A field that holds exactly that bit pattern in a cell
+     along a tile border makes the hand-off wait run into its bound: the call returns GFSHIP_EHIP with
+     the level in gfship_last_error().  Ordinary NaNs and infinities pass through like any value;
+   - the loop of a periodic level in one launch needs all its tiles (256 workgroups at 256^3) resident
+     on the device at the same time.  The library checks the occupancy and makes one trial run per
+     level; if another process or stream holds compute units later on, the bounded waits time out,
+     that solve fails with GFSHIP_EHIP (the field may then hold partially updated values) and the
+     domain falls back to one launch per sweep for the rest of its life -- results of later calls
+     are unaffected (same arithmetic, same order). */
 /* gfs_poisson_cycle, src/poisson.c:1109-1178 */
 int  gfship_poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
 			   gfship_field u, gfship_field rhs, gfship_field dia, gfship_field res);
