@@ -740,6 +740,7 @@ relax_ring_loop_kernel (SkewLoopArgs A)
 	sX = (m + 1) + XS*1; sLag = mh;
 	if (A.mirror && Q == 0) pNat = A.un + A.L.idx (0, jm, n) - sLag;
       }
+      if (tile == A.fault_tile && sw == 0) sOn = false;     /* fault injection for the test of the error path */
       // the consumer tile of the stream runs on this XCD: plain stores (they stay in the common L2)
       const bool sNear = A.near_mode != 0 && patch_same_xcd (A, g == 0 ? tJp : g == 1 ? tKp : g == 2 ? tJm : tKm);
       // ... and every lane writes the row of the skewed copy that the compute lane of the same number

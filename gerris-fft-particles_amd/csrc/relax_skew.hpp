@@ -90,6 +90,7 @@ struct SkewLoopArgs {
   const unsigned * arm_cum;
   // XCD of the workgroup that claimed each tile (armed all ones with the granules; relax_patch_loop.hip)
   unsigned * tile_xcd;
+  int fault_tile;          // test of the error path (GFSHIP_FAULT_DROP_HANDOFF=tile): that tile publishes nothing in sweep 0
   int near_mode;           // stores towards a consumer on the same XCD: 0 agent scope like the others, 1 plain, 2 workgroup scope
 };
 

@@ -858,6 +858,7 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   A.xticket = (unsigned *) S->ctl + 6;
   A.per_xcd = 0;
   A.near_mode = 0;
+  { const char * e = getenv ("GFSHIP_FAULT_DROP_HANDOFF"); A.fault_tile = e ? atoi (e) : -1; }
   if (patch_level (dom, level)) {
     /* the 2 x 2 kernels, GFSHIP_XCD_SCOPE=1: XCD blocks + narrower-scope stores towards consumers on
        the same XCD (tickets in the armed header).  Measured at 256^3 on one box: blocks alone 0.51-0.52

@@ -657,3 +657,41 @@ def test_every_sweep_implementation_bit_exact(impl, level, kind, use_dia, monkey
         assert np.array_equal(_interior(f["res"][0].leaf(), dim),
                               _interior(f["res"][1].download(), dim))
     gd.destroy()
+
+
+def test_a_hand_off_that_never_arrives_is_reported_and_the_domain_keeps_working(monkeypatch):
+    """include/gfship.h: the tiles of a fused relax loop wait for each other's lines with bounded waits.
+    A hand-off that never comes (here: tile 0 of the 128^3 level publishes nothing in its first sweep,
+    GFSHIP_FAULT_DROP_HANDOFF) becomes an error of the solve instead of a hang; the error is not
+    sticky: the same domain then solves the same problem (with one launch per sweep) bit for bit."""
+    L = O.lib()
+    dim, level = 3, 7
+    side, bck = SIDES["periodic"]
+    rng = np.random.default_rng(99)
+    od, gd = _pair(dim, level, side)
+    L.go_poisson_coefficients(od.ptr)
+    gd.poisson_coefficients()
+    f = _rand_fields(od, gd, ["u", "rhs", "dia", "res"], rng)
+    for l in range(level + 1):
+        f["dia"][0].level(l)[...] = 0.
+        f["dia"][1].fill(0., l)
+    u0 = f["u"][0].leaf().copy()
+    op, gp = od.params(), gd.params()
+    for p in (op, gp):
+        p.tolerance, p.nitermin, p.nitermax = 1e-30, 1, 1
+    gd.bc(f["u"][1])
+    gd.poisson_solve(gp, f["u"][1], f["rhs"][1], f["res"][1], f["dia"][1], 1.)     # warm: trial runs done
+    monkeypatch.setenv("GFSHIP_FAULT_DROP_HANDOFF", "0")
+    f["u"][1].upload(u0)
+    gd.bc(f["u"][1])
+    with pytest.raises(gfship.GfshipError, match="hand-off"):
+        gd.poisson_solve(gp, f["u"][1], f["rhs"][1], f["res"][1], f["dia"][1], 1.)
+    monkeypatch.delenv("GFSHIP_FAULT_DROP_HANDOFF")
+    # the same domain, the same data: equal to the oracle
+    f["u"][1].upload(u0)
+    L.go_bc(f["u"][0].ptr, f["u"][0].ptr, level)
+    gd.bc(f["u"][1])
+    L.go_poisson_solve(od.ptr, C.byref(op), f["u"][0].ptr, f["rhs"][0].ptr, f["res"][0].ptr, f["dia"][0].ptr, 1.)
+    gd.poisson_solve(gp, f["u"][1], f["rhs"][1], f["res"][1], f["dia"][1], 1.)
+    assert np.array_equal(_interior(f["u"][0].leaf(), dim), _interior(f["u"][1].download(), dim))
+    assert gp.residual.infty == op.residual.infty
