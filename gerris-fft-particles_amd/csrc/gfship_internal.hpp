@@ -225,7 +225,7 @@ int launch_correct (gfship_domain * dom, int level, double * u, const double * d
 int launch_fill (gfship_domain * dom, int level, double * a, double value);
 int launch_residual_norm (gfship_domain * dom, int level, const double * u, const double * rhs,
 			  const double * dia, double * res, double scale, double weight,
-			  double * out /* 5 values, or nullptr: left in h_pinned[8..12], not waited for */);
+			  double * out /* 5 values, or nullptr: left in h_pinned[8..12], not waited for */, bool dia_zero = false);
 int launch_norm_async (gfship_domain * dom, int level, const double * a, double scale, double weight);
 int launch_norm (gfship_domain * dom, int level, const double * a, double scale, double weight,
 		 double out[5] /* bias(sum of scaled), first, second, infty, raw sum */);

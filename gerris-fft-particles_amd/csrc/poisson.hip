@@ -136,7 +136,8 @@ static int residual_and_norm (gfship_domain * dom, double dt, Field * U, Field *
   }
   const double size = 1./dom->lay[L].n;
   double s[5];
-  int r = launch_residual_norm (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L], 1.*size*size, 1., s);
+  int r = launch_residual_norm (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L], 1.*size*size, 1., s,
+				D->zero[L]);
   if (r) return r;
   return norm_residual_finish (dom, dt, s, out);
 }
@@ -446,7 +447,7 @@ int gfship_poisson_solve (gfship_domain * dom, gfship_multilevel_params * par,
       if ((r = launch_norm_async (dom, L, S->lev[L], 1.*size*size, 1.))) return r;
     }
     else if ((r = launch_residual_norm (dom, L, U->lev[L], R->lev[L], D->lev[L], S->lev[L], 1.*size*size,
-					1., nullptr)))
+					1., nullptr, D->zero[L])))
       return r;
   }
   else {

@@ -1315,7 +1315,7 @@ residual_norm_kernel (Layout L, const double * __restrict__ u, const double * __
     const long row = L.idx (1, j, k);
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       const long c = row + i;
-      double a = dia[c], b = 0.;
+      double a = dia ? dia[c] : 0., b = 0.;     /* dia == nullptr: the level holds zeros (not read) */
       a += 1.; b += 1.*u[c + 1];
       a += 1.; b += 1.*u[c - 1];
       a += 1.; b += 1.*u[c + L.sy];
@@ -1355,7 +1355,7 @@ residual_norm_kernel (Layout L, const double * __restrict__ u, const double * __
 // the caller synchronises later, launch_norm_async's convention)
 int launch_residual_norm (gfship_domain * dom, int level, const double * u, const double * rhs,
 			  const double * dia, double * res, double scale, double weight,
-			  double * out)
+			  double * out, bool dia_zero)
 {
   const Layout & L = dom->lay[level];
   if (!power_of_two (scale)) {
@@ -1379,10 +1379,10 @@ int launch_residual_norm (gfship_domain * dom, int level, const double * u, cons
   double * result = out ? dom->h_pinned : dom->h_pinned + 8;
   if (dom->dim == 3)
     hipLaunchKernelGGL (residual_norm_kernel<3>, dim3 (nblocks), dim3 (block), 0, dom->stream, L, u,
-			rhs, dia, res, 1./scale, weight, partial);
+			rhs, dia_zero ? nullptr : dia, res, 1./scale, weight, partial);
   else
     hipLaunchKernelGGL (residual_norm_kernel<2>, dim3 (nblocks), dim3 (block), 0, dom->stream, L, u,
-			rhs, dia, res, 1./scale, weight, partial);
+			rhs, dia_zero ? nullptr : dia, res, 1./scale, weight, partial);
   hipLaunchKernelGGL (norm_final_kernel, dim3 (1), dim3 (256), 0, dom->stream,
 		      partial, nblocks, result);
   GFSHIP_HIP (hipGetLastError ());
