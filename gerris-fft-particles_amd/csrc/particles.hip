@@ -359,9 +359,11 @@ __device__ __forceinline__ double center_gradient (const double * __restrict__ v
 }
 
 // compute_inertial_force, :285-336
+// (fvel: the fluid velocity interpolated at the particle, computed once per particle and shared with
+// the lift and drag forces: the same gfs_interpolate of the same fields)
 template <int DIM>
 __device__ void inertial_force (const ParticulateArgs & A, const int cell[3], const double p[3],
-				long idx, double force[3])
+				long idx, const double fvel[3], double force[3])
 {
   const Layout & L = A.P.L;
   const long off[3] = { 1, (long) L.sy, (long) L.sz };
@@ -372,7 +374,7 @@ __device__ void inertial_force (const ParticulateArgs & A, const int cell[3], co
     return;
 #pragma unroll
   for (int c = 0; c < DIM; c++) {
-    const double fluid_vel = interpolate<DIM> (L, A.P.u[c], cell, p);
+    const double fluid_vel = fvel[c];
     const double fluid_veln = interpolate<DIM> (L, A.uold[c], cell, p);
     force[c] = fluid_rho*(fluid_vel - fluid_veln)/A.P.dt;
   }
@@ -441,14 +443,30 @@ particulate_list_event_kernel (ParticulateArgs A, int depth)
   double mass = A.mass[o];
   const double volume = A.volume[o];
   double pf[3] = { 0., 0., 0. };
+  // every force is a function of the state at the start of the event: what several of them need --
+  // the fluid velocity at the particle, Du/Dt -- is evaluated once (the reference re-evaluates the
+  // same expressions per force: same bits)
+  bool need_fvel = false, need_dudt = false;
+  for (int f = 0; f < A.nforces; f++) {
+    need_fvel = need_fvel || A.forces[f] != FORCE_BUOY;
+    need_dudt = need_dudt || A.forces[f] == FORCE_INERTIAL || A.forces[f] == FORCE_ADDEDMASS;
+  }
+  double fvel[3] = { 0., 0., 0. }, dudt[3] = { 0., 0., 0. };
+  if (need_fvel) {
+#pragma unroll
+    for (int c = 0; c < DIM; c++)
+      fvel[c] = interpolate<DIM> (L, P.u[c], cell, p);
+  }
+  if (need_dudt)
+    inertial_force<DIM> (A, cell, p, idx, fvel, dudt);
   for (int f = 0; f < A.nforces; f++) {
     double force[3] = { 0., 0., 0. };
     switch (A.forces[f]) {
     case FORCE_INERTIAL:
-      inertial_force<DIM> (A, cell, p, idx, force);
+      force[0] = dudt[0]; force[1] = dudt[1]; force[2] = dudt[2];
       break;
     case FORCE_ADDEDMASS: {     // compute_addedmass_force, :363-427
-      inertial_force<DIM> (A, cell, p, idx, force);
+      force[0] = dudt[0]; force[1] = dudt[1]; force[2] = dudt[2];
       const double cm = A.coef[f] ? A.coef[f][q] : 0.5;
 #pragma unroll
       for (int c = 0; c < DIM; c++)
@@ -460,7 +478,7 @@ particulate_list_event_kernel (ParticulateArgs A, int depth)
       double rel[3] = { 0., 0., 0. }, vort[3];
 #pragma unroll
       for (int c = 0; c < DIM; c++)
-	rel[c] = interpolate<DIM> (L, P.u[c], cell, p) - vel[c];
+	rel[c] = fvel[c] - vel[c];
       if (DIM == 2) {
 	vort[0] = 0.; vort[1] = 0.;
 	vort[2] = (center_gradient (P.u[1], idx, off[0]) - center_gradient (P.u[0], idx, off[1]))/size;
@@ -486,7 +504,7 @@ particulate_list_event_kernel (ParticulateArgs A, int depth)
       double rel[3] = { 0., 0., 0. };
 #pragma unroll
       for (int c = 0; c < DIM; c++)
-	rel[c] = interpolate<DIM> (L, P.u[c], cell, p) - vel[c];
+	rel[c] = fvel[c] - vel[c];
       const double dia = A.dia[o];
       const double norm = DIM == 3 ? sqrt (rel[0]*rel[0] + rel[1]*rel[1] + rel[2]*rel[2]) :
 	sqrt (rel[0]*rel[0] + rel[1]*rel[1]);
