@@ -534,18 +534,22 @@ struct LatticeCycleArgs {
 
 typedef __attribute__((address_space(1))) unsigned long long lat_gu64;
 
+// The layers travel as agent-scope atomics (coherent per location across the XCDs, no cache to flush):
+// a thread only has to wait until its own stores have been acknowledged (s_waitcnt vmcnt (0)) before
+// the workgroup's barrier, then one thread announces the workgroup and waits for the others.  (With
+// __threadfence () on both sides -- a write-back and an invalidate of the whole L2 each -- a barrier
+// cost 8 us.)
 __device__ __forceinline__ void lattice_barrier (unsigned * bar, unsigned & target, int nboxes)
 {
-  __threadfence ();                  /* the layers of this workgroup are visible device-wide ... */
+  asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads ();
   if (threadIdx.x == 0) {
     target += (unsigned) nboxes;
-    __hip_atomic_fetch_add (bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load (bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
-      __builtin_amdgcn_s_sleep (2);
+    __hip_atomic_fetch_add (bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load (bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+      __builtin_amdgcn_s_sleep (1);
   }
   __syncthreads ();
-  __threadfence ();                  /* ... and those of the others are read from memory */
 }
 
 template <int DIM>
