@@ -106,6 +106,30 @@ def cpu_relax_layouts(level=7, sweeps=4):
             "aos_bytes_per_cell": int(L.go_aos_bytes_per_cell())}
 
 
+def measure_vcycle(dom, u, rhs, dia, n):
+    """one whole gfs_poisson_cycle of the box as the projections run it (every level: restrictions,
+    relax loops with their copies, prolongations, the correction, the new residual), wall clock over
+    10 cycles enqueued back to back"""
+    res = dom.variable()
+    dia.fill(0.)
+    dom.bc(u)
+    dom.residual(u, rhs, dia, res)
+    par = dom.params()
+    par.depth = dom.depth
+    dom.poisson_cycle(par, u, rhs, dia, res)
+    dom.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        dom.poisson_cycle(par, u, rhs, dia, res)
+    dom.synchronize()
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    # algorithmic bytes of a cycle: per level 4 sweeps x 24 B + residual 32 B + restriction / prolongation
+    # / correction 8 + 8 + 24 B per cell; the levels below add 1/7 of the leaf level
+    cells = n ** 3 * 8. / 7.
+    return {"ms": ms, "algorithmic_GBps": cells * (4 * 24 + 32 + 40) / (ms * 1e-3) / 1e9,
+            "note": "gfship_poisson_cycle, all levels, 10 back to back"}
+
+
 def measure_roofline(dom, args, n):
     u, rhs, dia = dom.variable(), dom.variable(), dom.variable()
     rng = np.random.default_rng(0)
@@ -147,7 +171,8 @@ def measure_roofline(dom, args, n):
                                   "achieved": bytes_loop / (ms_incl * 1e-3) / 1e9,
                                   "frac": bytes_loop / (ms_incl * 1e-3) / 1e9 / HBM_PEAK_GBS},
                     "ms_per_sweep_in_loop": ms_loop / nrelax,
-                    "ms_single_sweep_launch": ms_sweep}
+                    "ms_single_sweep_launch": ms_sweep,
+                    "vcycle": measure_vcycle(dom, u, rhs, dia, n)}
     else:
         achieved = RELAX_BYTES_PER_CELL * n ** 3 / (ms_sweep * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
