@@ -553,8 +553,16 @@ int gfship_coarse_init (gfship_sim * s)
   GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
   std::vector<Field *> v;
   sim_variables (s, v);
-  for (Field * F : v) F->coarse_stale = false;
-  return launch_coarse_init (s->dom, v.data (), (int) v.size ());
+  /* Pmac is not touched between this point of the loop and the MAC projection of the next step:
+     its non-leaf values, whenever somebody reads them (a snapshot, a download of a coarse level:
+     coarse_flush), are the ones computed here -- so they are computed then, not in every step */
+  Field * pmac = get_field (s->dom, s->pmac);
+  std::vector<Field *> now;
+  for (Field * F : v) {
+    if (F == pmac) F->coarse_stale = true;
+    else { F->coarse_stale = false; now.push_back (F); }
+  }
+  return launch_coarse_init (s->dom, now.data (), (int) now.size ());
 }
 
 int gfship_sim_start (gfship_sim * s)
