@@ -106,13 +106,29 @@ int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, g
   return GFSHIP_OK;
 }
 
-// gfs_correct_centered_velocities, src/timestep.c:498-530
-int correct_centered_velocities (gfship_sim * s, const gfship_field g[3], double dt)
+// gfs_correct_centered_velocities, src/timestep.c:498-530.  with_coarse: the caller's next operation is
+// gfs_cell_coarse_init: the level below the leaves of U, V, W is then filled by the same pass (3-D)
+int correct_centered_velocities (gfship_sim * s, const gfship_field g[3], double dt,
+				 bool * with_coarse = nullptr)
 {
+  gfship_domain * dom = s->dom;
   double * u[3], * gp[3];
   ptrs3 (s, s->u, u);
   ptrs3 (s, g, gp);
-  TRY (launch_correct_centered (s->dom, u, gp, dt));
+  if (with_coarse && dom->dim == 3 && dom->depth >= 1) {
+    double * uc[3];
+    for (int c = 0; c < 3; c++) {
+      Field * F = get_field (dom, s->u[c]);
+      uc[c] = F->lev[dom->depth - 1];
+      F->zero[dom->depth - 1] = false;
+    }
+    TRY (launch_correct_centered_coarse (dom, u, gp, dt, uc));
+    *with_coarse = true;
+  }
+  else {
+    if (with_coarse) *with_coarse = false;
+    TRY (launch_correct_centered (dom, u, gp, dt));
+  }
   TRY (bc_leaf_vector (s, s->u));
   return GFSHIP_OK;
 }
@@ -548,21 +564,39 @@ int gfship_sim_set_tracer_gradient (gfship_sim * s, int t, int gradient)
   return GFSHIP_OK;
 }
 
+static int coarse_init (gfship_sim * s, bool u_done);
+
 int gfship_coarse_init (gfship_sim * s)
 {
   GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  return coarse_init (s, false);
+}
+
+// u_done: the level below the leaves of U, V, W has just been filled (correct_centered_coarse_kernel)
+static int coarse_init (gfship_sim * s, bool u_done)
+{
   std::vector<Field *> v;
   sim_variables (s, v);
   /* Pmac is not touched between this point of the loop and the MAC projection of the next step:
      its non-leaf values, whenever somebody reads them (a snapshot, a download of a coarse level:
      coarse_flush), are the ones computed here -- so they are computed then, not in every step */
   Field * pmac = get_field (s->dom, s->pmac);
-  std::vector<Field *> now;
+  std::vector<Field *> now, vel;
   for (Field * F : v) {
+    bool is_u = false;
+    for (int c = 0; c < s->dom->dim; c++)
+      if (F == get_field (s->dom, s->u[c])) is_u = true;
     if (F == pmac) F->coarse_stale = true;
-    else { F->coarse_stale = false; now.push_back (F); }
+    else {
+      F->coarse_stale = false;
+      F->coarse_valid = true;
+      if (u_done && is_u) vel.push_back (F); else now.push_back (F);
+    }
   }
-  return launch_coarse_init (s->dom, now.data (), (int) now.size ());
+  TRY (launch_coarse_init (s->dom, now.data (), (int) now.size ()));
+  if (!vel.empty () && s->dom->depth >= 2)
+    TRY (launch_coarse_init_from (s->dom, vel.data (), (int) vel.size (), s->dom->depth - 2));
+  return GFSHIP_OK;
 }
 
 int gfship_sim_start (gfship_sim * s)
@@ -645,11 +679,12 @@ int gfship_sim_step (gfship_sim * s)
   }
 
   TRY (gfship_centered_velocity_advection (s, s->gmac, s->i > 0 ? gc : s->gmac));
-  TRY (correct_centered_velocities (s, s->i > 0 ? gc : s->gmac, - s->advection_params.dt));
+  bool u_coarse = false;
+  TRY (correct_centered_velocities (s, s->i > 0 ? gc : s->gmac, - s->advection_params.dt, &u_coarse));
 
   /* gfs_cell_coarse_init at this point of the loop (src/simulation.c:530-533): the non-leaf
      values are those of the state before the approximate projection, so it cannot be deferred */
-  TRY (gfship_coarse_init (s));
+  TRY (coarse_init (s, u_coarse));
 
   TRY (gfship_approximate_projection (s, &s->approx_projection_params, s->advection_params.dt,
 				      s->p, s->g));

@@ -154,6 +154,41 @@ correct_centered_kernel (Layout L, Ptr3 u, CPtr3 g, double dt)
     u.p[cc][c] -= g.p[cc][c]*dt;
 }
 
+// K11b together with the first level of gfs_cell_coarse_init (src/adaptive.c:43-58) of the corrected
+// velocities: one thread per cell of the level below the leaves corrects its eight children and
+// leaves their average (children in child-id order: bit 0 -> +x, bit 1 -> -y, bit 2 -> -z) in the
+// parent -- the pass over U, V, W that coarse_init_kernel would make right afterwards is saved.
+__global__ void __launch_bounds__(256)
+correct_centered_coarse_kernel (Layout L, Layout Lc, Ptr3 u, CPtr3 g, double dt, Ptr3 uc)
+{
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  int i = blockIdx.x*blockDim.x + threadIdx.x + 1;
+  int j = blockIdx.y + 1, k = blockIdx.z + 1;
+  if (i > Lc.n) return;
+#pragma unroll
+  for (int cc = 0; cc < 3; cc++) {
+    double x[2][2][2];        // [dz: ck = 2k, 2k - 1][dy: cj = 2j, 2j - 1][dx: ci = 2i - 1, 2i]
+#pragma unroll
+    for (int dz = 0; dz < 2; dz++)
+#pragma unroll
+      for (int dy = 0; dy < 2; dy++) {
+	const long c = L.idx (2*i - 1, 2*j - dy, 2*k - dz);       /* even index: 16-byte aligned */
+	const d2 a = *(const d2 *) (u.p[cc] + c), b = *(const d2 *) (g.p[cc] + c);
+	d2 r;
+	r.x = a.x - b.x*dt; r.y = a.y - b.y*dt;
+	*(d2 *) (u.p[cc] + c) = r;
+	x[dz][dy][0] = r.x; x[dz][dy][1] = r.y;
+      }
+    double val = 0., sa = 0.;
+#pragma unroll
+    for (int id = 0; id < 8; id++) {
+      val += x[(id >> 2) & 1][(id >> 1) & 1][id & 1]*1.;
+      sa += 1.;
+    }
+    uc.p[cc][Lc.idx (i, j, k)] = val/sa;
+  }
+}
+
 // K10 + K11 in one pass over the pressure: correct_normal_velocity on every face, the centred
 // gradient of every cell (both kernels above, same expressions: each thread recomputes the
 // gradient of its - faces instead of reading it back), optionally K11b on the centred velocities
@@ -1388,6 +1423,18 @@ int launch_correct_centered (gfship_domain * dom, double * const u[3], double * 
   return GFSHIP_OK;
 }
 
+int launch_correct_centered_coarse (gfship_domain * dom, double * const u[3], double * const g[3],
+				    double dt, double * const uc[3])
+{
+  const Layout & L = dom->lay[dom->depth], & Lc = dom->lay[dom->depth - 1];
+  dim3 grid, block;
+  cell_grid (Lc, &grid, &block);
+  hipLaunchKernelGGL (correct_centered_coarse_kernel, grid, block, 0, dom->stream, L, Lc, m3 (u), c3 (g), dt,
+		      m3 (uc));
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
 int launch_advected_face_values (gfship_domain * dom, const double * v, double * const u[3],
 				 double * const un[3], double dt, int use_centered, int gradient,
 				 double * const fv[6], int cmask, double visc, double gsrc)
@@ -1690,9 +1737,15 @@ int launch_cfl (gfship_domain * dom, double * const u[3], double * const un[3],
 
 int launch_coarse_init (gfship_domain * dom, Field * const * v, int nf)
 {
+  return launch_coarse_init_from (dom, v, nf, dom->depth - 1);
+}
+
+// the levels top, top - 1, ... 0 from the level above each (top = depth - 1: everything)
+int launch_coarse_init_from (gfship_domain * dom, Field * const * v, int nf, int top)
+{
   for (int f0 = 0; f0 < nf; f0 += 8) {
     int m = nf - f0 < 8 ? nf - f0 : 8;
-    for (int l = dom->depth - 1; l >= 0; l--) {
+    for (int l = top; l >= 0; l--) {
       const Layout & Lc = dom->lay[l], & Lf = dom->lay[l + 1];
       CoarseArgs A;
       A.nf = m;

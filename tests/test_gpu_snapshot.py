@@ -62,6 +62,10 @@ def test_restart_from_a_snapshot_continues_bit_for_bit(make, level, nsteps):
         gs.step()
     variables = [gs.p, gs.pmac] + list(gs.u)
     image = gd.snapshot_tree(variables)
+    # every level of every variable as the oracle holds it at this point of the loop: the non-leaf
+    # values are those of gfs_cell_coarse_init before the last approximate projection (U, V, W: filled
+    # by the pass that corrects the leaves; Pmac: computed now, on demand; P: by coarse_init_kernel)
+    assert image == osim.dom.snapshot_tree([osim.p, osim.pmac] + list(osim.u[:osim.dim]))
     t, i = gs.t, gs.i
     for _ in range(nsteps):
         osim.step()
