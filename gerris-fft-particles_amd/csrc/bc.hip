@@ -259,43 +259,9 @@ static int halo_copy (gfship_domain * dom, double * a, int level, int side, doub
 // ---------------------------------------------------------------------------------------------
 // The BC application of up to three variables at once (the velocity components, the components of
 // a pressure gradient: gfs_domain_bc is called for them one after the other, src/timestep.c:
-// 85,527): one launch for the local sides, and on MPI sides one pack kernel, ONE message per side
-// carrying the layers of all of them, one unpack kernel.
+// 85,527): on MPI sides one pack kernel, ONE message per side carrying the layers of all of them,
+// one unpack kernel.
 // ---------------------------------------------------------------------------------------------
-struct BcMulti { BcDesc b[3]; double * a[3]; int nf; };
-
-__global__ void __launch_bounds__(256)
-bc_multi_kernel (Layout L, BcMulti M)
-{
-  const int n = L.n;
-  const int nface = L.dim == 3 ? n*n : n;
-  int f = blockIdx.x*blockDim.x + threadIdx.x;
-  int d = blockIdx.y;
-  const int q = blockIdx.z;
-  if (f >= nface) return;
-  const BcDesc & bc = M.b[q];
-  double * __restrict__ a = M.a[q];
-  if (bc.side[d] == GFSHIP_SIDE_EXTERNAL) return;
-  int c = d/2;
-  int t1 = f % n + 1, t2 = L.dim == 3 ? f / n + 1 : 0;
-  int ijk[3] = { 0, 0, 0 };
-  int ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
-  ijk[c] = (d & 1) ? 1 : n;
-  ijk[ta] = t1;
-  if (L.dim == 3) ijk[tb] = t2;
-  long o = c == 0 ? 1 : c == 1 ? L.sy : L.sz;
-  if (d & 1) o = - o;
-  long nb = L.idx (ijk[0], ijk[1], ijk[2]);
-  double v;
-  if (bc.side[d] == GFSHIP_SIDE_PERIODIC)
-    v = a[nb - (long) (n - 1)*o];
-  else {
-    double val = (!bc.homogeneous && bc.val[d]) ? bc.val[d][f] : 0.;
-    v = ghost_value_bc (bc.type[d], bc.component, c, a[nb], bc.homogeneous, val, 1./n);
-  }
-  a[nb + o] = v;
-}
-
 struct HaloMulti { int n; int side[6]; double * buf[6]; double * a[3]; int nf; };
 
 // blockIdx.y = entry of the side list, blockIdx.z = variable: its layer sits at buf + z nface
@@ -345,32 +311,9 @@ int launch_bc_multi (gfship_domain * dom, Field * const * v, int nf, int level, 
   const Layout & L = dom->lay[level];
   const int nface = dom->dim == 3 ? L.n*L.n : L.n;
   const int block = nface >= 256 ? 256 : 64;
-  bool local = false;
-  for (int d = 0; d < 2*dom->dim; d++)
-    if (dom->side[d] != GFSHIP_SIDE_EXTERNAL) local = true;
-  if (local) {
-    BcMulti M;
-    M.nf = nf;
-    for (int q = 0; q < nf; q++) {
-      for (int d = 0; d < 6; d++) {
-	M.b[q].side[d] = dom->side[d];
-	M.b[q].type[d] = v[q]->bc[d];
-	M.b[q].val[d] = (level == dom->depth) ? v[q]->bcval[d] : nullptr;
-      }
-      if (!homogeneous && level != dom->depth)
-	for (int d = 0; d < 2*dom->dim; d++)
-	  GFSHIP_CHECK (!(dom->side[d] == GFSHIP_SIDE_BOUNDARY && v[q]->bc[d] != GFSHIP_BC_SYMMETRY &&
-			  v[q]->bcval[d]),
-			GFSHIP_EUNSUPPORTED,
-			"non-homogeneous Dirichlet/Neumann values are held on the leaf level only");
-      M.b[q].component = v[q]->component;
-      M.b[q].homogeneous = homogeneous;
-      M.a[q] = v[q]->lev[level];
-    }
-    hipLaunchKernelGGL (bc_multi_kernel, dim3 ((nface + block - 1)/block, 2*dom->dim, nf), dim3 (block), 0,
-			dom->stream, L, M);
-    GFSHIP_HIP (hipGetLastError ());
-  }
+  /* the local sides: one launch per variable (measured: a three-variable kernel is no faster) */
+  for (int q = 0; q < nf; q++)
+    if (int r = launch_bc_kernel (dom, v[q], v[q], level, homogeneous)) return r;
   if (!dom->has_external)
     return GFSHIP_OK;
   if (!dom->comm || nf == 1) {

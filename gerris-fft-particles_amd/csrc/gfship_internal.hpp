@@ -239,6 +239,7 @@ int launch_correct_centered (gfship_domain * dom, double * const u[3], double * 
 int launch_correct_centered_coarse (gfship_domain * dom, double * const u[3], double * const g[3],
 				    double dt, double * const uc[3]);
 int launch_coarse_init_from (gfship_domain * dom, Field * const * v, int nf, int top);
+int launch_coarse_init_levels (gfship_domain * dom, Field * const * v, int nf, int top, int bottom);
 int launch_advected_face_values (gfship_domain * dom, const double * v, double * const u[3],
 				 double * const un[3], double dt, int use_centered, int gradient,
 				 double * const fv[6], int cmask, double visc = 0., double gsrc = 0.);

@@ -593,9 +593,13 @@ static int coarse_init (gfship_sim * s, bool u_done)
       if (u_done && is_u) vel.push_back (F); else now.push_back (F);
     }
   }
-  TRY (launch_coarse_init (s->dom, now.data (), (int) now.size ()));
-  if (!vel.empty () && s->dom->depth >= 2)
-    TRY (launch_coarse_init_from (s->dom, vel.data (), (int) vel.size (), s->dom->depth - 2));
+  if (vel.empty ())
+    return launch_coarse_init (s->dom, now.data (), (int) now.size ());
+  /* the level below the leaves for the others, then every variable together on the levels below */
+  TRY (launch_coarse_init_levels (s->dom, now.data (), (int) now.size (), s->dom->depth - 1, s->dom->depth - 1));
+  now.insert (now.end (), vel.begin (), vel.end ());
+  if (s->dom->depth >= 2)
+    TRY (launch_coarse_init_levels (s->dom, now.data (), (int) now.size (), s->dom->depth - 2, 0));
   return GFSHIP_OK;
 }
 

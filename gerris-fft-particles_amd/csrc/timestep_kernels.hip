@@ -1740,12 +1740,17 @@ int launch_coarse_init (gfship_domain * dom, Field * const * v, int nf)
   return launch_coarse_init_from (dom, v, nf, dom->depth - 1);
 }
 
-// the levels top, top - 1, ... 0 from the level above each (top = depth - 1: everything)
+// the levels top, top - 1, ... bottom from the level above each (depth - 1 .. 0: everything)
 int launch_coarse_init_from (gfship_domain * dom, Field * const * v, int nf, int top)
+{
+  return launch_coarse_init_levels (dom, v, nf, top, 0);
+}
+
+int launch_coarse_init_levels (gfship_domain * dom, Field * const * v, int nf, int top, int bottom)
 {
   for (int f0 = 0; f0 < nf; f0 += 8) {
     int m = nf - f0 < 8 ? nf - f0 : 8;
-    for (int l = top; l >= 0; l--) {
+    for (int l = top; l >= bottom; l--) {
       const Layout & Lc = dom->lay[l], & Lf = dom->lay[l + 1];
       CoarseArgs A;
       A.nf = m;
