@@ -236,3 +236,66 @@ def test_spectra_of_a_lattice_of_boxes_equal_those_of_the_whole_domain():
         assert np.abs(Ek - Ek0).max() <= 1e-12 * Etot0
         F, ks = r["sp"]
         assert ks == ks0 and np.abs(F - F0).max() <= 1e-13
+
+
+def test_lattice_flow_2d_device_boxes_equal_oracle_boxes():
+    """2 x 2 boxes of 32^2 in 2-D: the lattice-wide coarse cycle (lattice_cycle_kernel<2>), the BC of the
+    vector variables and the general Godunov kernels with MPI sides, against oracle boxes"""
+    import torch
+    nboxes, level, nsteps = 4, 5, 3
+    n = 1 << level
+    grid = D.BoxGrid(nboxes, 2)
+    L = O.lib()
+    dev = torch.device("cuda", 0)
+    tp = 2. * np.pi
+
+    def field(rank):
+        X, Y = M.global_centres(grid, rank, n, dim=2)
+        u = np.sin(tp * X) * np.cos(tp * Y) + 0.3 * np.cos(tp * (Y + 0.1)) + 0.25
+        v = -np.cos(tp * X) * np.sin(tp * Y) + 0.2 * np.sin(tp * (X + 0.3))
+        return u + 0. * v, v + 0. * u
+
+    def oworker(rank, fabric):
+        sim = O.Sim(2, level, grid.sides(rank))
+        hooks = M.OracleHooks(L, sim.dom.ptr, 2, M.LocalTransport(grid, rank, fabric))
+        for c, a in enumerate(field(rank)):
+            sim.u[c].interior()[...] = a
+        sim.set_time(end=10.)
+        sim.start()
+        for _ in range(nsteps):
+            sim.step()
+        out = dict(u=sim.u[0].interior().copy(), v=sim.u[1].interior().copy(), p=sim.p.interior().copy(),
+                   dt=sim.dt, niter=(sim.projection_params.niter, sim.approx_projection_params.niter))
+        del hooks
+        return out
+
+    def dworker(rank, fabric):
+        gd = gfship.Domain(2, level, grid.sides(rank))
+        gs = gfship.Simulation(gd)
+        hooks = D.DeviceHooks(gd, M.LocalTransport(grid, rank, fabric, dev))
+        for c, a in enumerate(field(rank)):
+            b = np.zeros((n + 2,) * 2)
+            b[1:-1, 1:-1] = a
+            gs.u[c].upload(b)
+        gs.set_time(end=10.)
+        gs.start()
+        for _ in range(nsteps):
+            gs.step()
+        gd.synchronize()
+        i2 = (slice(1, -1),) * 2
+        out = dict(u=gs.u[0].download()[i2], v=gs.u[1].download()[i2], p=gs.p.download()[i2], dt=gs.dt,
+                   niter=(gs.projection_params.niter, gs.approx_projection_params.niter),
+                   cycles=gd.path_counts()[0])
+        del hooks
+        gs.destroy()
+        gd.destroy()
+        return out
+
+    ora = M.run_boxes(nboxes, oworker)
+    dev_ = M.run_boxes(nboxes, dworker)
+    for rank, (d, o) in enumerate(zip(dev_, ora)):
+        for name in ("u", "v", "p"):
+            assert np.array_equal(d[name], o[name]), (rank, name)
+        assert d["dt"] == o["dt"] and tuple(d["niter"]) == tuple(o["niter"])
+        assert d["cycles"] >= 2 * nsteps
+    assert not np.array_equal(dev_[0]["u"], dev_[1]["u"])
