@@ -184,6 +184,8 @@ int call_reduce_norm (gfship_domain * dom, double * sums, int nsum, double * mx)
 // transport.hip
 int comm_exchange (gfship_domain * dom, double * a, int level, int kind);
 int comm_exchange_raw (gfship_domain * dom, double * const send[6], double * const recv[6], size_t count);
+int comm_migrate (gfship_domain * dom, int rs, const int nsend[6], const double * const send[6],
+		  int nrecv[6], std::vector<double> recv[6]);
 int comm_allgather (gfship_domain * dom, const double * send, double * recv, size_t count);
 int multi_buffers (gfship_domain * dom);
 int launch_bc_multi (gfship_domain * dom, Field * const * v, int nf, int level, int homogeneous);

@@ -952,8 +952,17 @@ static int particles_migrate (gfship_particles * pl)
     send[d].swap (sorted);
     sp[d] = send[d].data ();
   }
-  int r = pl->migrate (pl->migrate_ctx, nsend, sp, nrecv, rp);
-  GFSHIP_CHECK (r == 0, GFSHIP_EHIP, "the particle migration hook failed (%d)", r);
+  int r;
+  std::vector<double> inbox[6];
+  if (pl->migrate) {
+    r = pl->migrate (pl->migrate_ctx, nsend, sp, nrecv, rp);
+    GFSHIP_CHECK (r == 0, GFSHIP_EHIP, "the particle migration hook failed (%d)", r);
+  }
+  else {
+    /* the library's communicator */
+    if ((r = comm_migrate (dom, rs, nsend, sp, nrecv, inbox))) return r;
+    for (int d = 0; d < 6; d++) rp[d] = inbox[d].data ();
+  }
   int total = 0;
   for (int d = 0; d < 6; d++) total += nrecv[d];
   if (total == 0) return GFSHIP_OK;
@@ -1217,7 +1226,8 @@ int gfship_particles_download_particulate (gfship_particles * pl, double * vel, 
 int gfship_particle_list_event (gfship_particles * pl)
 {
   GFSHIP_CHECK (pl != nullptr, GFSHIP_EINVAL, "null particle list");
-  if (pl->n == 0 && !pl->migrate) return GFSHIP_OK;
+  const bool migrates = pl->migrate != nullptr || (pl->dom->comm && pl->dom->has_external);
+  if (pl->n == 0 && !migrates) return GFSHIP_OK;
   if (pl->sort_every > 0 &&
       (pl->events_since_sort < 0 || pl->events_since_sort >= pl->sort_every)) {
     int r = gfship_particles_sort (pl);
@@ -1239,12 +1249,12 @@ int gfship_particle_list_event (gfship_particles * pl)
   A.alive = pl->alive;
   A.dt = v.dt;
   A.count = pl->d_count;
-  A.migrate = pl->migrate != nullptr;
+  A.migrate = migrates;
   int block = 256, grid = (pl->n + block - 1)/block;
   if (pl->n > 0 && pl->particulate && pl->nforces > 0) {
     int r = particulate_event (pl, A, v.visc);
     if (r) return r;
-    return pl->migrate ? particles_migrate (pl) : GFSHIP_OK;
+    return migrates ? particles_migrate (pl) : GFSHIP_OK;
   }
   if (pl->n > 0) {
     if (dom->dim == 3)
@@ -1255,7 +1265,7 @@ int gfship_particle_list_event (gfship_particles * pl)
 			  A, dom->depth);
     GFSHIP_HIP (hipGetLastError ());
   }
-  if (pl->migrate)
+  if (migrates)
     return particles_migrate (pl);
   return GFSHIP_OK;
 }

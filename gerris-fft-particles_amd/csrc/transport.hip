@@ -12,6 +12,7 @@
 // RCCL is opened at run time (dlopen librccl.so.1): a single-box run never loads it, and a process
 // that already holds an RCCL (PyTorch's) shares that copy.
 #include "gfship_internal.hpp"
+#include <vector>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -82,6 +83,9 @@ struct Comm {
   // overlap = 1: the exchange of a sweep runs on a stream of its own beside the bulk of the sweep
   hipStream_t side = nullptr;
   hipEvent_t packed = nullptr, arrived = nullptr;
+  // particle migration: counts (6 out, 6 in) and packets
+  double * mcount = nullptr, * mbuf = nullptr;
+  size_t mcap = 0;
 };
 
 static int comm_rank_of (const Comm * C, int cx, int cy, int cz)
@@ -241,6 +245,73 @@ int comm_exchange_raw (gfship_domain * dom, double * const send[6], double * con
   return GFSHIP_OK;
 }
 
+// send_particles / rcv_particles (modules/particulatecommon.c:3218-3312) over the communicator: the
+// packets of particles that leave through each MPI side go to the box across it, the packets of
+// the neighbours come in -- counts first, then the payloads, each one ncclSend / ncclRecv pair per
+// side in one group, staged through device buffers (the lists are rebuilt on the host side of the
+// particle code, which sorts the packets by id)
+int comm_migrate (gfship_domain * dom, int rs, const int nsend[6], const double * const send[6],
+		  int nrecv[6], std::vector<double> recv[6])
+{
+  Comm * C = (Comm *) dom->comm;
+  int sd[6], rv[6];
+  const int ns = comm_sides (dom, sd, rv);
+  for (int d = 0; d < 6; d++) { nrecv[d] = 0; recv[d].clear (); }
+  if (ns == 0) return GFSHIP_OK;
+  // counts: one double per side
+  double hc[12];
+  for (int d = 0; d < 6; d++) { hc[d] = (double) nsend[d]; hc[6 + d] = 0.; }
+  if (!C->mcount)
+    GFSHIP_HIP (hipMalloc ((void **) &C->mcount, 12*sizeof (double)));
+  GFSHIP_HIP (hipMemcpyAsync (C->mcount, hc, 12*sizeof (double), hipMemcpyHostToDevice, dom->stream));
+  GFSHIP_NCCL (g_rccl.GroupStart ());
+  for (int q = 0; q < ns; q++)
+    GFSHIP_NCCL (g_rccl.Send (C->mcount + sd[q], 1, ncclDouble, C->peer[sd[q]], C->comm, dom->stream));
+  for (int q = 0; q < ns; q++)
+    GFSHIP_NCCL (g_rccl.Recv (C->mcount + 6 + rv[q], 1, ncclDouble, C->peer[rv[q]], C->comm, dom->stream));
+  GFSHIP_NCCL (g_rccl.GroupEnd ());
+  GFSHIP_HIP (hipMemcpyAsync (hc, C->mcount, 12*sizeof (double), hipMemcpyDeviceToHost, dom->stream));
+  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  size_t tot_s = 0, tot_r = 0, os[6], orr[6];
+  for (int d = 0; d < 6; d++) {
+    nrecv[d] = (int) hc[6 + d];
+    os[d] = tot_s; tot_s += (size_t) nsend[d]*rs;
+    orr[d] = tot_r; tot_r += (size_t) nrecv[d]*rs;
+  }
+  C->messages += 2*ns;
+  C->bytes += (tot_s + ns)*sizeof (double);
+  if (tot_s + tot_r == 0) return GFSHIP_OK;
+  if (C->mcap < tot_s + tot_r) {
+    if (C->mbuf) GFSHIP_HIP (hipFree (C->mbuf));
+    C->mbuf = nullptr; C->mcap = 0;
+    GFSHIP_HIP (hipMalloc ((void **) &C->mbuf, 2*(tot_s + tot_r)*sizeof (double)));
+    C->mcap = 2*(tot_s + tot_r);
+  }
+  double * ds = C->mbuf, * dr = C->mbuf + tot_s;
+  for (int d = 0; d < 6; d++)
+    if (nsend[d] > 0)
+      GFSHIP_HIP (hipMemcpyAsync (ds + os[d], send[d], (size_t) nsend[d]*rs*sizeof (double),
+				  hipMemcpyHostToDevice, dom->stream));
+  GFSHIP_NCCL (g_rccl.GroupStart ());
+  for (int q = 0; q < ns; q++)
+    if (nsend[sd[q]] > 0)
+      GFSHIP_NCCL (g_rccl.Send (ds + os[sd[q]], (size_t) nsend[sd[q]]*rs, ncclDouble, C->peer[sd[q]], C->comm,
+				dom->stream));
+  for (int q = 0; q < ns; q++)
+    if (nrecv[rv[q]] > 0)
+      GFSHIP_NCCL (g_rccl.Recv (dr + orr[rv[q]], (size_t) nrecv[rv[q]]*rs, ncclDouble, C->peer[rv[q]], C->comm,
+				dom->stream));
+  GFSHIP_NCCL (g_rccl.GroupEnd ());
+  for (int d = 0; d < 6; d++)
+    if (nrecv[d] > 0) {
+      recv[d].resize ((size_t) nrecv[d]*rs);
+      GFSHIP_HIP (hipMemcpyAsync (recv[d].data (), dr + orr[d], (size_t) nrecv[d]*rs*sizeof (double),
+				  hipMemcpyDeviceToHost, dom->stream));
+    }
+  GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+  return GFSHIP_OK;
+}
+
 // MPI_Allgather of `count' doubles per rank, in rank order, on the domain's stream
 int comm_allgather (gfship_domain * dom, const double * send, double * recv, size_t count)
 {
@@ -266,6 +337,8 @@ void comm_free (gfship_domain * dom)
     if (C->rbuf[d]) (void) hipFree (C->rbuf[d]);
   }
   if (C->dred) (void) hipFree (C->dred);
+  if (C->mcount) (void) hipFree (C->mcount);
+  if (C->mbuf) (void) hipFree (C->mbuf);
   if (C->hred) (void) hipHostFree (C->hred);
   delete C;
   dom->comm = nullptr;

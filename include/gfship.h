@@ -351,8 +351,10 @@ int  gfship_particle_list_event (gfship_particles * pl);
 int  gfship_particles_sort (gfship_particles * pl);
 int  gfship_particles_set_sort_interval (gfship_particles * pl, int every);
 /* particles crossing a GFSHIP_SIDE_EXTERNAL side go to the box across it (send_particles /
-   rcv_particles, modules/particulatecommon.c:3218-3312).  Without a hook they are dropped like at any
-   non-periodic side.  The hook is called once per event by every box: nsend[d] records leave
+   rcv_particles, modules/particulatecommon.c:3218-3312).  On a domain with the library's communicator
+   (gfship_domain_comm_init) the packets travel by ncclSend / ncclRecv, counts first, then the records,
+   and no hook is needed; without communicator and without hook the particles are dropped like at any
+   non-periodic side.  A hook, when set, takes precedence.  It is called once per event by every box: nsend[d] records leave
    through side d (send[d]: gfship_particles_record_size doubles each -- position, old position, id,
    for particulates also velocity, mass, volume, force -- already in the
    coordinates of the receiving box, sorted by id); it returns in nrecv[d] / recv[d] the records

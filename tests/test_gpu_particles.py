@@ -204,6 +204,75 @@ def test_particles_migrate_between_two_boxes_on_one_gpu():
     del ohooks
 
 
+@pytest.mark.parametrize("particulate", [False, True])
+def test_particles_migrate_through_the_library_communicator(particulate):
+    """the same hand-over without any hook: with a communicator on the domain (here one rank whose x
+    sides face the box itself) the packets travel by ncclSend / ncclRecv, counts first, then the
+    records (csrc/transport.hip comm_migrate) -- against the oracle box with the mirror transport"""
+    import multibox as M
+    level, nsteps, npart = 5, 4, 2500
+    side = [gfship.SIDE_EXTERNAL, gfship.SIDE_EXTERNAL] + [gfship.SIDE_PERIODIC] * 4
+    pos, ids = lcg_positions(npart)
+    pos[:200, 0] = 0.5 - 2e-4 * (1 + np.arange(200))
+    pos[200:300, 0] = -0.5 + 2e-4 * (1 + np.arange(100))
+    rng = np.random.default_rng(3)
+    vel = 0.3 * rng.standard_normal((npart, 3))
+    vol = 1e-3 * (0.5 + rng.random(npart))
+    mass = vol * (0.5 + 2.5 * rng.random(npart))
+    forces = [O.FORCE_DRAG, O.FORCE_BUOY, O.FORCE_INERTIAL]
+    nu = 1e-2 if particulate else 0.
+    osim = O.Sim(3, level, side)
+    x, y, z = osim.dom.centres()
+    from flow_cases import taylor_green_3d
+    for c, a in enumerate(taylor_green_3d(x, y, z)):
+        osim.u[c].interior()[...] = a + (0.7 if c == 0 else 0.)
+        if nu:
+            osim.set_viscosity(c, nu)
+    grid = type("G", (), {"external_sides": lambda s: [0, 1]})()
+    mt = _MirrorTransport(grid)
+    ohooks = M.OracleHooks(O.lib(), osim.dom.ptr, 3, mt)
+    gd, gs = _device_sim(osim, side)
+    for c in range(3):
+        if nu:
+            gs.set_viscosity(c, nu)
+    gd.comm_init(gfship.comm_unique_id(), 0, 1, (1, 1, 1))
+    opl = O.Particles(osim, pos, ids)
+    gpl = gfship.ParticleList(gs, pos, ids)
+    gpl.set_sort_interval(2)
+    if particulate:
+        opl.set_particulate(vel, mass, vol)
+        gpl.set_particulate(vel, mass, vol)
+        opl.set_forces(forces, (0., -0.4, 0.))
+        gpl.set_forces(forces, (0., -0.4, 0.))
+    osim.start()
+    gs.start()
+    moved = 0
+    for k in range(nsteps):
+        opl.event()
+        out = {d: opl.outbox(d) for d in (0, 1)}
+        moved += sum(len(a) for a in out.values())
+        opl.clear_outbox()
+        for d, a in sorted(mt.exchange_records(out, rs=15 if particulate else 7).items()):
+            opl.append(a)
+        gpl.event()
+        op, oi = opl.state()
+        gp, gi = gpl.download()
+        assert gpl.count() == len(oi) == len(gi), k
+        a, b = np.argsort(gi, kind="stable"), np.argsort(oi, kind="stable")
+        assert np.array_equal(gi[a], oi[b]), k
+        if particulate:
+            assert _rel_err(op[b], gp[a]) <= 1e-12, k
+            assert _rel_err(opl.particulate_state()[0][b], gpl.particulate_state()[0][a]) <= 1e-12, k
+        else:
+            assert np.array_equal(gp[a], op[b]), (k, np.abs(gp[a] - op[b]).max())
+        osim.step()
+        gs.step()
+    assert moved > 50
+    del ohooks
+    gs.destroy()
+    gd.destroy()
+
+
 # ---------------------------------------------------------------------------------------------
 # GfsParticulate with forces (SURVEY.md 8f rank 1): modules/particulatecommon.c:91-842
 # ---------------------------------------------------------------------------------------------
