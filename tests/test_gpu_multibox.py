@@ -74,9 +74,9 @@ def _same(dev, ora, what):
         assert d["res"] == o["res"], (what, rank)
 
 
-@pytest.mark.parametrize("nboxes,level", [(2, 5), (8, 4), (8, 5)])
+@pytest.mark.parametrize("nboxes,level", [(2, 5), (4, 4), (8, 4), (8, 5)])
 def test_lattice_flow_device_boxes_equal_oracle_boxes(nboxes, level):
-    """overlap = 0 (plain traversal order in every sweep): 2 x 1 x 1 and 2 x 2 x 2 boxes; at 32^3
+    """overlap = 0 (plain traversal order in every sweep): 2 x 1 x 1, 2 x 2 x 1 and 2 x 2 x 2 boxes; at 32^3
     the sweeps of the three finest levels run on the pipelined tile kernel with MPI ghost streams"""
     nsteps = 2
     ora = run_lattice_flow_threads(nboxes, level, nsteps, 0)
