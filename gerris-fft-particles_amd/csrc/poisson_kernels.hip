@@ -5,6 +5,7 @@
 // exact-mode results are bit-identical to the CPU algorithm.  Unit face weights
 // (gfs_poisson_coefficients with alpha = NULL on a uniform single box: every f[d].v == 1.).
 #include "gfship_internal.hpp"
+#include "relax_skew.hpp"
 #include <algorithm>
 #include <cstdlib>
 
@@ -67,6 +68,22 @@ __device__ __forceinline__ double relax_value (const double * __restrict__ u, lo
   if (dimension == 2)
     return a != 0. ? (1. - omega)*u[c] + omega*(b - rhs)/a : 0.;
   return a != 0. ? (b - rhs)/a : 0.;
+}
+
+// the same for unit weights, dia == 0 and dimension == 3: a = 0. + 1. + ... + 1. = 6. exactly and the
+// correctly rounded quotient comes from divide_by_6's reciprocal sequence (relax_skew.hpp) instead of
+// the division
+__device__ __forceinline__ double relax_value_six (const double * __restrict__ u, long c, long sy, long sz,
+						    double rhs)
+{
+  double b = 0.;
+  b += 1.*u[c + 1];
+  b += 1.*u[c - 1];
+  b += 1.*u[c + sy];
+  b += 1.*u[c - sy];
+  b += 1.*u[c + sz];
+  b += 1.*u[c - sz];
+  return divide_by_6 (b - rhs);
 }
 
 // Exact-order sweep, one launch per hyperplane I + J + K = plane of the oriented coordinates
@@ -399,8 +416,12 @@ coarse_cycle_kernel (CoarseCycleArgs A)
 	  if (I >= 0 && I < n) {
 	    int i = I + 1, j = n - J, k = DIM == 3 ? n - K : 0;
 	    long c = i + ssy*j + ssz*k;
-	    double dv = dia ? dia[L.idx (i, j, k)] : 0.;
-	    s[c] = relax_value<DIM, 0> (s, c, ssy, ssz, rhs[c], dv, A.dimension, A.omega, 1., 1.);
+	    if (DIM == 3 && !dia && A.dimension == 3)
+	      s[c] = relax_value_six (s, c, ssy, ssz, rhs[c]);
+	    else {
+	      double dv = dia ? dia[L.idx (i, j, k)] : 0.;
+	      s[c] = relax_value<DIM, 0> (s, c, ssy, ssz, rhs[c], dv, A.dimension, A.omega, 1., 1.);
+	    }
 	  }
 	}
 	__syncthreads ();
@@ -709,7 +730,10 @@ lattice_cycle_kernel (LatticeCycleArgs A)
 	  if (I >= 0 && I < n) {
 	    int i = I + 1, j = n - J, k = DIM == 3 ? n - K : 0;
 	    long c = i + ssy*j + ssz*k;
-	    s[c] = relax_value<DIM, 0> (s, c, ssy, ssz, rhs[c], 0., A.dimension, A.omega, 1., 1.);
+	    if (DIM == 3 && A.dimension == 3)
+	      s[c] = relax_value_six (s, c, ssy, ssz, rhs[c]);
+	    else
+	      s[c] = relax_value<DIM, 0> (s, c, ssy, ssz, rhs[c], 0., A.dimension, A.omega, 1., 1.);
 	  }
 	}
 	__syncthreads ();
