@@ -387,7 +387,9 @@ coarse_cycle_kernel (CoarseCycleArgs A)
     }
     const double * rhs = sres[l];
     const double * dia = A.dia[l];
-    for (unsigned sweep = 0; sweep < A.nrelax[l]; sweep++) {
+    const int S = (int) A.nrelax[l];
+    if (S > 0) {
+      // the BC before the first sweep, from the values the level starts with
       for (int q = tid; q < 2*DIM*nface; q += nt) {
 	int d = q / nface, f = q % nface;
 	int c = d/2;
@@ -408,19 +410,60 @@ coarse_cycle_kernel (CoarseCycleArgs A)
 	s[nb + o] = v;
       }
       __syncthreads ();
+      // The sweeps of the loop follow each other n planes apart instead of one after the other:
+      // sweep s is on plane q - s*n at iteration q.  A cell of sweep s+1 on plane p needs its
+      // later neighbours (plane p + 1) from sweep s -- two planes would do -- and the ghosts of its
+      // lines as the BC between the two sweeps leaves them: the image of the line's last cell,
+      // which sweep s reaches n - 1 planes after the line's first.  The thread that computes the
+      // last cell of a line refreshes both ghosts of the line then (sweep s has read them, sweep
+      // s+1 reaches the line one iteration later at the earliest); the last sweep refreshes
+      // none, so the ghosts stay those of the last BC application.  Same values in the same
+      // order as sweep after sweep, in half the barriers.
       const int nplanes = DIM == 3 ? 3*n - 2 : 2*n - 1;
-      for (int plane = 0; plane < nplanes; plane++) {
-	for (int t = tid; t < nface; t += nt) {
+      const int nconc = (nplanes + n - 1)/n;
+      const int niter = nplanes + (S - 1)*n;
+      const bool per0 = A.bc.side[0] == GFSHIP_SIDE_PERIODIC, per1 = A.bc.side[1] == GFSHIP_SIDE_PERIODIC;
+      const bool per2 = A.bc.side[2] == GFSHIP_SIDE_PERIODIC, per3 = A.bc.side[3] == GFSHIP_SIDE_PERIODIC;
+      const bool per4 = DIM == 3 && A.bc.side[4] == GFSHIP_SIDE_PERIODIC;
+      const bool per5 = DIM == 3 && A.bc.side[5] == GFSHIP_SIDE_PERIODIC;
+      for (int q = 0; q < niter; q++) {
+	const int shi = min (S - 1, q/n);
+	for (int w = tid; w < nconc*nface; w += nt) {
+	  const int sw = shi - w/nface, t = w % nface;
+	  const int plane = q - sw*n;
+	  if (sw < 0 || plane >= nplanes) continue;
 	  int J = t % n, K = DIM == 3 ? t / n : 0;
 	  int I = plane - J - K;
 	  if (I >= 0 && I < n) {
 	    int i = I + 1, j = n - J, k = DIM == 3 ? n - K : 0;
 	    long c = i + ssy*j + ssz*k;
+	    double v;
 	    if (DIM == 3 && !dia && A.dimension == 3)
-	      s[c] = relax_value_six (s, c, ssy, ssz, rhs[c]);
+	      v = relax_value_six (s, c, ssy, ssz, rhs[c]);
 	    else {
 	      double dv = dia ? dia[L.idx (i, j, k)] : 0.;
-	      s[c] = relax_value<DIM, 0> (s, c, ssy, ssz, rhs[c], dv, A.dimension, A.omega, 1., 1.);
+	      v = relax_value<DIM, 0> (s, c, ssy, ssz, rhs[c], dv, A.dimension, A.omega, 1., 1.);
+	    }
+	    s[c] = v;
+	    if (sw < S - 1) {
+	      if (i == n) {
+		long f = 1 + ssy*j + ssz*k;
+		double first = s[f];
+		s[f - 1] = per1 ? v : ghost_value (A.bc.type[1], A.bc.component, 0, first, 1, 0., 0.);
+		s[c + 1] = per0 ? first : ghost_value (A.bc.type[0], A.bc.component, 0, v, 1, 0., 0.);
+	      }
+	      if (j == 1) {
+		long f = i + ssy*n + ssz*k;
+		double first = s[f];
+		s[f + ssy] = per2 ? v : ghost_value (A.bc.type[2], A.bc.component, 1, first, 1, 0., 0.);
+		s[c - ssy] = per3 ? first : ghost_value (A.bc.type[3], A.bc.component, 1, v, 1, 0., 0.);
+	      }
+	      if (DIM == 3 && k == 1) {
+		long f = i + ssy*j + ssz*n;
+		double first = s[f];
+		s[f + ssz] = per4 ? v : ghost_value (A.bc.type[4], A.bc.component, 2, first, 1, 0., 0.);
+		s[c - ssz] = per5 ? first : ghost_value (A.bc.type[5], A.bc.component, 2, v, 1, 0., 0.);
+	      }
 	    }
 	  }
 	}
