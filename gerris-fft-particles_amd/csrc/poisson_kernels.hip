@@ -315,24 +315,44 @@ coarse_cycle_kernel (CoarseCycleArgs A)
 {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
+#ifdef GFSHIP_LAB_CLOCK
+  unsigned long long stamp[40]; int nstamp = 0;
+#define LAB_STAMP() do { if (nstamp < 40) stamp[nstamp++] = wall_clock64 (); } while (0)
+#else
+#define LAB_STAMP() do { } while (0)
+#endif
+  LAB_STAMP ();
   // LDS map: per level a dp array and a res array of (n+2)^DIM doubles
-  double * sdp[GFSHIP_MAXLEVEL + 1], * sres[GFSHIP_MAXLEVEL + 1];
-  {
-    size_t o = 0;
-    for (int l = A.lmin; l <= A.ltop; l++) {
-      size_t r = A.lay[l].n + 2, m = DIM == 3 ? r*r*r : r*r;
-      sdp[l] = lds + o; o += m;
-      sres[l] = lds + o; o += m;
+  // offsets, not pointers kept in an array: the accesses stay LDS instructions (an array of
+  // pointers indexed by the level lives in scratch and turns every access into a flat one)
+  auto lds_off = [&] (int l, int which) -> unsigned {
+    unsigned o = 0;
+    for (int q = A.lmin; q < l; q++) {
+      unsigned r = A.lay[q].n + 2;
+      o += 2*(DIM == 3 ? r*r*r : r*r);
     }
+    if (which) {
+      unsigned r = A.lay[l].n + 2;
+      o += DIM == 3 ? r*r*r : r*r;
+    }
+    return o;
+  };
+  {
+    const unsigned o = lds_off (A.ltop + 1, 0);
     for (size_t q = tid; q < o; q += nt)
       lds[q] = 0.;
   }
   __syncthreads ();
+  LAB_STAMP ();
   // ---- restrictions, finest first ----
   for (int l = A.ltop; l >= A.lmin; l--) {
     const Layout & Lc = A.lay[l], & Lf = A.lay[l + 1];
     const int n = Lc.n, r = n + 2, rf = 2*n + 2;
     const int ncell = DIM == 3 ? n*n*n : n*n;
+    const bool top = l == A.ltop;
+    const double * gf = A.res[l + 1];
+    const double * sf = lds + (top ? 0 : lds_off (l + 1, 1));
+    double * sc = lds + lds_off (l, 1);
     for (int q = tid; q < ncell; q += nt) {
       int i = q % n + 1, j = (q / n) % n + 1, k = DIM == 3 ? q / (n*n) + 1 : 0;
       double val = 0.;
@@ -341,14 +361,17 @@ coarse_cycle_kernel (CoarseCycleArgs A)
 	int ci = 2*i - 1 + (id & 1);
 	int cj = 2*j - 1 + ((id & 2) ? 0 : 1);
 	int ck = DIM == 3 ? 2*k - 1 + ((id & 4) ? 0 : 1) : 0;
-	val += l == A.ltop ? A.res[l + 1][Lf.idx (ci, cj, ck)]
-	  : sres[l + 1][ci + rf*(cj + (DIM == 3 ? rf*ck : 0))];
+	if (top)
+	  val += gf[Lf.idx (ci, cj, ck)];
+	else
+	  val += sf[ci + rf*(cj + (DIM == 3 ? rf*ck : 0))];
       }
       double v = A.dimension == 2 ? val : val/2.;
-      sres[l][i + r*(j + (DIM == 3 ? r*k : 0))] = v;
+      sc[i + r*(j + (DIM == 3 ? r*k : 0))] = v;
       A.res[l][Lc.idx (i, j, k)] = v;
     }
     __syncthreads ();
+    LAB_STAMP ();
   }
   // ---- relax loops from the coarsest level up ----
   for (int l = A.lmin; l <= A.ltop; l++) {
@@ -357,12 +380,12 @@ coarse_cycle_kernel (CoarseCycleArgs A)
     const long ssy = r, ssz = DIM == 3 ? (long) r*r : 0;
     const int ncell = DIM == 3 ? n*n*n : n*n;
     const int nface = DIM == 3 ? n*n : n;
-    double * s = sdp[l];
+    double * s = (lds + lds_off (l, 0));
     if (l > A.lmin) {
       // get_from_above, src/poisson.c:1005-1042 (prolongate_kernel), one thread per fine cell
       const int nc = n/2, rc = nc + 2;
       const long cy = rc, cz = DIM == 3 ? (long) rc*rc : 0;
-      const double * vc = sdp[l - 1];
+      const double * vc = (lds + lds_off (l - 1, 0));
       for (int q = tid; q < ncell; q += nt) {
 	int i = q % n + 1, j = (q / n) % n + 1, k = DIM == 3 ? q / (n*n) + 1 : 0;
 	int pi = (i + 1)/2, pj = (j + 1)/2, pk = DIM == 3 ? (k + 1)/2 : 0;
@@ -385,7 +408,8 @@ coarse_cycle_kernel (CoarseCycleArgs A)
       }
       __syncthreads ();
     }
-    const double * rhs = sres[l];
+    LAB_STAMP ();
+    const double * rhs = (lds + lds_off (l, 1));
     const double * dia = A.dia[l];
     const int S = (int) A.nrelax[l];
     if (S > 0) {
@@ -426,50 +450,110 @@ coarse_cycle_kernel (CoarseCycleArgs A)
       const bool per2 = A.bc.side[2] == GFSHIP_SIDE_PERIODIC, per3 = A.bc.side[3] == GFSHIP_SIDE_PERIODIC;
       const bool per4 = DIM == 3 && A.bc.side[4] == GFSHIP_SIDE_PERIODIC;
       const bool per5 = DIM == 3 && A.bc.side[5] == GFSHIP_SIDE_PERIODIC;
-      for (int q = 0; q < niter; q++) {
-	const int shi = min (S - 1, q/n);
-	for (int w = tid; w < nconc*nface; w += nt) {
-	  const int sw = shi - w/nface, t = w % nface;
-	  const int plane = q - sw*n;
-	  if (sw < 0 || plane >= nplanes) continue;
-	  int J = t % n, K = DIM == 3 ? t / n : 0;
-	  int I = plane - J - K;
-	  if (I >= 0 && I < n) {
-	    int i = I + 1, j = n - J, k = DIM == 3 ? n - K : 0;
-	    long c = i + ssy*j + ssz*k;
-	    double v;
-	    if (DIM == 3 && !dia && A.dimension == 3)
-	      v = relax_value_six (s, c, ssy, ssz, rhs[c]);
-	    else {
-	      double dv = dia ? dia[L.idx (i, j, k)] : 0.;
-	      v = relax_value<DIM, 0> (s, c, ssy, ssz, rhs[c], dv, A.dimension, A.omega, 1., 1.);
-	    }
-	    s[c] = v;
-	    if (sw < S - 1) {
+      const int lg = __ffs (n) - 1, lgf = DIM == 3 ? 2*lg : lg; // n is a power of two
+      auto cell = [&] (int sw, int I, int J, int K) {
+	int i = I + 1, j = n - J, k = DIM == 3 ? n - K : 0;
+	long c = i + ssy*j + ssz*k;
+	double v;
+	if (DIM == 3 && !dia && A.dimension == 3)
+	  v = relax_value_six (s, c, ssy, ssz, rhs[c]);
+	else {
+	  double dv = dia ? dia[L.idx (i, j, k)] : 0.;
+	  v = relax_value<DIM, 0> (s, c, ssy, ssz, rhs[c], dv, A.dimension, A.omega, 1., 1.);
+	}
+	s[c] = v;
+	if (sw < S - 1) {
+	  if (i == n) {
+	    long f = 1 + ssy*j + ssz*k;
+	    double first = s[f];
+	    s[f - 1] = per1 ? v : ghost_value (A.bc.type[1], A.bc.component, 0, first, 1, 0., 0.);
+	    s[c + 1] = per0 ? first : ghost_value (A.bc.type[0], A.bc.component, 0, v, 1, 0., 0.);
+	  }
+	  if (j == 1) {
+	    long f = i + ssy*n + ssz*k;
+	    double first = s[f];
+	    s[f + ssy] = per2 ? v : ghost_value (A.bc.type[2], A.bc.component, 1, first, 1, 0., 0.);
+	    s[c - ssy] = per3 ? first : ghost_value (A.bc.type[3], A.bc.component, 1, v, 1, 0., 0.);
+	  }
+	  if (DIM == 3 && k == 1) {
+	    long f = i + ssy*j + ssz*n;
+	    double first = s[f];
+	    s[f + ssz] = per4 ? v : ghost_value (A.bc.type[4], A.bc.component, 2, first, 1, 0., 0.);
+	    s[c - ssz] = per5 ? first : ghost_value (A.bc.type[5], A.bc.component, 2, v, 1, 0., 0.);
+	  }
+	}
+      };
+      if (DIM == 3 && !dia && A.dimension == 3 && nconc*nface <= nt) {
+	// the usual case, one (sweep slot, line of x) per thread for the whole loop: what does not
+	// change from plane to plane is computed once, an iteration is the stencil and a barrier
+	const int g = tid >> lgf, t = tid & (nface - 1);
+	const int J = t & (n - 1), K = t >> lg;
+	const int j = n - J, k = n - K;
+	double * srow = s + (ssy*j + ssz*k);
+	const double * rrow = rhs + (ssy*j + ssz*k);
+	double * sj = s + (ssy*n + ssz*k), * sk = s + (ssy*j + ssz*n); // first lines along y and z
+	const bool mine = g < nconc, jl = j == 1, kl = k == 1;
+	for (int q = 0; q < niter; q++) {
+	  const int sw = min (S - 1, q >> lg) - g;
+	  const int I = q - (sw << lg) - J - K;
+	  if (mine && sw >= 0 && (unsigned) I < (unsigned) n) {
+	    const int i = I + 1;
+	    double b = 0.;
+	    b += 1.*srow[i + 1];
+	    b += 1.*srow[i - 1];
+	    b += 1.*srow[i + ssy];
+	    b += 1.*srow[i - ssy];
+	    b += 1.*srow[i + ssz];
+	    b += 1.*srow[i - ssz];
+	    const double v = divide_by_6 (b - rrow[i]);
+	    srow[i] = v;
+	    if (sw < S - 1 && (i == n || jl || kl)) {
 	      if (i == n) {
-		long f = 1 + ssy*j + ssz*k;
-		double first = s[f];
-		s[f - 1] = per1 ? v : ghost_value (A.bc.type[1], A.bc.component, 0, first, 1, 0., 0.);
-		s[c + 1] = per0 ? first : ghost_value (A.bc.type[0], A.bc.component, 0, v, 1, 0., 0.);
+		double first = srow[1];
+		srow[0] = per1 ? v : ghost_value (A.bc.type[1], A.bc.component, 0, first, 1, 0., 0.);
+		srow[n + 1] = per0 ? first : ghost_value (A.bc.type[0], A.bc.component, 0, v, 1, 0., 0.);
 	      }
-	      if (j == 1) {
-		long f = i + ssy*n + ssz*k;
-		double first = s[f];
-		s[f + ssy] = per2 ? v : ghost_value (A.bc.type[2], A.bc.component, 1, first, 1, 0., 0.);
-		s[c - ssy] = per3 ? first : ghost_value (A.bc.type[3], A.bc.component, 1, v, 1, 0., 0.);
+	      if (jl) {
+		double first = sj[i];
+		sj[i + ssy] = per2 ? v : ghost_value (A.bc.type[2], A.bc.component, 1, first, 1, 0., 0.);
+		srow[i - ssy] = per3 ? first : ghost_value (A.bc.type[3], A.bc.component, 1, v, 1, 0., 0.);
 	      }
-	      if (DIM == 3 && k == 1) {
-		long f = i + ssy*j + ssz*n;
-		double first = s[f];
-		s[f + ssz] = per4 ? v : ghost_value (A.bc.type[4], A.bc.component, 2, first, 1, 0., 0.);
-		s[c - ssz] = per5 ? first : ghost_value (A.bc.type[5], A.bc.component, 2, v, 1, 0., 0.);
+	      if (kl) {
+		double first = sk[i];
+		sk[i + ssz] = per4 ? v : ghost_value (A.bc.type[4], A.bc.component, 2, first, 1, 0., 0.);
+		srow[i - ssz] = per5 ? first : ghost_value (A.bc.type[5], A.bc.component, 2, v, 1, 0., 0.);
 	      }
 	    }
 	  }
+	  __syncthreads ();
 	}
-	__syncthreads ();
       }
+      else if (nconc*nface <= nt) {
+	const int g = tid >> lgf, t = tid & (nface - 1);
+	const int J = t & (n - 1), K = DIM == 3 ? t >> lg : 0;
+	const bool mine = g < nconc;
+	for (int q = 0; q < niter; q++) {
+	  const int sw = min (S - 1, q >> lg) - g;
+	  const int I = q - (sw << lg) - J - K;
+	  if (mine && sw >= 0 && I >= 0 && I < n)
+	    cell (sw, I, J, K);
+	  __syncthreads ();
+	}
+      }
+      else
+	for (int q = 0; q < niter; q++) {
+	  const int shi = min (S - 1, q >> lg);
+	  for (int w = tid; w < nconc*nface; w += nt) {
+	    const int sw = shi - (w >> lgf), t = w & (nface - 1);
+	    const int J = t & (n - 1), K = DIM == 3 ? t >> lg : 0;
+	    const int I = q - (sw << lg) - J - K;
+	    if (sw >= 0 && I >= 0 && I < n)
+	      cell (sw, I, J, K);
+	  }
+	  __syncthreads ();
+	}
     }
+    LAB_STAMP ();
     // natural copy with the ghost layer of the last BC application
     const int nall = DIM == 3 ? r*r*r : r*r;
     for (int q = tid; q < nall; q += nt) {
@@ -477,7 +561,15 @@ coarse_cycle_kernel (CoarseCycleArgs A)
       A.dp[l][L.idx (i, j, k)] = s[q];
     }
     __syncthreads ();
+    LAB_STAMP ();
   }
+#ifdef GFSHIP_LAB_CLOCK
+  if (tid == 0) {
+    for (int q = 1; q < nstamp; q++)
+      printf ("coarse stamp %d: %.2f us\n", q, (double) (stamp[q] - stamp[q - 1])/100.);
+  }
+#endif
+#undef LAB_STAMP
 }
 
 // highest level of the coarse end that fits (0 .. ltop in LDS); -1 when it does not apply
@@ -638,14 +730,22 @@ lattice_cycle_kernel (LatticeCycleArgs A)
   }
   unsigned target = 0, parity = 0;
   const size_t xface = DIM == 3 ? (size_t) A.lay[A.ltop].n*A.lay[A.ltop].n : (size_t) A.lay[A.ltop].n;
-  double * sdp[GFSHIP_MAXLEVEL + 1], * sres[GFSHIP_MAXLEVEL + 1];
-  {
-    size_t o = 0;
-    for (int l = A.lmin; l <= A.ltop; l++) {
-      size_t r = A.lay[l].n + 2, m = DIM == 3 ? r*r*r : r*r;
-      sdp[l] = lds + o; o += m;
-      sres[l] = lds + o; o += m;
+  // offsets, not pointers kept in an array: the accesses stay LDS instructions (an array of
+  // pointers indexed by the level lives in scratch and turns every access into a flat one)
+  auto lds_off = [&] (int l, int which) -> unsigned {
+    unsigned o = 0;
+    for (int q = A.lmin; q < l; q++) {
+      unsigned r = A.lay[q].n + 2;
+      o += 2*(DIM == 3 ? r*r*r : r*r);
     }
+    if (which) {
+      unsigned r = A.lay[l].n + 2;
+      o += DIM == 3 ? r*r*r : r*r;
+    }
+    return o;
+  };
+  {
+    const unsigned o = lds_off (A.ltop + 1, 0);
     for (size_t q = tid; q < o; q += nt)
       lds[q] = 0.;
   }
@@ -656,9 +756,10 @@ lattice_cycle_kernel (LatticeCycleArgs A)
     const int n = L.n, r = n + 2;
     const int ncell = DIM == 3 ? n*n*n : n*n;
     const double * g = A.gres + (size_t) box*L.total;
+    double * st = lds + lds_off (A.ltop, 1);
     for (int q = tid; q < ncell; q += nt) {
       int i = q % n + 1, j = (q / n) % n + 1, k = DIM == 3 ? q / (n*n) + 1 : 0;
-      sres[A.ltop][i + r*(j + (DIM == 3 ? r*k : 0))] = g[L.idx (i, j, k)];
+      st[i + r*(j + (DIM == 3 ? r*k : 0))] = g[L.idx (i, j, k)];
     }
     __syncthreads ();
   }
@@ -666,6 +767,8 @@ lattice_cycle_kernel (LatticeCycleArgs A)
     const Layout & Lc = A.lay[l];
     const int n = Lc.n, r = n + 2, rf = 2*n + 2;
     const int ncell = DIM == 3 ? n*n*n : n*n;
+    const double * sf = lds + lds_off (l + 1, 1);
+    double * sc = lds + lds_off (l, 1);
     for (int q = tid; q < ncell; q += nt) {
       int i = q % n + 1, j = (q / n) % n + 1, k = DIM == 3 ? q / (n*n) + 1 : 0;
       double val = 0.;
@@ -674,10 +777,10 @@ lattice_cycle_kernel (LatticeCycleArgs A)
 	int ci = 2*i - 1 + (id & 1);
 	int cj = 2*j - 1 + ((id & 2) ? 0 : 1);
 	int ck = DIM == 3 ? 2*k - 1 + ((id & 4) ? 0 : 1) : 0;
-	val += sres[l + 1][ci + rf*(cj + (DIM == 3 ? rf*ck : 0))];
+	val += sf[ci + rf*(cj + (DIM == 3 ? rf*ck : 0))];
       }
       double v = A.dimension == 2 ? val : val/2.;
-      sres[l][i + r*(j + (DIM == 3 ? r*k : 0))] = v;
+      sc[i + r*(j + (DIM == 3 ? r*k : 0))] = v;
       if (own) A.res[l][Lc.idx (i, j, k)] = v;
     }
     __syncthreads ();
@@ -689,12 +792,12 @@ lattice_cycle_kernel (LatticeCycleArgs A)
     const long ssy = r, ssz = DIM == 3 ? (long) r*r : 0;
     const int ncell = DIM == 3 ? n*n*n : n*n;
     const int nface = DIM == 3 ? n*n : n;
-    double * s = sdp[l];
+    double * s = (lds + lds_off (l, 0));
     if (l > A.lmin) {
       // get_from_above, src/poisson.c:1005-1042 (prolongate_kernel), one thread per fine cell
       const int nc = n/2, rc = nc + 2;
       const long cy = rc, cz = DIM == 3 ? (long) rc*rc : 0;
-      const double * vc = sdp[l - 1];
+      const double * vc = (lds + lds_off (l - 1, 0));
       for (int q = tid; q < ncell; q += nt) {
 	int i = q % n + 1, j = (q / n) % n + 1, k = DIM == 3 ? q / (n*n) + 1 : 0;
 	int pi = (i + 1)/2, pj = (j + 1)/2, pk = DIM == 3 ? (k + 1)/2 : 0;
@@ -717,7 +820,7 @@ lattice_cycle_kernel (LatticeCycleArgs A)
       }
       __syncthreads ();
     }
-    const double * rhs = sres[l];
+    const double * rhs = (lds + lds_off (l, 1));
     for (unsigned sweep = 0; sweep < A.nrelax[l]; sweep++) {
       // BC application: the layers along the MPI sides go out ...
       unsigned long long * const out = A.xch + ((size_t) parity*A.nboxes + box)*6*xface;
