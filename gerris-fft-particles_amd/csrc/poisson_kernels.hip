@@ -869,21 +869,46 @@ lattice_cycle_kernel (LatticeCycleArgs A)
       parity ^= 1;
       __syncthreads ();
       const int nplanes = DIM == 3 ? 3*n - 2 : 2*n - 1;
-      for (int plane = 0; plane < nplanes; plane++) {
-	for (int t = tid; t < nface; t += nt) {
-	  int J = t % n, K = DIM == 3 ? t / n : 0;
-	  int I = plane - J - K;
-	  if (I >= 0 && I < n) {
-	    int i = I + 1, j = n - J, k = DIM == 3 ? n - K : 0;
-	    long c = i + ssy*j + ssz*k;
-	    if (DIM == 3 && A.dimension == 3)
-	      s[c] = relax_value_six (s, c, ssy, ssz, rhs[c]);
-	    else
-	      s[c] = relax_value<DIM, 0> (s, c, ssy, ssz, rhs[c], 0., A.dimension, A.omega, 1., 1.);
+      if (DIM == 3 && A.dimension == 3 && nface <= nt) {
+	// one line of x per thread, the addresses of the line computed once
+	const int lg = __ffs (n) - 1; // n is a power of two
+	const int J = tid & (n - 1), K = tid >> lg;
+	const int j = n - J, k = n - K;
+	double * srow = s + (ssy*j + ssz*k);
+	const double * rrow = rhs + (ssy*j + ssz*k);
+	const bool mine = tid < nface;
+	for (int plane = 0; plane < nplanes; plane++) {
+	  const int I = plane - J - K;
+	  if (mine && (unsigned) I < (unsigned) n) {
+	    const int i = I + 1;
+	    double b = 0.;
+	    b += 1.*srow[i + 1];
+	    b += 1.*srow[i - 1];
+	    b += 1.*srow[i + ssy];
+	    b += 1.*srow[i - ssy];
+	    b += 1.*srow[i + ssz];
+	    b += 1.*srow[i - ssz];
+	    srow[i] = divide_by_6 (b - rrow[i]);
 	  }
+	  __syncthreads ();
 	}
-	__syncthreads ();
       }
+      else
+	for (int plane = 0; plane < nplanes; plane++) {
+	  for (int t = tid; t < nface; t += nt) {
+	    int J = t % n, K = DIM == 3 ? t / n : 0;
+	    int I = plane - J - K;
+	    if (I >= 0 && I < n) {
+	      int i = I + 1, j = n - J, k = DIM == 3 ? n - K : 0;
+	      long c = i + ssy*j + ssz*k;
+	      if (DIM == 3 && A.dimension == 3)
+		s[c] = relax_value_six (s, c, ssy, ssz, rhs[c]);
+	      else
+		s[c] = relax_value<DIM, 0> (s, c, ssy, ssz, rhs[c], 0., A.dimension, A.omega, 1., 1.);
+	    }
+	  }
+	  __syncthreads ();
+	}
     }
     // natural copy of the own box with the ghost layer of the last BC application
     if (own) {
