@@ -1,0 +1,1395 @@
+/* go_tree2d.c -- oracle: the reference's time step on a 2-D quadtree with a statically refined
+ * patch (coarse-fine stencils) in one periodic box: the case of
+ * test/periodic/periodic.gfs with BOX = 1, 2.
+ * TEST INFRASTRUCTURE ONLY (see gfs_oracle.h): nothing of the product links or calls this.
+ *
+ * Pinned on the reference's test/periodic/r1.ref and r2.ref (tests/test_oracle_tree2d.py), and on
+ * r0.ref through the uniform tree (BOX = 0), where it must also agree with go_timestep.c.
+ *
+ * Storage: level l of the tree is a dense (n+2)^2 array, n = 2^l, one ghost layer (the ghost
+ * trees of the periodic GfsBoundary), index i + (n+2)*j, 1 <= i,j <= n inside, j grows with y;
+ * flag[l][q] says whether cell q of level l exists and whether it is a leaf.  A cell is the pair
+ * (level, index).  The reference's child numbering (ftt.c:301-316: bit 0 = +x, bit 1 = -y) and
+ * traversal orders are reproduced by the traversal functions, not by the layout.
+ *
+ * What is restated, with the fine / coarse branches that go_timestep.c / go_poisson.c leave out:
+ *   src/ftt.c:45-83,169-192,2013-2074   refinement with the neighbour and corner constraints
+ *   src/ftt.c:689-926, ftt_internal.c   cell and face traversals
+ *   src/fluid.c:64-93,178-197,283-309,364-396,434-475,778-893,2186-2198,2310-2324
+ *   src/poisson.c:507-557,634-678,756-901,998-1269
+ *   src/advection.c:27-99,132-180,267-343,398-435,513-587
+ *   src/timestep.c:36-187,356-444,498-530,560-596,644-717,872-921,976-1016
+ *   src/domain.c:2239-2288,2824-2923, src/simulation.c:432-557,1569-1633
+ * Compile with -ffp-contract=off (oracle/Makefile). */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <float.h>
+#include <assert.h>
+#include "gfs_oracle.h"
+
+#define GT_MAXL 12
+#define OPP(d) ((d) ^ 1)
+#define MIN(a, b) (((a) < (b)) ? (a) : (b))
+#define MAX(a, b) (((a) > (b)) ? (a) : (b))
+#define G_MAXINT 2147483647
+#ifndef M_PI
+#define M_PI 3.14159265358979323846   /* math.h, as used by the reference */
+#endif
+
+enum { GT_NONE = 0, GT_LEAF = 1, GT_NODE = 2 };
+
+typedef struct { int l, q; } Cell;            /* q < 0: no such cell (NULL) */
+typedef struct { double * lev[GT_MAXL + 1]; } Var;
+typedef struct { double a, b; } GfsGradient;  /* fluid.h: v = a*v(cell) + b */
+typedef struct { double a, b, c; } Gradient;  /* fluid.c:55-59 */
+
+typedef struct GtSim {
+  int depth;                                  /* deepest level present */
+  int n[GT_MAXL + 1], r[GT_MAXL + 1];
+  size_t size[GT_MAXL + 1];
+  unsigned char * flag[GT_MAXL + 1];
+  Var p, pmac, u[2], g[2], gmac[2];
+  Var un[4], fv[4];                           /* GFS_STATE (cell)->f[d].un, f[d].v (advection)   */
+  Var w[4];                                   /* GFS_STATE (cell)->f[d].v as Poisson weights     */
+  GoMultilevelParams projection_params, approx_projection_params;
+  double cfl, dt;                             /* GfsAdvectionParams */
+  double t, end, tnext;
+  unsigned i;
+} GtSim;
+
+static const Cell NOCELL = { 0, -1 };
+
+/* ---- topology ----------------------------------------------------------------------------- */
+
+static inline int cell_i (const GtSim * s, Cell c) { return c.q % s->r[c.l]; }
+static inline int cell_j (const GtSim * s, Cell c) { return c.q / s->r[c.l]; }
+static inline int exists (Cell c) { return c.q >= 0; }
+static inline int is_leaf (const GtSim * s, Cell c) { return s->flag[c.l][c.q] == GT_LEAF; }
+static inline double cell_size (Cell c) { return 1./(1 << c.l); }     /* ftt_cell_size, L = 1 */
+static inline double * val (const Var * v, Cell c) { return &v->lev[c.l][c.q]; }
+
+static Cell mkcell (const GtSim * s, int l, int i, int j)
+{
+  Cell c = { l, -1 };
+  if (l < 0 || l > s->depth || !s->flag[l] || i < 0 || j < 0 || i > s->n[l] + 1 || j > s->n[l] + 1)
+    return c;
+  int q = i + s->r[l]*j;
+  if (s->flag[l][q] != GT_NONE)
+    c.q = q;
+  return c;
+}
+
+/* FTT_CELL_ID: position among the siblings, ftt.c:301-316 (bit 0: +x, bit 1: -y) */
+static inline int cell_id (const GtSim * s, Cell c)
+{
+  int i = cell_i (s, c), j = cell_j (s, c);
+  return ((i + 1) & 1) + 2*(j & 1);
+}
+
+/* ftt_cell_neighbor, ftt.h:518-573: the neighbour at the same level or, failing that, the
+   (leaf) cell one level up that covers its place */
+static Cell neighbor (const GtSim * s, Cell c, int d)
+{
+  static const int di[4] = { 1, -1, 0, 0 }, dj[4] = { 0, 0, 1, -1 };
+  int i = cell_i (s, c) + di[d], j = cell_j (s, c) + dj[d];
+  if (i < 0 || j < 0 || i > s->n[c.l] + 1 || j > s->n[c.l] + 1)
+    return NOCELL;
+  Cell nb = mkcell (s, c.l, i, j);
+  if (exists (nb) || c.l == 0)
+    return nb;
+  return mkcell (s, c.l - 1, (i + 1)/2, (j + 1)/2);
+}
+
+static Cell child (const GtSim * s, Cell c, int k)
+{
+  return mkcell (s, c.l + 1, 2*cell_i (s, c) - 1 + (k & 1), 2*cell_j (s, c) - ((k >> 1) & 1));
+}
+
+/* ftt_cell_children_direction, ftt.h:321-355 */
+static void children_direction (const GtSim * s, Cell c, int d, Cell ch[2])
+{
+  static const int index[4][2] = { {1, 3}, {0, 2}, {0, 1}, {2, 3} };
+  ch[0] = child (s, c, index[d][0]);
+  ch[1] = child (s, c, index[d][1]);
+}
+
+/* ftt_cell_child_corner, ftt.h:366-400: the child in the corner of directions dx (0, 1), dy (2, 3) */
+static Cell child_corner (const GtSim * s, Cell c, int d0, int d1)
+{
+  int dx = d0 < 2 ? d0 : d1, dy = d0 < 2 ? d1 : d0;
+  return child (s, c, (dx == 0 ? 1 : 0) + (dy == 3 ? 2 : 0));
+}
+
+/* fluid.c:200-205 (and advection.c:289-294) */
+static const int perpendicular[4][4] =
+  {{-1,  2, -1,  3},
+   { 2, -1,  3, -1},
+   { 1,  0, -1, -1},
+   {-1, -1,  1,  0}};
+
+/* ---- traversals, ftt.c:689-926 -------------------------------------------------------------- */
+
+enum { T_ALL, T_LEAFS, T_NON_LEAFS, T_LEVEL, T_LEVEL_LEAFS, T_LEVEL_NON_LEAFS };
+typedef void (* CellFunc) (GtSim * s, Cell c, void * data);
+
+static void traverse_rec (GtSim * s, Cell c, int post, int flags, int max_depth,
+			  CellFunc fn, void * data)
+{
+  int leaf = is_leaf (s, c), visit = 0, descend = !leaf;
+  if (flags == T_ALL || flags == T_LEAFS || flags == T_NON_LEAFS) {
+    if (max_depth >= 0 && c.l > max_depth)
+      return;
+    visit = flags == T_ALL || (flags == T_LEAFS ? leaf : !leaf);
+  }
+  else if (flags == T_LEVEL) {
+    visit = c.l == max_depth;
+    descend = !visit && !leaf;
+  }
+  else if (flags == T_LEVEL_LEAFS) {
+    visit = c.l == max_depth || leaf;
+    descend = !visit;
+  }
+  else { /* T_LEVEL_NON_LEAFS */
+    visit = c.l == max_depth && !leaf;
+    descend = !visit && !leaf;
+  }
+  if (visit && !post)
+    (* fn) (s, c, data);
+  if (descend)
+    for (int k = 0; k < 4; k++) {
+      Cell ch = child (s, c, k);
+      if (exists (ch))
+	traverse_rec (s, ch, post, flags, max_depth, fn, data);
+    }
+  if (visit && post)
+    (* fn) (s, c, data);
+}
+
+static void cell_traverse (GtSim * s, int post, int flags, int max_depth, CellFunc fn, void * data)
+{
+  Cell root = { 0, 1 + s->r[0] };
+  traverse_rec (s, root, post, flags, max_depth, fn, data);
+}
+
+/* ftt_cell_traverse_boundary (ftt.c:1153-1243): the cells of the traversal that touch side d */
+typedef struct { int d; CellFunc fn; void * data; } BoundaryPar;
+
+static void boundary_filter (GtSim * s, Cell c, void * data)
+{
+  BoundaryPar * b = data;
+  int i = cell_i (s, c), j = cell_j (s, c), n = s->n[c.l];
+  if ((b->d == 0 && i == n) || (b->d == 1 && i == 1) || (b->d == 2 && j == n) || (b->d == 3 && j == 1))
+    (* b->fn) (s, c, b->data);
+}
+
+/* a face as seen from `cell' (FttCellFace) */
+typedef struct { Cell cell, neighbor; int d; } Face;
+typedef void (* FaceFunc) (GtSim * s, const Face * f, void * data);
+typedef struct { int d; FaceFunc fn; void * data; } FacePar;
+
+/* traverse_face, ftt_internal.c:1-42, flags = FTT_TRAVERSE_LEAFS, max_depth = -1.  (The
+   FTT_FLAG_TRAVERSED check only matters in the second pass, whose neighbours are ghost cells --
+   never traversed -- so it is not kept.) */
+static void traverse_face (GtSim * s, Cell cell, void * data)
+{
+  FacePar * p = data;
+  Face face = { cell, neighbor (s, cell, p->d), p->d };
+  if (!exists (face.neighbor))
+    return;
+  if (is_leaf (s, cell) && !is_leaf (s, face.neighbor)) {
+    /* coarse -> fine */
+    Cell ch[2];
+    face.d = OPP (face.d);
+    children_direction (s, face.neighbor, face.d, ch);
+    face.neighbor = face.cell;
+    for (int i = 0; i < 2; i++)
+      if (exists (face.cell = ch[i]))
+	(* p->fn) (s, &face, p->data);
+  }
+  else
+    (* p->fn) (s, &face, p->data);
+}
+
+static void traverse_all_direct_faces (GtSim * s, Cell cell, void * data)
+{
+  FacePar * p = data;
+  for (p->d = 0; p->d < 4; p->d += 2)
+    traverse_face (s, cell, p);
+}
+
+/* ftt_face_traverse (ftt.c:2152-2215) through gfs_domain_face_traverse (domain.c:1725-1793):
+   c < 0: FTT_XYZ; c = 0, 1: one component; leaves only */
+static void face_traverse (GtSim * s, int c, FaceFunc fn, void * data)
+{
+  FacePar p = { 0, fn, data };
+  if (c < 0) {
+    cell_traverse (s, 0, T_LEAFS, -1, traverse_all_direct_faces, &p);
+    for (int d = 1; d < 4; d += 2) {
+      BoundaryPar b = { d, traverse_face, &p };
+      p.d = d;
+      cell_traverse (s, 0, T_LEAFS, -1, boundary_filter, &b);
+    }
+  }
+  else {
+    p.d = 2*c;
+    cell_traverse (s, 0, T_LEAFS, -1, traverse_face, &p);
+    BoundaryPar b = { 2*c + 1, traverse_face, &p };
+    p.d = 2*c + 1;
+    cell_traverse (s, 0, T_LEAFS, -1, boundary_filter, &b);
+  }
+}
+
+static inline int fine_coarse (const Face * f) { return f->neighbor.l < f->cell.l; } /* ftt_face_type */
+
+/* ---- variables and boundary conditions ----------------------------------------------------- */
+
+static void var_alloc (GtSim * s, Var * v)
+{
+  for (int l = 0; l <= s->depth; l++)
+    v->lev[l] = calloc (s->size[l], sizeof (double));
+}
+
+static void var_free (GtSim * s, Var * v)
+{
+  for (int l = 0; l <= s->depth; l++)
+    free (v->lev[l]);
+}
+
+/* gfs_domain_copy_bc / gfs_domain_bc (domain.c:846-920) on a box whose four sides are periodic
+   (boundary.c:1240-1451): the ghost cells selected by (flags, max_depth) take the value of their
+   periodic image.  v1 == v for a plain BC; the homogeneous BC of a periodic side is the same copy. */
+static void bc (GtSim * s, Var * v, int flags, int max_depth)
+{
+  for (int l = 0; l <= s->depth; l++) {
+    if (max_depth >= 0 && l > max_depth)
+      break;
+    int n = s->n[l], r = s->r[l];
+    for (int side = 0; side < 4; side++)
+      for (int t = 1; t <= n; t++) {
+	int gi = side == 0 ? n + 1 : side == 1 ? 0 : t, gj = side == 2 ? n + 1 : side == 3 ? 0 : t;
+	int ii = side == 0 ? 1 : side == 1 ? n : t, ij = side == 2 ? 1 : side == 3 ? n : t;
+	int G = gi + r*gj;
+	unsigned char f = s->flag[l][G];
+	if (f == GT_NONE)
+	  continue;
+	int take = flags == T_LEAFS ? f == GT_LEAF :
+	  flags == T_LEVEL_LEAFS ? (l == max_depth || f == GT_LEAF) : 1;
+	if (take)
+	  v->lev[l][G] = v->lev[l][ii + r*ij];
+      }
+  }
+}
+
+/* ---- tree construction --------------------------------------------------------------------- */
+
+/* oct_new, ftt.c:45-83 with check_neighbors: a cell about to get children first makes sure that
+   none of its neighbours is coarser than itself */
+static void refine_single (GtSim * s, int l, int i, int j)
+{
+  assert (l < GT_MAXL);
+  int q = i + s->r[l]*j;
+  assert (s->flag[l][q] == GT_LEAF);
+  static const int di[4] = { 1, -1, 0, 0 }, dj[4] = { 0, 0, 1, -1 };
+  for (int d = 0; d < 4; d++) {
+    int ni = i + di[d], nj = j + dj[d];
+    if (ni < 1 || nj < 1 || ni > s->n[l] || nj > s->n[l])
+      continue; /* the ghost trees are matched at the end (gfs_domain_match) */
+    if (s->flag[l][ni + s->r[l]*nj] == GT_NONE) {
+      int pi = (ni + 1)/2, pj = (nj + 1)/2;
+      if (s->flag[l - 1][pi + s->r[l - 1]*pj] == GT_LEAF)
+	refine_single (s, l - 1, pi, pj);
+    }
+  }
+  s->flag[l][q] = GT_NODE;
+  if (!s->flag[l + 1])
+    s->flag[l + 1] = calloc (s->size[l + 1], 1);
+  for (int k = 0; k < 4; k++)
+    s->flag[l + 1][2*i - 1 + (k & 1) + s->r[l + 1]*(2*j - ((k >> 1) & 1))] = GT_LEAF;
+}
+
+/* ftt_cell_refine, ftt.c:169-192, with refine_maxlevel, refine.c:35-38: `refine' is the GfsFunction
+   of the GfsRefine object evaluated at the centre of the cell */
+typedef double (* GtRefineFunc) (double x, double y, void * ctx);
+
+static void refine_rec (GtSim * s, int l, int i, int j, GtRefineFunc refine, void * ctx)
+{
+  int q = i + s->r[l]*j;
+  if (s->flag[l][q] == GT_LEAF) {
+    double h = 1./s->n[l];
+    double x = -0.5 + (i - 0.5)*h, y = -0.5 + (j - 0.5)*h;
+    if (!(l < (* refine) (x, y, ctx)))
+      return;
+    refine_single (s, l, i, j);
+  }
+  for (int k = 0; k < 4; k++)
+    refine_rec (s, l + 1, 2*i - 1 + (k & 1), 2*j - ((k >> 1) & 1), refine, ctx);
+}
+
+/* ftt_refine_corner, ftt.c:2013-2074 */
+static int refine_corner (const GtSim * s, Cell cell)
+{
+  static const int perp[4][2] = { {2, 3}, {2, 3}, {1, 0}, {1, 0} };
+  for (int i = 0; i < 4; i++) {
+    Cell n = neighbor (s, cell, i);
+    if (exists (n) && !is_leaf (s, n)) {
+      Cell ch[2];
+      children_direction (s, n, OPP (i), ch);
+      for (int j = 0; j < 2; j++)
+	if (exists (ch[j])) {
+	  Cell nc = neighbor (s, ch[j], perp[i][j]);
+	  if (exists (nc) && !is_leaf (s, nc))
+	    return 1;
+	  if (!is_leaf (s, ch[j]))
+	    return 1;
+	}
+    }
+  }
+  return 0;
+}
+
+static void refine_cell_corner (GtSim * s, Cell c, void * data) /* simulation.c:1105-1109 */
+{
+  if (is_leaf (s, c) && refine_corner (s, c))
+    refine_single (s, c.l, cell_i (s, c), cell_j (s, c));
+}
+
+static void build_tree (GtSim * s, GtRefineFunc refine, void * ctx)
+{
+  for (int l = 0; l <= GT_MAXL; l++) {
+    s->n[l] = 1 << l;
+    s->r[l] = s->n[l] + 2;
+    s->size[l] = (size_t) s->r[l]*s->r[l];
+  }
+  s->flag[0] = calloc (s->size[0], 1);
+  s->depth = GT_MAXL; /* while the tree grows: every level refine_single allocates is valid */
+  s->flag[0][1 + s->r[0]] = GT_LEAF;
+  refine_rec (s, 0, 1, 1, refine, ctx);
+  /* gfs_domain_depth */
+  int depth = 0;
+  for (int l = 0; l <= GT_MAXL && s->flag[l]; l++)
+    depth = l;
+  /* gfs_simulation_refine, simulation.c:1226-1231 */
+  for (int l = depth - 2; l >= 0; l--)
+    cell_traverse (s, 0, T_LEVEL, l, refine_cell_corner, NULL);
+  s->depth = depth;
+  /* gfs_domain_match: the ghost trees of the periodic sides mirror the cells they face; the
+     refined patches of the cases restated here stay away from the sides */
+  for (int l = 0; l <= depth; l++) {
+    int n = s->n[l], r = s->r[l];
+    for (int t = 1; t <= n; t++) {
+      s->flag[l][0 + r*t] = s->flag[l][n + r*t];
+      s->flag[l][n + 1 + r*t] = s->flag[l][1 + r*t];
+      s->flag[l][t + r*0] = s->flag[l][t + r*n];
+      s->flag[l][t + r*(n + 1)] = s->flag[l][t + r*1];
+    }
+    for (int t = 1; t <= n; t++) /* both sides of a periodic pair at the same refinement */
+      assert (s->flag[l][n + r*t] == s->flag[l][1 + r*t] && s->flag[l][t + r*n] == s->flag[l][t + r*1]);
+  }
+}
+
+/* ---- fluid.c: neighbour values and gradients ---------------------------------------------- */
+
+/* average_neighbor_value, fluid.c:64-93 */
+static double average_neighbor_value (const GtSim * s, const Face * face, const Var * v, double * x)
+{
+  assert (face->neighbor.l == face->cell.l);
+  if (is_leaf (s, face->neighbor))
+    return *val (v, face->neighbor);
+  Cell ch[2];
+  double av = 0., a = 0.;
+  children_direction (s, face->neighbor, OPP (face->d), ch);
+  for (int i = 0; i < 2; i++)
+    if (exists (ch[i])) {
+      double w = 1.;
+      a += w;
+      av += w*(*val (v, ch[i]));
+    }
+  if (a > 0.) {
+    *x = 3./4.;
+    return av/a;
+  }
+  return *val (v, face->cell);
+}
+
+/* interpolate_1D1, fluid.c:178-197 */
+static GfsGradient interpolate_1D1 (const GtSim * s, Cell cell, int d, double x, const Var * v)
+{
+  GfsGradient p = { 1., 0. };
+  Face f = { cell, neighbor (s, cell, d), d };
+  if (exists (f.neighbor)) {
+    double x2 = 1.;
+    double p2 = average_neighbor_value (s, &f, v, &x2);
+    double a2 = x/x2;
+    p.b += a2*p2;
+    p.a -= a2;
+  }
+  return p;
+}
+
+/* gradient_fine_coarse, fluid.c:283-309 */
+static Gradient gradient_fine_coarse (const GtSim * s, const Face * face, const Var * v)
+{
+  Gradient g;
+  assert (fine_coarse (face));
+  int dp = perpendicular[face->d][cell_id (s, face->cell)];
+  assert (dp >= 0);
+  GfsGradient p = interpolate_1D1 (s, face->neighbor, dp, 1./4., v);
+  g.a = 2./3.;
+  g.b = 2.*p.a/3.;
+  g.c = 2.*p.b/3.;
+  return g;
+}
+
+/* gfs_neighbor_value, fluid.c:364-396 */
+static double neighbor_value (const GtSim * s, const Face * face, const Var * v, double * x)
+{
+  if (face->neighbor.l == face->cell.l)
+    return average_neighbor_value (s, face, v, x);
+  int dp = perpendicular[face->d][cell_id (s, face->cell)];
+  assert (dp >= 0);
+  GfsGradient vc = interpolate_1D1 (s, face->neighbor, dp, 1./4., v);
+  *x = 3./2.;
+  return vc.a*(*val (v, face->neighbor)) + vc.b;
+}
+
+/* gfs_center_gradient, fluid.c:434-475 */
+static double center_gradient (const GtSim * s, Cell cell, int c, const Var * v)
+{
+  int d = 2*c;
+  Face f1 = { cell, neighbor (s, cell, OPP (d)), OPP (d) };
+  double v0 = *val (v, cell);
+  if (exists (f1.neighbor)) {
+    Face f2 = { cell, neighbor (s, cell, d), d };
+    double x1 = 1., v1;
+    v1 = neighbor_value (s, &f1, v, &x1);
+    if (exists (f2.neighbor)) {
+      double x2 = 1., v2;
+      v2 = neighbor_value (s, &f2, v, &x2);
+      return (x1*x1*(v2 - v0) + x2*x2*(v0 - v1))/(x1*x2*(x2 + x1));
+    }
+    return (v0 - v1)/x1;
+  }
+  Face f2 = { cell, neighbor (s, cell, d), d };
+  if (exists (f2.neighbor)) {
+    double x2 = 1.;
+    return (neighbor_value (s, &f2, v, &x2) - v0)/x2;
+  }
+  return 0.;
+}
+
+/* gfs_face_gradient, fluid.c:778-829 */
+static void face_gradient (const GtSim * s, const Face * face, GfsGradient * g, const Var * v,
+			   int max_level)
+{
+  g->a = g->b = 0.;
+  if (!exists (face->neighbor))
+    return;
+  int level = face->cell.l;
+  if (face->neighbor.l < level) {
+    Gradient gcf = gradient_fine_coarse (s, face, v);
+    g->a = gcf.a;
+    g->b = gcf.b*(*val (v, face->neighbor)) + gcf.c;
+  }
+  else if (level == max_level || is_leaf (s, face->neighbor)) {
+    g->a = 1.;
+    g->b = *val (v, face->neighbor);
+  }
+  else {
+    Cell ch[2];
+    Face f;
+    f.d = OPP (face->d);
+    children_direction (s, face->neighbor, f.d, ch);
+    f.neighbor = face->cell;
+    int n = 2;
+    for (int i = 0; i < n; i++)
+      if (exists (f.cell = ch[i])) {
+	Gradient gcf = gradient_fine_coarse (s, &f, v);
+	double sf = 1.;
+	g->a += sf*gcf.b;
+	g->b += sf*(gcf.a*(*val (v, f.cell)) - gcf.c);
+      }
+    double sf = 1.*n/2.;
+    g->a /= sf;
+    g->b /= sf;
+  }
+}
+
+/* face_weighted_gradient, fluid.c:833-893 with dimension = 2 (gfs_face_weighted_gradient_2D) */
+static void face_weighted_gradient (const GtSim * s, const Face * face, GfsGradient * g,
+				    const Var * v, int max_level)
+{
+  g->a = g->b = 0.;
+  if (!exists (face->neighbor))
+    return;
+  int level = face->cell.l;
+  if (face->neighbor.l < level) {
+    double w = *val (&s->w[face->d], face->cell);
+    Gradient gcf = gradient_fine_coarse (s, face, v);
+    g->a = w*gcf.a;
+    g->b = w*(gcf.b*(*val (v, face->neighbor)) + gcf.c);
+  }
+  else if (level == max_level || is_leaf (s, face->neighbor)) {
+    double w = *val (&s->w[face->d], face->cell);
+    g->a = w;
+    g->b = w*(*val (v, face->neighbor));
+  }
+  else {
+    Cell ch[2];
+    Face f;
+    f.d = OPP (face->d);
+    children_direction (s, face->neighbor, f.d, ch);
+    f.neighbor = face->cell;
+    for (int i = 0; i < 2; i++)
+      if (exists (f.cell = ch[i])) {
+	double w = *val (&s->w[f.d], f.cell);
+	Gradient gcf = gradient_fine_coarse (s, &f, v);
+	g->a += w*gcf.b;
+	g->b += w*(gcf.a*(*val (v, f.cell)) - gcf.c);
+      }
+  }
+}
+
+/* gfs_face_interpolated_value, fluid.c:2186-2198 */
+static double face_interpolated_value (const GtSim * s, const Face * face, const Var * v)
+{
+  double x1 = 1., v1;
+  if (exists (face->neighbor)) {
+    assert (is_leaf (s, face->neighbor) || face->neighbor.l < face->cell.l);
+    v1 = neighbor_value (s, face, v, &x1);
+    return ((x1 - 0.5)*(*val (v, face->cell)) + 0.5*v1)/x1;
+  }
+  return *val (v, face->cell);
+}
+
+/* ---- Poisson: poisson.c ------------------------------------------------------------------- */
+
+static void reset_coeff (GtSim * s, Cell c, void * data) /* poisson.c:756-766 */
+{
+  for (int d = 0; d < 4; d++)
+    *val (&s->w[d], c) = 0.;
+}
+
+static void poisson_coeff (GtSim * s, const Face * face, void * data) /* poisson.c:768-799 */
+{
+  double alpha = 1.;
+  double v = 1.*alpha*1./1.;
+  *val (&s->w[face->d], face->cell) += v;
+  if (!fine_coarse (face))
+    *val (&s->w[OPP (face->d)], face->neighbor) += v;
+  else
+    *val (&s->w[OPP (face->d)], face->neighbor) += v/2.; /* FTT_CELLS_DIRECTION */
+}
+
+static void face_coeff_from_below (GtSim * s, Cell cell, void * data) /* poisson.c:826-853 */
+{
+  unsigned neighbors = 0;
+  for (int d = 0; d < 4; d++) {
+    Cell ch[2];
+    double * f = val (&s->w[d], cell);
+    *f = 0.;
+    children_direction (s, cell, d, ch);
+    for (int i = 0; i < 2; i++)
+      if (exists (ch[i]))
+	*f += *val (&s->w[d], ch[i]);
+    *f /= 2;
+    Cell nb = neighbor (s, cell, d);
+    if (*f != 0. && exists (nb)) {
+      int i = cell_i (s, nb), j = cell_j (s, nb), n = s->n[nb.l];
+      if (i >= 1 && i <= n && j >= 1 && j <= n) /* !GFS_CELL_IS_BOUNDARY */
+	neighbors++;
+    }
+  }
+  if (neighbors == 1)
+    for (int d = 0; d < 4; d++)
+      *val (&s->w[d], cell) = 0.;
+}
+
+/* gfs_poisson_coefficients (alpha = NULL), poisson.c:855-901.  The ghost cells are reset with
+   the cells they mirror (their weights are written by the faces of the sides, never read). */
+static void poisson_coefficients (GtSim * s)
+{
+  for (int d = 0; d < 4; d++)
+    for (int l = 0; l <= s->depth; l++)
+      memset (s->w[d].lev[l], 0, s->size[l]*sizeof (double));
+  cell_traverse (s, 0, T_ALL, -1, reset_coeff, NULL);
+  face_traverse (s, -1, poisson_coeff, NULL);
+  cell_traverse (s, 1, T_NON_LEAFS, -1, face_coeff_from_below, NULL);
+}
+
+typedef struct { Var * u, * rhs, * dia, * res; int maxlevel; double omega; } RelaxParams;
+
+static void relax2D (GtSim * s, Cell cell, void * data) /* poisson.c:532-557 */
+{
+  RelaxParams * p = data;
+  GfsGradient g, ng;
+  g.a = *val (p->dia, cell);
+  g.b = 0.;
+  Face f;
+  f.cell = cell;
+  for (f.d = 0; f.d < 4; f.d++) {
+    f.neighbor = neighbor (s, cell, f.d);
+    if (exists (f.neighbor)) {
+      face_weighted_gradient (s, &f, &ng, p->u, p->maxlevel);
+      g.a += ng.a;
+      g.b += ng.b;
+    }
+  }
+  if (g.a != 0.)
+    *val (p->u, cell) = (1. - p->omega)*(*val (p->u, cell))
+      + p->omega*(g.b - *val (p->rhs, cell))/g.a;
+  else
+    *val (p->u, cell) = 0.;
+}
+
+static void residual_set2D (GtSim * s, Cell cell, void * data) /* poisson.c:657-678 */
+{
+  RelaxParams * p = data;
+  GfsGradient g, ng;
+  g.a = *val (p->dia, cell);
+  g.b = 0.;
+  Face f;
+  f.cell = cell;
+  for (f.d = 0; f.d < 4; f.d++) {
+    f.neighbor = neighbor (s, cell, f.d);
+    if (exists (f.neighbor)) {
+      face_weighted_gradient (s, &f, &ng, p->u, p->maxlevel);
+      g.a += ng.a;
+      g.b += ng.b;
+    }
+  }
+  *val (p->res, cell) = *val (p->rhs, cell) - (g.b - *val (p->u, cell)*g.a);
+}
+
+/* gfs_residual on the leaves, poisson.c:721-747 */
+static void residual (GtSim * s, Var * u, Var * rhs, Var * dia, Var * res)
+{
+  RelaxParams p = { u, rhs, dia, res, -1, 1. };
+  cell_traverse (s, 0, T_LEAFS, -1, residual_set2D, &p);
+}
+
+typedef struct { Var * res; double bias; GoNorm n; } ResData;
+
+static void norm_add (GoNorm * n, double v, double weight) /* gfs_norm_add, fluid.c:2139-2151 */
+{
+  n->bias += weight*v;
+  v = fabs (v);
+  if (weight != 0. && v > n->infty)
+    n->infty = v;
+  n->first += weight*v;
+  n->second += weight*v*v;
+  n->w += weight;
+}
+
+static void norm_update (GoNorm * n) /* gfs_norm_update, fluid.c:2159-2171 */
+{
+  if (n->w > 0.0) {
+    n->bias /= n->w;
+    n->first /= n->w;
+    n->second = sqrt (n->second/n->w);
+  }
+  else
+    n->infty = 0.0;
+}
+
+static void add_norm_residual (GtSim * s, Cell cell, void * data) /* domain.c:2239-2246 */
+{
+  ResData * p = data;
+  double size = cell_size (cell);
+  norm_add (&p->n, *val (p->res, cell)/(1.*size*size), 1.);
+  p->bias += *val (p->res, cell);
+}
+
+static GoNorm norm_residual (GtSim * s, double dt, Var * res) /* domain.c:2264-2288 */
+{
+  ResData p = { res, 0., { 0., 0., 0., - DBL_MAX, 0. } };
+  cell_traverse (s, 0, T_LEAFS, -1, add_norm_residual, &p);
+  norm_update (&p.n);
+  dt *= dt;
+  p.n.bias = p.bias*dt;
+  p.n.first *= dt;
+  p.n.second *= dt;
+  p.n.infty *= dt;
+  return p.n;
+}
+
+static void get_from_below_2D (GtSim * s, Cell cell, void * data) /* poisson.c:1057-1068 */
+{
+  Var * v = data;
+  double sum = 0.;
+  for (int k = 0; k < 4; k++) {
+    Cell ch = child (s, cell, k);
+    if (exists (ch))
+      sum += *val (v, ch);
+  }
+  *val (v, cell) = sum;
+}
+
+static void get_from_above (GtSim * s, Cell parent, void * data) /* poisson.c:1005-1042 */
+{
+  Var * v = data;
+  int level = parent.l;
+  double h[2];
+  for (int c = 0; c < 2; c++) {
+    Face f;
+    GfsGradient g;
+    f.cell = parent;
+    f.d = 2*c;
+    f.neighbor = neighbor (s, parent, f.d);
+    face_gradient (s, &f, &g, v, level);
+    double g1 = g.b - g.a*(*val (v, parent));
+    f.d = 2*c + 1;
+    f.neighbor = neighbor (s, parent, f.d);
+    face_gradient (s, &f, &g, v, level);
+    double g2 = g.b - g.a*(*val (v, parent));
+    h[c] = (g1 - g2)/2.;
+  }
+  for (int k = 0; k < 4; k++) {
+    Cell ch = child (s, parent, k);
+    if (exists (ch)) {
+      /* ftt_cell_relative_pos, ftt.c:327-340 */
+      double px = (k & 1) ? 0.25 : -0.25, py = (k & 2) ? -0.25 : 0.25;
+      *val (v, ch) = *val (v, parent);
+      *val (v, ch) += px*h[0];
+      *val (v, ch) += py*h[1];
+    }
+  }
+}
+
+static void cell_reset (GtSim * s, Cell c, void * data) { *val ((Var *) data, c) = 0.; }
+
+/* relax_loop, poisson.c:1070-1089 (the homogeneous BC of a periodic side is the periodic copy) */
+static void relax_loop (GtSim * s, Var * dp, RelaxParams * q, unsigned nrelax)
+{
+  bc (s, dp, T_LEVEL_LEAFS, q->maxlevel);
+  for (unsigned n = 0; n < nrelax - 1; n++) {
+    cell_traverse (s, 0, T_LEVEL_LEAFS, q->maxlevel, relax2D, q);
+    bc (s, dp, T_LEVEL_LEAFS, q->maxlevel);
+  }
+  cell_traverse (s, 0, T_LEVEL_LEAFS, q->maxlevel, relax2D, q);
+}
+
+typedef struct { Var * u, * dp; } CorrectData;
+static void correct (GtSim * s, Cell c, void * data) /* poisson.c:998-1003 */
+{
+  CorrectData * d = data;
+  *val (d->u, c) += *val (d->dp, c);
+}
+
+/* gfs_poisson_cycle, poisson.c:1105-1178 */
+static void poisson_cycle (GtSim * s, GoMultilevelParams * p, Var * u, Var * rhs, Var * dia, Var * res)
+{
+  Var dp;
+  var_alloc (s, &dp);
+  unsigned minlevel = p->minlevel;
+  cell_traverse (s, 1, T_NON_LEAFS, -1, get_from_below_2D, res);
+  unsigned nrelax = p->nrelax;
+  for (unsigned l = minlevel; l < p->depth; l++)
+    nrelax *= p->erelax;
+  RelaxParams q = { &dp, res, dia, NULL, (int) minlevel, p->omega };
+  cell_traverse (s, 0, T_LEVEL_LEAFS, q.maxlevel, cell_reset, &dp);
+  relax_loop (s, &dp, &q, nrelax);
+  nrelax /= p->erelax;
+  for (q.maxlevel = minlevel + 1; q.maxlevel <= (int) p->depth; q.maxlevel++, nrelax /= p->erelax) {
+    cell_traverse (s, 0, T_LEVEL_NON_LEAFS, q.maxlevel - 1, get_from_above, &dp);
+    relax_loop (s, &dp, &q, nrelax);
+  }
+  CorrectData cd = { u, &dp };
+  cell_traverse (s, 0, T_LEAFS, -1, correct, &cd);
+  bc (s, u, T_LEAFS, -1);
+  residual (s, u, rhs, dia, res);
+  var_free (s, &dp);
+}
+
+/* gfs_poisson_solve, poisson.c:1225-1269 */
+static void poisson_solve (GtSim * s, GoMultilevelParams * par, Var * lhs, Var * rhs, Var * res,
+			   Var * dia, double dt)
+{
+  unsigned minlevel = par->minlevel;
+  par->depth = s->depth;
+  par->niter = 0;
+  residual (s, lhs, rhs, dia, res);
+  par->residual_before = par->residual = norm_residual (s, dt, res);
+  double res_max_before = par->residual.infty;
+  while (par->niter < par->nitermin ||
+	 (par->residual.infty > par->tolerance && par->niter < par->nitermax)) {
+    poisson_cycle (s, par, lhs, rhs, dia, res);
+    par->residual = norm_residual (s, dt, res);
+    if (par->residual.infty == res_max_before)
+      break;
+    if (par->residual.infty > res_max_before/1.1 && par->minlevel < par->depth)
+      par->minlevel++;
+    res_max_before = par->residual.infty;
+    par->niter++;
+  }
+  par->minlevel = minlevel;
+}
+
+/* ---- projection: timestep.c --------------------------------------------------------------- */
+
+static void face_reset_un (GtSim * s, const Face * f, void * data) /* advection.c:575-587 */
+{
+  *val (&s->un[OPP (f->d)], f->neighbor) = *val (&s->un[f->d], f->cell) = 0.;
+}
+
+static void face_interpolated_un (GtSim * s, const Face * f, void * data) /* advection.c:549-573 */
+{
+  double u = face_interpolated_value (s, f, &s->u[f->d/2]);
+  *val (&s->un[f->d], f->cell) = u;
+  if (!fine_coarse (f))
+    *val (&s->un[OPP (f->d)], f->neighbor) = u;
+  else
+    *val (&s->un[OPP (f->d)], f->neighbor) += u*1./(1.*2 /* FTT_CELLS_DIRECTION */);
+}
+
+typedef struct { Var * p, * gv; double dt; } CorrectPar;
+
+static void correct_normal_velocity (GtSim * s, const Face * face, void * data) /* timestep.c:118-144 */
+{
+  CorrectPar * par = data;
+  GfsGradient g;
+  face_weighted_gradient (s, face, &g, par->p, -1);
+  double dp = (g.b - g.a*(*val (par->p, face->cell)))/cell_size (face->cell);
+  if (face->d & 1)
+    dp = - dp;
+  double f = 1.;
+  if (f > 0.)
+    dp /= f;
+  *val (&s->un[face->d], face->cell) -= dp*par->dt;
+  if (par->gv)
+    *val (&par->gv[face->d/2], face->cell) += dp*1.;
+  if (fine_coarse (face))
+    dp *= 1./(1.*4/2);
+  *val (&s->un[OPP (face->d)], face->neighbor) -= dp*par->dt;
+  if (par->gv)
+    *val (&par->gv[face->d/2], face->neighbor) += dp*1.;
+}
+
+static void correct_normal_velocities (GtSim * s, Var * p, Var * g, double dt) /* timestep.c:163-179 */
+{
+  CorrectPar par = { p, g, dt };
+  face_traverse (s, 0, correct_normal_velocity, &par);  /* FTT_XY */
+  face_traverse (s, 1, correct_normal_velocity, &par);
+}
+
+static void reset_cell_gradients (GtSim * s, Cell c, void * data) /* timestep.c:36-41 */
+{
+  Var * g = data;
+  for (int k = 0; k < 2; k++)
+    *val (&g[k], c) = 0.;
+}
+
+static void scale_cell_gradients (GtSim * s, Cell cell, void * data) /* timestep.c:60-90 */
+{
+  Var * g = data;
+  for (int c = 0; c < 2; c++) {
+    Cell c1 = neighbor (s, cell, 2*c), c2 = neighbor (s, cell, 2*c + 1);
+    if (exists (c1) && exists (c2))
+      *val (&g[c], cell) /= 2.;
+  }
+}
+
+static void normal_divergence (GtSim * s, Cell cell, void * data) /* fluid.c:2310-2324 */
+{
+  Var * v = data;
+  double div = 0.;
+  for (int d = 0; d < 4; d++)
+    div += ((d & 1) ? -1. : 1.)*(*val (&s->un[d], cell))*1.;
+  *val (v, cell) = div*cell_size (cell);
+}
+
+typedef struct { Var * div; double dt; } ScalePar;
+static void scale_divergence (GtSim * s, Cell cell, void * data) /* timestep.c:181-187 */
+{
+  ScalePar * p = data;
+  *val (p->div, cell) /= p->dt;
+}
+
+/* mac_projection, timestep.c:356-444 */
+static void mac_projection (GtSim * s, GoMultilevelParams * par, double dt, Var * p, Var * g)
+{
+  cell_traverse (s, 0, T_LEAFS, -1, reset_cell_gradients, g);
+  Var dia, div, res1;
+  var_alloc (s, &dia);
+  var_alloc (s, &div);
+  var_alloc (s, &res1);
+  poisson_coefficients (s);
+  cell_traverse (s, 0, T_LEAFS, -1, normal_divergence, &div);
+  ScalePar sp = { &div, dt };
+  cell_traverse (s, 0, T_LEAFS, -1, scale_divergence, &sp);
+  poisson_solve (s, par, p, &div, &res1, &dia, dt);
+  var_free (s, &dia);
+  var_free (s, &div);
+  var_free (s, &res1);
+  correct_normal_velocities (s, p, g, dt);
+  /* gfs_scale_gradients, timestep.c:92-107 */
+  cell_traverse (s, 0, T_LEAFS, -1, scale_cell_gradients, g);
+  for (int c = 0; c < 2; c++)
+    bc (s, &g[c], T_LEAFS, -1);
+}
+
+typedef struct { Var * g; double dt; } CorrectCentered;
+static void correct_centered (GtSim * s, Cell cell, void * data) /* timestep.c:486-496 */
+{
+  CorrectCentered * p = data;
+  for (int c = 0; c < 2; c++)
+    *val (&s->u[c], cell) -= *val (&p->g[c], cell)*p->dt;
+}
+
+static void correct_centered_velocities (GtSim * s, Var * g, double dt) /* timestep.c:498-530 */
+{
+  CorrectCentered p = { g, dt };
+  cell_traverse (s, 0, T_LEAFS, -1, correct_centered, &p);
+  for (int c = 0; c < 2; c++)
+    bc (s, &s->u[c], T_LEAFS, -1);
+}
+
+static void approximate_projection (GtSim * s, GoMultilevelParams * par, double dt, Var * p, Var * g)
+{ /* timestep.c:560-596 */
+  face_traverse (s, -1, face_reset_un, NULL);
+  face_traverse (s, -1, face_interpolated_un, NULL);
+  mac_projection (s, par, dt, p, g);
+  correct_centered_velocities (s, g, dt);
+}
+
+/* ---- Godunov advection: advection.c ------------------------------------------------------- */
+
+typedef struct { double dt; Var * v; int use_centered_velocity; } AdvPar;
+
+static double transverse_term (GtSim * s, const AdvPar * par, Cell cell, const double * msize, int c)
+{ /* advection.c:27-47 */
+  double vtan = par->use_centered_velocity ?
+    *val (&s->u[c], cell) :
+    (*val (&s->un[2*c], cell) + *val (&s->un[2*c + 1], cell))/2.;
+  Face f;
+  GfsGradient gf;
+  f.d = vtan > 0. ? 2*c + 1 : 2*c;
+  f.cell = cell;
+  f.neighbor = neighbor (s, cell, f.d);
+  face_gradient (s, &f, &gf, par->v, -1);
+  double g = gf.b - gf.a*(*val (par->v, cell));
+  if (vtan > 0.) g = - g;
+  return par->dt*vtan*g/(2.*msize[c]);
+}
+
+static void cell_advected_face_values (GtSim * s, Cell cell, void * data) /* advection.c:58-99 */
+{
+  const AdvPar * par = data;
+  double size = cell_size (cell), msize[2] = { size, size };
+  for (int c = 0; c < 2; c++) {
+    double unorm = par->use_centered_velocity ?
+      par->dt*(*val (&s->u[c], cell))/msize[c] :
+      par->dt*(*val (&s->un[2*c], cell) + *val (&s->un[2*c + 1], cell))/(2.*msize[c]);
+    double g = center_gradient (s, cell, c, par->v);
+    double vl = *val (par->v, cell) + MIN ((1. - unorm)/2., 0.5)*g;
+    double vr = *val (par->v, cell) + MAX ((- 1. - unorm)/2., -0.5)*g;
+    double src = par->dt*0./2.;
+    double dv = transverse_term (s, par, cell, msize, (c + 1) % 2);
+    *val (&s->fv[2*c], cell)     = vl + src - dv;
+    *val (&s->fv[2*c + 1], cell) = vr + src - dv;
+  }
+}
+
+/* gfs_domain_face_bc (domain.c:1209-1232) on periodic sides (boundary.c:1251-1258,1343-1347): the
+   leaf ghost cell beyond side sd holds the face value f[OPP (sd)].v of its periodic image */
+static void face_bc (GtSim * s)
+{
+  for (int l = 0; l <= s->depth; l++) {
+    int n = s->n[l], r = s->r[l];
+    for (int sd = 0; sd < 4; sd++)
+      for (int t = 1; t <= n; t++) {
+	int gi = sd == 0 ? n + 1 : sd == 1 ? 0 : t, gj = sd == 2 ? n + 1 : sd == 3 ? 0 : t;
+	int ii = sd == 0 ? 1 : sd == 1 ? n : t, ij = sd == 2 ? 1 : sd == 3 ? n : t;
+	if (s->flag[l][gi + r*gj] == GT_LEAF)
+	  s->fv[OPP (sd)].lev[l][gi + r*gj] = s->fv[OPP (sd)].lev[l][ii + r*ij];
+      }
+  }
+}
+
+static void face_values_set (GtSim * s, AdvPar * par) /* timestep.c:644-654 */
+{
+  cell_traverse (s, 0, T_LEAFS, -1, cell_advected_face_values, par);
+  face_bc (s);
+}
+
+/* interpolate_1D1 of advection.c:132-180.  The fork's text declares s2 twice (the second, inner
+   declaration shadows the variable the two assignments above it set); the restatement takes the
+   assigned values, which is upstream Gerris' behaviour -- the one that produced the .ref files. */
+static double adv_interpolate_1D1 (const GtSim * s, Cell cell, int dright, int dup, double x)
+{
+  int dleft = OPP (dright);
+  Cell n = neighbor (s, cell, dup);
+  int boundary = 1;
+  if (exists (n)) {
+    int i = cell_i (s, n), j = cell_j (s, n), nn = s->n[n.l];
+    boundary = !(i >= 1 && i <= nn && j >= 1 && j <= nn);
+  }
+  if (exists (n) && !boundary) {
+    double s2 = is_leaf (s, n) ? 1. : 0.5;
+    double s1 = 1.;
+    double v1 = *val (&s->fv[dleft], cell), v2;
+    assert (n.l == cell.l);
+    if (is_leaf (s, n))
+      v2 = *val (&s->fv[dleft], n);
+    else {
+      n = child_corner (s, n, dleft, OPP (dup));
+      if (exists (n))
+	v2 = *val (&s->fv[dleft], n);
+      else
+	s2 = v2 = 0.;
+    }
+    return s2 > 0. ? (v2*(s1 - 1. + 2.*x) + v1*(s2 + 1. - 2.*x))/(s1 + s2) : v1;
+  }
+  return *val (&s->fv[dleft], cell);
+}
+
+/* gfs_face_upwinded_value, advection.c:267-343 */
+static double face_upwinded_value (GtSim * s, const Face * face, int centered_upwinding)
+{
+  double un;
+  if (centered_upwinding)
+    un = face_interpolated_value (s, face, &s->u[face->d/2]);
+  else
+    un = *val (&s->un[face->d], face->cell);
+  if (face->d & 1)
+    un = - un;
+  double fc = *val (&s->fv[face->d], face->cell);
+  if (!fine_coarse (face)) {
+    double fn = *val (&s->fv[OPP (face->d)], face->neighbor);
+    return un > 0. ? fc : un < 0. ? fn : (fc + fn)/2.;
+  }
+  if (un > 0.)
+    return fc;
+  int dp = perpendicular[face->d][cell_id (s, face->cell)];
+  assert (dp >= 0);
+  double vcoarse = adv_interpolate_1D1 (s, face->neighbor, face->d, dp, 1./4.);
+  if (un == 0.)
+    return (fc + vcoarse)/2.;
+  return vcoarse;
+}
+
+static void face_advected_normal_velocity (GtSim * s, const Face * face, void * data)
+{ /* advection.c:513-539 */
+  double u = face_upwinded_value (s, face, 1);
+  *val (&s->un[face->d], face->cell) = u;
+  if (!fine_coarse (face))
+    *val (&s->un[OPP (face->d)], face->neighbor) = u;
+  else
+    *val (&s->un[OPP (face->d)], face->neighbor) += u*1./(1.*2);
+}
+
+static void predicted_face_velocities (GtSim * s) /* timestep.c:681-717 */
+{
+  face_traverse (s, -1, face_reset_un, NULL);
+  AdvPar par = { s->dt, NULL, 1 };
+  for (int c = 0; c < 2; c++) {
+    par.v = &s->u[c];
+    face_values_set (s, &par);
+    face_traverse (s, c, face_advected_normal_velocity, NULL);
+  }
+}
+
+typedef struct { double dt; Var * fvar, * g; int c; } FluxPar;
+
+static void face_reset (GtSim * s, const Face * f, void * data) /* fluid.c gfs_face_reset */
+{
+  FluxPar * p = data;
+  *val (p->fvar, f->cell) = *val (p->fvar, f->neighbor) = 0.;
+}
+
+static void face_velocity_advection_flux (GtSim * s, const Face * face, void * data)
+{ /* advection.c:398-435 */
+  FluxPar * par = data;
+  double flux = 1.*(*val (&s->un[face->d], face->cell))*par->dt/cell_size (face->cell);
+  flux *= face_upwinded_value (s, face, 0)
+    - face_interpolated_value (s, face, &par->g[par->c])*par->dt/2.;
+  if (face->d & 1)
+    flux = - flux;
+  *val (par->fvar, face->cell) -= flux;
+  if (!fine_coarse (face))
+    *val (par->fvar, face->neighbor) += flux;
+  else
+    *val (par->fvar, face->neighbor) += flux/4 /* FTT_CELLS */;
+}
+
+typedef struct { Var * sv, * fvar, * g; double dt; } UpdatePar;
+static void advection_update (GtSim * s, Cell cell, void * data) /* advection.c:784-819 */
+{
+  UpdatePar * p = data;
+  *val (p->sv, cell) += *val (p->fvar, cell)/1.;
+}
+static void add_pressure_gradient (GtSim * s, Cell cell, void * data) /* timestep.c:809-812 */
+{
+  UpdatePar * p = data;
+  *val (p->sv, cell) -= *val (p->g, cell)*p->dt;
+}
+
+/* variable_sources, timestep.c:872-921, for a velocity component */
+static void variable_sources (GtSim * s, int c, double dt, Var * gmac, Var * g)
+{
+  Var fvar;
+  var_alloc (s, &fvar);
+  FluxPar fp = { dt, &fvar, gmac, c };
+  AdvPar ap = { dt, &s->u[c], 0 };
+  face_traverse (s, -1, face_reset, &fp);
+  face_values_set (s, &ap);
+  face_traverse (s, -1, face_velocity_advection_flux, &fp);
+  UpdatePar up = { &s->u[c], &fvar, g ? &g[c] : NULL, dt };
+  cell_traverse (s, 0, T_LEAFS, -1, advection_update, &up);
+  var_free (s, &fvar);
+  if (g)
+    cell_traverse (s, 0, T_LEAFS, -1, add_pressure_gradient, &up);
+}
+
+static void centered_velocity_advection (GtSim * s, Var * gmac, Var * g) /* timestep.c:976-1016 */
+{
+  for (int c = 0; c < 2; c++)
+    variable_sources (s, c, s->dt, gmac, g);
+  for (int c = 0; c < 2; c++)
+    bc (s, &s->u[c], T_LEAFS, -1);
+}
+
+/* ---- CFL, time step, coarse values ----------------------------------------------------------- */
+
+static void minimum_mac_cfl (GtSim * s, const Face * face, void * data) /* domain.c:2824-2856 */
+{
+  double * cfl = data;
+  double un = *val (&s->un[face->d], face->cell);
+  double length = cell_size (face->cell);
+  if (un != 0.) {
+    double cflu = length/fabs (un);
+    if (cflu*cflu < *cfl)
+      *cfl = cflu*cflu;
+  }
+}
+
+static void minimum_cfl (GtSim * s, Cell cell, void * data) /* domain.c:2858-2897 */
+{
+  double * cfl = data;
+  double length = cell_size (cell);
+  for (int c = 0; c < 2; c++) {
+    double fm = 1.;
+    if (*val (&s->u[c], cell) != 0.) {
+      double cflu = length/fabs (fm*(*val (&s->u[c], cell)));
+      if (cflu*cflu < *cfl)
+	*cfl = cflu*cflu;
+    }
+  }
+}
+
+static double domain_cfl (GtSim * s) /* domain.c:2899-2923 */
+{
+  double cfl = DBL_MAX;
+  face_traverse (s, -1, minimum_mac_cfl, &cfl);
+  cell_traverse (s, 0, T_LEAFS, -1, minimum_cfl, &cfl);
+  return sqrt (cfl);
+}
+
+static void set_timestep (GtSim * s) /* simulation.c:1569-1633; the only event time is `end' */
+{
+  double t = s->t;
+  s->dt = s->cfl*domain_cfl (s);
+  double tnext = G_MAXINT;
+  if (s->end < tnext)
+    tnext = s->end;
+  double n = ceil ((tnext - t)/s->dt);
+  if (n > 0. && n < G_MAXINT) {
+    s->dt = (tnext - t)/n;
+    if (n == 1.)
+      s->tnext = tnext;
+    else
+      s->tnext = t + s->dt;
+  }
+  else
+    s->tnext = t + s->dt;
+  if (s->dt < 1e-9)
+    s->dt = 1e-9;
+}
+
+static void get_from_below_intensive (GtSim * s, Cell cell, void * data) /* fluid.c:1843-1864 */
+{
+  Var * v = data;
+  double sum = 0., sa = 0.;
+  for (int k = 0; k < 4; k++) {
+    Cell ch = child (s, cell, k);
+    if (exists (ch)) {
+      double a = 1.;
+      sum += *val (v, ch)*a;
+      sa += a;
+    }
+  }
+  *val (v, cell) = sum/sa;
+}
+
+static void coarse_init (GtSim * s) /* adaptive.c:43-58 on every variable */
+{
+  Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1] };
+  for (unsigned k = 0; k < sizeof (all)/sizeof (all[0]); k++)
+    cell_traverse (s, 1, T_NON_LEAFS, -1, get_from_below_intensive, all[k]);
+}
+
+/* ---- the simulation of test/periodic/periodic.gfs ------------------------------------------ */
+
+static void cell_pos (const GtSim * s, Cell c, double * x, double * y) /* ftt_cell_pos, box = unit square */
+{
+  double h = cell_size (c);
+  *x = -0.5 + (cell_i (s, c) - 0.5)*h;
+  *y = -0.5 + (cell_j (s, c) - 0.5)*h;
+}
+
+static void init_uv (GtSim * s, Cell c, void * data) /* periodic.gfs:26-29 */
+{
+  double x, y;
+  cell_pos (s, c, &x, &y);
+  *val (&s->u[0], c) = (1. - 2.*cos (2.*M_PI*x)*sin (2.*M_PI*y));
+  *val (&s->u[1], c) = (1. + 2.*sin (2.*M_PI*x)*cos (2.*M_PI*y));
+}
+
+/* a GfsSimulation on one periodic box refined by `refine' (default parameters of
+   gfs_multilevel_params_init / gfs_advection_params_init; U, V, P zero) */
+GtSim * gt_new (GtRefineFunc refine, void * ctx)
+{
+  GtSim * s = calloc (1, sizeof (GtSim));
+  build_tree (s, refine, ctx);
+  Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1], &s->g[0], &s->g[1], &s->gmac[0], &s->gmac[1] };
+  for (unsigned k = 0; k < sizeof (all)/sizeof (all[0]); k++)
+    var_alloc (s, all[k]);
+  for (int d = 0; d < 4; d++) {
+    var_alloc (s, &s->un[d]);
+    var_alloc (s, &s->fv[d]);
+    var_alloc (s, &s->w[d]);
+  }
+  go_multilevel_params_init (&s->projection_params, 2);
+  go_multilevel_params_init (&s->approx_projection_params, 2);
+  s->cfl = 0.8;
+  s->end = DBL_MAX;
+  return s;
+}
+
+void gt_set_time (GtSim * s, double end, double cfl)
+{
+  s->end = end;
+  s->cfl = cfl;
+}
+
+/* the Refine function of test/periodic/periodic.gfs:25 */
+typedef struct { int level, box; } PeriodicRefine;
+static double periodic_refine (double x, double y, void * ctx)
+{
+  PeriodicRefine * p = ctx;
+  return (x < -0.25 || x > 0.25 || y < -0.25 || y > 0.25 ? p->level : p->level + p->box);
+}
+
+/* test/periodic/periodic.gfs with LEVEL = level, BOX = box */
+GtSim * gt_periodic_new (int level, int box)
+{
+  PeriodicRefine pr = { level, box };
+  GtSim * s = gt_new (periodic_refine, &pr);
+  s->projection_params.tolerance = 1e-6;        /* periodic.gfs:30-31 */
+  s->approx_projection_params.tolerance = 1e-6;
+  s->cfl = 0.75;                                /* periodic.gfs:24 */
+  s->end = 0.5;                                 /* periodic.gfs:23 */
+  cell_traverse (s, 0, T_LEAFS, -1, init_uv, NULL);
+  return s;
+}
+
+void gt_destroy (GtSim * s)
+{
+  Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1], &s->g[0], &s->g[1], &s->gmac[0], &s->gmac[1] };
+  for (unsigned k = 0; k < sizeof (all)/sizeof (all[0]); k++)
+    var_free (s, all[k]);
+  for (int d = 0; d < 4; d++) {
+    var_free (s, &s->un[d]);
+    var_free (s, &s->fv[d]);
+    var_free (s, &s->w[d]);
+  }
+  for (int l = 0; l <= s->depth; l++)
+    free (s->flag[l]);
+  free (s);
+}
+
+/* simulation_run up to the loop, simulation.c:458-476 */
+void gt_start (GtSim * s)
+{
+  Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1] };
+  for (unsigned k = 0; k < sizeof (all)/sizeof (all[0]); k++)
+    bc (s, all[k], T_LEAFS, -1);
+  coarse_init (s);
+  set_timestep (s);
+  approximate_projection (s, &s->approx_projection_params, s->dt, &s->p, s->g);
+  set_timestep (s);
+}
+
+/* one iteration of the loop, simulation.c:479-548 */
+void gt_step (GtSim * s)
+{
+  predicted_face_velocities (s);
+  mac_projection (s, &s->projection_params, s->dt/2., &s->pmac, s->gmac); /* p <-> pmac swapped */
+  centered_velocity_advection (s, s->gmac, s->i > 0 ? s->g : s->gmac);
+  correct_centered_velocities (s, s->i > 0 ? s->g : s->gmac, - s->dt);
+  coarse_init (s);
+  approximate_projection (s, &s->approx_projection_params, s->dt, &s->p, s->g);
+  s->t = s->tnext;
+  s->i++;
+  set_timestep (s);
+}
+
+double gt_time (const GtSim * s) { return s->t; }
+double gt_end (const GtSim * s) { return s->end; }
+unsigned gt_iter (const GtSim * s) { return s->i; }
+int gt_depth (const GtSim * s) { return s->depth; }
+double gt_dt (const GtSim * s) { return s->dt; }
+GoMultilevelParams * gt_projection_params (GtSim * s, int approx)
+{ return approx ? &s->approx_projection_params : &s->projection_params; }
+
+/* number of leaves per level (tree checks) */
+void gt_leaf_count (const GtSim * s, long * count)
+{
+  for (int l = 0; l <= s->depth; l++) {
+    count[l] = 0;
+    for (int j = 1; j <= s->n[l]; j++)
+      for (int i = 1; i <= s->n[l]; i++)
+	if (s->flag[l][i + s->r[l]*j] == GT_LEAF)
+	  count[l]++;
+  }
+}
+
+/* flags / values of a level for the tests: which = 0 U, 1 V, 2 P, 3 Pmac, 4-5 g, 6-7 gmac, 8-11 un */
+const unsigned char * gt_flags (const GtSim * s, int l) { return s->flag[l]; }
+double * gt_values (GtSim * s, int which, int l)
+{
+  Var * v[] = { &s->u[0], &s->u[1], &s->p, &s->pmac, &s->g[0], &s->g[1], &s->gmac[0], &s->gmac[1],
+	       &s->un[0], &s->un[1], &s->un[2], &s->un[3] };
+  return v[which]->lev[l];
+}
+
+/* GfsOutputErrorNorm { v = U } { s = 1 - 2 cos (2 pi (x - t)) sin (2 pi (y - t)) } (periodic.gfs:32-34,
+   output.c:2953-3013, domain.c:2116-2122): norms of U - s over the leaves, weight = cell volume */
+typedef struct { GoNorm n; double t; } ErrPar;
+static void add_error (GtSim * s, Cell c, void * data)
+{
+  ErrPar * p = data;
+  double x, y, h = cell_size (c);
+  cell_pos (s, c, &x, &y);
+  double ref = (1. - 2.*cos (2.*M_PI*(x - p->t))*sin (2.*M_PI*(y - p->t)));
+  norm_add (&p->n, *val (&s->u[0], c) - ref, h*h);
+}
+
+void gt_error_norm (GtSim * s, double * first, double * second, double * infty)
+{
+  ErrPar p = { { 0., 0., 0., - DBL_MAX, 0. }, s->t };
+  cell_traverse (s, 0, T_LEAFS, -1, add_error, &p);
+  norm_update (&p.n);
+  *first = p.n.first;
+  *second = p.n.second;
+  *infty = p.n.infty;
+}
+
+/* the whole run: returns the number of steps */
+unsigned gt_run (GtSim * s)
+{
+  gt_start (s);
+  while (s->t < s->end)
+    gt_step (s);
+  return s->i;
+}

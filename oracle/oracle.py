@@ -503,3 +503,95 @@ class Particles:
             lib().go_particles_destroy(self.ptr)
         except Exception:
             pass
+
+
+REFINE_FUNC = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_void_p)
+
+
+def _tree_sigs(L):
+    vp, i, d, u = C.c_void_p, C.c_int, C.c_double, C.c_uint
+    pd = C.POINTER(C.c_double)
+    sig = {
+        "gt_new": (vp, [REFINE_FUNC, vp]),
+        "gt_periodic_new": (vp, [i, i]),
+        "gt_destroy": (None, [vp]),
+        "gt_set_time": (None, [vp, d, d]),
+        "gt_start": (None, [vp]),
+        "gt_step": (None, [vp]),
+        "gt_run": (u, [vp]),
+        "gt_time": (d, [vp]),
+        "gt_end": (d, [vp]),
+        "gt_dt": (d, [vp]),
+        "gt_iter": (u, [vp]),
+        "gt_depth": (i, [vp]),
+        "gt_projection_params": (C.POINTER(MultilevelParams), [vp, i]),
+        "gt_flags": (C.POINTER(C.c_ubyte), [vp, i]),
+        "gt_values": (pd, [vp, i, i]),
+        "gt_error_norm": (None, [vp, pd, pd, pd]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+
+
+class Tree2D:
+    """go_tree2d.c: a GfsSimulation on one periodic 2-D box with a statically refined tree
+    (coarse-fine stencils).  Levels are dense (n+2)^2 arrays [j, i] with a flag per cell:
+    0 absent, 1 leaf, 2 non-leaf."""
+    U, V, P, PMAC, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3 = range(12)
+
+    def __init__(self, refine=None, periodic=None):
+        L = lib()
+        if not hasattr(L, "_tree_ready"):
+            _tree_sigs(L)
+            L._tree_ready = True
+        self.L = L
+        if periodic is not None:
+            self.ptr = L.gt_periodic_new(*periodic)
+        else:
+            self._cb = REFINE_FUNC(lambda x, y, ctx: float(refine(x, y)))
+            self.ptr = L.gt_new(self._cb, None)
+        self.depth = L.gt_depth(self.ptr)
+        self.projection_params = L.gt_projection_params(self.ptr, 0).contents
+        self.approx_projection_params = L.gt_projection_params(self.ptr, 1).contents
+
+    def flags(self, l):
+        r = (1 << l) + 2
+        return np.ctypeslib.as_array(self.L.gt_flags(self.ptr, l), shape=(r, r))
+
+    def values(self, which, l):
+        r = (1 << l) + 2
+        return np.ctypeslib.as_array(self.L.gt_values(self.ptr, which, l), shape=(r, r))
+
+    def centres(self, l):
+        """x[j, i], y[j, i] of the cells of level l (ghosts included)"""
+        n = 1 << l
+        c = -0.5 + (np.arange(n + 2) - 0.5) / n
+        return np.meshgrid(c, c, indexing="xy")
+
+    def set_time(self, end, cfl):
+        self.L.gt_set_time(self.ptr, end, cfl)
+
+    def start(self):
+        self.L.gt_start(self.ptr)
+
+    def step(self):
+        self.L.gt_step(self.ptr)
+
+    def run(self):
+        return self.L.gt_run(self.ptr)
+
+    t = property(lambda self: self.L.gt_time(self.ptr))
+    end = property(lambda self: self.L.gt_end(self.ptr))
+    dt = property(lambda self: self.L.gt_dt(self.ptr))
+    i = property(lambda self: self.L.gt_iter(self.ptr))
+
+    def error_norm(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self.L.gt_error_norm(self.ptr, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def destroy(self):
+        if self.ptr:
+            self.L.gt_destroy(self.ptr)
+            self.ptr = None

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Prints the rows of test/periodic's r0 / r1 / r2 files as computed by the quadtree oracle
+(oracle/go_tree2d.c) next to the reference's: the long cases tests/test_oracle_tree2d.py leaves out
+(level 7; BOX = 2 at level 6 and 7 take 1 to 10 minutes on one core).
+usage: tree2d_ref_rows.py [boxes, e.g. 1,2] [levels, e.g. 5,6,7]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O
+
+boxes = [int(b) for b in (sys.argv[1] if len(sys.argv) > 1 else "0,1,2").split(",")]
+levels = [int(l) for l in (sys.argv[2] if len(sys.argv) > 2 else "5,6,7").split(",")]
+for box in boxes:
+    ref = {}
+    with open(os.path.join(ROOT, "tests", "golden", "reference", "periodic_r%d.ref" % box)) as f:
+        for line in f:
+            w = line.split()
+            ref[int(w[0])] = w[1:3]
+    for level in levels:
+        t0 = time.time()
+        s = O.Tree2D(periodic=(level, box))
+        n = s.run()
+        _, second, infty = s.error_norm()
+        got = ["%.3e" % second, "%.3e" % infty]
+        print("BOX %d LEVEL %d: oracle %s %s  reference %s %s  %s  (%d steps, %.0f s)"
+              % (box, level, got[0], got[1], ref[level][0], ref[level][1],
+                 "ok" if got == ref[level] else "DIFFERS", n, time.time() - t0), flush=True)
+        s.destroy()
