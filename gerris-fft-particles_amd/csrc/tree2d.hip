@@ -1,0 +1,1287 @@
+// tree2d.hip -- the reference's time step on a statically refined 2-D quadtree in one periodic box
+// (the coarse-fine stencils; the case of test/periodic/periodic.gfs with BOX = 1, 2).
+//
+// How the tree algorithms of the reference map onto the device:
+//  * cell loops whose result does not depend on the order (src/ftt.c:689-926 traversals of leaves,
+//    of the non-leaf cells of a level ...) are one thread per entry of a list built once on the host;
+//  * face loops that scatter into both cells of a face (ftt_face_traverse, src/ftt.c:2152-2215:
+//    MAC velocities, pressure correction, fluxes) are split into a kernel that computes one number
+//    per face and a kernel in which every cell gathers the numbers of its faces IN THE ORDER the
+//    reference's traversal visits them -- the same floating-point sums, no atomics;
+//  * the Gauss-Seidel sweep of gfs_relax visits the cells of a level and the coarser leaves in tree
+//    order (src/poisson.c:604-632): the host derives, from the very stencil code the kernels run
+//    (tree2d.hpp with a recording reader), which cells each cell reads, and groups the cells of the
+//    sweep into dependency levels; one workgroup then runs a whole relax loop (nrelax sweeps with
+//    the periodic copies between them, src/poisson.c:1070-1089), level after level, barrier between.
+// The 2-D refined cases are small (10^4 - 10^5 cells): this path is about the reference's results on
+// a tree, not about bandwidth; the uniform 3-D path of the other files is the one that is benchmarked.
+//
+// Restated here: src/poisson.c:998-1269 (cycle, solve), src/timestep.c:36-187,356-444,498-530,560-596,
+// 644-717,872-921,976-1016, src/advection.c:27-99,132-180,267-343,398-435,513-587,
+// src/fluid.c:1843-1864,2310-2324, src/domain.c:2239-2288,2824-2923, src/simulation.c:432-557,
+// 1569-1633, src/ftt.c:45-83,169-192,2013-2074 (refinement with the neighbour and corner rules).
+#include "gfship_internal.hpp"
+#include "tree2d.hpp"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <functional>
+
+using namespace gfship;
+using namespace gfship::tree;
+
+namespace {
+
+enum { V_P, V_PMAC, V_U, V_V, V_GX, V_GY, V_GMX, V_GMY, V_UN0, V_UN1, V_UN2, V_UN3,
+       V_FV0, V_FV1, V_FV2, V_FV3, V_DIV, V_RES, V_DP, V_NVAR };
+
+struct FaceRec { Cell cell, neighbor; int d; };
+struct Ghost { int g, img, side; };
+
+struct FaceSet {            // the faces of one ftt_face_traverse, in its order
+  int nfaces = 0;
+  FaceRec * faces = nullptr;          // device
+  int * inc_off = nullptr;            // device, per leaf (position in the leaf list) + 1
+  int * inc = nullptr;                // device: face << 1 | role (0: the cell of the face, 1: its neighbour)
+  double * fval = nullptr;            // device, one number per face
+};
+
+struct Sweep {              // T_LEVEL_LEAFS (m) in dependency levels
+  int ncells = 0, nlev = 0;
+  Cell * cells = nullptr;             // device, sorted by level (stable: traversal order inside)
+  int * lev_off = nullptr;            // device, nlev + 1
+  Ghost * ghosts = nullptr; int nghosts = 0;   // ghost cells of the selection
+};
+
+struct DevReader {
+  const double * p;
+  __device__ inline double operator() (const Topo & T, Cell c) const { return p[T.gi (c)]; }
+};
+
+struct Recorder {           // host: which cells does the stencil read?
+  std::vector<int> * out;
+  inline double operator() (const Topo & T, Cell c) const { out->push_back (T.gi (c)); return 1.; }
+};
+
+} // namespace
+
+struct gfship_tree {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Topo H, D;
+  std::vector<unsigned char> hflag;
+  unsigned char * dflag = nullptr;
+  int ncell = 0;
+  double * var[V_NVAR] = {};
+  int nleaves = 0;
+  Cell * leaves = nullptr;                        // device: interior leaves in traversal order
+  std::vector<Cell> hleaves;
+  int nnonleaf[GFSHIP_MAXLEVEL + 1] = {};
+  Cell * nonleaf[GFSHIP_MAXLEVEL + 1] = {};       // device: interior non-leaf cells of a level
+  Ghost * ghost_leaves = nullptr; int nghost_leaves = 0;
+  Sweep sweep[GFSHIP_MAXLEVEL + 1];
+  FaceSet fs[3];                                  // 0: FTT_XYZ, 1: x faces, 2: y faces
+  double * d_red = nullptr;                       // reductions: [0] max bits / min bits, [1..3] sums
+  double * h_red = nullptr;                       // pinned
+  gfship_multilevel_params projection_params, approx_projection_params;
+  double cfl = 0.8, dt = 0., t = 0., end = DBL_MAX, tnext = 0.;
+  unsigned iter = 0;
+};
+
+namespace {
+
+// ---- kernels --------------------------------------------------------------------------------
+
+__global__ void t_copy_ghosts (const Ghost * gh, int n, double * v)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t < n) v[gh[t].g] = v[gh[t].img];
+}
+
+// gfs_domain_face_bc on periodic sides (src/boundary.c:1251-1258,1343-1347): the leaf ghost beyond
+// side sd takes f[OPP (sd)].v of its image
+__global__ void t_face_bc (const Ghost * gh, int n, double * fv0, double * fv1, double * fv2, double * fv3)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  double * fv[4] = { fv0, fv1, fv2, fv3 };
+  double * a = fv[gh[t].side ^ 1];
+  a[gh[t].g] = a[gh[t].img];
+}
+
+// gfs_get_from_below_intensive (src/fluid.c:1843-1864, mode 0) / get_from_below_2D
+// (src/poisson.c:1057-1068, mode 1) on the non-leaf cells of one level
+__global__ void t_from_below (Topo T, const Cell * cells, int n, double * v, int mode)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Cell c = cells[t];
+  double val = 0., sa = 0.;
+  for (int k = 0; k < 4; k++) {
+    const Cell ch = T.child (c, k);
+    if (exists (ch)) {
+      if (mode == 0) {
+	val += v[T.gi (ch)]*1.;
+	sa += 1.;
+      }
+      else
+	val += v[T.gi (ch)];
+    }
+  }
+  v[T.gi (c)] = mode == 0 ? val/sa : val;
+}
+
+// get_from_above, src/poisson.c:1005-1042
+__global__ void t_from_above (Topo T, const Cell * cells, int n, double * v)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Cell parent = cells[t];
+  DevReader R = { v };
+  const double vp = v[T.gi (parent)];
+  double h[2];
+  for (int c = 0; c < 2; c++) {
+    Face f;
+    f.cell = parent;
+    f.d = 2*c;
+    f.neighbor = T.neighbor (parent, f.d);
+    Grad2 g = face_gradient (T, f, R, parent.l);
+    const double g1 = g.b - g.a*vp;
+    f.d = 2*c + 1;
+    f.neighbor = T.neighbor (parent, f.d);
+    g = face_gradient (T, f, R, parent.l);
+    const double g2 = g.b - g.a*vp;
+    h[c] = (g1 - g2)/2.;
+  }
+  for (int k = 0; k < 4; k++) {
+    const Cell ch = T.child (parent, k);
+    if (exists (ch)) {
+      const double px = (k & 1) ? 0.25 : -0.25, py = (k & 2) ? -0.25 : 0.25;   /* ftt_cell_relative_pos */
+      double x = vp;
+      x += px*h[0];
+      x += py*h[1];
+      v[T.gi (ch)] = x;
+    }
+  }
+}
+
+// relax_loop, src/poisson.c:1070-1089, of one level: one workgroup, the cells of a sweep by
+// dependency level
+__global__ void __launch_bounds__(1024)
+t_relax_loop (Topo T, const Cell * cells, const int * lev_off, int nlev, const Ghost * gh, int ngh,
+	      double * u, const double * rhs, unsigned nrelax, double omega, int max_level)
+{
+  DevReader R = { u };
+  for (int t = threadIdx.x; t < ngh; t += blockDim.x)
+    u[gh[t].g] = u[gh[t].img];
+  __syncthreads ();
+  for (unsigned s = 0; s < nrelax; s++) {
+    for (int L = 0; L < nlev; L++) {
+      const int a = lev_off[L], b = lev_off[L + 1];
+      for (int t = a + threadIdx.x; t < b; t += blockDim.x) {
+	const Cell c = cells[t];
+	const int g = T.gi (c);
+	u[g] = relax_cell (T, c, R, rhs[g], omega, max_level);
+      }
+      __syncthreads ();
+    }
+    if (s + 1 < nrelax) {
+      for (int t = threadIdx.x; t < ngh; t += blockDim.x)
+	u[gh[t].g] = u[gh[t].img];
+      __syncthreads ();
+    }
+  }
+}
+
+__device__ inline void atomic_max_pos (double * addr, double v)   /* v >= 0 */
+{
+  atomicMax ((unsigned long long *) addr, (unsigned long long) __double_as_longlong (v));
+}
+__device__ inline void atomic_min_pos (double * addr, double v)
+{
+  atomicMin ((unsigned long long *) addr, (unsigned long long) __double_as_longlong (v));
+}
+
+// gfs_residual on the leaves + add_norm_residual (src/domain.c:2239-2246): the maximum is exact, the
+// sums are accumulated in no particular order (reported, never branched on)
+__global__ void t_residual (Topo T, const Cell * cells, int n, const double * u, const double * rhs,
+			    double * res, double * red)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Cell c = cells[t];
+  DevReader R = { u };
+  const int g = T.gi (c);
+  const double r = residual_cell (T, c, R, rhs[g]);
+  res[g] = r;
+  const double size = T.size (c);
+  const double val = r/(1.*size*size);
+  atomic_max_pos (&red[0], fabs (val));
+  atomicAdd (&red[1], r);
+  atomicAdd (&red[2], fabs (val));
+  atomicAdd (&red[3], val*val);
+}
+
+__global__ void t_correct (Topo T, const Cell * cells, int n, double * u, const double * dp)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int g = T.gi (cells[t]);
+  u[g] += dp[g];
+}
+
+// gfs_face_interpolated_normal_velocity, src/advection.c:549-573: the value of the face
+__global__ void t_face_interp (Topo T, const FaceRec * faces, int n, const double * u0, const double * u1,
+			       double * fval)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Face f = { faces[t].cell, faces[t].neighbor, faces[t].d };
+  DevReader R = { f.d < 2 ? u0 : u1 };
+  fval[t] = face_interpolated_value (T, f, R);
+}
+
+// the normal velocities of a leaf from the faces that touch it, in the order of the traversal:
+// f[d].un of the cell of a face is set; that of its neighbour is set (same level) or gets half of
+// the value (coarser neighbour, FTT_CELLS_DIRECTION = 2), after gfs_face_reset_normal_velocity
+__global__ void t_gather_un (Topo T, const Cell * cells, int n, const FaceRec * faces, const int * inc_off,
+			     const int * inc, const double * fval, double * un0, double * un1,
+			     double * un2, double * un3, int dmask)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  double * un[4] = { un0, un1, un2, un3 };
+  double acc[4] = { 0., 0., 0., 0. };
+  for (int k = inc_off[t]; k < inc_off[t + 1]; k++) {
+    const int fi = inc[k] >> 1, role = inc[k] & 1;
+    const FaceRec & f = faces[fi];
+    const double u = fval[fi];
+    if (role == 0)
+      acc[f.d] = u;
+    else if (f.neighbor.l == f.cell.l)
+      acc[f.d ^ 1] = u;
+    else
+      acc[f.d ^ 1] += u*1./(1.*2);
+  }
+  const int g = T.gi (cells[t]);
+  for (int d = 0; d < 4; d++)
+    if (dmask & (1 << d))
+      un[d][g] = acc[d];
+}
+
+// correct_normal_velocity, src/timestep.c:118-144: dp of the face
+__global__ void t_face_correct (Topo T, const FaceRec * faces, int n, const double * p, double * fval)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Face f = { faces[t].cell, faces[t].neighbor, faces[t].d };
+  DevReader R = { p };
+  const Grad2 g = face_gradient (T, f, R, -1);
+  double dp = (g.b - g.a*p[T.gi (f.cell)])/T.size (f.cell);
+  if (f.d & 1)
+    dp = - dp;
+  dp /= 1.;
+  fval[t] = dp;
+}
+
+__global__ void t_gather_correct (Topo T, const Cell * cells, int n, const FaceRec * faces,
+				  const int * inc_off, const int * inc, const double * fval,
+				  double * un0, double * un1, double * un2, double * un3,
+				  double * gv, double dt)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  double * un[4] = { un0, un1, un2, un3 };
+  const int g = T.gi (cells[t]);
+  double gacc = gv ? gv[g] : 0.;
+  for (int k = inc_off[t]; k < inc_off[t + 1]; k++) {
+    const int fi = inc[k] >> 1, role = inc[k] & 1;
+    const FaceRec & f = faces[fi];
+    double dp = fval[fi];
+    if (role == 0) {
+      un[f.d][g] -= dp*dt;
+      gacc += dp*1.;
+    }
+    else {
+      if (f.neighbor.l < f.cell.l)
+	dp *= 1./(1.*4/2);
+      un[f.d ^ 1][g] -= dp*dt;
+      gacc += dp*1.;
+    }
+  }
+  if (gv)
+    gv[g] = gacc;
+}
+
+// gfs_normal_divergence + scale_divergence, src/fluid.c:2310-2324, src/timestep.c:181-187
+__global__ void t_divergence (Topo T, const Cell * cells, int n, const double * un0, const double * un1,
+			      const double * un2, const double * un3, double * div, double dt)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Cell c = cells[t];
+  const int g = T.gi (c);
+  double d = 0.;
+  d += 1.*un0[g]*1.;
+  d += -1.*un1[g]*1.;
+  d += 1.*un2[g]*1.;
+  d += -1.*un3[g]*1.;
+  d = d*T.size (c);
+  div[g] = d/dt;
+}
+
+__global__ void t_scale2 (Topo T, const Cell * cells, int n, double * a, double * b, double s, int mode,
+			  const double * ga, const double * gb)
+{
+  // mode 0: a /= 2, b /= 2 (scale_cell_gradients, src/timestep.c:60-90: both neighbours exist);
+  // mode 1: a -= ga*s, b -= gb*s (correct, src/timestep.c:486-496)
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int g = T.gi (cells[t]);
+  if (mode == 0) {
+    a[g] /= 2.;
+    b[g] /= 2.;
+  }
+  else {
+    a[g] -= ga[g]*s;
+    b[g] -= gb[g]*s;
+  }
+}
+
+struct AdvArgs {
+  const double * v, * u[2], * un[4];
+  double * fv[4];
+  double dt;
+  int use_centered;
+};
+
+// gfs_cell_advected_face_values, src/advection.c:58-99 (centred gradient, no sources)
+__global__ void t_face_values (Topo T, const Cell * cells, int n, AdvArgs A)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Cell cell = cells[t];
+  const int g = T.gi (cell);
+  DevReader R = { A.v };
+  const double size = T.size (cell);
+  const double v0 = A.v[g];
+  for (int c = 0; c < 2; c++) {
+    const double msize = size;
+    const double unorm = A.use_centered ? A.dt*A.u[c][g]/msize :
+      A.dt*(A.un[2*c][g] + A.un[2*c + 1][g])/(2.*msize);
+    const double gr = center_gradient (T, cell, c, R);
+    const double m1 = (1. - unorm)/2., m2 = (- 1. - unorm)/2.;
+    const double vl = v0 + (m1 < 0.5 ? m1 : 0.5)*gr;
+    const double vr = v0 + (m2 > -0.5 ? m2 : -0.5)*gr;
+    const double src = A.dt*0./2.;
+    // transverse_term, src/advection.c:27-47
+    const int ct = (c + 1) % 2;
+    const double vtan = A.use_centered ? A.u[ct][g] : (A.un[2*ct][g] + A.un[2*ct + 1][g])/2.;
+    Face f;
+    f.d = vtan > 0. ? 2*ct + 1 : 2*ct;
+    f.cell = cell;
+    f.neighbor = T.neighbor (cell, f.d);
+    const Grad2 gf = face_gradient (T, f, R, -1);
+    double gt = gf.b - gf.a*v0;
+    if (vtan > 0.) gt = - gt;
+    const double dv = A.dt*vtan*gt/(2.*msize);
+    A.fv[2*c][g]     = vl + src - dv;
+    A.fv[2*c + 1][g] = vr + src - dv;
+  }
+}
+
+struct UpwindArgs { const double * u[2], * un[4], * fv[4]; };
+
+// interpolate_1D1 of src/advection.c:132-180 (the assigned values of s2: see oracle/go_tree2d.c)
+__device__ inline double adv_interpolate_1D1 (const Topo & T, const UpwindArgs & A, Cell cell, int dright,
+					      int dup, double x)
+{
+  const int dleft = dright ^ 1;
+  Cell nb = T.neighbor (cell, dup);
+  if (exists (nb) && T.interior (nb)) {
+    double s2 = T.leaf (nb) ? 1. : 0.5;
+    const double s1 = 1.;
+    const double v1 = A.fv[dleft][T.gi (cell)];
+    double v2;
+    if (T.leaf (nb))
+      v2 = A.fv[dleft][T.gi (nb)];
+    else {
+      // ftt_cell_child_corner: the child of nb in the corner (dleft, opposite of dup)
+      const int dx = dleft < 2 ? dleft : (dup ^ 1), dy = dleft < 2 ? (dup ^ 1) : dleft;
+      nb = T.child (nb, (dx == 0 ? 1 : 0) + (dy == 3 ? 2 : 0));
+      if (exists (nb))
+	v2 = A.fv[dleft][T.gi (nb)];
+      else
+	s2 = v2 = 0.;
+    }
+    return s2 > 0. ? (v2*(s1 - 1. + 2.*x) + v1*(s2 + 1. - 2.*x))/(s1 + s2) : v1;
+  }
+  return A.fv[dleft][T.gi (cell)];
+}
+
+// gfs_face_upwinded_value, src/advection.c:267-343
+__device__ inline double face_upwinded_value (const Topo & T, const UpwindArgs & A, const Face & face,
+					      int centered)
+{
+  double un;
+  if (centered) {
+    DevReader R = { A.u[face.d/2] };
+    un = face_interpolated_value (T, face, R);
+  }
+  else
+    un = A.un[face.d][T.gi (face.cell)];
+  if (face.d & 1)
+    un = - un;
+  const double fc = A.fv[face.d][T.gi (face.cell)];
+  if (!fine_coarse (face)) {
+    const double fn = A.fv[face.d ^ 1][T.gi (face.neighbor)];
+    return un > 0. ? fc : un < 0. ? fn : (fc + fn)/2.;
+  }
+  if (un > 0.)
+    return fc;
+  const double vcoarse = adv_interpolate_1D1 (T, A, face.neighbor, face.d,
+					      perpendicular (face.d, T.id (face.cell)), 1./4.);
+  if (un == 0.)
+    return (fc + vcoarse)/2.;
+  return vcoarse;
+}
+
+// gfs_face_advected_normal_velocity, src/advection.c:513-539: the value of the face
+__global__ void t_face_advected_un (Topo T, const FaceRec * faces, int n, UpwindArgs A, double * fval)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Face f = { faces[t].cell, faces[t].neighbor, faces[t].d };
+  fval[t] = face_upwinded_value (T, A, f, 1);
+}
+
+// gfs_face_velocity_advection_flux, src/advection.c:398-435: the flux of the face
+__global__ void t_face_flux (Topo T, const FaceRec * faces, int n, UpwindArgs A, const double * gm,
+			     double dt, double * fval)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Face f = { faces[t].cell, faces[t].neighbor, faces[t].d };
+  DevReader G = { gm };
+  double flux = 1.*A.un[f.d][T.gi (f.cell)]*dt/T.size (f.cell);
+  flux *= face_upwinded_value (T, A, f, 0) - face_interpolated_value (T, f, G)*dt/2.;
+  if (f.d & 1)
+    flux = - flux;
+  fval[t] = flux;
+}
+
+// the flux sums of a leaf in traversal order, gfs_advection_update (src/advection.c:784-819) and
+// add_pressure_gradient (src/timestep.c:809-812)
+__global__ void t_gather_flux (Topo T, const Cell * cells, int n, const FaceRec * faces,
+			       const int * inc_off, const int * inc, const double * fval,
+			       double * v, const double * g, double dt)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  double f = 0.;
+  for (int k = inc_off[t]; k < inc_off[t + 1]; k++) {
+    const int fi = inc[k] >> 1, role = inc[k] & 1;
+    const FaceRec & F = faces[fi];
+    const double flux = fval[fi];
+    if (role == 0)
+      f -= flux;
+    else if (F.neighbor.l == F.cell.l)
+      f += flux;
+    else
+      f += flux/4;
+  }
+  const int gi = T.gi (cells[t]);
+  double x = v[gi];
+  x += f/1.;
+  if (g)
+    x -= g[gi]*dt;
+  v[gi] = x;
+}
+
+// gfs_domain_cfl, src/domain.c:2824-2923: the minimum of (length/|u|)^2 over faces and cells
+__global__ void t_cfl_faces (Topo T, const FaceRec * faces, int n, const double * un0, const double * un1,
+			     const double * un2, const double * un3, double * red)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double * un[4] = { un0, un1, un2, un3 };
+  const double u = un[faces[t].d][T.gi (faces[t].cell)];
+  if (u != 0.) {
+    const double cflu = T.size (faces[t].cell)/fabs (u);
+    atomic_min_pos (red, cflu*cflu);
+  }
+}
+
+__global__ void t_cfl_cells (Topo T, const Cell * cells, int n, const double * u0, const double * u1,
+			     double * red)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int g = T.gi (cells[t]);
+  const double length = T.size (cells[t]);
+  const double * u[2] = { u0, u1 };
+  for (int c = 0; c < 2; c++) {
+    const double fm = 1.;
+    if (u[c][g] != 0.) {
+      const double cflu = length/fabs (fm*u[c][g]);
+      atomic_min_pos (red, cflu*cflu);
+    }
+  }
+}
+
+inline int blocks (int n) { return (n + 255)/256; }
+
+// ---- host: tree construction and lists --------------------------------------------------------
+
+struct Builder {
+  std::vector<std::vector<unsigned char>> flag;     // per level, (n + 2)^2
+  int r (int l) const { return (1 << l) + 2; }
+  void ensure (int l) { if ((int) flag.size () <= l) flag.resize (l + 1); if (flag[l].empty ()) flag[l].assign ((size_t) r (l)*r (l), NONE); }
+  // oct_new with check_neighbors, src/ftt.c:45-83
+  int refine_single (int l, int i, int j) {
+    if (l + 1 > GFSHIP_MAXLEVEL) return GFSHIP_EUNSUPPORTED;
+    static const int di[4] = { 1, -1, 0, 0 }, dj[4] = { 0, 0, 1, -1 };
+    const int n = 1 << l;
+    for (int d = 0; d < 4; d++) {
+      const int ni = i + di[d], nj = j + dj[d];
+      if (ni < 1 || nj < 1 || ni > n || nj > n)
+	continue;                   // the ghost trees are matched at the end (gfs_domain_match)
+      if (flag[l][ni + r (l)*nj] == NONE) {
+	const int pi = (ni + 1)/2, pj = (nj + 1)/2;
+	if (flag[l - 1][pi + r (l - 1)*pj] == LEAF) {
+	  int e = refine_single (l - 1, pi, pj);
+	  if (e) return e;
+	}
+      }
+    }
+    flag[l][i + r (l)*j] = NODE;
+    ensure (l + 1);
+    for (int k = 0; k < 4; k++)
+      flag[l + 1][2*i - 1 + (k & 1) + r (l + 1)*(2*j - ((k >> 1) & 1))] = LEAF;
+    return 0;
+  }
+  // ftt_cell_refine (src/ftt.c:169-192) with refine_maxlevel (src/refine.c:35-38)
+  int refine_rec (int l, int i, int j, gfship_refine_fn fn, void * ctx) {
+    if (flag[l][i + r (l)*j] == LEAF) {
+      const double h = 1./(1 << l);
+      const double x = -0.5 + (i - 0.5)*h, y = -0.5 + (j - 0.5)*h;
+      if (!(l < (* fn) (x, y, 0., ctx)))
+	return 0;
+      int e = refine_single (l, i, j);
+      if (e) return e;
+    }
+    for (int k = 0; k < 4; k++) {
+      int e = refine_rec (l + 1, 2*i - 1 + (k & 1), 2*j - ((k >> 1) & 1), fn, ctx);
+      if (e) return e;
+    }
+    return 0;
+  }
+};
+
+typedef std::function<void (Cell)> CellFn;
+enum { T_ALL, T_LEAFS, T_NON_LEAFS, T_LEVEL, T_LEVEL_LEAFS, T_LEVEL_NON_LEAFS };
+
+// ftt_cell_traverse, src/ftt.c:689-926 (pre-order; the post-order loops are done level by level)
+void traverse (const Topo & T, Cell c, int flags, int max_depth, const CellFn & fn)
+{
+  const bool leaf = T.leaf (c);
+  bool visit = false, descend = !leaf;
+  if (flags == T_ALL || flags == T_LEAFS || flags == T_NON_LEAFS) {
+    if (max_depth >= 0 && c.l > max_depth)
+      return;
+    visit = flags == T_ALL || (flags == T_LEAFS ? leaf : !leaf);
+  }
+  else if (flags == T_LEVEL) {
+    visit = c.l == max_depth;
+    descend = !visit && !leaf;
+  }
+  else if (flags == T_LEVEL_LEAFS) {
+    visit = c.l == max_depth || leaf;
+    descend = !visit;
+  }
+  else {
+    visit = c.l == max_depth && !leaf;
+    descend = !visit && !leaf;
+  }
+  if (visit)
+    fn (c);
+  if (descend)
+    for (int k = 0; k < 4; k++) {
+      const Cell ch = T.child (c, k);
+      if (exists (ch))
+	traverse (T, ch, flags, max_depth, fn);
+    }
+}
+
+inline Cell root_cell (const Topo & T) { Cell c = { 0, 1 + T.r (0) }; return c; }
+
+// ftt_refine_corner, src/ftt.c:2013-2074
+bool refine_corner (const Topo & T, Cell cell)
+{
+  static const int perp[4][2] = { {2, 3}, {2, 3}, {1, 0}, {1, 0} };
+  for (int i = 0; i < 4; i++) {
+    const Cell nb = T.neighbor (cell, i);
+    if (exists (nb) && !T.leaf (nb))
+      for (int j = 0; j < 2; j++) {
+	const Cell c = T.child_direction (nb, i ^ 1, j);
+	if (exists (c)) {
+	  const Cell nc = T.neighbor (c, perp[i][j]);
+	  if ((exists (nc) && !T.leaf (nc)) || !T.leaf (c))
+	    return true;
+	}
+      }
+  }
+  return false;
+}
+
+// traverse_face, src/ftt_internal.c:1-42 (leaves, max_depth = -1; the FTT_FLAG_TRAVERSED check
+// only matters for the second pass, whose neighbours are ghost cells)
+void traverse_face (const Topo & T, Cell cell, int d, std::vector<FaceRec> & out)
+{
+  FaceRec f = { cell, T.neighbor (cell, d), d };
+  if (!exists (f.neighbor))
+    return;
+  if (T.leaf (cell) && !T.leaf (f.neighbor)) {
+    const Cell coarse = cell, node = f.neighbor;
+    f.d = d ^ 1;
+    f.neighbor = coarse;
+    for (int i = 0; i < 2; i++) {
+      f.cell = T.child_direction (node, f.d, i);
+      if (exists (f.cell))
+	out.push_back (f);
+    }
+  }
+  else
+    out.push_back (f);
+}
+
+bool touches_side (const Topo & T, Cell c, int d)
+{
+  const int i = T.ci (c), j = T.cj (c), n = T.n (c.l);
+  return (d == 0 && i == n) || (d == 1 && i == 1) || (d == 2 && j == n) || (d == 3 && j == 1);
+}
+
+// ftt_face_traverse (src/ftt.c:2152-2215) as called by gfs_domain_face_traverse: kind 0 = FTT_XYZ,
+// 1 + c = component c
+void face_list (const Topo & T, const std::vector<Cell> & leaves, int kind, std::vector<FaceRec> & out)
+{
+  if (kind == 0) {
+    for (Cell c : leaves)
+      for (int d = 0; d < 4; d += 2)
+	traverse_face (T, c, d, out);
+    for (int d = 1; d < 4; d += 2)
+      for (Cell c : leaves)
+	if (touches_side (T, c, d))
+	  traverse_face (T, c, d, out);
+  }
+  else {
+    const int c0 = kind - 1;
+    for (Cell c : leaves)
+      traverse_face (T, c, 2*c0, out);
+    for (Cell c : leaves)
+      if (touches_side (T, c, 2*c0 + 1))
+	traverse_face (T, c, 2*c0 + 1, out);
+  }
+}
+
+template <class X> int to_device (const std::vector<X> & h, X ** d)
+{
+  *d = nullptr;
+  if (h.empty ()) return 0;
+  GFSHIP_HIP (hipMalloc ((void **) d, h.size ()*sizeof (X)));
+  GFSHIP_HIP (hipMemcpy (*d, h.data (), h.size ()*sizeof (X), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// the ghost cells of a selection of the traversal and their periodic images
+void ghost_list (const Topo & T, int flags, int max_depth, std::vector<Ghost> & out)
+{
+  for (int l = 0; l <= T.depth; l++) {
+    if (max_depth >= 0 && l > max_depth)
+      break;
+    const int n = T.n (l), r = T.r (l);
+    for (int side = 0; side < 4; side++)
+      for (int t = 1; t <= n; t++) {
+	const int gi = side == 0 ? n + 1 : side == 1 ? 0 : t, gj = side == 2 ? n + 1 : side == 3 ? 0 : t;
+	const int ii = side == 0 ? 1 : side == 1 ? n : t, ij = side == 2 ? 1 : side == 3 ? n : t;
+	const unsigned char f = T.flag[T.off[l] + gi + r*gj];
+	if (f == NONE)
+	  continue;
+	const bool take = flags == T_LEAFS ? f == LEAF : (l == max_depth || f == LEAF);
+	if (take) {
+	  Ghost g = { T.off[l] + gi + r*gj, T.off[l] + ii + r*ij, side };
+	  out.push_back (g);
+	}
+      }
+  }
+}
+
+// dependency levels of an exact-order sweep over `order': a cell runs after every earlier cell
+// it reads (it must see the new value) and after every earlier cell that reads it (which must
+// still see the old one)
+int sweep_plan (gfship_tree * tr, int m, Sweep * S)
+{
+  const Topo & T = tr->H;
+  std::vector<Cell> order;
+  traverse (T, root_cell (T), T_LEVEL_LEAFS, m, [&] (Cell c) { order.push_back (c); });
+  std::vector<int> pos (tr->ncell, -1);
+  for (size_t k = 0; k < order.size (); k++)
+    pos[T.gi (order[k])] = (int) k;
+  std::vector<int> lev (order.size (), 0), minlev (order.size (), 0), reads;
+  Recorder R = { &reads };
+  int nlev = 0;
+  for (size_t k = 0; k < order.size (); k++) {
+    reads.clear ();
+    relax_cell (T, order[k], R, 0., 1., m);
+    int L = minlev[k];
+    for (int g : reads) {
+      const int p = pos[g];
+      if (p >= 0 && p < (int) k)
+	L = std::max (L, lev[p] + 1);
+    }
+    lev[k] = L;
+    for (int g : reads) {
+      const int p = pos[g];
+      if (p > (int) k)
+	minlev[p] = std::max (minlev[p], L + 1);
+    }
+    nlev = std::max (nlev, L + 1);
+  }
+  std::vector<int> off (nlev + 1, 0);
+  for (size_t k = 0; k < order.size (); k++)
+    off[lev[k] + 1]++;
+  for (int L = 0; L < nlev; L++)
+    off[L + 1] += off[L];
+  std::vector<Cell> sorted (order.size ());
+  std::vector<int> cur (off.begin (), off.end () - 1);
+  for (size_t k = 0; k < order.size (); k++)
+    sorted[cur[lev[k]]++] = order[k];
+  std::vector<Ghost> gh;
+  ghost_list (T, T_LEVEL_LEAFS, m, gh);
+  S->ncells = (int) order.size ();
+  S->nlev = nlev;
+  S->nghosts = (int) gh.size ();
+  int e;
+  if ((e = to_device (sorted, &S->cells)) || (e = to_device (off, &S->lev_off)) ||
+      (e = to_device (gh, &S->ghosts)))
+    return e;
+  return 0;
+}
+
+int face_set (gfship_tree * tr, int kind, FaceSet * F)
+{
+  const Topo & T = tr->H;
+  std::vector<FaceRec> faces;
+  face_list (T, tr->hleaves, kind, faces);
+  std::vector<int> leafpos (tr->ncell, -1);
+  for (size_t k = 0; k < tr->hleaves.size (); k++)
+    leafpos[T.gi (tr->hleaves[k])] = (int) k;
+  std::vector<std::vector<int>> inc (tr->hleaves.size ());
+  for (size_t k = 0; k < faces.size (); k++) {
+    const int a = leafpos[T.gi (faces[k].cell)], b = leafpos[T.gi (faces[k].neighbor)];
+    if (a >= 0) inc[a].push_back ((int) (k << 1));
+    if (b >= 0) inc[b].push_back ((int) (k << 1 | 1));
+  }
+  std::vector<int> off (inc.size () + 1, 0), flat;
+  for (size_t k = 0; k < inc.size (); k++) {
+    off[k + 1] = off[k] + (int) inc[k].size ();
+    flat.insert (flat.end (), inc[k].begin (), inc[k].end ());
+  }
+  F->nfaces = (int) faces.size ();
+  int e;
+  if ((e = to_device (faces, &F->faces)) || (e = to_device (off, &F->inc_off)) ||
+      (e = to_device (flat, &F->inc)))
+    return e;
+  GFSHIP_HIP (hipMalloc ((void **) &F->fval, std::max<size_t> (1, faces.size ())*sizeof (double)));
+  return 0;
+}
+
+#define KCHECK() GFSHIP_HIP (hipGetLastError ())
+
+// ---- host: the algorithms ----------------------------------------------------------------------
+
+int bc_leaves (gfship_tree * tr, double * v)
+{
+  if (tr->nghost_leaves)
+    t_copy_ghosts<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves, v);
+  KCHECK ();
+  return 0;
+}
+
+// post-order traversal of the non-leaf cells: deepest level first
+int from_below (gfship_tree * tr, double * v, int mode)
+{
+  for (int l = tr->H.depth - 1; l >= 0; l--)
+    if (tr->nnonleaf[l]) {
+      t_from_below<<<blocks (tr->nnonleaf[l]), 256, 0, tr->stream>>> (tr->D, tr->nonleaf[l], tr->nnonleaf[l], v, mode);
+      KCHECK ();
+    }
+  return 0;
+}
+
+int residual_norm (gfship_tree * tr, const double * u, const double * rhs, double * res, double dt,
+		   gfship_norm * out)
+{
+  GFSHIP_HIP (hipMemsetAsync (tr->d_red, 0, 4*sizeof (double), tr->stream));
+  t_residual<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, u, rhs, res, tr->d_red);
+  KCHECK ();
+  GFSHIP_HIP (hipMemcpyAsync (tr->h_red, tr->d_red, 4*sizeof (double), hipMemcpyDeviceToHost, tr->stream));
+  GFSHIP_HIP (hipStreamSynchronize (tr->stream));
+  // gfs_norm_update + the scaling of gfs_domain_norm_residual, src/domain.c:2264-2288
+  const double w = tr->nleaves;
+  dt *= dt;
+  out->bias = tr->h_red[1]*dt;
+  out->first = tr->h_red[2]/w*dt;
+  out->second = sqrt (tr->h_red[3]/w)*dt;
+  out->infty = tr->h_red[0]*dt;
+  out->w = w;
+  return 0;
+}
+
+int relax_loop (gfship_tree * tr, int m, unsigned nrelax, double omega)
+{
+  Sweep & S = tr->sweep[m];
+  t_relax_loop<<<1, 1024, 0, tr->stream>>> (tr->D, S.cells, S.lev_off, S.nlev, S.ghosts, S.nghosts,
+					     tr->var[V_DP], tr->var[V_RES], nrelax, omega, m);
+  KCHECK ();
+  return 0;
+}
+
+// gfs_poisson_cycle, src/poisson.c:1105-1178 (dia = 0)
+int poisson_cycle (gfship_tree * tr, gfship_multilevel_params * p, double * u, const double * rhs)
+{
+  int e;
+  const unsigned minlevel = p->minlevel;
+  if ((e = from_below (tr, tr->var[V_RES], 1))) return e;
+  unsigned nrelax = p->nrelax;
+  for (unsigned l = minlevel; l < p->depth; l++)
+    nrelax *= p->erelax;
+  // dp: the cells of the first level are reset, every other cell is written before it is read
+  GFSHIP_HIP (hipMemsetAsync (tr->var[V_DP], 0, tr->ncell*sizeof (double), tr->stream));
+  if ((e = relax_loop (tr, minlevel, nrelax, p->omega))) return e;
+  nrelax /= p->erelax;
+  for (unsigned m = minlevel + 1; m <= p->depth; m++, nrelax /= p->erelax) {
+    if (tr->nnonleaf[m - 1]) {
+      t_from_above<<<blocks (tr->nnonleaf[m - 1]), 256, 0, tr->stream>>> (tr->D, tr->nonleaf[m - 1], tr->nnonleaf[m - 1], tr->var[V_DP]);
+      KCHECK ();
+    }
+    if ((e = relax_loop (tr, m, nrelax, p->omega))) return e;
+  }
+  t_correct<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, u, tr->var[V_DP]);
+  KCHECK ();
+  return bc_leaves (tr, u);
+}
+
+// gfs_poisson_solve, src/poisson.c:1225-1269
+int poisson_solve (gfship_tree * tr, gfship_multilevel_params * par, double * lhs, const double * rhs, double dt)
+{
+  int e;
+  const unsigned minlevel = par->minlevel;
+  par->depth = tr->H.depth;
+  par->niter = 0;
+  if ((e = residual_norm (tr, lhs, rhs, tr->var[V_RES], dt, &par->residual))) return e;
+  par->residual_before = par->residual;
+  double res_max_before = par->residual.infty;
+  while (par->niter < par->nitermin ||
+	 (par->residual.infty > par->tolerance && par->niter < par->nitermax)) {
+    if ((e = poisson_cycle (tr, par, lhs, rhs))) return e;
+    if ((e = residual_norm (tr, lhs, rhs, tr->var[V_RES], dt, &par->residual))) return e;
+    if (par->residual.infty == res_max_before)
+      break;
+    if (par->residual.infty > res_max_before/1.1 && par->minlevel < par->depth)
+      par->minlevel++;
+    res_max_before = par->residual.infty;
+    par->niter++;
+  }
+  par->minlevel = minlevel;
+  return 0;
+}
+
+int gather_un (gfship_tree * tr, int kind, int dmask)
+{
+  FaceSet & F = tr->fs[kind];
+  t_gather_un<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, F.faces, F.inc_off, F.inc, F.fval,
+      tr->var[V_UN0], tr->var[V_UN1], tr->var[V_UN2], tr->var[V_UN3], dmask);
+  KCHECK ();
+  return 0;
+}
+
+// mac_projection, src/timestep.c:356-444
+int mac_projection (gfship_tree * tr, gfship_multilevel_params * par, double dt, double * p, int gvar)
+{
+  int e;
+  double * g[2] = { tr->var[gvar], tr->var[gvar + 1] };
+  for (int c = 0; c < 2; c++)   /* gfs_reset_gradients on the leaves (the other cells are never read) */
+    GFSHIP_HIP (hipMemsetAsync (g[c], 0, tr->ncell*sizeof (double), tr->stream));
+  t_divergence<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, tr->var[V_UN0], tr->var[V_UN1],
+      tr->var[V_UN2], tr->var[V_UN3], tr->var[V_DIV], dt);
+  KCHECK ();
+  if ((e = poisson_solve (tr, par, p, tr->var[V_DIV], dt))) return e;
+  // gfs_correct_normal_velocities (FTT_XY: the x faces, then the y faces), src/timestep.c:163-179
+  for (int c = 0; c < 2; c++) {
+    FaceSet & F = tr->fs[1 + c];
+    t_face_correct<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, p, F.fval);
+    KCHECK ();
+    t_gather_correct<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, F.faces, F.inc_off, F.inc, F.fval,
+	tr->var[V_UN0], tr->var[V_UN1], tr->var[V_UN2], tr->var[V_UN3], g[c], dt);
+    KCHECK ();
+  }
+  // gfs_scale_gradients, src/timestep.c:92-107
+  t_scale2<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, g[0], g[1], 0., 0, nullptr, nullptr);
+  KCHECK ();
+  for (int c = 0; c < 2; c++)
+    if ((e = bc_leaves (tr, g[c]))) return e;
+  return 0;
+}
+
+int correct_centered (gfship_tree * tr, int gvar, double dt)   /* src/timestep.c:498-530 */
+{
+  int e;
+  t_scale2<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, tr->var[V_U], tr->var[V_V], dt, 1,
+      tr->var[gvar], tr->var[gvar + 1]);
+  KCHECK ();
+  for (int c = 0; c < 2; c++)
+    if ((e = bc_leaves (tr, tr->var[V_U + c]))) return e;
+  return 0;
+}
+
+int approximate_projection (gfship_tree * tr, gfship_multilevel_params * par, double dt)
+{ /* src/timestep.c:560-596 */
+  int e;
+  FaceSet & F = tr->fs[0];
+  t_face_interp<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, tr->var[V_U], tr->var[V_V], F.fval);
+  KCHECK ();
+  if ((e = gather_un (tr, 0, 15))) return e;
+  if ((e = mac_projection (tr, par, dt, tr->var[V_P], V_GX))) return e;
+  return correct_centered (tr, V_GX, dt);
+}
+
+UpwindArgs upwind_args (gfship_tree * tr)
+{
+  UpwindArgs A;
+  for (int c = 0; c < 2; c++) A.u[c] = tr->var[V_U + c];
+  for (int d = 0; d < 4; d++) { A.un[d] = tr->var[V_UN0 + d]; A.fv[d] = tr->var[V_FV0 + d]; }
+  return A;
+}
+
+int face_values_set (gfship_tree * tr, const double * v, double dt, int use_centered)
+{ /* src/timestep.c:644-654 */
+  AdvArgs A;
+  A.v = v; A.dt = dt; A.use_centered = use_centered;
+  for (int c = 0; c < 2; c++) A.u[c] = tr->var[V_U + c];
+  for (int d = 0; d < 4; d++) { A.un[d] = tr->var[V_UN0 + d]; A.fv[d] = tr->var[V_FV0 + d]; }
+  t_face_values<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, A);
+  KCHECK ();
+  if (tr->nghost_leaves)
+    t_face_bc<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves,
+	tr->var[V_FV0], tr->var[V_FV1], tr->var[V_FV2], tr->var[V_FV3]);
+  KCHECK ();
+  return 0;
+}
+
+int predicted_face_velocities (gfship_tree * tr)   /* src/timestep.c:681-717 */
+{
+  int e;
+  for (int c = 0; c < 2; c++) {
+    if ((e = face_values_set (tr, tr->var[V_U + c], tr->dt, 1))) return e;
+    FaceSet & F = tr->fs[1 + c];
+    t_face_advected_un<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, upwind_args (tr), F.fval);
+    KCHECK ();
+    if ((e = gather_un (tr, 1 + c, 3 << (2*c)))) return e;
+  }
+  return 0;
+}
+
+// gfs_centered_velocity_advection_diffusion, src/timestep.c:976-1016, with variable_sources :872-921
+int centered_velocity_advection (gfship_tree * tr, int gmac, int g)
+{
+  int e;
+  FaceSet & F = tr->fs[0];
+  for (int c = 0; c < 2; c++) {
+    if ((e = face_values_set (tr, tr->var[V_U + c], tr->dt, 0))) return e;
+    t_face_flux<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, upwind_args (tr), tr->var[gmac + c], tr->dt, F.fval);
+    KCHECK ();
+    t_gather_flux<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, F.faces, F.inc_off, F.inc, F.fval,
+	tr->var[V_U + c], tr->var[g + c], tr->dt);
+    KCHECK ();
+  }
+  for (int c = 0; c < 2; c++)
+    if ((e = bc_leaves (tr, tr->var[V_U + c]))) return e;
+  return 0;
+}
+
+int domain_cfl (gfship_tree * tr, double * cfl)   /* src/domain.c:2899-2923 */
+{
+  const double big = DBL_MAX;
+  GFSHIP_HIP (hipMemcpyAsync (tr->d_red, &big, sizeof (double), hipMemcpyHostToDevice, tr->stream));
+  FaceSet & F = tr->fs[0];
+  t_cfl_faces<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, tr->var[V_UN0], tr->var[V_UN1], tr->var[V_UN2],
+      tr->var[V_UN3], tr->d_red);
+  KCHECK ();
+  t_cfl_cells<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, tr->var[V_U], tr->var[V_V], tr->d_red);
+  KCHECK ();
+  GFSHIP_HIP (hipMemcpyAsync (tr->h_red, tr->d_red, sizeof (double), hipMemcpyDeviceToHost, tr->stream));
+  GFSHIP_HIP (hipStreamSynchronize (tr->stream));
+  *cfl = sqrt (tr->h_red[0]);
+  return 0;
+}
+
+int set_timestep (gfship_tree * tr)   /* src/simulation.c:1569-1633; the only event time is `end' */
+{
+  int e;
+  double c;
+  if ((e = domain_cfl (tr, &c))) return e;
+  const double t = tr->t;
+  tr->dt = tr->cfl*c;
+  double tnext = 2147483647;
+  if (tr->end < tnext)
+    tnext = tr->end;
+  const double n = ceil ((tnext - t)/tr->dt);
+  if (n > 0. && n < 2147483647) {
+    tr->dt = (tnext - t)/n;
+    if (n == 1.)
+      tr->tnext = tnext;
+    else
+      tr->tnext = t + tr->dt;
+  }
+  else
+    tr->tnext = t + tr->dt;
+  if (tr->dt < 1e-9)
+    tr->dt = 1e-9;
+  return 0;
+}
+
+int coarse_init (gfship_tree * tr)   /* src/adaptive.c:43-58 */
+{
+  int e;
+  static const int vars[] = { V_P, V_PMAC, V_U, V_V };
+  for (int v : vars)
+    if ((e = from_below (tr, tr->var[v], 0))) return e;
+  return 0;
+}
+
+void tree_free (gfship_tree * tr)
+{
+  if (!tr) return;
+  (void) hipFree (tr->dflag);
+  for (double * p : tr->var) (void) hipFree (p);
+  (void) hipFree (tr->leaves);
+  (void) hipFree (tr->ghost_leaves);
+  for (int l = 0; l <= GFSHIP_MAXLEVEL; l++) {
+    (void) hipFree (tr->nonleaf[l]);
+    (void) hipFree (tr->sweep[l].cells); (void) hipFree (tr->sweep[l].lev_off); (void) hipFree (tr->sweep[l].ghosts);
+  }
+  for (FaceSet & F : tr->fs) { (void) hipFree (F.faces); (void) hipFree (F.inc_off); (void) hipFree (F.inc); (void) hipFree (F.fval); }
+  (void) hipFree (tr->d_red);
+  if (tr->h_red) (void) hipHostFree (tr->h_red);
+  if (tr->stream) (void) hipStreamDestroy (tr->stream);
+  delete tr;
+}
+
+} // namespace
+
+// ---- C ABI -------------------------------------------------------------------------------------
+
+extern "C" {
+
+int gfship_tree_create (gfship_tree ** out, int dim, gfship_refine_fn refine, void * ctx, int device)
+{
+  GFSHIP_CHECK (out && refine, GFSHIP_EINVAL, "gfship_tree_create: null argument");
+  GFSHIP_CHECK (dim == 2, GFSHIP_EUNSUPPORTED,
+		"gfship_tree_create: refined trees are implemented in 2-D only (dim = %d)", dim);
+  int ndev = 0;
+  if (hipGetDeviceCount (&ndev) != hipSuccess || ndev == 0) {
+    set_error ("gfship_tree_create: no HIP device");
+    return GFSHIP_ENODEVICE;
+  }
+  GFSHIP_CHECK (device >= 0 && device < ndev, GFSHIP_EINVAL, "gfship_tree_create: device %d of %d", device, ndev);
+  GFSHIP_HIP (hipSetDevice (device));
+
+  // gfs_refine_refine + gfs_simulation_refine, src/refine.c:45-60, src/simulation.c:1203-1233
+  Builder B;
+  B.ensure (0);
+  B.flag[0][1 + B.r (0)] = LEAF;
+  int e = B.refine_rec (0, 1, 1, refine, ctx);
+  GFSHIP_CHECK (e == 0, e, "gfship_tree_create: more than %d levels", GFSHIP_MAXLEVEL);
+  gfship_tree * tr = new gfship_tree;
+  tr->device = device;
+  auto flatten = [&] () {
+    Topo & H = tr->H;
+    H.depth = (int) B.flag.size () - 1;
+    int off = 0;
+    for (int l = 0; l <= H.depth; l++) {
+      H.off[l] = off;
+      off += B.r (l)*B.r (l);
+    }
+    H.off[H.depth + 1] = off;
+    tr->ncell = off;
+    tr->hflag.assign (off, NONE);
+    for (int l = 0; l <= H.depth; l++)
+      std::copy (B.flag[l].begin (), B.flag[l].end (), tr->hflag.begin () + H.off[l]);
+    H.flag = tr->hflag.data ();
+  };
+  flatten ();
+  for (int l = tr->H.depth - 2; l >= 0; l--) {
+    // the refinements of a level are applied while the level is traversed (simulation.c:1105-1109)
+    traverse (tr->H, root_cell (tr->H), T_LEVEL, l, [&] (Cell c) {
+	if (tr->H.leaf (c) && refine_corner (tr->H, c)) {
+	  B.refine_single (c.l, tr->H.ci (c), tr->H.cj (c));
+	  for (int ll = 0; ll <= tr->H.depth; ll++)
+	    std::copy (B.flag[ll].begin (), B.flag[ll].end (), tr->hflag.begin () + tr->H.off[ll]);
+	}
+      });
+  }
+  // gfs_domain_match: the ghost trees of the periodic sides mirror the cells they face; both cells
+  // of a periodic pair must be at the same refinement
+  for (int l = 0; l <= tr->H.depth; l++) {
+    const int n = 1 << l, r = n + 2;
+    unsigned char * f = tr->hflag.data () + tr->H.off[l];
+    for (int t = 1; t <= n; t++) {
+      if (f[n + r*t] != f[1 + r*t] || f[t + r*n] != f[t + r*1]) {
+	delete tr;
+	set_error ("gfship_tree_create: the refinement differs across a periodic side (level %d)", l);
+	return GFSHIP_EUNSUPPORTED;
+      }
+      f[0 + r*t] = f[n + r*t];
+      f[n + 1 + r*t] = f[1 + r*t];
+      f[t + r*0] = f[t + r*n];
+      f[t + r*(n + 1)] = f[t + r*1];
+    }
+  }
+
+  const Topo & T = tr->H;
+  hipError_t he = hipStreamCreate (&tr->stream);
+  if (he != hipSuccess) { tree_free (tr); return hip_fail (he, "hipStreamCreate", __FILE__, __LINE__); }
+#define TRY(call) do { int e_ = (call); if (e_) { tree_free (tr); return e_; } } while (0)
+#define TRYHIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { tree_free (tr); \
+      return hip_fail (e_, #call, __FILE__, __LINE__); } } while (0)
+  TRYHIP (hipMalloc ((void **) &tr->dflag, tr->ncell));
+  TRYHIP (hipMemcpy (tr->dflag, tr->hflag.data (), tr->ncell, hipMemcpyHostToDevice));
+  tr->D = tr->H;
+  tr->D.flag = tr->dflag;
+  for (int v = 0; v < V_NVAR; v++) {
+    TRYHIP (hipMalloc ((void **) &tr->var[v], tr->ncell*sizeof (double)));
+    TRYHIP (hipMemset (tr->var[v], 0, tr->ncell*sizeof (double)));
+  }
+  TRYHIP (hipMalloc ((void **) &tr->d_red, 4*sizeof (double)));
+  TRYHIP (hipHostMalloc ((void **) &tr->h_red, 4*sizeof (double), 0));
+  traverse (T, root_cell (T), T_LEAFS, -1, [&] (Cell c) { tr->hleaves.push_back (c); });
+  tr->nleaves = (int) tr->hleaves.size ();
+  TRY (to_device (tr->hleaves, &tr->leaves));
+  for (int l = 0; l < T.depth; l++) {
+    std::vector<Cell> nl;
+    traverse (T, root_cell (T), T_LEVEL_NON_LEAFS, l, [&] (Cell c) { nl.push_back (c); });
+    tr->nnonleaf[l] = (int) nl.size ();
+    TRY (to_device (nl, &tr->nonleaf[l]));
+  }
+  std::vector<Ghost> gh;
+  ghost_list (T, T_LEAFS, -1, gh);
+  tr->nghost_leaves = (int) gh.size ();
+  TRY (to_device (gh, &tr->ghost_leaves));
+  for (int m = 0; m <= T.depth; m++)
+    TRY (sweep_plan (tr, m, &tr->sweep[m]));
+  for (int k = 0; k < 3; k++)
+    TRY (face_set (tr, k, &tr->fs[k]));
+#undef TRY
+#undef TRYHIP
+  gfship_multilevel_params_init (&tr->projection_params, 2);
+  gfship_multilevel_params_init (&tr->approx_projection_params, 2);
+  *out = tr;
+  return GFSHIP_OK;
+}
+
+void gfship_tree_destroy (gfship_tree * tr) { tree_free (tr); }
+
+int gfship_tree_depth (const gfship_tree * tr) { return tr ? tr->H.depth : -1; }
+
+int gfship_tree_flags (const gfship_tree * tr, int level, unsigned char * out)
+{
+  GFSHIP_CHECK (tr && out && level >= 0 && level <= tr->H.depth, GFSHIP_EINVAL, "gfship_tree_flags: bad argument");
+  const int r = tr->H.r (level);
+  memcpy (out, tr->hflag.data () + tr->H.off[level], (size_t) r*r);
+  return GFSHIP_OK;
+}
+
+int gfship_tree_upload (gfship_tree * tr, int var, int level, const double * in)
+{
+  GFSHIP_CHECK (tr && in && var >= 0 && var <= V_UN3 && level >= 0 && level <= tr->H.depth, GFSHIP_EINVAL,
+		"gfship_tree_upload: bad argument");
+  const int r = tr->H.r (level);
+  GFSHIP_HIP (hipMemcpyAsync (tr->var[var] + tr->H.off[level], in, (size_t) r*r*sizeof (double),
+			      hipMemcpyHostToDevice, tr->stream));
+  GFSHIP_HIP (hipStreamSynchronize (tr->stream));
+  return GFSHIP_OK;
+}
+
+int gfship_tree_download (gfship_tree * tr, int var, int level, double * out)
+{
+  GFSHIP_CHECK (tr && out && var >= 0 && var <= V_UN3 && level >= 0 && level <= tr->H.depth, GFSHIP_EINVAL,
+		"gfship_tree_download: bad argument");
+  const int r = tr->H.r (level);
+  GFSHIP_HIP (hipMemcpyAsync (out, tr->var[var] + tr->H.off[level], (size_t) r*r*sizeof (double),
+			      hipMemcpyDeviceToHost, tr->stream));
+  GFSHIP_HIP (hipStreamSynchronize (tr->stream));
+  return GFSHIP_OK;
+}
+
+gfship_multilevel_params * gfship_tree_projection_params (gfship_tree * tr, int approx)
+{
+  return approx ? &tr->approx_projection_params : &tr->projection_params;
+}
+
+int gfship_tree_set_time (gfship_tree * tr, double end, double cfl)
+{
+  GFSHIP_CHECK (tr && cfl > 0., GFSHIP_EINVAL, "gfship_tree_set_time: bad argument");
+  tr->end = end;
+  tr->cfl = cfl;
+  return GFSHIP_OK;
+}
+
+double gfship_tree_time (const gfship_tree * tr) { return tr->t; }
+double gfship_tree_dt (const gfship_tree * tr) { return tr->dt; }
+unsigned gfship_tree_iter (const gfship_tree * tr) { return tr->iter; }
+
+/* the cells of the sweep of level `level' and the number of dependency levels they form */
+int gfship_tree_sweep_levels (const gfship_tree * tr, int level, int * ncells, int * nlevels)
+{
+  GFSHIP_CHECK (tr && level >= 0 && level <= tr->H.depth, GFSHIP_EINVAL, "gfship_tree_sweep_levels: bad argument");
+  if (ncells) *ncells = tr->sweep[level].ncells;
+  if (nlevels) *nlevels = tr->sweep[level].nlev;
+  return GFSHIP_OK;
+}
+
+/* simulation_run up to the loop, src/simulation.c:458-476 */
+int gfship_tree_start (gfship_tree * tr)
+{
+  GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_start: null tree");
+  GFSHIP_HIP (hipSetDevice (tr->device));
+  int e;
+  static const int vars[] = { V_P, V_PMAC, V_U, V_V };
+  for (int v : vars)
+    if ((e = bc_leaves (tr, tr->var[v]))) return e;
+  if ((e = coarse_init (tr))) return e;
+  if ((e = set_timestep (tr))) return e;
+  if ((e = approximate_projection (tr, &tr->approx_projection_params, tr->dt))) return e;
+  return set_timestep (tr);
+}
+
+/* one iteration of the loop, src/simulation.c:479-548 */
+int gfship_tree_step (gfship_tree * tr)
+{
+  GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_step: null tree");
+  GFSHIP_HIP (hipSetDevice (tr->device));
+  int e;
+  if ((e = predicted_face_velocities (tr))) return e;
+  /* gfs_variables_swap (p, pmac) around the MAC projection */
+  if ((e = mac_projection (tr, &tr->projection_params, tr->dt/2., tr->var[V_PMAC], V_GMX))) return e;
+  const int g = tr->iter > 0 ? V_GX : V_GMX;
+  if ((e = centered_velocity_advection (tr, V_GMX, g))) return e;
+  if ((e = correct_centered (tr, g, - tr->dt))) return e;
+  if ((e = coarse_init (tr))) return e;
+  if ((e = approximate_projection (tr, &tr->approx_projection_params, tr->dt))) return e;
+  tr->t = tr->tnext;
+  tr->iter++;
+  return set_timestep (tr);
+}
+
+} // extern "C"

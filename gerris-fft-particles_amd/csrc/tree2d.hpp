@@ -1,0 +1,254 @@
+// tree2d.hpp -- the coarse-fine stencils of a statically refined 2-D quadtree.
+//
+// The reference keeps a tree of FttOct records and reaches a neighbour, a parent or the children
+// of a cell through pointers (src/ftt.h:134-159,518-573).  Here level l of the tree is a dense
+// (n + 2)^2 array, n = 2^l, with one ghost layer (the ghost trees of the periodic sides); all levels
+// of a variable sit behind each other in one allocation, and a byte per cell says whether the cell
+// exists and whether it is a leaf.  Neighbour, parent and children are index arithmetic.
+//
+// Everything in this file is __host__ __device__ and templated on how a value is read: the kernels
+// (tree2d.hip) read device arrays; the host instantiates the same stencil code with a reader that
+// records WHICH cells are read, and derives from that the dependency levels of an exact-order sweep
+// (the reference relaxes the cells of a level, coarser leaves included, in tree order:
+// src/poisson.c:604-632, src/ftt.c:689-926).
+//
+// Restated with the fine / coarse branches (unit face weights, no solid fractions, 2-D):
+//   average_neighbor_value src/fluid.c:64-93        interpolate_1D1 :178-197
+//   gradient_fine_coarse   :283-309                 gfs_neighbor_value :364-396
+//   gfs_center_gradient    :434-475                 gfs_face_gradient :778-829
+//   face_weighted_gradient :833-893 (w = 1: the same numbers as gfs_face_gradient in 2-D)
+//   gfs_face_interpolated_value :2186-2198
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gfship.h"
+
+namespace gfship { namespace tree {
+
+enum { NONE = 0, LEAF = 1, NODE = 2 };
+
+struct Cell { int l, q; };              // q < 0: no such cell
+
+struct Face { Cell cell, neighbor; int d; };   // FttCellFace
+
+struct Topo {
+  int depth;
+  int off[GFSHIP_MAXLEVEL + 2];         // first cell of each level in the concatenated arrays
+  const unsigned char * flag;
+
+  __host__ __device__ inline int n (int l) const { return 1 << l; }
+  __host__ __device__ inline int r (int l) const { return (1 << l) + 2; }
+  __host__ __device__ inline int gi (Cell c) const { return off[c.l] + c.q; }
+  __host__ __device__ inline int ci (Cell c) const { return c.q % r (c.l); }
+  __host__ __device__ inline int cj (Cell c) const { return c.q / r (c.l); }
+  __host__ __device__ inline bool leaf (Cell c) const { return flag[gi (c)] == LEAF; }
+  __host__ __device__ inline Cell make (int l, int i, int j) const {
+    Cell c = { l, -1 };
+    if (l < 0 || l > depth || i < 0 || j < 0 || i > n (l) + 1 || j > n (l) + 1)
+      return c;
+    int q = i + r (l)*j;
+    if (flag[off[l] + q] != NONE)
+      c.q = q;
+    return c;
+  }
+  // FTT_CELL_ID (src/ftt.c:301-316): bit 0 = +x, bit 1 = -y
+  __host__ __device__ inline int id (Cell c) const { return ((ci (c) + 1) & 1) + 2*(cj (c) & 1); }
+  // ftt_cell_neighbor, src/ftt.h:518-573
+  __host__ __device__ inline Cell neighbor (Cell c, int d) const {
+    const int i = ci (c) + (d == 0) - (d == 1), j = cj (c) + (d == 2) - (d == 3);
+    Cell nb = make (c.l, i, j);
+    if (nb.q >= 0 || c.l == 0 || i < 0 || j < 0 || i > n (c.l) + 1 || j > n (c.l) + 1)
+      return nb;
+    return make (c.l - 1, (i + 1)/2, (j + 1)/2);
+  }
+  __host__ __device__ inline Cell child (Cell c, int k) const {
+    return make (c.l + 1, 2*ci (c) - 1 + (k & 1), 2*cj (c) - ((k >> 1) & 1));
+  }
+  // ftt_cell_children_direction, src/ftt.h:321-355
+  __host__ __device__ inline Cell child_direction (Cell c, int d, int i) const {
+    const int index = d == 0 ? (i ? 3 : 1) : d == 1 ? (i ? 2 : 0) : d == 2 ? i : 2 + i;
+    return child (c, index);
+  }
+  __host__ __device__ inline bool interior (Cell c) const {
+    const int i = ci (c), j = cj (c);
+    return i >= 1 && j >= 1 && i <= n (c.l) && j <= n (c.l);
+  }
+  __host__ __device__ inline double size (Cell c) const { return 1./(1 << c.l); }
+};
+
+__host__ __device__ inline bool exists (Cell c) { return c.q >= 0; }
+__host__ __device__ inline bool fine_coarse (const Face & f) { return f.neighbor.l < f.cell.l; }
+
+// src/fluid.c:200-205: the direction, seen from the coarse neighbour, in which the fine cell sits
+__host__ __device__ inline int perpendicular (int d, int id)
+{
+  // {{-1,2,-1,3},{2,-1,3,-1},{1,0,-1,-1},{-1,-1,1,0}}
+  return d < 2 ? ((id & 2) ? 3 : 2) : ((id & 1) ? 0 : 1);
+}
+
+struct Grad2 { double a, b; };          // GfsGradient: v = a*v(cell) + b
+struct Grad3 { double a, b, c; };
+
+template <class V>
+__host__ __device__ inline double average_neighbor_value (const Topo & T, const Face & face, V & v, double & x)
+{
+  if (T.leaf (face.neighbor))
+    return v (T, face.neighbor);
+  double av = 0., a = 0.;
+  for (int i = 0; i < 2; i++) {
+    const Cell ch = T.child_direction (face.neighbor, face.d ^ 1, i);
+    if (exists (ch)) {
+      a += 1.;
+      av += 1.*v (T, ch);
+    }
+  }
+  if (a > 0.) {
+    x = 3./4.;
+    return av/a;
+  }
+  return v (T, face.cell);
+}
+
+template <class V>
+__host__ __device__ inline Grad2 interpolate_1D1 (const Topo & T, Cell cell, int d, double x, V & v)
+{
+  Grad2 p = { 1., 0. };
+  const Face f = { cell, T.neighbor (cell, d), d };
+  if (exists (f.neighbor)) {
+    double x2 = 1.;
+    const double p2 = average_neighbor_value (T, f, v, x2);
+    const double a2 = x/x2;
+    p.b += a2*p2;
+    p.a -= a2;
+  }
+  return p;
+}
+
+template <class V>
+__host__ __device__ inline Grad3 gradient_fine_coarse (const Topo & T, const Face & face, V & v)
+{
+  const Grad2 p = interpolate_1D1 (T, face.neighbor, perpendicular (face.d, T.id (face.cell)), 1./4., v);
+  Grad3 g;
+  g.a = 2./3.;
+  g.b = 2.*p.a/3.;
+  g.c = 2.*p.b/3.;
+  return g;
+}
+
+template <class V>
+__host__ __device__ inline double neighbor_value (const Topo & T, const Face & face, V & v, double & x)
+{
+  if (face.neighbor.l == face.cell.l)
+    return average_neighbor_value (T, face, v, x);
+  const Grad2 vc = interpolate_1D1 (T, face.neighbor, perpendicular (face.d, T.id (face.cell)), 1./4., v);
+  x = 3./2.;
+  return vc.a*v (T, face.neighbor) + vc.b;
+}
+
+template <class V>
+__host__ __device__ inline double center_gradient (const Topo & T, Cell cell, int c, V & v)
+{
+  const int d = 2*c;
+  const Face f1 = { cell, T.neighbor (cell, d ^ 1), d ^ 1 };
+  const Face f2 = { cell, T.neighbor (cell, d), d };
+  const double v0 = v (T, cell);
+  if (exists (f1.neighbor)) {
+    double x1 = 1.;
+    const double v1 = neighbor_value (T, f1, v, x1);
+    if (exists (f2.neighbor)) {
+      double x2 = 1.;
+      const double v2 = neighbor_value (T, f2, v, x2);
+      return (x1*x1*(v2 - v0) + x2*x2*(v0 - v1))/(x1*x2*(x2 + x1));
+    }
+    return (v0 - v1)/x1;
+  }
+  if (exists (f2.neighbor)) {
+    double x2 = 1.;
+    return (neighbor_value (T, f2, v, x2) - v0)/x2;
+  }
+  return 0.;
+}
+
+// gfs_face_gradient; with unit weights also face_weighted_gradient (dimension 2)
+template <class V>
+__host__ __device__ inline Grad2 face_gradient (const Topo & T, const Face & face, V & v, int max_level)
+{
+  Grad2 g = { 0., 0. };
+  if (!exists (face.neighbor))
+    return g;
+  const int level = face.cell.l;
+  if (face.neighbor.l < level) {
+    const Grad3 gcf = gradient_fine_coarse (T, face, v);
+    g.a = gcf.a;
+    g.b = gcf.b*v (T, face.neighbor) + gcf.c;
+  }
+  else if (level == max_level || T.leaf (face.neighbor)) {
+    g.a = 1.;
+    g.b = v (T, face.neighbor);
+  }
+  else {
+    Face f;
+    f.d = face.d ^ 1;
+    f.neighbor = face.cell;
+    for (int i = 0; i < 2; i++) {
+      f.cell = T.child_direction (face.neighbor, f.d, i);
+      if (exists (f.cell)) {
+	const Grad3 gcf = gradient_fine_coarse (T, f, v);
+	g.a += 1.*gcf.b;
+	g.b += 1.*(gcf.a*v (T, f.cell) - gcf.c);
+      }
+    }
+  }
+  return g;
+}
+
+template <class V>
+__host__ __device__ inline double face_interpolated_value (const Topo & T, const Face & face, V & v)
+{
+  double x1 = 1.;
+  if (exists (face.neighbor)) {
+    const double v1 = neighbor_value (T, face, v, x1);
+    return ((x1 - 0.5)*v (T, face.cell) + 0.5*v1)/x1;
+  }
+  return v (T, face.cell);
+}
+
+// relax2D, src/poisson.c:532-557, dia = 0, unit weights: the new value of u at `cell'
+template <class V>
+__host__ __device__ inline double relax_cell (const Topo & T, Cell cell, V & u, double rhs, double omega,
+					      int max_level)
+{
+  Grad2 g = { 0., 0. };
+  Face f;
+  f.cell = cell;
+  for (f.d = 0; f.d < 4; f.d++) {
+    f.neighbor = T.neighbor (cell, f.d);
+    if (exists (f.neighbor)) {
+      const Grad2 ng = face_gradient (T, f, u, max_level);
+      g.a += ng.a;
+      g.b += ng.b;
+    }
+  }
+  if (g.a != 0.)
+    return (1. - omega)*u (T, cell) + omega*(g.b - rhs)/g.a;
+  return 0.;
+}
+
+// residual_set2D, src/poisson.c:657-678
+template <class V>
+__host__ __device__ inline double residual_cell (const Topo & T, Cell cell, V & u, double rhs)
+{
+  Grad2 g = { 0., 0. };
+  Face f;
+  f.cell = cell;
+  for (f.d = 0; f.d < 4; f.d++) {
+    f.neighbor = T.neighbor (cell, f.d);
+    if (exists (f.neighbor)) {
+      const Grad2 ng = face_gradient (T, f, u, -1);
+      g.a += ng.a;
+      g.b += ng.b;
+    }
+  }
+  return rhs - (g.b - u (T, cell)*g.a);
+}
+
+} } // namespace gfship::tree

@@ -152,6 +152,20 @@ SIGNATURES = {
     "gfship_particles_set_forces": (_i, [_vp, _i, C.POINTER(_i), _pd]),
     "gfship_particles_set_force_coefficient": (_i, [_vp, _i, C.c_char_p]),
     "gfship_particles_download_particulate": (_i, [_vp, _pd, _pd, _pd]),
+    "gfship_tree_create": (_i, [C.POINTER(_vp), _i, C.c_void_p, _vp, _i]),
+    "gfship_tree_destroy": (None, [_vp]),
+    "gfship_tree_depth": (_i, [_vp]),
+    "gfship_tree_flags": (_i, [_vp, _i, C.POINTER(C.c_ubyte)]),
+    "gfship_tree_upload": (_i, [_vp, _i, _i, _pd]),
+    "gfship_tree_download": (_i, [_vp, _i, _i, _pd]),
+    "gfship_tree_projection_params": (C.POINTER(MultilevelParams), [_vp, _i]),
+    "gfship_tree_set_time": (_i, [_vp, _d, _d]),
+    "gfship_tree_time": (_d, [_vp]),
+    "gfship_tree_dt": (_d, [_vp]),
+    "gfship_tree_iter": (_u, [_vp]),
+    "gfship_tree_start": (_i, [_vp]),
+    "gfship_tree_step": (_i, [_vp]),
+    "gfship_tree_sweep_levels": (_i, [_vp, _i, _pi, _pi]),
 }
 
 
@@ -635,4 +649,67 @@ class ParticleList:
     def destroy(self):
         if self.ptr:
             lib().gfship_particles_destroy(self.ptr)
+            self.ptr = None
+
+
+REFINE_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p)
+
+
+class Tree:
+    """gfship_tree: a GfsSimulation on one periodic 2-D box refined by a GfsRefine function
+    (coarse-fine stencils).  refine (x, y) -> level wanted at that position."""
+    P, PMAC, U, V, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3 = range(12)
+
+    def __init__(self, refine, dim=2, device=0):
+        self._cb = REFINE_FN(lambda x, y, z, ctx: float(refine(x, y)))
+        p = _vp()
+        _check(lib().gfship_tree_create(C.byref(p), dim, C.cast(self._cb, C.c_void_p), None, device))
+        self.ptr = p
+        self.depth = lib().gfship_tree_depth(p)
+        self.projection_params = lib().gfship_tree_projection_params(p, 0).contents
+        self.approx_projection_params = lib().gfship_tree_projection_params(p, 1).contents
+
+    def flags(self, level):
+        r = (1 << level) + 2
+        a = np.zeros((r, r), dtype=np.uint8)
+        _check(lib().gfship_tree_flags(self.ptr, level, a.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        return a
+
+    def centres(self, level):
+        n = 1 << level
+        c = -0.5 + (np.arange(n + 2) - 0.5) / n
+        return np.meshgrid(c, c, indexing="xy")
+
+    def upload(self, var, level, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.shape == ((1 << level) + 2,) * 2
+        _check(lib().gfship_tree_upload(self.ptr, var, level, a.ctypes.data_as(_pd)))
+
+    def download(self, var, level):
+        r = (1 << level) + 2
+        a = np.empty((r, r))
+        _check(lib().gfship_tree_download(self.ptr, var, level, a.ctypes.data_as(_pd)))
+        return a
+
+    def set_time(self, end, cfl):
+        _check(lib().gfship_tree_set_time(self.ptr, end, cfl))
+
+    def start(self):
+        _check(lib().gfship_tree_start(self.ptr))
+
+    def step(self):
+        _check(lib().gfship_tree_step(self.ptr))
+
+    def sweep_levels(self, level):
+        a, b = C.c_int(), C.c_int()
+        _check(lib().gfship_tree_sweep_levels(self.ptr, level, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    t = property(lambda self: lib().gfship_tree_time(self.ptr))
+    dt = property(lambda self: lib().gfship_tree_dt(self.ptr))
+    i = property(lambda self: lib().gfship_tree_iter(self.ptr))
+
+    def destroy(self):
+        if self.ptr:
+            lib().gfship_tree_destroy(self.ptr)
             self.ptr = None

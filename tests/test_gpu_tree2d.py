@@ -1,0 +1,123 @@
+"""The refined-quadtree path of libgfship (csrc/tree2d.hip: coarse-fine stencils)
+against the quadtree oracle (oracle/go_tree2d.c, itself pinned on the reference's r1.ref / r2.ref),
+bit for bit, through the C ABI; and the reference's test/periodic rows from the device run."""
+import os
+
+import numpy as np
+import pytest
+
+import gfship
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def periodic_refine(level, box):
+    """Refine (x < -0.25 || x > 0.25 || y < -0.25 || y > 0.25 ? LEVEL : LEVEL + BOX), periodic.gfs:25"""
+    return lambda x, y: level if (x < -0.25 or x > 0.25 or y < -0.25 or y > 0.25) else level + box
+
+
+def periodic_pair(level, box):
+    o = O.Tree2D(periodic=(level, box))
+    g = gfship.Tree(periodic_refine(level, box))
+    assert g.depth == o.depth
+    for l in range(o.depth + 1):
+        assert np.array_equal(g.flags(l), o.flags(l)), "tree flags differ on level %d" % l
+        # Init {} { U = ... V = ... } on the leaves (the oracle has done it; same numbers)
+        for var, which in ((gfship.Tree.U, O.Tree2D.U), (gfship.Tree.V, O.Tree2D.V)):
+            g.upload(var, l, o.values(which, l))
+    for gp, op in ((g.projection_params, o.projection_params),
+                   (g.approx_projection_params, o.approx_projection_params)):
+        gp.tolerance = op.tolerance
+    g.set_time(0.5, 0.75)
+    return o, g
+
+
+def assert_same_leaves(o, g, what):
+    pairs = ((gfship.Tree.U, O.Tree2D.U, "U"), (gfship.Tree.V, O.Tree2D.V, "V"),
+             (gfship.Tree.P, O.Tree2D.P, "P"), (gfship.Tree.PMAC, O.Tree2D.PMAC, "Pmac"))
+    for l in range(o.depth + 1):
+        leaf = o.flags(l)[1:-1, 1:-1] == 1
+        if not leaf.any():
+            continue
+        for gv, ov, name in pairs:
+            a = g.download(gv, l)[1:-1, 1:-1][leaf]
+            b = o.values(ov, l)[1:-1, 1:-1][leaf]
+            assert np.array_equal(a, b), "%s: %s differs on the leaves of level %d (max %g)" % (
+                what, name, l, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("level,box,steps", [(4, 1, 5), (5, 1, 4), (4, 2, 5), (5, 2, 3), (5, 0, 3)])
+def test_tree_steps_bit_exact(level, box, steps):
+    o, g = periodic_pair(level, box)
+    o.start()
+    g.start()
+    assert g.dt == o.dt
+    assert_same_leaves(o, g, "after the initial projection")
+    assert g.approx_projection_params.niter == o.approx_projection_params.niter
+    assert g.approx_projection_params.residual.infty == o.approx_projection_params.residual.infty
+    for k in range(steps):
+        o.step()
+        g.step()
+        assert g.t == o.t and g.dt == o.dt, (k, g.t, o.t, g.dt, o.dt)
+        assert g.projection_params.niter == o.projection_params.niter
+        assert g.projection_params.residual.infty == o.projection_params.residual.infty
+        # the sums of the residual norm are accumulated in another order on the device
+        assert g.projection_params.residual.second == pytest.approx(
+            o.projection_params.residual.second, rel=1e-12)
+        assert_same_leaves(o, g, "step %d" % (k + 1))
+    # the MAC velocities of the leaves too
+    for l in range(o.depth + 1):
+        leaf = o.flags(l)[1:-1, 1:-1] == 1
+        for d in range(4):
+            a = g.download(gfship.Tree.UN0 + d, l)[1:-1, 1:-1][leaf]
+            b = o.values(O.Tree2D.UN0 + d, l)[1:-1, 1:-1][leaf]
+            assert np.array_equal(a, b), "un[%d] differs on level %d" % (d, l)
+    o.destroy()
+    g.destroy()
+
+
+def test_sweep_dependency_levels():
+    """the tree-order sweep of the finest level of the BOX = 2 tree keeps many cells per step"""
+    g = gfship.Tree(periodic_refine(5, 2))
+    ncells, nlev = g.sweep_levels(g.depth)
+    assert ncells == 700 + 272 + 4096
+    assert 0 < nlev < ncells / 8
+    g.destroy()
+
+
+def test_unsupported_trees_are_refused():
+    with pytest.raises(gfship.GfshipError):
+        gfship.Tree(lambda x, y: 4, dim=3)
+    # refinement that reaches one side of a periodic pair only
+    with pytest.raises(gfship.GfshipError):
+        gfship.Tree(lambda x, y: 5 if x > 0.25 else 4)
+
+
+@pytest.mark.parametrize("box", [1, 2])
+def test_periodic_rows_from_the_device(golden_dir, box):
+    """test/periodic/periodic.sh at LEVEL = 5: the run to t = 0.5 on the device, then the L2 / Linf
+    error of U as GfsOutputErrorNorm prints it (weights: cell volumes), against r1.ref / r2.ref"""
+    level = 5
+    with open(os.path.join(golden_dir, "reference", "periodic_r%d.ref" % box)) as f:
+        rows = {int(w[0]): w[1:3] for w in (l.split() for l in f) if w}
+    o, g = periodic_pair(level, box)
+    o.destroy()
+    g.start()
+    while g.t < 0.5:
+        g.step()
+    t = g.t
+    se, sw, mx = 0., 0., 0.
+    for l in range(g.depth + 1):
+        leaf = g.flags(l)[1:-1, 1:-1] == 1
+        if not leaf.any():
+            continue
+        x, y = g.centres(l)
+        exact = 1. - 2. * np.cos(2. * np.pi * (x - t)) * np.sin(2. * np.pi * (y - t))
+        e = (g.download(gfship.Tree.U, l) - exact)[1:-1, 1:-1][leaf]
+        w = 1. / (1 << l) ** 2
+        se += w * float(np.sum(e * e))
+        sw += w * e.size
+        mx = max(mx, float(np.abs(e).max()))
+    assert ["%.3e" % np.sqrt(se / sw), "%.3e" % mx] == rows[level]
+    g.destroy()
