@@ -144,10 +144,19 @@ struct Run {
   FunctionSet functions;
   gfship_domain * dom = nullptr;
   gfship_sim * sim = nullptr;
+  // a Refine function that asks for a non-uniform tree (2-D, one periodic box): gfship_tree.  The
+  // host copy of a variable is then one value per leaf, the leaves in the order of
+  // ftt_cell_traverse (src/ftt.c:689-926); (leaf_i, leaf_j) are the cell's indices on level leaf_l
+  bool tree_mode = false;
+  gfship_tree * tree = nullptr;
+  std::vector<int> leaf_l, leaf_i, leaf_j;
   std::chrono::steady_clock::time_point clock0;
 
   int n () const { return 1 << level; }
-  size_t total () const { size_t r = n () + 2; return dim == 3 ? r*r*r : r*r; }
+  size_t total () const {
+    if (tree_mode) return leaf_l.size ();
+    size_t r = n () + 2; return dim == 3 ? r*r*r : r*r;
+  }
   size_t idx (int i, int j, int k) const {
     size_t r = n () + 2;
     return i + r*(j + (dim == 3 ? r*(size_t) k : 0));
@@ -178,7 +187,24 @@ struct Run {
 std::vector<double> & host_of (Run & R, int v)
 {
   Variable & V = R.vars[v];
-  if (V.dev >= 0) {
+  if (R.tree_mode && V.dev >= 0) {
+    if (V.host.size () != R.total () || V.host_time != (double) R.i) {
+      V.host.resize (R.total ());
+      int depth = gfship_tree_depth (R.tree);
+      std::vector<std::vector<double>> lev (depth + 1);
+      for (size_t c = 0; c < R.leaf_l.size (); c++) {
+	int l = R.leaf_l[c];
+	size_t r = (1 << l) + 2;
+	if (lev[l].empty ()) {
+	  lev[l].resize (r*r);
+	  CHECK (gfship_tree_download (R.tree, V.dev, l, lev[l].data ()));
+	}
+	V.host[c] = lev[l][R.leaf_i[c] + r*R.leaf_j[c]];
+      }
+      V.host_time = (double) R.i;
+    }
+  }
+  else if (V.dev >= 0) {
     if (V.host.size () != R.total () || V.host_time != (double) R.i) {
       V.host.resize (R.total ());
       CHECK (gfship_field_download (R.dom, V.dev, R.level, V.host.data ()));
@@ -207,6 +233,13 @@ void invalidate_device_copies (Run & R)
 void cell_pos (const Run & R, int i, int j, int k, double p[3])
 {
   // ftt_cell_pos on the unit box centred on the origin, src/ftt.c:349-367
+  if (R.tree_mode) {       /* for_each_cell hands over the level of the leaf as k */
+    double h = 1./(1 << k);
+    p[0] = -0.5 + (i - 0.5)*h;
+    p[1] = -0.5 + (j - 0.5)*h;
+    p[2] = 0.;
+    return;
+  }
   double h = 1./R.n ();
   p[0] = -0.5 + (i - 0.5)*h;
   p[1] = -0.5 + (j - 0.5)*h;
@@ -237,6 +270,11 @@ double eval (Run & R, const Function * f, const double p[3], long cell)
 
 template <class F> void for_each_cell (const Run & R, F f)
 {
+  if (R.tree_mode) {
+    for (size_t c = 0; c < R.leaf_l.size (); c++)
+      f (R.leaf_i[c], R.leaf_j[c], R.leaf_l[c], c);
+    return;
+  }
   int n = R.n ();
   for (int k = 1; k <= (R.dim == 3 ? n : 1); k++)
     for (int j = 1; j <= n; j++)
@@ -252,7 +290,8 @@ gfship_norm norm_of (const Run & R, const std::vector<double> & a)
   gfship_norm nm = { 0., 0., 0., 0., 0. };
   double h = 1./R.n ();
   double w = R.dim == 3 ? h*h*h : h*h;
-  for_each_cell (R, [&] (int, int, int, size_t c) {
+  for_each_cell (R, [&] (int, int, int k, size_t c) {
+    if (R.tree_mode) { double hl = 1./(1 << k); w = hl*hl; }    /* gfs_cell_volume of the leaf */
     double val = a[c];
     nm.bias += w*val;
     val = fabs (val);
@@ -859,7 +898,7 @@ void parse_object (Run & R, Reader & r)
       Run & R = *pr;
       double real = std::chrono::duration<double> (std::chrono::steady_clock::now () - R.clock0).count ();
       fprintf (o->open (), "step: %7u t: %15.8f dt: %13.6e cpu: %15.8f real: %15.8f\n",
-	       R.i, R.t, R.sim ? gfship_sim_advection_params (R.sim)->dt : 0., real, real);
+	       R.i, R.t, R.tree ? gfship_tree_dt (R.tree) : R.sim ? gfship_sim_advection_params (R.sim)->dt : 0., real, real);
       fflush (o->fp);
     };
     add_event (R, e, cls, line);
@@ -884,13 +923,15 @@ void parse_object (Run & R, Reader & r)
       }
       else {
 	// projection_stats_event, src/output.c:486-500
-	const gfship_multilevel_params * p = gfship_sim_projection_params (R.sim);
+	const gfship_multilevel_params * p = R.tree ? gfship_tree_projection_params (R.tree, 0) :
+	  gfship_sim_projection_params (R.sim);
 	if (p->niter > 0) {
 	  fprintf (fp, "MAC projection        before     after       rate\n");
 	  stats_write (p, fp);
 	}
 	fprintf (fp, "Approximate projection\n");
-	stats_write (gfship_sim_approx_projection_params (R.sim), fp);
+	stats_write (R.tree ? gfship_tree_projection_params (R.tree, 1) :
+		     gfship_sim_approx_projection_params (R.sim), fp);
       }
       fflush (fp);
     };
@@ -918,6 +959,7 @@ void parse_object (Run & R, Reader & r)
 	double h = 1./R.n (), vol = R.dim == 3 ? h*h*h : h*h, sum = 0.;
 	for_each_cell (R, [&] (int i, int j, int k, size_t c) {
 	  double w = vol;
+	  if (R.tree_mode) { double hl = 1./(1 << k); w = hl*hl; }
 	  if (s.w) { double p[3]; cell_pos (R, i, j, k, p); w = eval (R, s.w, p, (long) c); }
 	  sum += w*a[c];
 	});
@@ -1441,7 +1483,20 @@ void apply_init (Run & R)
       a[c] = eval (R, kv.second, p, (long) c);
     });
     R.vars[v].host = a;
-    if (R.vars[v].dev >= 0) {
+    if (R.tree_mode && R.vars[v].dev >= 0) {
+      int depth = gfship_tree_depth (R.tree);
+      for (int l = 0; l <= depth; l++) {
+	size_t r = (1 << l) + 2;
+	std::vector<double> lev (r*r, 0.);
+	bool any = false;
+	for (size_t c = 0; c < R.leaf_l.size (); c++)
+	  if (R.leaf_l[c] == l) { lev[R.leaf_i[c] + r*R.leaf_j[c]] = a[c]; any = true; }
+	if (any)
+	  CHECK (gfship_tree_upload (R.tree, R.vars[v].dev, l, lev.data ()));
+      }
+      R.vars[v].host_time = (double) R.i;
+    }
+    else if (R.vars[v].dev >= 0) {
       CHECK (gfship_field_upload (R.dom, R.vars[v].dev, R.level, a.data ()));
       R.vars[v].host_time = (double) R.i;
     }
@@ -1464,8 +1519,17 @@ void resolve_refine (Run & R)
 	  if (level < eval (R, R.refine_fn, p, -1)) yes++; else no++;
 	}
     if (yes && no) {
+      // a statically refined tree: gfship_tree (2-D GfsSimulation, one box, all sides periodic)
+      bool periodic = true;
+      for (int d = 0; d < 2*R.dim; d++)
+	if (R.side[d] != GFSHIP_SIDE_PERIODIC) periodic = false;
+      if (R.dim == 2 && R.sim_class == "Simulation" && periodic) {
+	R.tree_mode = true;
+	R.level = level;     /* the coarsest leaves */
+	return;
+      }
       fprintf (stderr, "gfship: line %d: the Refine function asks for a non-uniform tree at level %d "
-	       "(adaptive refinement is not supported)\n", R.refine_line, level);
+	       "(refined trees: 2-D GfsSimulation in one periodic box only)\n", R.refine_line, level);
       exit (1);
     }
     if (!yes) break;
@@ -1477,6 +1541,102 @@ void resolve_refine (Run & R)
   R.level = level;
 }
 
+double refine_hook (double x, double y, double z, void * ctx)
+{
+  Run & R = *(Run *) ctx;
+  double p[3] = { x, y, z };
+  return eval (R, R.refine_fn, p, -1);
+}
+
+// the leaves of the tree in the order of ftt_cell_traverse (pre-order, children 0..3: bit 0 = +x,
+// bit 1 = -y, src/ftt.c:301-316)
+void tree_leaves (Run & R, const std::vector<std::vector<unsigned char>> & flag, int l, int i, int j)
+{
+  size_t r = (1 << l) + 2;
+  unsigned char f = flag[l][i + r*j];
+  if (f == 1) {
+    R.leaf_l.push_back (l); R.leaf_i.push_back (i); R.leaf_j.push_back (j);
+  }
+  else if (f == 2)
+    for (int k = 0; k < 4; k++)
+      tree_leaves (R, flag, l + 1, 2*i - 1 + (k & 1), 2*j - ((k >> 1) & 1));
+}
+
+// simulation_run (src/simulation.c:432-557) on a statically refined tree
+int run_tree (Run & R)
+{
+  auto refuse = [] (const char * what) {
+    fprintf (stderr, "gfship: %s is not supported on a refined tree\n", what);
+    return 1;
+  };
+  if (!R.tracers.empty ()) return refuse ("a tracer");
+  if (!R.plists.empty ()) return refuse ("a particle list");
+  if (!R.init_spectra.empty ()) return refuse ("GfsInitSpectra");
+  if (!R.device_vars.empty ()) return refuse ("a turbulent-viscosity variable");
+  if (R.snapshot.has_tree) return refuse ("cell data in the simulation file");
+  if (R.dtmax != DBL_MAX) return refuse ("Time { dtmax }");
+  for (int c = 0; c < 3; c++)
+    if (R.visc[c] != 0. || R.source[c] != 0.) return refuse ("a source term");
+  for (auto & kv : R.adv_set)
+    if (kv.first != "cfl" && !(kv.first == "gradient" && kv.second == "gfs_center_gradient") &&
+	!(kv.first == "gc" && atoi (kv.second.c_str ()) == 1))
+      return refuse ("this AdvectionParams setting");
+  static const char * ok[] = { "OutputErrorNorm", "OutputScalarNorm", "OutputScalarSum", "OutputScalarStats",
+			       "OutputTime", "OutputProjectionStats", "EventScript", "EventStop" };
+  for (auto & e : R.events) {
+    bool found = false;
+    for (const char * c : ok) if (e->cls == c) found = true;
+    if (!found) {
+      fprintf (stderr, "gfship: line %d: Gfs%s is not supported on a refined tree\n", e->line, e->cls.c_str ());
+      return 1;
+    }
+  }
+  for (const char * nm : { "Divergence", "Vorticity" }) {
+    int v = R.var_index (nm);
+    std::string name = nm;
+    if (v >= 0)
+      R.vars[v].derive = [name] (Variable &) {
+	fprintf (stderr, "gfship: the variable %s is not supported on a refined tree\n", name.c_str ());
+	exit (1);
+      };
+  }
+  CHECK (gfship_tree_create (&R.tree, R.dim, refine_hook, &R, R.device));
+  int depth = gfship_tree_depth (R.tree);
+  std::vector<std::vector<unsigned char>> flag (depth + 1);
+  for (int l = 0; l <= depth; l++) {
+    size_t r = (1 << l) + 2;
+    flag[l].resize (r*r);
+    CHECK (gfship_tree_flags (R.tree, l, flag[l].data ()));
+  }
+  tree_leaves (R, flag, 0, 1, 1);
+  R.vars[R.var_index ("P")].dev = GFSHIP_TREE_P;
+  R.vars[R.var_index ("Pmac")].dev = GFSHIP_TREE_PMAC;
+  R.vars[R.var_index ("U")].dev = GFSHIP_TREE_U;
+  R.vars[R.var_index ("V")].dev = GFSHIP_TREE_V;
+  apply_multilevel (gfship_tree_projection_params (R.tree, 0), R.proj_set);
+  apply_multilevel (gfship_tree_projection_params (R.tree, 1), R.approx_set);
+  double cfl = 0.8;        /* gfs_advection_params_init, src/advection.c:922-942 */
+  for (auto & kv : R.adv_set)
+    if (kv.first == "cfl") cfl = atof (kv.second.c_str ());
+  apply_init (R);
+  events_init (R);
+  CHECK (gfship_tree_set_time (R.tree, R.end, cfl));
+  CHECK (gfship_tree_set_next_event (R.tree, next_event_hook, &R));
+  CHECK (gfship_tree_start (R.tree));
+  while (R.t < R.end && R.i < R.iend) {
+    events_do (R);
+    CHECK (gfship_tree_set_time (R.tree, R.end, cfl));
+    CHECK (gfship_tree_step (R.tree));
+    R.t = gfship_tree_time (R.tree);
+    R.i = gfship_tree_iter (R.tree);
+  }
+  events_do (R);
+  for (auto & o : R.outputs) o->close ();
+  gfship_tree_destroy (R.tree);
+  R.tree = nullptr;
+  return 0;
+}
+
 int run (Run & R)
 {
   R.clock0 = std::chrono::steady_clock::now ();
@@ -1485,6 +1645,8 @@ int run (Run & R)
   add_derived (R);
   R.functions.resolve (R.var_names ());
   resolve_refine (R);
+  if (R.tree_mode)
+    return run_tree (R);
   CHECK (gfship_domain_create (&R.dom, R.dim, R.level, R.side, R.device));
   CHECK (gfship_sim_create (&R.sim, R.dom));
   R.vars[R.var_index ("P")].dev = gfship_sim_variable (R.sim, GFSHIP_VAR_P, 0);
@@ -1740,7 +1902,10 @@ int check (Run & R)
   add_derived (R);
   R.functions.resolve (R.var_names ());
   resolve_refine (R);
-  printf ("class Gfs%s dim %d level %d\n", R.sim_class.c_str (), R.dim, R.level);
+  printf ("class Gfs%s dim %d level %d%s\n", R.sim_class.c_str (), R.dim, R.level,
+	  R.tree_mode ? " (coarsest leaves of a refined tree)" : "");
+  if (R.tree_mode)        /* no host copies of fields without the tree, which needs the device */
+    R.init.clear ();
   printf ("sides");
   for (int d = 0; d < 2*R.dim; d++)
     printf (" %s=%s", side_name[d], R.side[d] == GFSHIP_SIDE_PERIODIC ? "periodic" : "boundary");

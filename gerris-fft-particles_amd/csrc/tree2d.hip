@@ -86,6 +86,7 @@ struct gfship_tree {
   gfship_multilevel_params projection_params, approx_projection_params;
   double cfl = 0.8, dt = 0., t = 0., end = DBL_MAX, tnext = 0.;
   unsigned iter = 0;
+  gfship_next_event_fn next_event = nullptr; void * next_event_ctx = nullptr;
 };
 
 namespace {
@@ -1034,6 +1035,8 @@ int set_timestep (gfship_tree * tr)   /* src/simulation.c:1569-1633; the only ev
   const double t = tr->t;
   tr->dt = tr->cfl*c;
   double tnext = 2147483647;
+  if (tr->next_event)          /* the gfs_event_next loop, src/simulation.c:1603-1610 */
+    tnext = tr->next_event (tr->next_event_ctx, t, tr->iter);
   if (tr->end < tnext)
     tnext = tr->end;
   const double n = ceil ((tnext - t)/tr->dt);
@@ -1234,6 +1237,14 @@ int gfship_tree_set_time (gfship_tree * tr, double end, double cfl)
   GFSHIP_CHECK (tr && cfl > 0., GFSHIP_EINVAL, "gfship_tree_set_time: bad argument");
   tr->end = end;
   tr->cfl = cfl;
+  return GFSHIP_OK;
+}
+
+int gfship_tree_set_next_event (gfship_tree * tr, gfship_next_event_fn fn, void * ctx)
+{
+  GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_set_next_event: null tree");
+  tr->next_event = fn;
+  tr->next_event_ctx = ctx;
   return GFSHIP_OK;
 }
 

@@ -160,6 +160,7 @@ SIGNATURES = {
     "gfship_tree_download": (_i, [_vp, _i, _i, _pd]),
     "gfship_tree_projection_params": (C.POINTER(MultilevelParams), [_vp, _i]),
     "gfship_tree_set_time": (_i, [_vp, _d, _d]),
+    "gfship_tree_set_next_event": (_i, [_vp, _vp, _vp]),
     "gfship_tree_time": (_d, [_vp]),
     "gfship_tree_dt": (_d, [_vp]),
     "gfship_tree_iter": (_u, [_vp]),

@@ -520,6 +520,7 @@ int  gfship_tree_upload (gfship_tree * tree, int var, int level, const double * 
 int  gfship_tree_download (gfship_tree * tree, int var, int level, double * out);
 gfship_multilevel_params * gfship_tree_projection_params (gfship_tree * tree, int approx);
 int  gfship_tree_set_time (gfship_tree * tree, double end, double cfl);  /* GfsTime end, AdvectionParams cfl */
+int  gfship_tree_set_next_event (gfship_tree * tree, gfship_next_event_fn fn, void * ctx); /* as gfship_sim_set_next_event */
 double   gfship_tree_time (const gfship_tree * tree);
 double   gfship_tree_dt (const gfship_tree * tree);
 unsigned gfship_tree_iter (const gfship_tree * tree);

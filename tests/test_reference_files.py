@@ -71,13 +71,22 @@ def test_reference_files_parse_unmodified(tmp_path, name, defs, sed, expect):
         assert "sides right=periodic left=periodic top=periodic bottom=periodic" in out
 
 
-def test_refined_patch_of_periodic_gfs_is_refused(tmp_path):
-    """BOX = 1 asks for a refined patch (test/periodic r1): adaptive trees are out of scope"""
+def test_refined_patch_of_periodic_gfs_is_accepted(tmp_path):
+    """BOX = 1, 2 ask for a refined patch (test/periodic r1 / r2): a 2-D GfsSimulation in one periodic
+    box goes to the refined-tree path (gfship_tree)"""
     _stage(tmp_path, "periodic.gfs")
-    text = open(str(tmp_path / "periodic.gfs")).read().replace("LEVEL", "5").replace("BOX", "1")
+    for box in (1, 2):
+        out = _run(tmp_path, "periodic.gfs", {}, check=True, sed={"LEVEL": 5, "BOX": box}).stdout
+        assert "class GfsSimulation dim 2 level 5 (coarsest leaves of a refined tree)" in out
+
+
+def test_refined_tree_outside_its_scope_is_refused(tmp_path):
+    """a refined patch in a box with boundaries, or in 3-D, is refused with the line of the Refine"""
+    text = ("1 0 GfsSimulation GfsBox GfsGEdge {} {\n  Time { end = 0.1 }\n"
+            "  Refine (x > 0.2 ? 5 : 4)\n}\nGfsBox {}\n")
     r = subprocess.run([BIN, "--check", "-"], cwd=str(tmp_path), input=text,
                        capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "non-uniform tree" in r.stderr
+    assert r.returncode != 0 and "non-uniform tree" in r.stderr and "line 3" in r.stderr
 
 
 @pytest.mark.gpu
@@ -112,6 +121,17 @@ def test_reynolds_gfs_against_div5_ref(tmp_path):
     assert len(got) == len(ref)
     for k in range(1, len(ref)):        # t = 0: 1e-15 round-off, libm dependent
         assert got[k] == ref[k], (k, got[k], ref[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("box,levels", [(1, (5, 6)), (2, (5,))])
+def test_periodic_gfs_refined_patch_against_r1_r2_ref(tmp_path, box, levels):
+    """periodic.sh with BOX = 1, 2: the statically refined patch (coarse-fine stencils, gfship_tree)"""
+    _stage(tmp_path, "periodic.gfs")
+    for level in levels:
+        out = _run(tmp_path, "periodic.gfs", {}, sed={"LEVEL": level, "BOX": box}).stdout.split()
+        want = [r for r in _rows("periodic_r%d.ref" % box) if r[0] == str(level)][0]
+        assert ["%.3e" % float(out[6]), "%.3e" % float(out[8])] == want[1:3], (box, level, out)
 
 
 @pytest.mark.gpu
