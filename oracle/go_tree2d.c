@@ -1,6 +1,9 @@
-/* go_tree2d.c -- oracle: the reference's time step on a 2-D quadtree with a statically refined
- * patch (coarse-fine stencils) in one periodic box: the case of
- * test/periodic/periodic.gfs with BOX = 1, 2.
+/* go_tree2d.c -- oracle: the reference's time step on a quadtree (2-D) or octree (3-D) with a
+ * statically refined patch (coarse-fine stencils) in one periodic box: the case of
+ * test/periodic/periodic.gfs with BOX = 1, 2, and its 3-D analogues (FTT_3D branches of the same
+ * functions: interpolate_2D1, four children per face, FTT_CELLS = 8; the reference holds no 3-D
+ * golden file: in 3-D this restatement is pinned by the 2-D files through the shared code, by the
+ * uniform 3-D oracle on a uniform octree, and by the z-invariant case, tests/test_oracle_tree2d.py).
  * TEST INFRASTRUCTURE ONLY (see gfs_oracle.h): nothing of the product links or calls this.
  *
  * Pinned on the reference's test/periodic/r1.ref and r2.ref (tests/test_oracle_tree2d.py), and on
@@ -45,13 +48,15 @@ typedef struct { double a, b; } GfsGradient;  /* fluid.h: v = a*v(cell) + b */
 typedef struct { double a, b, c; } Gradient;  /* fluid.c:55-59 */
 
 typedef struct GtSim {
+  int dim;                                    /* 2 or 3 */
+  int nd, nc;                                 /* FTT_NEIGHBORS = 2 dim, FTT_CELLS = 2^dim */
   int depth;                                  /* deepest level present */
   int n[GT_MAXL + 1], r[GT_MAXL + 1];
   size_t size[GT_MAXL + 1];
   unsigned char * flag[GT_MAXL + 1];
-  Var p, pmac, u[2], g[2], gmac[2];
-  Var un[4], fv[4];                           /* GFS_STATE (cell)->f[d].un, f[d].v (advection)   */
-  Var w[4];                                   /* GFS_STATE (cell)->f[d].v as Poisson weights     */
+  Var p, pmac, u[3], g[3], gmac[3];
+  Var un[6], fv[6];                           /* GFS_STATE (cell)->f[d].un, f[d].v (advection)   */
+  Var w[6];                                   /* GFS_STATE (cell)->f[d].v as Poisson weights     */
   GoMultilevelParams projection_params, approx_projection_params;
   double cfl, dt;                             /* GfsAdvectionParams */
   double t, end, tnext;
@@ -63,70 +68,92 @@ static const Cell NOCELL = { 0, -1 };
 /* ---- topology ----------------------------------------------------------------------------- */
 
 static inline int cell_i (const GtSim * s, Cell c) { return c.q % s->r[c.l]; }
-static inline int cell_j (const GtSim * s, Cell c) { return c.q / s->r[c.l]; }
+static inline int cell_j (const GtSim * s, Cell c) { return (c.q / s->r[c.l]) % s->r[c.l]; }
+static inline int cell_k (const GtSim * s, Cell c) { return s->dim == 3 ? c.q / (s->r[c.l]*s->r[c.l]) : 1; }
 static inline int exists (Cell c) { return c.q >= 0; }
 static inline int is_leaf (const GtSim * s, Cell c) { return s->flag[c.l][c.q] == GT_LEAF; }
 static inline double cell_size (Cell c) { return 1./(1 << c.l); }     /* ftt_cell_size, L = 1 */
 static inline double * val (const Var * v, Cell c) { return &v->lev[c.l][c.q]; }
 
-static Cell mkcell (const GtSim * s, int l, int i, int j)
+static Cell mkcell (const GtSim * s, int l, int i, int j, int k)
 {
   Cell c = { l, -1 };
   if (l < 0 || l > s->depth || !s->flag[l] || i < 0 || j < 0 || i > s->n[l] + 1 || j > s->n[l] + 1)
     return c;
-  int q = i + s->r[l]*j;
+  if (s->dim == 3 && (k < 0 || k > s->n[l] + 1))
+    return c;
+  int q = i + s->r[l]*(j + (s->dim == 3 ? s->r[l]*k : 0));
   if (s->flag[l][q] != GT_NONE)
     c.q = q;
   return c;
 }
 
-/* FTT_CELL_ID: position among the siblings, ftt.c:301-316 (bit 0: +x, bit 1: -y) */
+/* FTT_CELL_ID: position among the siblings, ftt.c:301-316 (bit 0: +x, bit 1: -y, bit 2: -z) */
 static inline int cell_id (const GtSim * s, Cell c)
 {
   int i = cell_i (s, c), j = cell_j (s, c);
-  return ((i + 1) & 1) + 2*(j & 1);
+  return ((i + 1) & 1) + 2*(j & 1) + (s->dim == 3 ? 4*(cell_k (s, c) & 1) : 0);
 }
 
 /* ftt_cell_neighbor, ftt.h:518-573: the neighbour at the same level or, failing that, the
    (leaf) cell one level up that covers its place */
 static Cell neighbor (const GtSim * s, Cell c, int d)
 {
-  static const int di[4] = { 1, -1, 0, 0 }, dj[4] = { 0, 0, 1, -1 };
-  int i = cell_i (s, c) + di[d], j = cell_j (s, c) + dj[d];
-  if (i < 0 || j < 0 || i > s->n[c.l] + 1 || j > s->n[c.l] + 1)
+  static const int di[6] = { 1, -1, 0, 0, 0, 0 }, dj[6] = { 0, 0, 1, -1, 0, 0 }, dk[6] = { 0, 0, 0, 0, 1, -1 };
+  int i = cell_i (s, c) + di[d], j = cell_j (s, c) + dj[d], k = cell_k (s, c) + dk[d];
+  if (i < 0 || j < 0 || k < 0 || i > s->n[c.l] + 1 || j > s->n[c.l] + 1 || k > s->n[c.l] + 1)
     return NOCELL;
-  Cell nb = mkcell (s, c.l, i, j);
+  Cell nb = mkcell (s, c.l, i, j, k);
   if (exists (nb) || c.l == 0)
     return nb;
-  return mkcell (s, c.l - 1, (i + 1)/2, (j + 1)/2);
+  return mkcell (s, c.l - 1, (i + 1)/2, (j + 1)/2, (k + 1)/2);
 }
 
 static Cell child (const GtSim * s, Cell c, int k)
 {
-  return mkcell (s, c.l + 1, 2*cell_i (s, c) - 1 + (k & 1), 2*cell_j (s, c) - ((k >> 1) & 1));
+  return mkcell (s, c.l + 1, 2*cell_i (s, c) - 1 + (k & 1), 2*cell_j (s, c) - ((k >> 1) & 1),
+		 2*cell_k (s, c) - ((k >> 2) & 1));
 }
 
-/* ftt_cell_children_direction, ftt.h:321-355 */
-static void children_direction (const GtSim * s, Cell c, int d, Cell ch[2])
+/* ftt_cell_children_direction, ftt.h:321-355: 2 children in 2-D, 4 in 3-D */
+static int children_direction (const GtSim * s, Cell c, int d, Cell ch[4])
 {
-  static const int index[4][2] = { {1, 3}, {0, 2}, {0, 1}, {2, 3} };
-  ch[0] = child (s, c, index[d][0]);
-  ch[1] = child (s, c, index[d][1]);
+  static const int index2[4][2] = { {1, 3}, {0, 2}, {0, 1}, {2, 3} };
+  static const int index3[6][4] = { {1, 3, 5, 7}, {0, 2, 4, 6}, {0, 1, 4, 5}, {2, 3, 6, 7},
+				    {0, 1, 2, 3}, {4, 5, 6, 7} };
+  int n = s->nc/2;
+  for (int i = 0; i < n; i++)
+    ch[i] = child (s, c, s->dim == 3 ? index3[d][i] : index2[d][i]);
+  return n;
 }
 
-/* ftt_cell_child_corner, ftt.h:366-400: the child in the corner of directions dx (0, 1), dy (2, 3) */
-static Cell child_corner (const GtSim * s, Cell c, int d0, int d1)
+/* ftt_cell_child_corner, ftt.h:366-425: the child in the corner of the given directions (one per
+   axis; an axis that is not given: d < 0) */
+static Cell child_corner (const GtSim * s, Cell c, int d0, int d1, int d2)
 {
-  int dx = d0 < 2 ? d0 : d1, dy = d0 < 2 ? d1 : d0;
-  return child (s, c, (dx == 0 ? 1 : 0) + (dy == 3 ? 2 : 0));
+  int d[3] = { d0, d1, d2 }, id = 0;
+  for (int a = 0; a < 3; a++) {
+    if (d[a] == 0) id |= 1;
+    if (d[a] == 3) id |= 2;
+    if (d[a] == 5) id |= 4;
+  }
+  return child (s, c, id);
 }
 
-/* fluid.c:200-205 (and advection.c:289-294) */
-static const int perpendicular[4][4] =
+/* fluid.c:200-213 (and advection.c:289-304): the directions, seen from the coarse neighbour, in
+   which the fine cell sits */
+static const int perpendicular2[4][4] =
   {{-1,  2, -1,  3},
    { 2, -1,  3, -1},
    { 1,  0, -1, -1},
    {-1, -1,  1,  0}};
+static const int perpendicular3[6][8][2] =
+  {{{-1,-1},{2,4},{-1,-1},{3,4},{-1,-1},{2,5},{-1,-1},{3,5}},
+   {{2,4},{-1,-1},{3,4},{-1,-1},{2,5},{-1,-1},{3,5},{-1,-1}},
+   {{4,1},{4,0},{-1,-1},{-1,-1},{5,1},{5,0},{-1,-1},{-1,-1}},
+   {{-1,-1},{-1,-1},{4,1},{4,0},{-1,-1},{-1,-1},{5,1},{5,0}},
+   {{1,2},{0,2},{1,3},{0,3},{-1,-1},{-1,-1},{-1,-1},{-1,-1}},
+   {{-1,-1},{-1,-1},{-1,-1},{-1,-1},{1,2},{0,2},{1,3},{0,3}}};
 
 /* ---- traversals, ftt.c:689-926 -------------------------------------------------------------- */
 
@@ -157,7 +184,7 @@ static void traverse_rec (GtSim * s, Cell c, int post, int flags, int max_depth,
   if (visit && !post)
     (* fn) (s, c, data);
   if (descend)
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < s->nc; k++) {
       Cell ch = child (s, c, k);
       if (exists (ch))
 	traverse_rec (s, ch, post, flags, max_depth, fn, data);
@@ -168,7 +195,7 @@ static void traverse_rec (GtSim * s, Cell c, int post, int flags, int max_depth,
 
 static void cell_traverse (GtSim * s, int post, int flags, int max_depth, CellFunc fn, void * data)
 {
-  Cell root = { 0, 1 + s->r[0] };
+  Cell root = mkcell (s, 0, 1, 1, 1);
   traverse_rec (s, root, post, flags, max_depth, fn, data);
 }
 
@@ -178,8 +205,9 @@ typedef struct { int d; CellFunc fn; void * data; } BoundaryPar;
 static void boundary_filter (GtSim * s, Cell c, void * data)
 {
   BoundaryPar * b = data;
-  int i = cell_i (s, c), j = cell_j (s, c), n = s->n[c.l];
-  if ((b->d == 0 && i == n) || (b->d == 1 && i == 1) || (b->d == 2 && j == n) || (b->d == 3 && j == 1))
+  int i = cell_i (s, c), j = cell_j (s, c), k = cell_k (s, c), n = s->n[c.l];
+  if ((b->d == 0 && i == n) || (b->d == 1 && i == 1) || (b->d == 2 && j == n) || (b->d == 3 && j == 1) ||
+      (b->d == 4 && k == n) || (b->d == 5 && k == 1))
     (* b->fn) (s, c, b->data);
 }
 
@@ -199,11 +227,11 @@ static void traverse_face (GtSim * s, Cell cell, void * data)
     return;
   if (is_leaf (s, cell) && !is_leaf (s, face.neighbor)) {
     /* coarse -> fine */
-    Cell ch[2];
+    Cell ch[4];
     face.d = OPP (face.d);
-    children_direction (s, face.neighbor, face.d, ch);
+    int n = children_direction (s, face.neighbor, face.d, ch);
     face.neighbor = face.cell;
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < n; i++)
       if (exists (face.cell = ch[i]))
 	(* p->fn) (s, &face, p->data);
   }
@@ -214,7 +242,7 @@ static void traverse_face (GtSim * s, Cell cell, void * data)
 static void traverse_all_direct_faces (GtSim * s, Cell cell, void * data)
 {
   FacePar * p = data;
-  for (p->d = 0; p->d < 4; p->d += 2)
+  for (p->d = 0; p->d < s->nd; p->d += 2)
     traverse_face (s, cell, p);
 }
 
@@ -225,7 +253,7 @@ static void face_traverse (GtSim * s, int c, FaceFunc fn, void * data)
   FacePar p = { 0, fn, data };
   if (c < 0) {
     cell_traverse (s, 0, T_LEAFS, -1, traverse_all_direct_faces, &p);
-    for (int d = 1; d < 4; d += 2) {
+    for (int d = 1; d < s->nd; d += 2) {
       BoundaryPar b = { d, traverse_face, &p };
       p.d = d;
       cell_traverse (s, 0, T_LEAFS, -1, boundary_filter, &b);
@@ -259,25 +287,45 @@ static void var_free (GtSim * s, Var * v)
 /* gfs_domain_copy_bc / gfs_domain_bc (domain.c:846-920) on a box whose four sides are periodic
    (boundary.c:1240-1451): the ghost cells selected by (flags, max_depth) take the value of their
    periodic image.  v1 == v for a plain BC; the homogeneous BC of a periodic side is the same copy. */
+/* the ghost cells of side `side' of level l and their periodic images: calls fn (G, image) */
+typedef void (* GhostFunc) (GtSim * s, int l, int side, int G, int image, void * data);
+static void ghost_traverse (GtSim * s, int l, GhostFunc fn, void * data)
+{
+  int n = s->n[l], r = s->r[l];
+  for (int side = 0; side < s->nd; side++)
+    for (int tb = 1; tb <= (s->dim == 3 ? n : 1); tb++)
+      for (int ta = 1; ta <= n; ta++) {
+	int g[3], im[3], a = side/2;     /* axis of the side; the two others run over 1..n */
+	int o1 = a == 0 ? 1 : 0, o2 = a == 2 ? 1 : 2;
+	g[a] = (side & 1) ? 0 : n + 1;
+	im[a] = (side & 1) ? n : 1;
+	g[o1] = im[o1] = ta;
+	g[o2] = im[o2] = s->dim == 3 ? tb : 0;
+	int G = g[0] + r*(g[1] + r*g[2]), I = im[0] + r*(im[1] + r*im[2]);
+	(* fn) (s, l, side, G, I, data);
+      }
+}
+
+typedef struct { Var * v; int flags, max_depth; } BcPar;
+static void bc_ghost (GtSim * s, int l, int side, int G, int image, void * data)
+{
+  BcPar * p = data;
+  unsigned char f = s->flag[l][G];
+  if (f == GT_NONE)
+    return;
+  int take = p->flags == T_LEAFS ? f == GT_LEAF :
+    p->flags == T_LEVEL_LEAFS ? (l == p->max_depth || f == GT_LEAF) : 1;
+  if (take)
+    p->v->lev[l][G] = p->v->lev[l][image];
+}
+
 static void bc (GtSim * s, Var * v, int flags, int max_depth)
 {
+  BcPar p = { v, flags, max_depth };
   for (int l = 0; l <= s->depth; l++) {
     if (max_depth >= 0 && l > max_depth)
       break;
-    int n = s->n[l], r = s->r[l];
-    for (int side = 0; side < 4; side++)
-      for (int t = 1; t <= n; t++) {
-	int gi = side == 0 ? n + 1 : side == 1 ? 0 : t, gj = side == 2 ? n + 1 : side == 3 ? 0 : t;
-	int ii = side == 0 ? 1 : side == 1 ? n : t, ij = side == 2 ? 1 : side == 3 ? n : t;
-	int G = gi + r*gj;
-	unsigned char f = s->flag[l][G];
-	if (f == GT_NONE)
-	  continue;
-	int take = flags == T_LEAFS ? f == GT_LEAF :
-	  flags == T_LEVEL_LEAFS ? (l == max_depth || f == GT_LEAF) : 1;
-	if (take)
-	  v->lev[l][G] = v->lev[l][ii + r*ij];
-      }
+    ghost_traverse (s, l, bc_ghost, &p);
   }
 }
 
@@ -285,61 +333,79 @@ static void bc (GtSim * s, Var * v, int flags, int max_depth)
 
 /* oct_new, ftt.c:45-83 with check_neighbors: a cell about to get children first makes sure that
    none of its neighbours is coarser than itself */
-static void refine_single (GtSim * s, int l, int i, int j)
+static void refine_single (GtSim * s, int l, int i, int j, int k)
 {
   assert (l < GT_MAXL);
-  int q = i + s->r[l]*j;
+  int r = s->r[l], q = i + r*(j + (s->dim == 3 ? r*k : 0));
   assert (s->flag[l][q] == GT_LEAF);
-  static const int di[4] = { 1, -1, 0, 0 }, dj[4] = { 0, 0, 1, -1 };
-  for (int d = 0; d < 4; d++) {
-    int ni = i + di[d], nj = j + dj[d];
-    if (ni < 1 || nj < 1 || ni > s->n[l] || nj > s->n[l])
+  static const int di[6] = { 1, -1, 0, 0, 0, 0 }, dj[6] = { 0, 0, 1, -1, 0, 0 }, dk[6] = { 0, 0, 0, 0, 1, -1 };
+  for (int d = 0; d < s->nd; d++) {
+    int ni = i + di[d], nj = j + dj[d], nk = k + dk[d];
+    if (ni < 1 || nj < 1 || ni > s->n[l] || nj > s->n[l] || (s->dim == 3 && (nk < 1 || nk > s->n[l])))
       continue; /* the ghost trees are matched at the end (gfs_domain_match) */
-    if (s->flag[l][ni + s->r[l]*nj] == GT_NONE) {
-      int pi = (ni + 1)/2, pj = (nj + 1)/2;
-      if (s->flag[l - 1][pi + s->r[l - 1]*pj] == GT_LEAF)
-	refine_single (s, l - 1, pi, pj);
+    if (s->flag[l][ni + r*(nj + (s->dim == 3 ? r*nk : 0))] == GT_NONE) {
+      int pi = (ni + 1)/2, pj = (nj + 1)/2, pk = (nk + 1)/2, pr = s->r[l - 1];
+      if (s->flag[l - 1][pi + pr*(pj + (s->dim == 3 ? pr*pk : 0))] == GT_LEAF)
+	refine_single (s, l - 1, pi, pj, pk);
     }
   }
   s->flag[l][q] = GT_NODE;
   if (!s->flag[l + 1])
     s->flag[l + 1] = calloc (s->size[l + 1], 1);
-  for (int k = 0; k < 4; k++)
-    s->flag[l + 1][2*i - 1 + (k & 1) + s->r[l + 1]*(2*j - ((k >> 1) & 1))] = GT_LEAF;
+  int cr = s->r[l + 1];
+  for (int c = 0; c < s->nc; c++)
+    s->flag[l + 1][2*i - 1 + (c & 1) + cr*(2*j - ((c >> 1) & 1) + (s->dim == 3 ? cr*(2*k - ((c >> 2) & 1)) : 0))] = GT_LEAF;
 }
 
 /* ftt_cell_refine, ftt.c:169-192, with refine_maxlevel, refine.c:35-38: `refine' is the GfsFunction
    of the GfsRefine object evaluated at the centre of the cell */
-typedef double (* GtRefineFunc) (double x, double y, void * ctx);
+typedef double (* GtRefineFunc) (double x, double y, double z, void * ctx);
 
-static void refine_rec (GtSim * s, int l, int i, int j, GtRefineFunc refine, void * ctx)
+static void refine_rec (GtSim * s, int l, int i, int j, int k, GtRefineFunc refine, void * ctx)
 {
-  int q = i + s->r[l]*j;
+  int r = s->r[l], q = i + r*(j + (s->dim == 3 ? r*k : 0));
   if (s->flag[l][q] == GT_LEAF) {
     double h = 1./s->n[l];
-    double x = -0.5 + (i - 0.5)*h, y = -0.5 + (j - 0.5)*h;
-    if (!(l < (* refine) (x, y, ctx)))
+    double x = -0.5 + (i - 0.5)*h, y = -0.5 + (j - 0.5)*h, z = s->dim == 3 ? -0.5 + (k - 0.5)*h : 0.;
+    if (!(l < (* refine) (x, y, z, ctx)))
       return;
-    refine_single (s, l, i, j);
+    refine_single (s, l, i, j, k);
   }
-  for (int k = 0; k < 4; k++)
-    refine_rec (s, l + 1, 2*i - 1 + (k & 1), 2*j - ((k >> 1) & 1), refine, ctx);
+  for (int c = 0; c < s->nc; c++)
+    refine_rec (s, l + 1, 2*i - 1 + (c & 1), 2*j - ((c >> 1) & 1), 2*k - ((c >> 2) & 1), refine, ctx);
 }
 
 /* ftt_refine_corner, ftt.c:2013-2074 */
 static int refine_corner (const GtSim * s, Cell cell)
 {
-  static const int perp[4][2] = { {2, 3}, {2, 3}, {1, 0}, {1, 0} };
-  for (int i = 0; i < 4; i++) {
+  static const int perp2[4][2] = { {2, 3}, {2, 3}, {1, 0}, {1, 0} };
+  static const int perp3[6][4][2] =
+    {{{4,2},{4,3},{5,2},{5,3}},
+     {{4,2},{4,3},{5,2},{5,3}},
+     {{4,1},{4,0},{5,1},{5,0}},
+     {{4,1},{4,0},{5,1},{5,0}},
+     {{2,1},{2,0},{3,1},{3,0}},
+     {{2,1},{2,0},{3,1},{3,0}}};
+  for (int i = 0; i < s->nd; i++) {
     Cell n = neighbor (s, cell, i);
     if (exists (n) && !is_leaf (s, n)) {
-      Cell ch[2];
-      children_direction (s, n, OPP (i), ch);
-      for (int j = 0; j < 2; j++)
+      Cell ch[4];
+      int k = children_direction (s, n, OPP (i), ch);
+      for (int j = 0; j < k; j++)
 	if (exists (ch[j])) {
-	  Cell nc = neighbor (s, ch[j], perp[i][j]);
-	  if (exists (nc) && !is_leaf (s, nc))
-	    return 1;
+	  if (s->dim == 2) {
+	    Cell nc = neighbor (s, ch[j], perp2[i][j]);
+	    if (exists (nc) && !is_leaf (s, nc))
+	      return 1;
+	  }
+	  else {
+	    Cell nc0 = neighbor (s, ch[j], perp3[i][j][0]);
+	    if (exists (nc0) && !is_leaf (s, nc0))
+	      return 1;
+	    Cell nc1 = neighbor (s, ch[j], perp3[i][j][1]);
+	    if (exists (nc1) && !is_leaf (s, nc1))
+	      return 1;
+	  }
 	  if (!is_leaf (s, ch[j]))
 	    return 1;
 	}
@@ -351,7 +417,21 @@ static int refine_corner (const GtSim * s, Cell cell)
 static void refine_cell_corner (GtSim * s, Cell c, void * data) /* simulation.c:1105-1109 */
 {
   if (is_leaf (s, c) && refine_corner (s, c))
-    refine_single (s, c.l, cell_i (s, c), cell_j (s, c));
+    refine_single (s, c.l, cell_i (s, c), cell_j (s, c), cell_k (s, c));
+}
+
+typedef struct { int bad; } MatchPar;
+static void match_ghost (GtSim * s, int l, int side, int G, int image, void * data)
+{
+  MatchPar * m = data;
+  /* the cell along the side itself: the image seen from the opposite side */
+  int n = s->n[l], r = s->r[l], a = side/2;
+  int stride = a == 0 ? 1 : a == 1 ? r : r*r;
+  int own = (side & 1) ? G + stride : G - stride;
+  if (s->flag[l][own] != s->flag[l][image])
+    m->bad = 1;
+  s->flag[l][G] = s->flag[l][image];
+  (void) n;
 }
 
 static void build_tree (GtSim * s, GtRefineFunc refine, void * ctx)
@@ -359,12 +439,12 @@ static void build_tree (GtSim * s, GtRefineFunc refine, void * ctx)
   for (int l = 0; l <= GT_MAXL; l++) {
     s->n[l] = 1 << l;
     s->r[l] = s->n[l] + 2;
-    s->size[l] = (size_t) s->r[l]*s->r[l];
+    s->size[l] = (size_t) s->r[l]*s->r[l]*(s->dim == 3 ? s->r[l] : 1);
   }
   s->flag[0] = calloc (s->size[0], 1);
   s->depth = GT_MAXL; /* while the tree grows: every level refine_single allocates is valid */
-  s->flag[0][1 + s->r[0]] = GT_LEAF;
-  refine_rec (s, 0, 1, 1, refine, ctx);
+  s->flag[0][1 + s->r[0]*(1 + (s->dim == 3 ? s->r[0] : 0))] = GT_LEAF;
+  refine_rec (s, 0, 1, 1, 1, refine, ctx);
   /* gfs_domain_depth */
   int depth = 0;
   for (int l = 0; l <= GT_MAXL && s->flag[l]; l++)
@@ -374,18 +454,12 @@ static void build_tree (GtSim * s, GtRefineFunc refine, void * ctx)
     cell_traverse (s, 0, T_LEVEL, l, refine_cell_corner, NULL);
   s->depth = depth;
   /* gfs_domain_match: the ghost trees of the periodic sides mirror the cells they face; the
-     refined patches of the cases restated here stay away from the sides */
-  for (int l = 0; l <= depth; l++) {
-    int n = s->n[l], r = s->r[l];
-    for (int t = 1; t <= n; t++) {
-      s->flag[l][0 + r*t] = s->flag[l][n + r*t];
-      s->flag[l][n + 1 + r*t] = s->flag[l][1 + r*t];
-      s->flag[l][t + r*0] = s->flag[l][t + r*n];
-      s->flag[l][t + r*(n + 1)] = s->flag[l][t + r*1];
-    }
-    for (int t = 1; t <= n; t++) /* both sides of a periodic pair at the same refinement */
-      assert (s->flag[l][n + r*t] == s->flag[l][1 + r*t] && s->flag[l][t + r*n] == s->flag[l][t + r*1]);
-  }
+     refined patches of the cases restated here stay away from the sides (both cells of a periodic
+     pair at the same refinement) */
+  MatchPar m = { 0 };
+  for (int l = 0; l <= depth; l++)
+    ghost_traverse (s, l, match_ghost, &m);
+  assert (!m.bad);
 }
 
 /* ---- fluid.c: neighbour values and gradients ---------------------------------------------- */
@@ -396,10 +470,10 @@ static double average_neighbor_value (const GtSim * s, const Face * face, const 
   assert (face->neighbor.l == face->cell.l);
   if (is_leaf (s, face->neighbor))
     return *val (v, face->neighbor);
-  Cell ch[2];
+  Cell ch[4];
   double av = 0., a = 0.;
-  children_direction (s, face->neighbor, OPP (face->d), ch);
-  for (int i = 0; i < 2; i++)
+  int n = children_direction (s, face->neighbor, OPP (face->d), ch);
+  for (int i = 0; i < n; i++)
     if (exists (ch[i])) {
       double w = 1.;
       a += w;
@@ -427,14 +501,51 @@ static GfsGradient interpolate_1D1 (const GtSim * s, Cell cell, int d, double x,
   return p;
 }
 
+/* interpolate_2D1, fluid.c:214-245 (3-D) */
+static GfsGradient interpolate_2D1 (const GtSim * s, Cell cell, int d1, int d2, double x, double y,
+				    const Var * v)
+{
+  GfsGradient p = { 1., 0. };
+  Face f1 = { cell, neighbor (s, cell, d1), d1 };
+  if (exists (f1.neighbor)) {
+    double y1 = 1.;
+    double p1 = average_neighbor_value (s, &f1, v, &y1);
+    double a1 = y/y1;
+    p.b += a1*p1;
+    p.a -= a1;
+  }
+  Face f2 = { cell, neighbor (s, cell, d2), d2 };
+  if (exists (f2.neighbor)) {
+    double x2 = 1.;
+    double p2 = average_neighbor_value (s, &f2, v, &x2);
+    double a2 = x/x2;
+    p.b += a2*p2;
+    p.a -= a2;
+  }
+  return p;
+}
+
+/* the interpolation in the coarse neighbour of a fine-coarse face towards the fine cell:
+   interpolate_1D1 (FTT_2D) or interpolate_2D1, as gradient_fine_coarse and gfs_neighbor_value call it */
+static GfsGradient interpolate_coarse (const GtSim * s, const Face * face, const Var * v)
+{
+  int id = cell_id (s, face->cell);
+  if (s->dim == 2) {
+    int dp = perpendicular2[face->d][id];
+    assert (dp >= 0);
+    return interpolate_1D1 (s, face->neighbor, dp, 1./4., v);
+  }
+  const int * dp = perpendicular3[face->d][id];
+  assert (dp[0] >= 0 && dp[1] >= 0);
+  return interpolate_2D1 (s, face->neighbor, dp[0], dp[1], 1./4., 1./4., v);
+}
+
 /* gradient_fine_coarse, fluid.c:283-309 */
 static Gradient gradient_fine_coarse (const GtSim * s, const Face * face, const Var * v)
 {
   Gradient g;
   assert (fine_coarse (face));
-  int dp = perpendicular[face->d][cell_id (s, face->cell)];
-  assert (dp >= 0);
-  GfsGradient p = interpolate_1D1 (s, face->neighbor, dp, 1./4., v);
+  GfsGradient p = interpolate_coarse (s, face, v);
   g.a = 2./3.;
   g.b = 2.*p.a/3.;
   g.c = 2.*p.b/3.;
@@ -446,9 +557,7 @@ static double neighbor_value (const GtSim * s, const Face * face, const Var * v,
 {
   if (face->neighbor.l == face->cell.l)
     return average_neighbor_value (s, face, v, x);
-  int dp = perpendicular[face->d][cell_id (s, face->cell)];
-  assert (dp >= 0);
-  GfsGradient vc = interpolate_1D1 (s, face->neighbor, dp, 1./4., v);
+  GfsGradient vc = interpolate_coarse (s, face, v);
   *x = 3./2.;
   return vc.a*(*val (v, face->neighbor)) + vc.b;
 }
@@ -496,12 +605,11 @@ static void face_gradient (const GtSim * s, const Face * face, GfsGradient * g, 
     g->b = *val (v, face->neighbor);
   }
   else {
-    Cell ch[2];
+    Cell ch[4];
     Face f;
     f.d = OPP (face->d);
-    children_direction (s, face->neighbor, f.d, ch);
+    int n = children_direction (s, face->neighbor, f.d, ch);
     f.neighbor = face->cell;
-    int n = 2;
     for (int i = 0; i < n; i++)
       if (exists (f.cell = ch[i])) {
 	Gradient gcf = gradient_fine_coarse (s, &f, v);
@@ -515,7 +623,7 @@ static void face_gradient (const GtSim * s, const Face * face, GfsGradient * g, 
   }
 }
 
-/* face_weighted_gradient, fluid.c:833-893 with dimension = 2 (gfs_face_weighted_gradient_2D) */
+/* face_weighted_gradient, fluid.c:833-893 (dimension = FTT_DIMENSION) */
 static void face_weighted_gradient (const GtSim * s, const Face * face, GfsGradient * g,
 				    const Var * v, int max_level)
 {
@@ -535,18 +643,22 @@ static void face_weighted_gradient (const GtSim * s, const Face * face, GfsGradi
     g->b = w*(*val (v, face->neighbor));
   }
   else {
-    Cell ch[2];
+    Cell ch[4];
     Face f;
     f.d = OPP (face->d);
-    children_direction (s, face->neighbor, f.d, ch);
+    int n = children_direction (s, face->neighbor, f.d, ch);
     f.neighbor = face->cell;
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < n; i++)
       if (exists (f.cell = ch[i])) {
 	double w = *val (&s->w[f.d], f.cell);
 	Gradient gcf = gradient_fine_coarse (s, &f, v);
 	g->a += w*gcf.b;
 	g->b += w*(gcf.a*(*val (v, f.cell)) - gcf.c);
       }
+    if (s->dim > 2) {
+      g->a /= n/2.;
+      g->b /= n/2.;
+    }
   }
 }
 
@@ -566,7 +678,7 @@ static double face_interpolated_value (const GtSim * s, const Face * face, const
 
 static void reset_coeff (GtSim * s, Cell c, void * data) /* poisson.c:756-766 */
 {
-  for (int d = 0; d < 4; d++)
+  for (int d = 0; d < s->nd; d++)
     *val (&s->w[d], c) = 0.;
 }
 
@@ -578,30 +690,30 @@ static void poisson_coeff (GtSim * s, const Face * face, void * data) /* poisson
   if (!fine_coarse (face))
     *val (&s->w[OPP (face->d)], face->neighbor) += v;
   else
-    *val (&s->w[OPP (face->d)], face->neighbor) += v/2.; /* FTT_CELLS_DIRECTION */
+    *val (&s->w[OPP (face->d)], face->neighbor) += v/(s->nc/2); /* FTT_CELLS_DIRECTION */
 }
 
 static void face_coeff_from_below (GtSim * s, Cell cell, void * data) /* poisson.c:826-853 */
 {
   unsigned neighbors = 0;
-  for (int d = 0; d < 4; d++) {
-    Cell ch[2];
+  for (int d = 0; d < s->nd; d++) {
+    Cell ch[4];
     double * f = val (&s->w[d], cell);
     *f = 0.;
-    children_direction (s, cell, d, ch);
-    for (int i = 0; i < 2; i++)
+    int n = children_direction (s, cell, d, ch);
+    for (int i = 0; i < n; i++)
       if (exists (ch[i]))
 	*f += *val (&s->w[d], ch[i]);
-    *f /= 2;
+    *f /= n;
     Cell nb = neighbor (s, cell, d);
     if (*f != 0. && exists (nb)) {
-      int i = cell_i (s, nb), j = cell_j (s, nb), n = s->n[nb.l];
-      if (i >= 1 && i <= n && j >= 1 && j <= n) /* !GFS_CELL_IS_BOUNDARY */
+      int i = cell_i (s, nb), j = cell_j (s, nb), k = cell_k (s, nb), nn = s->n[nb.l];
+      if (i >= 1 && i <= nn && j >= 1 && j <= nn && k >= 1 && k <= nn) /* !GFS_CELL_IS_BOUNDARY */
 	neighbors++;
     }
   }
   if (neighbors == 1)
-    for (int d = 0; d < 4; d++)
+    for (int d = 0; d < s->nd; d++)
       *val (&s->w[d], cell) = 0.;
 }
 
@@ -609,7 +721,7 @@ static void face_coeff_from_below (GtSim * s, Cell cell, void * data) /* poisson
    the cells they mirror (their weights are written by the faces of the sides, never read). */
 static void poisson_coefficients (GtSim * s)
 {
-  for (int d = 0; d < 4; d++)
+  for (int d = 0; d < s->nd; d++)
     for (int l = 0; l <= s->depth; l++)
       memset (s->w[d].lev[l], 0, s->size[l]*sizeof (double));
   cell_traverse (s, 0, T_ALL, -1, reset_coeff, NULL);
@@ -627,7 +739,7 @@ static void relax2D (GtSim * s, Cell cell, void * data) /* poisson.c:532-557 */
   g.b = 0.;
   Face f;
   f.cell = cell;
-  for (f.d = 0; f.d < 4; f.d++) {
+  for (f.d = 0; f.d < s->nd; f.d++) {
     f.neighbor = neighbor (s, cell, f.d);
     if (exists (f.neighbor)) {
       face_weighted_gradient (s, &f, &ng, p->u, p->maxlevel);
@@ -635,9 +747,13 @@ static void relax2D (GtSim * s, Cell cell, void * data) /* poisson.c:532-557 */
       g.b += ng.b;
     }
   }
-  if (g.a != 0.)
-    *val (p->u, cell) = (1. - p->omega)*(*val (p->u, cell))
-      + p->omega*(g.b - *val (p->rhs, cell))/g.a;
+  if (g.a != 0.) {
+    if (s->dim == 2)        /* relax2D, poisson.c:532-557 */
+      *val (p->u, cell) = (1. - p->omega)*(*val (p->u, cell))
+	+ p->omega*(g.b - *val (p->rhs, cell))/g.a;
+    else                    /* relax, poisson.c:507-530 */
+      *val (p->u, cell) = (g.b - *val (p->rhs, cell))/g.a;
+  }
   else
     *val (p->u, cell) = 0.;
 }
@@ -650,7 +766,7 @@ static void residual_set2D (GtSim * s, Cell cell, void * data) /* poisson.c:657-
   g.b = 0.;
   Face f;
   f.cell = cell;
-  for (f.d = 0; f.d < 4; f.d++) {
+  for (f.d = 0; f.d < s->nd; f.d++) {
     f.neighbor = neighbor (s, cell, f.d);
     if (exists (f.neighbor)) {
       face_weighted_gradient (s, &f, &ng, p->u, p->maxlevel);
@@ -717,20 +833,20 @@ static void get_from_below_2D (GtSim * s, Cell cell, void * data) /* poisson.c:1
 {
   Var * v = data;
   double sum = 0.;
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < s->nc; k++) {
     Cell ch = child (s, cell, k);
     if (exists (ch))
       sum += *val (v, ch);
   }
-  *val (v, cell) = sum;
+  *val (v, cell) = s->dim == 2 ? sum : sum/2.;   /* get_from_below_2D / _3D, poisson.c:1044-1068 */
 }
 
 static void get_from_above (GtSim * s, Cell parent, void * data) /* poisson.c:1005-1042 */
 {
   Var * v = data;
   int level = parent.l;
-  double h[2];
-  for (int c = 0; c < 2; c++) {
+  double h[3];
+  for (int c = 0; c < s->dim; c++) {
     Face f;
     GfsGradient g;
     f.cell = parent;
@@ -744,14 +860,16 @@ static void get_from_above (GtSim * s, Cell parent, void * data) /* poisson.c:10
     double g2 = g.b - g.a*(*val (v, parent));
     h[c] = (g1 - g2)/2.;
   }
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < s->nc; k++) {
     Cell ch = child (s, parent, k);
     if (exists (ch)) {
       /* ftt_cell_relative_pos, ftt.c:327-340 */
-      double px = (k & 1) ? 0.25 : -0.25, py = (k & 2) ? -0.25 : 0.25;
+      double px = (k & 1) ? 0.25 : -0.25, py = (k & 2) ? -0.25 : 0.25, pz = (k & 4) ? -0.25 : 0.25;
       *val (v, ch) = *val (v, parent);
       *val (v, ch) += px*h[0];
       *val (v, ch) += py*h[1];
+      if (s->dim == 3)
+	*val (v, ch) += pz*h[2];
     }
   }
 }
@@ -839,7 +957,7 @@ static void face_interpolated_un (GtSim * s, const Face * f, void * data) /* adv
   if (!fine_coarse (f))
     *val (&s->un[OPP (f->d)], f->neighbor) = u;
   else
-    *val (&s->un[OPP (f->d)], f->neighbor) += u*1./(1.*2 /* FTT_CELLS_DIRECTION */);
+    *val (&s->un[OPP (f->d)], f->neighbor) += u*1./(1.*(s->nc/2) /* FTT_CELLS_DIRECTION */);
 }
 
 typedef struct { Var * p, * gv; double dt; } CorrectPar;
@@ -859,7 +977,7 @@ static void correct_normal_velocity (GtSim * s, const Face * face, void * data) 
   if (par->gv)
     *val (&par->gv[face->d/2], face->cell) += dp*1.;
   if (fine_coarse (face))
-    dp *= 1./(1.*4/2);
+    dp *= 1./(1.*s->nc/2);
   *val (&s->un[OPP (face->d)], face->neighbor) -= dp*par->dt;
   if (par->gv)
     *val (&par->gv[face->d/2], face->neighbor) += dp*1.;
@@ -868,21 +986,25 @@ static void correct_normal_velocity (GtSim * s, const Face * face, void * data) 
 static void correct_normal_velocities (GtSim * s, Var * p, Var * g, double dt) /* timestep.c:163-179 */
 {
   CorrectPar par = { p, g, dt };
-  face_traverse (s, 0, correct_normal_velocity, &par);  /* FTT_XY */
-  face_traverse (s, 1, correct_normal_velocity, &par);
+  if (s->dim == 2) {
+    face_traverse (s, 0, correct_normal_velocity, &par);  /* FTT_XY */
+    face_traverse (s, 1, correct_normal_velocity, &par);
+  }
+  else
+    face_traverse (s, -1, correct_normal_velocity, &par); /* FTT_XYZ */
 }
 
 static void reset_cell_gradients (GtSim * s, Cell c, void * data) /* timestep.c:36-41 */
 {
   Var * g = data;
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < s->dim; k++)
     *val (&g[k], c) = 0.;
 }
 
 static void scale_cell_gradients (GtSim * s, Cell cell, void * data) /* timestep.c:60-90 */
 {
   Var * g = data;
-  for (int c = 0; c < 2; c++) {
+  for (int c = 0; c < s->dim; c++) {
     Cell c1 = neighbor (s, cell, 2*c), c2 = neighbor (s, cell, 2*c + 1);
     if (exists (c1) && exists (c2))
       *val (&g[c], cell) /= 2.;
@@ -893,7 +1015,7 @@ static void normal_divergence (GtSim * s, Cell cell, void * data) /* fluid.c:231
 {
   Var * v = data;
   double div = 0.;
-  for (int d = 0; d < 4; d++)
+  for (int d = 0; d < s->nd; d++)
     div += ((d & 1) ? -1. : 1.)*(*val (&s->un[d], cell))*1.;
   *val (v, cell) = div*cell_size (cell);
 }
@@ -924,7 +1046,7 @@ static void mac_projection (GtSim * s, GoMultilevelParams * par, double dt, Var 
   correct_normal_velocities (s, p, g, dt);
   /* gfs_scale_gradients, timestep.c:92-107 */
   cell_traverse (s, 0, T_LEAFS, -1, scale_cell_gradients, g);
-  for (int c = 0; c < 2; c++)
+  for (int c = 0; c < s->dim; c++)
     bc (s, &g[c], T_LEAFS, -1);
 }
 
@@ -932,7 +1054,7 @@ typedef struct { Var * g; double dt; } CorrectCentered;
 static void correct_centered (GtSim * s, Cell cell, void * data) /* timestep.c:486-496 */
 {
   CorrectCentered * p = data;
-  for (int c = 0; c < 2; c++)
+  for (int c = 0; c < s->dim; c++)
     *val (&s->u[c], cell) -= *val (&p->g[c], cell)*p->dt;
 }
 
@@ -940,7 +1062,7 @@ static void correct_centered_velocities (GtSim * s, Var * g, double dt) /* times
 {
   CorrectCentered p = { g, dt };
   cell_traverse (s, 0, T_LEAFS, -1, correct_centered, &p);
-  for (int c = 0; c < 2; c++)
+  for (int c = 0; c < s->dim; c++)
     bc (s, &s->u[c], T_LEAFS, -1);
 }
 
@@ -975,8 +1097,8 @@ static double transverse_term (GtSim * s, const AdvPar * par, Cell cell, const d
 static void cell_advected_face_values (GtSim * s, Cell cell, void * data) /* advection.c:58-99 */
 {
   const AdvPar * par = data;
-  double size = cell_size (cell), msize[2] = { size, size };
-  for (int c = 0; c < 2; c++) {
+  double size = cell_size (cell), msize[3] = { size, size, size };
+  for (int c = 0; c < s->dim; c++) {
     double unorm = par->use_centered_velocity ?
       par->dt*(*val (&s->u[c], cell))/msize[c] :
       par->dt*(*val (&s->un[2*c], cell) + *val (&s->un[2*c + 1], cell))/(2.*msize[c]);
@@ -984,7 +1106,14 @@ static void cell_advected_face_values (GtSim * s, Cell cell, void * data) /* adv
     double vl = *val (par->v, cell) + MIN ((1. - unorm)/2., 0.5)*g;
     double vr = *val (par->v, cell) + MAX ((- 1. - unorm)/2., -0.5)*g;
     double src = par->dt*0./2.;
-    double dv = transverse_term (s, par, cell, msize, (c + 1) % 2);
+    double dv;
+    if (s->dim == 2)
+      dv = transverse_term (s, par, cell, msize, (c + 1) % 2);
+    else {
+      static const int orthogonal[3][2] = { {1, 2}, {0, 2}, {0, 1} };
+      dv =  transverse_term (s, par, cell, msize, orthogonal[c][0]);
+      dv += transverse_term (s, par, cell, msize, orthogonal[c][1]);
+    }
     *val (&s->fv[2*c], cell)     = vl + src - dv;
     *val (&s->fv[2*c + 1], cell) = vr + src - dv;
   }
@@ -992,24 +1121,28 @@ static void cell_advected_face_values (GtSim * s, Cell cell, void * data) /* adv
 
 /* gfs_domain_face_bc (domain.c:1209-1232) on periodic sides (boundary.c:1251-1258,1343-1347): the
    leaf ghost cell beyond side sd holds the face value f[OPP (sd)].v of its periodic image */
+static void face_bc_ghost (GtSim * s, int l, int side, int G, int image, void * data)
+{
+  if (s->flag[l][G] == GT_LEAF)
+    s->fv[OPP (side)].lev[l][G] = s->fv[OPP (side)].lev[l][image];
+}
+
 static void face_bc (GtSim * s)
 {
-  for (int l = 0; l <= s->depth; l++) {
-    int n = s->n[l], r = s->r[l];
-    for (int sd = 0; sd < 4; sd++)
-      for (int t = 1; t <= n; t++) {
-	int gi = sd == 0 ? n + 1 : sd == 1 ? 0 : t, gj = sd == 2 ? n + 1 : sd == 3 ? 0 : t;
-	int ii = sd == 0 ? 1 : sd == 1 ? n : t, ij = sd == 2 ? 1 : sd == 3 ? n : t;
-	if (s->flag[l][gi + r*gj] == GT_LEAF)
-	  s->fv[OPP (sd)].lev[l][gi + r*gj] = s->fv[OPP (sd)].lev[l][ii + r*ij];
-      }
-  }
+  for (int l = 0; l <= s->depth; l++)
+    ghost_traverse (s, l, face_bc_ghost, NULL);
 }
 
 static void face_values_set (GtSim * s, AdvPar * par) /* timestep.c:644-654 */
 {
   cell_traverse (s, 0, T_LEAFS, -1, cell_advected_face_values, par);
   face_bc (s);
+}
+
+static int is_interior (const GtSim * s, Cell c)   /* !GFS_CELL_IS_BOUNDARY */
+{
+  int i = cell_i (s, c), j = cell_j (s, c), k = cell_k (s, c), n = s->n[c.l];
+  return i >= 1 && i <= n && j >= 1 && j <= n && k >= 1 && k <= n;
 }
 
 /* interpolate_1D1 of advection.c:132-180.  The fork's text declares s2 twice (the second, inner
@@ -1019,12 +1152,7 @@ static double adv_interpolate_1D1 (const GtSim * s, Cell cell, int dright, int d
 {
   int dleft = OPP (dright);
   Cell n = neighbor (s, cell, dup);
-  int boundary = 1;
-  if (exists (n)) {
-    int i = cell_i (s, n), j = cell_j (s, n), nn = s->n[n.l];
-    boundary = !(i >= 1 && i <= nn && j >= 1 && j <= nn);
-  }
-  if (exists (n) && !boundary) {
+  if (exists (n) && is_interior (s, n)) {
     double s2 = is_leaf (s, n) ? 1. : 0.5;
     double s1 = 1.;
     double v1 = *val (&s->fv[dleft], cell), v2;
@@ -1032,7 +1160,7 @@ static double adv_interpolate_1D1 (const GtSim * s, Cell cell, int dright, int d
     if (is_leaf (s, n))
       v2 = *val (&s->fv[dleft], n);
     else {
-      n = child_corner (s, n, dleft, OPP (dup));
+      n = child_corner (s, n, dleft, OPP (dup), -1);
       if (exists (n))
 	v2 = *val (&s->fv[dleft], n);
       else
@@ -1041,6 +1169,54 @@ static double adv_interpolate_1D1 (const GtSim * s, Cell cell, int dright, int d
     return s2 > 0. ? (v2*(s1 - 1. + 2.*x) + v1*(s2 + 1. - 2.*x))/(s1 + s2) : v1;
   }
   return *val (&s->fv[dleft], cell);
+}
+
+/* interpolate_2D1 of advection.c:183-249 (3-D) */
+static double adv_interpolate_2D1 (const GtSim * s, Cell cell, int dright, int d1, int d2,
+				   double x, double y)
+{
+  double x1 = 0., y1 = 1.;
+  double x2 = 1., y2 = 0.;
+  double v0, v1, v2;
+  int dleft = OPP (dright);
+  v0 = *val (&s->fv[dleft], cell);
+  Cell n1 = neighbor (s, cell, d1);
+  if (exists (n1) && is_interior (s, n1)) {
+    assert (n1.l == cell.l);
+    if (!is_leaf (s, n1)) {
+      n1 = child_corner (s, n1, OPP (dright), OPP (d1), d2);
+      if (exists (n1)) {
+	v1 = *val (&s->fv[dleft], n1);
+	x1 = 1./4.;
+	y1 = 3./4.;
+      }
+      else
+	v1 = v0;
+    }
+    else
+      v1 = *val (&s->fv[dleft], n1);
+  }
+  else
+    v1 = v0;
+  Cell n2 = neighbor (s, cell, d2);
+  if (exists (n2) && is_interior (s, n2)) {
+    assert (n2.l == cell.l);
+    if (!is_leaf (s, n2)) {
+      n2 = child_corner (s, n2, OPP (dright), OPP (d2), d1);
+      if (exists (n2)) {
+	v2 = *val (&s->fv[dleft], n2);
+	x2 = 3./4.;
+	y2 = 1./4.;
+      }
+      else
+	v2 = v0;
+    }
+    else
+      v2 = *val (&s->fv[dleft], n2);
+  }
+  else
+    v2 = v0;
+  return ((v1 - v0)*(x*y2 - x2*y) + (v2 - v0)*(x1*y - x*y1))/(x1*y2 - x2*y1) + v0;
 }
 
 /* gfs_face_upwinded_value, advection.c:267-343 */
@@ -1060,9 +1236,17 @@ static double face_upwinded_value (GtSim * s, const Face * face, int centered_up
   }
   if (un > 0.)
     return fc;
-  int dp = perpendicular[face->d][cell_id (s, face->cell)];
-  assert (dp >= 0);
-  double vcoarse = adv_interpolate_1D1 (s, face->neighbor, face->d, dp, 1./4.);
+  double vcoarse;
+  if (s->dim == 2) {
+    int dp = perpendicular2[face->d][cell_id (s, face->cell)];
+    assert (dp >= 0);
+    vcoarse = adv_interpolate_1D1 (s, face->neighbor, face->d, dp, 1./4.);
+  }
+  else {
+    const int * dp = perpendicular3[face->d][cell_id (s, face->cell)];
+    assert (dp[0] >= 0 && dp[1] >= 0);
+    vcoarse = adv_interpolate_2D1 (s, face->neighbor, face->d, dp[0], dp[1], 1./4., 1./4.);
+  }
   if (un == 0.)
     return (fc + vcoarse)/2.;
   return vcoarse;
@@ -1075,14 +1259,14 @@ static void face_advected_normal_velocity (GtSim * s, const Face * face, void * 
   if (!fine_coarse (face))
     *val (&s->un[OPP (face->d)], face->neighbor) = u;
   else
-    *val (&s->un[OPP (face->d)], face->neighbor) += u*1./(1.*2);
+    *val (&s->un[OPP (face->d)], face->neighbor) += u*1./(1.*(s->nc/2));
 }
 
 static void predicted_face_velocities (GtSim * s) /* timestep.c:681-717 */
 {
   face_traverse (s, -1, face_reset_un, NULL);
   AdvPar par = { s->dt, NULL, 1 };
-  for (int c = 0; c < 2; c++) {
+  for (int c = 0; c < s->dim; c++) {
     par.v = &s->u[c];
     face_values_set (s, &par);
     face_traverse (s, c, face_advected_normal_velocity, NULL);
@@ -1109,7 +1293,7 @@ static void face_velocity_advection_flux (GtSim * s, const Face * face, void * d
   if (!fine_coarse (face))
     *val (par->fvar, face->neighbor) += flux;
   else
-    *val (par->fvar, face->neighbor) += flux/4 /* FTT_CELLS */;
+    *val (par->fvar, face->neighbor) += flux/s->nc /* FTT_CELLS */;
 }
 
 typedef struct { Var * sv, * fvar, * g; double dt; } UpdatePar;
@@ -1143,9 +1327,9 @@ static void variable_sources (GtSim * s, int c, double dt, Var * gmac, Var * g)
 
 static void centered_velocity_advection (GtSim * s, Var * gmac, Var * g) /* timestep.c:976-1016 */
 {
-  for (int c = 0; c < 2; c++)
+  for (int c = 0; c < s->dim; c++)
     variable_sources (s, c, s->dt, gmac, g);
-  for (int c = 0; c < 2; c++)
+  for (int c = 0; c < s->dim; c++)
     bc (s, &s->u[c], T_LEAFS, -1);
 }
 
@@ -1167,7 +1351,7 @@ static void minimum_cfl (GtSim * s, Cell cell, void * data) /* domain.c:2858-289
 {
   double * cfl = data;
   double length = cell_size (cell);
-  for (int c = 0; c < 2; c++) {
+  for (int c = 0; c < s->dim; c++) {
     double fm = 1.;
     if (*val (&s->u[c], cell) != 0.) {
       double cflu = length/fabs (fm*(*val (&s->u[c], cell)));
@@ -1210,7 +1394,7 @@ static void get_from_below_intensive (GtSim * s, Cell cell, void * data) /* flui
 {
   Var * v = data;
   double sum = 0., sa = 0.;
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < s->nc; k++) {
     Cell ch = child (s, cell, k);
     if (exists (ch)) {
       double a = 1.;
@@ -1223,8 +1407,8 @@ static void get_from_below_intensive (GtSim * s, Cell cell, void * data) /* flui
 
 static void coarse_init (GtSim * s) /* adaptive.c:43-58 on every variable */
 {
-  Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1] };
-  for (unsigned k = 0; k < sizeof (all)/sizeof (all[0]); k++)
+  Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1], &s->u[2] };
+  for (int k = 0; k < 2 + s->dim; k++)
     cell_traverse (s, 1, T_NON_LEAFS, -1, get_from_below_intensive, all[k]);
 }
 
@@ -1247,20 +1431,25 @@ static void init_uv (GtSim * s, Cell c, void * data) /* periodic.gfs:26-29 */
 
 /* a GfsSimulation on one periodic box refined by `refine' (default parameters of
    gfs_multilevel_params_init / gfs_advection_params_init; U, V, P zero) */
-GtSim * gt_new (GtRefineFunc refine, void * ctx)
+GtSim * gt_new (int dim, GtRefineFunc refine, void * ctx)
 {
   GtSim * s = calloc (1, sizeof (GtSim));
+  assert (dim == 2 || dim == 3);
+  s->dim = dim;
+  s->nd = 2*dim;
+  s->nc = 1 << dim;
   build_tree (s, refine, ctx);
-  Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1], &s->g[0], &s->g[1], &s->gmac[0], &s->gmac[1] };
+  Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1], &s->u[2], &s->g[0], &s->g[1], &s->g[2],
+		  &s->gmac[0], &s->gmac[1], &s->gmac[2] };
   for (unsigned k = 0; k < sizeof (all)/sizeof (all[0]); k++)
     var_alloc (s, all[k]);
-  for (int d = 0; d < 4; d++) {
+  for (int d = 0; d < 6; d++) {
     var_alloc (s, &s->un[d]);
     var_alloc (s, &s->fv[d]);
     var_alloc (s, &s->w[d]);
   }
-  go_multilevel_params_init (&s->projection_params, 2);
-  go_multilevel_params_init (&s->approx_projection_params, 2);
+  go_multilevel_params_init (&s->projection_params, dim);
+  go_multilevel_params_init (&s->approx_projection_params, dim);
   s->cfl = 0.8;
   s->end = DBL_MAX;
   return s;
@@ -1274,7 +1463,7 @@ void gt_set_time (GtSim * s, double end, double cfl)
 
 /* the Refine function of test/periodic/periodic.gfs:25 */
 typedef struct { int level, box; } PeriodicRefine;
-static double periodic_refine (double x, double y, void * ctx)
+static double periodic_refine (double x, double y, double z, void * ctx)
 {
   PeriodicRefine * p = ctx;
   return (x < -0.25 || x > 0.25 || y < -0.25 || y > 0.25 ? p->level : p->level + p->box);
@@ -1284,7 +1473,7 @@ static double periodic_refine (double x, double y, void * ctx)
 GtSim * gt_periodic_new (int level, int box)
 {
   PeriodicRefine pr = { level, box };
-  GtSim * s = gt_new (periodic_refine, &pr);
+  GtSim * s = gt_new (2, periodic_refine, &pr);
   s->projection_params.tolerance = 1e-6;        /* periodic.gfs:30-31 */
   s->approx_projection_params.tolerance = 1e-6;
   s->cfl = 0.75;                                /* periodic.gfs:24 */
@@ -1295,10 +1484,11 @@ GtSim * gt_periodic_new (int level, int box)
 
 void gt_destroy (GtSim * s)
 {
-  Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1], &s->g[0], &s->g[1], &s->gmac[0], &s->gmac[1] };
+  Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1], &s->u[2], &s->g[0], &s->g[1], &s->g[2],
+		  &s->gmac[0], &s->gmac[1], &s->gmac[2] };
   for (unsigned k = 0; k < sizeof (all)/sizeof (all[0]); k++)
     var_free (s, all[k]);
-  for (int d = 0; d < 4; d++) {
+  for (int d = 0; d < 6; d++) {
     var_free (s, &s->un[d]);
     var_free (s, &s->fv[d]);
     var_free (s, &s->w[d]);
@@ -1311,8 +1501,8 @@ void gt_destroy (GtSim * s)
 /* simulation_run up to the loop, simulation.c:458-476 */
 void gt_start (GtSim * s)
 {
-  Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1] };
-  for (unsigned k = 0; k < sizeof (all)/sizeof (all[0]); k++)
+  Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1], &s->u[2] };
+  for (int k = 0; k < 2 + s->dim; k++)
     bc (s, all[k], T_LEAFS, -1);
   coarse_init (s);
   set_timestep (s);
@@ -1342,24 +1532,29 @@ double gt_dt (const GtSim * s) { return s->dt; }
 GoMultilevelParams * gt_projection_params (GtSim * s, int approx)
 { return approx ? &s->approx_projection_params : &s->projection_params; }
 
+int gt_dim (const GtSim * s) { return s->dim; }
+
 /* number of leaves per level (tree checks) */
 void gt_leaf_count (const GtSim * s, long * count)
 {
   for (int l = 0; l <= s->depth; l++) {
     count[l] = 0;
-    for (int j = 1; j <= s->n[l]; j++)
-      for (int i = 1; i <= s->n[l]; i++)
-	if (s->flag[l][i + s->r[l]*j] == GT_LEAF)
-	  count[l]++;
+    for (int k = 1; k <= (s->dim == 3 ? s->n[l] : 1); k++)
+      for (int j = 1; j <= s->n[l]; j++)
+	for (int i = 1; i <= s->n[l]; i++)
+	  if (s->flag[l][i + s->r[l]*(j + (s->dim == 3 ? s->r[l]*k : 0))] == GT_LEAF)
+	    count[l]++;
   }
 }
 
-/* flags / values of a level for the tests: which = 0 U, 1 V, 2 P, 3 Pmac, 4-5 g, 6-7 gmac, 8-11 un */
+/* flags / values of a level for the tests: which = 0 U, 1 V, 2 P, 3 Pmac, 4-5 g, 6-7 gmac, 8-11 un[0..3],
+   12 W, 13 g[2], 14 gmac[2], 15-16 un[4..5] */
 const unsigned char * gt_flags (const GtSim * s, int l) { return s->flag[l]; }
 double * gt_values (GtSim * s, int which, int l)
 {
   Var * v[] = { &s->u[0], &s->u[1], &s->p, &s->pmac, &s->g[0], &s->g[1], &s->gmac[0], &s->gmac[1],
-	       &s->un[0], &s->un[1], &s->un[2], &s->un[3] };
+		&s->un[0], &s->un[1], &s->un[2], &s->un[3], &s->u[2], &s->g[2], &s->gmac[2],
+		&s->un[4], &s->un[5] };
   return v[which]->lev[l];
 }
 
@@ -1372,7 +1567,7 @@ static void add_error (GtSim * s, Cell c, void * data)
   double x, y, h = cell_size (c);
   cell_pos (s, c, &x, &y);
   double ref = (1. - 2.*cos (2.*M_PI*(x - p->t))*sin (2.*M_PI*(y - p->t)));
-  norm_add (&p->n, *val (&s->u[0], c) - ref, h*h);
+  norm_add (&p->n, *val (&s->u[0], c) - ref, s->dim == 3 ? h*h*h : h*h);   /* gfs_cell_volume */
 }
 
 void gt_error_norm (GtSim * s, double * first, double * second, double * infty)

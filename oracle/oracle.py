@@ -505,14 +505,15 @@ class Particles:
             pass
 
 
-REFINE_FUNC = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_void_p)
+REFINE_FUNC = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p)
 
 
 def _tree_sigs(L):
     vp, i, d, u = C.c_void_p, C.c_int, C.c_double, C.c_uint
     pd = C.POINTER(C.c_double)
     sig = {
-        "gt_new": (vp, [REFINE_FUNC, vp]),
+        "gt_new": (vp, [i, REFINE_FUNC, vp]),
+        "gt_dim": (i, [vp]),
         "gt_periodic_new": (vp, [i, i]),
         "gt_destroy": (None, [vp]),
         "gt_set_time": (None, [vp, d, d]),
@@ -535,12 +536,12 @@ def _tree_sigs(L):
 
 
 class Tree2D:
-    """go_tree2d.c: a GfsSimulation on one periodic 2-D box with a statically refined tree
-    (coarse-fine stencils).  Levels are dense (n+2)^2 arrays [j, i] with a flag per cell:
-    0 absent, 1 leaf, 2 non-leaf."""
-    U, V, P, PMAC, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3 = range(12)
+    """go_tree2d.c: a GfsSimulation on one periodic 2-D / 3-D box with a statically refined tree
+    (coarse-fine stencils).  Levels are dense (n+2)^dim arrays [(k,) j, i] with a flag per cell:
+    0 absent, 1 leaf, 2 non-leaf.  refine (x, y) or refine (x, y, z) -> level wanted there."""
+    U, V, P, PMAC, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3, W, GZ, GMACZ, UN4, UN5 = range(17)
 
-    def __init__(self, refine=None, periodic=None):
+    def __init__(self, refine=None, periodic=None, dim=2):
         L = lib()
         if not hasattr(L, "_tree_ready"):
             _tree_sigs(L)
@@ -549,25 +550,32 @@ class Tree2D:
         if periodic is not None:
             self.ptr = L.gt_periodic_new(*periodic)
         else:
-            self._cb = REFINE_FUNC(lambda x, y, ctx: float(refine(x, y)))
-            self.ptr = L.gt_new(self._cb, None)
+            if dim == 2:
+                self._cb = REFINE_FUNC(lambda x, y, z, ctx: float(refine(x, y)))
+            else:
+                self._cb = REFINE_FUNC(lambda x, y, z, ctx: float(refine(x, y, z)))
+            self.ptr = L.gt_new(dim, self._cb, None)
+        self.dim = L.gt_dim(self.ptr)
         self.depth = L.gt_depth(self.ptr)
         self.projection_params = L.gt_projection_params(self.ptr, 0).contents
         self.approx_projection_params = L.gt_projection_params(self.ptr, 1).contents
 
     def flags(self, l):
         r = (1 << l) + 2
-        return np.ctypeslib.as_array(self.L.gt_flags(self.ptr, l), shape=(r, r))
+        return np.ctypeslib.as_array(self.L.gt_flags(self.ptr, l), shape=(r,) * self.dim)
 
     def values(self, which, l):
         r = (1 << l) + 2
-        return np.ctypeslib.as_array(self.L.gt_values(self.ptr, which, l), shape=(r, r))
+        return np.ctypeslib.as_array(self.L.gt_values(self.ptr, which, l), shape=(r,) * self.dim)
 
     def centres(self, l):
-        """x[j, i], y[j, i] of the cells of level l (ghosts included)"""
+        """x, y (, z) of the cells of level l (ghosts included), indexed [(k,) j, i]"""
         n = 1 << l
         c = -0.5 + (np.arange(n + 2) - 0.5) / n
-        return np.meshgrid(c, c, indexing="xy")
+        if self.dim == 2:
+            return np.meshgrid(c, c, indexing="xy")
+        z, y, x = np.meshgrid(c, c, c, indexing="ij")
+        return x, y, z
 
     def set_time(self, end, cfl):
         self.L.gt_set_time(self.ptr, end, cfl)

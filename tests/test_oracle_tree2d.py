@@ -61,3 +61,99 @@ def test_uniform_tree_equals_uniform_oracle():
     for which, f in ((O.Tree2D.U, b.u[0]), (O.Tree2D.V, b.u[1]), (O.Tree2D.P, b.p)):
         assert np.array_equal(a.values(which, level)[1:-1, 1:-1], f.interior())
     a.destroy()
+
+
+# ---- 3-D (octree): the FTT_3D branches of the same functions.  The reference holds no 3-D golden
+# file; the pins are the uniform 3-D oracle on a uniform octree, the 2-D results through flows that
+# do not depend on one coordinate (refined column), and the same column along another axis.
+
+def test_uniform_octree_equals_uniform_oracle():
+    from flow_cases import oracle_taylor_green, taylor_green_3d
+    level = 4
+    a = O.Tree2D(refine=lambda x, y, z: level, dim=3)
+    b = oracle_taylor_green(level)
+    x, y, z = a.centres(level)
+    for which, arr in zip((O.Tree2D.U, O.Tree2D.V, O.Tree2D.W), taylor_green_3d(x, y, z)):
+        a.values(which, level)[...] = arr
+    a.start()
+    b.start()
+    for _ in range(2):
+        a.step()
+        b.step()
+    assert a.t == b.t and a.dt == b.advection_params.dt
+    for which, f in ((O.Tree2D.U, b.u[0]), (O.Tree2D.V, b.u[1]), (O.Tree2D.W, b.u[2]), (O.Tree2D.P, b.p)):
+        assert np.array_equal(a.values(which, level)[1:-1, 1:-1, 1:-1], f.interior())
+    a.destroy()
+
+
+def _column(level, box, axis, tol=1e-6):
+    """the vortex of test/periodic in the plane normal to `axis', uniform along it, on an octree
+    refined inside the square column |.|, |.| < 1/4 along that axis"""
+    p, q = [c for c in range(3) if c != axis]           # the two coordinates of the plane
+    inside = lambda a, b: not (a < -0.25 or a > 0.25 or b < -0.25 or b > 0.25)
+    s = O.Tree2D(refine=lambda x, y, z: level + box if inside((x, y, z)[p], (x, y, z)[q]) else level, dim=3)
+    vel = (O.Tree2D.U, O.Tree2D.V, O.Tree2D.W)
+    for l in range(s.depth + 1):
+        xyz = s.centres(l)
+        s.values(vel[p], l)[...] = 1. - 2. * np.cos(2. * np.pi * xyz[p]) * np.sin(2. * np.pi * xyz[q])
+        s.values(vel[q], l)[...] = 1. + 2. * np.sin(2. * np.pi * xyz[p]) * np.cos(2. * np.pi * xyz[q])
+    s.projection_params.tolerance = s.approx_projection_params.tolerance = tol
+    s.set_time(0.5, 0.75)
+    return s, vel[p], vel[axis], p, q
+
+
+def _column_error(s, var, p, q):
+    """L2 / Linf error of the first in-plane component against the translated vortex (as add_error)"""
+    t = s.t
+    se = sw = mx = 0.
+    for l in range(s.depth + 1):
+        leaf = s.flags(l)[1:-1, 1:-1, 1:-1] == 1
+        if not leaf.any():
+            continue
+        xyz = s.centres(l)
+        exact = 1. - 2. * np.cos(2. * np.pi * (xyz[p] - t)) * np.sin(2. * np.pi * (xyz[q] - t))
+        e = (s.values(var, l) - exact)[1:-1, 1:-1, 1:-1][leaf]
+        w = 1. / (1 << l) ** 3
+        se += w * float(np.sum(e * e))
+        sw += w * e.size
+        mx = max(mx, float(np.abs(e).max()))
+    return np.sqrt(se / sw), mx
+
+
+@pytest.mark.parametrize("box", [1, 2])
+def test_octree_column_reproduces_the_quadtree_run(box):
+    """a flow that does not depend on z on an octree refined in a column: interpolate_2D1 with one
+    transverse neighbour equal to the cell itself is interpolate_1D1, every face sum has two equal
+    halves: the errors of the run are those of the 2-D run up to the tolerance of the projections
+    (1e-6), and W stays at that level"""
+    level = 4 if box == 1 else 3
+    s2 = O.Tree2D(periodic=(level, box))
+    s2.run()
+    _, l2, linf = s2.error_norm()
+    s, var, wvar, p, q = _column(level, box, 2)
+    n = s.run()
+    assert n == s2.i
+    e2, emax = _column_error(s, var, p, q)
+    assert e2 == pytest.approx(l2, rel=1e-4) and emax == pytest.approx(linf, rel=1e-3)
+    assert max(float(np.abs(s.values(wvar, l)).max()) for l in range(s.depth + 1)) < 1e-4
+    s.destroy()
+    s2.destroy()
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_octree_column_along_another_axis(axis):
+    """the same column along x or y: the direction tables of the 3-D branches (children of a face,
+    perpendicular directions, corner children) must treat the three axes alike.  The vortex in the
+    (p, q) plane is not the image of the (x, y) one under a rotation that keeps the child order, so
+    the comparison is on the error norms, to the tolerance of the projections"""
+    level, box = 3, 1
+    ref, var, _, p, q = _column(level, box, 2)
+    ref.run()
+    want = _column_error(ref, var, p, q)
+    s, var, wvar, p, q = _column(level, box, axis)
+    s.run()
+    got = _column_error(s, var, p, q)
+    assert got[0] == pytest.approx(want[0], rel=1e-4) and got[1] == pytest.approx(want[1], rel=1e-3)
+    assert max(float(np.abs(s.values(wvar, l)).max()) for l in range(s.depth + 1)) < 1e-4
+    s.destroy()
+    ref.destroy()

@@ -8,11 +8,11 @@ O=${1:-$R/gpurun_out/periodic_rows}
 mkdir -p $O && cd $O && rm -f r0 r1 r2 times
 for r in 0 1 2; do
   for level in 5 6 7; do
-    t0=$(date +%s.%N)
+    t0=$(date +%s%N)
     sed "s/LEVEL/$level/g" < $R/tests/golden/reference_inputs/periodic.gfs | sed "s/BOX/$r/g" | \
       $R/gerris-fft-particles_amd/bin/gfship2D - | \
       awk -v level=$level '{ print level " " $7 " " $9 }' >> r$r || exit 1
-    echo "r=$r level=$level $(echo "$(date +%s.%N) - $t0" | bc) s" | tee -a times
+    echo "r=$r level=$level $(( ($(date +%s%N) - t0)/1000000 )) ms" | tee -a times
   done
 done
 rc=0
