@@ -1,5 +1,6 @@
-// tree2d.hip -- the reference's time step on a statically refined 2-D quadtree in one periodic box
-// (the coarse-fine stencils; the case of test/periodic/periodic.gfs with BOX = 1, 2).
+// tree2d.hip -- the reference's time step on a statically refined quadtree (2-D) or octree (3-D) in
+// one periodic box (the coarse-fine stencils; the case of test/periodic/periodic.gfs
+// with BOX = 1, 2 and its 3-D analogues).
 //
 // How the tree algorithms of the reference map onto the device:
 //  * cell loops whose result does not depend on the order (src/ftt.c:689-926 traversals of leaves,
@@ -32,8 +33,16 @@ using namespace gfship::tree;
 
 namespace {
 
-enum { V_P, V_PMAC, V_U, V_V, V_GX, V_GY, V_GMX, V_GMY, V_UN0, V_UN1, V_UN2, V_UN3,
-       V_FV0, V_FV1, V_FV2, V_FV3, V_DIV, V_RES, V_DP, V_NVAR };
+enum { V_P, V_PMAC, V_U /* 3 */, V_G = V_U + 3 /* 3 */, V_GM = V_G + 3 /* 3 */, V_UN = V_GM + 3 /* 6 */,
+       V_FV = V_UN + 6 /* 6 */, V_DIV = V_FV + 6, V_RES, V_DP, V_NVAR };
+
+// the variables of the C ABI (GFSHIP_TREE_*) -> storage
+const int abi_var[] = { V_P, V_PMAC, V_U, V_U + 1, V_G, V_G + 1, V_GM, V_GM + 1, V_UN, V_UN + 1, V_UN + 2,
+			V_UN + 3, V_U + 2, V_G + 2, V_GM + 2, V_UN + 4, V_UN + 5 };
+const int abi_nvar = sizeof (abi_var)/sizeof (abi_var[0]);
+
+struct P3 { double * p[3]; };       // the components of a vector
+struct P6 { double * p[6]; };       // a number per direction
 
 struct FaceRec { Cell cell, neighbor; int d; };
 struct Ghost { int g, img, side; };
@@ -80,7 +89,7 @@ struct gfship_tree {
   Cell * nonleaf[GFSHIP_MAXLEVEL + 1] = {};       // device: interior non-leaf cells of a level
   Ghost * ghost_leaves = nullptr; int nghost_leaves = 0;
   Sweep sweep[GFSHIP_MAXLEVEL + 1];
-  FaceSet fs[3];                                  // 0: FTT_XYZ, 1: x faces, 2: y faces
+  FaceSet fs[4];                                  // 0: FTT_XYZ, 1 + c: the faces normal to c
   double * d_red = nullptr;                       // reductions: [0] max bits / min bits, [1..3] sums
   double * h_red = nullptr;                       // pinned
   gfship_multilevel_params projection_params, approx_projection_params;
@@ -101,12 +110,11 @@ __global__ void t_copy_ghosts (const Ghost * gh, int n, double * v)
 
 // gfs_domain_face_bc on periodic sides (src/boundary.c:1251-1258,1343-1347): the leaf ghost beyond
 // side sd takes f[OPP (sd)].v of its image
-__global__ void t_face_bc (const Ghost * gh, int n, double * fv0, double * fv1, double * fv2, double * fv3)
+__global__ void t_face_bc (const Ghost * gh, int n, P6 fv)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
-  double * fv[4] = { fv0, fv1, fv2, fv3 };
-  double * a = fv[gh[t].side ^ 1];
+  double * a = fv.p[gh[t].side ^ 1];
   a[gh[t].g] = a[gh[t].img];
 }
 
@@ -118,7 +126,7 @@ __global__ void t_from_below (Topo T, const Cell * cells, int n, double * v, int
   if (t >= n) return;
   const Cell c = cells[t];
   double val = 0., sa = 0.;
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < T.nc (); k++) {
     const Cell ch = T.child (c, k);
     if (exists (ch)) {
       if (mode == 0) {
@@ -129,7 +137,8 @@ __global__ void t_from_below (Topo T, const Cell * cells, int n, double * v, int
 	val += v[T.gi (ch)];
     }
   }
-  v[T.gi (c)] = mode == 0 ? val/sa : val;
+  // get_from_below_2D: the sum; get_from_below_3D: the sum/2 (src/poisson.c:1044-1068)
+  v[T.gi (c)] = mode == 0 ? val/sa : T.dim == 2 ? val : val/2.;
 }
 
 // get_from_above, src/poisson.c:1005-1042
@@ -140,8 +149,8 @@ __global__ void t_from_above (Topo T, const Cell * cells, int n, double * v)
   const Cell parent = cells[t];
   DevReader R = { v };
   const double vp = v[T.gi (parent)];
-  double h[2];
-  for (int c = 0; c < 2; c++) {
+  double h[3];
+  for (int c = 0; c < T.dim; c++) {
     Face f;
     f.cell = parent;
     f.d = 2*c;
@@ -154,13 +163,16 @@ __global__ void t_from_above (Topo T, const Cell * cells, int n, double * v)
     const double g2 = g.b - g.a*vp;
     h[c] = (g1 - g2)/2.;
   }
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < T.nc (); k++) {
     const Cell ch = T.child (parent, k);
     if (exists (ch)) {
-      const double px = (k & 1) ? 0.25 : -0.25, py = (k & 2) ? -0.25 : 0.25;   /* ftt_cell_relative_pos */
+      const double px = (k & 1) ? 0.25 : -0.25, py = (k & 2) ? -0.25 : 0.25,
+	pz = (k & 4) ? -0.25 : 0.25;                 /* ftt_cell_relative_pos */
       double x = vp;
       x += px*h[0];
       x += py*h[1];
+      if (T.dim == 3)
+	x += pz*h[2];
       v[T.gi (ch)] = x;
     }
   }
@@ -232,13 +244,12 @@ __global__ void t_correct (Topo T, const Cell * cells, int n, double * u, const 
 }
 
 // gfs_face_interpolated_normal_velocity, src/advection.c:549-573: the value of the face
-__global__ void t_face_interp (Topo T, const FaceRec * faces, int n, const double * u0, const double * u1,
-			       double * fval)
+__global__ void t_face_interp (Topo T, const FaceRec * faces, int n, P3 u, double * fval)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
   const Face f = { faces[t].cell, faces[t].neighbor, faces[t].d };
-  DevReader R = { f.d < 2 ? u0 : u1 };
+  DevReader R = { u.p[f.d/2] };
   fval[t] = face_interpolated_value (T, f, R);
 }
 
@@ -246,13 +257,11 @@ __global__ void t_face_interp (Topo T, const FaceRec * faces, int n, const doubl
 // f[d].un of the cell of a face is set; that of its neighbour is set (same level) or gets half of
 // the value (coarser neighbour, FTT_CELLS_DIRECTION = 2), after gfs_face_reset_normal_velocity
 __global__ void t_gather_un (Topo T, const Cell * cells, int n, const FaceRec * faces, const int * inc_off,
-			     const int * inc, const double * fval, double * un0, double * un1,
-			     double * un2, double * un3, int dmask)
+			     const int * inc, const double * fval, P6 un, int dmask)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
-  double * un[4] = { un0, un1, un2, un3 };
-  double acc[4] = { 0., 0., 0., 0. };
+  double acc[6] = { 0., 0., 0., 0., 0., 0. };
   for (int k = inc_off[t]; k < inc_off[t + 1]; k++) {
     const int fi = inc[k] >> 1, role = inc[k] & 1;
     const FaceRec & f = faces[fi];
@@ -262,12 +271,12 @@ __global__ void t_gather_un (Topo T, const Cell * cells, int n, const FaceRec * 
     else if (f.neighbor.l == f.cell.l)
       acc[f.d ^ 1] = u;
     else
-      acc[f.d ^ 1] += u*1./(1.*2);
+      acc[f.d ^ 1] += u*1./(1.*T.ncd ());
   }
   const int g = T.gi (cells[t]);
-  for (int d = 0; d < 4; d++)
+  for (int d = 0; d < T.nd (); d++)
     if (dmask & (1 << d))
-      un[d][g] = acc[d];
+      un.p[d][g] = acc[d];
 }
 
 // correct_normal_velocity, src/timestep.c:118-144: dp of the face
@@ -287,74 +296,84 @@ __global__ void t_face_correct (Topo T, const FaceRec * faces, int n, const doub
 
 __global__ void t_gather_correct (Topo T, const Cell * cells, int n, const FaceRec * faces,
 				  const int * inc_off, const int * inc, const double * fval,
-				  double * un0, double * un1, double * un2, double * un3,
-				  double * gv, double dt)
+				  P6 un, P3 gv, double dt)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
-  double * un[4] = { un0, un1, un2, un3 };
   const int g = T.gi (cells[t]);
-  double gacc = gv ? gv[g] : 0.;
+  double gacc[3];
+  for (int c = 0; c < 3; c++)
+    gacc[c] = gv.p[c] ? gv.p[c][g] : 0.;
   for (int k = inc_off[t]; k < inc_off[t + 1]; k++) {
     const int fi = inc[k] >> 1, role = inc[k] & 1;
     const FaceRec & f = faces[fi];
     double dp = fval[fi];
     if (role == 0) {
-      un[f.d][g] -= dp*dt;
-      gacc += dp*1.;
+      un.p[f.d][g] -= dp*dt;
+      gacc[f.d/2] += dp*1.;
     }
     else {
       if (f.neighbor.l < f.cell.l)
-	dp *= 1./(1.*4/2);
-      un[f.d ^ 1][g] -= dp*dt;
-      gacc += dp*1.;
+	dp *= 1./(1.*T.nc ()/2);
+      un.p[f.d ^ 1][g] -= dp*dt;
+      gacc[f.d/2] += dp*1.;
     }
   }
-  if (gv)
-    gv[g] = gacc;
+  for (int c = 0; c < 3; c++)
+    if (gv.p[c])
+      gv.p[c][g] = gacc[c];
 }
 
 // gfs_normal_divergence + scale_divergence, src/fluid.c:2310-2324, src/timestep.c:181-187
-__global__ void t_divergence (Topo T, const Cell * cells, int n, const double * un0, const double * un1,
-			      const double * un2, const double * un3, double * div, double dt)
+__global__ void t_divergence (Topo T, const Cell * cells, int n, P6 un, double * div, double dt)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
   const Cell c = cells[t];
   const int g = T.gi (c);
   double d = 0.;
-  d += 1.*un0[g]*1.;
-  d += -1.*un1[g]*1.;
-  d += 1.*un2[g]*1.;
-  d += -1.*un3[g]*1.;
+  for (int e = 0; e < T.nd (); e++)
+    d += ((e & 1) ? -1. : 1.)*un.p[e][g]*1.;
   d = d*T.size (c);
   div[g] = d/dt;
 }
 
-__global__ void t_scale2 (Topo T, const Cell * cells, int n, double * a, double * b, double s, int mode,
-			  const double * ga, const double * gb)
+__global__ void t_scale (Topo T, const Cell * cells, int n, P3 a, double s, int mode, P3 g)
 {
-  // mode 0: a /= 2, b /= 2 (scale_cell_gradients, src/timestep.c:60-90: both neighbours exist);
-  // mode 1: a -= ga*s, b -= gb*s (correct, src/timestep.c:486-496)
+  // mode 0: a[c] /= 2 (scale_cell_gradients, src/timestep.c:60-90: both neighbours exist);
+  // mode 1: a[c] -= g[c]*s (correct, src/timestep.c:486-496)
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
-  const int g = T.gi (cells[t]);
-  if (mode == 0) {
-    a[g] /= 2.;
-    b[g] /= 2.;
-  }
-  else {
-    a[g] -= ga[g]*s;
-    b[g] -= gb[g]*s;
+  const int gi = T.gi (cells[t]);
+  for (int c = 0; c < T.dim; c++) {
+    if (mode == 0)
+      a.p[c][gi] /= 2.;
+    else
+      a.p[c][gi] -= g.p[c][gi]*s;
   }
 }
 
 struct AdvArgs {
-  const double * v, * u[2], * un[4];
-  double * fv[4];
+  const double * v, * u[3], * un[6];
+  double * fv[6];
   double dt;
   int use_centered;
 };
+
+// transverse_term, src/advection.c:27-47
+__device__ inline double transverse_term (const Topo & T, const AdvArgs & A, Cell cell, int g, double v0,
+					  DevReader & R, double msize, int ct)
+{
+  const double vtan = A.use_centered ? A.u[ct][g] : (A.un[2*ct][g] + A.un[2*ct + 1][g])/2.;
+  Face f;
+  f.d = vtan > 0. ? 2*ct + 1 : 2*ct;
+  f.cell = cell;
+  f.neighbor = T.neighbor (cell, f.d);
+  const Grad2 gf = face_gradient (T, f, R, -1);
+  double gt = gf.b - gf.a*v0;
+  if (vtan > 0.) gt = - gt;
+  return A.dt*vtan*gt/(2.*msize);
+}
 
 // gfs_cell_advected_face_values, src/advection.c:58-99 (centred gradient, no sources)
 __global__ void t_face_values (Topo T, const Cell * cells, int n, AdvArgs A)
@@ -366,7 +385,7 @@ __global__ void t_face_values (Topo T, const Cell * cells, int n, AdvArgs A)
   DevReader R = { A.v };
   const double size = T.size (cell);
   const double v0 = A.v[g];
-  for (int c = 0; c < 2; c++) {
+  for (int c = 0; c < T.dim; c++) {
     const double msize = size;
     const double unorm = A.use_centered ? A.dt*A.u[c][g]/msize :
       A.dt*(A.un[2*c][g] + A.un[2*c + 1][g])/(2.*msize);
@@ -375,23 +394,21 @@ __global__ void t_face_values (Topo T, const Cell * cells, int n, AdvArgs A)
     const double vl = v0 + (m1 < 0.5 ? m1 : 0.5)*gr;
     const double vr = v0 + (m2 > -0.5 ? m2 : -0.5)*gr;
     const double src = A.dt*0./2.;
-    // transverse_term, src/advection.c:27-47
-    const int ct = (c + 1) % 2;
-    const double vtan = A.use_centered ? A.u[ct][g] : (A.un[2*ct][g] + A.un[2*ct + 1][g])/2.;
-    Face f;
-    f.d = vtan > 0. ? 2*ct + 1 : 2*ct;
-    f.cell = cell;
-    f.neighbor = T.neighbor (cell, f.d);
-    const Grad2 gf = face_gradient (T, f, R, -1);
-    double gt = gf.b - gf.a*v0;
-    if (vtan > 0.) gt = - gt;
-    const double dv = A.dt*vtan*gt/(2.*msize);
+    double dv;
+    if (T.dim == 2)
+      dv = transverse_term (T, A, cell, g, v0, R, msize, (c + 1) % 2);
+    else {
+      // orthogonal[c] = { {Y, Z}, {X, Z}, {X, Y} }
+      const int o0 = c == 0 ? 1 : 0, o1 = c == 2 ? 1 : 2;
+      dv =  transverse_term (T, A, cell, g, v0, R, msize, o0);
+      dv += transverse_term (T, A, cell, g, v0, R, msize, o1);
+    }
     A.fv[2*c][g]     = vl + src - dv;
     A.fv[2*c + 1][g] = vr + src - dv;
   }
 }
 
-struct UpwindArgs { const double * u[2], * un[4], * fv[4]; };
+struct UpwindArgs { const double * u[3], * un[6], * fv[6]; };
 
 // interpolate_1D1 of src/advection.c:132-180 (the assigned values of s2: see oracle/go_tree2d.c)
 __device__ inline double adv_interpolate_1D1 (const Topo & T, const UpwindArgs & A, Cell cell, int dright,
@@ -408,8 +425,7 @@ __device__ inline double adv_interpolate_1D1 (const Topo & T, const UpwindArgs &
       v2 = A.fv[dleft][T.gi (nb)];
     else {
       // ftt_cell_child_corner: the child of nb in the corner (dleft, opposite of dup)
-      const int dx = dleft < 2 ? dleft : (dup ^ 1), dy = dleft < 2 ? (dup ^ 1) : dleft;
-      nb = T.child (nb, (dx == 0 ? 1 : 0) + (dy == 3 ? 2 : 0));
+      nb = T.child_corner (nb, dleft, dup ^ 1, -1);
       if (exists (nb))
 	v2 = A.fv[dleft][T.gi (nb)];
       else
@@ -418,6 +434,52 @@ __device__ inline double adv_interpolate_1D1 (const Topo & T, const UpwindArgs &
     return s2 > 0. ? (v2*(s1 - 1. + 2.*x) + v1*(s2 + 1. - 2.*x))/(s1 + s2) : v1;
   }
   return A.fv[dleft][T.gi (cell)];
+}
+
+// interpolate_2D1 of src/advection.c:183-249 (3-D)
+__device__ inline double adv_interpolate_2D1 (const Topo & T, const UpwindArgs & A, Cell cell, int dright,
+					      int d1, int d2, double x, double y)
+{
+  double x1 = 0., y1 = 1.;
+  double x2 = 1., y2 = 0.;
+  double v1, v2;
+  const int dleft = dright ^ 1;
+  const double v0 = A.fv[dleft][T.gi (cell)];
+  Cell n1 = T.neighbor (cell, d1);
+  if (exists (n1) && T.interior (n1)) {
+    if (!T.leaf (n1)) {
+      n1 = T.child_corner (n1, dright ^ 1, d1 ^ 1, d2);
+      if (exists (n1)) {
+	v1 = A.fv[dleft][T.gi (n1)];
+	x1 = 1./4.;
+	y1 = 3./4.;
+      }
+      else
+	v1 = v0;
+    }
+    else
+      v1 = A.fv[dleft][T.gi (n1)];
+  }
+  else
+    v1 = v0;
+  Cell n2 = T.neighbor (cell, d2);
+  if (exists (n2) && T.interior (n2)) {
+    if (!T.leaf (n2)) {
+      n2 = T.child_corner (n2, dright ^ 1, d2 ^ 1, d1);
+      if (exists (n2)) {
+	v2 = A.fv[dleft][T.gi (n2)];
+	x2 = 3./4.;
+	y2 = 1./4.;
+      }
+      else
+	v2 = v0;
+    }
+    else
+      v2 = A.fv[dleft][T.gi (n2)];
+  }
+  else
+    v2 = v0;
+  return ((v1 - v0)*(x*y2 - x2*y) + (v2 - v0)*(x1*y - x*y1))/(x1*y2 - x2*y1) + v0;
 }
 
 // gfs_face_upwinded_value, src/advection.c:267-343
@@ -440,8 +502,11 @@ __device__ inline double face_upwinded_value (const Topo & T, const UpwindArgs &
   }
   if (un > 0.)
     return fc;
-  const double vcoarse = adv_interpolate_1D1 (T, A, face.neighbor, face.d,
-					      perpendicular (face.d, T.id (face.cell)), 1./4.);
+  const int id = T.id (face.cell);
+  const double vcoarse = T.dim == 2 ?
+    adv_interpolate_1D1 (T, A, face.neighbor, face.d, perpendicular (face.d, id), 1./4.) :
+    adv_interpolate_2D1 (T, A, face.neighbor, face.d, perpendicular3 (face.d, id, 0),
+			 perpendicular3 (face.d, id, 1), 1./4., 1./4.);
   if (un == 0.)
     return (fc + vcoarse)/2.;
   return vcoarse;
@@ -489,7 +554,7 @@ __global__ void t_gather_flux (Topo T, const Cell * cells, int n, const FaceRec 
     else if (F.neighbor.l == F.cell.l)
       f += flux;
     else
-      f += flux/4;
+      f += flux/T.nc ();
   }
   const int gi = T.gi (cells[t]);
   double x = v[gi];
@@ -500,31 +565,27 @@ __global__ void t_gather_flux (Topo T, const Cell * cells, int n, const FaceRec 
 }
 
 // gfs_domain_cfl, src/domain.c:2824-2923: the minimum of (length/|u|)^2 over faces and cells
-__global__ void t_cfl_faces (Topo T, const FaceRec * faces, int n, const double * un0, const double * un1,
-			     const double * un2, const double * un3, double * red)
+__global__ void t_cfl_faces (Topo T, const FaceRec * faces, int n, P6 un, double * red)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
-  const double * un[4] = { un0, un1, un2, un3 };
-  const double u = un[faces[t].d][T.gi (faces[t].cell)];
+  const double u = un.p[faces[t].d][T.gi (faces[t].cell)];
   if (u != 0.) {
     const double cflu = T.size (faces[t].cell)/fabs (u);
     atomic_min_pos (red, cflu*cflu);
   }
 }
 
-__global__ void t_cfl_cells (Topo T, const Cell * cells, int n, const double * u0, const double * u1,
-			     double * red)
+__global__ void t_cfl_cells (Topo T, const Cell * cells, int n, P3 u, double * red)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
   const int g = T.gi (cells[t]);
   const double length = T.size (cells[t]);
-  const double * u[2] = { u0, u1 };
-  for (int c = 0; c < 2; c++) {
+  for (int c = 0; c < T.dim; c++) {
     const double fm = 1.;
-    if (u[c][g] != 0.) {
-      const double cflu = length/fabs (fm*u[c][g]);
+    if (u.p[c][g] != 0.) {
+      const double cflu = length/fabs (fm*u.p[c][g]);
       atomic_min_pos (red, cflu*cflu);
     }
   }
@@ -535,44 +596,49 @@ inline int blocks (int n) { return (n + 255)/256; }
 // ---- host: tree construction and lists --------------------------------------------------------
 
 struct Builder {
-  std::vector<std::vector<unsigned char>> flag;     // per level, (n + 2)^2
+  int dim = 2;
+  std::vector<std::vector<unsigned char>> flag;     // per level, (n + 2)^dim
   int r (int l) const { return (1 << l) + 2; }
-  void ensure (int l) { if ((int) flag.size () <= l) flag.resize (l + 1); if (flag[l].empty ()) flag[l].assign ((size_t) r (l)*r (l), NONE); }
+  size_t idx (int l, int i, int j, int k) const { return i + (size_t) r (l)*(j + (dim == 3 ? (size_t) r (l)*k : 0)); }
+  void ensure (int l) {
+    if ((int) flag.size () <= l) flag.resize (l + 1);
+    if (flag[l].empty ()) flag[l].assign ((size_t) r (l)*r (l)*(dim == 3 ? r (l) : 1), NONE);
+  }
   // oct_new with check_neighbors, src/ftt.c:45-83
-  int refine_single (int l, int i, int j) {
+  int refine_single (int l, int i, int j, int k) {
     if (l + 1 > GFSHIP_MAXLEVEL) return GFSHIP_EUNSUPPORTED;
-    static const int di[4] = { 1, -1, 0, 0 }, dj[4] = { 0, 0, 1, -1 };
+    static const int di[6] = { 1, -1, 0, 0, 0, 0 }, dj[6] = { 0, 0, 1, -1, 0, 0 }, dk[6] = { 0, 0, 0, 0, 1, -1 };
     const int n = 1 << l;
-    for (int d = 0; d < 4; d++) {
-      const int ni = i + di[d], nj = j + dj[d];
-      if (ni < 1 || nj < 1 || ni > n || nj > n)
+    for (int d = 0; d < 2*dim; d++) {
+      const int ni = i + di[d], nj = j + dj[d], nk = k + dk[d];
+      if (ni < 1 || nj < 1 || ni > n || nj > n || (dim == 3 && (nk < 1 || nk > n)))
 	continue;                   // the ghost trees are matched at the end (gfs_domain_match)
-      if (flag[l][ni + r (l)*nj] == NONE) {
-	const int pi = (ni + 1)/2, pj = (nj + 1)/2;
-	if (flag[l - 1][pi + r (l - 1)*pj] == LEAF) {
-	  int e = refine_single (l - 1, pi, pj);
+      if (flag[l][idx (l, ni, nj, nk)] == NONE) {
+	const int pi = (ni + 1)/2, pj = (nj + 1)/2, pk = (nk + 1)/2;
+	if (flag[l - 1][idx (l - 1, pi, pj, pk)] == LEAF) {
+	  int e = refine_single (l - 1, pi, pj, pk);
 	  if (e) return e;
 	}
       }
     }
-    flag[l][i + r (l)*j] = NODE;
+    flag[l][idx (l, i, j, k)] = NODE;
     ensure (l + 1);
-    for (int k = 0; k < 4; k++)
-      flag[l + 1][2*i - 1 + (k & 1) + r (l + 1)*(2*j - ((k >> 1) & 1))] = LEAF;
+    for (int c = 0; c < (1 << dim); c++)
+      flag[l + 1][idx (l + 1, 2*i - 1 + (c & 1), 2*j - ((c >> 1) & 1), 2*k - ((c >> 2) & 1))] = LEAF;
     return 0;
   }
   // ftt_cell_refine (src/ftt.c:169-192) with refine_maxlevel (src/refine.c:35-38)
-  int refine_rec (int l, int i, int j, gfship_refine_fn fn, void * ctx) {
-    if (flag[l][i + r (l)*j] == LEAF) {
+  int refine_rec (int l, int i, int j, int k, gfship_refine_fn fn, void * ctx) {
+    if (flag[l][idx (l, i, j, k)] == LEAF) {
       const double h = 1./(1 << l);
-      const double x = -0.5 + (i - 0.5)*h, y = -0.5 + (j - 0.5)*h;
-      if (!(l < (* fn) (x, y, 0., ctx)))
+      const double x = -0.5 + (i - 0.5)*h, y = -0.5 + (j - 0.5)*h, z = dim == 3 ? -0.5 + (k - 0.5)*h : 0.;
+      if (!(l < (* fn) (x, y, z, ctx)))
 	return 0;
-      int e = refine_single (l, i, j);
+      int e = refine_single (l, i, j, k);
       if (e) return e;
     }
-    for (int k = 0; k < 4; k++) {
-      int e = refine_rec (l + 1, 2*i - 1 + (k & 1), 2*j - ((k >> 1) & 1), fn, ctx);
+    for (int c = 0; c < (1 << dim); c++) {
+      int e = refine_rec (l + 1, 2*i - 1 + (c & 1), 2*j - ((c >> 1) & 1), 2*k - ((c >> 2) & 1), fn, ctx);
       if (e) return e;
     }
     return 0;
@@ -607,27 +673,41 @@ void traverse (const Topo & T, Cell c, int flags, int max_depth, const CellFn & 
   if (visit)
     fn (c);
   if (descend)
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < T.nc (); k++) {
       const Cell ch = T.child (c, k);
       if (exists (ch))
 	traverse (T, ch, flags, max_depth, fn);
     }
 }
 
-inline Cell root_cell (const Topo & T) { Cell c = { 0, 1 + T.r (0) }; return c; }
+inline Cell root_cell (const Topo & T) { return T.make (0, 1, 1, 1); }
 
 // ftt_refine_corner, src/ftt.c:2013-2074
 bool refine_corner (const Topo & T, Cell cell)
 {
-  static const int perp[4][2] = { {2, 3}, {2, 3}, {1, 0}, {1, 0} };
-  for (int i = 0; i < 4; i++) {
+  static const int perp2[4][2] = { {2, 3}, {2, 3}, {1, 0}, {1, 0} };
+  static const int perp3[6][4][2] =
+    {{{4,2},{4,3},{5,2},{5,3}}, {{4,2},{4,3},{5,2},{5,3}},
+     {{4,1},{4,0},{5,1},{5,0}}, {{4,1},{4,0},{5,1},{5,0}},
+     {{2,1},{2,0},{3,1},{3,0}}, {{2,1},{2,0},{3,1},{3,0}}};
+  for (int i = 0; i < T.nd (); i++) {
     const Cell nb = T.neighbor (cell, i);
     if (exists (nb) && !T.leaf (nb))
-      for (int j = 0; j < 2; j++) {
+      for (int j = 0; j < T.ncd (); j++) {
 	const Cell c = T.child_direction (nb, i ^ 1, j);
 	if (exists (c)) {
-	  const Cell nc = T.neighbor (c, perp[i][j]);
-	  if ((exists (nc) && !T.leaf (nc)) || !T.leaf (c))
+	  if (T.dim == 2) {
+	    const Cell nc = T.neighbor (c, perp2[i][j]);
+	    if (exists (nc) && !T.leaf (nc))
+	      return true;
+	  }
+	  else
+	    for (int w = 0; w < 2; w++) {
+	      const Cell nc = T.neighbor (c, perp3[i][j][w]);
+	      if (exists (nc) && !T.leaf (nc))
+		return true;
+	    }
+	  if (!T.leaf (c))
 	    return true;
 	}
       }
@@ -646,7 +726,7 @@ void traverse_face (const Topo & T, Cell cell, int d, std::vector<FaceRec> & out
     const Cell coarse = cell, node = f.neighbor;
     f.d = d ^ 1;
     f.neighbor = coarse;
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < T.ncd (); i++) {
       f.cell = T.child_direction (node, f.d, i);
       if (exists (f.cell))
 	out.push_back (f);
@@ -658,8 +738,9 @@ void traverse_face (const Topo & T, Cell cell, int d, std::vector<FaceRec> & out
 
 bool touches_side (const Topo & T, Cell c, int d)
 {
-  const int i = T.ci (c), j = T.cj (c), n = T.n (c.l);
-  return (d == 0 && i == n) || (d == 1 && i == 1) || (d == 2 && j == n) || (d == 3 && j == 1);
+  const int i = T.ci (c), j = T.cj (c), k = T.ck (c), n = T.n (c.l);
+  return (d == 0 && i == n) || (d == 1 && i == 1) || (d == 2 && j == n) || (d == 3 && j == 1) ||
+    (d == 4 && k == n) || (d == 5 && k == 1);
 }
 
 // ftt_face_traverse (src/ftt.c:2152-2215) as called by gfs_domain_face_traverse: kind 0 = FTT_XYZ,
@@ -668,9 +749,9 @@ void face_list (const Topo & T, const std::vector<Cell> & leaves, int kind, std:
 {
   if (kind == 0) {
     for (Cell c : leaves)
-      for (int d = 0; d < 4; d += 2)
+      for (int d = 0; d < T.nd (); d += 2)
 	traverse_face (T, c, d, out);
-    for (int d = 1; d < 4; d += 2)
+    for (int d = 1; d < T.nd (); d += 2)
       for (Cell c : leaves)
 	if (touches_side (T, c, d))
 	  traverse_face (T, c, d, out);
@@ -701,19 +782,25 @@ void ghost_list (const Topo & T, int flags, int max_depth, std::vector<Ghost> & 
     if (max_depth >= 0 && l > max_depth)
       break;
     const int n = T.n (l), r = T.r (l);
-    for (int side = 0; side < 4; side++)
-      for (int t = 1; t <= n; t++) {
-	const int gi = side == 0 ? n + 1 : side == 1 ? 0 : t, gj = side == 2 ? n + 1 : side == 3 ? 0 : t;
-	const int ii = side == 0 ? 1 : side == 1 ? n : t, ij = side == 2 ? 1 : side == 3 ? n : t;
-	const unsigned char f = T.flag[T.off[l] + gi + r*gj];
-	if (f == NONE)
-	  continue;
-	const bool take = flags == T_LEAFS ? f == LEAF : (l == max_depth || f == LEAF);
-	if (take) {
-	  Ghost g = { T.off[l] + gi + r*gj, T.off[l] + ii + r*ij, side };
-	  out.push_back (g);
+    for (int side = 0; side < T.nd (); side++)
+      for (int tb = 1; tb <= (T.dim == 3 ? n : 1); tb++)
+	for (int ta = 1; ta <= n; ta++) {
+	  int g[3], im[3];
+	  const int a = side/2, o1 = a == 0 ? 1 : 0, o2 = a == 2 ? 1 : 2;
+	  g[a] = (side & 1) ? 0 : n + 1;
+	  im[a] = (side & 1) ? n : 1;
+	  g[o1] = im[o1] = ta;
+	  g[o2] = im[o2] = T.dim == 3 ? tb : 0;
+	  const int G = g[0] + r*(g[1] + r*g[2]), I = im[0] + r*(im[1] + r*im[2]);
+	  const unsigned char f = T.flag[T.off[l] + G];
+	  if (f == NONE)
+	    continue;
+	  const bool take = flags == T_LEAFS ? f == LEAF : (l == max_depth || f == LEAF);
+	  if (take) {
+	    Ghost gh = { T.off[l] + G, T.off[l] + I, side };
+	    out.push_back (gh);
+	  }
 	}
-      }
   }
 }
 
@@ -898,11 +985,25 @@ int poisson_solve (gfship_tree * tr, gfship_multilevel_params * par, double * lh
   return 0;
 }
 
+P3 p3 (gfship_tree * tr, int first)
+{
+  P3 a;
+  for (int c = 0; c < 3; c++) a.p[c] = tr->var[first + c];
+  return a;
+}
+
+P6 p6 (gfship_tree * tr, int first)
+{
+  P6 a;
+  for (int d = 0; d < 6; d++) a.p[d] = tr->var[first + d];
+  return a;
+}
+
 int gather_un (gfship_tree * tr, int kind, int dmask)
 {
   FaceSet & F = tr->fs[kind];
   t_gather_un<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, F.faces, F.inc_off, F.inc, F.fval,
-      tr->var[V_UN0], tr->var[V_UN1], tr->var[V_UN2], tr->var[V_UN3], dmask);
+      p6 (tr, V_UN), dmask);
   KCHECK ();
   return 0;
 }
@@ -911,37 +1012,39 @@ int gather_un (gfship_tree * tr, int kind, int dmask)
 int mac_projection (gfship_tree * tr, gfship_multilevel_params * par, double dt, double * p, int gvar)
 {
   int e;
-  double * g[2] = { tr->var[gvar], tr->var[gvar + 1] };
-  for (int c = 0; c < 2; c++)   /* gfs_reset_gradients on the leaves (the other cells are never read) */
-    GFSHIP_HIP (hipMemsetAsync (g[c], 0, tr->ncell*sizeof (double), tr->stream));
-  t_divergence<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, tr->var[V_UN0], tr->var[V_UN1],
-      tr->var[V_UN2], tr->var[V_UN3], tr->var[V_DIV], dt);
+  const int dim = tr->H.dim;
+  for (int c = 0; c < dim; c++)   /* gfs_reset_gradients on the leaves (the other cells are never read) */
+    GFSHIP_HIP (hipMemsetAsync (tr->var[gvar + c], 0, tr->ncell*sizeof (double), tr->stream));
+  t_divergence<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, p6 (tr, V_UN), tr->var[V_DIV], dt);
   KCHECK ();
   if ((e = poisson_solve (tr, par, p, tr->var[V_DIV], dt))) return e;
-  // gfs_correct_normal_velocities (FTT_XY: the x faces, then the y faces), src/timestep.c:163-179
-  for (int c = 0; c < 2; c++) {
-    FaceSet & F = tr->fs[1 + c];
+  // gfs_correct_normal_velocities, src/timestep.c:163-179: FTT_XY (the x faces, then the y faces) in
+  // 2-D, FTT_XYZ (one traversal) in 3-D
+  for (int k = 0; k < (dim == 2 ? 2 : 1); k++) {
+    FaceSet & F = tr->fs[dim == 2 ? 1 + k : 0];
+    P3 gv = { { nullptr, nullptr, nullptr } };
+    if (dim == 2) gv.p[k] = tr->var[gvar + k];
+    else gv = p3 (tr, gvar);
     t_face_correct<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, p, F.fval);
     KCHECK ();
     t_gather_correct<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, F.faces, F.inc_off, F.inc, F.fval,
-	tr->var[V_UN0], tr->var[V_UN1], tr->var[V_UN2], tr->var[V_UN3], g[c], dt);
+	p6 (tr, V_UN), gv, dt);
     KCHECK ();
   }
   // gfs_scale_gradients, src/timestep.c:92-107
-  t_scale2<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, g[0], g[1], 0., 0, nullptr, nullptr);
+  t_scale<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, p3 (tr, gvar), 0., 0, p3 (tr, gvar));
   KCHECK ();
-  for (int c = 0; c < 2; c++)
-    if ((e = bc_leaves (tr, g[c]))) return e;
+  for (int c = 0; c < dim; c++)
+    if ((e = bc_leaves (tr, tr->var[gvar + c]))) return e;
   return 0;
 }
 
 int correct_centered (gfship_tree * tr, int gvar, double dt)   /* src/timestep.c:498-530 */
 {
   int e;
-  t_scale2<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, tr->var[V_U], tr->var[V_V], dt, 1,
-      tr->var[gvar], tr->var[gvar + 1]);
+  t_scale<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, p3 (tr, V_U), dt, 1, p3 (tr, gvar));
   KCHECK ();
-  for (int c = 0; c < 2; c++)
+  for (int c = 0; c < tr->H.dim; c++)
     if ((e = bc_leaves (tr, tr->var[V_U + c]))) return e;
   return 0;
 }
@@ -950,18 +1053,18 @@ int approximate_projection (gfship_tree * tr, gfship_multilevel_params * par, do
 { /* src/timestep.c:560-596 */
   int e;
   FaceSet & F = tr->fs[0];
-  t_face_interp<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, tr->var[V_U], tr->var[V_V], F.fval);
+  t_face_interp<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, p3 (tr, V_U), F.fval);
   KCHECK ();
-  if ((e = gather_un (tr, 0, 15))) return e;
-  if ((e = mac_projection (tr, par, dt, tr->var[V_P], V_GX))) return e;
-  return correct_centered (tr, V_GX, dt);
+  if ((e = gather_un (tr, 0, 63))) return e;
+  if ((e = mac_projection (tr, par, dt, tr->var[V_P], V_G))) return e;
+  return correct_centered (tr, V_G, dt);
 }
 
 UpwindArgs upwind_args (gfship_tree * tr)
 {
   UpwindArgs A;
-  for (int c = 0; c < 2; c++) A.u[c] = tr->var[V_U + c];
-  for (int d = 0; d < 4; d++) { A.un[d] = tr->var[V_UN0 + d]; A.fv[d] = tr->var[V_FV0 + d]; }
+  for (int c = 0; c < 3; c++) A.u[c] = tr->var[V_U + c];
+  for (int d = 0; d < 6; d++) { A.un[d] = tr->var[V_UN + d]; A.fv[d] = tr->var[V_FV + d]; }
   return A;
 }
 
@@ -969,13 +1072,12 @@ int face_values_set (gfship_tree * tr, const double * v, double dt, int use_cent
 { /* src/timestep.c:644-654 */
   AdvArgs A;
   A.v = v; A.dt = dt; A.use_centered = use_centered;
-  for (int c = 0; c < 2; c++) A.u[c] = tr->var[V_U + c];
-  for (int d = 0; d < 4; d++) { A.un[d] = tr->var[V_UN0 + d]; A.fv[d] = tr->var[V_FV0 + d]; }
+  for (int c = 0; c < 3; c++) A.u[c] = tr->var[V_U + c];
+  for (int d = 0; d < 6; d++) { A.un[d] = tr->var[V_UN + d]; A.fv[d] = tr->var[V_FV + d]; }
   t_face_values<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, A);
   KCHECK ();
   if (tr->nghost_leaves)
-    t_face_bc<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves,
-	tr->var[V_FV0], tr->var[V_FV1], tr->var[V_FV2], tr->var[V_FV3]);
+    t_face_bc<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves, p6 (tr, V_FV));
   KCHECK ();
   return 0;
 }
@@ -983,7 +1085,7 @@ int face_values_set (gfship_tree * tr, const double * v, double dt, int use_cent
 int predicted_face_velocities (gfship_tree * tr)   /* src/timestep.c:681-717 */
 {
   int e;
-  for (int c = 0; c < 2; c++) {
+  for (int c = 0; c < tr->H.dim; c++) {
     if ((e = face_values_set (tr, tr->var[V_U + c], tr->dt, 1))) return e;
     FaceSet & F = tr->fs[1 + c];
     t_face_advected_un<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, upwind_args (tr), F.fval);
@@ -998,7 +1100,7 @@ int centered_velocity_advection (gfship_tree * tr, int gmac, int g)
 {
   int e;
   FaceSet & F = tr->fs[0];
-  for (int c = 0; c < 2; c++) {
+  for (int c = 0; c < tr->H.dim; c++) {
     if ((e = face_values_set (tr, tr->var[V_U + c], tr->dt, 0))) return e;
     t_face_flux<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, upwind_args (tr), tr->var[gmac + c], tr->dt, F.fval);
     KCHECK ();
@@ -1006,7 +1108,7 @@ int centered_velocity_advection (gfship_tree * tr, int gmac, int g)
 	tr->var[V_U + c], tr->var[g + c], tr->dt);
     KCHECK ();
   }
-  for (int c = 0; c < 2; c++)
+  for (int c = 0; c < tr->H.dim; c++)
     if ((e = bc_leaves (tr, tr->var[V_U + c]))) return e;
   return 0;
 }
@@ -1016,10 +1118,9 @@ int domain_cfl (gfship_tree * tr, double * cfl)   /* src/domain.c:2899-2923 */
   const double big = DBL_MAX;
   GFSHIP_HIP (hipMemcpyAsync (tr->d_red, &big, sizeof (double), hipMemcpyHostToDevice, tr->stream));
   FaceSet & F = tr->fs[0];
-  t_cfl_faces<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, tr->var[V_UN0], tr->var[V_UN1], tr->var[V_UN2],
-      tr->var[V_UN3], tr->d_red);
+  t_cfl_faces<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, p6 (tr, V_UN), tr->d_red);
   KCHECK ();
-  t_cfl_cells<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, tr->var[V_U], tr->var[V_V], tr->d_red);
+  t_cfl_cells<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, p3 (tr, V_U), tr->d_red);
   KCHECK ();
   GFSHIP_HIP (hipMemcpyAsync (tr->h_red, tr->d_red, sizeof (double), hipMemcpyDeviceToHost, tr->stream));
   GFSHIP_HIP (hipStreamSynchronize (tr->stream));
@@ -1057,9 +1158,9 @@ int set_timestep (gfship_tree * tr)   /* src/simulation.c:1569-1633; the only ev
 int coarse_init (gfship_tree * tr)   /* src/adaptive.c:43-58 */
 {
   int e;
-  static const int vars[] = { V_P, V_PMAC, V_U, V_V };
-  for (int v : vars)
-    if ((e = from_below (tr, tr->var[v], 0))) return e;
+  const int vars[] = { V_P, V_PMAC, V_U, V_U + 1, V_U + 2 };
+  for (int k = 0; k < 2 + tr->H.dim; k++)
+    if ((e = from_below (tr, tr->var[vars[k]], 0))) return e;
   return 0;
 }
 
@@ -1090,8 +1191,7 @@ extern "C" {
 int gfship_tree_create (gfship_tree ** out, int dim, gfship_refine_fn refine, void * ctx, int device)
 {
   GFSHIP_CHECK (out && refine, GFSHIP_EINVAL, "gfship_tree_create: null argument");
-  GFSHIP_CHECK (dim == 2, GFSHIP_EUNSUPPORTED,
-		"gfship_tree_create: refined trees are implemented in 2-D only (dim = %d)", dim);
+  GFSHIP_CHECK (dim == 2 || dim == 3, GFSHIP_EINVAL, "gfship_tree_create: dim = %d", dim);
   int ndev = 0;
   if (hipGetDeviceCount (&ndev) != hipSuccess || ndev == 0) {
     set_error ("gfship_tree_create: no HIP device");
@@ -1102,19 +1202,21 @@ int gfship_tree_create (gfship_tree ** out, int dim, gfship_refine_fn refine, vo
 
   // gfs_refine_refine + gfs_simulation_refine, src/refine.c:45-60, src/simulation.c:1203-1233
   Builder B;
+  B.dim = dim;
   B.ensure (0);
-  B.flag[0][1 + B.r (0)] = LEAF;
-  int e = B.refine_rec (0, 1, 1, refine, ctx);
+  B.flag[0][B.idx (0, 1, 1, 1)] = LEAF;
+  int e = B.refine_rec (0, 1, 1, 1, refine, ctx);
   GFSHIP_CHECK (e == 0, e, "gfship_tree_create: more than %d levels", GFSHIP_MAXLEVEL);
   gfship_tree * tr = new gfship_tree;
   tr->device = device;
   auto flatten = [&] () {
     Topo & H = tr->H;
+    H.dim = dim;
     H.depth = (int) B.flag.size () - 1;
     int off = 0;
     for (int l = 0; l <= H.depth; l++) {
       H.off[l] = off;
-      off += B.r (l)*B.r (l);
+      off += H.lsize (l);
     }
     H.off[H.depth + 1] = off;
     tr->ncell = off;
@@ -1128,7 +1230,7 @@ int gfship_tree_create (gfship_tree ** out, int dim, gfship_refine_fn refine, vo
     // the refinements of a level are applied while the level is traversed (simulation.c:1105-1109)
     traverse (tr->H, root_cell (tr->H), T_LEVEL, l, [&] (Cell c) {
 	if (tr->H.leaf (c) && refine_corner (tr->H, c)) {
-	  B.refine_single (c.l, tr->H.ci (c), tr->H.cj (c));
+	  B.refine_single (c.l, tr->H.ci (c), tr->H.cj (c), tr->H.ck (c));
 	  for (int ll = 0; ll <= tr->H.depth; ll++)
 	    std::copy (B.flag[ll].begin (), B.flag[ll].end (), tr->hflag.begin () + tr->H.off[ll]);
 	}
@@ -1136,20 +1238,34 @@ int gfship_tree_create (gfship_tree ** out, int dim, gfship_refine_fn refine, vo
   }
   // gfs_domain_match: the ghost trees of the periodic sides mirror the cells they face; both cells
   // of a periodic pair must be at the same refinement
-  for (int l = 0; l <= tr->H.depth; l++) {
-    const int n = 1 << l, r = n + 2;
-    unsigned char * f = tr->hflag.data () + tr->H.off[l];
-    for (int t = 1; t <= n; t++) {
-      if (f[n + r*t] != f[1 + r*t] || f[t + r*n] != f[t + r*1]) {
-	delete tr;
-	set_error ("gfship_tree_create: the refinement differs across a periodic side (level %d)", l);
-	return GFSHIP_EUNSUPPORTED;
-      }
-      f[0 + r*t] = f[n + r*t];
-      f[n + 1 + r*t] = f[1 + r*t];
-      f[t + r*0] = f[t + r*n];
-      f[t + r*(n + 1)] = f[t + r*1];
+  {
+    std::vector<Ghost> all;
+    Topo every = tr->H;
+    for (int l = 0; l <= tr->H.depth; l++) {
+      // every ghost position of the level, whatever its flag: mark them present for the listing
+      const int n = 1 << l, r = n + 2;
+      unsigned char * f = tr->hflag.data () + tr->H.off[l];
+      for (int side = 0; side < 2*dim; side++)
+	for (int tb = 1; tb <= (dim == 3 ? n : 1); tb++)
+	  for (int ta = 1; ta <= n; ta++) {
+	    int g[3], im[3], own[3];
+	    const int a = side/2, o1 = a == 0 ? 1 : 0, o2 = a == 2 ? 1 : 2;
+	    g[a] = (side & 1) ? 0 : n + 1;
+	    im[a] = (side & 1) ? n : 1;
+	    own[a] = (side & 1) ? 1 : n;
+	    g[o1] = im[o1] = own[o1] = ta;
+	    g[o2] = im[o2] = own[o2] = dim == 3 ? tb : 0;
+	    const int G = g[0] + r*(g[1] + r*g[2]), I = im[0] + r*(im[1] + r*im[2]),
+	      O = own[0] + r*(own[1] + r*own[2]);
+	    if (f[O] != f[I]) {
+	      delete tr;
+	      set_error ("gfship_tree_create: the refinement differs across a periodic side (level %d)", l);
+	      return GFSHIP_EUNSUPPORTED;
+	    }
+	    f[G] = f[I];
+	  }
     }
+    (void) every; (void) all;
   }
 
   const Topo & T = tr->H;
@@ -1183,12 +1299,12 @@ int gfship_tree_create (gfship_tree ** out, int dim, gfship_refine_fn refine, vo
   TRY (to_device (gh, &tr->ghost_leaves));
   for (int m = 0; m <= T.depth; m++)
     TRY (sweep_plan (tr, m, &tr->sweep[m]));
-  for (int k = 0; k < 3; k++)
+  for (int k = 0; k < 1 + dim; k++)
     TRY (face_set (tr, k, &tr->fs[k]));
 #undef TRY
 #undef TRYHIP
-  gfship_multilevel_params_init (&tr->projection_params, 2);
-  gfship_multilevel_params_init (&tr->approx_projection_params, 2);
+  gfship_multilevel_params_init (&tr->projection_params, dim);
+  gfship_multilevel_params_init (&tr->approx_projection_params, dim);
   *out = tr;
   return GFSHIP_OK;
 }
@@ -1196,21 +1312,20 @@ int gfship_tree_create (gfship_tree ** out, int dim, gfship_refine_fn refine, vo
 void gfship_tree_destroy (gfship_tree * tr) { tree_free (tr); }
 
 int gfship_tree_depth (const gfship_tree * tr) { return tr ? tr->H.depth : -1; }
+int gfship_tree_dim (const gfship_tree * tr) { return tr ? tr->H.dim : -1; }
 
 int gfship_tree_flags (const gfship_tree * tr, int level, unsigned char * out)
 {
   GFSHIP_CHECK (tr && out && level >= 0 && level <= tr->H.depth, GFSHIP_EINVAL, "gfship_tree_flags: bad argument");
-  const int r = tr->H.r (level);
-  memcpy (out, tr->hflag.data () + tr->H.off[level], (size_t) r*r);
+  memcpy (out, tr->hflag.data () + tr->H.off[level], (size_t) tr->H.lsize (level));
   return GFSHIP_OK;
 }
 
 int gfship_tree_upload (gfship_tree * tr, int var, int level, const double * in)
 {
-  GFSHIP_CHECK (tr && in && var >= 0 && var <= V_UN3 && level >= 0 && level <= tr->H.depth, GFSHIP_EINVAL,
+  GFSHIP_CHECK (tr && in && var >= 0 && var < abi_nvar && level >= 0 && level <= tr->H.depth, GFSHIP_EINVAL,
 		"gfship_tree_upload: bad argument");
-  const int r = tr->H.r (level);
-  GFSHIP_HIP (hipMemcpyAsync (tr->var[var] + tr->H.off[level], in, (size_t) r*r*sizeof (double),
+  GFSHIP_HIP (hipMemcpyAsync (tr->var[abi_var[var]] + tr->H.off[level], in, (size_t) tr->H.lsize (level)*sizeof (double),
 			      hipMemcpyHostToDevice, tr->stream));
   GFSHIP_HIP (hipStreamSynchronize (tr->stream));
   return GFSHIP_OK;
@@ -1218,10 +1333,9 @@ int gfship_tree_upload (gfship_tree * tr, int var, int level, const double * in)
 
 int gfship_tree_download (gfship_tree * tr, int var, int level, double * out)
 {
-  GFSHIP_CHECK (tr && out && var >= 0 && var <= V_UN3 && level >= 0 && level <= tr->H.depth, GFSHIP_EINVAL,
+  GFSHIP_CHECK (tr && out && var >= 0 && var < abi_nvar && level >= 0 && level <= tr->H.depth, GFSHIP_EINVAL,
 		"gfship_tree_download: bad argument");
-  const int r = tr->H.r (level);
-  GFSHIP_HIP (hipMemcpyAsync (out, tr->var[var] + tr->H.off[level], (size_t) r*r*sizeof (double),
+  GFSHIP_HIP (hipMemcpyAsync (out, tr->var[abi_var[var]] + tr->H.off[level], (size_t) tr->H.lsize (level)*sizeof (double),
 			      hipMemcpyDeviceToHost, tr->stream));
   GFSHIP_HIP (hipStreamSynchronize (tr->stream));
   return GFSHIP_OK;
@@ -1267,9 +1381,9 @@ int gfship_tree_start (gfship_tree * tr)
   GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_start: null tree");
   GFSHIP_HIP (hipSetDevice (tr->device));
   int e;
-  static const int vars[] = { V_P, V_PMAC, V_U, V_V };
-  for (int v : vars)
-    if ((e = bc_leaves (tr, tr->var[v]))) return e;
+  const int vars[] = { V_P, V_PMAC, V_U, V_U + 1, V_U + 2 };
+  for (int k = 0; k < 2 + tr->H.dim; k++)
+    if ((e = bc_leaves (tr, tr->var[vars[k]]))) return e;
   if ((e = coarse_init (tr))) return e;
   if ((e = set_timestep (tr))) return e;
   if ((e = approximate_projection (tr, &tr->approx_projection_params, tr->dt))) return e;
@@ -1284,9 +1398,9 @@ int gfship_tree_step (gfship_tree * tr)
   int e;
   if ((e = predicted_face_velocities (tr))) return e;
   /* gfs_variables_swap (p, pmac) around the MAC projection */
-  if ((e = mac_projection (tr, &tr->projection_params, tr->dt/2., tr->var[V_PMAC], V_GMX))) return e;
-  const int g = tr->iter > 0 ? V_GX : V_GMX;
-  if ((e = centered_velocity_advection (tr, V_GMX, g))) return e;
+  if ((e = mac_projection (tr, &tr->projection_params, tr->dt/2., tr->var[V_PMAC], V_GM))) return e;
+  const int g = tr->iter > 0 ? V_G : V_GM;
+  if ((e = centered_velocity_advection (tr, V_GM, g))) return e;
   if ((e = correct_centered (tr, g, - tr->dt))) return e;
   if ((e = coarse_init (tr))) return e;
   if ((e = approximate_projection (tr, &tr->approx_projection_params, tr->dt))) return e;

@@ -155,6 +155,7 @@ SIGNATURES = {
     "gfship_tree_create": (_i, [C.POINTER(_vp), _i, C.c_void_p, _vp, _i]),
     "gfship_tree_destroy": (None, [_vp]),
     "gfship_tree_depth": (_i, [_vp]),
+    "gfship_tree_dim": (_i, [_vp]),
     "gfship_tree_flags": (_i, [_vp, _i, C.POINTER(C.c_ubyte)]),
     "gfship_tree_upload": (_i, [_vp, _i, _i, _pd]),
     "gfship_tree_download": (_i, [_vp, _i, _i, _pd]),
@@ -657,12 +658,16 @@ REFINE_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_double, C.c_void
 
 
 class Tree:
-    """gfship_tree: a GfsSimulation on one periodic 2-D box refined by a GfsRefine function
-    (coarse-fine stencils).  refine (x, y) -> level wanted at that position."""
-    P, PMAC, U, V, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3 = range(12)
+    """gfship_tree: a GfsSimulation on one periodic box refined by a GfsRefine function (coarse-fine
+    stencils; quadtree or octree).  refine (x, y) or refine (x, y, z) -> level wanted there."""
+    P, PMAC, U, V, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3, W, GZ, GMACZ, UN4, UN5 = range(17)
 
     def __init__(self, refine, dim=2, device=0):
-        self._cb = REFINE_FN(lambda x, y, z, ctx: float(refine(x, y)))
+        self.dim = dim
+        if dim == 2:
+            self._cb = REFINE_FN(lambda x, y, z, ctx: float(refine(x, y)))
+        else:
+            self._cb = REFINE_FN(lambda x, y, z, ctx: float(refine(x, y, z)))
         p = _vp()
         _check(lib().gfship_tree_create(C.byref(p), dim, C.cast(self._cb, C.c_void_p), None, device))
         self.ptr = p
@@ -672,23 +677,26 @@ class Tree:
 
     def flags(self, level):
         r = (1 << level) + 2
-        a = np.zeros((r, r), dtype=np.uint8)
+        a = np.zeros((r,) * self.dim, dtype=np.uint8)
         _check(lib().gfship_tree_flags(self.ptr, level, a.ctypes.data_as(C.POINTER(C.c_ubyte))))
         return a
 
     def centres(self, level):
         n = 1 << level
         c = -0.5 + (np.arange(n + 2) - 0.5) / n
-        return np.meshgrid(c, c, indexing="xy")
+        if self.dim == 2:
+            return np.meshgrid(c, c, indexing="xy")
+        z, y, x = np.meshgrid(c, c, c, indexing="ij")
+        return x, y, z
 
     def upload(self, var, level, a):
         a = np.ascontiguousarray(a, dtype=np.float64)
-        assert a.shape == ((1 << level) + 2,) * 2
+        assert a.shape == ((1 << level) + 2,) * self.dim
         _check(lib().gfship_tree_upload(self.ptr, var, level, a.ctypes.data_as(_pd)))
 
     def download(self, var, level):
         r = (1 << level) + 2
-        a = np.empty((r, r))
+        a = np.empty((r,) * self.dim)
         _check(lib().gfship_tree_download(self.ptr, var, level, a.ctypes.data_as(_pd)))
         return a
 

@@ -494,29 +494,32 @@ int  gfship_halo_unpack_sides (gfship_domain * dom, void * dev_ptr, int level, i
 /* ---- statically refined quadtree (coarse-fine stencils, 2-D) -------------------------------- */
 
 /* A GfsSimulation on one periodic GfsBox whose tree is refined by a GfsRefine function instead of
-   `Refine <int>' (the case of test/periodic/periodic.gfs with BOX = 1, 2): replaces the tree of
-   FttCell / FttOct records (src/ftt.h:134-159) by one dense (n + 2)^2 array per level -- n = 2^l, one
-   ghost layer, index i + (n + 2) j with 1 <= i, j <= n inside and j growing with y -- and a flag per
+   `Refine <int>' (the case of test/periodic/periodic.gfs with BOX = 1, 2; quadtree for dim = 2, octree
+   for dim = 3): replaces the tree of FttCell / FttOct records (src/ftt.h:134-159) by one dense
+   (n + 2)^dim array per level -- n = 2^l, one ghost layer, index i + (n + 2) (j + (n + 2) k) with
+   1 <= i, j, k <= n inside, j growing with y and k with z (no k in 2-D) -- and a flag per
    cell: 0 no such cell, 1 leaf, 2 refined.  `refine' is the GfsFunction of the GfsRefine object:
    a cell whose level is below refine (x, y, z) at its centre is refined (refine_maxlevel,
    src/refine.c:35-38), with the constraints of the reference: neighbours differ by one level at most
    (oct_new, src/ftt.c:45-83) and the corner rule of ftt_refine_corner (src/ftt.c:2013-2074,
    src/simulation.c:1226-1231).  The algorithms are those of gfship_sim with the fine / coarse
    branches of src/fluid.c:64-93,178-197,283-309,364-396,778-893, src/advection.c:132-180,267-343,
-   398-435,513-587, src/timestep.c:118-144: Euler equations, centred gradients, alpha = NULL, all four
-   sides periodic, refinement equal across each periodic pair (else GFSHIP_EUNSUPPORTED); 3-D trees:
-   GFSHIP_EUNSUPPORTED.  Results are those of the reference's traversal orders: the sweeps of
+   398-435,513-587, src/timestep.c:118-144 (in 3-D their FTT_3D forms: interpolate_2D1, src/fluid.c:214-245,
+   src/advection.c:183-249): Euler equations, centred gradients, alpha = NULL, all sides periodic,
+   refinement equal across each periodic pair (else GFSHIP_EUNSUPPORTED).  Results are those of the reference's traversal orders: the sweeps of
    gfs_relax run in tree order, the face loops accumulate in face-traversal order. */
 typedef struct gfship_tree gfship_tree;
 typedef double (* gfship_refine_fn) (double x, double y, double z, void * ctx);
 enum { GFSHIP_TREE_P = 0, GFSHIP_TREE_PMAC, GFSHIP_TREE_U, GFSHIP_TREE_V, GFSHIP_TREE_GX, GFSHIP_TREE_GY,
        GFSHIP_TREE_GMACX, GFSHIP_TREE_GMACY, GFSHIP_TREE_UN0, GFSHIP_TREE_UN1, GFSHIP_TREE_UN2,
-       GFSHIP_TREE_UN3 };           /* variables of a tree: P, Pmac, U, V, g, gmac, f[d].un */
+       GFSHIP_TREE_UN3, GFSHIP_TREE_W, GFSHIP_TREE_GZ, GFSHIP_TREE_GMACZ, GFSHIP_TREE_UN4,
+       GFSHIP_TREE_UN5 };           /* variables of a tree: P, Pmac, U, V, g, gmac, f[d].un; then the 3-D ones */
 int  gfship_tree_create (gfship_tree ** tree, int dim, gfship_refine_fn refine, void * ctx, int device);
 void gfship_tree_destroy (gfship_tree * tree);
 int  gfship_tree_depth (const gfship_tree * tree);                   /* gfs_domain_depth */
-int  gfship_tree_flags (const gfship_tree * tree, int level, unsigned char * out /* (n + 2)^2 */);
-int  gfship_tree_upload (gfship_tree * tree, int var, int level, const double * in /* (n + 2)^2 */);
+int  gfship_tree_dim (const gfship_tree * tree);
+int  gfship_tree_flags (const gfship_tree * tree, int level, unsigned char * out /* (n + 2)^dim */);
+int  gfship_tree_upload (gfship_tree * tree, int var, int level, const double * in /* (n + 2)^dim */);
 int  gfship_tree_download (gfship_tree * tree, int var, int level, double * out);
 gfship_multilevel_params * gfship_tree_projection_params (gfship_tree * tree, int approx);
 int  gfship_tree_set_time (gfship_tree * tree, double end, double cfl);  /* GfsTime end, AdvectionParams cfl */

@@ -87,8 +87,6 @@ def test_sweep_dependency_levels():
 
 
 def test_unsupported_trees_are_refused():
-    with pytest.raises(gfship.GfshipError):
-        gfship.Tree(lambda x, y: 4, dim=3)
     # refinement that reaches one side of a periodic pair only
     with pytest.raises(gfship.GfshipError):
         gfship.Tree(lambda x, y: 5 if x > 0.25 else 4)
@@ -120,4 +118,78 @@ def test_periodic_rows_from_the_device(golden_dir, box):
         sw += w * e.size
         mx = max(mx, float(np.abs(e).max()))
     assert ["%.3e" % np.sqrt(se / sw), "%.3e" % mx] == rows[level]
+    g.destroy()
+
+
+# ---- octrees (3-D): the same comparison, bit for bit
+
+def _refine3(kind, level, box):
+    inside = lambda a, b: not (a < -0.25 or a > 0.25 or b < -0.25 or b > 0.25)
+    if kind == "cube":          # a cube in the middle: coarse-fine faces, edges and corners in all directions
+        return lambda x, y, z: level + box if (inside(x, y) and -0.25 <= z <= 0.25) else level
+    if kind == "column_x":
+        return lambda x, y, z: level + box if inside(y, z) else level
+    if kind == "blob":          # off-centre, not aligned with the coarse cells one level up
+        return lambda x, y, z: level + box if ((x - 0.125) ** 2 + (y + 0.06) ** 2 + z ** 2 < 0.04) else level
+    return lambda x, y, z: level
+
+
+def _pair3(kind, level, box):
+    f = _refine3(kind, level, box)
+    o = O.Tree2D(refine=f, dim=3)
+    g = gfship.Tree(f, dim=3)
+    assert g.depth == o.depth
+    T, G = O.Tree2D, gfship.Tree
+    for l in range(o.depth + 1):
+        assert np.array_equal(g.flags(l), o.flags(l)), "octree flags differ on level %d" % l
+        x, y, z = o.centres(l)
+        # a velocity field that depends on the three coordinates, not divergence-free (the first
+        # projection has work to do), periodic
+        u = np.sin(2. * np.pi * x) * np.cos(2. * np.pi * y) * np.cos(2. * np.pi * z) + 0.3
+        v = -np.cos(2. * np.pi * x) * np.sin(2. * np.pi * y) * np.cos(4. * np.pi * z) - 0.2
+        w = 0.5 * np.sin(2. * np.pi * (x + y)) * np.sin(2. * np.pi * z) + 0.1
+        for arr, ov, gv in ((u, T.U, G.U), (v, T.V, G.V), (w, T.W, G.W)):
+            o.values(ov, l)[...] = arr
+            g.upload(gv, l, arr)
+    for p in (o.projection_params, o.approx_projection_params, g.projection_params,
+              g.approx_projection_params):
+        p.tolerance = 1e-4
+    o.set_time(0.5, 0.75)
+    g.set_time(0.5, 0.75)
+    return o, g
+
+
+@pytest.mark.parametrize("kind,level,box,steps", [("uniform", 3, 0, 2), ("cube", 3, 1, 3), ("cube", 2, 2, 3),
+                                                  ("column_x", 3, 1, 2), ("blob", 3, 2, 2)])
+def test_octree_steps_bit_exact(kind, level, box, steps):
+    o, g = _pair3(kind, level, box)
+    T, G = O.Tree2D, gfship.Tree
+    pairs = ((G.U, T.U, "U"), (G.V, T.V, "V"), (G.W, T.W, "W"), (G.P, T.P, "P"), (G.PMAC, T.PMAC, "Pmac"),
+             (G.UN0, T.UN0, "un0"), (G.UN1, T.UN1, "un1"), (G.UN2, T.UN2, "un2"), (G.UN3, T.UN3, "un3"),
+             (G.UN4, T.UN4, "un4"), (G.UN5, T.UN5, "un5"))
+
+    def same(what):
+        for l in range(o.depth + 1):
+            leaf = o.flags(l)[1:-1, 1:-1, 1:-1] == 1
+            if not leaf.any():
+                continue
+            for gv, ov, name in pairs:
+                a = g.download(gv, l)[1:-1, 1:-1, 1:-1][leaf]
+                b = o.values(ov, l)[1:-1, 1:-1, 1:-1][leaf]
+                assert np.array_equal(a, b), "%s: %s differs on the leaves of level %d (max %g)" % (
+                    what, name, l, np.abs(a - b).max())
+
+    o.start()
+    g.start()
+    assert g.dt == o.dt
+    assert g.approx_projection_params.niter == o.approx_projection_params.niter
+    same("after the initial projection")
+    for k in range(steps):
+        o.step()
+        g.step()
+        assert g.t == o.t and g.dt == o.dt
+        assert g.projection_params.niter == o.projection_params.niter
+        assert g.projection_params.residual.infty == o.projection_params.residual.infty
+        same("step %d" % (k + 1))
+    o.destroy()
     g.destroy()
