@@ -144,12 +144,19 @@ struct Run {
   FunctionSet functions;
   gfship_domain * dom = nullptr;
   gfship_sim * sim = nullptr;
-  // a Refine function that asks for a non-uniform tree (2-D, one periodic box): gfship_tree.  The
+  // a Refine function that asks for a non-uniform tree (one periodic box): gfship_tree.  The
   // host copy of a variable is then one value per leaf, the leaves in the order of
-  // ftt_cell_traverse (src/ftt.c:689-926); (leaf_i, leaf_j) are the cell's indices on level leaf_l
+  // ftt_cell_traverse (src/ftt.c:689-926); (leaf_i, leaf_j, leaf_k) are the cell's indices on level
+  // leaf_l.  for_each_cell hands the level over in the upper bits of its k (TREE_K)
   bool tree_mode = false;
   gfship_tree * tree = nullptr;
-  std::vector<int> leaf_l, leaf_i, leaf_j;
+  std::vector<int> leaf_l, leaf_i, leaf_j, leaf_k;
+  static int TREE_K (int k, int l) { return k | (l << 16); }
+  size_t tree_index (size_t c) const {
+    size_t r = (1 << leaf_l[c]) + 2;
+    return leaf_i[c] + r*(leaf_j[c] + (dim == 3 ? r*leaf_k[c] : 0));
+  }
+  size_t tree_level_size (int l) const { size_t r = (1 << l) + 2; return dim == 3 ? r*r*r : r*r; }
   std::chrono::steady_clock::time_point clock0;
 
   int n () const { return 1 << level; }
@@ -194,12 +201,11 @@ std::vector<double> & host_of (Run & R, int v)
       std::vector<std::vector<double>> lev (depth + 1);
       for (size_t c = 0; c < R.leaf_l.size (); c++) {
 	int l = R.leaf_l[c];
-	size_t r = (1 << l) + 2;
 	if (lev[l].empty ()) {
-	  lev[l].resize (r*r);
+	  lev[l].resize (R.tree_level_size (l));
 	  CHECK (gfship_tree_download (R.tree, V.dev, l, lev[l].data ()));
 	}
-	V.host[c] = lev[l][R.leaf_i[c] + r*R.leaf_j[c]];
+	V.host[c] = lev[l][R.tree_index (c)];
       }
       V.host_time = (double) R.i;
     }
@@ -233,11 +239,11 @@ void invalidate_device_copies (Run & R)
 void cell_pos (const Run & R, int i, int j, int k, double p[3])
 {
   // ftt_cell_pos on the unit box centred on the origin, src/ftt.c:349-367
-  if (R.tree_mode) {       /* for_each_cell hands over the level of the leaf as k */
-    double h = 1./(1 << k);
+  if (R.tree_mode) {       /* for_each_cell hands over the level of the leaf in the upper bits of k */
+    double h = 1./(1 << (k >> 16));
     p[0] = -0.5 + (i - 0.5)*h;
     p[1] = -0.5 + (j - 0.5)*h;
-    p[2] = 0.;
+    p[2] = R.dim == 3 ? -0.5 + ((k & 0xffff) - 0.5)*h : 0.;
     return;
   }
   double h = 1./R.n ();
@@ -272,7 +278,7 @@ template <class F> void for_each_cell (const Run & R, F f)
 {
   if (R.tree_mode) {
     for (size_t c = 0; c < R.leaf_l.size (); c++)
-      f (R.leaf_i[c], R.leaf_j[c], R.leaf_l[c], c);
+      f (R.leaf_i[c], R.leaf_j[c], Run::TREE_K (R.leaf_k[c], R.leaf_l[c]), c);
     return;
   }
   int n = R.n ();
@@ -291,7 +297,7 @@ gfship_norm norm_of (const Run & R, const std::vector<double> & a)
   double h = 1./R.n ();
   double w = R.dim == 3 ? h*h*h : h*h;
   for_each_cell (R, [&] (int, int, int k, size_t c) {
-    if (R.tree_mode) { double hl = 1./(1 << k); w = hl*hl; }    /* gfs_cell_volume of the leaf */
+    if (R.tree_mode) { double hl = 1./(1 << (k >> 16)); w = R.dim == 3 ? hl*hl*hl : hl*hl; }  /* gfs_cell_volume of the leaf */
     double val = a[c];
     nm.bias += w*val;
     val = fabs (val);
@@ -959,7 +965,7 @@ void parse_object (Run & R, Reader & r)
 	double h = 1./R.n (), vol = R.dim == 3 ? h*h*h : h*h, sum = 0.;
 	for_each_cell (R, [&] (int i, int j, int k, size_t c) {
 	  double w = vol;
-	  if (R.tree_mode) { double hl = 1./(1 << k); w = hl*hl; }
+	  if (R.tree_mode) { double hl = 1./(1 << (k >> 16)); w = R.dim == 3 ? hl*hl*hl : hl*hl; }
 	  if (s.w) { double p[3]; cell_pos (R, i, j, k, p); w = eval (R, s.w, p, (long) c); }
 	  sum += w*a[c];
 	});
@@ -1486,11 +1492,10 @@ void apply_init (Run & R)
     if (R.tree_mode && R.vars[v].dev >= 0) {
       int depth = gfship_tree_depth (R.tree);
       for (int l = 0; l <= depth; l++) {
-	size_t r = (1 << l) + 2;
-	std::vector<double> lev (r*r, 0.);
+	std::vector<double> lev (R.tree_level_size (l), 0.);
 	bool any = false;
 	for (size_t c = 0; c < R.leaf_l.size (); c++)
-	  if (R.leaf_l[c] == l) { lev[R.leaf_i[c] + r*R.leaf_j[c]] = a[c]; any = true; }
+	  if (R.leaf_l[c] == l) { lev[R.tree_index (c)] = a[c]; any = true; }
 	if (any)
 	  CHECK (gfship_tree_upload (R.tree, R.vars[v].dev, l, lev.data ()));
       }
@@ -1519,17 +1524,17 @@ void resolve_refine (Run & R)
 	  if (level < eval (R, R.refine_fn, p, -1)) yes++; else no++;
 	}
     if (yes && no) {
-      // a statically refined tree: gfship_tree (2-D GfsSimulation, one box, all sides periodic)
+      // a statically refined tree: gfship_tree (GfsSimulation, one box, all sides periodic)
       bool periodic = true;
       for (int d = 0; d < 2*R.dim; d++)
 	if (R.side[d] != GFSHIP_SIDE_PERIODIC) periodic = false;
-      if (R.dim == 2 && R.sim_class == "Simulation" && periodic) {
+      if (R.sim_class == "Simulation" && periodic) {
 	R.tree_mode = true;
 	R.level = level;     /* the coarsest leaves */
 	return;
       }
       fprintf (stderr, "gfship: line %d: the Refine function asks for a non-uniform tree at level %d "
-	       "(refined trees: 2-D GfsSimulation in one periodic box only)\n", R.refine_line, level);
+	       "(refined trees: GfsSimulation in one periodic box only)\n", R.refine_line, level);
       exit (1);
     }
     if (!yes) break;
@@ -1550,16 +1555,16 @@ double refine_hook (double x, double y, double z, void * ctx)
 
 // the leaves of the tree in the order of ftt_cell_traverse (pre-order, children 0..3: bit 0 = +x,
 // bit 1 = -y, src/ftt.c:301-316)
-void tree_leaves (Run & R, const std::vector<std::vector<unsigned char>> & flag, int l, int i, int j)
+void tree_leaves (Run & R, const std::vector<std::vector<unsigned char>> & flag, int l, int i, int j, int k)
 {
   size_t r = (1 << l) + 2;
-  unsigned char f = flag[l][i + r*j];
+  unsigned char f = flag[l][i + r*(j + (R.dim == 3 ? r*k : 0))];
   if (f == 1) {
-    R.leaf_l.push_back (l); R.leaf_i.push_back (i); R.leaf_j.push_back (j);
+    R.leaf_l.push_back (l); R.leaf_i.push_back (i); R.leaf_j.push_back (j); R.leaf_k.push_back (k);
   }
   else if (f == 2)
-    for (int k = 0; k < 4; k++)
-      tree_leaves (R, flag, l + 1, 2*i - 1 + (k & 1), 2*j - ((k >> 1) & 1));
+    for (int c = 0; c < (1 << R.dim); c++)
+      tree_leaves (R, flag, l + 1, 2*i - 1 + (c & 1), 2*j - ((c >> 1) & 1), 2*k - ((c >> 2) & 1));
 }
 
 // simulation_run (src/simulation.c:432-557) on a statically refined tree
@@ -1604,15 +1609,16 @@ int run_tree (Run & R)
   int depth = gfship_tree_depth (R.tree);
   std::vector<std::vector<unsigned char>> flag (depth + 1);
   for (int l = 0; l <= depth; l++) {
-    size_t r = (1 << l) + 2;
-    flag[l].resize (r*r);
+    flag[l].resize (R.tree_level_size (l));
     CHECK (gfship_tree_flags (R.tree, l, flag[l].data ()));
   }
-  tree_leaves (R, flag, 0, 1, 1);
+  tree_leaves (R, flag, 0, 1, 1, 1);
   R.vars[R.var_index ("P")].dev = GFSHIP_TREE_P;
   R.vars[R.var_index ("Pmac")].dev = GFSHIP_TREE_PMAC;
   R.vars[R.var_index ("U")].dev = GFSHIP_TREE_U;
   R.vars[R.var_index ("V")].dev = GFSHIP_TREE_V;
+  if (R.dim == 3)
+    R.vars[R.var_index ("W")].dev = GFSHIP_TREE_W;
   apply_multilevel (gfship_tree_projection_params (R.tree, 0), R.proj_set);
   apply_multilevel (gfship_tree_projection_params (R.tree, 1), R.approx_set);
   double cfl = 0.8;        /* gfs_advection_params_init, src/advection.c:922-942 */

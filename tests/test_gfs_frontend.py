@@ -338,3 +338,47 @@ def test_rotation_case_matches_error_ref(golden_dir, tmp_path):
         sums = [float(l.split()[4]) for l in open(tmp_path / ("t-%d" % level)) if l.strip()]
         # the rotation crosses the walls of the square box: the sum is only nearly conserved
         assert abs(sums[-1] - sums[0]) < 1e-3 * abs(sums[0])
+
+
+@pytest.mark.gpu
+def test_refined_cube_case_3d():
+    """tests/cases/refined_cube.gfs: an octree with two extra levels inside a cube (gfship3D, the
+    refined-tree path) against the octree oracle set up by hand with the same numbers: the volume-
+    weighted norms OutputScalarNorm prints, to the printed digits, and the time of OutputTime"""
+    from oracle import oracle as O
+    level, box, nsteps = 3, 2, 3
+    out = _run("refined_cube.gfs", {"LEVEL": level, "BOX": box, "NSTEPS": nsteps},
+               exe=BIN.replace("2D", "3D"))
+    inside = lambda a: not (a < -0.25 or a > 0.25)
+    s = O.Tree2D(refine=lambda x, y, z: level + box if (inside(x) and inside(y) and inside(z)) else level,
+                 dim=3)
+    for l in range(s.depth + 1):
+        x, y, z = s.centres(l)
+        s.values(O.Tree2D.U, l)[...] = np.sin(2. * np.pi * x) * np.cos(2. * np.pi * y) * np.cos(2. * np.pi * z) + 0.3
+        s.values(O.Tree2D.V, l)[...] = - np.cos(2. * np.pi * x) * np.sin(2. * np.pi * y) * np.cos(2. * np.pi * z) - 0.2
+        s.values(O.Tree2D.W, l)[...] = 0.1 * np.sin(2. * np.pi * (x + y)) * np.sin(2. * np.pi * z)
+    s.projection_params.tolerance = s.approx_projection_params.tolerance = 1e-5
+    s.set_time(1e30, 0.75)
+    s.start()
+    for _ in range(nsteps):
+        s.step()
+    lines = out.splitlines()
+    for name, which in (("U", O.Tree2D.U), ("W", O.Tree2D.W)):
+        first = second = wsum = 0.
+        infty = 0.
+        for l in range(s.depth + 1):
+            leaf = s.flags(l)[1:-1, 1:-1, 1:-1] == 1
+            if not leaf.any():
+                continue
+            a = np.abs(s.values(which, l)[1:-1, 1:-1, 1:-1][leaf])
+            w = 1. / (1 << l) ** 3
+            first += w * float(a.sum())
+            second += w * float((a * a).sum())
+            wsum += w * a.size
+            infty = max(infty, float(a.max()))
+        want = "%s time: %g first: % 10.3e second: % 10.3e infty: % 10.3e" % (
+            name, s.t, first / wsum, math.sqrt(second / wsum), infty)
+        assert want in lines, (want, lines)
+    step = [l for l in lines if l.startswith("step:")][0].split()
+    assert int(step[1]) == nsteps and float(step[3]) == pytest.approx(s.t, abs=1e-8)
+    s.destroy()
