@@ -1,4 +1,4 @@
-// tree2d.hip -- the reference's time step on a statically refined quadtree (2-D) or octree (3-D) in
+// tree.hip -- the reference's time step on a statically refined quadtree (2-D) or octree (3-D) in
 // one periodic box (the coarse-fine stencils; the case of test/periodic/periodic.gfs
 // with BOX = 1, 2 and its 3-D analogues).
 //
@@ -11,7 +11,7 @@
 //    reference's traversal visits them -- the same floating-point sums, no atomics;
 //  * the Gauss-Seidel sweep of gfs_relax visits the cells of a level and the coarser leaves in tree
 //    order (src/poisson.c:604-632): the host derives, from the very stencil code the kernels run
-//    (tree2d.hpp with a recording reader), which cells each cell reads, and groups the cells of the
+//    (tree.hpp with a recording reader), which cells each cell reads, and groups the cells of the
 //    sweep into dependency levels; one workgroup then runs a whole relax loop (nrelax sweeps with
 //    the periodic copies between them, src/poisson.c:1070-1089), level after level, barrier between.
 // The 2-D refined cases are small (10^4 - 10^5 cells): this path is about the reference's results on
@@ -22,7 +22,7 @@
 // src/fluid.c:1843-1864,2310-2324, src/domain.c:2239-2288,2824-2923, src/simulation.c:432-557,
 // 1569-1633, src/ftt.c:45-83,169-192,2013-2074 (refinement with the neighbour and corner rules).
 #include "gfship_internal.hpp"
-#include "tree2d.hpp"
+#include "tree.hpp"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -410,7 +410,7 @@ __global__ void t_face_values (Topo T, const Cell * cells, int n, AdvArgs A)
 
 struct UpwindArgs { const double * u[3], * un[6], * fv[6]; };
 
-// interpolate_1D1 of src/advection.c:132-180 (the assigned values of s2: see oracle/go_tree2d.c)
+// interpolate_1D1 of src/advection.c:132-180 (the assigned values of s2: see oracle/go_tree.c)
 __device__ inline double adv_interpolate_1D1 (const Topo & T, const UpwindArgs & A, Cell cell, int dright,
 					      int dup, double x)
 {

@@ -1,4 +1,4 @@
-// tree2d.hpp -- the coarse-fine stencils of a statically refined quadtree / octree.
+// tree.hpp -- the coarse-fine stencils of a statically refined quadtree / octree.
 //
 // The reference keeps a tree of FttOct records and reaches a neighbour, a parent or the children
 // of a cell through pointers (src/ftt.h:134-159,518-573).  Here level l of the tree is a dense
@@ -7,7 +7,7 @@
 // exists and whether it is a leaf.  Neighbour, parent and children are index arithmetic.
 //
 // Everything in this file is __host__ __device__ and templated on how a value is read: the kernels
-// (tree2d.hip) read device arrays; the host instantiates the same stencil code with a reader that
+// (tree.hip) read device arrays; the host instantiates the same stencil code with a reader that
 // records WHICH cells are read, and derives from that the dependency levels of an exact-order sweep
 // (the reference relaxes the cells of a level, coarser leaves included, in tree order:
 // src/poisson.c:604-632, src/ftt.c:689-926).

@@ -1,12 +1,12 @@
-/* go_tree2d.c -- oracle: the reference's time step on a quadtree (2-D) or octree (3-D) with a
+/* go_tree.c -- oracle: the reference's time step on a quadtree (2-D) or octree (3-D) with a
  * statically refined patch (coarse-fine stencils) in one periodic box: the case of
  * test/periodic/periodic.gfs with BOX = 1, 2, and its 3-D analogues (FTT_3D branches of the same
  * functions: interpolate_2D1, four children per face, FTT_CELLS = 8; the reference holds no 3-D
  * golden file: in 3-D this restatement is pinned by the 2-D files through the shared code, by the
- * uniform 3-D oracle on a uniform octree, and by the z-invariant case, tests/test_oracle_tree2d.py).
+ * uniform 3-D oracle on a uniform octree, and by the z-invariant case, tests/test_oracle_tree.py).
  * TEST INFRASTRUCTURE ONLY (see gfs_oracle.h): nothing of the product links or calls this.
  *
- * Pinned on the reference's test/periodic/r1.ref and r2.ref (tests/test_oracle_tree2d.py), and on
+ * Pinned on the reference's test/periodic/r1.ref and r2.ref (tests/test_oracle_tree.py), and on
  * r0.ref through the uniform tree (BOX = 0), where it must also agree with go_timestep.c.
  *
  * Storage: level l of the tree is a dense (n+2)^2 array, n = 2^l, one ghost layer (the ghost

@@ -535,8 +535,8 @@ def _tree_sigs(L):
         f.restype, f.argtypes = res, args
 
 
-class Tree2D:
-    """go_tree2d.c: a GfsSimulation on one periodic 2-D / 3-D box with a statically refined tree
+class Tree:
+    """go_tree.c: a GfsSimulation on one periodic 2-D / 3-D box with a statically refined tree
     (coarse-fine stencils).  Levels are dense (n+2)^dim arrays [(k,) j, i] with a flag per cell:
     0 absent, 1 leaf, 2 non-leaf.  refine (x, y) or refine (x, y, z) -> level wanted there."""
     U, V, P, PMAC, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3, W, GZ, GMACZ, UN4, UN5 = range(17)

@@ -350,20 +350,20 @@ def test_refined_cube_case_3d():
     out = _run("refined_cube.gfs", {"LEVEL": level, "BOX": box, "NSTEPS": nsteps},
                exe=BIN.replace("2D", "3D"))
     inside = lambda a: not (a < -0.25 or a > 0.25)
-    s = O.Tree2D(refine=lambda x, y, z: level + box if (inside(x) and inside(y) and inside(z)) else level,
+    s = O.Tree(refine=lambda x, y, z: level + box if (inside(x) and inside(y) and inside(z)) else level,
                  dim=3)
     for l in range(s.depth + 1):
         x, y, z = s.centres(l)
-        s.values(O.Tree2D.U, l)[...] = np.sin(2. * np.pi * x) * np.cos(2. * np.pi * y) * np.cos(2. * np.pi * z) + 0.3
-        s.values(O.Tree2D.V, l)[...] = - np.cos(2. * np.pi * x) * np.sin(2. * np.pi * y) * np.cos(2. * np.pi * z) - 0.2
-        s.values(O.Tree2D.W, l)[...] = 0.1 * np.sin(2. * np.pi * (x + y)) * np.sin(2. * np.pi * z)
+        s.values(O.Tree.U, l)[...] = np.sin(2. * np.pi * x) * np.cos(2. * np.pi * y) * np.cos(2. * np.pi * z) + 0.3
+        s.values(O.Tree.V, l)[...] = - np.cos(2. * np.pi * x) * np.sin(2. * np.pi * y) * np.cos(2. * np.pi * z) - 0.2
+        s.values(O.Tree.W, l)[...] = 0.1 * np.sin(2. * np.pi * (x + y)) * np.sin(2. * np.pi * z)
     s.projection_params.tolerance = s.approx_projection_params.tolerance = 1e-5
     s.set_time(1e30, 0.75)
     s.start()
     for _ in range(nsteps):
         s.step()
     lines = out.splitlines()
-    for name, which in (("U", O.Tree2D.U), ("W", O.Tree2D.W)):
+    for name, which in (("U", O.Tree.U), ("W", O.Tree.W)):
         first = second = wsum = 0.
         infty = 0.
         for l in range(s.depth + 1):

@@ -1,5 +1,5 @@
-"""The refined-quadtree path of libgfship (csrc/tree2d.hip: coarse-fine stencils)
-against the quadtree oracle (oracle/go_tree2d.c, itself pinned on the reference's r1.ref / r2.ref),
+"""The refined-quadtree path of libgfship (csrc/tree.hip: coarse-fine stencils)
+against the quadtree oracle (oracle/go_tree.c, itself pinned on the reference's r1.ref / r2.ref),
 bit for bit, through the C ABI; and the reference's test/periodic rows from the device run."""
 import os
 
@@ -18,13 +18,13 @@ def periodic_refine(level, box):
 
 
 def periodic_pair(level, box):
-    o = O.Tree2D(periodic=(level, box))
+    o = O.Tree(periodic=(level, box))
     g = gfship.Tree(periodic_refine(level, box))
     assert g.depth == o.depth
     for l in range(o.depth + 1):
         assert np.array_equal(g.flags(l), o.flags(l)), "tree flags differ on level %d" % l
         # Init {} { U = ... V = ... } on the leaves (the oracle has done it; same numbers)
-        for var, which in ((gfship.Tree.U, O.Tree2D.U), (gfship.Tree.V, O.Tree2D.V)):
+        for var, which in ((gfship.Tree.U, O.Tree.U), (gfship.Tree.V, O.Tree.V)):
             g.upload(var, l, o.values(which, l))
     for gp, op in ((g.projection_params, o.projection_params),
                    (g.approx_projection_params, o.approx_projection_params)):
@@ -34,8 +34,8 @@ def periodic_pair(level, box):
 
 
 def assert_same_leaves(o, g, what):
-    pairs = ((gfship.Tree.U, O.Tree2D.U, "U"), (gfship.Tree.V, O.Tree2D.V, "V"),
-             (gfship.Tree.P, O.Tree2D.P, "P"), (gfship.Tree.PMAC, O.Tree2D.PMAC, "Pmac"))
+    pairs = ((gfship.Tree.U, O.Tree.U, "U"), (gfship.Tree.V, O.Tree.V, "V"),
+             (gfship.Tree.P, O.Tree.P, "P"), (gfship.Tree.PMAC, O.Tree.PMAC, "Pmac"))
     for l in range(o.depth + 1):
         leaf = o.flags(l)[1:-1, 1:-1] == 1
         if not leaf.any():
@@ -71,7 +71,7 @@ def test_tree_steps_bit_exact(level, box, steps):
         leaf = o.flags(l)[1:-1, 1:-1] == 1
         for d in range(4):
             a = g.download(gfship.Tree.UN0 + d, l)[1:-1, 1:-1][leaf]
-            b = o.values(O.Tree2D.UN0 + d, l)[1:-1, 1:-1][leaf]
+            b = o.values(O.Tree.UN0 + d, l)[1:-1, 1:-1][leaf]
             assert np.array_equal(a, b), "un[%d] differs on level %d" % (d, l)
     o.destroy()
     g.destroy()
@@ -136,10 +136,10 @@ def _refine3(kind, level, box):
 
 def _pair3(kind, level, box):
     f = _refine3(kind, level, box)
-    o = O.Tree2D(refine=f, dim=3)
+    o = O.Tree(refine=f, dim=3)
     g = gfship.Tree(f, dim=3)
     assert g.depth == o.depth
-    T, G = O.Tree2D, gfship.Tree
+    T, G = O.Tree, gfship.Tree
     for l in range(o.depth + 1):
         assert np.array_equal(g.flags(l), o.flags(l)), "octree flags differ on level %d" % l
         x, y, z = o.centres(l)
@@ -163,7 +163,7 @@ def _pair3(kind, level, box):
                                                   ("column_x", 3, 1, 2), ("blob", 3, 2, 2)])
 def test_octree_steps_bit_exact(kind, level, box, steps):
     o, g = _pair3(kind, level, box)
-    T, G = O.Tree2D, gfship.Tree
+    T, G = O.Tree, gfship.Tree
     pairs = ((G.U, T.U, "U"), (G.V, T.V, "V"), (G.W, T.W, "W"), (G.P, T.P, "P"), (G.PMAC, T.PMAC, "Pmac"),
              (G.UN0, T.UN0, "un0"), (G.UN1, T.UN1, "un1"), (G.UN2, T.UN2, "un2"), (G.UN3, T.UN3, "un3"),
              (G.UN4, T.UN4, "un4"), (G.UN5, T.UN5, "un5"))

@@ -1,4 +1,4 @@
-"""The quadtree oracle (oracle/go_tree2d.c: the coarse-fine stencils of SURVEY.md 8f-4) against the
+"""The quadtree oracle (oracle/go_tree.c: the coarse-fine stencils of SURVEY.md 8f-4) against the
 reference's own golden files of test/periodic: r1.ref and r2.ref (one / two extra levels inside the
 square |x|, |y| < 0.25), every printed digit, and r0.ref through the uniform tree, where it must
 also give the bits of the uniform oracle (go_timestep.c)."""
@@ -16,7 +16,7 @@ def _rows(golden_dir, name):
 
 
 def _run(level, box):
-    s = O.Tree2D(periodic=(level, box))
+    s = O.Tree(periodic=(level, box))
     s.run()
     _, second, infty = s.error_norm()
     return s, ["%.3e" % second, "%.3e" % infty]
@@ -25,7 +25,7 @@ def _run(level, box):
 def test_tree_shape_box2():
     """the 2:1 constraints of ftt.c:45-83 and the corner rule of ftt.c:2013-2074: two extra levels
     inside the square make a ring of cells one level up around it, corners included"""
-    s = O.Tree2D(periodic=(5, 2))
+    s = O.Tree(periodic=(5, 2))
     assert s.depth == 7
     leaves = [int(np.sum(s.flags(l)[1:-1, 1:-1] == 1)) for l in range(s.depth + 1)]
     # 16 x 16 cells of level 5 refined twice; the ring of 18^2 - 16^2 = 68 cells refined once
@@ -38,7 +38,7 @@ def test_tree_shape_box2():
 def test_periodic_refined_patch_matches_ref(golden_dir, box, levels):
     """test/periodic/periodic.sh: L2 and Linf error of U at t = 0.5 as printed by OutputErrorNorm,
     against r0.ref / r1.ref / r2.ref (the level-7 rows and BOX = 2 at level 6 take minutes on one
-    core: tools/tree2d_ref_rows.py prints them)"""
+    core: tools/tree_ref_rows.py prints them)"""
     rows = {int(r[0]): r[1:3] for r in _rows(golden_dir, "periodic_r%d.ref" % box)}
     for level in levels:
         s, got = _run(level, box)
@@ -50,7 +50,7 @@ def test_uniform_tree_equals_uniform_oracle():
     """BOX = 0: the tree code runs the same statements as go_timestep.c on a uniform grid"""
     from flow_cases import oracle_periodic
     level = 5
-    a = O.Tree2D(periodic=(level, 0))
+    a = O.Tree(periodic=(level, 0))
     b = oracle_periodic(level)
     a.start()
     b.start()
@@ -58,7 +58,7 @@ def test_uniform_tree_equals_uniform_oracle():
         a.step()
         b.step()
     assert a.t == b.t and a.dt == b.advection_params.dt
-    for which, f in ((O.Tree2D.U, b.u[0]), (O.Tree2D.V, b.u[1]), (O.Tree2D.P, b.p)):
+    for which, f in ((O.Tree.U, b.u[0]), (O.Tree.V, b.u[1]), (O.Tree.P, b.p)):
         assert np.array_equal(a.values(which, level)[1:-1, 1:-1], f.interior())
     a.destroy()
 
@@ -70,10 +70,10 @@ def test_uniform_tree_equals_uniform_oracle():
 def test_uniform_octree_equals_uniform_oracle():
     from flow_cases import oracle_taylor_green, taylor_green_3d
     level = 4
-    a = O.Tree2D(refine=lambda x, y, z: level, dim=3)
+    a = O.Tree(refine=lambda x, y, z: level, dim=3)
     b = oracle_taylor_green(level)
     x, y, z = a.centres(level)
-    for which, arr in zip((O.Tree2D.U, O.Tree2D.V, O.Tree2D.W), taylor_green_3d(x, y, z)):
+    for which, arr in zip((O.Tree.U, O.Tree.V, O.Tree.W), taylor_green_3d(x, y, z)):
         a.values(which, level)[...] = arr
     a.start()
     b.start()
@@ -81,7 +81,7 @@ def test_uniform_octree_equals_uniform_oracle():
         a.step()
         b.step()
     assert a.t == b.t and a.dt == b.advection_params.dt
-    for which, f in ((O.Tree2D.U, b.u[0]), (O.Tree2D.V, b.u[1]), (O.Tree2D.W, b.u[2]), (O.Tree2D.P, b.p)):
+    for which, f in ((O.Tree.U, b.u[0]), (O.Tree.V, b.u[1]), (O.Tree.W, b.u[2]), (O.Tree.P, b.p)):
         assert np.array_equal(a.values(which, level)[1:-1, 1:-1, 1:-1], f.interior())
     a.destroy()
 
@@ -91,8 +91,8 @@ def _column(level, box, axis, tol=1e-6):
     refined inside the square column |.|, |.| < 1/4 along that axis"""
     p, q = [c for c in range(3) if c != axis]           # the two coordinates of the plane
     inside = lambda a, b: not (a < -0.25 or a > 0.25 or b < -0.25 or b > 0.25)
-    s = O.Tree2D(refine=lambda x, y, z: level + box if inside((x, y, z)[p], (x, y, z)[q]) else level, dim=3)
-    vel = (O.Tree2D.U, O.Tree2D.V, O.Tree2D.W)
+    s = O.Tree(refine=lambda x, y, z: level + box if inside((x, y, z)[p], (x, y, z)[q]) else level, dim=3)
+    vel = (O.Tree.U, O.Tree.V, O.Tree.W)
     for l in range(s.depth + 1):
         xyz = s.centres(l)
         s.values(vel[p], l)[...] = 1. - 2. * np.cos(2. * np.pi * xyz[p]) * np.sin(2. * np.pi * xyz[q])
@@ -127,7 +127,7 @@ def test_octree_column_reproduces_the_quadtree_run(box):
     halves: the errors of the run are those of the 2-D run up to the tolerance of the projections
     (1e-6), and W stays at that level"""
     level = 4 if box == 1 else 3
-    s2 = O.Tree2D(periodic=(level, box))
+    s2 = O.Tree(periodic=(level, box))
     s2.run()
     _, l2, linf = s2.error_norm()
     s, var, wvar, p, q = _column(level, box, 2)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Prints the rows of test/periodic's r0 / r1 / r2 files as computed by the quadtree oracle
-(oracle/go_tree2d.c) next to the reference's: the long cases tests/test_oracle_tree2d.py leaves out
+(oracle/go_tree.c) next to the reference's: the long cases tests/test_oracle_tree.py leaves out
 (level 7; BOX = 2 at level 6 and 7 take 1 to 10 minutes on one core).
-usage: tree2d_ref_rows.py [boxes, e.g. 1,2] [levels, e.g. 5,6,7]"""
+usage: tree_ref_rows.py [boxes, e.g. 1,2] [levels, e.g. 5,6,7]"""
 import os
 import sys
 import time
@@ -21,7 +21,7 @@ for box in boxes:
             ref[int(w[0])] = w[1:3]
     for level in levels:
         t0 = time.time()
-        s = O.Tree2D(periodic=(level, box))
+        s = O.Tree(periodic=(level, box))
         n = s.run()
         _, second, infty = s.error_norm()
         got = ["%.3e" % second, "%.3e" % infty]
