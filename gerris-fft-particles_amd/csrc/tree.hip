@@ -80,6 +80,10 @@ struct gfship_tree {
   Topo H, D;
   std::vector<unsigned char> hflag;
   unsigned char * dflag = nullptr;
+  std::vector<int> h_nbtab, h_child0;
+  std::vector<unsigned char> h_cmask, h_idtab;
+  int * d_nbtab = nullptr, * d_child0 = nullptr;
+  unsigned char * d_cmask = nullptr, * d_idtab = nullptr;
   int ncell = 0;
   double * var[V_NVAR] = {};
   int nleaves = 0;
@@ -1168,6 +1172,7 @@ void tree_free (gfship_tree * tr)
 {
   if (!tr) return;
   (void) hipFree (tr->dflag);
+  (void) hipFree (tr->d_nbtab); (void) hipFree (tr->d_child0); (void) hipFree (tr->d_cmask); (void) hipFree (tr->d_idtab);
   for (double * p : tr->var) (void) hipFree (p);
   (void) hipFree (tr->leaves);
   (void) hipFree (tr->ghost_leaves);
@@ -1276,8 +1281,48 @@ int gfship_tree_create (gfship_tree ** out, int dim, gfship_refine_fn refine, vo
       return hip_fail (e_, #call, __FILE__, __LINE__); } } while (0)
   TRYHIP (hipMalloc ((void **) &tr->dflag, tr->ncell));
   TRYHIP (hipMemcpy (tr->dflag, tr->hflag.data (), tr->ncell, hipMemcpyHostToDevice));
+  {
+    // the tables of Topo (tree.hpp), from the computed answers
+    Topo & H = tr->H;
+    const int nd = H.nd ();
+    tr->h_nbtab.assign ((size_t) tr->ncell*nd, -1);
+    tr->h_child0.assign (tr->ncell, 0);
+    tr->h_cmask.assign (tr->ncell, 0);
+    tr->h_idtab.assign (tr->ncell, 0);
+    for (int l = 0; l <= H.depth; l++)
+      for (int q = 0; q < H.lsize (l); q++) {
+	const int g = H.off[l] + q;
+	if (tr->hflag[g] == NONE)
+	  continue;
+	const Cell c = { l, q };
+	for (int d = 0; d < nd; d++) {
+	  const Cell nb = H.neighbor (c, d);
+	  tr->h_nbtab[(size_t) g*nd + d] = !exists (nb) ? -1 : nb.l == l ? nb.q : - nb.q - 2;
+	}
+	tr->h_idtab[g] = (unsigned char) (H.id (c) | (H.interior (c) ? 8 : 0));
+	if (l < H.depth) {
+	  const int rr = H.r (l + 1);
+	  tr->h_child0[g] = 2*H.ci (c) - 1 + rr*(2*H.cj (c) + (dim == 3 ? rr*2*H.ck (c) : 0));
+	  for (int k = 0; k < H.nc (); k++)
+	    if (exists (H.child (c, k)))
+	      tr->h_cmask[g] |= (unsigned char) (1 << k);
+	}
+      }
+    H.nbtab = tr->h_nbtab.data ();
+    H.child0 = tr->h_child0.data ();
+    H.cmask = tr->h_cmask.data ();
+    H.idtab = tr->h_idtab.data ();
+  }
+  TRY (to_device (tr->h_nbtab, &tr->d_nbtab));
+  TRY (to_device (tr->h_child0, &tr->d_child0));
+  TRY (to_device (tr->h_cmask, &tr->d_cmask));
+  TRY (to_device (tr->h_idtab, &tr->d_idtab));
   tr->D = tr->H;
   tr->D.flag = tr->dflag;
+  tr->D.nbtab = tr->d_nbtab;
+  tr->D.child0 = tr->d_child0;
+  tr->D.cmask = tr->d_cmask;
+  tr->D.idtab = tr->d_idtab;
   for (int v = 0; v < V_NVAR; v++) {
     TRYHIP (hipMalloc ((void **) &tr->var[v], tr->ncell*sizeof (double)));
     TRYHIP (hipMemset (tr->var[v], 0, tr->ncell*sizeof (double)));

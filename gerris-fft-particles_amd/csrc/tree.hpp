@@ -35,6 +35,13 @@ struct Topo {
   int depth;
   int off[GFSHIP_MAXLEVEL + 2];         // first cell of each level in the concatenated arrays
   const unsigned char * flag;
+  // the tree is static: once it is built the answers of neighbor (), child () and id () are read
+  // from tables (one load instead of a chain of index divisions and flag loads -- the sweeps of a
+  // tree are bound by the latency of such chains); nullptr while the tree is being built
+  const int * nbtab = nullptr;          // [cell*nd + d]: q of the neighbour (>= 0 same level, <= -2: -q - 2 one level up, -1 none)
+  const int * child0 = nullptr;         // [cell]: q of the child (2i - 1, 2j, 2k) on the next level
+  const unsigned char * cmask = nullptr;// [cell]: bit c = child c exists
+  const unsigned char * idtab = nullptr;// [cell]: FTT_CELL_ID | 8*interior
 
   __host__ __device__ inline int nd () const { return 2*dim; }           // FTT_NEIGHBORS
   __host__ __device__ inline int nc () const { return 1 << dim; }        // FTT_CELLS
@@ -60,10 +67,17 @@ struct Topo {
   }
   // FTT_CELL_ID (src/ftt.c:301-316): bit 0 = +x, bit 1 = -y, bit 2 = -z
   __host__ __device__ inline int id (Cell c) const {
+    if (idtab) return idtab[gi (c)] & 7;
     return ((ci (c) + 1) & 1) + 2*(cj (c) & 1) + (dim == 3 ? 4*(ck (c) & 1) : 0);
   }
   // ftt_cell_neighbor, src/ftt.h:518-573
   __host__ __device__ inline Cell neighbor (Cell c, int d) const {
+    if (nbtab) {
+      const int v = nbtab[gi (c)*nd () + d];
+      Cell nb = { c.l, v };
+      if (v <= -2) { nb.l = c.l - 1; nb.q = - v - 2; }
+      return nb;
+    }
     const int i = ci (c) + (d == 0) - (d == 1), j = cj (c) + (d == 2) - (d == 3),
       k = ck (c) + (d == 4) - (d == 5);
     Cell nb = make (c.l, i, j, k);
@@ -73,6 +87,15 @@ struct Topo {
     return make (c.l - 1, (i + 1)/2, (j + 1)/2, (k + 1)/2);
   }
   __host__ __device__ inline Cell child (Cell c, int k) const {
+    if (cmask) {
+      const int g = gi (c);
+      Cell ch = { c.l + 1, -1 };
+      if ((cmask[g] >> k) & 1) {
+	const int rr = r (c.l + 1);
+	ch.q = child0[g] + (k & 1) - rr*((k >> 1) & 1) - (dim == 3 ? rr*rr*((k >> 2) & 1) : 0);
+      }
+      return ch;
+    }
     return make (c.l + 1, 2*ci (c) - 1 + (k & 1), 2*cj (c) - ((k >> 1) & 1), 2*ck (c) - ((k >> 2) & 1));
   }
   // ftt_cell_children_direction, src/ftt.h:321-355: child i (of ncd ()) on the side d of the cell
@@ -97,6 +120,7 @@ struct Topo {
     return child (c, idx);
   }
   __host__ __device__ inline bool interior (Cell c) const {
+    if (idtab) return (idtab[gi (c)] & 8) != 0;
     const int i = ci (c), j = cj (c), k = ck (c);
     return i >= 1 && j >= 1 && k >= 1 && i <= n (c.l) && j <= n (c.l) && k <= n (c.l);
   }
