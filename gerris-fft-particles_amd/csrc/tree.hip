@@ -60,6 +60,14 @@ struct Sweep {              // T_LEVEL_LEAFS (m) in dependency levels
   Cell * cells = nullptr;             // device, sorted by level (stable: traversal order inside)
   int * lev_off = nullptr;            // device, nlev + 1
   Ghost * ghosts = nullptr; int nghosts = 0;   // ghost cells of the selection
+  // the stencils of the sweep compiled once (the tree is static): per cell, in the order of `cells',
+  // a stream of codes / counts (ti), of constant coefficients (td) and of the cells whose values it
+  // reads (tv); the cells of a dependency level in chunks that fit the LDS (stencil_tape)
+  int * ti = nullptr, * tv = nullptr;
+  double * td = nullptr;
+  int * cell_off = nullptr;           // device, 3*(ncells + 1): start of each cell in ti / td / tv
+  int * chunk = nullptr; int nchunks = 0;   // device, 2*(nchunks): first cell, dependency level; + end marker
+  bool taped = false;
 };
 
 struct DevReader {
@@ -199,6 +207,138 @@ t_relax_loop (Topo T, const Cell * cells, const int * lev_off, int nlev, const G
 	const Cell c = cells[t];
 	const int g = T.gi (c);
 	u[g] = relax_cell (T, c, R, rhs[g], omega, max_level);
+      }
+      __syncthreads ();
+    }
+    if (s + 1 < nrelax) {
+      for (int t = threadIdx.x; t < ngh; t += blockDim.x)
+	u[gh[t].g] = u[gh[t].img];
+      __syncthreads ();
+    }
+  }
+}
+
+// ---- compiled stencils ------------------------------------------------------------------------
+// relax_cell / face_gradient (tree.hpp) walk the tree for every cell of every sweep: a chain of
+// dependent loads (neighbour table, flags, children, values) that one thread pays in full, and the
+// slowest cell of a dependency level -- a coarse leaf with fine neighbours reads ~40 values through
+// two levels of interpolation -- sets the time of the level.  The tree does not change: the host
+// walks it once per cell (stencil_tape, below) and writes down what the walk found: which values are
+// read, with which constant coefficients, combined in which order.  The sweep kernel stages the
+// streams of a chunk of cells in LDS together with the gathered values (one independent load per
+// thread), then evaluates them from LDS: same operations in the same order as the template code.
+enum { K_NONE = 0, K_SAME = 1, K_FC = 2, K_DEEP = 3 };
+
+struct TapeCursor { const int * ti; const double * td; const double * tv; };
+
+// p.b of interpolate_1D1 / interpolate_2D1 from the streams: sum of a_j * P_j, P_j a value or the
+// average of the children of a refined neighbour (average_neighbor_value)
+__device__ inline double tape_interpolation (TapeCursor & c)
+{
+  const int nt = *c.ti++;
+  double pb = 0.;
+  for (int t = 0; t < nt; t++) {
+    const double a = *c.td++;
+    const int cnt = *c.ti++;
+    double P;
+    if (cnt == 0)
+      P = *c.tv++;
+    else {
+      double av = 0., n = 0.;
+      for (int k = 0; k < cnt; k++) {
+	n += 1.;
+	av += 1.*(*c.tv++);
+      }
+      P = av/n;
+    }
+    pb += a*P;
+  }
+  return pb;
+}
+
+// the sums g.a, g.b of relax / residual_set over the faces of a cell (src/poisson.c:507-557,634-678)
+__device__ inline void tape_cell (TapeCursor & c, int nd, int dim, int ncd, double & ga, double & gb)
+{
+  ga = 0.; gb = 0.;
+  for (int d = 0; d < nd; d++) {
+    const int kind = *c.ti++;
+    if (kind == K_NONE)
+      continue;
+    double na, nb;
+    if (kind == K_SAME) {
+      na = 1.;
+      nb = *c.tv++;
+    }
+    else if (kind == K_FC) {      /* gradient_fine_coarse towards a coarser neighbour */
+      const double cb = *c.td++;
+      const double uN = *c.tv++;
+      const double pb = tape_interpolation (c);
+      const double gc = 2.*pb/3.;
+      na = 2./3.;
+      nb = cb*uN + gc;
+    }
+    else {                        /* the fine cells behind a face of a coarser leaf */
+      const int nch = *c.ti++;
+      na = 0.; nb = 0.;
+      for (int i = 0; i < nch; i++) {
+	const double gbi = *c.td++;
+	const double uch = *c.tv++;
+	const double pb = tape_interpolation (c);
+	const double gc = 2.*pb/3.;
+	na += 1.*gbi;
+	nb += 1.*((2./3.)*uch - gc);
+      }
+      if (dim > 2) {
+	na /= ncd/2.;
+	nb /= ncd/2.;
+      }
+    }
+    ga += na;
+    gb += nb;
+  }
+}
+
+#define TAPE_LDS_BYTES (120*1024)
+
+// relax_loop (src/poisson.c:1070-1089) of one level from the compiled stencils: one workgroup; per
+// chunk of a dependency level: stage the streams and gather the values (all threads), barrier,
+// one thread per cell evaluates from LDS and stores the new value, barrier
+__global__ void __launch_bounds__(1024)
+t_relax_tape (Topo T, const Cell * cells, const int * cell_off, int ncells, const int * chunk, int nchunks,
+	      const int * ti_g, const double * td_g, const int * tv_g,
+	      const Ghost * gh, int ngh, double * u, const double * rhs, unsigned nrelax, double omega)
+{
+  extern __shared__ double lds[];
+  const int nd = T.nd (), dim = T.dim, ncd = T.ncd ();
+  for (int t = threadIdx.x; t < ngh; t += blockDim.x)
+    u[gh[t].g] = u[gh[t].img];
+  __syncthreads ();
+  for (unsigned s = 0; s < nrelax; s++) {
+    for (int k = 0; k < nchunks; k++) {
+      const int c0 = chunk[k], c1 = chunk[k + 1];
+      const int i0 = cell_off[3*c0], i1 = cell_off[3*c1];
+      const int d0 = cell_off[3*c0 + 1], d1 = cell_off[3*c1 + 1];
+      const int v0 = cell_off[3*c0 + 2], v1 = cell_off[3*c1 + 2];
+      // LDS: values, then constants, then codes
+      double * lv = lds, * ld = lds + (v1 - v0);
+      int * li = (int *) (ld + (d1 - d0));
+      for (int t = threadIdx.x; t < v1 - v0; t += blockDim.x)
+	lv[t] = u[tv_g[v0 + t]];
+      for (int t = threadIdx.x; t < d1 - d0; t += blockDim.x)
+	ld[t] = td_g[d0 + t];
+      for (int t = threadIdx.x; t < i1 - i0; t += blockDim.x)
+	li[t] = ti_g[i0 + t];
+      __syncthreads ();
+      for (int c = c0 + threadIdx.x; c < c1; c += blockDim.x) {
+	TapeCursor cur = { li + (cell_off[3*c] - i0), ld + (cell_off[3*c + 1] - d0), lv + (cell_off[3*c + 2] - v0) };
+	const double self = *cur.tv++;
+	double ga, gb;
+	tape_cell (cur, nd, dim, ncd, ga, gb);
+	const int g = T.gi (cells[c]);
+	double x = 0.;
+	if (ga != 0.)
+	  x = dim == 2 ? (1. - omega)*self + omega*(gb - rhs[g])/ga : (gb - rhs[g])/ga;
+	u[g] = x;
       }
       __syncthreads ();
     }
@@ -808,6 +948,9 @@ void ghost_list (const Topo & T, int flags, int max_depth, std::vector<Ghost> & 
   }
 }
 
+int stencil_tape (gfship_tree * tr, int m, Sweep * S, const std::vector<Cell> & sorted,
+		  const std::vector<int> & lev_off);
+
 // dependency levels of an exact-order sweep over `order': a cell runs after every earlier cell
 // it reads (it must see the new value) and after every earlier cell that reads it (which must
 // still see the old one)
@@ -857,6 +1000,133 @@ int sweep_plan (gfship_tree * tr, int m, Sweep * S)
   if ((e = to_device (sorted, &S->cells)) || (e = to_device (off, &S->lev_off)) ||
       (e = to_device (gh, &S->ghosts)))
     return e;
+  return stencil_tape (tr, m, S, sorted, off);
+}
+
+// ---- compiled stencils: the host side ---------------------------------------------------------
+
+struct TapeOut { std::vector<int> ti, tv; std::vector<double> td; };
+
+// interpolate_1D1 / interpolate_2D1 in the coarse cell A towards the fine cell (face: fine -> A in
+// direction dface), src/fluid.c:178-245: the terms of p.b go to the streams, p.a is returned
+double tape_interpolation_gen (const Topo & T, Cell fine, Cell A, int dface, TapeOut & o)
+{
+  const int id = T.id (fine);
+  int dirs[2], ndirs;
+  if (T.dim == 2) { dirs[0] = perpendicular (dface, id); ndirs = 1; }
+  else { dirs[0] = perpendicular3 (dface, id, 0); dirs[1] = perpendicular3 (dface, id, 1); ndirs = 2; }
+  double pa = 1.;
+  const size_t nt_at = o.ti.size ();
+  o.ti.push_back (0);
+  int nt = 0;
+  for (int w = 0; w < ndirs; w++) {
+    const Cell nb = T.neighbor (A, dirs[w]);
+    if (!exists (nb))
+      continue;
+    double x2 = 1.;
+    std::vector<int> idx;
+    int cnt = 0;
+    if (T.leaf (nb))
+      idx.push_back (T.gi (nb));
+    else {
+      for (int i = 0; i < T.ncd (); i++) {
+	const Cell ch = T.child_direction (nb, dirs[w] ^ 1, i);
+	if (exists (ch)) { idx.push_back (T.gi (ch)); cnt++; }
+      }
+      if (cnt > 0)
+	x2 = 3./4.;
+      else
+	idx.push_back (T.gi (A));       /* average_neighbor_value falls back on the cell of the face */
+    }
+    const double a = (1./4.)/x2;
+    o.td.push_back (a);
+    o.ti.push_back (cnt);
+    for (int g : idx) o.tv.push_back (g);
+    pa -= a;
+    nt++;
+  }
+  o.ti[nt_at] = nt;
+  return pa;
+}
+
+// one cell of the sweep of level max_level: what face_gradient (tree.hpp) does for each direction
+void tape_cell_gen (const Topo & T, Cell cell, int max_level, TapeOut & o)
+{
+  o.tv.push_back (T.gi (cell));          /* the value of the cell itself */
+  for (int d = 0; d < T.nd (); d++) {
+    const Cell nb = T.neighbor (cell, d);
+    if (!exists (nb)) { o.ti.push_back (K_NONE); continue; }
+    if (nb.l < cell.l) {
+      o.ti.push_back (K_FC);
+      const size_t cb_at = o.td.size ();
+      o.td.push_back (0.);
+      o.tv.push_back (T.gi (nb));
+      const double pa = tape_interpolation_gen (T, cell, nb, d, o);
+      o.td[cb_at] = 2.*pa/3.;
+    }
+    else if (cell.l == max_level || T.leaf (nb)) {
+      o.ti.push_back (K_SAME);
+      o.tv.push_back (T.gi (nb));
+    }
+    else {
+      o.ti.push_back (K_DEEP);
+      const size_t n_at = o.ti.size ();
+      o.ti.push_back (0);
+      int nch = 0;
+      for (int i = 0; i < T.ncd (); i++) {
+	const Cell ch = T.child_direction (nb, d ^ 1, i);
+	if (!exists (ch))
+	  continue;
+	const size_t gb_at = o.td.size ();
+	o.td.push_back (0.);
+	o.tv.push_back (T.gi (ch));
+	const double pa = tape_interpolation_gen (T, ch, cell, d ^ 1, o);
+	o.td[gb_at] = 2.*pa/3.;
+	nch++;
+      }
+      o.ti[n_at] = nch;
+    }
+  }
+}
+
+int stencil_tape (gfship_tree * tr, int m, Sweep * S, const std::vector<Cell> & sorted,
+		  const std::vector<int> & lev_off)
+{
+  const Topo & T = tr->H;
+  TapeOut o;
+  std::vector<int> cell_off;
+  for (size_t c = 0; c < sorted.size (); c++) {
+    cell_off.push_back ((int) o.ti.size ()); cell_off.push_back ((int) o.td.size ()); cell_off.push_back ((int) o.tv.size ());
+    tape_cell_gen (T, sorted[c], m, o);
+  }
+  cell_off.push_back ((int) o.ti.size ()); cell_off.push_back ((int) o.td.size ()); cell_off.push_back ((int) o.tv.size ());
+  // chunks: consecutive cells of one dependency level whose streams fit the LDS
+  std::vector<int> chunk;
+  for (size_t L = 0; L + 1 < lev_off.size (); L++) {
+    int c = lev_off[L];
+    while (c < lev_off[L + 1]) {
+      chunk.push_back (c);
+      int e = c;
+      while (e < lev_off[L + 1]) {
+	const size_t bytes = 8*(size_t) (cell_off[3*(e + 1) + 2] - cell_off[3*c + 2]) +
+	  8*(size_t) (cell_off[3*(e + 1) + 1] - cell_off[3*c + 1]) + 4*(size_t) (cell_off[3*(e + 1)] - cell_off[3*c]) + 8;
+	if (bytes > TAPE_LDS_BYTES)
+	  break;
+	e++;
+      }
+      if (e == c) return GFSHIP_EUNSUPPORTED;      /* one cell larger than the LDS: cannot happen */
+      c = e;
+    }
+  }
+  S->nchunks = (int) chunk.size ();
+  chunk.push_back ((int) sorted.size ());
+  int e;
+  if ((e = to_device (o.ti, &S->ti)) || (e = to_device (o.td, &S->td)) || (e = to_device (o.tv, &S->tv)) ||
+      (e = to_device (cell_off, &S->cell_off)) || (e = to_device (chunk, &S->chunk)))
+    return e;
+  if (o.td.empty ())      /* to_device leaves nullptr for an empty stream: never dereferenced */
+    S->td = nullptr;
+  S->taped = true;
   return 0;
 }
 
@@ -933,8 +1203,23 @@ int residual_norm (gfship_tree * tr, const double * u, const double * rhs, doubl
 int relax_loop (gfship_tree * tr, int m, unsigned nrelax, double omega)
 {
   Sweep & S = tr->sweep[m];
-  t_relax_loop<<<1, 1024, 0, tr->stream>>> (tr->D, S.cells, S.lev_off, S.nlev, S.ghosts, S.nghosts,
-					     tr->var[V_DP], tr->var[V_RES], nrelax, omega, m);
+  static int use_template = -1;
+  if (use_template < 0) {
+    const char * e = getenv ("GFSHIP_TREE_TEMPLATE_RELAX");   /* 1: the stencil code walks the tree in every sweep */
+    use_template = e ? atoi (e) : 0;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {       /* more than 64 KB of dynamic LDS needs the attribute */
+    GFSHIP_HIP (hipFuncSetAttribute ((const void *) t_relax_tape, hipFuncAttributeMaxDynamicSharedMemorySize,
+				     TAPE_LDS_BYTES));
+    attr_set = true;
+  }
+  if (S.taped && !use_template)
+    t_relax_tape<<<1, 1024, TAPE_LDS_BYTES, tr->stream>>> (tr->D, S.cells, S.cell_off, S.ncells, S.chunk, S.nchunks,
+	S.ti, S.td, S.tv, S.ghosts, S.nghosts, tr->var[V_DP], tr->var[V_RES], nrelax, omega);
+  else
+    t_relax_loop<<<1, 1024, 0, tr->stream>>> (tr->D, S.cells, S.lev_off, S.nlev, S.ghosts, S.nghosts,
+					       tr->var[V_DP], tr->var[V_RES], nrelax, omega, m);
   KCHECK ();
   return 0;
 }
@@ -1179,6 +1464,8 @@ void tree_free (gfship_tree * tr)
   for (int l = 0; l <= GFSHIP_MAXLEVEL; l++) {
     (void) hipFree (tr->nonleaf[l]);
     (void) hipFree (tr->sweep[l].cells); (void) hipFree (tr->sweep[l].lev_off); (void) hipFree (tr->sweep[l].ghosts);
+    (void) hipFree (tr->sweep[l].ti); (void) hipFree (tr->sweep[l].td); (void) hipFree (tr->sweep[l].tv);
+    (void) hipFree (tr->sweep[l].cell_off); (void) hipFree (tr->sweep[l].chunk);
   }
   for (FaceSet & F : tr->fs) { (void) hipFree (F.faces); (void) hipFree (F.inc_off); (void) hipFree (F.inc); (void) hipFree (F.fval); }
   (void) hipFree (tr->d_red);
