@@ -1596,13 +1596,28 @@ int run_tree (Run & R)
       return 1;
     }
   }
-  for (const char * nm : { "Divergence", "Vorticity" }) {
-    int v = R.var_index (nm);
-    std::string name = nm;
+  {
+    int v = R.var_index ("Vorticity");
     if (v >= 0)
-      R.vars[v].derive = [name] (Variable &) {
-	fprintf (stderr, "gfship: the variable %s is not supported on a refined tree\n", name.c_str ());
+      R.vars[v].derive = [] (Variable &) {
+	fprintf (stderr, "gfship: the variable Vorticity is not supported on a refined tree\n");
 	exit (1);
+      };
+    v = R.var_index ("Divergence");
+    Run * pr = &R;
+    if (v >= 0)      /* gfs_divergence on the device, then one value per leaf */
+      R.vars[v].derive = [pr] (Variable & V) {
+	Run & R = *pr;
+	CHECK (gfship_tree_divergence (R.tree));
+	std::vector<std::vector<double>> lev (gfship_tree_depth (R.tree) + 1);
+	for (size_t c = 0; c < R.leaf_l.size (); c++) {
+	  int l = R.leaf_l[c];
+	  if (lev[l].empty ()) {
+	    lev[l].resize (R.tree_level_size (l));
+	    CHECK (gfship_tree_download (R.tree, GFSHIP_TREE_DIV, l, lev[l].data ()));
+	  }
+	  V.host[c] = lev[l][R.tree_index (c)];
+	}
       };
   }
   CHECK (gfship_tree_create (&R.tree, R.dim, refine_hook, &R, R.device));

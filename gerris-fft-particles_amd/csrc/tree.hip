@@ -38,7 +38,7 @@ enum { V_P, V_PMAC, V_U /* 3 */, V_G = V_U + 3 /* 3 */, V_GM = V_G + 3 /* 3 */, 
 
 // the variables of the C ABI (GFSHIP_TREE_*) -> storage
 const int abi_var[] = { V_P, V_PMAC, V_U, V_U + 1, V_G, V_G + 1, V_GM, V_GM + 1, V_UN, V_UN + 1, V_UN + 2,
-			V_UN + 3, V_U + 2, V_G + 2, V_GM + 2, V_UN + 4, V_UN + 5 };
+			V_UN + 3, V_U + 2, V_G + 2, V_GM + 2, V_UN + 4, V_UN + 5, V_DIV };
 const int abi_nvar = sizeof (abi_var)/sizeof (abi_var[0]);
 
 struct P3 { double * p[3]; };       // the components of a vector
@@ -706,6 +706,25 @@ __global__ void t_gather_flux (Topo T, const Cell * cells, int n, const FaceRec 
   if (g)
     x -= g[gi]*dt;
   v[gi] = x;
+}
+
+// gfs_divergence, src/fluid.c:2357-2376: the derived variable `Divergence' of the leaves
+__global__ void t_divergence_centered (Topo T, const Cell * cells, int n, P3 u, double * div)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Cell cell = cells[t];
+  double d = 0.;
+  Face f;
+  f.cell = cell;
+  for (f.d = 0; f.d < T.nd (); f.d++) {
+    f.neighbor = T.neighbor (cell, f.d);
+    if (exists (f.neighbor)) {
+      DevReader R = { u.p[f.d/2] };
+      d += 1.*((f.d & 1) ? -1. : 1.)*face_interpolated_value_generic (T, f, R);
+    }
+  }
+  div[T.gi (cell)] = d/(1.*T.size (cell));
 }
 
 // gfs_domain_cfl, src/domain.c:2824-2923: the minimum of (length/|u|)^2 over faces and cells
@@ -1697,6 +1716,18 @@ int gfship_tree_set_next_event (gfship_tree * tr, gfship_next_event_fn fn, void 
 double gfship_tree_time (const gfship_tree * tr) { return tr->t; }
 double gfship_tree_dt (const gfship_tree * tr) { return tr->dt; }
 unsigned gfship_tree_iter (const gfship_tree * tr) { return tr->iter; }
+
+/* gfs_divergence of (U, V, W) on the leaves into the variable GFSHIP_TREE_DIV (the scratch `div' of
+   the projections: valid until the next step) */
+int gfship_tree_divergence (gfship_tree * tr)
+{
+  GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_divergence: null tree");
+  GFSHIP_HIP (hipSetDevice (tr->device));
+  GFSHIP_HIP (hipMemsetAsync (tr->var[V_DIV], 0, tr->ncell*sizeof (double), tr->stream));
+  t_divergence_centered<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, p3 (tr, V_U), tr->var[V_DIV]);
+  KCHECK ();
+  return GFSHIP_OK;
+}
 
 /* the cells of the sweep of level `level' and the number of dependency levels they form */
 int gfship_tree_sweep_levels (const gfship_tree * tr, int level, int * ncells, int * nlevels)

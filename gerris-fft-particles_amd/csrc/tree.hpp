@@ -314,6 +314,25 @@ __host__ __device__ inline double face_interpolated_value (const Topo & T, const
   return v (T, face.cell);
 }
 
+// gfs_face_interpolated_value_generic, src/fluid.c:2200-2221
+template <class V>
+__host__ __device__ inline double face_interpolated_value_generic (const Topo & T, const Face & face, V & v)
+{
+  if (!exists (face.neighbor) || T.leaf (face.neighbor) || face.neighbor.l < face.cell.l)
+    return face_interpolated_value (T, face, v);
+  Face f;
+  f.neighbor = face.cell;
+  f.d = face.d ^ 1;
+  const int n = T.ncd ();
+  double avg = 0.;
+  for (int i = 0; i < n; i++) {
+    f.cell = T.child_direction (face.neighbor, f.d, i);
+    if (exists (f.cell))
+      avg += face_interpolated_value (T, f, v)*1.;
+  }
+  return avg == 0. ? 0. : avg/(1.*n);
+}
+
 // relax2D (src/poisson.c:532-557) / relax (:507-530, no omega), dia = 0, unit weights: the new value of u at `cell'
 template <class V>
 __host__ __device__ inline double relax_cell (const Topo & T, Cell cell, V & u, double rhs, double omega,

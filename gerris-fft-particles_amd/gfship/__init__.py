@@ -168,6 +168,7 @@ SIGNATURES = {
     "gfship_tree_start": (_i, [_vp]),
     "gfship_tree_step": (_i, [_vp]),
     "gfship_tree_sweep_levels": (_i, [_vp, _i, _pi, _pi]),
+    "gfship_tree_divergence": (_i, [_vp]),
 }
 
 
@@ -660,7 +661,7 @@ REFINE_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_double, C.c_void
 class Tree:
     """gfship_tree: a GfsSimulation on one periodic box refined by a GfsRefine function (coarse-fine
     stencils; quadtree or octree).  refine (x, y) or refine (x, y, z) -> level wanted there."""
-    P, PMAC, U, V, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3, W, GZ, GMACZ, UN4, UN5 = range(17)
+    P, PMAC, U, V, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3, W, GZ, GMACZ, UN4, UN5, DIV = range(18)
 
     def __init__(self, refine, dim=2, device=0):
         self.dim = dim
@@ -708,6 +709,11 @@ class Tree:
 
     def step(self):
         _check(lib().gfship_tree_step(self.ptr))
+
+    def divergence(self, level):
+        """the derived variable Divergence of the leaves of a level (gfs_divergence)"""
+        _check(lib().gfship_tree_divergence(self.ptr))
+        return self.download(self.DIV, level)
 
     def sweep_levels(self, level):
         a, b = C.c_int(), C.c_int()

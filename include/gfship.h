@@ -513,7 +513,8 @@ typedef double (* gfship_refine_fn) (double x, double y, double z, void * ctx);
 enum { GFSHIP_TREE_P = 0, GFSHIP_TREE_PMAC, GFSHIP_TREE_U, GFSHIP_TREE_V, GFSHIP_TREE_GX, GFSHIP_TREE_GY,
        GFSHIP_TREE_GMACX, GFSHIP_TREE_GMACY, GFSHIP_TREE_UN0, GFSHIP_TREE_UN1, GFSHIP_TREE_UN2,
        GFSHIP_TREE_UN3, GFSHIP_TREE_W, GFSHIP_TREE_GZ, GFSHIP_TREE_GMACZ, GFSHIP_TREE_UN4,
-       GFSHIP_TREE_UN5 };           /* variables of a tree: P, Pmac, U, V, g, gmac, f[d].un; then the 3-D ones */
+       GFSHIP_TREE_UN5, GFSHIP_TREE_DIV };  /* variables of a tree: P, Pmac, U, V, g, gmac, f[d].un; then the
+					       3-D ones; DIV: the result of gfship_tree_divergence */
 int  gfship_tree_create (gfship_tree ** tree, int dim, gfship_refine_fn refine, void * ctx, int device);
 void gfship_tree_destroy (gfship_tree * tree);
 int  gfship_tree_depth (const gfship_tree * tree);                   /* gfs_domain_depth */
@@ -530,6 +531,9 @@ unsigned gfship_tree_iter (const gfship_tree * tree);
 /* simulation_run up to its loop (src/simulation.c:458-476) and one iteration of the loop (:479-548) */
 int  gfship_tree_start (gfship_tree * tree);
 int  gfship_tree_step (gfship_tree * tree);
+/* the derived variable `Divergence' (gfs_divergence, src/fluid.c:2357-2376, with
+   gfs_face_interpolated_value_generic :2200-2221) of the leaves into GFSHIP_TREE_DIV */
+int  gfship_tree_divergence (gfship_tree * tree);
 /* diagnostics: the cells of the sweep of gfs_relax on `level' (the cells of the level and the
    coarser leaves) and the number of dependency levels its tree order leaves on the device */
 int  gfship_tree_sweep_levels (const gfship_tree * tree, int level, int * ncells, int * nlevels);

@@ -1580,6 +1580,72 @@ void gt_error_norm (GtSim * s, double * first, double * second, double * infty)
   *infty = p.n.infty;
 }
 
+/* gfs_face_interpolated_value_generic, fluid.c:2200-2221 */
+static double face_interpolated_value_generic (const GtSim * s, const Face * face, const Var * v)
+{
+  if (!exists (face->neighbor) || is_leaf (s, face->neighbor) || face->neighbor.l < face->cell.l)
+    return face_interpolated_value (s, face, v);
+  /* finer neighbor */
+  Face f = { NOCELL, face->cell, OPP (face->d) };
+  Cell ch[4];
+  int n = children_direction (s, face->neighbor, f.d, ch);
+  double avg = 0.;
+  for (int i = 0; i < n; i++)
+    if (exists (ch[i])) {
+      f.cell = ch[i];
+      avg += face_interpolated_value (s, &f, v)*1.;
+    }
+  return avg == 0. ? 0. : avg/(1.*n);
+}
+
+/* gfs_divergence, fluid.c:2357-2376: the derived variable `Divergence' of a leaf */
+static double divergence (const GtSim * s, Cell cell)
+{
+  double div = 0.;
+  Face f;
+  f.cell = cell;
+  for (f.d = 0; f.d < s->nd; f.d++) {
+    f.neighbor = neighbor (s, cell, f.d);
+    if (exists (f.neighbor))
+      div += 1.*((f.d & 1) ? -1. : 1.)*face_interpolated_value_generic (s, &f, &s->u[f.d/2]);
+  }
+  return div/(1.*cell_size (cell));
+}
+
+typedef struct { GoNorm n; double sum; } DivPar;
+static void add_divergence (GtSim * s, Cell c, void * data)
+{
+  DivPar * p = data;
+  double h = cell_size (c), vol = s->dim == 3 ? h*h*h : h*h;
+  norm_add (&p->n, divergence (s, c), vol);
+  double v2 = 0.;
+  for (int k = 0; k < s->dim; k++)
+    v2 += *val (&s->u[k], c)*(*val (&s->u[k], c));
+  p->sum += vol*v2;
+}
+
+/* GfsOutputScalarNorm { v = Divergence } (output.c:1966-1986, domain.c:2197-2232: weights = cell
+   volumes) and GfsOutputScalarSum { v = Velocity2 } (output.c:2089-2123) over the leaves */
+void gt_divergence_norm (GtSim * s, double * first, double * second, double * infty, double * velocity2_sum)
+{
+  DivPar p = { { 0., 0., 0., - DBL_MAX, 0. }, 0. };
+  cell_traverse (s, 0, T_LEAFS, -1, add_divergence, &p);
+  norm_update (&p.n);
+  *first = p.n.first;
+  *second = p.n.second;
+  *infty = p.n.infty;
+  *velocity2_sum = p.sum;
+}
+
+/* the value of `Divergence' on the leaves of a level (other cells: 0) */
+void gt_divergence_level (GtSim * s, int l, double * out)
+{
+  for (size_t q = 0; q < s->size[l]; q++) {
+    Cell c = { l, (int) q };
+    out[q] = s->flag[l][q] == GT_LEAF && is_interior (s, c) ? divergence (s, c) : 0.;
+  }
+}
+
 /* the whole run: returns the number of steps */
 unsigned gt_run (GtSim * s)
 {

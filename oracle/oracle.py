@@ -529,6 +529,8 @@ def _tree_sigs(L):
         "gt_flags": (C.POINTER(C.c_ubyte), [vp, i]),
         "gt_values": (pd, [vp, i, i]),
         "gt_error_norm": (None, [vp, pd, pd, pd]),
+        "gt_divergence_norm": (None, [vp, pd, pd, pd, pd]),
+        "gt_divergence_level": (None, [vp, i, pd]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -598,6 +600,18 @@ class Tree:
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         self.L.gt_error_norm(self.ptr, C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
+
+    def divergence_norm(self):
+        """(first, second, infty) of the derived variable Divergence, and the sum of Velocity2"""
+        a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        self.L.gt_divergence_norm(self.ptr, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return a.value, b.value, c.value, d.value
+
+    def divergence(self, l):
+        r = (1 << l) + 2
+        out = np.zeros((r,) * self.dim)
+        self.L.gt_divergence_level(self.ptr, l, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
 
     def destroy(self):
         if self.ptr:

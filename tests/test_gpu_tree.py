@@ -193,3 +193,19 @@ def test_octree_steps_bit_exact(kind, level, box, steps):
         same("step %d" % (k + 1))
     o.destroy()
     g.destroy()
+
+
+def test_divergence_variable_on_a_tree():
+    """gfs_divergence (the derived variable Divergence) of the leaves after two steps, against the
+    oracle's, bit for bit"""
+    o, g = periodic_pair(4, 2)
+    o.start()
+    g.start()
+    for _ in range(2):
+        o.step()
+        g.step()
+    for l in range(o.depth + 1):
+        leaf = o.flags(l)[1:-1, 1:-1] == 1
+        assert np.array_equal(g.divergence(l)[1:-1, 1:-1][leaf], o.divergence(l)[1:-1, 1:-1][leaf])
+    o.destroy()
+    g.destroy()

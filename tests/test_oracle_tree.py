@@ -157,3 +157,47 @@ def test_octree_column_along_another_axis(axis):
     assert max(float(np.abs(s.values(wvar, l)).max()) for l in range(s.depth + 1)) < 1e-4
     s.destroy()
     ref.destroy()
+
+
+# ---- test/reynolds/box: the decaying vortices of test/reynolds with one extra level inside the
+# square: the norms of the derived variable Divergence after EVERY step (146 / 368 / 773 rows of
+# three numbers) and the effective Reynolds number
+
+def _box_sim(level):
+    s = O.Tree(refine=lambda x, y: level if (x > 0.25 or x < -0.25 or y > 0.25 or y < -0.25) else level + 1)
+    for l in range(s.depth + 1):
+        x, y = s.centres(l)
+        s.values(O.Tree.U, l)[...] = - np.cos(8. * np.pi * x) * np.sin(8. * np.pi * y)
+        s.values(O.Tree.V, l)[...] = np.sin(8. * np.pi * x) * np.cos(8. * np.pi * y)
+    s.projection_params.tolerance = s.approx_projection_params.tolerance = 1e-6   # box.gfs:59-60
+    s.set_time(2., 0.8)
+    return s
+
+
+@pytest.mark.parametrize("level", [5, 6])
+def test_reynolds_box_divergence_history_matches_ref(golden_dir, level):
+    """every printed digit of test/reynolds/box/div5.ref, div6.ref (level 7: tools/tree_ref_rows.py
+    box) and reynolds.ref as reynolds.sh computes it"""
+    import math
+    ref = _rows(golden_dir, "reynolds_box_div%d.ref" % level)
+    s = _box_sim(level)
+    s.start()
+    k = 0
+    while True:
+        first, second, infty, ke = s.divergence_norm()
+        got = ("Divergence time: %g first: % 10.3e second: % 10.3e infty: % 10.3e"
+               % (s.t, first, second, infty)).split()
+        assert got == ref[k], (k, got, ref[k])
+        if k == 0:
+            ke0 = ke
+        if s.t >= 2.:
+            break
+        s.step()
+        k += 1
+    assert k == len(ref) - 1
+    rey = {r[0]: float(r[1]) for r in _rows(golden_dir, "reynolds_box_reynolds.ref")}
+    ke, ke0 = float('% 15.6e' % ke), float('% 15.6e' % ke0)      # as OutputScalarSum prints them
+    a = -math.log(ke / ke0) / s.t
+    nu = a / (4. * (2. * 4 * 3.14159265359) ** 2)                # reynolds.sh:9-16 with m = 4
+    assert 1. / nu == pytest.approx(rey[str(level)], rel=2e-5)
+    s.destroy()

@@ -24,7 +24,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden", "reference")
 
 
 def _stage(tmp_path, name):
-    shutil.copy(os.path.join(INPUTS, name), str(tmp_path / name))
+    shutil.copy(os.path.join(INPUTS, name), str(tmp_path / name))   # reynolds_box.gfs = test/reynolds/box/box.gfs
     if name == "lid.gfs":
         shutil.copy(os.path.join(GOLDEN, "lid_xprofile"), str(tmp_path / "xprofile"))
         shutil.copy(os.path.join(GOLDEN, "lid_yprofile"), str(tmp_path / "yprofile"))
@@ -60,6 +60,7 @@ def _rows(name):
     ("lid.gfs", {}, None, "class GfsSimulation dim 2 level 6"),
     ("periodic.gfs", {}, {"LEVEL": 6, "BOX": 0}, "class GfsSimulation dim 2 level 6"),
     ("poiseuille.gfs", {"LEVEL": 5}, None, "class GfsSimulation dim 2 level 5"),
+    ("reynolds_box.gfs", {}, {"LEVEL": 5}, "class GfsSimulation dim 2 level 5 (coarsest leaves of a refined tree)"),
 ])
 def test_reference_files_parse_unmodified(tmp_path, name, defs, sed, expect):
     _stage(tmp_path, name)
@@ -132,6 +133,25 @@ def test_periodic_gfs_refined_patch_against_r1_r2_ref(tmp_path, box, levels):
         out = _run(tmp_path, "periodic.gfs", {}, sed={"LEVEL": level, "BOX": box}).stdout.split()
         want = [r for r in _rows("periodic_r%d.ref" % box) if r[0] == str(level)][0]
         assert ["%.3e" % float(out[6]), "%.3e" % float(out[8])] == want[1:3], (box, level, out)
+
+
+@pytest.mark.gpu
+def test_reynolds_box_gfs_against_its_div5_ref(tmp_path):
+    """test/reynolds/box/box.gfs (`sh ../reynolds.sh box.gfs 4'): one extra level inside the square;
+    the norms of Divergence after every step (146 rows) and the effective Reynolds number"""
+    import math
+    _stage(tmp_path, "reynolds_box.gfs")
+    out = _run(tmp_path, "reynolds_box.gfs", {}, sed={"LEVEL": 5}).stdout
+    got = [l.split() for l in open(str(tmp_path / "div5"))]
+    ref = _rows("reynolds_box_div5.ref")
+    assert got == ref
+    # reynolds.sh:6-16: columns 3 and 5 of the OutputScalarSum lines on standard output
+    lines = [l.split() for l in out.splitlines() if l.startswith("Velocity2")]
+    ke0, ke, t = float(lines[0][4]), float(lines[-1][4]), float(lines[-1][2])
+    nu = (-math.log(ke / ke0) / t) / (4. * (2. * 4 * 3.14159265359) ** 2)
+    want = [r for r in _rows("reynolds_box_reynolds.ref") if r[0] == "5"][0]
+    assert 1. / nu == pytest.approx(float(want[1]), rel=2e-5)
+    assert os.path.exists(str(tmp_path / "error5.dat"))
 
 
 @pytest.mark.gpu

@@ -11,6 +11,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import oracle as O
 
+if len(sys.argv) > 1 and sys.argv[1] == "box":
+    # test/reynolds/box: the Divergence norms of every step against div5 / div6 / div7.ref
+    import numpy as np
+    for level in [int(l) for l in (sys.argv[2] if len(sys.argv) > 2 else "5,6,7").split(",")]:
+        ref = [l.split() for l in open(os.path.join(ROOT, "tests", "golden", "reference",
+                                                    "reynolds_box_div%d.ref" % level))]
+        s = O.Tree(refine=lambda x, y: level if (x > 0.25 or x < -0.25 or y > 0.25 or y < -0.25) else level + 1)
+        for l in range(s.depth + 1):
+            x, y = s.centres(l)
+            s.values(O.Tree.U, l)[...] = - np.cos(8. * np.pi * x) * np.sin(8. * np.pi * y)
+            s.values(O.Tree.V, l)[...] = np.sin(8. * np.pi * x) * np.cos(8. * np.pi * y)
+        s.projection_params.tolerance = s.approx_projection_params.tolerance = 1e-6
+        s.set_time(2., 0.8)
+        s.start()
+        k = bad = 0
+        t0 = time.time()
+        while True:
+            f, se, inf, _ = s.divergence_norm()
+            got = ("Divergence time: %g first: % 10.3e second: % 10.3e infty: % 10.3e" % (s.t, f, se, inf)).split()
+            bad += got != ref[k]
+            if s.t >= 2.:
+                break
+            s.step()
+            k += 1
+        print("reynolds/box LEVEL %d: %d rows, %d in the reference, %d differ (%.0f s)"
+              % (level, k + 1, len(ref), bad, time.time() - t0), flush=True)
+        s.destroy()
+    sys.exit(0)
 boxes = [int(b) for b in (sys.argv[1] if len(sys.argv) > 1 else "0,1,2").split(",")]
 levels = [int(l) for l in (sys.argv[2] if len(sys.argv) > 2 else "5,6,7").split(",")]
 for box in boxes:
