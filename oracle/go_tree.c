@@ -61,6 +61,13 @@ typedef struct GtSim {
   double cfl, dt;                             /* GfsAdvectionParams */
   double t, end, tnext;
   unsigned i;
+  /* sides with a GfsBoundary instead of the periodic image (GfsPoisson runs only): the condition of
+     P on each side (GO_BC_*) and, per ghost cell, the value of its GfsFunction at the face centre */
+  int side[6];                                /* GO_SIDE_PERIODIC / GO_SIDE_BOUNDARY */
+  int bc_p[6];
+  Var bcval;
+  const Var * bc_var;                         /* the variable the conditions belong to (P) */
+  int bc_homogeneous;                         /* set around the homogeneous BCs of a relax loop */
 } GtSim;
 
 static const Cell NOCELL = { 0, -1 };
@@ -307,6 +314,14 @@ static void ghost_traverse (GtSim * s, int l, GhostFunc fn, void * data)
 }
 
 typedef struct { Var * v; int flags, max_depth; } BcPar;
+/* the interior cell a ghost cell of side `side' touches */
+static int ghost_own (const GtSim * s, int l, int side, int G)
+{
+  int r = s->r[l], a = side/2;
+  int stride = a == 0 ? 1 : a == 1 ? r : r*r;
+  return (side & 1) ? G + stride : G - stride;
+}
+
 static void bc_ghost (GtSim * s, int l, int side, int G, int image, void * data)
 {
   BcPar * p = data;
@@ -315,8 +330,22 @@ static void bc_ghost (GtSim * s, int l, int side, int G, int image, void * data)
     return;
   int take = p->flags == T_LEAFS ? f == GT_LEAF :
     p->flags == T_LEVEL_LEAFS ? (l == p->max_depth || f == GT_LEAF) : 1;
-  if (take)
+  if (!take)
+    return;
+  if (s->side[side] == GO_SIDE_PERIODIC) {
     p->v->lev[l][G] = p->v->lev[l][image];
+    return;
+  }
+  /* GfsBoundary: symmetry (default, scalar) boundary.c:45-62, Dirichlet :253-279, Neumann :336-347 */
+  double nb = p->v->lev[l][ghost_own (s, l, side, G)];
+  double h = 1./s->n[l];
+  int kind = s->bc_p[side];
+  if (s->bc_homogeneous)
+    p->v->lev[l][G] = kind == GO_BC_DIRICHLET ? - nb : nb;
+  else {
+    double value = s->bcval.lev[l][G];
+    p->v->lev[l][G] = kind == GO_BC_DIRICHLET ? 2.*value - nb : kind == GO_BC_NEUMANN ? nb + value*h : nb;
+  }
 }
 
 static void bc (GtSim * s, Var * v, int flags, int max_depth)
@@ -428,6 +457,10 @@ static void match_ghost (GtSim * s, int l, int side, int G, int image, void * da
   int n = s->n[l], r = s->r[l], a = side/2;
   int stride = a == 0 ? 1 : a == 1 ? r : r*r;
   int own = (side & 1) ? G + stride : G - stride;
+  if (s->side[side] != GO_SIDE_PERIODIC) {    /* the ghost tree of a GfsBoundary matches its own side */
+    s->flag[l][G] = s->flag[l][own];
+    return;
+  }
   if (s->flag[l][own] != s->flag[l][image])
     m->bad = 1;
   s->flag[l][G] = s->flag[l][image];
@@ -879,11 +912,13 @@ static void cell_reset (GtSim * s, Cell c, void * data) { *val ((Var *) data, c)
 /* relax_loop, poisson.c:1070-1089 (the homogeneous BC of a periodic side is the periodic copy) */
 static void relax_loop (GtSim * s, Var * dp, RelaxParams * q, unsigned nrelax)
 {
+  s->bc_homogeneous = 1;     /* gfs_domain_homogeneous_bc */
   bc (s, dp, T_LEVEL_LEAFS, q->maxlevel);
   for (unsigned n = 0; n < nrelax - 1; n++) {
     cell_traverse (s, 0, T_LEVEL_LEAFS, q->maxlevel, relax2D, q);
     bc (s, dp, T_LEVEL_LEAFS, q->maxlevel);
   }
+  s->bc_homogeneous = 0;
   cell_traverse (s, 0, T_LEVEL_LEAFS, q->maxlevel, relax2D, q);
 }
 
@@ -1431,14 +1466,32 @@ static void init_uv (GtSim * s, Cell c, void * data) /* periodic.gfs:26-29 */
 
 /* a GfsSimulation on one periodic box refined by `refine' (default parameters of
    gfs_multilevel_params_init / gfs_advection_params_init; U, V, P zero) */
+static GtSim * gt_new_sides (int dim, GtRefineFunc refine, void * ctx, const int * side);
+
 GtSim * gt_new (int dim, GtRefineFunc refine, void * ctx)
+{
+  return gt_new_sides (dim, refine, ctx, NULL);
+}
+
+/* side[d] = GO_SIDE_PERIODIC or GO_SIDE_BOUNDARY (NULL: all periodic) */
+GtSim * gt_new_with_sides (int dim, GtRefineFunc refine, void * ctx, const int * side)
+{
+  return gt_new_sides (dim, refine, ctx, side);
+}
+
+static GtSim * gt_new_sides (int dim, GtRefineFunc refine, void * ctx, const int * side)
 {
   GtSim * s = calloc (1, sizeof (GtSim));
   assert (dim == 2 || dim == 3);
   s->dim = dim;
   s->nd = 2*dim;
   s->nc = 1 << dim;
+  for (int d = 0; d < 6; d++) {
+    s->side[d] = side && d < 2*dim ? side[d] : GO_SIDE_PERIODIC;
+    s->bc_p[d] = GO_BC_SYMMETRY;
+  }
   build_tree (s, refine, ctx);
+  var_alloc (s, &s->bcval);
   Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1], &s->u[2], &s->g[0], &s->g[1], &s->g[2],
 		  &s->gmac[0], &s->gmac[1], &s->gmac[2] };
   for (unsigned k = 0; k < sizeof (all)/sizeof (all[0]); k++)
@@ -1493,6 +1546,7 @@ void gt_destroy (GtSim * s)
     var_free (s, &s->fv[d]);
     var_free (s, &s->w[d]);
   }
+  var_free (s, &s->bcval);
   for (int l = 0; l <= s->depth; l++)
     free (s->flag[l]);
   free (s);
@@ -1578,6 +1632,61 @@ void gt_error_norm (GtSim * s, double * first, double * second, double * infty)
   *first = p.n.first;
   *second = p.n.second;
   *infty = p.n.infty;
+}
+
+/* ---- GfsPoisson: poisson_run, simulation.c:2150-2285 ---------------------------------------- */
+
+void gt_set_bc (GtSim * s, int d, int kind) { s->bc_p[d] = kind; }
+double * gt_bc_values (GtSim * s, int l) { return s->bcval.lev[l]; }
+
+typedef struct { Var * divu, * div; double sum_div, sum_vol, ddiv; long n; } DivData;
+
+static void rescale_div (GtSim * s, Cell c, void * data) /* simulation.c:2156-2162 */
+{
+  DivData * p = data;
+  double size = cell_size (c);
+  double a = size*size*1.;
+  *val (p->div, c) = *val (p->divu, c)*a;
+  p->sum_vol += a;        /* gts_range_add_value: mean = sum/n */
+  p->n++;
+}
+
+static void sum_div (GtSim * s, Cell c, void * data) { ((DivData *) data)->sum_div += *val (((DivData *) data)->div, c); }
+
+static void add_ddiv (GtSim * s, Cell c, void * data) /* simulation.c:2164-2168 */
+{
+  DivData * p = data;
+  double size = cell_size (c);
+  *val (p->div, c) += size*size*p->ddiv*1.;
+}
+
+/* one iteration of poisson_run: `divu' holds the variable Div on the leaves, P the current guess;
+   the solve uses the approximate-projection parameters.  The residual is left in `res'. */
+void gt_poisson_run (GtSim * s, Var * divu_unused)
+{
+  (void) divu_unused;
+  Var div, dia, res;
+  var_alloc (s, &div); var_alloc (s, &dia); var_alloc (s, &res);
+  int dirichlet = 0;
+  for (int d = 0; d < s->nd; d++)
+    if (s->side[d] == GO_SIDE_BOUNDARY && s->bc_p[d] == GO_BC_DIRICHLET)
+      dirichlet = 1;
+  /* gfs_simulation_init: the BCs of every variable; gfs_cell_coarse_init */
+  s->bc_homogeneous = 0;
+  bc (s, &s->p, T_LEAFS, -1);
+  cell_traverse (s, 1, T_NON_LEAFS, -1, get_from_below_intensive, &s->p);
+  /* correct_div, simulation.c:2170-2190: the variable Div is kept in pmac here */
+  DivData dd = { &s->pmac, &div, 0., 0., 0., 0 };
+  cell_traverse (s, 0, T_LEAFS, -1, rescale_div, &dd);
+  if (!dirichlet) {
+    cell_traverse (s, 0, T_LEAFS, -1, sum_div, &dd);
+    dd.ddiv = - (dd.sum_div/dd.n)/(dd.sum_vol/dd.n);
+    cell_traverse (s, 0, T_LEAFS, -1, add_ddiv, &dd);
+  }
+  poisson_coefficients (s);
+  poisson_solve (s, &s->approx_projection_params, &s->p, &div, &res, &dia, 1.);
+  s->i++;
+  var_free (s, &div); var_free (s, &dia); var_free (s, &res);
 }
 
 /* gfs_face_interpolated_value_generic, fluid.c:2200-2221 */

@@ -375,6 +375,19 @@ class Sim:
                                                     p.ctypes.data_as(pd)) for f in fields])
         return np.array(rows)
 
+    def set_bc(self, d, kind):
+        """condition of P on side d (BC_DIRICHLET / BC_NEUMANN / BC_SYMMETRY)"""
+        self.L.gt_set_bc(self.ptr, d, kind)
+
+    def bc_values(self, l):
+        """the values of the GfsFunction of the conditions at the face centres, one per ghost cell"""
+        r = (1 << l) + 2
+        return np.ctypeslib.as_array(self.L.gt_bc_values(self.ptr, l), shape=(r,) * self.dim)
+
+    def poisson_run(self):
+        """one iteration of poisson_run: Div in the PMAC slot, the guess in P"""
+        self.L.gt_poisson_run(self.ptr, None)
+
     def divergence_norm(self):
         e = self.dom.field()
         lib().go_divergence(self.ptr, e.ptr)
@@ -513,6 +526,10 @@ def _tree_sigs(L):
     pd = C.POINTER(C.c_double)
     sig = {
         "gt_new": (vp, [i, REFINE_FUNC, vp]),
+        "gt_new_with_sides": (vp, [i, REFINE_FUNC, vp, C.POINTER(C.c_int)]),
+        "gt_set_bc": (None, [vp, i, i]),
+        "gt_bc_values": (pd, [vp, i]),
+        "gt_poisson_run": (None, [vp, vp]),
         "gt_dim": (i, [vp]),
         "gt_periodic_new": (vp, [i, i]),
         "gt_destroy": (None, [vp]),
@@ -543,7 +560,7 @@ class Tree:
     0 absent, 1 leaf, 2 non-leaf.  refine (x, y) or refine (x, y, z) -> level wanted there."""
     U, V, P, PMAC, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3, W, GZ, GMACZ, UN4, UN5 = range(17)
 
-    def __init__(self, refine=None, periodic=None, dim=2):
+    def __init__(self, refine=None, periodic=None, dim=2, sides=None):
         L = lib()
         if not hasattr(L, "_tree_ready"):
             _tree_sigs(L)
@@ -556,7 +573,10 @@ class Tree:
                 self._cb = REFINE_FUNC(lambda x, y, z, ctx: float(refine(x, y)))
             else:
                 self._cb = REFINE_FUNC(lambda x, y, z, ctx: float(refine(x, y, z)))
-            self.ptr = L.gt_new(dim, self._cb, None)
+            if sides is None:
+                self.ptr = L.gt_new(dim, self._cb, None)
+            else:
+                self.ptr = L.gt_new_with_sides(dim, self._cb, None, (C.c_int * 6)(*(list(sides) + [0] * 6)[:6]))
         self.dim = L.gt_dim(self.ptr)
         self.depth = L.gt_depth(self.ptr)
         self.projection_params = L.gt_projection_params(self.ptr, 0).contents
@@ -600,6 +620,19 @@ class Tree:
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         self.L.gt_error_norm(self.ptr, C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
+
+    def set_bc(self, d, kind):
+        """condition of P on side d (BC_DIRICHLET / BC_NEUMANN / BC_SYMMETRY)"""
+        self.L.gt_set_bc(self.ptr, d, kind)
+
+    def bc_values(self, l):
+        """the values of the GfsFunction of the conditions at the face centres, one per ghost cell"""
+        r = (1 << l) + 2
+        return np.ctypeslib.as_array(self.L.gt_bc_values(self.ptr, l), shape=(r,) * self.dim)
+
+    def poisson_run(self):
+        """one iteration of poisson_run: Div in the PMAC slot, the guess in P"""
+        self.L.gt_poisson_run(self.ptr, None)
 
     def divergence_norm(self):
         """(first, second, infty) of the derived variable Divergence, and the sum of Velocity2"""

@@ -201,3 +201,55 @@ def test_reynolds_box_divergence_history_matches_ref(golden_dir, level):
     nu = a / (4. * (2. * 4 * 3.14159265359) ** 2)                # reynolds.sh:9-16 with m = 4
     assert 1. / nu == pytest.approx(rey[str(level)], rel=2e-5)
     s.destroy()
+
+
+# ---- test/poisson/circle: GfsPoisson with Neumann conditions on the four sides and two extra levels
+# inside a circle: the multigrid on a tree with boundaries, cycle by cycle
+
+def _circle(level, cycle):
+    import math
+    pi = math.pi
+    s = O.Tree(refine=lambda x, y: level + 2 if x * x + y * y <= 0.25 * 0.25 else level,
+               sides=[O.SIDE_BOUNDARY] * 4)
+    for d in range(4):
+        s.set_bc(d, O.BC_NEUMANN)
+    for l in range(s.depth + 1):
+        x, y = s.centres(l)
+        s.values(O.Tree.PMAC, l)[...] = -pi * pi * 18. * np.sin(pi * 3 * x) * np.sin(pi * 3 * y)   # Div, circle.gfs:54-59
+        b = s.bc_values(l)                                           # circle.gfs:77-80, at the face centres
+        yy, xx = y[:, -1], x[-1, :]
+        b[:, -1] = 3. * pi * np.cos(pi * 3. * 0.5) * np.sin(pi * 3. * yy)
+        b[:, 0] = -3. * pi * np.cos(pi * 3. * (-0.5)) * np.sin(pi * 3. * yy)
+        b[-1, :] = 3. * pi * np.cos(pi * 3. * 0.5) * np.sin(pi * 3. * xx)
+        b[0, :] = -3. * pi * np.cos(pi * 3. * (-0.5)) * np.sin(pi * 3. * xx)
+    par = s.approx_projection_params
+    par.tolerance, par.nitermin, par.nitermax = 1e-30, cycle, cycle
+    s.poisson_run()
+    e, w = [], []
+    for l in range(s.depth + 1):
+        leaf = s.flags(l)[1:-1, 1:-1] == 1
+        if leaf.any():
+            x, y = s.centres(l)
+            err = (s.values(O.Tree.P, l) - np.sin(pi * 3 * x) * np.sin(pi * 3 * y))[1:-1, 1:-1][leaf]
+            e.append(err)
+            w.append(np.full(err.shape, 1. / (1 << l) ** 2))
+    e, w = np.concatenate(e), np.concatenate(w)
+    e = e - float((w * e).sum() / w.sum())                           # unbiased = 1
+    norms = (float((w * np.abs(e)).sum() / w.sum()), math.sqrt(float((w * e * e).sum() / w.sum())),
+             float(np.abs(e).max()))
+    res = par.residual.infty
+    s.destroy()
+    return res, norms
+
+
+def test_poisson_circle_res7_and_error_refs(golden_dir):
+    """test/poisson/circle (`sh ../poisson.sh circle.gfs'): res-7.ref column 3 (the maximum residual
+    after 0 .. 10 V-cycles, LEVEL = 8: a tree of depth 10) and error.ref (levels 3 .. 8 after 10
+    cycles), every printed digit"""
+    ref = _rows(golden_dir, "poisson_circle_res-7.ref")
+    for cyc in range(11):
+        res, _ = _circle(8, cyc)
+        assert "%.3e" % res == ref[cyc][2], (cyc, res, ref[cyc])
+    for row in _rows(golden_dir, "poisson_circle_error.ref"):
+        _, norms = _circle(int(row[0]), 10)
+        assert ["%.3e" % v for v in norms] == row[1:4], (row, norms)
