@@ -34,18 +34,19 @@ using namespace gfship::tree;
 namespace {
 
 enum { V_P, V_PMAC, V_U /* 3 */, V_G = V_U + 3 /* 3 */, V_GM = V_G + 3 /* 3 */, V_UN = V_GM + 3 /* 6 */,
-       V_FV = V_UN + 6 /* 6 */, V_DIV = V_FV + 6, V_RES, V_DP, V_NVAR };
+       V_FV = V_UN + 6 /* 6 */, V_DIV = V_FV + 6, V_RES, V_DP, V_BCVAL, V_NVAR };
 
 // the variables of the C ABI (GFSHIP_TREE_*) -> storage
 const int abi_var[] = { V_P, V_PMAC, V_U, V_U + 1, V_G, V_G + 1, V_GM, V_GM + 1, V_UN, V_UN + 1, V_UN + 2,
-			V_UN + 3, V_U + 2, V_G + 2, V_GM + 2, V_UN + 4, V_UN + 5, V_DIV };
+			V_UN + 3, V_U + 2, V_G + 2, V_GM + 2, V_UN + 4, V_UN + 5, V_DIV, V_BCVAL, V_RES };
 const int abi_nvar = sizeof (abi_var)/sizeof (abi_var[0]);
 
 struct P3 { double * p[3]; };       // the components of a vector
 struct P6 { double * p[6]; };       // a number per direction
 
 struct FaceRec { Cell cell, neighbor; int d; };
-struct Ghost { int g, img, side; };
+struct Ghost { int g, img, side, l; };   // img: the periodic image, or the cell the ghost touches (GfsBoundary)
+struct Sgn6 { double s[6]; };            // homogeneous condition of each side: ghost = s * cell
 
 struct FaceSet {            // the faces of one ftt_face_traverse, in its order
   int nfaces = 0;
@@ -108,6 +109,9 @@ struct gfship_tree {
   double cfl = 0.8, dt = 0., t = 0., end = DBL_MAX, tnext = 0.;
   unsigned iter = 0;
   gfship_next_event_fn next_event = nullptr; void * next_event_ctx = nullptr;
+  int side[6] = { 0, 0, 0, 0, 0, 0 };             // GFSHIP_SIDE_PERIODIC / GFSHIP_SIDE_BOUNDARY
+  int bc_p[6] = { 0, 0, 0, 0, 0, 0 };             // condition of P on a GfsBoundary side (GFSHIP_BC_*)
+  bool has_boundary = false;
 };
 
 namespace {
@@ -118,6 +122,23 @@ __global__ void t_copy_ghosts (const Ghost * gh, int n, double * v)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t < n) v[gh[t].g] = v[gh[t].img];
+}
+
+// the conditions of P on GfsBoundary sides (src/boundary.c:45-62,253-279,336-347): symmetry (scalar),
+// Dirichlet 2 val - nb, Neumann nb + val h; periodic sides: the copy
+__global__ void t_bc_values (const Ghost * gh, int n, double * v, const double * bcval, Sgn6 kind)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Ghost G = gh[t];
+  const double nb = v[G.img];
+  const int k = (int) kind.s[G.side];     /* -1 periodic, else GFSHIP_BC_* */
+  double x = nb;
+  if (k == GFSHIP_BC_DIRICHLET)
+    x = 2.*bcval[G.g] - nb;
+  else if (k == GFSHIP_BC_NEUMANN)
+    x = nb + bcval[G.g]*(1./(1 << G.l));
+  v[G.g] = x;
 }
 
 // gfs_domain_face_bc on periodic sides (src/boundary.c:1251-1258,1343-1347): the leaf ghost beyond
@@ -194,11 +215,11 @@ __global__ void t_from_above (Topo T, const Cell * cells, int n, double * v)
 // dependency level
 __global__ void __launch_bounds__(1024)
 t_relax_loop (Topo T, const Cell * cells, const int * lev_off, int nlev, const Ghost * gh, int ngh,
-	      double * u, const double * rhs, unsigned nrelax, double omega, int max_level)
+	      double * u, const double * rhs, unsigned nrelax, double omega, int max_level, Sgn6 sg)
 {
   DevReader R = { u };
   for (int t = threadIdx.x; t < ngh; t += blockDim.x)
-    u[gh[t].g] = u[gh[t].img];
+    u[gh[t].g] = sg.s[gh[t].side]*u[gh[t].img];
   __syncthreads ();
   for (unsigned s = 0; s < nrelax; s++) {
     for (int L = 0; L < nlev; L++) {
@@ -212,7 +233,7 @@ t_relax_loop (Topo T, const Cell * cells, const int * lev_off, int nlev, const G
     }
     if (s + 1 < nrelax) {
       for (int t = threadIdx.x; t < ngh; t += blockDim.x)
-	u[gh[t].g] = u[gh[t].img];
+	u[gh[t].g] = sg.s[gh[t].side]*u[gh[t].img];
       __syncthreads ();
     }
   }
@@ -306,12 +327,12 @@ __device__ inline void tape_cell (TapeCursor & c, int nd, int dim, int ncd, doub
 __global__ void __launch_bounds__(1024)
 t_relax_tape (Topo T, const Cell * cells, const int * cell_off, int ncells, const int * chunk, int nchunks,
 	      const int * ti_g, const double * td_g, const int * tv_g,
-	      const Ghost * gh, int ngh, double * u, const double * rhs, unsigned nrelax, double omega)
+	      const Ghost * gh, int ngh, double * u, const double * rhs, unsigned nrelax, double omega, Sgn6 sg)
 {
   extern __shared__ double lds[];
   const int nd = T.nd (), dim = T.dim, ncd = T.ncd ();
   for (int t = threadIdx.x; t < ngh; t += blockDim.x)
-    u[gh[t].g] = u[gh[t].img];
+    u[gh[t].g] = sg.s[gh[t].side]*u[gh[t].img];
   __syncthreads ();
   for (unsigned s = 0; s < nrelax; s++) {
     for (int k = 0; k < nchunks; k++) {
@@ -344,7 +365,7 @@ t_relax_tape (Topo T, const Cell * cells, const int * cell_off, int ncells, cons
     }
     if (s + 1 < nrelax) {
       for (int t = threadIdx.x; t < ngh; t += blockDim.x)
-	u[gh[t].g] = u[gh[t].img];
+	u[gh[t].g] = sg.s[gh[t].side]*u[gh[t].img];
       __syncthreads ();
     }
   }
@@ -939,7 +960,7 @@ template <class X> int to_device (const std::vector<X> & h, X ** d)
 }
 
 // the ghost cells of a selection of the traversal and their periodic images
-void ghost_list (const Topo & T, int flags, int max_depth, std::vector<Ghost> & out)
+void ghost_list (const Topo & T, const int * sides, int flags, int max_depth, std::vector<Ghost> & out)
 {
   for (int l = 0; l <= T.depth; l++) {
     if (max_depth >= 0 && l > max_depth)
@@ -952,6 +973,8 @@ void ghost_list (const Topo & T, int flags, int max_depth, std::vector<Ghost> & 
 	  const int a = side/2, o1 = a == 0 ? 1 : 0, o2 = a == 2 ? 1 : 2;
 	  g[a] = (side & 1) ? 0 : n + 1;
 	  im[a] = (side & 1) ? n : 1;
+	  if (sides[side] != GFSHIP_SIDE_PERIODIC)     /* GfsBoundary: the cell the ghost touches */
+	    im[a] = (side & 1) ? 1 : n;
 	  g[o1] = im[o1] = ta;
 	  g[o2] = im[o2] = T.dim == 3 ? tb : 0;
 	  const int G = g[0] + r*(g[1] + r*g[2]), I = im[0] + r*(im[1] + r*im[2]);
@@ -960,7 +983,7 @@ void ghost_list (const Topo & T, int flags, int max_depth, std::vector<Ghost> & 
 	    continue;
 	  const bool take = flags == T_LEAFS ? f == LEAF : (l == max_depth || f == LEAF);
 	  if (take) {
-	    Ghost gh = { T.off[l] + G, T.off[l] + I, side };
+	    Ghost gh = { T.off[l] + G, T.off[l] + I, side, l };
 	    out.push_back (gh);
 	  }
 	}
@@ -1011,7 +1034,7 @@ int sweep_plan (gfship_tree * tr, int m, Sweep * S)
   for (size_t k = 0; k < order.size (); k++)
     sorted[cur[lev[k]]++] = order[k];
   std::vector<Ghost> gh;
-  ghost_list (T, T_LEVEL_LEAFS, m, gh);
+  ghost_list (T, tr->side, T_LEVEL_LEAFS, m, gh);
   S->ncells = (int) order.size ();
   S->nlev = nlev;
   S->nghosts = (int) gh.size ();
@@ -1181,8 +1204,32 @@ int face_set (gfship_tree * tr, int kind, FaceSet * F)
 
 // ---- host: the algorithms ----------------------------------------------------------------------
 
+// the homogeneous form of the conditions (gfs_domain_homogeneous_bc): ghost = s * cell
+Sgn6 homogeneous_signs (const gfship_tree * tr)
+{
+  Sgn6 sg;
+  for (int d = 0; d < 6; d++)
+    sg.s[d] = tr->side[d] != GFSHIP_SIDE_PERIODIC && tr->bc_p[d] == GFSHIP_BC_DIRICHLET ? -1. : 1.;
+  return sg;
+}
+
+// gfs_domain_bc of P on the leaves of a tree with GfsBoundary sides
+int bc_solution (gfship_tree * tr, double * v)
+{
+  if (!tr->nghost_leaves) return 0;
+  Sgn6 kind;
+  for (int d = 0; d < 6; d++)
+    kind.s[d] = tr->side[d] == GFSHIP_SIDE_PERIODIC ? -1. : (double) tr->bc_p[d];
+  t_bc_values<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves, v,
+      tr->var[V_BCVAL], kind);
+  GFSHIP_HIP (hipGetLastError ());
+  return 0;
+}
+
 int bc_leaves (gfship_tree * tr, double * v)
 {
+  if (tr->has_boundary)      /* only P lives on such a tree (gfship_tree_poisson_solve) */
+    return bc_solution (tr, v);
   if (tr->nghost_leaves)
     t_copy_ghosts<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves, v);
   KCHECK ();
@@ -1235,10 +1282,10 @@ int relax_loop (gfship_tree * tr, int m, unsigned nrelax, double omega)
   }
   if (S.taped && !use_template)
     t_relax_tape<<<1, 1024, TAPE_LDS_BYTES, tr->stream>>> (tr->D, S.cells, S.cell_off, S.ncells, S.chunk, S.nchunks,
-	S.ti, S.td, S.tv, S.ghosts, S.nghosts, tr->var[V_DP], tr->var[V_RES], nrelax, omega);
+	S.ti, S.td, S.tv, S.ghosts, S.nghosts, tr->var[V_DP], tr->var[V_RES], nrelax, omega, homogeneous_signs (tr));
   else
     t_relax_loop<<<1, 1024, 0, tr->stream>>> (tr->D, S.cells, S.lev_off, S.nlev, S.ghosts, S.nghosts,
-					       tr->var[V_DP], tr->var[V_RES], nrelax, omega, m);
+					       tr->var[V_DP], tr->var[V_RES], nrelax, omega, m, homogeneous_signs (tr));
   KCHECK ();
   return 0;
 }
@@ -1501,6 +1548,12 @@ extern "C" {
 
 int gfship_tree_create (gfship_tree ** out, int dim, gfship_refine_fn refine, void * ctx, int device)
 {
+  return gfship_tree_create_sides (out, dim, refine, ctx, nullptr, device);
+}
+
+int gfship_tree_create_sides (gfship_tree ** out, int dim, gfship_refine_fn refine, void * ctx,
+			      const int * side, int device)
+{
   GFSHIP_CHECK (out && refine, GFSHIP_EINVAL, "gfship_tree_create: null argument");
   GFSHIP_CHECK (dim == 2 || dim == 3, GFSHIP_EINVAL, "gfship_tree_create: dim = %d", dim);
   int ndev = 0;
@@ -1520,6 +1573,16 @@ int gfship_tree_create (gfship_tree ** out, int dim, gfship_refine_fn refine, vo
   GFSHIP_CHECK (e == 0, e, "gfship_tree_create: more than %d levels", GFSHIP_MAXLEVEL);
   gfship_tree * tr = new gfship_tree;
   tr->device = device;
+  for (int d = 0; d < 2*dim; d++) {
+    tr->side[d] = side ? side[d] : GFSHIP_SIDE_PERIODIC;
+    if (tr->side[d] != GFSHIP_SIDE_PERIODIC && tr->side[d] != GFSHIP_SIDE_BOUNDARY) {
+      delete tr;
+      set_error ("gfship_tree_create: side %d: periodic or boundary", d);
+      return GFSHIP_EINVAL;
+    }
+    if (tr->side[d] == GFSHIP_SIDE_BOUNDARY) tr->has_boundary = true;
+    tr->bc_p[d] = GFSHIP_BC_SYMMETRY;
+  }
   auto flatten = [&] () {
     Topo & H = tr->H;
     H.dim = dim;
@@ -1568,6 +1631,10 @@ int gfship_tree_create (gfship_tree ** out, int dim, gfship_refine_fn refine, vo
 	    g[o2] = im[o2] = own[o2] = dim == 3 ? tb : 0;
 	    const int G = g[0] + r*(g[1] + r*g[2]), I = im[0] + r*(im[1] + r*im[2]),
 	      O = own[0] + r*(own[1] + r*own[2]);
+	    if (tr->side[side] != GFSHIP_SIDE_PERIODIC) {    /* the ghost tree of a GfsBoundary matches its side */
+	      f[G] = f[O];
+	      continue;
+	    }
 	    if (f[O] != f[I]) {
 	      delete tr;
 	      set_error ("gfship_tree_create: the refinement differs across a periodic side (level %d)", l);
@@ -1645,7 +1712,7 @@ int gfship_tree_create (gfship_tree ** out, int dim, gfship_refine_fn refine, vo
     TRY (to_device (nl, &tr->nonleaf[l]));
   }
   std::vector<Ghost> gh;
-  ghost_list (T, T_LEAFS, -1, gh);
+  ghost_list (T, tr->side, T_LEAFS, -1, gh);
   tr->nghost_leaves = (int) gh.size ();
   TRY (to_device (gh, &tr->ghost_leaves));
   for (int m = 0; m <= T.depth; m++)
@@ -1697,6 +1764,26 @@ gfship_multilevel_params * gfship_tree_projection_params (gfship_tree * tr, int 
   return approx ? &tr->approx_projection_params : &tr->projection_params;
 }
 
+int gfship_tree_set_bc (gfship_tree * tr, int d, int kind)
+{
+  GFSHIP_CHECK (tr && d >= 0 && d < 2*tr->H.dim && tr->side[d] == GFSHIP_SIDE_BOUNDARY &&
+		(kind == GFSHIP_BC_SYMMETRY || kind == GFSHIP_BC_DIRICHLET || kind == GFSHIP_BC_NEUMANN),
+		GFSHIP_EINVAL, "gfship_tree_set_bc: bad argument");
+  tr->bc_p[d] = kind;
+  return GFSHIP_OK;
+}
+
+/* gfs_poisson_solve (src/poisson.c:1225-1269) on the tree: P (GFSHIP_TREE_P) holds the guess, the
+   right-hand side is in GFSHIP_TREE_DIV, dia = 0, alpha = NULL; the residual is left in GFSHIP_TREE_RES */
+int gfship_tree_poisson_solve (gfship_tree * tr, gfship_multilevel_params * par, double dt)
+{
+  GFSHIP_CHECK (tr && par, GFSHIP_EINVAL, "gfship_tree_poisson_solve: null argument");
+  GFSHIP_HIP (hipSetDevice (tr->device));
+  int e;
+  if ((e = bc_leaves (tr, tr->var[V_P]))) return e;
+  return poisson_solve (tr, par, tr->var[V_P], tr->var[V_DIV], dt);
+}
+
 int gfship_tree_set_time (gfship_tree * tr, double end, double cfl)
 {
   GFSHIP_CHECK (tr && cfl > 0., GFSHIP_EINVAL, "gfship_tree_set_time: bad argument");
@@ -1742,6 +1829,8 @@ int gfship_tree_sweep_levels (const gfship_tree * tr, int level, int * ncells, i
 int gfship_tree_start (gfship_tree * tr)
 {
   GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_start: null tree");
+  GFSHIP_CHECK (!tr->has_boundary, GFSHIP_EUNSUPPORTED,
+		"gfship_tree_start: the time step needs periodic sides (a tree with GfsBoundary sides: gfship_tree_poisson_solve)");
   GFSHIP_HIP (hipSetDevice (tr->device));
   int e;
   const int vars[] = { V_P, V_PMAC, V_U, V_U + 1, V_U + 2 };
@@ -1757,6 +1846,7 @@ int gfship_tree_start (gfship_tree * tr)
 int gfship_tree_step (gfship_tree * tr)
 {
   GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_step: null tree");
+  GFSHIP_CHECK (!tr->has_boundary, GFSHIP_EUNSUPPORTED, "gfship_tree_step: the time step needs periodic sides");
   GFSHIP_HIP (hipSetDevice (tr->device));
   int e;
   if ((e = predicted_face_velocities (tr))) return e;

@@ -153,6 +153,9 @@ SIGNATURES = {
     "gfship_particles_set_force_coefficient": (_i, [_vp, _i, C.c_char_p]),
     "gfship_particles_download_particulate": (_i, [_vp, _pd, _pd, _pd]),
     "gfship_tree_create": (_i, [C.POINTER(_vp), _i, C.c_void_p, _vp, _i]),
+    "gfship_tree_create_sides": (_i, [C.POINTER(_vp), _i, C.c_void_p, _vp, _pi, _i]),
+    "gfship_tree_set_bc": (_i, [_vp, _i, _i]),
+    "gfship_tree_poisson_solve": (_i, [_vp, C.POINTER(MultilevelParams), _d]),
     "gfship_tree_destroy": (None, [_vp]),
     "gfship_tree_depth": (_i, [_vp]),
     "gfship_tree_dim": (_i, [_vp]),
@@ -661,16 +664,21 @@ REFINE_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_double, C.c_void
 class Tree:
     """gfship_tree: a GfsSimulation on one periodic box refined by a GfsRefine function (coarse-fine
     stencils; quadtree or octree).  refine (x, y) or refine (x, y, z) -> level wanted there."""
-    P, PMAC, U, V, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3, W, GZ, GMACZ, UN4, UN5, DIV = range(18)
+    P, PMAC, U, V, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3, W, GZ, GMACZ, UN4, UN5, DIV, BCVAL, RES = range(20)
 
-    def __init__(self, refine, dim=2, device=0):
+    def __init__(self, refine, dim=2, device=0, sides=None):
         self.dim = dim
         if dim == 2:
             self._cb = REFINE_FN(lambda x, y, z, ctx: float(refine(x, y)))
         else:
             self._cb = REFINE_FN(lambda x, y, z, ctx: float(refine(x, y, z)))
         p = _vp()
-        _check(lib().gfship_tree_create(C.byref(p), dim, C.cast(self._cb, C.c_void_p), None, device))
+        if sides is None:
+            _check(lib().gfship_tree_create(C.byref(p), dim, C.cast(self._cb, C.c_void_p), None, device))
+        else:
+            arr = (C.c_int * 6)(*(list(sides) + [0] * 6)[:6])
+            _check(lib().gfship_tree_create_sides(C.byref(p), dim, C.cast(self._cb, C.c_void_p), None, arr,
+                                                  device))
         self.ptr = p
         self.depth = lib().gfship_tree_depth(p)
         self.projection_params = lib().gfship_tree_projection_params(p, 0).contents
@@ -709,6 +717,13 @@ class Tree:
 
     def step(self):
         _check(lib().gfship_tree_step(self.ptr))
+
+    def set_bc(self, d, kind):
+        _check(lib().gfship_tree_set_bc(self.ptr, d, kind))
+
+    def poisson_solve(self, par, dt=1.):
+        """gfs_poisson_solve: guess in P, right-hand side in DIV, residual left in RES"""
+        _check(lib().gfship_tree_poisson_solve(self.ptr, C.byref(par), dt))
 
     def divergence(self, level):
         """the derived variable Divergence of the leaves of a level (gfs_divergence)"""

@@ -513,9 +513,25 @@ typedef double (* gfship_refine_fn) (double x, double y, double z, void * ctx);
 enum { GFSHIP_TREE_P = 0, GFSHIP_TREE_PMAC, GFSHIP_TREE_U, GFSHIP_TREE_V, GFSHIP_TREE_GX, GFSHIP_TREE_GY,
        GFSHIP_TREE_GMACX, GFSHIP_TREE_GMACY, GFSHIP_TREE_UN0, GFSHIP_TREE_UN1, GFSHIP_TREE_UN2,
        GFSHIP_TREE_UN3, GFSHIP_TREE_W, GFSHIP_TREE_GZ, GFSHIP_TREE_GMACZ, GFSHIP_TREE_UN4,
-       GFSHIP_TREE_UN5, GFSHIP_TREE_DIV };  /* variables of a tree: P, Pmac, U, V, g, gmac, f[d].un; then the
-					       3-D ones; DIV: the result of gfship_tree_divergence */
+       GFSHIP_TREE_UN5, GFSHIP_TREE_DIV, GFSHIP_TREE_BCVAL, GFSHIP_TREE_RES };
+				    /* variables of a tree: P, Pmac, U, V, g, gmac, f[d].un; then the 3-D ones;
+				       DIV: the result of gfship_tree_divergence / the right-hand side of
+				       gfship_tree_poisson_solve; BCVAL: the values of the conditions of P, one per
+				       ghost cell (at the face centres); RES: the residual of the last solve */
 int  gfship_tree_create (gfship_tree ** tree, int dim, gfship_refine_fn refine, void * ctx, int device);
+/* the same with GfsBoundary sides (side[d] = GFSHIP_SIDE_PERIODIC or GFSHIP_SIDE_BOUNDARY; the ghost
+   cells of a boundary are refined like the cells they touch, gfs_domain_match): such a tree carries
+   the Poisson problem of a GfsPoisson simulation (poisson_run, src/simulation.c:2213-2285; the case
+   of test/poisson/circle/circle.gfs) -- gfship_tree_set_bc gives the condition of P on a side
+   (GFSHIP_BC_SYMMETRY by default, _DIRICHLET, _NEUMANN: src/boundary.c:45-62,253-279,336-347), its
+   values are uploaded as the variable GFSHIP_TREE_BCVAL, the right-hand side as GFSHIP_TREE_DIV, and
+   gfship_tree_poisson_solve is gfs_poisson_solve (src/poisson.c:1225-1269) with dia = 0: the
+   homogeneous conditions between the sweeps, the conditions themselves after each correction.
+   gfship_tree_start / _step need periodic sides (GFSHIP_EUNSUPPORTED otherwise). */
+int  gfship_tree_create_sides (gfship_tree ** tree, int dim, gfship_refine_fn refine, void * ctx,
+			       const int * side, int device);
+int  gfship_tree_set_bc (gfship_tree * tree, int d, int kind);
+int  gfship_tree_poisson_solve (gfship_tree * tree, gfship_multilevel_params * par, double dt);
 void gfship_tree_destroy (gfship_tree * tree);
 int  gfship_tree_depth (const gfship_tree * tree);                   /* gfs_domain_depth */
 int  gfship_tree_dim (const gfship_tree * tree);

@@ -1683,6 +1683,8 @@ void gt_poisson_run (GtSim * s, Var * divu_unused)
     dd.ddiv = - (dd.sum_div/dd.n)/(dd.sum_vol/dd.n);
     cell_traverse (s, 0, T_LEAFS, -1, add_ddiv, &dd);
   }
+  for (int l = 0; l <= s->depth; l++)     /* kept for the tests: the right-hand side of the solve (slot g[0]) */
+    memcpy (s->g[0].lev[l], div.lev[l], s->size[l]*sizeof (double));
   poisson_coefficients (s);
   poisson_solve (s, &s->approx_projection_params, &s->p, &div, &res, &dia, 1.);
   s->i++;

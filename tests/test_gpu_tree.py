@@ -209,3 +209,63 @@ def test_divergence_variable_on_a_tree():
         assert np.array_equal(g.divergence(l)[1:-1, 1:-1][leaf], o.divergence(l)[1:-1, 1:-1][leaf])
     o.destroy()
     g.destroy()
+
+
+# ---- trees with GfsBoundary sides: the Poisson problem of test/poisson/circle
+
+def _circle_pair(level, kind):
+    import math
+    pi = math.pi
+    refine = lambda x, y: level + 2 if x * x + y * y <= 0.25 * 0.25 else level
+    o = O.Tree(refine=refine, sides=[O.SIDE_BOUNDARY] * 4)
+    g = gfship.Tree(refine, sides=[gfship.SIDE_BOUNDARY] * 4)
+    for d in range(4):
+        o.set_bc(d, kind)
+        g.set_bc(d, kind)
+    for l in range(o.depth + 1):
+        assert np.array_equal(g.flags(l), o.flags(l))
+        x, y = o.centres(l)
+        div = -pi * pi * 18. * np.sin(pi * 3 * x) * np.sin(pi * 3 * y)
+        b = o.bc_values(l)
+        yy, xx = y[:, -1], x[-1, :]
+        if kind == O.BC_NEUMANN:        # circle.gfs:77-80
+            b[:, -1] = 3. * pi * np.cos(pi * 3. * 0.5) * np.sin(pi * 3. * yy)
+            b[:, 0] = -3. * pi * np.cos(pi * 3. * (-0.5)) * np.sin(pi * 3. * yy)
+            b[-1, :] = 3. * pi * np.cos(pi * 3. * 0.5) * np.sin(pi * 3. * xx)
+            b[0, :] = -3. * pi * np.cos(pi * 3. * (-0.5)) * np.sin(pi * 3. * xx)
+        else:                           # the exact solution on the sides (test/poisson/poisson.gfs)
+            b[:, -1] = np.sin(pi * 3. * 0.5) * np.sin(pi * 3. * yy)
+            b[:, 0] = np.sin(pi * 3. * (-0.5)) * np.sin(pi * 3. * yy)
+            b[-1, :] = np.sin(pi * 3. * 0.5) * np.sin(pi * 3. * xx)
+            b[0, :] = np.sin(pi * 3. * (-0.5)) * np.sin(pi * 3. * xx)
+        o.values(O.Tree.PMAC, l)[...] = div
+        g.upload(gfship.Tree.BCVAL, l, b)
+    return o, g
+
+
+@pytest.mark.parametrize("kind,level,cycles", [(gfship.BC_NEUMANN, 5, 3), (gfship.BC_NEUMANN, 6, 10),
+                                               (gfship.BC_DIRICHLET, 5, 4)])
+def test_poisson_on_a_tree_with_boundaries(kind, level, cycles):
+    """poisson_run of test/poisson/circle (Neumann sides, two extra levels inside a circle) and its
+    Dirichlet variant: the solve on the device against the oracle's, P and the maximum residual
+    bit for bit"""
+    o, g = _circle_pair(level, kind)
+    par = o.approx_projection_params
+    par.tolerance, par.nitermin, par.nitermax = 1e-30, cycles, cycles
+    o.poisson_run()
+    # the right-hand side after correct_div (src/simulation.c:2170-2190), as the oracle computed it
+    for l in range(o.depth + 1):
+        g.upload(gfship.Tree.DIV, l, o.values(O.Tree.GX, l))
+    gp = gfship.MultilevelParams()
+    gfship.lib().gfship_multilevel_params_init(gp, 2)
+    gp.tolerance, gp.nitermin, gp.nitermax = 1e-30, cycles, cycles
+    g.poisson_solve(gp)
+    assert gp.niter == par.niter
+    assert gp.residual.infty == par.residual.infty
+    for l in range(o.depth + 1):
+        leaf = o.flags(l)[1:-1, 1:-1] == 1
+        a = g.download(gfship.Tree.P, l)[1:-1, 1:-1][leaf]
+        b = o.values(O.Tree.P, l)[1:-1, 1:-1][leaf]
+        assert np.array_equal(a, b), "P differs on level %d" % l
+    o.destroy()
+    g.destroy()
