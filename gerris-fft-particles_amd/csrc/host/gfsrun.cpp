@@ -1528,13 +1528,16 @@ void resolve_refine (Run & R)
       bool periodic = true;
       for (int d = 0; d < 2*R.dim; d++)
 	if (R.side[d] != GFSHIP_SIDE_PERIODIC) periodic = false;
-      if (R.sim_class == "Simulation" && periodic) {
+      bool sides_ok = true;      /* GfsPoisson: periodic or GfsBoundary sides */
+      for (int d = 0; d < 2*R.dim; d++)
+	if (R.side[d] != GFSHIP_SIDE_PERIODIC && R.side[d] != GFSHIP_SIDE_BOUNDARY) sides_ok = false;
+      if ((R.sim_class == "Simulation" && periodic) || (R.sim_class == "Poisson" && sides_ok)) {
 	R.tree_mode = true;
 	R.level = level;     /* the coarsest leaves */
 	return;
       }
       fprintf (stderr, "gfship: line %d: the Refine function asks for a non-uniform tree at level %d "
-	       "(refined trees: GfsSimulation in one periodic box only)\n", R.refine_line, level);
+	       "(refined trees: GfsSimulation in one periodic box, GfsPoisson in one box)\n", R.refine_line, level);
       exit (1);
     }
     if (!yes) break;
@@ -1567,9 +1570,123 @@ void tree_leaves (Run & R, const std::vector<std::vector<unsigned char>> & flag,
       tree_leaves (R, flag, l + 1, 2*i - 1 + (c & 1), 2*j - ((c >> 1) & 1), 2*k - ((c >> 2) & 1));
 }
 
+// poisson_run (src/simulation.c:2213-2285) on a statically refined tree, sides periodic or GfsBoundary
+int run_tree_poisson (Run & R)
+{
+  static const char * ok[] = { "OutputErrorNorm", "OutputScalarNorm", "OutputScalarSum", "OutputScalarStats",
+			       "OutputTime", "OutputProjectionStats", "EventScript" };
+  for (auto & e : R.events) {
+    bool found = false;
+    for (const char * c : ok) if (e->cls == c) found = true;
+    if (e->cls == "OutputSimulation") {
+      fprintf (stderr, "gfship: line %d: GfsOutputSimulation is not written for a refined tree (skipped)\n", e->line);
+      e->action = [] () {};
+      found = true;
+    }
+    if (!found) {
+      fprintf (stderr, "gfship: line %d: Gfs%s is not supported on a refined tree\n", e->line, e->cls.c_str ());
+      return 1;
+    }
+  }
+  CHECK (gfship_tree_create_sides (&R.tree, R.dim, refine_hook, &R, R.side, R.device));
+  int depth = gfship_tree_depth (R.tree);
+  std::vector<std::vector<unsigned char>> flag (depth + 1);
+  for (int l = 0; l <= depth; l++) {
+    flag[l].resize (R.tree_level_size (l));
+    CHECK (gfship_tree_flags (R.tree, l, flag[l].data ()));
+  }
+  tree_leaves (R, flag, 0, 1, 1, 1);
+  R.vars[R.var_index ("P")].dev = GFSHIP_TREE_P;
+  // the conditions of P: kind per side, value of the GfsFunction at the centre of the face of every
+  // leaf ghost cell (gfs_function_face_value at ftt_face_pos)
+  bool dirichlet = false;
+  for (int d = 0; d < 2*R.dim; d++) {
+    if (R.side[d] != GFSHIP_SIDE_BOUNDARY) continue;
+    for (auto & kv : R.bc[d])
+      if (kv.first != "P") {
+	fprintf (stderr, "gfship: a boundary condition on `%s' is not supported on a refined tree\n", kv.first.c_str ());
+	return 1;
+      }
+    int kind = R.bc[d].count ("P") ? R.bc[d]["P"].kind : GFSHIP_BC_SYMMETRY;
+    if (kind == GFSHIP_BC_DIRICHLET) dirichlet = true;
+    CHECK (gfship_tree_set_bc (R.tree, d, kind));
+  }
+  for (int l = 0; l <= depth; l++) {
+    const int n = 1 << l, r = n + 2;
+    const double h = 1./n;
+    std::vector<double> val (R.tree_level_size (l), 0.);
+    bool any = false;
+    for (int d = 0; d < 2*R.dim; d++) {
+      if (R.side[d] != GFSHIP_SIDE_BOUNDARY || !R.bc[d].count ("P") || !R.bc[d]["P"].val) continue;
+      const int c = d/2, ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
+      for (int b = 1; b <= (R.dim == 3 ? n : 1); b++)
+	for (int a = 1; a <= n; a++) {
+	  int g[3] = { 0, 0, 0 };
+	  g[c] = (d & 1) ? 0 : n + 1;
+	  g[ta] = a;
+	  g[tb] = R.dim == 3 ? b : 0;
+	  size_t G = g[0] + (size_t) r*(g[1] + (R.dim == 3 ? (size_t) r*g[2] : 0));
+	  if (flag[l][G] != 1) continue;          /* leaf ghost cells only */
+	  double p[3] = { -0.5 + (g[0] - 0.5)*h, -0.5 + (g[1] - 0.5)*h, R.dim == 3 ? -0.5 + (g[2] - 0.5)*h : 0. };
+	  p[c] = (d & 1) ? -0.5 : 0.5;            /* the face between the ghost cell and the box */
+	  val[G] = eval (R, R.bc[d]["P"].val, p, -1);
+	  any = true;
+	}
+    }
+    if (any)
+      CHECK (gfship_tree_upload (R.tree, GFSHIP_TREE_BCVAL, l, val.data ()));
+  }
+  apply_multilevel (gfship_tree_projection_params (R.tree, 1), R.approx_set);
+  apply_init (R);
+  events_init (R);
+  gfship_multilevel_params * par = gfship_tree_projection_params (R.tree, 1);
+  while (R.i < R.iend && R.t < R.end) {
+    {
+      // correct_div, src/simulation.c:2170-2190: div = Div size^2 on the leaves; without a Dirichlet
+      // condition its mean is removed (GtsRange means: sums in traversal order over the leaves)
+      const std::vector<double> & Div = host_of (R, R.var_index ("Div"));
+      std::vector<double> div (R.total (), 0.);
+      double sum = 0., vol = 0.;
+      for (size_t c = 0; c < R.leaf_l.size (); c++) {
+	double size = 1./(1 << R.leaf_l[c]);
+	double a = size*size*1.;
+	div[c] = Div[c]*a;
+	vol += a;
+      }
+      if (!dirichlet) {
+	for (size_t c = 0; c < R.leaf_l.size (); c++) sum += div[c];
+	double nn = (double) R.leaf_l.size ();
+	double ddiv = - (sum/nn)/(vol/nn);
+	for (size_t c = 0; c < R.leaf_l.size (); c++) {
+	  double size = 1./(1 << R.leaf_l[c]);
+	  div[c] += size*size*ddiv*1.;
+	}
+      }
+      for (int l = 0; l <= depth; l++) {
+	std::vector<double> lev (R.tree_level_size (l), 0.);
+	bool any = false;
+	for (size_t c = 0; c < R.leaf_l.size (); c++)
+	  if (R.leaf_l[c] == l) { lev[R.tree_index (c)] = div[c]; any = true; }
+	if (any)
+	  CHECK (gfship_tree_upload (R.tree, GFSHIP_TREE_DIV, l, lev.data ()));
+      }
+    }
+    CHECK (gfship_tree_poisson_solve (R.tree, par, 1.));
+    R.t = 0.;
+    R.i++;
+    events_do (R);
+  }
+  for (auto & o : R.outputs) o->close ();
+  gfship_tree_destroy (R.tree);
+  R.tree = nullptr;
+  return 0;
+}
+
 // simulation_run (src/simulation.c:432-557) on a statically refined tree
 int run_tree (Run & R)
 {
+  if (R.sim_class == "Poisson")
+    return run_tree_poisson (R);
   auto refuse = [] (const char * what) {
     fprintf (stderr, "gfship: %s is not supported on a refined tree\n", what);
     return 1;

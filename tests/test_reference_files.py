@@ -61,6 +61,8 @@ def _rows(name):
     ("periodic.gfs", {}, {"LEVEL": 6, "BOX": 0}, "class GfsSimulation dim 2 level 6"),
     ("poiseuille.gfs", {"LEVEL": 5}, None, "class GfsSimulation dim 2 level 5"),
     ("reynolds_box.gfs", {}, {"LEVEL": 5}, "class GfsSimulation dim 2 level 5 (coarsest leaves of a refined tree)"),
+    ("poisson_circle.gfs", {"LEVEL": 5, "CYCLE": 3, "SOLVER": "gerris"}, None,
+     "class GfsPoisson dim 2 level 5 (coarsest leaves of a refined tree)"),
 ])
 def test_reference_files_parse_unmodified(tmp_path, name, defs, sed, expect):
     _stage(tmp_path, name)
@@ -133,6 +135,29 @@ def test_periodic_gfs_refined_patch_against_r1_r2_ref(tmp_path, box, levels):
         out = _run(tmp_path, "periodic.gfs", {}, sed={"LEVEL": level, "BOX": box}).stdout.split()
         want = [r for r in _rows("periodic_r%d.ref" % box) if r[0] == str(level)][0]
         assert ["%.3e" % float(out[6]), "%.3e" % float(out[8])] == want[1:3], (box, level, out)
+
+
+@pytest.mark.gpu
+def test_poisson_circle_gfs_against_res7_and_error_refs(tmp_path):
+    """test/poisson/circle/circle.gfs (`sh ../poisson.sh circle.gfs'): GfsPoisson, Neumann conditions
+    on the four sides, two extra levels inside a circle -- the refined-tree path with GfsBoundary
+    sides.  res-7.ref column 3: LEVEL = 8 (a tree of depth 10) after CYCLE V-cycles; error.ref:
+    levels 3 .. 8 after 10 cycles"""
+    _stage(tmp_path, "poisson_circle.gfs")
+    ref = _rows("poisson_circle_res-7.ref")
+    cycles = (0, 1, 2, 5, 9)
+    for cyc in cycles:
+        _run(tmp_path, "poisson_circle.gfs", {"LEVEL": 8, "CYCLE": cyc, "SOLVER": "gerris"})
+    proj = [l.split() for l in open(str(tmp_path / "proj"))]
+    assert [int(r[0]) for r in proj] == list(cycles)
+    for row in proj:
+        assert "%.3e" % float(row[1]) == ref[int(row[0])][2], (row, ref[int(row[0])])
+    os.remove(str(tmp_path / "error"))
+    for level in (3, 4, 5, 6, 7, 8):
+        _run(tmp_path, "poisson_circle.gfs", {"LEVEL": level, "CYCLE": 10, "SOLVER": "gerris"})
+    err = [l.split() for l in open(str(tmp_path / "error"))]
+    want = _rows("poisson_circle_error.ref")
+    assert [["%d" % int(r[0])] + ["%.3e" % float(x) for x in r[1:4]] for r in err] == [w[:4] for w in want]
 
 
 @pytest.mark.gpu
