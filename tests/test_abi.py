@@ -33,6 +33,8 @@ def test_version():
 def test_no_device_is_an_error_not_a_fallback():
     with pytest.raises(gfship.GfshipError, match="no HIP device"):
         gfship.Domain(3, 3)
+    with pytest.raises(gfship.GfshipError, match="no HIP device"):
+        gfship.Tree(lambda x, y: 3)           # the refined-tree path has no host fallback either
 
 
 def test_multilevel_params_defaults_match_reference():
