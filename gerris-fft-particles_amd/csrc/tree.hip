@@ -112,6 +112,7 @@ struct gfship_tree {
   int side[6] = { 0, 0, 0, 0, 0, 0 };             // GFSHIP_SIDE_PERIODIC / GFSHIP_SIDE_BOUNDARY
   int bc_p[6] = { 0, 0, 0, 0, 0, 0 };             // condition of P on a GfsBoundary side (GFSHIP_BC_*)
   bool has_boundary = false;
+  bool tape_attr_set = false;                     // dynamic-LDS limit of t_relax_tape raised on this device
 };
 
 namespace {
@@ -1274,11 +1275,10 @@ int relax_loop (gfship_tree * tr, int m, unsigned nrelax, double omega)
     const char * e = getenv ("GFSHIP_TREE_TEMPLATE_RELAX");   /* 1: the stencil code walks the tree in every sweep */
     use_template = e ? atoi (e) : 0;
   }
-  static bool attr_set = false;
-  if (!attr_set) {       /* more than 64 KB of dynamic LDS needs the attribute */
+  if (!tr->tape_attr_set) {       /* more than 64 KB of dynamic LDS needs the attribute */
     GFSHIP_HIP (hipFuncSetAttribute ((const void *) t_relax_tape, hipFuncAttributeMaxDynamicSharedMemorySize,
 				     TAPE_LDS_BYTES));
-    attr_set = true;
+    tr->tape_attr_set = true;
   }
   if (S.taped && !use_template)
     t_relax_tape<<<1, 1024, TAPE_LDS_BYTES, tr->stream>>> (tr->D, S.cells, S.cell_off, S.ncells, S.chunk, S.nchunks,
@@ -1582,6 +1582,16 @@ int gfship_tree_create_sides (gfship_tree ** out, int dim, gfship_refine_fn refi
     }
     if (tr->side[d] == GFSHIP_SIDE_BOUNDARY) tr->has_boundary = true;
     tr->bc_p[d] = GFSHIP_BC_SYMMETRY;
+  }
+  {
+    long long total = 0;      /* 32-bit cell indices, times the number of directions in the tables */
+    for (size_t l = 0; l < B.flag.size (); l++)
+      total += (long long) B.flag[l].size ();
+    if (total > (1ll << 27)) {
+      delete tr;
+      set_error ("gfship_tree_create: more than 2^27 cells in the dense levels of the tree");
+      return GFSHIP_EUNSUPPORTED;
+    }
   }
   auto flatten = [&] () {
     Topo & H = tr->H;
