@@ -14,6 +14,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once, as
+    # __graft_entry__.build() does (hipcc cross-compiles without a GPU).  Nothing is rebuilt when the
+    # library, the front end and the oracle are there.
+    pkg = os.path.join(ROOT, "gerris-fft-particles_amd")
+    need = [os.path.join(pkg, "lib", "libgfship.so"), os.path.join(pkg, "bin", "gfship2D"),
+            os.path.join(ROOT, "oracle", "libgfsoracle.so")]
+    if not all(os.path.exists(f) for f in need):
+        import subprocess
+        subprocess.check_call(["bash", os.path.join(pkg, "csrc", "build.sh")])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 
 
 @pytest.fixture(scope="session")
