@@ -69,6 +69,18 @@ struct Sweep {              // T_LEVEL_LEAFS (m) in dependency levels
   int * cell_off = nullptr;           // device, 3*(ncells + 1): start of each cell in ti / td / tv
   int * chunk = nullptr; int nchunks = 0;   // device, 2*(nchunks): first cell, dependency level; + end marker
   bool taped = false;
+  // host copies of the streams and of the order, for the plan of a whole relax loop (loop_plan)
+  std::vector<int> h_ti, h_tv, h_cell_off, h_g;
+  std::vector<double> h_td;
+  std::vector<Ghost> h_ghosts;
+  // a whole relax loop (nrelax sweeps + the copies of the ghosts between them) as ONE list of
+  // nodes in dependency levels: sweep s + 1 of a cell starts as soon as what it reads is final
+  struct Loop {
+    unsigned nrelax = 0;
+    int nnodes = 0, nlev = 0, nchunks = 0;
+    int * ti = nullptr, * tv = nullptr, * node_off = nullptr, * node_g = nullptr, * chunk = nullptr;
+    double * td = nullptr;
+  } loop;
 };
 
 struct DevReader {
@@ -249,7 +261,7 @@ t_relax_loop (Topo T, const Cell * cells, const int * lev_off, int nlev, const G
 // read, with which constant coefficients, combined in which order.  The sweep kernel stages the
 // streams of a chunk of cells in LDS together with the gathered values (one independent load per
 // thread), then evaluates them from LDS: same operations in the same order as the template code.
-enum { K_NONE = 0, K_SAME = 1, K_FC = 2, K_DEEP = 3 };
+enum { K_NONE = 0, K_SAME = 1, K_FC = 2, K_DEEP = 3, K_GHOST = 4 };
 
 struct TapeCursor { const int * ti; const double * td; const double * tv; };
 
@@ -369,6 +381,48 @@ t_relax_tape (Topo T, const Cell * cells, const int * cell_off, int ncells, cons
 	u[gh[t].g] = sg.s[gh[t].side]*u[gh[t].img];
       __syncthreads ();
     }
+  }
+}
+
+// the same for the plan of a whole relax loop (loop_plan): the nodes -- (cell, sweep) and the copies
+// of the ghost cells between the sweeps -- by dependency level; the streams are laid out in node order
+__global__ void __launch_bounds__(1024)
+t_relax_nodes (Topo T, const int * node_g, const int * node_off, const int * chunk, int nchunks,
+	       const int * ti_g, const double * td_g, const int * tv_g, double * u, const double * rhs,
+	       double omega)
+{
+  extern __shared__ double lds[];
+  const int nd = T.nd (), dim = T.dim, ncd = T.ncd ();
+  for (int k = 0; k < nchunks; k++) {
+    const int c0 = chunk[k], c1 = chunk[k + 1];
+    const int i0 = node_off[3*c0], i1 = node_off[3*c1];
+    const int d0 = node_off[3*c0 + 1], d1 = node_off[3*c1 + 1];
+    const int v0 = node_off[3*c0 + 2], v1 = node_off[3*c1 + 2];
+    double * lv = lds, * ld = lds + (v1 - v0);
+    int * li = (int *) (ld + (d1 - d0));
+    for (int t = threadIdx.x; t < v1 - v0; t += blockDim.x)
+      lv[t] = u[tv_g[v0 + t]];
+    for (int t = threadIdx.x; t < d1 - d0; t += blockDim.x)
+      ld[t] = td_g[d0 + t];
+    for (int t = threadIdx.x; t < i1 - i0; t += blockDim.x)
+      li[t] = ti_g[i0 + t];
+    __syncthreads ();
+    for (int c = c0 + threadIdx.x; c < c1; c += blockDim.x) {
+      TapeCursor cur = { li + (node_off[3*c] - i0), ld + (node_off[3*c + 1] - d0), lv + (node_off[3*c + 2] - v0) };
+      const int g = node_g[c];
+      if (*cur.ti == K_GHOST)       /* homogeneous condition / periodic copy: ghost = s * cell */
+	u[g] = (*cur.td)*(*cur.tv);
+      else {
+	const double self = *cur.tv++;
+	double ga, gb;
+	tape_cell (cur, nd, dim, ncd, ga, gb);
+	double x = 0.;
+	if (ga != 0.)
+	  x = dim == 2 ? (1. - omega)*self + omega*(gb - rhs[g])/ga : (gb - rhs[g])/ga;
+	u[g] = x;
+      }
+    }
+    __syncthreads ();
   }
 }
 
@@ -993,6 +1047,7 @@ void ghost_list (const Topo & T, const int * sides, int flags, int max_depth, st
 
 int stencil_tape (gfship_tree * tr, int m, Sweep * S, const std::vector<Cell> & sorted,
 		  const std::vector<int> & lev_off);
+Sgn6 homogeneous_signs (const gfship_tree * tr);
 
 // dependency levels of an exact-order sweep over `order': a cell runs after every earlier cell
 // it reads (it must see the new value) and after every earlier cell that reads it (which must
@@ -1025,6 +1080,40 @@ int sweep_plan (gfship_tree * tr, int m, Sweep * S)
     }
     nlev = std::max (nlev, L + 1);
   }
+  if (getenv ("GFSHIP_TREE_DEBUG")) {
+    // what pipelining the nrelax sweeps of a loop would give: the sequential program [copies of the
+    // ghosts][sweep 0][copies][sweep 1]... scheduled into levels that keep its RAW / WAR / WAW order
+    const int nrelax = 4;
+    std::vector<Ghost> gh0;
+    ghost_list (T, tr->side, T_LEVEL_LEAFS, m, gh0);
+    std::vector<int> wlev (tr->ncell, 0), rlev (tr->ncell, 0);
+    int tot = 0;
+    std::vector<std::vector<int>> rd (order.size ());
+    for (size_t k = 0; k < order.size (); k++) {
+      reads.clear ();
+      relax_cell (T, order[k], R, 0., 1., m);
+      rd[k] = reads;
+    }
+    for (int sw = 0; sw < nrelax; sw++) {
+      for (const Ghost & G : gh0) {
+	int L = std::max (wlev[G.img], std::max (rlev[G.g], wlev[G.g])) + 1;
+	rlev[G.img] = std::max (rlev[G.img], L);
+	wlev[G.g] = L; rlev[G.g] = 0;
+	tot = std::max (tot, L);
+      }
+      for (size_t k = 0; k < order.size (); k++) {
+	const int w = T.gi (order[k]);
+	int L = std::max (rlev[w], wlev[w]);
+	for (int g : rd[k]) L = std::max (L, wlev[g]);
+	L++;
+	for (int g : rd[k]) rlev[g] = std::max (rlev[g], L);
+	wlev[w] = L; rlev[w] = 0;
+	tot = std::max (tot, L);
+      }
+    }
+    fprintf (stderr, "gfship_tree: sweep of level %d: %zu cells, %d dependency levels per sweep, %d x %d = %d sequential, %d pipelined\n",
+	     m, order.size (), nlev, nrelax, nlev, nrelax*nlev, tot);
+  }
   std::vector<int> off (nlev + 1, 0);
   for (size_t k = 0; k < order.size (); k++)
     off[lev[k] + 1]++;
@@ -1039,6 +1128,7 @@ int sweep_plan (gfship_tree * tr, int m, Sweep * S)
   S->ncells = (int) order.size ();
   S->nlev = nlev;
   S->nghosts = (int) gh.size ();
+  S->h_ghosts = gh;
   int e;
   if ((e = to_device (sorted, &S->cells)) || (e = to_device (off, &S->lev_off)) ||
       (e = to_device (gh, &S->ghosts)))
@@ -1170,6 +1260,109 @@ int stencil_tape (gfship_tree * tr, int m, Sweep * S, const std::vector<Cell> & 
   if (o.td.empty ())      /* to_device leaves nullptr for an empty stream: never dereferenced */
     S->td = nullptr;
   S->taped = true;
+  S->h_ti = o.ti; S->h_tv = o.tv; S->h_td = o.td; S->h_cell_off = cell_off;
+  S->h_g.resize (sorted.size ());
+  for (size_t c = 0; c < sorted.size (); c++) S->h_g[c] = T.gi (sorted[c]);
+  return 0;
+}
+
+void loop_free (Sweep::Loop & P)
+{
+  (void) hipFree (P.ti); (void) hipFree (P.tv); (void) hipFree (P.td);
+  (void) hipFree (P.node_off); (void) hipFree (P.node_g); (void) hipFree (P.chunk);
+  P = Sweep::Loop ();
+}
+
+// The relax loop of level m as one program: [copies of the ghosts][sweep 0 in tree order][copies]
+// [sweep 1] ... [sweep nrelax - 1], scheduled into levels that keep the order of every read after the
+// write it must see, and of every write after the reads of the value it replaces (RAW, WAR, WAW of
+// the sequential program): the results are those of the sequential program, and sweep s + 1 follows
+// sweep s a few levels behind instead of waiting for its end
+int loop_plan (gfship_tree * tr, int m, unsigned nrelax, Sweep * S)
+{
+  loop_free (S->loop);
+  const Sgn6 sg = homogeneous_signs (tr);
+  const size_t nc = S->h_g.size ();
+  // the cells were sorted by single-sweep dependency level; the sequential order inside a sweep is
+  // the tree order: recover it from the positions the sweep plan kept (sorted is stable per level,
+  // and any order consistent with the single-sweep levels is a valid sequential order)
+  struct Node { int kind, idx, sweep, level; };   /* kind 0: cell idx of the sweep, 1: ghost idx */
+  std::vector<Node> nodes;
+  nodes.reserve (nrelax*(nc + S->h_ghosts.size ()));
+  std::vector<int> wlev (tr->ncell, 0), rlev (tr->ncell, 0);
+  int nlev = 0;
+  for (unsigned sw = 0; sw < nrelax; sw++) {
+    for (size_t q = 0; q < S->h_ghosts.size (); q++) {
+      const Ghost & G = S->h_ghosts[q];
+      const int L = std::max (wlev[G.img], std::max (rlev[G.g], wlev[G.g])) + 1;
+      rlev[G.img] = std::max (rlev[G.img], L);
+      wlev[G.g] = L; rlev[G.g] = 0;
+      nodes.push_back ({ 1, (int) q, (int) sw, L });
+      nlev = std::max (nlev, L);
+    }
+    for (size_t c = 0; c < nc; c++) {
+      const int w = S->h_g[c];
+      int L = std::max (rlev[w], wlev[w]);
+      for (int k = S->h_cell_off[3*c + 2]; k < S->h_cell_off[3*(c + 1) + 2]; k++)
+	L = std::max (L, wlev[S->h_tv[k]]);
+      L++;
+      for (int k = S->h_cell_off[3*c + 2]; k < S->h_cell_off[3*(c + 1) + 2]; k++)
+	rlev[S->h_tv[k]] = std::max (rlev[S->h_tv[k]], L);
+      wlev[w] = L; rlev[w] = 0;
+      nodes.push_back ({ 0, (int) c, (int) sw, L });
+      nlev = std::max (nlev, L);
+    }
+  }
+  std::stable_sort (nodes.begin (), nodes.end (), [] (const Node & a, const Node & b) { return a.level < b.level; });
+  std::vector<int> ti, tv, node_off, node_g, chunk;
+  std::vector<double> td;
+  for (const Node & N : nodes) {
+    node_off.push_back ((int) ti.size ()); node_off.push_back ((int) td.size ()); node_off.push_back ((int) tv.size ());
+    if (N.kind == 1) {
+      const Ghost & G = S->h_ghosts[N.idx];
+      ti.push_back (K_GHOST);
+      td.push_back (sg.s[G.side]);
+      tv.push_back (G.img);
+      node_g.push_back (G.g);
+    }
+    else {
+      const int c = N.idx;
+      ti.insert (ti.end (), S->h_ti.begin () + S->h_cell_off[3*c], S->h_ti.begin () + S->h_cell_off[3*(c + 1)]);
+      td.insert (td.end (), S->h_td.begin () + S->h_cell_off[3*c + 1], S->h_td.begin () + S->h_cell_off[3*(c + 1) + 1]);
+      tv.insert (tv.end (), S->h_tv.begin () + S->h_cell_off[3*c + 2], S->h_tv.begin () + S->h_cell_off[3*(c + 1) + 2]);
+      node_g.push_back (S->h_g[c]);
+    }
+  }
+  node_off.push_back ((int) ti.size ()); node_off.push_back ((int) td.size ()); node_off.push_back ((int) tv.size ());
+  // chunks: consecutive nodes of one level whose streams fit the LDS
+  size_t c = 0;
+  while (c < nodes.size ()) {
+    chunk.push_back ((int) c);
+    size_t e = c;
+    while (e < nodes.size () && nodes[e].level == nodes[c].level) {
+      const size_t bytes = 8*(size_t) (node_off[3*(e + 1) + 2] - node_off[3*c + 2]) +
+	8*(size_t) (node_off[3*(e + 1) + 1] - node_off[3*c + 1]) + 4*(size_t) (node_off[3*(e + 1)] - node_off[3*c]) + 8;
+      if (bytes > TAPE_LDS_BYTES)
+	break;
+      e++;
+    }
+    if (e == c) return GFSHIP_EUNSUPPORTED;
+    c = e;
+  }
+  Sweep::Loop & P = S->loop;
+  P.nchunks = (int) chunk.size ();
+  chunk.push_back ((int) nodes.size ());
+  P.nnodes = (int) nodes.size ();
+  P.nlev = nlev;
+  int e;
+  if ((e = to_device (ti, &P.ti)) || (e = to_device (td, &P.td)) || (e = to_device (tv, &P.tv)) ||
+      (e = to_device (node_off, &P.node_off)) || (e = to_device (node_g, &P.node_g)) ||
+      (e = to_device (chunk, &P.chunk)))
+    return e;
+  P.nrelax = nrelax;
+  if (getenv ("GFSHIP_TREE_DEBUG"))
+    fprintf (stderr, "gfship_tree: relax loop of level %d: %u sweeps, %d nodes in %d levels, %d chunks\n",
+	     m, nrelax, P.nnodes, P.nlev, P.nchunks);
   return 0;
 }
 
@@ -1280,7 +1473,22 @@ int relax_loop (gfship_tree * tr, int m, unsigned nrelax, double omega)
 				     TAPE_LDS_BYTES));
     tr->tape_attr_set = true;
   }
-  if (S.taped && !use_template)
+  static int no_pipeline = -1;
+  if (no_pipeline < 0) {
+    const char * e = getenv ("GFSHIP_TREE_NO_PIPELINE");      /* 1: sweep after sweep (t_relax_tape) */
+    no_pipeline = e ? atoi (e) : 0;
+  }
+  if (S.taped && !use_template && !no_pipeline) {
+    if (S.loop.nrelax != nrelax) {
+      int e = loop_plan (tr, m, nrelax, &S);
+      if (e) return e;
+    }
+    GFSHIP_HIP (hipFuncSetAttribute ((const void *) t_relax_nodes, hipFuncAttributeMaxDynamicSharedMemorySize,
+				     TAPE_LDS_BYTES));
+    t_relax_nodes<<<1, 1024, TAPE_LDS_BYTES, tr->stream>>> (tr->D, S.loop.node_g, S.loop.node_off, S.loop.chunk,
+	S.loop.nchunks, S.loop.ti, S.loop.td, S.loop.tv, tr->var[V_DP], tr->var[V_RES], omega);
+  }
+  else if (S.taped && !use_template)
     t_relax_tape<<<1, 1024, TAPE_LDS_BYTES, tr->stream>>> (tr->D, S.cells, S.cell_off, S.ncells, S.chunk, S.nchunks,
 	S.ti, S.td, S.tv, S.ghosts, S.nghosts, tr->var[V_DP], tr->var[V_RES], nrelax, omega, homogeneous_signs (tr));
   else
@@ -1532,6 +1740,7 @@ void tree_free (gfship_tree * tr)
     (void) hipFree (tr->sweep[l].cells); (void) hipFree (tr->sweep[l].lev_off); (void) hipFree (tr->sweep[l].ghosts);
     (void) hipFree (tr->sweep[l].ti); (void) hipFree (tr->sweep[l].td); (void) hipFree (tr->sweep[l].tv);
     (void) hipFree (tr->sweep[l].cell_off); (void) hipFree (tr->sweep[l].chunk);
+    loop_free (tr->sweep[l].loop);
   }
   for (FaceSet & F : tr->fs) { (void) hipFree (F.faces); (void) hipFree (F.inc_off); (void) hipFree (F.inc); (void) hipFree (F.fval); }
   (void) hipFree (tr->d_red);
@@ -1780,6 +1989,8 @@ int gfship_tree_set_bc (gfship_tree * tr, int d, int kind)
 		(kind == GFSHIP_BC_SYMMETRY || kind == GFSHIP_BC_DIRICHLET || kind == GFSHIP_BC_NEUMANN),
 		GFSHIP_EINVAL, "gfship_tree_set_bc: bad argument");
   tr->bc_p[d] = kind;
+  for (int l = 0; l <= GFSHIP_MAXLEVEL; l++)     /* the signs of the homogeneous conditions are in the plans */
+    loop_free (tr->sweep[l].loop);
   return GFSHIP_OK;
 }
 
