@@ -271,17 +271,20 @@ def test_poisson_on_a_tree_with_boundaries(kind, level, cycles):
     g.destroy()
 
 
-def test_tree_walking_relax_kernel_gives_the_same_bits():
+@pytest.mark.parametrize("switch", ["GFSHIP_TREE_TEMPLATE_RELAX", "GFSHIP_TREE_NO_PIPELINE"])
+def test_other_relax_kernels_give_the_same_bits(switch):
     """GFSHIP_TREE_TEMPLATE_RELAX=1: the sweeps by the kernel that walks the tree for every cell
-    (the code the compiled stencils were derived from) instead of the compiled stencils: the same
-    comparison with the oracle, in a process of its own (the switch is read once)"""
+    (the code the compiled stencils were derived from); GFSHIP_TREE_NO_PIPELINE=1: compiled stencils,
+    sweep after sweep instead of the plan of a whole loop: the same comparison with the oracle, in a
+    process of its own (the switches are read once)"""
     import subprocess
     import sys
     code = ("import sys; sys.path.insert(0, %r); import test_gpu_tree as t; "
             "t.test_tree_steps_bit_exact(4, 2, 3); t.test_octree_steps_bit_exact('blob', 3, 2, 2); "
             "t.test_poisson_on_a_tree_with_boundaries(t.gfship.BC_NEUMANN, 5, 3)"
             % os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GFSHIP_TREE_TEMPLATE_RELAX="1")
+    env = dict(os.environ)
+    env[switch] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "gerris-fft-particles_amd"),
                                          env.get("PYTHONPATH", "")])
