@@ -290,3 +290,52 @@ def test_other_relax_kernels_give_the_same_bits(switch):
                                          env.get("PYTHONPATH", "")])
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_poisson_on_an_octree_with_dirichlet_sides():
+    """the 3-D analogue of test/poisson (BASELINE config B: P = sin 3 pi x sin 3 pi y sin 3 pi z on the six
+    sides, Div = -27 pi^2 P) on an octree with two extra levels inside a ball: the solve on the device
+    against the octree oracle, P and the maximum residual bit for bit"""
+    import math
+    pi = math.pi
+    level, cycles = 4, 5
+    refine = lambda x, y, z: level + 2 if x * x + y * y + z * z <= 0.2 * 0.2 else level
+    o = O.Tree(refine=refine, dim=3, sides=[O.SIDE_BOUNDARY] * 6)
+    g = gfship.Tree(refine, dim=3, sides=[gfship.SIDE_BOUNDARY] * 6)
+    exact = lambda x, y, z: np.sin(3 * pi * x) * np.sin(3 * pi * y) * np.sin(3 * pi * z)
+    for d in range(6):
+        o.set_bc(d, O.BC_DIRICHLET)
+        g.set_bc(d, gfship.BC_DIRICHLET)
+    for l in range(o.depth + 1):
+        assert np.array_equal(g.flags(l), o.flags(l))
+        x, y, z = o.centres(l)
+        o.values(O.Tree.PMAC, l)[...] = -27. * pi * pi * exact(x, y, z)
+        b = o.bc_values(l)
+        # the value at the centre of the face between a ghost cell and the box: clamp the coordinate
+        # normal to the side to +-1/2
+        cx, cy, cz = np.clip(x, -0.5, 0.5), np.clip(y, -0.5, 0.5), np.clip(z, -0.5, 0.5)
+        b[...] = exact(cx, cy, cz)
+        g.upload(gfship.Tree.BCVAL, l, b)
+    par = o.approx_projection_params
+    par.tolerance, par.nitermin, par.nitermax = 1e-30, cycles, cycles
+    o.poisson_run()
+    for l in range(o.depth + 1):
+        g.upload(gfship.Tree.DIV, l, o.values(O.Tree.GX, l))
+    gp = gfship.MultilevelParams()
+    gfship.lib().gfship_multilevel_params_init(gp, 3)
+    gp.tolerance, gp.nitermin, gp.nitermax = 1e-30, cycles, cycles
+    g.poisson_solve(gp)
+    assert gp.niter == par.niter and gp.residual.infty == par.residual.infty
+    assert par.residual.infty < 1e-2 * par.residual_before.infty          # and it does converge
+    err = 0.
+    for l in range(o.depth + 1):
+        leaf = o.flags(l)[1:-1, 1:-1, 1:-1] == 1
+        a = g.download(gfship.Tree.P, l)[1:-1, 1:-1, 1:-1][leaf]
+        b = o.values(O.Tree.P, l)[1:-1, 1:-1, 1:-1][leaf]
+        assert np.array_equal(a, b), "P differs on level %d" % l
+        if leaf.any():
+            x, y, z = o.centres(l)
+            err = max(err, float(np.abs(a - exact(x, y, z)[1:-1, 1:-1, 1:-1][leaf]).max()))
+    assert err < 0.1          # 16^3 base grid, 1.5 wavelengths per side (2-D, test/poisson/circle: 2.9e-2)
+    o.destroy()
+    g.destroy()
