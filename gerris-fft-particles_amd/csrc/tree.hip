@@ -80,6 +80,9 @@ struct Sweep {              // T_LEVEL_LEAFS (m) in dependency levels
     int nnodes = 0, nlev = 0, nchunks = 0;
     int * ti = nullptr, * tv = nullptr, * node_off = nullptr, * node_g = nullptr, * chunk = nullptr;
     double * td = nullptr;
+    // host copies (gfship_tree_host_check)
+    std::vector<int> h_ti, h_tv, h_node_off, h_node_g, h_node_level;
+    std::vector<double> h_td;
   } loop;
 };
 
@@ -267,7 +270,7 @@ struct TapeCursor { const int * ti; const double * td; const double * tv; };
 
 // p.b of interpolate_1D1 / interpolate_2D1 from the streams: sum of a_j * P_j, P_j a value or the
 // average of the children of a refined neighbour (average_neighbor_value)
-__device__ inline double tape_interpolation (TapeCursor & c)
+__host__ __device__ inline double tape_interpolation (TapeCursor & c)
 {
   const int nt = *c.ti++;
   double pb = 0.;
@@ -291,7 +294,7 @@ __device__ inline double tape_interpolation (TapeCursor & c)
 }
 
 // the sums g.a, g.b of relax / residual_set over the faces of a cell (src/poisson.c:507-557,634-678)
-__device__ inline void tape_cell (TapeCursor & c, int nd, int dim, int ncd, double & ga, double & gb)
+__host__ __device__ inline void tape_cell (TapeCursor & c, int nd, int dim, int ncd, double & ga, double & gb)
 {
   ga = 0.; gb = 0.;
   for (int d = 0; d < nd; d++) {
@@ -1005,10 +1008,14 @@ void face_list (const Topo & T, const std::vector<Cell> & leaves, int kind, std:
   }
 }
 
+// gfship_tree_host_check builds the host side of a tree (flags, tables, lists, dependency levels,
+// compiled stencils, loop plans) without a device: nothing is uploaded
+bool g_host_only = false;
+
 template <class X> int to_device (const std::vector<X> & h, X ** d)
 {
   *d = nullptr;
-  if (h.empty ()) return 0;
+  if (h.empty () || g_host_only) return 0;
   GFSHIP_HIP (hipMalloc ((void **) d, h.size ()*sizeof (X)));
   GFSHIP_HIP (hipMemcpy (*d, h.data (), h.size ()*sizeof (X), hipMemcpyHostToDevice));
   return 0;
@@ -1360,6 +1367,10 @@ int loop_plan (gfship_tree * tr, int m, unsigned nrelax, Sweep * S)
       (e = to_device (chunk, &P.chunk)))
     return e;
   P.nrelax = nrelax;
+  if (g_host_only) {
+    P.h_ti = ti; P.h_tv = tv; P.h_td = td; P.h_node_off = node_off; P.h_node_g = node_g;
+    for (const Node & N : nodes) P.h_node_level.push_back (N.level);
+  }
   if (getenv ("GFSHIP_TREE_DEBUG"))
     fprintf (stderr, "gfship_tree: relax loop of level %d: %u sweeps, %d nodes in %d levels, %d chunks\n",
 	     m, nrelax, P.nnodes, P.nlev, P.nchunks);
@@ -1390,7 +1401,8 @@ int face_set (gfship_tree * tr, int kind, FaceSet * F)
   if ((e = to_device (faces, &F->faces)) || (e = to_device (off, &F->inc_off)) ||
       (e = to_device (flat, &F->inc)))
     return e;
-  GFSHIP_HIP (hipMalloc ((void **) &F->fval, std::max<size_t> (1, faces.size ())*sizeof (double)));
+  if (!g_host_only)
+    GFSHIP_HIP (hipMalloc ((void **) &F->fval, std::max<size_t> (1, faces.size ())*sizeof (double)));
   return 0;
 }
 
@@ -1765,13 +1777,15 @@ int gfship_tree_create_sides (gfship_tree ** out, int dim, gfship_refine_fn refi
 {
   GFSHIP_CHECK (out && refine, GFSHIP_EINVAL, "gfship_tree_create: null argument");
   GFSHIP_CHECK (dim == 2 || dim == 3, GFSHIP_EINVAL, "gfship_tree_create: dim = %d", dim);
-  int ndev = 0;
-  if (hipGetDeviceCount (&ndev) != hipSuccess || ndev == 0) {
-    set_error ("gfship_tree_create: no HIP device");
-    return GFSHIP_ENODEVICE;
+  if (!g_host_only) {
+    int ndev = 0;
+    if (hipGetDeviceCount (&ndev) != hipSuccess || ndev == 0) {
+      set_error ("gfship_tree_create: no HIP device");
+      return GFSHIP_ENODEVICE;
+    }
+    GFSHIP_CHECK (device >= 0 && device < ndev, GFSHIP_EINVAL, "gfship_tree_create: device %d of %d", device, ndev);
+    GFSHIP_HIP (hipSetDevice (device));
   }
-  GFSHIP_CHECK (device >= 0 && device < ndev, GFSHIP_EINVAL, "gfship_tree_create: device %d of %d", device, ndev);
-  GFSHIP_HIP (hipSetDevice (device));
 
   // gfs_refine_refine + gfs_simulation_refine, src/refine.c:45-60, src/simulation.c:1203-1233
   Builder B;
@@ -1866,13 +1880,17 @@ int gfship_tree_create_sides (gfship_tree ** out, int dim, gfship_refine_fn refi
   }
 
   const Topo & T = tr->H;
-  hipError_t he = hipStreamCreate (&tr->stream);
-  if (he != hipSuccess) { tree_free (tr); return hip_fail (he, "hipStreamCreate", __FILE__, __LINE__); }
+  if (!g_host_only) {
+    hipError_t he = hipStreamCreate (&tr->stream);
+    if (he != hipSuccess) { tree_free (tr); return hip_fail (he, "hipStreamCreate", __FILE__, __LINE__); }
+  }
 #define TRY(call) do { int e_ = (call); if (e_) { tree_free (tr); return e_; } } while (0)
 #define TRYHIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { tree_free (tr); \
       return hip_fail (e_, #call, __FILE__, __LINE__); } } while (0)
-  TRYHIP (hipMalloc ((void **) &tr->dflag, tr->ncell));
-  TRYHIP (hipMemcpy (tr->dflag, tr->hflag.data (), tr->ncell, hipMemcpyHostToDevice));
+  if (!g_host_only) {
+    TRYHIP (hipMalloc ((void **) &tr->dflag, tr->ncell));
+    TRYHIP (hipMemcpy (tr->dflag, tr->hflag.data (), tr->ncell, hipMemcpyHostToDevice));
+  }
   {
     // the tables of Topo (tree.hpp), from the computed answers
     Topo & H = tr->H;
@@ -1915,12 +1933,14 @@ int gfship_tree_create_sides (gfship_tree ** out, int dim, gfship_refine_fn refi
   tr->D.child0 = tr->d_child0;
   tr->D.cmask = tr->d_cmask;
   tr->D.idtab = tr->d_idtab;
-  for (int v = 0; v < V_NVAR; v++) {
+  for (int v = 0; v < V_NVAR && !g_host_only; v++) {
     TRYHIP (hipMalloc ((void **) &tr->var[v], tr->ncell*sizeof (double)));
     TRYHIP (hipMemset (tr->var[v], 0, tr->ncell*sizeof (double)));
   }
-  TRYHIP (hipMalloc ((void **) &tr->d_red, 4*sizeof (double)));
-  TRYHIP (hipHostMalloc ((void **) &tr->h_red, 4*sizeof (double), 0));
+  if (!g_host_only) {
+    TRYHIP (hipMalloc ((void **) &tr->d_red, 4*sizeof (double)));
+    TRYHIP (hipHostMalloc ((void **) &tr->h_red, 4*sizeof (double), 0));
+  }
   traverse (T, root_cell (T), T_LEAFS, -1, [&] (Cell c) { tr->hleaves.push_back (c); });
   tr->nleaves = (int) tr->hleaves.size ();
   TRY (to_device (tr->hleaves, &tr->leaves));
@@ -2035,6 +2055,135 @@ int gfship_tree_divergence (gfship_tree * tr)
   t_divergence_centered<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, p3 (tr, V_U), tr->var[V_DIV]);
   KCHECK ();
   return GFSHIP_OK;
+}
+
+/* Host-side self-check of the plans of a tree, without a device (for the CPU tests): builds the tree
+   and, for every level m, runs the relax loop of nrelax sweeps on pseudo-random values three ways on
+   the host -- (1) the reference's program: copies of the ghosts, the cells in tree order through the
+   stencil code that walks the tree (tree.hpp), sweep after sweep; (2) sweep after sweep through the
+   compiled stencils, the cells of a dependency level in REVERSE order; (3) the plan of the whole loop,
+   the nodes of a level in reverse order -- and compares the three results bit for bit.
+   stats[0] = cells of all sweeps, [1] = dependency levels sweep after sweep, [2] = levels of the loop
+   plans, [3] = cells whose results differ (0 when the plans are right). */
+int gfship_tree_host_check (int dim, gfship_refine_fn refine, void * ctx, const int * side,
+			    unsigned nrelax, long long stats[4])
+{
+  GFSHIP_CHECK (refine && stats && nrelax >= 1, GFSHIP_EINVAL, "gfship_tree_host_check: bad argument");
+  gfship_tree * tr = nullptr;
+  g_host_only = true;
+  int e = gfship_tree_create_sides (&tr, dim, refine, ctx, side, 0);
+  if (e) { g_host_only = false; return e; }
+  const Topo & T = tr->H;
+  stats[0] = stats[1] = stats[2] = stats[3] = 0;
+  const Sgn6 sg = homogeneous_signs (tr);
+  struct HostReader {
+    const double * p;
+    double operator() (const Topo & T, Cell c) const { return p[T.gi (c)]; }
+  };
+  for (int m = 0; m <= T.depth && !e; m++) {
+    Sweep & S = tr->sweep[m];
+    e = loop_plan (tr, m, nrelax, &S);
+    if (e) break;
+    std::vector<double> u0 (tr->ncell), rhs (tr->ncell);
+    unsigned long long seed = 88172645463325252ull + m;
+    for (int g = 0; g < tr->ncell; g++) {
+      seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17;
+      u0[g] = (double) (seed % 2000001)/1e6 - 1.;
+      seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17;
+      rhs[g] = (double) (seed % 2000001)/1e6 - 1.;
+    }
+    const double omega = 1.;
+    // (1) the sequential program through the tree-walking stencil code
+    std::vector<double> a = u0;
+    std::vector<Cell> order;
+    traverse (T, root_cell (T), T_LEVEL_LEAFS, m, [&] (Cell c) { order.push_back (c); });
+    for (unsigned sw = 0; sw < nrelax; sw++) {
+      for (const Ghost & G : S.h_ghosts) a[G.g] = sg.s[G.side]*a[G.img];
+      HostReader R = { a.data () };
+      for (Cell c : order) {
+	const int g = T.gi (c);
+	a[g] = relax_cell (T, c, R, rhs[g], omega, m);
+      }
+    }
+    // (2) compiled stencils, sweep after sweep, each dependency level backwards
+    std::vector<double> b = u0;
+    {
+      std::vector<int> lev_of (S.h_g.size (), 0);   /* recompute the levels from the read sets */
+      std::vector<int> wl (tr->ncell, 0), rl (tr->ncell, 0);
+      int nl = 0;
+      for (size_t c = 0; c < S.h_g.size (); c++) {
+	const int w = S.h_g[c];
+	int L = std::max (rl[w], wl[w]);
+	for (int k = S.h_cell_off[3*c + 2]; k < S.h_cell_off[3*(c + 1) + 2]; k++) L = std::max (L, wl[S.h_tv[k]]);
+	L++;
+	for (int k = S.h_cell_off[3*c + 2]; k < S.h_cell_off[3*(c + 1) + 2]; k++) rl[S.h_tv[k]] = std::max (rl[S.h_tv[k]], L);
+	wl[w] = L; rl[w] = 0;
+	lev_of[c] = L; nl = std::max (nl, L);
+      }
+      stats[1] += (long long) nl*nrelax;
+      for (unsigned sw = 0; sw < nrelax; sw++) {
+	for (const Ghost & G : S.h_ghosts) b[G.g] = sg.s[G.side]*b[G.img];
+	for (int L = 1; L <= nl; L++) {
+	  std::vector<std::pair<int, double>> out;
+	  for (size_t c = S.h_g.size (); c-- > 0; )
+	    if (lev_of[c] == L) {
+	      std::vector<double> vals;
+	      for (int k = S.h_cell_off[3*c + 2]; k < S.h_cell_off[3*(c + 1) + 2]; k++) vals.push_back (b[S.h_tv[k]]);
+	      TapeCursor cur = { S.h_ti.data () + S.h_cell_off[3*c], S.h_td.data () + S.h_cell_off[3*c + 1], vals.data () };
+	      const double self = *cur.tv++;
+	      double ga, gb;
+	      tape_cell (cur, T.nd (), T.dim, T.ncd (), ga, gb);
+	      const int g = S.h_g[c];
+	      double x = 0.;
+	      if (ga != 0.)
+		x = T.dim == 2 ? (1. - omega)*self + omega*(gb - rhs[g])/ga : (gb - rhs[g])/ga;
+	      out.push_back ({ g, x });
+	    }
+	  for (auto & kv : out) b[kv.first] = kv.second;      /* the level's stores after its loads */
+	}
+      }
+    }
+    // (3) the plan of the whole loop, the nodes of a level backwards
+    std::vector<double> c3 = u0;
+    {
+      const Sweep::Loop & P = S.loop;
+      stats[2] += P.nlev;
+      size_t k0 = 0;
+      const size_t nn = P.h_node_g.size ();
+      while (k0 < nn) {
+	size_t k1 = k0;
+	while (k1 < nn && P.h_node_level[k1] == P.h_node_level[k0]) k1++;
+	std::vector<std::pair<int, double>> out;
+	for (size_t k = k1; k-- > k0; ) {
+	  std::vector<double> vals;
+	  for (int q = P.h_node_off[3*k + 2]; q < P.h_node_off[3*(k + 1) + 2]; q++) vals.push_back (c3[P.h_tv[q]]);
+	  TapeCursor cur = { P.h_ti.data () + P.h_node_off[3*k], P.h_td.data () + P.h_node_off[3*k + 1], vals.data () };
+	  const int g = P.h_node_g[k];
+	  double x;
+	  if (*cur.ti == K_GHOST)
+	    x = (*cur.td)*(*cur.tv);
+	  else {
+	    const double self = *cur.tv++;
+	    double ga, gb;
+	    tape_cell (cur, T.nd (), T.dim, T.ncd (), ga, gb);
+	    x = 0.;
+	    if (ga != 0.)
+	      x = T.dim == 2 ? (1. - omega)*self + omega*(gb - rhs[g])/ga : (gb - rhs[g])/ga;
+	  }
+	  out.push_back ({ g, x });
+	}
+	for (auto & kv : out) c3[kv.first] = kv.second;
+	k0 = k1;
+      }
+    }
+    stats[0] += (long long) order.size ()*nrelax;
+    for (int g = 0; g < tr->ncell; g++)
+      if (memcmp (&a[g], &b[g], sizeof (double)) || memcmp (&a[g], &c3[g], sizeof (double)))
+	stats[3]++;
+  }
+  tree_free (tr);
+  g_host_only = false;
+  return e;
 }
 
 /* the cells of the sweep of level `level' and the number of dependency levels they form */

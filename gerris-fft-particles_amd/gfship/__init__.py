@@ -172,6 +172,7 @@ SIGNATURES = {
     "gfship_tree_step": (_i, [_vp]),
     "gfship_tree_sweep_levels": (_i, [_vp, _i, _pi, _pi]),
     "gfship_tree_divergence": (_i, [_vp]),
+    "gfship_tree_host_check": (_i, [_i, C.c_void_p, _vp, _pi, _u, C.POINTER(C.c_longlong)]),
 }
 
 
@@ -659,6 +660,19 @@ class ParticleList:
 
 
 REFINE_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p)
+
+
+def tree_host_check(refine, dim=2, sides=None, nrelax=4):
+    """gfship_tree_host_check: the plans of a tree validated on the host (no device needed);
+    returns (cell updates, levels sweep after sweep, levels of the loop plans, differing values)"""
+    if dim == 2:
+        cb = REFINE_FN(lambda x, y, z, ctx: float(refine(x, y)))
+    else:
+        cb = REFINE_FN(lambda x, y, z, ctx: float(refine(x, y, z)))
+    arr = (C.c_int * 6)(*(list(sides) + [0] * 6)[:6]) if sides is not None else None
+    stats = (C.c_longlong * 4)()
+    _check(lib().gfship_tree_host_check(dim, C.cast(cb, C.c_void_p), None, arr, nrelax, stats))
+    return tuple(stats)
 
 
 class Tree:

@@ -550,6 +550,14 @@ int  gfship_tree_step (gfship_tree * tree);
 /* the derived variable `Divergence' (gfs_divergence, src/fluid.c:2357-2376, with
    gfs_face_interpolated_value_generic :2200-2221) of the leaves into GFSHIP_TREE_DIV */
 int  gfship_tree_divergence (gfship_tree * tree);
+/* host-side self-check of the plans of a tree, needs no device (CPU tests): for every level the relax
+   loop of nrelax sweeps is run on the host (a) as the reference's program -- ghost copies, the cells in
+   tree order through the stencil code that walks the tree --, (b) through the compiled stencils by
+   dependency level, each level backwards, (c) through the plan of the whole loop, each level
+   backwards; stats[0] = cell updates, [1] = dependency levels sweep after sweep, [2] = levels of the
+   loop plans, [3] = number of values that differ between (a), (b), (c): 0 for valid plans */
+int  gfship_tree_host_check (int dim, gfship_refine_fn refine, void * ctx, const int * side,
+			     unsigned nrelax, long long stats[4]);
 /* diagnostics: the cells of the sweep of gfs_relax on `level' (the cells of the level and the
    coarser leaves) and the number of dependency levels its tree order leaves on the device */
 int  gfship_tree_sweep_levels (const gfship_tree * tree, int level, int * ncells, int * nlevels);
