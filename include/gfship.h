@@ -491,7 +491,7 @@ int  gfship_halo_pack_sides (gfship_domain * dom, const void * dev_ptr, int leve
 int  gfship_halo_unpack_sides (gfship_domain * dom, void * dev_ptr, int level, int nsides,
 			       const int * sides, void * const * dev_bufs);
 
-/* ---- statically refined quadtree (coarse-fine stencils, 2-D) -------------------------------- */
+/* ---- statically refined quadtree / octree (coarse-fine stencils) ---------------------------- */
 
 /* A GfsSimulation on one periodic GfsBox whose tree is refined by a GfsRefine function instead of
    `Refine <int>' (the case of test/periodic/periodic.gfs with BOX = 1, 2; quadtree for dim = 2, octree
@@ -506,8 +506,11 @@ int  gfship_halo_unpack_sides (gfship_domain * dom, void * dev_ptr, int level, i
    branches of src/fluid.c:64-93,178-197,283-309,364-396,778-893, src/advection.c:132-180,267-343,
    398-435,513-587, src/timestep.c:118-144 (in 3-D their FTT_3D forms: interpolate_2D1, src/fluid.c:214-245,
    src/advection.c:183-249): Euler equations, centred gradients, alpha = NULL, all sides periodic,
-   refinement equal across each periodic pair (else GFSHIP_EUNSUPPORTED).  Results are those of the reference's traversal orders: the sweeps of
-   gfs_relax run in tree order, the face loops accumulate in face-traversal order. */
+   refinement equal across each periodic pair (else GFSHIP_EUNSUPPORTED).  Results are those of the
+   reference's traversal orders: the sweeps of gfs_relax run in tree order, the face loops accumulate
+   in face-traversal order.  gfship_tree_host_check is not reentrant (it switches the library into a
+   host-only mode while it runs); everything else follows the threading rule of the rest of the ABI:
+   one thread per tree. */
 typedef struct gfship_tree gfship_tree;
 typedef double (* gfship_refine_fn) (double x, double y, double z, void * ctx);
 enum { GFSHIP_TREE_P = 0, GFSHIP_TREE_PMAC, GFSHIP_TREE_U, GFSHIP_TREE_V, GFSHIP_TREE_GX, GFSHIP_TREE_GY,
