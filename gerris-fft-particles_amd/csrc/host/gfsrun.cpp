@@ -1531,13 +1531,14 @@ void resolve_refine (Run & R)
       bool sides_ok = true;      /* GfsPoisson: periodic or GfsBoundary sides */
       for (int d = 0; d < 2*R.dim; d++)
 	if (R.side[d] != GFSHIP_SIDE_PERIODIC && R.side[d] != GFSHIP_SIDE_BOUNDARY) sides_ok = false;
-      if ((R.sim_class == "Simulation" && periodic) || (R.sim_class == "Poisson" && sides_ok)) {
+      (void) periodic;
+      if ((R.sim_class == "Simulation" || R.sim_class == "Poisson") && sides_ok) {
 	R.tree_mode = true;
 	R.level = level;     /* the coarsest leaves */
 	return;
       }
       fprintf (stderr, "gfship: line %d: the Refine function asks for a non-uniform tree at level %d "
-	       "(refined trees: GfsSimulation in one periodic box, GfsPoisson in one box)\n", R.refine_line, level);
+	       "(refined trees: GfsSimulation or GfsPoisson in one box)\n", R.refine_line, level);
       exit (1);
     }
     if (!yes) break;
@@ -1737,7 +1738,13 @@ int run_tree (Run & R)
 	}
       };
   }
-  CHECK (gfship_tree_create (&R.tree, R.dim, refine_hook, &R, R.device));
+  for (int d = 0; d < 2*R.dim; d++)
+    if (!R.bc[d].empty ()) {     /* GfsBoundary sides: the default conditions (symmetry: slip walls) only */
+      fprintf (stderr, "gfship: a GfsSimulation on a refined tree knows the default boundary conditions only "
+	       "(side %s has a Bc)\n", side_name[d]);
+      return 1;
+    }
+  CHECK (gfship_tree_create_sides (&R.tree, R.dim, refine_hook, &R, R.side, R.device));
   int depth = gfship_tree_depth (R.tree);
   std::vector<std::vector<unsigned char>> flag (depth + 1);
   for (int l = 0; l <= depth; l++) {

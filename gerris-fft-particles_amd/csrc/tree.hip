@@ -140,6 +140,13 @@ __global__ void t_copy_ghosts (const Ghost * gh, int n, double * v)
   if (t < n) v[gh[t].g] = v[gh[t].img];
 }
 
+// symmetry (the default GfsBc, src/boundary.c:45-62) of a vector component / periodic copy: ghost = s * cell
+__global__ void t_copy_ghosts_signed (const Ghost * gh, int n, double * v, Sgn6 sg)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t < n) v[gh[t].g] = sg.s[gh[t].side]*v[gh[t].img];
+}
+
 // the conditions of P on GfsBoundary sides (src/boundary.c:45-62,253-279,336-347): symmetry (scalar),
 // Dirichlet 2 val - nb, Neumann nb + val h; periodic sides: the copy
 __global__ void t_bc_values (const Ghost * gh, int n, double * v, const double * bcval, Sgn6 kind)
@@ -159,12 +166,22 @@ __global__ void t_bc_values (const Ghost * gh, int n, double * v, const double *
 
 // gfs_domain_face_bc on periodic sides (src/boundary.c:1251-1258,1343-1347): the leaf ghost beyond
 // side sd takes f[OPP (sd)].v of its image
-__global__ void t_face_bc (const Ghost * gh, int n, P6 fv)
+__global__ void t_face_bc (const Ghost * gh, int n, P6 fv, Sgn6 wall, int comp)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
-  double * a = fv.p[gh[t].side ^ 1];
-  a[gh[t].g] = a[gh[t].img];
+  const Ghost G = gh[t];
+  double * a = fv.p[G.side ^ 1];
+  if (wall.s[G.side] == 0.) {       /* periodic side */
+    a[G.g] = a[G.img];
+    return;
+  }
+  // face_symmetry, src/boundary.c:64-74 (img: the cell the ghost touches)
+  double * own = fv.p[G.side];
+  if (comp == G.side/2)
+    a[G.g] = own[G.img] = 0.;
+  else
+    a[G.g] = own[G.img];
 }
 
 // gfs_get_from_below_intensive (src/fluid.c:1843-1864, mode 0) / get_from_below_2D
@@ -1432,9 +1449,18 @@ int bc_solution (gfship_tree * tr, double * v)
   return 0;
 }
 
-int bc_leaves (gfship_tree * tr, double * v)
+int bc_leaves (gfship_tree * tr, double * v, int comp = -1)
 {
-  if (tr->has_boundary)      /* only P lives on such a tree (gfship_tree_poisson_solve) */
+  if (tr->has_boundary && comp >= 0) {      /* a vector component: symmetry on the GfsBoundary sides */
+    Sgn6 sg;
+    for (int d = 0; d < 6; d++)
+      sg.s[d] = tr->side[d] != GFSHIP_SIDE_PERIODIC && comp == d/2 ? -1. : 1.;
+    if (tr->nghost_leaves)
+      t_copy_ghosts_signed<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves, v, sg);
+    GFSHIP_HIP (hipGetLastError ());
+    return 0;
+  }
+  if (tr->has_boundary)      /* P and the other scalars: the conditions of P */
     return bc_solution (tr, v);
   if (tr->nghost_leaves)
     t_copy_ghosts<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves, v);
@@ -1610,7 +1636,7 @@ int mac_projection (gfship_tree * tr, gfship_multilevel_params * par, double dt,
   t_scale<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, p3 (tr, gvar), 0., 0, p3 (tr, gvar));
   KCHECK ();
   for (int c = 0; c < dim; c++)
-    if ((e = bc_leaves (tr, tr->var[gvar + c]))) return e;
+    if ((e = bc_leaves (tr, tr->var[gvar + c], c))) return e;
   return 0;
 }
 
@@ -1620,7 +1646,7 @@ int correct_centered (gfship_tree * tr, int gvar, double dt)   /* src/timestep.c
   t_scale<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, p3 (tr, V_U), dt, 1, p3 (tr, gvar));
   KCHECK ();
   for (int c = 0; c < tr->H.dim; c++)
-    if ((e = bc_leaves (tr, tr->var[V_U + c]))) return e;
+    if ((e = bc_leaves (tr, tr->var[V_U + c], c))) return e;
   return 0;
 }
 
@@ -1643,7 +1669,7 @@ UpwindArgs upwind_args (gfship_tree * tr)
   return A;
 }
 
-int face_values_set (gfship_tree * tr, const double * v, double dt, int use_centered)
+int face_values_set (gfship_tree * tr, const double * v, double dt, int use_centered, int comp)
 { /* src/timestep.c:644-654 */
   AdvArgs A;
   A.v = v; A.dt = dt; A.use_centered = use_centered;
@@ -1652,7 +1678,11 @@ int face_values_set (gfship_tree * tr, const double * v, double dt, int use_cent
   t_face_values<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, A);
   KCHECK ();
   if (tr->nghost_leaves)
-    t_face_bc<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves, p6 (tr, V_FV));
+  {
+    Sgn6 wall;
+    for (int d = 0; d < 6; d++) wall.s[d] = tr->side[d] != GFSHIP_SIDE_PERIODIC ? 1. : 0.;
+    t_face_bc<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves, p6 (tr, V_FV), wall, comp);
+  }
   KCHECK ();
   return 0;
 }
@@ -1661,7 +1691,7 @@ int predicted_face_velocities (gfship_tree * tr)   /* src/timestep.c:681-717 */
 {
   int e;
   for (int c = 0; c < tr->H.dim; c++) {
-    if ((e = face_values_set (tr, tr->var[V_U + c], tr->dt, 1))) return e;
+    if ((e = face_values_set (tr, tr->var[V_U + c], tr->dt, 1, c))) return e;
     FaceSet & F = tr->fs[1 + c];
     t_face_advected_un<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, upwind_args (tr), F.fval);
     KCHECK ();
@@ -1676,7 +1706,7 @@ int centered_velocity_advection (gfship_tree * tr, int gmac, int g)
   int e;
   FaceSet & F = tr->fs[0];
   for (int c = 0; c < tr->H.dim; c++) {
-    if ((e = face_values_set (tr, tr->var[V_U + c], tr->dt, 0))) return e;
+    if ((e = face_values_set (tr, tr->var[V_U + c], tr->dt, 0, c))) return e;
     t_face_flux<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, upwind_args (tr), tr->var[gmac + c], tr->dt, F.fval);
     KCHECK ();
     t_gather_flux<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, F.faces, F.inc_off, F.inc, F.fval,
@@ -1684,7 +1714,7 @@ int centered_velocity_advection (gfship_tree * tr, int gmac, int g)
     KCHECK ();
   }
   for (int c = 0; c < tr->H.dim; c++)
-    if ((e = bc_leaves (tr, tr->var[V_U + c]))) return e;
+    if ((e = bc_leaves (tr, tr->var[V_U + c], c))) return e;
   return 0;
 }
 
@@ -2199,13 +2229,14 @@ int gfship_tree_sweep_levels (const gfship_tree * tr, int level, int * ncells, i
 int gfship_tree_start (gfship_tree * tr)
 {
   GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_start: null tree");
-  GFSHIP_CHECK (!tr->has_boundary, GFSHIP_EUNSUPPORTED,
-		"gfship_tree_start: the time step needs periodic sides (a tree with GfsBoundary sides: gfship_tree_poisson_solve)");
+  for (int d = 0; d < 2*tr->H.dim; d++)
+    GFSHIP_CHECK (tr->side[d] == GFSHIP_SIDE_PERIODIC || tr->bc_p[d] == GFSHIP_BC_SYMMETRY, GFSHIP_EUNSUPPORTED,
+		  "gfship_tree_start: the time step knows the default (symmetry) conditions on GfsBoundary sides only");
   GFSHIP_HIP (hipSetDevice (tr->device));
   int e;
   const int vars[] = { V_P, V_PMAC, V_U, V_U + 1, V_U + 2 };
   for (int k = 0; k < 2 + tr->H.dim; k++)
-    if ((e = bc_leaves (tr, tr->var[vars[k]]))) return e;
+    if ((e = bc_leaves (tr, tr->var[vars[k]], k - 2))) return e;
   if ((e = coarse_init (tr))) return e;
   if ((e = set_timestep (tr))) return e;
   if ((e = approximate_projection (tr, &tr->approx_projection_params, tr->dt))) return e;
@@ -2216,7 +2247,7 @@ int gfship_tree_start (gfship_tree * tr)
 int gfship_tree_step (gfship_tree * tr)
 {
   GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_step: null tree");
-  GFSHIP_CHECK (!tr->has_boundary, GFSHIP_EUNSUPPORTED, "gfship_tree_step: the time step needs periodic sides");
+
   GFSHIP_HIP (hipSetDevice (tr->device));
   int e;
   if ((e = predicted_face_velocities (tr))) return e;

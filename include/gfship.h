@@ -530,7 +530,9 @@ int  gfship_tree_create (gfship_tree ** tree, int dim, gfship_refine_fn refine, 
    values are uploaded as the variable GFSHIP_TREE_BCVAL, the right-hand side as GFSHIP_TREE_DIV, and
    gfship_tree_poisson_solve is gfs_poisson_solve (src/poisson.c:1225-1269) with dia = 0: the
    homogeneous conditions between the sweeps, the conditions themselves after each correction.
-   gfship_tree_start / _step need periodic sides (GFSHIP_EUNSUPPORTED otherwise). */
+   gfship_tree_start / _step run on such a tree with the default conditions (GfsBc symmetry: slip
+   walls -- the normal velocity component and its face values odd, everything else even,
+   src/boundary.c:45-74); with a Dirichlet or Neumann condition set: GFSHIP_EUNSUPPORTED. */
 int  gfship_tree_create_sides (gfship_tree ** tree, int dim, gfship_refine_fn refine, void * ctx,
 			       const int * side, int device);
 int  gfship_tree_set_bc (gfship_tree * tree, int d, int kind);

@@ -314,6 +314,15 @@ static void ghost_traverse (GtSim * s, int l, GhostFunc fn, void * data)
 }
 
 typedef struct { Var * v; int flags, max_depth; } BcPar;
+/* the component of a vector a variable is (gfs_variable_set_vector: U, V, W, g, gmac), or -1 */
+static int var_component (const GtSim * s, const Var * v)
+{
+  for (int c = 0; c < 3; c++)
+    if (v == &s->u[c] || v == &s->g[c] || v == &s->gmac[c])
+      return c;
+  return -1;
+}
+
 /* the interior cell a ghost cell of side `side' touches */
 static int ghost_own (const GtSim * s, int l, int side, int G)
 {
@@ -339,6 +348,11 @@ static void bc_ghost (GtSim * s, int l, int side, int G, int image, void * data)
   /* GfsBoundary: symmetry (default, scalar) boundary.c:45-62, Dirichlet :253-279, Neumann :336-347 */
   double nb = p->v->lev[l][ghost_own (s, l, side, G)];
   double h = 1./s->n[l];
+  int comp = var_component (s, p->v);
+  if (comp >= 0) {      /* symmetry (the default GfsBc) of a vector component, boundary.c:45-62 */
+    p->v->lev[l][G] = comp == side/2 ? - nb : nb;
+    return;
+  }
   int kind = s->bc_p[side];
   if (s->bc_homogeneous)
     p->v->lev[l][G] = kind == GO_BC_DIRICHLET ? - nb : nb;
@@ -1158,20 +1172,31 @@ static void cell_advected_face_values (GtSim * s, Cell cell, void * data) /* adv
    leaf ghost cell beyond side sd holds the face value f[OPP (sd)].v of its periodic image */
 static void face_bc_ghost (GtSim * s, int l, int side, int G, int image, void * data)
 {
-  if (s->flag[l][G] == GT_LEAF)
+  if (s->flag[l][G] != GT_LEAF)
+    return;
+  if (s->side[side] == GO_SIDE_PERIODIC) {
     s->fv[OPP (side)].lev[l][G] = s->fv[OPP (side)].lev[l][image];
+    return;
+  }
+  /* face_symmetry, boundary.c:64-74 */
+  int comp = *(int *) data, own = ghost_own (s, l, side, G);
+  if (comp == side/2)
+    s->fv[OPP (side)].lev[l][G] = s->fv[side].lev[l][own] = 0.;
+  else
+    s->fv[OPP (side)].lev[l][G] = s->fv[side].lev[l][own];
 }
 
-static void face_bc (GtSim * s)
+static void face_bc (GtSim * s, const Var * v)
 {
+  int comp = var_component (s, v);
   for (int l = 0; l <= s->depth; l++)
-    ghost_traverse (s, l, face_bc_ghost, NULL);
+    ghost_traverse (s, l, face_bc_ghost, &comp);
 }
 
 static void face_values_set (GtSim * s, AdvPar * par) /* timestep.c:644-654 */
 {
   cell_traverse (s, 0, T_LEAFS, -1, cell_advected_face_values, par);
-  face_bc (s);
+  face_bc (s, par->v);
 }
 
 static int is_interior (const GtSim * s, Cell c)   /* !GFS_CELL_IS_BOUNDARY */

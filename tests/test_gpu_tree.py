@@ -339,3 +339,52 @@ def test_poisson_on_an_octree_with_dirichlet_sides():
     assert err < 0.1          # 16^3 base grid, 1.5 wavelengths per side (2-D, test/poisson/circle: 2.9e-2)
     o.destroy()
     g.destroy()
+
+
+# ---- the time step in a closed box: GfsBoundary sides with the default (symmetry) conditions
+
+@pytest.mark.parametrize("dim,level,box", [(2, 4, 2), (2, 5, 1), (3, 3, 1)])
+def test_tree_steps_with_slip_walls(dim, level, box):
+    """a refined patch that TOUCHES two walls (the ghost trees of the boundaries are refined like the
+    cells they face): vortices that respect the walls, device against the oracle, bit for bit"""
+    if dim == 2:
+        refine = lambda x, y: level + box if (x < -0.25 and y > 0.) else level
+        sides = [gfship.SIDE_BOUNDARY] * 4
+    else:
+        refine = lambda x, y, z: level + box if (x < -0.25 and y > 0. and abs(z) < 0.26) else level
+        sides = [gfship.SIDE_BOUNDARY] * 4 + [gfship.SIDE_PERIODIC] * 2
+    o = O.Tree(refine=refine, dim=dim, sides=sides)
+    g = gfship.Tree(refine, dim=dim, sides=sides)
+    T, G = O.Tree, gfship.Tree
+    for l in range(o.depth + 1):
+        assert np.array_equal(g.flags(l), o.flags(l))
+        c = o.centres(l)
+        X, Y = c[0] + 0.5, c[1] + 0.5
+        zf = np.cos(2. * np.pi * c[2]) if dim == 3 else 1.
+        u = (np.sin(np.pi * X) * np.cos(np.pi * Y) + 0.3 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y)) * zf
+        v = (-np.cos(np.pi * X) * np.sin(np.pi * Y) - 0.3 * np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y)) * zf
+        fields = [(u, T.U, G.U), (v, T.V, G.V)]
+        if dim == 3:
+            fields.append((0.2 * np.sin(np.pi * X) * np.sin(np.pi * Y) * np.sin(2. * np.pi * c[2]), T.W, G.W))
+        for arr, ov, gv in fields:
+            o.values(ov, l)[...] = arr
+            g.upload(gv, l, arr)
+    for p in (o.projection_params, o.approx_projection_params, g.projection_params, g.approx_projection_params):
+        p.tolerance = 1e-4
+    o.set_time(1e30, 0.8)
+    g.set_time(1e30, 0.8)
+    o.start()
+    g.start()
+    assert g.dt == o.dt
+    inner = (slice(1, -1),) * dim
+    names = [(G.U, T.U), (G.V, T.V), (G.P, T.P)] + ([(G.W, T.W)] if dim == 3 else [])
+    for k in range(3):
+        o.step()
+        g.step()
+        assert g.t == o.t and g.dt == o.dt
+        for l in range(o.depth + 1):
+            leaf = o.flags(l)[inner] == 1
+            for gv, ov in names:
+                assert np.array_equal(g.download(gv, l)[inner][leaf], o.values(ov, l)[inner][leaf]), (k, l, gv)
+    o.destroy()
+    g.destroy()

@@ -258,3 +258,30 @@ def test_poisson_circle_res7_and_error_refs(golden_dir):
     for row in _rows(golden_dir, "poisson_circle_error.ref"):
         _, norms = _circle(int(row[0]), 10)
         assert ["%.3e" % v for v in norms] == row[1:4], (row, norms)
+
+
+def test_uniform_tree_with_slip_walls_equals_uniform_oracle():
+    """GfsBoundary sides with the default (symmetry) conditions: on a uniform tree the tree code gives
+    the bits of go_timestep.c with GO_SIDE_BOUNDARY sides (itself pinned by the lid and poiseuille
+    cases, which have walls)"""
+    level = 5
+    sides = [O.SIDE_BOUNDARY] * 4
+    a = O.Tree(refine=lambda x, y: level, sides=sides)
+    b = O.Sim(2, level, sides)
+    x, y = a.centres(level)
+    X, Y = x + 0.5, y + 0.5
+    u = np.sin(np.pi * X) * np.cos(np.pi * Y) + 0.3 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y)
+    v = -np.cos(np.pi * X) * np.sin(np.pi * Y) - 0.3 * np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y)
+    a.values(O.Tree.U, level)[...] = u
+    a.values(O.Tree.V, level)[...] = v
+    b.u[0].interior()[...] = u[1:-1, 1:-1]
+    b.u[1].interior()[...] = v[1:-1, 1:-1]
+    a.start()
+    b.start()
+    for _ in range(4):
+        a.step()
+        b.step()
+    assert a.t == b.t
+    for which, f in ((O.Tree.U, b.u[0]), (O.Tree.V, b.u[1]), (O.Tree.P, b.p)):
+        assert np.array_equal(a.values(which, level)[1:-1, 1:-1], f.interior())
+    a.destroy()

@@ -84,12 +84,18 @@ def test_refined_patch_of_periodic_gfs_is_accepted(tmp_path):
 
 
 def test_refined_tree_outside_its_scope_is_refused(tmp_path):
-    """a refined patch in a box with boundaries, or in 3-D, is refused with the line of the Refine"""
+    """a refined patch in a GfsAdvection simulation is refused with the line of the Refine; in a
+    GfsSimulation with walls it is accepted (default conditions: slip walls)"""
+    text = ("1 0 GfsAdvection GfsBox GfsGEdge {} {\n  Time { end = 0.1 }\n"
+            "  Refine (x > 0.2 ? 5 : 4)\n  VariableTracer T\n}\nGfsBox {}\n")
+    r = subprocess.run([BIN, "--check", "-"], cwd=str(tmp_path), input=text,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "non-uniform tree" in r.stderr and "line 3" in r.stderr
     text = ("1 0 GfsSimulation GfsBox GfsGEdge {} {\n  Time { end = 0.1 }\n"
             "  Refine (x > 0.2 ? 5 : 4)\n}\nGfsBox {}\n")
     r = subprocess.run([BIN, "--check", "-"], cwd=str(tmp_path), input=text,
                        capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "non-uniform tree" in r.stderr and "line 3" in r.stderr
+    assert r.returncode == 0 and "refined tree" in r.stdout
 
 
 @pytest.mark.gpu
