@@ -72,7 +72,8 @@ def test_check_cavity_and_periodic_cases(golden_dir):
 
 def test_unsupported_input_fails_loudly(tmp_path):
     bad = tmp_path / "bad.gfs"
-    bad.write_text("1 0 GfsSimulation GfsBox GfsGEdge {} {\n  Refine (x > 0 ? 5 : 4)\n}\nGfsBox {}\n")
+    # a refined tree outside the classes that know it (GfsSimulation, GfsPoisson: DESIGN.md 10)
+    bad.write_text("1 0 GfsAdvection GfsBox GfsGEdge {} {\n  Refine (x > 0 ? 5 : 4)\n}\nGfsBox {}\n")
     r = subprocess.run([BIN, "--check", str(bad)], capture_output=True, text=True)
     assert r.returncode != 0 and "non-uniform" in r.stderr and "line 2" in r.stderr
     bad.write_text("1 0 GfsSimulation GfsBox GfsGEdge {} {\n  Refine 4\n  Solid (x*x + y*y - 0.1)\n}\nGfsBox {}\n")
