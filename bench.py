@@ -254,23 +254,36 @@ def main():
         dom = gfship.Domain(3, args.level, grid.sides(rank), device=local_rank)
         if backend == "rccl":
             import torch
-            uid = torch.zeros(gfship.UNIQUE_ID_BYTES, dtype=torch.uint8)
-            if rank == 0:
-                uid = torch.frombuffer(bytearray(gfship.comm_unique_id()), dtype=torch.uint8).clone()
-            dist.broadcast(uid, 0)
+            # two phases, so that no rank can be left alone inside the collective ncclCommInitRank:
+            # (1) everything that can fail locally -- the library loaded, RCCL opened, the device
+            # selected (all done by the Domain above and comm_unique_id), the unique id received --
+            # is agreed on over gloo first; (2) only then every rank enters comm_init.  A failure
+            # inside (2) ends the run with a non-zero exit code on that rank (the launcher then ends
+            # the others): no asymmetric fallback is attempted
             ok = torch.ones(1, dtype=torch.int32)
+            uid = torch.zeros(gfship.UNIQUE_ID_BYTES, dtype=torch.uint8)
             try:
-                dom.comm_init(bytes(uid.numpy().tobytes()), rank, world, grid.b)
-                rccl_world = dom.comm_size()
-            except Exception as e:      # reported, never silent: see "transport" in the line
-                sys.stderr.write("bench.py: rank %d: RCCL communicator failed: %s\n" % (rank, e))
+                if rank == 0:
+                    uid = torch.frombuffer(bytearray(gfship.comm_unique_id()), dtype=torch.uint8).clone()
+                else:
+                    gfship.comm_available()
+            except Exception as e:      # reported, never silent: see "parallelism" in the line
+                sys.stderr.write("bench.py: rank %d: RCCL not usable: %s\n" % (rank, e))
                 ok[0] = 0
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                # every rank takes the same decision: host-staged hooks, and the line says so
-                backend = "gloo-staged (RCCL communicator failed on some rank)"
-                dom.destroy()
-                dom = gfship.Domain(3, args.level, grid.sides(rank), device=local_rank)
+            if int(ok.item()) == 1:
+                dist.broadcast(uid, 0)
+                try:
+                    dom.comm_init(bytes(uid.numpy().tobytes()), rank, world, grid.b)
+                    rccl_world = dom.comm_size()
+                except Exception as e:
+                    sys.stderr.write("bench.py: rank %d: ncclCommInitRank failed: %s\n" % (rank, e))
+                    sys.stderr.flush()
+                    os._exit(3)
+            else:
+                # every rank takes the same decision, before anybody entered a collective of RCCL:
+                # host-staged hooks, and the line says so
+                backend = "gloo-staged (RCCL not usable on some rank)"
         if backend != "rccl":
             import torch
             torch.cuda.set_device(local_rank)
@@ -299,11 +312,13 @@ def main():
             dist.barrier()
 
     barrier()
+    comm0 = dom.comm_stats() if rccl_world else (0, 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sim.step()
     barrier()
     elapsed = time.perf_counter() - t0
+    comm1 = dom.comm_stats() if rccl_world else (0, 0)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -397,6 +412,13 @@ def main():
                                          int(sim.approx_projection_params.niter)]},
             "roofline": roofline,
         }
+        if rccl_world:
+            # what rank 0 sent through the library's communicator during the timed steps
+            # (gfship_domain_comm_stats: domain->mpi_messages / mpi_size of the reference)
+            out["comm"] = {"messages_per_step": (comm1[0] - comm0[0]) / args.steps,
+                           "bytes_per_step": (comm1[1] - comm0[1]) / args.steps,
+                           "overlap": 0,
+                           "per": "rank 0"}
         if particles is not None:
             out["particles"] = particles
         if world == 1 and not args.no_cpu_baseline:

@@ -10,7 +10,13 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-ma
 OBJS=""
 for f in "$HERE"/*.hip; do
   o="$OUT/$(basename "${f%.hip}").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/relax_skew.hpp" -nt "$o" ] || [ "$HERE/gfship_internal.hpp" -nt "$o" ] || [ "$HERE/../../include/gfship.h" -nt "$o" ]; then
+  stale=0
+  [ -f "$o" ] || stale=1
+  # every header of this directory (relax_skew.hpp, gfship_internal.hpp, tree.hpp ...) and the C ABI
+  for d in "$f" "$HERE"/*.hpp "$HERE/../../include/gfship.h"; do
+    [ "$d" -nt "$o" ] && stale=1
+  done
+  if [ $stale = 1 ]; then
     "$HIPCC" $FLAGS -c "$f" -o "$o" &
   fi
   OBJS="$OBJS $o"

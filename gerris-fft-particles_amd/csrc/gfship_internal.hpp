@@ -207,6 +207,7 @@ int launch_relax_loop_small (gfship_domain * dom, unsigned dimension, int level,
 			     unsigned nrelax, bool * done, const RelaxOp * op = nullptr);
 int coarse_cycle_top (gfship_domain * dom, int minlevel);
 int lattice_cycle_top (gfship_domain * dom, int minlevel, Field * dia);
+int lattice_check_error (gfship_domain * dom);
 int launch_lattice_cycle (gfship_domain * dom, unsigned dimension, double omega, int lmin, int ltop,
 			  const unsigned * nrelax, Field * dp, Field * ubc, Field * res);
 int launch_coarse_cycle (gfship_domain * dom, unsigned dimension, double omega, int lmin, int ltop,

@@ -31,6 +31,10 @@
 #include <iostream>
 #include <functional>
 #include <sstream>
+#include <fcntl.h>
+#include <sys/types.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include "gfship.h"
 #include "gfs_text.hpp"
 #include "gfs_snapshot.hpp"
@@ -67,6 +71,55 @@ struct Event {                     // GfsEvent, src/event.c:60-169
   int line = 0;
   std::function<void ()> action;
 };
+
+// Shell commands of the file (GfsEventScript) run in a helper process forked at program start, before
+// anything touches the GPU: a process that has initialised the device never forks or execs.  The
+// helper reads { length, script } records and answers with the status of system ().
+struct ShellServer {
+  int to = -1, from = -1;
+  pid_t pid = -1;
+  void start () {
+    int a[2], b[2];
+    if (pipe (a) != 0 || pipe (b) != 0) return;
+    fflush (stdout); fflush (stderr);
+    pid = fork ();
+    if (pid == 0) {
+      ::close (a[1]); ::close (b[0]);
+      for (;;) {
+	size_t len = 0;
+	if (read (a[0], &len, sizeof (len)) != (ssize_t) sizeof (len)) _exit (0);
+	std::string script (len, '\0');
+	size_t got = 0;
+	while (got < len) {
+	  ssize_t q = read (a[0], &script[got], len - got);
+	  if (q <= 0) _exit (0);
+	  got += (size_t) q;
+	}
+	int status = system (script.c_str ());
+	if (write (b[1], &status, sizeof (status)) != (ssize_t) sizeof (status)) _exit (0);
+      }
+    }
+    ::close (a[0]); ::close (b[1]);
+    if (pid < 0) { ::close (a[1]); ::close (b[0]); return; }
+    to = a[1]; from = b[0];
+    fcntl (to, F_SETFD, FD_CLOEXEC); fcntl (from, F_SETFD, FD_CLOEXEC);
+  }
+  int run (const std::string & script) {
+    if (to < 0) return -1;
+    size_t len = script.size ();
+    int status = -1;
+    if (write (to, &len, sizeof (len)) != (ssize_t) sizeof (len) ||
+	write (to, script.data (), len) != (ssize_t) len ||
+	read (from, &status, sizeof (status)) != (ssize_t) sizeof (status))
+      return -1;
+    return status;
+  }
+  void stop () {
+    if (to >= 0) { ::close (to); ::close (from); to = from = -1; }
+    if (pid > 0) { int st; waitpid (pid, &st, 0); pid = -1; }
+  }
+};
+static ShellServer g_shell;
 
 struct Output {                    // GfsOutput, src/output.c:143-212
   std::string format;             // stdout, stderr, a file name or a { shell script }
@@ -401,6 +454,15 @@ Output * read_output (Run & R, Reader & r)
   else
     o->format = r.word (false);
   return o;
+}
+
+// the `{ shell script }' outputs are started (popen: a fork) before the device is created; files and
+// the standard streams are opened when their event first fires, as in the reference
+void open_pipes (Run & R)
+{
+  for (auto & o : R.outputs)
+    if (!o->format.empty () && o->format[0] == '{')
+      o->open ();
 }
 
 double rate (double a, double b, unsigned n)
@@ -889,7 +951,7 @@ void parse_object (Run & R, Reader & r)
     std::string script = r.braces ();
     e->action = [script] () {
       fflush (stdout);
-      if (system (script.c_str ()) != 0)
+      if (g_shell.run (script) != 0)      /* in the helper forked before the device was touched */
 	fprintf (stderr, "gfship: EventScript returned a non-zero status\n");
     };
     add_event (R, e, cls, line);
@@ -1589,6 +1651,7 @@ int run_tree_poisson (Run & R)
       return 1;
     }
   }
+  open_pipes (R);
   CHECK (gfship_tree_create_sides (&R.tree, R.dim, refine_hook, &R, R.side, R.device));
   int depth = gfship_tree_depth (R.tree);
   std::vector<std::vector<unsigned char>> flag (depth + 1);
@@ -1744,6 +1807,7 @@ int run_tree (Run & R)
 	       "(side %s has a Bc)\n", side_name[d]);
       return 1;
     }
+  open_pipes (R);
   CHECK (gfship_tree_create_sides (&R.tree, R.dim, refine_hook, &R, R.side, R.device));
   int depth = gfship_tree_depth (R.tree);
   std::vector<std::vector<unsigned char>> flag (depth + 1);
@@ -1792,6 +1856,7 @@ int run (Run & R)
   resolve_refine (R);
   if (R.tree_mode)
     return run_tree (R);
+  open_pipes (R);
   CHECK (gfship_domain_create (&R.dom, R.dim, R.level, R.side, R.device));
   CHECK (gfship_sim_create (&R.sim, R.dom));
   R.vars[R.var_index ("P")].dev = gfship_sim_variable (R.sim, GFSHIP_VAR_P, 0);
@@ -2104,6 +2169,8 @@ int main (int argc, char ** argv)
     else file = s;
   }
   if (file.empty ()) { fprintf (stderr, "gfship: no simulation file given\n"); return 1; }
+  g_shell.start ();
+  struct ShellStop { ~ShellStop () { g_shell.stop (); } } shell_stop;
   std::stringstream ss;
   if (file == "-")                       /* `gerris2D -': the simulation file on standard input */
     ss << std::cin.rdbuf ();

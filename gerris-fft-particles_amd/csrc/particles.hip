@@ -68,7 +68,7 @@ struct gfship_particles {
   // GfsFunction coefficients of the GfsForceCoeff objects, compiled for the device (rtc.hip): the
   // variables Rep, Urelp, Vrelp, Wrelp, Pdia of every particle (slot order), and the values
   gfship::RtcKernel * coef_fn[8] = {};
-  double * coef[8] = {}, * cin[5] = {};
+  double * coef[8] = {}, * cin[6] = {};
   int coef_cap = 0;
 };
 
@@ -348,7 +348,8 @@ struct ParticulateArgs {
   int nforces, forces[8];
   double gravity[3], viscosity;
   const double * coef[8];      // values of the GfsFunction of force f per slot; nullptr: the default
-  double * cin[5];             // Rep, Urelp, Vrelp, Wrelp, Pdia per slot (coefficient inputs)
+  double * cin[6];             // Rep, Urelp, Vrelp, Wrelp, Pdia per slot (coefficient inputs); [5]: the Rep of
+                               // GfsForceDrag in 2-D (two-component norm, particulatecommon.c:549-556)
 };
 
 // gfs_center_gradient, src/fluid.c:434-475, both neighbours at the same level (x1 = x2 = 1.)
@@ -413,6 +414,8 @@ particulate_coeff_inputs_kernel (ParticulateArgs A, int depth)
   A.cin[0][q] = norm*dia*fluid_rho/viscosity;
   A.cin[1][q] = rel[0]; A.cin[2][q] = rel[1]; A.cin[3][q] = rel[2];
   A.cin[4][q] = dia;
+  if (DIM == 2)      /* compute_drag_force takes the norm of the two components in 2-D (:549-556) */
+    A.cin[5][q] = sqrt (rel[0]*rel[0] + rel[1]*rel[1])*dia*fluid_rho/viscosity;
 }
 
 // gfs_particulate_event (:768-842) in a gfs_particle_list_event (:980-1015)
@@ -756,7 +759,7 @@ void gfship_particles_destroy (gfship_particles * pl)
     if (pl->coef[f]) (void) hipFree (pl->coef[f]);
     gfship::rtc_free (pl->coef_fn[f]);
   }
-  for (int q = 0; q < 5; q++)
+  for (int q = 0; q < 6; q++)
     if (pl->cin[q]) (void) hipFree (pl->cin[q]);
   delete pl;
 }
@@ -1064,11 +1067,11 @@ static int particulate_event (gfship_particles * pl, const PartArgs & P, double 
     A.coef[f] = nullptr;
     if (f < pl->nforces && pl->coef_fn[f]) any = true;
   }
-  for (int q = 0; q < 5; q++) A.cin[q] = nullptr;
+  for (int q = 0; q < 6; q++) A.cin[q] = nullptr;
   if (any) {
     /* the GfsFunction coefficients: inputs of every particle, then one compiled kernel per function */
     if (pl->coef_cap < pl->cap) {
-      for (int q = 0; q < 5; q++) {
+      for (int q = 0; q < 6; q++) {
 	if (pl->cin[q]) GFSHIP_HIP (hipFree (pl->cin[q]));
 	pl->cin[q] = nullptr;
 	GFSHIP_HIP (hipMalloc ((void **) &pl->cin[q], (size_t) pl->cap*sizeof (double)));
@@ -1081,7 +1084,7 @@ static int particulate_event (gfship_particles * pl, const PartArgs & P, double 
       }
       pl->coef_cap = pl->cap;
     }
-    for (int q = 0; q < 5; q++) A.cin[q] = pl->cin[q];
+    for (int q = 0; q < 6; q++) A.cin[q] = pl->cin[q];
     if (dom->dim == 3)
       hipLaunchKernelGGL (particulate_coeff_inputs_kernel<3>, dim3 (grid), dim3 (block), 0, dom->stream,
 			  A, dom->depth);
@@ -1094,7 +1097,8 @@ static int particulate_event (gfship_particles * pl, const PartArgs & P, double 
       if (pl->coef_fn[f]) {
 	if (!pl->coef[f])
 	  GFSHIP_HIP (hipMalloc ((void **) &pl->coef[f], (size_t) pl->coef_cap*sizeof (double)));
-	int r = rtc_launch_coefficient (pl->coef_fn[f], dom->stream, pl->n, P.alive, pl->cin[0], rel, pl->cin[4],
+	const double * rep = dom->dim == 2 && pl->forces[f] == GFSHIP_FORCE_DRAG ? pl->cin[5] : pl->cin[0];
+	int r = rtc_launch_coefficient (pl->coef_fn[f], dom->stream, pl->n, P.alive, rep, rel, pl->cin[4],
 					gfship_sim_time (pl->sim), pl->coef[f]);
 	if (r) return r;
 	A.coef[f] = pl->coef[f];
@@ -1153,9 +1157,19 @@ int gfship_particles_set_forces (gfship_particles * pl, int nforces, const int *
   GFSHIP_CHECK (pl->particulate, GFSHIP_EINVAL, "forces act on particulates (gfship_particles_set_particulate)");
   GFSHIP_CHECK (nforces >= 0 && nforces <= 8, GFSHIP_EINVAL, "at most 8 forces");
   bool coeff = false;
-  for (int f = 0; f < nforces; f++) {
+  for (int f = 0; f < nforces; f++)
     GFSHIP_CHECK (kinds[f] >= GFSHIP_FORCE_INERTIAL && kinds[f] <= GFSHIP_FORCE_BUOY, GFSHIP_EINVAL,
 		  "unknown force");
+  /* a new list of forces: the compiled GfsFunction of a slot belonged to the force that sat there
+     (gfship_particles_set_force_coefficient comes after this call) */
+  GFSHIP_HIP (hipStreamSynchronize (pl->dom->stream));
+  for (int f = 0; f < 8; f++) {
+    gfship::rtc_free (pl->coef_fn[f]);
+    pl->coef_fn[f] = nullptr;
+    if (pl->coef[f]) (void) hipFree (pl->coef[f]);
+    pl->coef[f] = nullptr;
+  }
+  for (int f = 0; f < nforces; f++) {
     pl->forces[f] = kinds[f];
     if (kinds[f] != GFSHIP_FORCE_BUOY) coeff = true;
   }

@@ -495,6 +495,8 @@ int gfship_poisson_solve (gfship_domain * dom, gfship_multilevel_params * par,
   par->minlevel = minlevel;
   if (r == GFSHIP_OK)
     r = skew_check_error (dom);
+  if (r == GFSHIP_OK)
+    r = lattice_check_error (dom);
   return r;
 }
 

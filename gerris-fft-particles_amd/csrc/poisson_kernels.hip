@@ -682,6 +682,7 @@ struct LatticeCycleArgs {
   const double * gres;                       // res[ltop] of every box (natural layout), in rank order
   unsigned long long * xch;                  // [2][B][6][nface (ltop)] layers between the boxes
   unsigned * bar;                            // barrier counter, zero at launch
+  unsigned * err;                            // host-mapped word: set when a barrier wait gives up
   BcDesc bc;
   unsigned dimension;
   double omega;
@@ -695,15 +696,27 @@ typedef __attribute__((address_space(1))) unsigned long long lat_gu64;
 // the workgroup's barrier, then one thread announces the workgroup and waits for the others.  (With
 // __threadfence () on both sides -- a write-back and an invalidate of the whole L2 each -- a barrier
 // cost 8 us.)
-__device__ __forceinline__ void lattice_barrier (unsigned * bar, unsigned & target, int nboxes)
+// The wait is bounded (2^22 polls, tens of milliseconds): should the workgroups not all be resident
+// after all (lattice_cycle_top checks the occupancy, but the device may be shared) the kernel sets
+// *err, stops waiting at every later barrier too and ends -- the solve is reported as failed
+// (lattice_check_error) instead of hanging the device.
+__device__ __forceinline__ void lattice_barrier (unsigned * bar, unsigned & target, int nboxes,
+						 unsigned * err)
 {
   asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads ();
   if (threadIdx.x == 0) {
     target += (unsigned) nboxes;
     __hip_atomic_fetch_add (bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load (bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+    unsigned spins = 0;
+    while (__hip_atomic_load (bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep (1);
+      if (++spins > (1u << 22) ||
+	  __hip_atomic_load (err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+	__hip_atomic_store (err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	break;
+      }
+    }
   }
   __syncthreads ();
 }
@@ -838,7 +851,7 @@ lattice_cycle_kernel (LatticeCycleArgs A)
 			    (unsigned long long) __double_as_longlong (s[ijk[0] + ssy*ijk[1] + ssz*ijk[2]]),
 			    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      lattice_barrier (A.bar, target, A.nboxes);
+      lattice_barrier (A.bar, target, A.nboxes, A.err);
       // ... and the ghost cells are filled: local sides as in bc_kernel, MPI sides from the layer the
       // box across the side has just written (its side d ^ 1, same position on the face)
       for (int q = tid; q < 2*DIM*nface; q += nt) {
@@ -922,6 +935,25 @@ lattice_cycle_kernel (LatticeCycleArgs A)
   }
 }
 
+// the "a barrier wait gave up" word: host memory mapped on the device, next to the words of the
+// sweep kernels (relax_skew.hip: h_pinned + 32, one per level; this one after them)
+static unsigned * lattice_err_word (gfship_domain * dom)
+{
+  return (unsigned *) (dom->h_pinned + 32) + GFSHIP_MAXLEVEL + 2;
+}
+
+static int lattice_attr (gfship_domain * dom)
+{
+  if (!dom->lattice_attr_set) {
+    GFSHIP_HIP (hipFuncSetAttribute ((const void *) lattice_cycle_kernel<3>,
+				     hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
+    GFSHIP_HIP (hipFuncSetAttribute ((const void *) lattice_cycle_kernel<2>,
+				     hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
+    dom->lattice_attr_set = true;
+  }
+  return GFSHIP_OK;
+}
+
 // highest level of the replicated coarse end (lmin .. ltop in LDS per box); -1 when it does not apply
 int lattice_cycle_top (gfship_domain * dom, int minlevel, Field * dia)
 {
@@ -932,7 +964,7 @@ int lattice_cycle_top (gfship_domain * dom, int minlevel, Field * dia)
   if (dom->relax_mode != GFSHIP_RELAX_EXACT || dom->force_hyperplane || dom->no_fused_loop)
     return -1;
   int top = -1;
-  size_t bytes = 0;
+  size_t bytes = 0, bytes_top = 0;
   for (int l = minlevel; l < dom->depth; l++) {     /* the leaf level is never part of it */
     if (dom->dim == 3 && skew_supported (dom, l)) break;
     if (!dia->zero[l]) break;
@@ -940,8 +972,38 @@ int lattice_cycle_top (gfship_domain * dom, int minlevel, Field * dia)
     bytes += 2*(dom->dim == 3 ? r*r*r : r*r)*sizeof (double);
     if (bytes > 150*1024) break;
     top = l;
+    bytes_top = bytes;
+  }
+  if (top >= 0) {
+    /* the workgroups meet at a barrier: all lat_n of them must be resident at once (1024 threads and
+       up to 150 KB of LDS each: one per CU).  Checked against the occupancy of the kernel on this
+       device; a device that does not deliver (CUs masked or in use) is caught by the bounded wait */
+    if (int r = lattice_attr (dom)) { (void) r; return -1; }
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = dom->dim == 3 ?
+      hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, lattice_cycle_kernel<3>, 1024, bytes_top) :
+      hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, lattice_cycle_kernel<2>, 1024, bytes_top);
+    if (e != hipSuccess || hipGetDevice (&dev) != hipSuccess ||
+	hipGetDeviceProperties (&prop, dev) != hipSuccess ||
+	(long) per_cu*prop.multiProcessorCount < dom->lat_n)
+      return -1;
   }
   return top;
+}
+
+int lattice_check_error (gfship_domain * dom)
+{
+  unsigned * w = lattice_err_word (dom);
+  if (*w != 0) {
+    *w = 0;
+    dom->no_lattice_cycle = true;
+    set_error ("lattice_cycle_kernel: a barrier wait timed out (workgroups not all resident: CUs held "
+	       "by another process or stream?); this solve failed, the domain falls back to one "
+	       "exchange per sweep and level");
+    return GFSHIP_EHIP;
+  }
+  return GFSHIP_OK;
 }
 
 int launch_lattice_cycle (gfship_domain * dom, unsigned dimension, double omega, int lmin, int ltop,
@@ -999,13 +1061,8 @@ int launch_lattice_cycle (gfship_domain * dom, unsigned dimension, double omega,
   A.omega = omega;
   A.rank = dom->lat_rank; A.nboxes = B;
   for (int c = 0; c < 3; c++) A.b[c] = dom->lat_b[c];
-  if (!dom->lattice_attr_set) {
-    GFSHIP_HIP (hipFuncSetAttribute ((const void *) lattice_cycle_kernel<3>,
-				     hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
-    GFSHIP_HIP (hipFuncSetAttribute ((const void *) lattice_cycle_kernel<2>,
-				     hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
-    dom->lattice_attr_set = true;
-  }
+  A.err = lattice_err_word (dom);
+  if ((r = lattice_attr (dom))) return r;
   if (dom->dim == 3)
     hipLaunchKernelGGL (lattice_cycle_kernel<3>, dim3 (B), dim3 (1024), bytes, dom->stream, A);
   else

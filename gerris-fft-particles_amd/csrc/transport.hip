@@ -12,6 +12,7 @@
 // RCCL is opened at run time (dlopen librccl.so.1): a single-box run never loads it, and a process
 // that already holds an RCCL (PyTorch's) shares that copy.
 #include "gfship_internal.hpp"
+#include <cstdlib>
 #include <vector>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -38,12 +39,20 @@ static RcclApi g_rccl;
 static int rccl_load ()
 {
   if (g_rccl.handle) return GFSHIP_OK;
+  /* GFSHIP_RCCL_LIBRARY: the RCCL to open (a site's own build; the test suite's in-process stand-in,
+     tests/mock_rccl, which runs N ranks of this transport as N threads on one GPU): no fallback to the
+     system's library when it is set and cannot be opened */
+  const char * named = getenv ("GFSHIP_RCCL_LIBRARY");
   const char * names[] = { "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" };
   void * h = nullptr;
-  for (const char * nm : names)
-    if ((h = dlopen (nm, RTLD_NOW | RTLD_GLOBAL)))
-      break;
-  GFSHIP_CHECK (h != nullptr, GFSHIP_EUNSUPPORTED, "cannot open librccl.so.1: %s", dlerror ());
+  if (named && *named)
+    h = dlopen (named, RTLD_NOW | RTLD_LOCAL);
+  else
+    for (const char * nm : names)
+      if ((h = dlopen (nm, RTLD_NOW | RTLD_GLOBAL)))
+	break;
+  GFSHIP_CHECK (h != nullptr, GFSHIP_EUNSUPPORTED, "cannot open %s: %s",
+		named && *named ? named : "librccl.so.1", dlerror ());
 #define SYM(field, name) do { \
     *(void **) &g_rccl.field = dlsym (h, name); \
     GFSHIP_CHECK (g_rccl.field != nullptr, GFSHIP_EUNSUPPORTED, "librccl: no symbol %s", name); \
@@ -349,6 +358,11 @@ void comm_free (gfship_domain * dom)
 using namespace gfship;
 
 extern "C" {
+
+int gfship_comm_available (void)
+{
+  return rccl_load ();
+}
 
 int gfship_comm_unique_id (void * id)
 {

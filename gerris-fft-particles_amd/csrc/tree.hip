@@ -27,6 +27,7 @@
 #include <cfloat>
 #include <cmath>
 #include <functional>
+#include <new>
 
 using namespace gfship;
 using namespace gfship::tree;
@@ -859,9 +860,21 @@ struct Builder {
   std::vector<std::vector<unsigned char>> flag;     // per level, (n + 2)^dim
   int r (int l) const { return (1 << l) + 2; }
   size_t idx (int l, int i, int j, int k) const { return i + (size_t) r (l)*(j + (dim == 3 ? (size_t) r (l)*k : 0)); }
-  void ensure (int l) {
+  // cells of the dense levels allocated so far; the limit of gfship_tree_create (32-bit cell indices
+  // times the number of directions in the tables) is enforced BEFORE a level is allocated: a Refine
+  // function asking for level 10 in 3-D would otherwise allocate 1, 8.6, 68 GB on the host first
+  long long total = 0;
+  bool too_large = false;
+  static constexpr long long MAX_CELLS = 1ll << 27;
+  bool ensure (int l) {
     if ((int) flag.size () <= l) flag.resize (l + 1);
-    if (flag[l].empty ()) flag[l].assign ((size_t) r (l)*r (l)*(dim == 3 ? r (l) : 1), NONE);
+    if (flag[l].empty ()) {
+      const long long cells = (long long) r (l)*r (l)*(dim == 3 ? r (l) : 1);
+      if (total + cells > MAX_CELLS) { too_large = true; return false; }
+      total += cells;
+      flag[l].assign ((size_t) cells, NONE);
+    }
+    return true;
   }
   // oct_new with check_neighbors, src/ftt.c:45-83
   int refine_single (int l, int i, int j, int k) {
@@ -880,8 +893,8 @@ struct Builder {
 	}
       }
     }
+    if (!ensure (l + 1)) return GFSHIP_EUNSUPPORTED;
     flag[l][idx (l, i, j, k)] = NODE;
-    ensure (l + 1);
     for (int c = 0; c < (1 << dim); c++)
       flag[l + 1][idx (l + 1, 2*i - 1 + (c & 1), 2*j - ((c >> 1) & 1), 2*k - ((c >> 2) & 1))] = LEAF;
     return 0;
@@ -1802,7 +1815,23 @@ int gfship_tree_create (gfship_tree ** out, int dim, gfship_refine_fn refine, vo
   return gfship_tree_create_sides (out, dim, refine, ctx, nullptr, device);
 }
 
+static int tree_create_sides (gfship_tree ** out, int dim, gfship_refine_fn refine, void * ctx,
+			      const int * side, int device);
+
+// no exception crosses the C ABI: a tree too large for the host comes back as an error
 int gfship_tree_create_sides (gfship_tree ** out, int dim, gfship_refine_fn refine, void * ctx,
+			      const int * side, int device)
+{
+  try {
+    return tree_create_sides (out, dim, refine, ctx, side, device);
+  }
+  catch (const std::bad_alloc &) {
+    set_error ("gfship_tree_create: out of host memory while the tree was built");
+    return GFSHIP_EUNSUPPORTED;
+  }
+}
+
+static int tree_create_sides (gfship_tree ** out, int dim, gfship_refine_fn refine, void * ctx,
 			      const int * side, int device)
 {
   GFSHIP_CHECK (out && refine, GFSHIP_EINVAL, "gfship_tree_create: null argument");
@@ -1823,6 +1852,8 @@ int gfship_tree_create_sides (gfship_tree ** out, int dim, gfship_refine_fn refi
   B.ensure (0);
   B.flag[0][B.idx (0, 1, 1, 1)] = LEAF;
   int e = B.refine_rec (0, 1, 1, 1, refine, ctx);
+  GFSHIP_CHECK (!B.too_large, GFSHIP_EUNSUPPORTED,
+		"gfship_tree_create: more than 2^27 cells in the dense levels of the tree");
   GFSHIP_CHECK (e == 0, e, "gfship_tree_create: more than %d levels", GFSHIP_MAXLEVEL);
   gfship_tree * tr = new gfship_tree;
   tr->device = device;
@@ -1867,7 +1898,7 @@ int gfship_tree_create_sides (gfship_tree ** out, int dim, gfship_refine_fn refi
     // the refinements of a level are applied while the level is traversed (simulation.c:1105-1109)
     traverse (tr->H, root_cell (tr->H), T_LEVEL, l, [&] (Cell c) {
 	if (tr->H.leaf (c) && refine_corner (tr->H, c)) {
-	  B.refine_single (c.l, tr->H.ci (c), tr->H.cj (c), tr->H.ck (c));
+	  (void) B.refine_single (c.l, tr->H.ci (c), tr->H.cj (c), tr->H.ck (c));
 	  for (int ll = 0; ll <= tr->H.depth; ll++)
 	    std::copy (B.flag[ll].begin (), B.flag[ll].end (), tr->hflag.begin () + tr->H.off[ll]);
 	}

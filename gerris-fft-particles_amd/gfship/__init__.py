@@ -121,6 +121,7 @@ SIGNATURES = {
     "gfship_snapshot_tree_bytes": (C.c_size_t, [_vp, _i]),
     "gfship_snapshot_tree_write": (_i, [_vp, _i, _pi, _vp, C.c_size_t]),
     "gfship_snapshot_tree_read": (_i, [_vp, _i, _pi, _vp, C.c_size_t]),
+    "gfship_comm_available": (_i, []),
     "gfship_comm_unique_id": (_i, [_vp]),
     "gfship_domain_comm_init": (_i, [_vp, _vp, _i, _i, _pi]),
     "gfship_domain_comm_size": (_i, [_vp]),
@@ -177,6 +178,11 @@ SIGNATURES = {
 
 
 UNIQUE_ID_BYTES = 128
+
+
+def comm_available():
+    """RCCL can be opened on this rank (gfship_comm_available); raises otherwise"""
+    _check(lib().gfship_comm_available())
 
 
 def comm_unique_id():

@@ -465,12 +465,16 @@ int  gfship_domain_path_counts (gfship_domain * dom, unsigned long long * lattic
    kernel, on the domain's stream; norms and the CFL minimum are reduced over the boxes
    (src/domain.c:2135-2166,2921) in one collective each.  Sides facing another box must be
    GFSHIP_SIDE_EXTERNAL; a communicator takes precedence over the hooks above.
+     gfship_comm_available: opens RCCL (dlopen) without creating anything: GFSHIP_OK when
+       gfship_domain_comm_init can be entered on this rank -- a launcher agrees on that over its own
+       channel BEFORE the collective ncclCommInitRank, so that no rank waits in it alone;
      gfship_comm_unique_id: ncclGetUniqueId (GFSHIP_UNIQUE_ID_BYTES bytes): called by one rank, the
        bytes are then given to every rank (through the launcher's own channel: a file, a TCP store);
      gfship_domain_comm_init: ncclCommInitRank on the domain's device, collective over the ranks;
      gfship_domain_comm_size: ncclCommCount (0 without a communicator);
      gfship_domain_comm_stats: messages and bytes sent so far (domain->mpi_messages, mpi_size). */
 #define GFSHIP_UNIQUE_ID_BYTES 128
+int  gfship_comm_available (void);
 int  gfship_comm_unique_id (void * id);
 int  gfship_domain_comm_init (gfship_domain * dom, const void * unique_id, int rank, int nranks,
 			      const int lattice[3]);

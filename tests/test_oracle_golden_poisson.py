@@ -34,6 +34,24 @@ def test_error_norms_match_error_ref(golden_dir):
         assert got == row[1:4], (level, got, row)
 
 
+def test_order_of_convergence_matches_order_ref(golden_dir):
+    """order.ref: the convergence orders poisson.sh:32-39 derives (awk) from the printed rows of the
+    `error' file -- here from the oracle's own errors, printed as the reference prints them."""
+    import math
+    rows = []
+    for row in _load(golden_dir, "poisson_error.ref"):
+        level = int(row[0])
+        dom, P, _, _, ex = oracle_dirichlet_solve(2, level, 10)
+        nm = error_norm_unbiased(dom, P, ex)
+        rows.append([level] + [float("%.3e" % v) for v in (nm.first, nm.second, nm.infty)])
+    ref = _load(golden_dir, "poisson_order.ref")
+    assert len(ref) == len(rows) - 1
+    for i in range(1, len(rows)):
+        got = ["%d" % rows[i][0]] + ["%.6g" % (math.log(rows[i - 1][c] / rows[i][c]) / math.log(2.))
+                                     for c in (1, 2, 3)]
+        assert got == ref[i - 1], (got, ref[i - 1])
+
+
 def test_lexicographic_sweep_is_bit_identical_to_tree_order():
     """The device kernels sweep hyperplanes of the (+x,-y,-z) lexicographic order; this must be
     bit-identical to the reference's tree pre-order sweep (hard part 1)."""
