@@ -11,6 +11,7 @@
 // poisson_kernels.hip with the diffusion cell update (RelaxOp kind 1).
 #include "gfship_internal.hpp"
 #include <cmath>
+#include <cstdlib>
 
 using namespace gfship;
 
@@ -125,6 +126,13 @@ static int relax_loop (gfship_domain * dom, Field * dp, Field * u, int level, Fi
     return r;
   if (done)
     return GFSHIP_OK;
+  /* 3-D levels of 32^3 and more: the pipelined tile kernels with the diffusion cell update (rhoc
+     travels as their dia stream); the whole loop in one launch on boxes without MPI sides */
+  static const bool pipelined = getenv ("GFSHIP_DIFFUSION_HYPERPLANES") == nullptr;
+  if (pipelined && dom->dim == 3 && dom->relax_mode == GFSHIP_RELAX_EXACT && !dom->force_hyperplane &&
+      skew_supported (dom, level) && !(dom->has_external && dom->overlap && nrelax > 1))
+    return launch_relax_loop_skew (dom, level, dp, u, res->lev[level], dia->lev[level], false, nrelax,
+				   true, nullptr, nullptr, &op);
   if ((r = launch_bc (dom, u, dp, level, 1))) return r;
   for (unsigned n = 0; n < nrelax - 1; n++) {
     if ((r = launch_relax_exact (dom, dom->dim, level, 1., dp->lev[level], res->lev[level],

@@ -95,6 +95,8 @@ int gfship_domain_create (gfship_domain ** out, int dim, int depth, const int si
   hipError_t e = hipStreamCreateWithFlags (&dom->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate (&dom->ev0);
   if (e == hipSuccess) e = hipEventCreate (&dom->ev1);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags (&dom->side_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags (&dom->side_fork, hipEventDisableTiming);
   dom->scratch_doubles = 5*8192 + 64;
   if (e == hipSuccess) e = hipMalloc ((void **) &dom->d_scratch, dom->scratch_doubles*sizeof (double));
   if (e == hipSuccess) e = hipHostMalloc ((void **) &dom->h_pinned, 64*sizeof (double), hipHostMallocDefault);
@@ -114,6 +116,7 @@ int gfship_domain_create (gfship_domain ** out, int dim, int depth, const int si
   dom->no_kernel_arming = getenv ("GFSHIP_KERNEL_ARMING") == nullptr;
   dom->no_xcd_scope = getenv ("GFSHIP_XCD_SCOPE") == nullptr;
   dom->no_fused_restriction = getenv ("GFSHIP_NO_FUSED_RESTRICTION") != nullptr;
+  dom->no_arm_ahead = getenv ("GFSHIP_NO_ARM_AHEAD") != nullptr;
   { const char * w = getenv ("GFSHIP_XCD_PLACE"); dom->xcd_place = w && w[0] == '1'; }
   { const char * w = getenv ("GFSHIP_WAVE_LOOP"); dom->wave_loop = w && w[0] == '1'; }
   *out = dom;
@@ -125,6 +128,7 @@ void gfship_domain_destroy (gfship_domain * dom)
   if (!dom) return;
   (void) hipSetDevice (dom->device);
   if (dom->stream) (void) hipStreamSynchronize (dom->stream);
+  if (dom->side_stream) (void) hipStreamSynchronize (dom->side_stream);
   for (size_t f = 0; f < dom->fields.size (); f++)
     if (dom->fields[f].used)
       gfship_field_free (dom, (gfship_field) f);
@@ -143,6 +147,8 @@ void gfship_domain_destroy (gfship_domain * dom)
   if (dom->h_pinned) (void) hipHostFree (dom->h_pinned);
   if (dom->ev0) (void) hipEventDestroy (dom->ev0);
   if (dom->ev1) (void) hipEventDestroy (dom->ev1);
+  if (dom->side_fork) (void) hipEventDestroy (dom->side_fork);
+  if (dom->side_stream) (void) hipStreamDestroy (dom->side_stream);
   if (dom->stream) (void) hipStreamDestroy (dom->stream);
   delete dom;
 }

@@ -60,6 +60,10 @@ struct SkewPlan {
   int cur_set = 0;
   size_t armed[2] = { 0, 0 };
   unsigned * arm_cum = nullptr;   // share of each tile in that arming (cumulative weights)
+  // the set the next loop of the level will use is armed ahead of time on the domain's side stream,
+  // beside the coarser levels of the cycle (skew_arm_ahead): the loop then waits for this event
+  hipEvent_t arm_ev = nullptr;
+  bool arm_wait = false;
   bool loop_checked = false;      // the trial run of the fused loop has been made on this level
   void * stats_loop = nullptr;    // optional per-tile, per-sweep timing of the fused loop (debug)
   void * ctl = nullptr;           // { ticket, err }
@@ -95,6 +99,12 @@ struct gfship_domain {
   std::deque<gfship::Field> fields;   // deque: handles stay valid while fields are added
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // side stream of the V-cycle: byte-moving work that nothing on the main stream waits for soon (the
+  // arming of the hand-off granules of the next relax loop of a fine level) runs here, beside the
+  // latency-bound coarse levels, forked and joined with events
+  hipStream_t side_stream = nullptr;
+  hipEvent_t side_fork = nullptr;
+  bool no_arm_ahead = false;       // GFSHIP_NO_ARM_AHEAD=1: the granules are armed in line, before the loop
   double * d_scratch = nullptr;   // reduction scratch
   size_t scratch_doubles = 0;
   double * h_pinned = nullptr;    // pinned host buffer for small read-backs
@@ -265,9 +275,11 @@ int launch_face_interp_div (gfship_domain * dom, double * const u[3], double * c
 			    double * div, double dt);
 int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt, int gradient,
 			     const double visc[3], double * const un[3]);
+// corr_dt != 0: gfs_correct_centered_velocities with gc and corr_dt applied in the same pass, and with uc
+// the level below the leaves of the corrected velocities (gfs_cell_coarse_init's first level)
 int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * const out[3],
 			  double * const un[3], double * const gm[3], double * const gc[3],
-			  double dt, int gradient);
+			  double dt, int gradient, double corr_dt = 0., double * const uc[3] = nullptr);
 int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, double * out,
 			 double * const un[3], const double * gm, const double * gc, double dt,
 			 int gradient, double visc, double gsrc = 0.);
@@ -278,15 +290,18 @@ bool skew_supported (const gfship_domain * dom, int level);
 int  launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * ubc,
 			     const double * rhs, const double * dia, bool dia_zero,
 			     unsigned nrelax, bool bc, double * correct_into = nullptr,
-			     const double * prolong_from = nullptr);
+			     const double * prolong_from = nullptr, const RelaxOp * op = nullptr);
 void skew_free (gfship_domain * dom);
 bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool bc);
 int  skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia,
-		    unsigned nrelax, float * ms = nullptr, const Field * ubc = nullptr);
+		    unsigned nrelax, float * ms = nullptr, const Field * ubc = nullptr,
+		    const RelaxOp * op = nullptr);
 int  skew_time_loop (gfship_domain * dom, int level, Field * u, const double * rhs,
 		     const double * dia, bool dia_zero, unsigned nrelax, int reps,
 		     double * ms_per_loop, int * fused, double * ms_inclusive = nullptr);
 int  skew_check_error (gfship_domain * dom);
+// arm the granules of the next relax loop of `level' on the side stream, from this point of the main stream
+int  skew_arm_ahead (gfship_domain * dom, int level, unsigned nrelax);
 // relax_patch_loop.hip
 int  patch_resident_per_cu ();
 // the prolongation onto `level' can be done by the copy into the skewed layout of its relax loop

@@ -358,6 +358,11 @@ static int poisson_cycle (gfship_domain * dom, gfship_multilevel_params * p,
     const int ltop = ctop >= 0 ? -1 : lattice_cycle_top (dom, (int) minlevel, D);
     /* compute residual on non-leafs cells (get_from_below, post-order: finest parents first) */
     for (int l = L - 1; l >= (ctop >= 0 ? ctop + 1 : ltop >= 0 ? ltop : 0); l--) {
+      /* the hand-off granules of the relax loop of level l + 1, which comes on the way up, are armed
+	 from here on the side stream, beside the loops of the levels below */
+      if (dom->relax_mode == GFSHIP_RELAX_EXACT && p->dimension == 3 && !dom->weighted &&
+	  !dom->force_hyperplane && skew_supported (dom, l + 1))
+	TRY (skew_arm_ahead (dom, l + 1, nrl[l + 1]));
       /* where level l + 1 runs its relax loop on the 2 x 2 kernels the residual is copied into their
 	 layout by the same pass that restricts it (and so is the restricted one, where level l does) */
       if (!dom->no_fused_restriction && !dom->skew[l + 1].rs_ready &&

@@ -117,6 +117,126 @@ relax_hyperplane_kernel (Layout L, int plane, unsigned dimension, double omega, 
   u[c] = relax_value<DIM, OP> (u, c, L.sy, L.sz, rhs[c], dia[c], dimension, omega, w, h2, &wf);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The exact-order sweep of a 2-D level in ONE launch (relax2D, src/poisson.c:532-557, and
+// diffusion_relax in 2-D): one workgroup, one thread per row.  Thread J owns the row j = n - J and
+// walks it in the direction of the sweep, one step behind thread J - 1: at step t it updates the
+// cell I = t - J (i = I + 1) -- the hyperplane I + J = t of the oriented coordinates, all of whose
+// cells are independent (launch_relax_exact's order, one launch per hyperplane before: 2 n - 1
+// launches per sweep, 4.2 s for the 128^2 run of test/periodic).  What a cell needs from other rows
+// travels through LDS, double-buffered by the parity of the step (one barrier per step): the new
+// value of the row above (thread J - 1, computed one step earlier) and the old value of the row
+// below (thread J + 1 publishes what it holds as its `right' neighbour for its next step).  A
+// thread reads its own row ahead of its stores (RX_D steps: a register ring, the step loop unrolled
+// by RX_D) and nobody else's, so no global-memory ordering between threads is involved; the ghost
+// rows j = n + 1 and j = 0 (written by the BC application before the sweep, not by the sweep) are
+// streamed by the threads of the first and the last row.  Same expressions as relax_value<2, OP>.
+// ---------------------------------------------------------------------------------------------
+#define RX_D 8
+
+template <int OP>
+__global__ void __launch_bounds__(1024)
+relax_rows2d_kernel (Layout L, double omega, double w, double h2,
+		     double * __restrict__ u, const double * __restrict__ rhs,
+		     const double * __restrict__ dia)
+{
+  __shared__ double N[2][1024 + 2], O[2][1024 + 2];
+  const int n = L.n;
+  const int J = threadIdx.x;
+  const bool mine = J < n;
+  const int j = mine ? n - J : 1;
+  double * const row = u + L.idx (0, j, 0) - 1;           // row[i + 1] = u (i, j): i = -1 is never used
+  const double * const rrow = rhs + L.idx (0, j, 0) - 1;
+  const double * const drow = dia + L.idx (0, j, 0) - 1;
+  // the ghost row beside the first / the last row of the sweep
+  const double * const erow = J == 0 ? u + L.idx (0, n + 1, 0) - 1 :
+    J == n - 1 ? u + L.idx (0, 0, 0) - 1 : nullptr;
+  auto clampi = [n] (int i) { return i < 0 ? 0 : i > n + 1 ? n + 1 : i; };
+  // at step t: I = t - J; right = u (I + 2, j) = row[I + 3]; rhs, dia, ghost row at i = I + 1
+  double pR[RX_D], pH[RX_D], pD[RX_D], pE[RX_D];
+#pragma unroll
+  for (int q = 0; q < RX_D; q++) {
+    const int i = q - J + 1;
+    pR[q] = row[clampi (i + 1) + 1];
+    pH[q] = rrow[clampi (i) + 1];
+    pD[q] = drow[clampi (i) + 1];
+    pE[q] = erow ? erow[clampi (i) + 1] : 0.;
+  }
+  double left = row[0 + 1], cur = row[1 + 1];
+  if (mine) {
+    // what thread J - 1 reads at step 0 as the old value below its cell I = - (J - 1): only the
+    // thread J = 1 is read then (I = 0 of thread 0): its cell i = 1
+    O[0][J + 1] = cur;
+    N[0][J + 1] = 0.;
+  }
+  __syncthreads ();
+  const int T = (2*n - 1 + RX_D - 1)/RX_D*RX_D;
+  for (int t0 = 0; t0 < T; t0 += RX_D) {
+#pragma unroll
+    for (int q = 0; q < RX_D; q++) {
+      const int t = t0 + q, I = t - J;
+      const int rd = t & 1, wr = rd ^ 1;
+      const double right = pR[q], rh = pH[q], di = pD[q], ex = pE[q];
+      // the loads of step t + RX_D
+      {
+	const int i = I + RX_D + 1;
+	pR[q] = row[clampi (i + 1) + 1];
+	pH[q] = rrow[clampi (i) + 1];
+	pD[q] = drow[clampi (i) + 1];
+	if (erow) pE[q] = erow[clampi (i) + 1];
+      }
+      double v = 0.;
+      const bool active = mine && I >= 0 && I < n;
+      if (active) {
+	const double top = J == 0 ? ex : N[rd][J];              // new value of (I, J - 1): row j + 1
+	const double bottom = J == n - 1 ? ex : O[rd][J + 2];     // old value of (I, J + 1): row j - 1
+	if (OP == 1) {
+	  double ga = 0., gb = 0.;
+	  ga += w; gb += w*right;
+	  ga += w; gb += w*left;
+	  ga += w; gb += w*top;
+	  ga += w; gb += w*bottom;
+	  double a = di*h2;
+	  ga = 1. + ga/a;
+	  v = (gb/a + rh)/ga;
+	}
+	else {
+	  double a = di, b = 0.;
+	  a += 1.; b += 1.*right;
+	  a += 1.; b += 1.*left;
+	  a += 1.; b += 1.*top;
+	  a += 1.; b += 1.*bottom;
+	  v = a != 0. ? (1. - omega)*cur + omega*(b - rh)/a : 0.;
+	}
+	row[I + 1 + 1] = v;
+	left = v;
+	cur = right;
+      }
+      if (mine) {
+	N[wr][J + 1] = v;
+	// the old value thread J - 1 needs below its cell of step t + 1: my `right' of step t + 1
+	O[wr][J + 1] = pR[(q + 1) % RX_D];
+      }
+      __syncthreads ();
+    }
+  }
+}
+
+static int launch_relax_rows2d (gfship_domain * dom, int level, double omega, double * u,
+				const double * rhs, const double * dia, int kind, double w, double h2)
+{
+  const Layout & L = dom->lay[level];
+  const int block = L.n <= 64 ? 64 : L.n <= 128 ? 128 : L.n <= 256 ? 256 : L.n <= 512 ? 512 : 1024;
+  if (kind)
+    hipLaunchKernelGGL (relax_rows2d_kernel<1>, dim3 (1), dim3 (block), 0, dom->stream, L, omega, w, h2,
+			u, rhs, dia);
+  else
+    hipLaunchKernelGGL (relax_rows2d_kernel<0>, dim3 (1), dim3 (block), 0, dom->stream, L, omega, w, h2,
+			u, rhs, dia);
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
 int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, double omega,
 			double * u, const double * rhs, const double * dia, const RelaxOp * op)
 {
@@ -124,6 +244,9 @@ int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, doub
   const double w = op ? op->w : 1., h2 = op ? op->h2 : 1.;
   const Layout & L = dom->lay[level];
   int n = L.n;
+  static const bool rows2d = getenv ("GFSHIP_NO_ROWS2D") == nullptr;
+  if (dom->dim == 2 && dimension == 2 && kind != 2 && n >= 8 && n <= 1024 && rows2d && !dom->force_hyperplane)
+    return launch_relax_rows2d (dom, level, omega, u, rhs, dia, kind, w, h2);
   int nplanes = dom->dim == 3 ? 3*n - 2 : 2*n - 1;
   int nthreads = dom->dim == 3 ? n*n : n;
   int block = 256;
@@ -1607,6 +1730,83 @@ residual_norm_kernel (Layout L, const double * __restrict__ u, const double * __
   }
 }
 
+// The same for 3-D levels with n >= 4, two cells of a row per thread: the rows of a level start 16-byte
+// aligned (Layout), so the centre, the four neighbour rows, the right-hand side and the result move
+// as 16-byte accesses and only the two cells beside the pair as 8-byte ones -- 8 loads and 1 store per
+// two cells instead of 16 and 2 (the 8-byte version moved 3.1 TB/s of its 24 B per cell at 256^3: bound
+// by the number of requests, not by bytes).  Same arithmetic per cell; the sums are accumulated in
+// another order (they are tree-reduced anyway: 1e-12), the maximum is exact.
+__global__ void __launch_bounds__(256)
+residual_norm2_kernel (Layout L, const double * __restrict__ u, const double * __restrict__ rhs,
+		       const double * __restrict__ dia, double * __restrict__ res, double inv,
+		       double weight, double * __restrict__ partial)
+{
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const int n = L.n, half = n >> 1;
+  const long nitems = (long) n*n*half;
+  double s0 = 0., s1 = 0., s2 = 0., s3 = 0., s4 = 0.;
+  for (long it = (long) blockIdx.x*blockDim.x + threadIdx.x; it < nitems; it += (long) gridDim.x*blockDim.x) {
+    const int pr = (int) (it % half);
+    const long r = it / half;
+    const int j = (int) (r % n) + 1, k = (int) (r / n) + 1;
+    const long c = L.idx (1 + 2*pr, j, k);           /* even index: 16-byte aligned */
+    const d2 uc = *(const d2 *) (u + c);
+    const double ul = u[c - 1], ur = u[c + 2];
+    const d2 ut = *(const d2 *) (u + c + L.sy), ub = *(const d2 *) (u + c - L.sy);
+    const d2 uf = *(const d2 *) (u + c + L.sz), uk = *(const d2 *) (u + c - L.sz);
+    const d2 rh = *(const d2 *) (rhs + c);
+    d2 di = { 0., 0. };
+    if (dia) di = *(const d2 *) (dia + c);
+    d2 out;
+    {
+      double a = di.x, b = 0.;
+      a += 1.; b += 1.*uc.y;
+      a += 1.; b += 1.*ul;
+      a += 1.; b += 1.*ut.x;
+      a += 1.; b += 1.*ub.x;
+      a += 1.; b += 1.*uf.x;
+      a += 1.; b += 1.*uk.x;
+      out.x = rh.x - (b - uc.x*a);
+    }
+    {
+      double a = di.y, b = 0.;
+      a += 1.; b += 1.*ur;
+      a += 1.; b += 1.*uc.x;
+      a += 1.; b += 1.*ut.y;
+      a += 1.; b += 1.*ub.y;
+      a += 1.; b += 1.*uf.y;
+      a += 1.; b += 1.*uk.y;
+      out.y = rh.y - (b - uc.y*a);
+    }
+    *(d2 *) (res + c) = out;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const double raw = e ? out.y : out.x;
+      double val = raw*inv;
+      s0 += weight*val;
+      val = fabs (val);
+      s3 = fmax (s3, val);
+      s1 += weight*val;
+      s2 += weight*val*val;
+      s4 += raw;
+    }
+  }
+  __shared__ double sh[5][4];
+  s0 = wave_sum (s0); s1 = wave_sum (s1); s2 = wave_sum (s2); s3 = wave_max (s3); s4 = wave_sum (s4);
+  int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { sh[0][w] = s0; sh[1][w] = s1; sh[2][w] = s2; sh[3][w] = s3; sh[4][w] = s4; }
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    int nw = blockDim.x >> 6;
+    double r0 = 0., r1 = 0., r2 = 0., r3 = 0., r4 = 0.;
+    for (int q = 0; q < nw; q++) {
+      r0 += sh[0][q]; r1 += sh[1][q]; r2 += sh[2][q]; r3 = fmax (r3, sh[3][q]); r4 += sh[4][q];
+    }
+    double * p = partial + 5*(size_t) blockIdx.x;
+    p[0] = r0; p[1] = r1; p[2] = r2; p[3] = r3; p[4] = r4;
+  }
+}
+
 // result_slot: 0 = dom->h_pinned (waited for, copied to out), 8 = dom->h_pinned + 8 (not waited for:
 // the caller synchronises later, launch_norm_async's convention)
 int launch_residual_norm (gfship_domain * dom, int level, const double * u, const double * rhs,
@@ -1633,7 +1833,15 @@ int launch_residual_norm (gfship_domain * dom, int level, const double * u, cons
   int nblocks = (int) (nrows > rn_blocks ? rn_blocks : nrows);
   double * partial = dom->d_scratch;
   double * result = out ? dom->h_pinned : dom->h_pinned + 8;
-  if (dom->dim == 3)
+  static const bool rn_pairs = getenv ("GFSHIP_RN_SCALAR") == nullptr;
+  if (dom->dim == 3 && L.n >= 64 && rn_pairs) {
+    const long nitems = (long) L.n*L.n*(L.n/2);
+    long nb = (nitems + 255)/256;
+    nblocks = (int) (nb > rn_blocks ? rn_blocks : nb);
+    hipLaunchKernelGGL (residual_norm2_kernel, dim3 (nblocks), dim3 (256), 0, dom->stream, L, u,
+			rhs, dia_zero ? nullptr : dia, res, 1./scale, weight, partial);
+  }
+  else if (dom->dim == 3)
     hipLaunchKernelGGL (residual_norm_kernel<3>, dim3 (nblocks), dim3 (block), 0, dom->stream, L, u,
 			rhs, dia_zero ? nullptr : dia, res, 1./scale, weight, partial);
   else

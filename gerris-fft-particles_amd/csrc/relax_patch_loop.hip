@@ -113,11 +113,13 @@ __device__ __forceinline__ bool patch_same_xcd (const SkewLoopArgs & A, int t)
 // four cells of a step form one dependent chain, a branch per cell would cut it into basic blocks
 // that the scheduler cannot interleave.  The step tests the four flags once and, in the (never
 // observed) case that one is set, recomputes its cells with true divisions.
-template <bool HAS_DIA>
+template <bool HAS_DIA, int OP = 0>
 __device__ __forceinline__ double patch_cell (double right, double left, double top, double bottom,
 					      double front, double back, double rhs, double dia,
-					      bool & tiny, bool exact)
+					      bool & tiny, bool exact, double w = 1., double h2 = 1.)
 {
+  if (OP == 1)
+    return diffusion_cell (right, left, top, bottom, front, back, rhs, dia, w, h2);
   double aa = HAS_DIA ? dia : 0., bb = 0.;
   aa += 1.; bb += 1.*right;
   aa += 1.; bb += 1.*left;
@@ -516,7 +518,7 @@ relax_patch_loop_kernel (SkewLoopArgs A)
 #endif
 #define RK_NTHREADS 256
 
-template <bool HAS_DIA>
+template <bool HAS_DIA, int OP>
 __global__ void __launch_bounds__(RK_NTHREADS)
 relax_ring_loop_kernel (SkewLoopArgs A)
 {
@@ -863,13 +865,13 @@ relax_ring_loop_kernel (SkewLoopArgs A)
 	  }
 	  bool tiny = false;
 	  // (a0, b0): top and front from the neighbour lanes, bottom and back the lane's own old values
-	  double v0 = patch_cell<HAS_DIA> (nx[0], prev[0], Tn0, cur[1], Fn0, cur[2], h01.x, e01.x, tiny, false);
+	  double v0 = patch_cell<HAS_DIA, OP> (nx[0], prev[0], Tn0, cur[1], Fn0, cur[2], h01.x, e01.x, tiny, false, A.w, A.h2);
 	  // (a0 + 1, b0): top = the new (a0, b0)
-	  double v1 = patch_cell<HAS_DIA> (nx[1], prev[1], v0, Bo0, Fn1, cur[3], h01.y, e01.y, tiny, false);
+	  double v1 = patch_cell<HAS_DIA, OP> (nx[1], prev[1], v0, Bo0, Fn1, cur[3], h01.y, e01.y, tiny, false, A.w, A.h2);
 	  // (a0, b0 + 1): front = the new (a0, b0)
-	  double v2 = patch_cell<HAS_DIA> (nx[2], prev[2], Tn1, cur[3], v0, Bk0, h23.x, e23.x, tiny, false);
+	  double v2 = patch_cell<HAS_DIA, OP> (nx[2], prev[2], Tn1, cur[3], v0, Bk0, h23.x, e23.x, tiny, false, A.w, A.h2);
 	  // (a0 + 1, b0 + 1)
-	  double v3 = patch_cell<HAS_DIA> (nx[3], prev[3], v2, Bo1, v1, Bk1, h23.y, e23.y, tiny, false);
+	  double v3 = patch_cell<HAS_DIA, OP> (nx[3], prev[3], v2, Bo1, v1, Bk1, h23.y, e23.y, tiny, false, A.w, A.h2);
 	  if (!HAS_DIA && __builtin_expect (__builtin_amdgcn_ballot_w64 (tiny) != 0, 0)) {
 	    v0 = patch_cell<HAS_DIA> (nx[0], prev[0], Tn0, cur[1], Fn0, cur[2], h01.x, e01.x, tiny, true);
 	    v1 = patch_cell<HAS_DIA> (nx[1], prev[1], v0, Bo0, Fn1, cur[3], h01.y, e01.y, tiny, true);
@@ -995,6 +997,85 @@ __device__ __forceinline__ double patch_prolong (const Layout & Lc, const double
   for (int cc = 0; cc < 3; cc++)
     val += rel[cc]*h[cc];
   return val;
+}
+
+// get_from_above (src/poisson.c:1005-1042) of a whole level STRAIGHT INTO the patch-skewed layout of
+// its relax loop: the initial guess of the loop is produced where the loop reads it, the natural
+// array of the level only gets the cells along the six box sides (what the BC application that
+// follows reads).  One wave = one tile and PR_ROWS rows of it; lane (A, B) owns the 2 x 2 lines of
+// the loop kernels and writes their four cells of row rho = I + A + B: every store instruction of the
+// wave is one contiguous KB of a row.  The 2 x 2 lines of a lane and two consecutive I are the eight
+// children of ONE coarse cell -- (m + 1, n/2 - 8 P - A, n/2 - 8 Q - B), m = I >> 1 -- whose value and
+// three half-differences the lane keeps for two rows: 7 loads (scattered over the 64 coarse lines of
+// the wave, L1-resident for 32 rows) and 10 operations per 8 cells, 3 additions per cell.  Operand
+// order of patch_prolong / prolongate_kernel: val = p; val += rel_x h_x; += rel_y h_y; += rel_z h_z,
+// rel = -+ 1/4 (the products by -+ 1/4 are exact: formed once per coarse cell as 0.25 h, negated).
+#define PR_ROWS 16
+#define PR_WAVES 4
+
+__global__ void __launch_bounds__(64*PR_WAVES)
+patch_prolong_kernel (PatchPackArgs A)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.y;
+  const int r0 = (blockIdx.x*PR_WAVES + wave)*PR_ROWS;
+  const int n = A.L.n;
+  if (r0 >= n + PK_SKEW) return;
+  const int P = tile % A.ntj, Q = tile / A.ntj;
+  const int PA = lane & 7, PB = lane >> 3, s = PA + PB;
+  double * const dst = A.dst[0] + (long) tile*(A.RT + 2*SK_FP)*SK_NL + SK_FP*SK_NL + 2*lane;
+  // the coarse line of the lane and its neighbours
+  const int pj = n/2 - 8*P - PA, pk = n/2 - 8*Q - PB;
+  const double * __restrict__ const vc = A.coarse;
+  const long cline = A.Lc.idx (0, pj, pk);
+  const long csy = A.Lc.sy, csz = A.Lc.sz;
+  // natural lines of the lane (p = da + 2 db) and whether they lie along a box side
+  const int j0 = n - (SK_T*P + 2*PA), k0 = n - (SK_T*Q + 2*PB);
+  const bool side_j[2] = { j0 == n, j0 - 1 == 1 }, side_k[2] = { k0 == n, k0 - 1 == 1 };
+  int cur_m = -1;
+  double pv = 0., qx = 0., qy = 0., qz = 0.;
+  const int r1 = r0 + PR_ROWS;
+  for (int rho = r0; rho < r1; rho++) {
+    const int I = rho - s;
+    if ((unsigned) I >= (unsigned) n) continue;
+    const int m = I >> 1;
+    if (m != cur_m) {
+      cur_m = m;
+      const long p = cline + (m + 1);
+      pv = vc[p];
+      {
+	const double g1 = vc[p + 1] - 1.*pv, g2 = vc[p - 1] - 1.*pv;
+	qx = 0.25*((g1 - g2)/2.);
+      }
+      {
+	const double g1 = vc[p + csy] - 1.*pv, g2 = vc[p - csy] - 1.*pv;
+	qy = 0.25*((g1 - g2)/2.);
+      }
+      {
+	const double g1 = vc[p + csz] - 1.*pv, g2 = vc[p - csz] - 1.*pv;
+	qz = 0.25*((g1 - g2)/2.);
+      }
+    }
+    // i = I + 1 odd (I even): the first child along x, rel = -1/4; j even (a even): +1/4; k even: +1/4
+    const double bx = pv + ((I & 1) ? qx : - qx);
+    d2 o01, o23;
+    {
+      const double by0 = bx + qy, by1 = bx + (- qy);
+      o01.x = by0 + qz;     o01.y = by1 + qz;
+      o23.x = by0 + (- qz); o23.y = by1 + (- qz);
+    }
+    double * const row = dst + (long) rho*SK_NL;
+    *(d2 *) row = o01;
+    *(d2 *) (row + 128) = o23;
+    if (__builtin_expect (I == 0 || I == n - 1 || side_j[0] || side_j[1] || side_k[0] || side_k[1], 0)) {
+      const bool ends = I == 0 || I == n - 1;
+      const double vv[4] = { o01.x, o01.y, o23.x, o23.y };
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+	if (ends || side_j[q & 1] || side_k[q >> 1])
+	  A.nat[A.L.idx (I + 1, j0 - (q & 1), k0 - (q >> 1))] = vv[q];
+    }
+  }
 }
 
 #define PP_ROWS 16
@@ -1169,7 +1250,11 @@ int patch_resident_per_cu ()
   int per_cu = 0;
   hipError_t e = patch_regs () ?
     hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_patch_loop_kernel<true>, PK_NTHREADS, 0) :
-    hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_ring_loop_kernel<true>, RK_NTHREADS, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_ring_loop_kernel<true, 0>, RK_NTHREADS, 0);
+  int per_cu1 = 0;
+  if (e == hipSuccess)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu1, relax_ring_loop_kernel<true, 1>, RK_NTHREADS, 0);
+  if (per_cu1 < per_cu) per_cu = per_cu1;
   return e == hipSuccess ? per_cu : 0;
 }
 
@@ -1187,6 +1272,21 @@ int patch_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u, 
   if (rhs) { A.src[A.narr] = rhs; A.dst[A.narr++] = S->rs; }     /* nullptr: already there (patch_restrict_pack) */
   if (dia) { A.src[A.narr] = dia; A.dst[A.narr++] = S->ds; }
   const int rows = A.L.n + PK_SKEW + 1;
+  if (coarse && !getenv ("GFSHIP_OLD_PROLONG_PACK")) {
+    /* the prolongation straight into the layout (patch_prolong_kernel); arrays that still have to be
+       copied (a dia that is not zero; the rhs when the restriction has not left it there) follow in
+       the transposing copy */
+    PatchPackArgs Pr = A;
+    Pr.narr = 1;
+    dim3 pgrid ((rows + PR_ROWS*PR_WAVES - 1)/(PR_ROWS*PR_WAVES), S->ntj*S->ntj);
+    hipLaunchKernelGGL (patch_prolong_kernel, pgrid, dim3 (64*PR_WAVES), 0, dom->stream, Pr);
+    GFSHIP_HIP (hipGetLastError ());
+    if (A.narr == 1)
+      return GFSHIP_OK;
+    for (int q = 1; q < A.narr; q++) { A.src[q - 1] = A.src[q]; A.dst[q - 1] = A.dst[q]; }
+    A.narr--;
+    A.coarse = nullptr;
+  }
   dim3 grid ((rows + PP_ROWS - 1)/PP_ROWS, 8, S->ntj*S->ntj);
   hipLaunchKernelGGL (patch_pack_kernel, grid, dim3 (256), 0, dom->stream, A);
   GFSHIP_HIP (hipGetLastError ());
@@ -1231,16 +1331,18 @@ int patch_loop_launch (gfship_domain * dom, const SkewLoopArgs & A, int ntiles, 
 		       unsigned nrelax, float * ms)
 {
   if (ms) GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
-  if (patch_regs ()) {      /* the variant that streams through registers (GFSHIP_PATCH_REGS=1) */
+  if (A.op == 1)            /* diffusion_relax: the ring kernel (rhoc travels as the dia stream) */
+    hipLaunchKernelGGL ((relax_ring_loop_kernel<true, 1>), dim3 (ntiles), dim3 (RK_NTHREADS), 0, dom->stream, A);
+  else if (patch_regs ()) {      /* the variant that streams through registers (GFSHIP_PATCH_REGS=1) */
     if (has_dia)
       hipLaunchKernelGGL (relax_patch_loop_kernel<true>, dim3 (ntiles), dim3 (PK_NTHREADS), 0, dom->stream, A);
     else
       hipLaunchKernelGGL (relax_patch_loop_kernel<false>, dim3 (ntiles), dim3 (PK_NTHREADS), 0, dom->stream, A);
   }
   else if (has_dia)
-    hipLaunchKernelGGL (relax_ring_loop_kernel<true>, dim3 (ntiles), dim3 (RK_NTHREADS), 0, dom->stream, A);
+    hipLaunchKernelGGL ((relax_ring_loop_kernel<true, 0>), dim3 (ntiles), dim3 (RK_NTHREADS), 0, dom->stream, A);
   else
-    hipLaunchKernelGGL (relax_ring_loop_kernel<false>, dim3 (ntiles), dim3 (RK_NTHREADS), 0, dom->stream, A);
+    hipLaunchKernelGGL ((relax_ring_loop_kernel<false, 0>), dim3 (ntiles), dim3 (RK_NTHREADS), 0, dom->stream, A);
   GFSHIP_HIP (hipGetLastError ());
   if (ms) {
     GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));

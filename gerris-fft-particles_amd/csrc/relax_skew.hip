@@ -405,6 +405,7 @@ void skew_free (gfship_domain * dom)
     if (S.hb) (void) hipFree (S.hb);
     if (S.hbf) (void) hipFree (S.hbf);
     if (S.arm_cum) (void) hipFree (S.arm_cum);
+    if (S.arm_ev) (void) hipEventDestroy (S.arm_ev);
     if (S.stats_loop) (void) hipFree (S.stats_loop);
     if (S.ctl) (void) hipFree (S.ctl);
     if (S.stats) (void) hipFree (S.stats);
@@ -468,12 +469,13 @@ static int skew_launch (gfship_domain * dom, int level, SkewPlan * S, double * u
   return GFSHIP_OK;
 }
 
-static int skew_sweep (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia)
+static int skew_sweep (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia,
+		       const RelaxOp * op = nullptr)
 {
   /* the six-wave kernel of relax_skew_loop.hip also runs a single sweep (any sides); the
      four-wave kernel below is kept as an independent implementation (GFSHIP_SKEW_OLD=1) */
-  if (!dom->skew_old)
-    return skew_loop_run (dom, level, S, u_nat, has_dia, 1);
+  if (!dom->skew_old || (op && op->kind))
+    return skew_loop_run (dom, level, S, u_nat, has_dia, 1, nullptr, nullptr, op);
   // ticket = 0 (err is sticky), hand-off granules = sentinel
   GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
   if (S->ntj > 1)
@@ -522,7 +524,8 @@ bool prolongation_fused (gfship_domain * dom, unsigned dimension, int level, uns
 
 int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * ubc,
 			    const double * rhs, const double * dia, bool dia_zero,
-			    unsigned nrelax, bool bc, double * correct_into, const double * prolong_from)
+			    unsigned nrelax, bool bc, double * correct_into, const double * prolong_from,
+			    const RelaxOp * op)
 {
   SkewPlan * S;
   int r;
@@ -542,11 +545,11 @@ int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * 
   if (!fusedp && (r = skew_pack (dom, level, S, u, rhs_pack, dia_zero ? nullptr : dia))) return r;
   if (!dom->no_fused_loop && skew_loop_supported (dom, level, nrelax, bc)) {
     /* the sweeps of the loop pipelined in one launch (relax_skew_loop.hip) */
-    if ((r = skew_loop_run (dom, level, S, u, !dia_zero, nrelax, nullptr, ubc))) return r;
+    if ((r = skew_loop_run (dom, level, S, u, !dia_zero, nrelax, nullptr, ubc, op))) return r;
     return skew_unpack (dom, level, S, u, correct_into);
   }
   for (unsigned q = 0; q < nrelax; q++) {
-    if ((r = skew_sweep (dom, level, S, u, !dia_zero))) return r;
+    if ((r = skew_sweep (dom, level, S, u, !dia_zero, op))) return r;
     if (bc && q + 1 < nrelax && (r = launch_bc (dom, ubc, dp, level, 1))) return r;
   }
   return skew_unpack (dom, level, S, u, correct_into);

@@ -92,6 +92,10 @@ struct SkewLoopArgs {
   unsigned * tile_xcd;
   int fault_tile;          // test of the error path (GFSHIP_FAULT_DROP_HANDOFF=tile): that tile publishes nothing in sweep 0
   int near_mode;           // stores towards a consumer on the same XCD: 0 agent scope like the others, 1 plain, 2 workgroup scope
+  // cell update (RelaxOp): 0 = relax (src/poisson.c:507-530, unit weights), 1 = diffusion_relax
+  // (:1455-1484) with the uniform face weight w of the level and h2 = h*h; dia is then rhoc
+  int op;
+  double w, h2;
 };
 
 typedef __attribute__((address_space(1))) u64 gu64;
@@ -133,5 +137,24 @@ __device__ __forceinline__ double divide_by_6 (double x)
 
 int patch_loop_launch (gfship_domain * dom, const SkewLoopArgs & A, int ntiles, bool has_dia,
 		       unsigned nrelax, float * ms);
+
+// diffusion_relax of one cell, src/poisson.c:1455-1484 with gfs_face_cm_weighted_gradient's
+// same-level branch (relax_value<3, 1> of poisson_kernels.hip): d = 0..5 = right, left, top, bottom,
+// front, back
+__device__ __forceinline__ double diffusion_cell (double right, double left, double top, double bottom,
+						  double front, double back, double rhs, double dia,
+						  double w, double h2)
+{
+  double ga = 0., gb = 0.;
+  ga += w; gb += w*right;
+  ga += w; gb += w*left;
+  ga += w; gb += w*top;
+  ga += w; gb += w*bottom;
+  ga += w; gb += w*front;
+  ga += w; gb += w*back;
+  const double a = dia*h2;
+  ga = 1. + ga/a;
+  return (gb/a + rhs)/ga;
+}
 
 } // namespace gfship

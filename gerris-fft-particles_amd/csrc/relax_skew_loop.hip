@@ -74,7 +74,7 @@ __device__ __forceinline__ unsigned skew_claim_tile (const SkewLoopArgs & A)
 // became slower and the step no faster.)
 #define SK_NTHREADS (SK_NL + 128)
 
-template <bool HAS_DIA>
+template <bool HAS_DIA, int OP>
 __global__ void __launch_bounds__(SK_NTHREADS)
 relax_skew_loop_kernel (SkewLoopArgs A)
 {
@@ -341,7 +341,8 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 	  aa += 1.; bb += 1.*Bo;
 	  aa += 1.; bb += 1.*Fn;
 	  aa += 1.; bb += 1.*Bk;
-	  const double v = HAS_DIA ? (aa != 0. ? (bb - pRhs[q])/aa : 0.) : divide_by_6 (bb - pRhs[q]);
+	  const double v = OP == 1 ? diffusion_cell (Rv, prev, Tn, Bo, Fn, Bk, pRhs[q], pDia[q], A.w, A.h2) :
+	    HAS_DIA ? (aa != 0. ? (bb - pRhs[q])/aa : 0.) : divide_by_6 (bb - pRhs[q]);
 	  prev = act ? v : prev;
 	  first = I == 0 ? v : first;
 	  X[B ^ 1][iOwnX] = v;
@@ -758,7 +759,7 @@ static int skew_loop_resident (gfship_domain * dom, int level)
     int per_cu = 0, per_cu_w = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice (&dev) != hipSuccess || hipGetDeviceProperties (&prop, dev) != hipSuccess ||
-	hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_skew_loop_kernel<true>,
+	hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_skew_loop_kernel<true, 1>,
 						      SK_NTHREADS, 0) != hipSuccess ||
 	hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu_w, relax_wave_loop_kernel,
 						      WV_NTHREADS, 0) != hipSuccess) {
@@ -784,37 +785,90 @@ bool skew_loop_supported (gfship_domain * dom, int level, unsigned nrelax, bool 
   return ntiles <= skew_loop_resident (dom, level);
 }
 
+// geometry of the granule sets of a level: words of the header, of a set, and of what a loop of
+// nrelax sweeps needs armed
+struct SetGeometry { long hb_words, hb_sweep; size_t hdr, set_words, need; };
+
+static SetGeometry skew_set_geometry (const gfship_domain * dom, int level, const SkewPlan * S, unsigned nrelax)
+{
+  const Layout & L = dom->lay[level];
+  const int ntiles = S->ntj*S->ntj;
+  SetGeometry G;
+  const long hstride = (long) SK_HROWS (L.n)*SK_T;
+  G.hb_words = (long) ntiles*hstride;
+  G.hb_sweep = 4*G.hb_words;
+  /* header: [0] ticket, [1..4] the 8 tickets of the XCD blocks, [8..] the XCD of each tile (32 bits each) */
+  G.hdr = 8 + ((size_t) ntiles + 1)/2 + 8;
+  G.set_words = (size_t) SK_MAXF*G.hb_sweep + G.hdr + (G.hdr & 1);
+  /* a single sweep only uses the two hand-off arrays of its granule set; the snapshots of the last
+     sweep are neither written nor read: its two hand-off arrays end the armed range */
+  G.need = G.hdr + (G.hdr & 1) + (size_t) (nrelax - 1)*G.hb_sweep + (size_t) 2*G.hb_words;
+  return G;
+}
+
+// The granules of the set the NEXT loop of `level' will use, armed from this point of the main
+// stream on the side stream (poisson_cycle calls this on the way down the V-cycle: the fill -- 148 MB
+// at 256^3 -- then runs beside the relax loops of the coarser levels, which are bound by the latency
+// of their hand-off chains and leave the memory system idle; in line it costs 37 us per loop at
+// 256^3).  The loop waits for the event.  Arming beside the loop of the level ITSELF was tried in
+// round 2 and lost what it gained (its stores delay the hand-offs); this is a different place.
+int skew_arm_ahead (gfship_domain * dom, int level, unsigned nrelax)
+{
+  SkewPlan * S = &dom->skew[level];
+  if (dom->no_arm_ahead || !dom->side_stream || !S->hbf || S->arm_wait || nrelax < 2 || nrelax > SK_MAXF)
+    return GFSHIP_OK;           /* nothing allocated yet (first loop of the level): armed in line */
+  if (dom->no_fused_loop || !skew_loop_supported (dom, level, nrelax, true))
+    return GFSHIP_OK;
+  if (patch_level (dom, level) && !dom->no_kernel_arming)
+    return GFSHIP_OK;           /* the loop kernels arm the other set themselves (opt-in) */
+  const SetGeometry G = skew_set_geometry (dom, level, S, nrelax);
+  const int set = S->cur_set;
+  if (S->armed[set] >= G.need)
+    return GFSHIP_OK;
+  if (!S->arm_ev)
+    GFSHIP_HIP (hipEventCreateWithFlags (&S->arm_ev, hipEventDisableTiming));
+  u64 * const base = (u64 *) S->hbf + (size_t) set*G.set_words;
+  GFSHIP_HIP (hipEventRecord (dom->side_fork, dom->stream));
+  GFSHIP_HIP (hipStreamWaitEvent (dom->side_stream, dom->side_fork, 0));
+  GFSHIP_HIP (hipMemsetAsync (base, 0xFF, G.need*sizeof (u64), dom->side_stream));
+  GFSHIP_HIP (hipEventRecord (S->arm_ev, dom->side_stream));
+  S->armed[set] = G.need;
+  S->arm_wait = true;
+  return GFSHIP_OK;
+}
+
 // nrelax >= 2: the fused loop of a periodic level.  nrelax == 1: one sweep of any level the
 // pipelined sweep runs on (any sides; the BC kernel is applied around it by the caller, so the
 // cells next to the box sides are mirrored into the natural array).
 int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat, bool has_dia,
-		   unsigned nrelax, float * ms, const Field * ubc)
+		   unsigned nrelax, float * ms, const Field * ubc, const RelaxOp * op)
 {
   const Layout & L = dom->lay[level];
   int ntiles = S->ntj*S->ntj;
-  long hstride = (long) SK_HROWS (L.n)*SK_T;
-  long hb_words = (long) ntiles*hstride;
-  long hb_sweep = 4*hb_words;
+  GFSHIP_CHECK (!op || op->kind == 0 || (op->kind == 1 && has_dia), GFSHIP_EUNSUPPORTED,
+		"the pipelined sweep knows the Poisson and the diffusion cell updates");
   /* 8 words in front of the granules: the ticket counter, armed with them (it then counts from all
      ones: the claims add one).  Two sets of granules used in turn.  With GFSHIP_KERNEL_ARMING=1 the
      2 x 2 loop kernels arm the other set for the next loop of this level themselves, while their
      tiles wait for their first hand-off -- the fill before the launch (148 MB, 37 us at 256^3)
      disappears, but measured on the same box the loop gets slower by about as much (the arming
      stores delay the hand-offs of the pipeline's fill phase): off by default. */
-  /* header: [0] ticket, [1..4] the 8 tickets of the XCD blocks, [8..] the XCD of each tile (32 bits each) */
-  const size_t hdr = 8 + ((size_t) ntiles + 1)/2 + 8;
-  const size_t set_words = (size_t) SK_MAXF*hb_sweep + hdr + (hdr & 1);
+  const SetGeometry G = skew_set_geometry (dom, level, S, nrelax);
+  const long hb_words = G.hb_words, hb_sweep = G.hb_sweep;
+  const size_t hdr = G.hdr, set_words = G.set_words, need = G.need;
   if (!S->hbf) {
     GFSHIP_HIP (hipMalloc ((void **) &S->hbf, 2*set_words*sizeof (u64)));
     S->armed[0] = S->armed[1] = 0;
     S->cur_set = 0;
   }
-  /* a single sweep only uses the two hand-off arrays of its granule set; the snapshots of the last
-     sweep are neither written nor read: its two hand-off arrays end the armed range */
-  const size_t need = hdr + (hdr & 1) + (size_t) (nrelax - 1)*hb_sweep + (size_t) 2*hb_words;
   const int set = S->cur_set;
   u64 * const base = (u64 *) S->hbf + (size_t) set*set_words;
   u64 * const other = (u64 *) S->hbf + (size_t) (set ^ 1)*set_words;
+  if (S->arm_wait) {
+    /* armed ahead on the side stream (skew_arm_ahead): the loop comes after that fill */
+    GFSHIP_HIP (hipStreamWaitEvent (dom->stream, S->arm_ev, 0));
+    S->arm_wait = false;
+  }
   if (S->armed[set] < need)
     GFSHIP_HIP (hipMemsetAsync (base, 0xFF, need*sizeof (u64), dom->stream));
   const bool arms = patch_level (dom, level) && !dom->no_kernel_arming;
@@ -858,6 +912,9 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   A.xticket = (unsigned *) S->ctl + 6;
   A.per_xcd = 0;
   A.near_mode = 0;
+  A.op = op ? op->kind : 0;
+  A.w = op ? op->w : 1.;
+  A.h2 = op ? op->h2 : 1.;
   { const char * e = getenv ("GFSHIP_FAULT_DROP_HANDOFF"); A.fault_tile = e ? atoi (e) : -1; }
   if (patch_level (dom, level)) {
     /* the 2 x 2 kernels, GFSHIP_XCD_SCOPE=1: XCD blocks + narrower-scope stores towards consumers on
@@ -893,12 +950,14 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
     return GFSHIP_OK;
   }
   if (ms) GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
-  if (dom->wave_loop && nrelax >= 2 && !has_dia)     /* one compute wave per tile */
+  if (A.op == 1)                                     /* diffusion_relax */
+    hipLaunchKernelGGL ((relax_skew_loop_kernel<true, 1>), dim3 (ntiles), dim3 (SK_NTHREADS), 0, dom->stream, A);
+  else if (dom->wave_loop && nrelax >= 2 && !has_dia)     /* one compute wave per tile */
     hipLaunchKernelGGL (relax_wave_loop_kernel, dim3 (ntiles), dim3 (WV_NTHREADS), 0, dom->stream, A);
   else if (has_dia)
-    hipLaunchKernelGGL (relax_skew_loop_kernel<true>, dim3 (ntiles), dim3 (SK_NTHREADS), 0, dom->stream, A);
+    hipLaunchKernelGGL ((relax_skew_loop_kernel<true, 0>), dim3 (ntiles), dim3 (SK_NTHREADS), 0, dom->stream, A);
   else
-    hipLaunchKernelGGL (relax_skew_loop_kernel<false>, dim3 (ntiles), dim3 (SK_NTHREADS), 0, dom->stream, A);
+    hipLaunchKernelGGL ((relax_skew_loop_kernel<false, 0>), dim3 (ntiles), dim3 (SK_NTHREADS), 0, dom->stream, A);
   GFSHIP_HIP (hipGetLastError ());
   if (ms) {
     GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));

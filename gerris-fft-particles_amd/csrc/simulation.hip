@@ -402,10 +402,25 @@ int gfship_approximate_projection (gfship_sim * s, gfship_multilevel_params * pa
   return GFSHIP_OK;
 }
 
+// corr_dt != 0 (the loop body of simulation_run): the caller's next operation is
+// gfs_correct_centered_velocities (g, corr_dt) followed by gfs_cell_coarse_init -- where the three
+// components are advected in one pass that pass also applies the correction and fills the level below
+// the leaves of U, V, W (*corrected, *u_coarse set)
+static int centered_velocity_advection (gfship_sim * s, const gfship_field gmac[3], const gfship_field g[3],
+					 double corr_dt, bool * corrected, bool * u_coarse);
+
 int gfship_centered_velocity_advection (gfship_sim * s, const gfship_field gmac[3],
 					const gfship_field g[3])
 {
   GFSHIP_CHECK (s && gmac, GFSHIP_EINVAL, "null argument");
+  return centered_velocity_advection (s, gmac, g, 0., nullptr, nullptr);
+}
+
+static int centered_velocity_advection (gfship_sim * s, const gfship_field gmac[3], const gfship_field g[3],
+					 double corr_dt, bool * corrected, bool * u_coarse)
+{
+  if (corrected) *corrected = false;
+  if (u_coarse) *u_coarse = false;
   if (s->dom->dim == 3 && (godunov_fused_supported (s->dom) || godunov_fused_mpi_supported (s->dom)) &&
       !s->dom->no_fused_godunov3 &&
       s->visc[0] == 0. && s->visc[1] == 0. && s->visc[2] == 0.) {
@@ -424,11 +439,23 @@ int gfship_centered_velocity_advection (gfship_sim * s, const gfship_field gmac[
     ptrs3 (s, s->un, un);
     ptrs3 (s, gmac, gm);
     if (g) ptrs3 (s, g, gc);
+    const bool fuse = corr_dt != 0. && g && corrected && !getenv ("GFSHIP_NO_FUSED_CORRECTION");
+    double * uc[3] = { nullptr, nullptr, nullptr };
+    if (fuse && u_coarse && L >= 1)
+      for (int c = 0; c < 3; c++) {
+	Field * F = get_field (dom, s->u[c]);
+	uc[c] = F->lev[L - 1];
+	F->zero[L - 1] = false;
+      }
     TRY (launch_advect3_fused (dom, v, out, un, gm, g ? gc : nullptr, s->advection_params.dt,
-			       s->advection_params.gradient));
+			       s->advection_params.gradient, fuse ? corr_dt : 0., uc[0] ? uc : nullptr));
     for (int c = 0; c < 3; c++) {
       std::swap (dom->fields[s->u[c]].lev[L], dom->fields[s->adv_tmp3[c]].lev[L]);
       dom->fields[s->u[c]].zero[L] = false;
+    }
+    if (fuse) {
+      *corrected = true;
+      if (u_coarse) *u_coarse = uc[0] != nullptr;
     }
     TRY (bc_leaf_vector (s, s->u));
     return GFSHIP_OK;
@@ -682,9 +709,11 @@ int gfship_sim_step (gfship_sim * s)
     if (r != GFSHIP_OK) return r;
   }
 
-  TRY (gfship_centered_velocity_advection (s, s->gmac, s->i > 0 ? gc : s->gmac));
-  bool u_coarse = false;
-  TRY (correct_centered_velocities (s, s->i > 0 ? gc : s->gmac, - s->advection_params.dt, &u_coarse));
+  bool u_coarse = false, corrected = false;
+  TRY (centered_velocity_advection (s, s->gmac, s->i > 0 ? gc : s->gmac, - s->advection_params.dt,
+				    &corrected, &u_coarse));
+  if (!corrected)
+    TRY (correct_centered_velocities (s, s->i > 0 ? gc : s->gmac, - s->advection_params.dt, &u_coarse));
 
   /* gfs_cell_coarse_init at this point of the loop (src/simulation.c:530-533): the non-leaf
      values are those of the state before the approximate projection, so it cannot be deferred */

@@ -626,8 +626,10 @@ __device__ __forceinline__ FacePair face_values_dir (const Layout & L, const dou
   for (int cc = 0; cc < DIM; cc++)
     if (cc != D) {
       double vtan = use_centered_velocity ? u.p[cc][c] : (un.p[cc][c] + un.p[cc][c - off[cc]])/2.;
-      int nb = vtan > 0. ? c - off[cc] : c + off[cc];
-      double g = v[nb] - 1.*v0;
+      /* both neighbours are loaded and the upwind one selected: no load address depends on a loaded
+	 velocity (two dependent global loads in a row were most of the wait time of the tiled kernels) */
+      const double vm_ = v[c - off[cc]], vp_ = v[c + off[cc]];
+      double g = (vtan > 0. ? vm_ : vp_) - 1.*v0;
       if (vtan > 0.) g = - g;
       tt[cc] = dt*vtan*g*rsize2;
     }
@@ -942,6 +944,50 @@ __device__ __forceinline__ double adv_transverse (const double * __restrict__ v,
   return dt*vtan*g*rsize2;
 }
 
+// the same from the two neighbours along the direction, already loaded: the upwind neighbour is
+// SELECTED, not loaded through an address that depends on the sign of vtan -- in the tiled kernels
+// every load of a cell is then issued up front, independent of the MAC velocities (round 3: the
+// counters of advect3_tiled_kernel showed 59 % of its wave cycles in s_waitcnt behind such chains
+// of two dependent global loads, profiles/r03_pmc_advect3.json)
+__device__ __forceinline__ double adv_transverse_v (double vminus, double vplus, double v0, double vtan,
+						    double dt, double rsize2)
+{
+  double g = (vtan > 0. ? vminus : vplus) - 1.*v0;
+  if (vtan > 0.) g = - g;
+  return dt*vtan*g*rsize2;
+}
+
+// the seven values of the stencil of a cell
+struct Stencil7 { double v0, m[3], p[3]; };
+
+__device__ __forceinline__ Stencil7 load_stencil7 (const double * __restrict__ v, int c, const int off[3])
+{
+  Stencil7 S;
+  S.v0 = v[c];
+#pragma unroll
+  for (int cc = 0; cc < 3; cc++) {
+    S.m[cc] = v[c - off[cc]];
+    S.p[cc] = v[c + off[cc]];
+  }
+  return S;
+}
+
+template <int D, bool VL, bool SRC>
+__device__ __forceinline__ FacePair adv_face_values_v (double v0, double v1, double v2, double unorm,
+						       double ta, double tb, double dt, double gsrc);
+
+// the two face values of direction D of a cell whose stencil is loaded (transverse terms of the other
+// two directions in increasing order of direction)
+template <int D, bool VL, bool SRC>
+__device__ __forceinline__ FacePair adv_face_values_s (const Stencil7 & W, const AdvShared & S, double dt,
+							double rsize2, double gsrc)
+{
+  constexpr int A = D == 0 ? 1 : 0, B = D == 2 ? 1 : 2;
+  const double ta = adv_transverse_v (W.m[A], W.p[A], W.v0, S.vtan[A], dt, rsize2);
+  const double tb = adv_transverse_v (W.m[B], W.p[B], W.v0, S.vtan[B], dt, rsize2);
+  return adv_face_values_v<D, VL, SRC> (W.v0, W.m[D], W.p[D], S.unorm[D], ta, tb, dt, gsrc);
+}
+
 // the two face values of direction D given the transverse terms ta, tb of the other two directions
 // (in increasing order of direction): face_values_dir with CEN = false, VS = false
 template <int D, bool VL, bool SRC>
@@ -950,6 +996,13 @@ __device__ __forceinline__ FacePair adv_face_values (const double * __restrict__
 						     double dt, double gsrc)
 {
   const double v1 = v[c - o], v2 = v[c + o];
+  return adv_face_values_v<D, VL, SRC> (v0, v1, v2, unorm, ta, tb, dt, gsrc);
+}
+
+template <int D, bool VL, bool SRC>
+__device__ __forceinline__ FacePair adv_face_values_v (double v0, double v1, double v2, double unorm,
+						       double ta, double tb, double dt, double gsrc)
+{
   const double g = VL ? van_leer_gradient (v0, v1, v2) : center_gradient (v0, v1, v2);
   const double vl = v0 + GMIN ((1. - unorm)/2., 0.5)*g;
   const double vr = v0 + GMAX ((- 1. - unorm)/2., -0.5)*g;
@@ -1036,16 +1089,30 @@ boundary_face_values_kernel (Layout L, CPtr3 v, CPtr3 un, double dt, Visc3 visc,
   }
 }
 
-// WPE: waves per SIMD the register allocation is held to (4 = 128 VGPRs = two tiles per CU: the
-// variants that would take a few more are held to it; 1 = no constraint)
-template <bool VL, bool MPI, bool SRC, int WPE>
+// WPE: waves per SIMD the register allocation is held to (1 = no constraint)
+// CORR: gfs_correct_centered_velocities (src/timestep.c:498-530) with the same gradient and - dt, the
+// reference's next operation on U, V, W in simulation_run (src/simulation.c:519-525), applied to the
+// value before it is stored -- u = (v + fluxes - g dt) - g (- dt), the two roundings of the two
+// passes -- and, with uc, the first level of gfs_cell_coarse_init of the corrected velocities
+// (correct_centered_coarse_kernel's expressions; a tile holds whole groups of eight children).  The
+// BC application between the two operations of the reference writes ghost cells only, which the one
+// after the correction rewrites.
+// LDS: 49.9 KB per tile (the x halos in arrays of their own size): three tiles per CU instead of two.
+struct AdvCorr { double dt; double * uc[3]; Layout Lc; };
+#ifndef ADV3_WPE
+#define ADV3_WPE 4     /* two tiles of 512 threads per CU: 4 waves per SIMD, 128 VGPRs (80 for three tiles spills) */
+#endif
+
+template <bool VL, bool MPI, bool SRC, int WPE, bool CORR>
 __global__ void __launch_bounds__(GN, WPE)
 advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt, GhostFv G,
-		      Visc3 src3)
+		      Visc3 src3, AdvCorr K)
 {
-  // R: right face values, then (after they have been read) the fluxes of the + faces
+  // R: right face values, then (after they have been read) the fluxes of the + faces, then (CORR)
+  // the new values for the coarse cells
   __shared__ double R[3][3][GN];
-  __shared__ double hm[3][3][GX*GZ], hp[3][3][GX*GZ];   // l of the cell before / r of the cell after the tile
+  // l of the cell before / r of the cell after the tile: y and z halos, x halos
+  __shared__ double hm[3][2][GX*GZ], hp[3][2][GX*GZ], hmx[3][GY*GZ], hpx[3][GY*GZ];
   const TileIdx T;
   const int n = L.n;
   const double rn = (double) n, rsize2 = (double) n/2.;
@@ -1054,20 +1121,17 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
   const int own = T.own ();
   double v0[3], fl[3][3], fr[3][3];
   {
+    // no load of the cell depends on the MAC velocities: the upwind neighbours are selected
     const AdvShared S = adv_shared (L, un, c, dt);
 #pragma unroll
     for (int q = 0; q < 3; q++) {
-      const double * vq = v.p[q];
-      v0[q] = vq[c];
-      double t[3];
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++)
-	t[cc] = adv_transverse (vq, c, off[cc], v0[q], S.vtan[cc], dt, rsize2);
-      FacePair f = adv_face_values<0, VL, SRC> (vq, c, off[0], v0[q], S.unorm[0], t[1], t[2], dt, src3.g[q]);
+      const Stencil7 W = load_stencil7 (v.p[q], c, off);
+      v0[q] = W.v0;
+      FacePair f = adv_face_values_s<0, VL, SRC> (W, S, dt, rsize2, src3.g[q]);
       fl[q][0] = f.l; fr[q][0] = f.r;
-      f = adv_face_values<1, VL, SRC> (vq, c, off[1], v0[q], S.unorm[1], t[0], t[2], dt, src3.g[q]);
+      f = adv_face_values_s<1, VL, SRC> (W, S, dt, rsize2, src3.g[q]);
       fl[q][1] = f.l; fr[q][1] = f.r;
-      f = adv_face_values<2, VL, SRC> (vq, c, off[2], v0[q], S.unorm[2], t[0], t[1], dt, src3.g[q]);
+      f = adv_face_values_s<2, VL, SRC> (W, S, dt, rsize2, src3.g[q]);
       fl[q][2] = f.l; fr[q][2] = f.r;
 #pragma unroll
       for (int d = 0; d < 3; d++)
@@ -1088,20 +1152,17 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
 	const double * g = gs + face_pos (1, n, hi_, hj, hk);
 #pragma unroll
 	for (int q = 0; q < 3; q++)
-	  if (grp) hp[q][1][idx] = g[q*nf]; else hm[q][1][idx] = g[q*nf];
+	  if (grp) hp[q][0][idx] = g[q*nf]; else hm[q][0][idx] = g[q*nf];
       }
       else {
-      const int ci = image<3> (L, hi_, hj, hk);
-      const AdvShared S = adv_shared (L, un, ci, dt);
+	const int ci = image<3> (L, hi_, hj, hk);
+	const AdvShared S = adv_shared (L, un, ci, dt);
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
-	const double * vq = v.p[q];
-	const double w0 = vq[ci];
-	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
-	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
-	const FacePair f = adv_face_values<1, VL, SRC> (vq, ci, off[1], w0, S.unorm[1], ta, tb, dt, src3.g[q]);
-	if (grp) hp[q][1][idx] = f.r; else hm[q][1][idx] = f.l;
-      }
+	for (int q = 0; q < 3; q++) {
+	  const Stencil7 W = load_stencil7 (v.p[q], ci, off);
+	  const FacePair f = adv_face_values_s<1, VL, SRC> (W, S, dt, rsize2, src3.g[q]);
+	  if (grp) hp[q][0][idx] = f.r; else hm[q][0][idx] = f.l;
+	}
       }
     }
     else {
@@ -1111,20 +1172,17 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
 	const double * g = gs + face_pos (2, n, hi_, hj, hk);
 #pragma unroll
 	for (int q = 0; q < 3; q++)
-	  if (grp == 3) hp[q][2][idx] = g[q*nf]; else hm[q][2][idx] = g[q*nf];
+	  if (grp == 3) hp[q][1][idx] = g[q*nf]; else hm[q][1][idx] = g[q*nf];
       }
       else {
-      const int ci = image<3> (L, hi_, hj, hk);
-      const AdvShared S = adv_shared (L, un, ci, dt);
+	const int ci = image<3> (L, hi_, hj, hk);
+	const AdvShared S = adv_shared (L, un, ci, dt);
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
-	const double * vq = v.p[q];
-	const double w0 = vq[ci];
-	const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
-	const double tb = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
-	const FacePair f = adv_face_values<2, VL, SRC> (vq, ci, off[2], w0, S.unorm[2], ta, tb, dt, src3.g[q]);
-	if (grp == 3) hp[q][2][idx] = f.r; else hm[q][2][idx] = f.l;
-      }
+	for (int q = 0; q < 3; q++) {
+	  const Stencil7 W = load_stencil7 (v.p[q], ci, off);
+	  const FacePair f = adv_face_values_s<2, VL, SRC> (W, S, dt, rsize2, src3.g[q]);
+	  if (grp == 3) hp[q][1][idx] = f.r; else hm[q][1][idx] = f.l;
+	}
       }
     }
     if (h < 2*GY*GZ) {
@@ -1135,22 +1193,32 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
 	const double * g = gs + face_pos (0, n, hi_, hj, hk);
 #pragma unroll
 	for (int q = 0; q < 3; q++)
-	  if (plus) hp[q][0][hh] = g[q*nf]; else hm[q][0][hh] = g[q*nf];
+	  if (plus) hpx[q][hh] = g[q*nf]; else hmx[q][hh] = g[q*nf];
       }
       else {
-      const int ci = image<3> (L, hi_, hj, hk);
-      const AdvShared S = adv_shared (L, un, ci, dt);
+	const int ci = image<3> (L, hi_, hj, hk);
+	const AdvShared S = adv_shared (L, un, ci, dt);
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
-	const double * vq = v.p[q];
-	const double w0 = vq[ci];
-	const double ta = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
-	const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
-	const FacePair f = adv_face_values<0, VL, SRC> (vq, ci, off[0], w0, S.unorm[0], ta, tb, dt, src3.g[q]);
-	if (plus) hp[q][0][hh] = f.r; else hm[q][0][hh] = f.l;
-      }
+	for (int q = 0; q < 3; q++) {
+	  const Stencil7 W = load_stencil7 (v.p[q], ci, off);
+	  const FacePair f = adv_face_values_s<0, VL, SRC> (W, S, dt, rsize2, src3.g[q]);
+	  if (plus) hpx[q][hh] = f.r; else hmx[q][hh] = f.l;
+	}
       }
     }
+  }
+  // what the flux phase reads from memory, issued before the barrier
+  double unf[3], gm0[3], gmp[3][3], gcv[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++)
+    unf[d] = un.p[d][c];
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    gm0[q] = gm.p[q][c];
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+      gmp[q][d] = gm.p[q][c + off[d]];
+    gcv[q] = gc.p[q] ? gc.p[q][c] : 0.;
   }
   __syncthreads ();
   const int t3[3] = { T.tx, T.ty, T.tz }, g3[3] = { GX, GY, GZ };
@@ -1160,10 +1228,11 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
   // src/advection.c:398-435): flux = 1.*un*dt/h; flux *= upwinded value - interpolated g*dt/2.
   double Fp[3][3], rnb[3][3];
 #pragma unroll
-  for (int d = 0; d < 3; d++)
-#pragma unroll
-    for (int q = 0; q < 3; q++)
-      rnb[q][d] = t3[d] + 1 < g3[d] ? R[q][d][own + so[d]] : hp[q][d][hi[d]];
+  for (int q = 0; q < 3; q++) {
+    rnb[q][0] = t3[0] + 1 < g3[0] ? R[q][0][own + so[0]] : hpx[q][hi[0]];
+    rnb[q][1] = t3[1] + 1 < g3[1] ? R[q][1][own + so[1]] : hp[q][0][hi[1]];
+    rnb[q][2] = t3[2] + 1 < g3[2] ? R[q][2][own + so[2]] : hp[q][1][hi[2]];
+  }
   __syncthreads ();          // every right value has been read: R now takes the fluxes
 #pragma unroll
   for (int d = 0; d < 3; d++) {
@@ -1190,11 +1259,12 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
     }
     else {
       const int a = c - off[d];
-      const double unf = un.p[d][a];
-      const double fu = 1.*unf*dt*rn;
+      const double ua = un.p[d][a];
+      const double fu = 1.*ua*dt*rn;
 #pragma unroll
       for (int q = 0; q < 3; q++) {
-	const double upw = upwinded (unf, hm[q][d][hi[d]], fr[q][d]);
+	const double lm = d == 0 ? hmx[q][hi[0]] : hm[q][d - 1][hi[d]];
+	const double upw = upwinded (ua, lm, fr[q][d]);
 	double f = fu;
 	f *= upw - face_interp (gm.p[q][a], gm.p[q][c])*dt/2.;
 	Fm[q][d] = f;
@@ -1203,8 +1273,9 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
   }
   // the gather in the reference's scatter order (flux_update_kernel)
   const int i = T.i, j = T.j, k = T.k;
-  const unsigned J = n - j, K = n - k;
-  const bool back_first = __ffs (~J) > __ffs (~K);
+  const unsigned J = n - j, K_ = n - k;
+  const bool back_first = __ffs (~J) > __ffs (~K_);
+  double res[3];
 #pragma unroll
   for (int q = 0; q < 3; q++) {
     double acc = 0.;
@@ -1229,14 +1300,43 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
       acc += Fm[q][2];
     double val = v0[q];
     val += acc/1.;
+    const double gcv = gc.p[q] ? gc.p[q][c] : 0.;
     if (gc.p[q])
-      val -= gc.p[q][c]*dt;
+      val -= gcv*dt;
     if (SRC && src3.g[q] != 0.) { /* gfs_domain_variable_centered_sources, src/source.c:62-108 */
       double sum = 0;
       sum += src3.g[q];
       val += dt*sum;
     }
+    if (CORR)          /* correct (src/timestep.c:486-496): u[c] -= g[c]*dt with dt = K.dt */
+      val = val - gcv*K.dt;
     out.p[q][c] = val;
+    res[q] = val;
+  }
+  if (CORR && K.uc[0]) {
+    // gfs_get_from_below_intensive of the corrected velocities (coarse_init_kernel): the eight
+    // children of a coarse cell are cells of this tile; children in child-id order
+    __syncthreads ();        // the fluxes in R have been read
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+      R[q][0][own] = res[q];
+    __syncthreads ();
+    if (threadIdx.x < GN/8) {
+      const int cx = threadIdx.x % (GX/2), cy = (threadIdx.x / (GX/2)) % (GY/2), cz = threadIdx.x / ((GX/2)*(GY/2));
+      const int pi = blockIdx.x*(GX/2) + cx + 1, pj = blockIdx.y*(GY/2) + cy + 1, pk = blockIdx.z*(GZ/2) + cz + 1;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	double val = 0., sa = 0.;
+#pragma unroll
+	for (int id = 0; id < 8; id++) {
+	  // ci = 2 pi - 1 + (id & 1), cj = 2 pj - ((id >> 1) & 1), ck = 2 pk - ((id >> 2) & 1): local indices
+	  const int lx = 2*cx + (id & 1), ly = 2*cy + 1 - ((id >> 1) & 1), lz = 2*cz + 1 - ((id >> 2) & 1);
+	  val += R[q][0][lx + GX*(ly + GY*lz)]*1.;
+	  sa += 1.;
+	}
+	K.uc[q][K.Lc.idx (pi, pj, pk)] = val/sa;
+      }
+    }
   }
 }
 
@@ -1674,7 +1774,7 @@ int launch_advect_fused (gfship_domain * dom, bool velocity, const double * v, d
 // the three velocity components at once (3-D box of periodic / MPI sides, no viscosity)
 int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * const out[3],
 			  double * const un[3], double * const gm[3], double * const gc[3],
-			  double dt, int gradient)
+			  double dt, int gradient, double corr_dt, double * const uc[3])
 {
   const Layout & L = dom->lay[dom->depth];
   dim3 grid (L.n/GX, L.n/GY, L.n/GZ);
@@ -1683,6 +1783,12 @@ int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * con
   GhostFv G;
   for (int d = 0; d < 6; d++) { G.r[d] = nullptr; G.s[d] = nullptr; }
   Visc3 vs = { { 0., 0., 0. }, { dom->src[0], dom->src[1], dom->src[2] } };
+  AdvCorr K;
+  K.dt = corr_dt;
+  for (int c = 0; c < 3; c++) K.uc[c] = uc ? uc[c] : nullptr;
+  K.Lc = dom->lay[dom->depth > 0 ? dom->depth - 1 : 0];
+  const bool corr = corr_dt != 0.;
+  GFSHIP_CHECK (!corr || gc, GFSHIP_EINVAL, "the fused correction needs the centred gradient");
   const bool mpi = dom->has_external;
   if (mpi) {
     int r = ghost_fv (dom, &G);
@@ -1698,17 +1804,20 @@ int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * con
     if ((r = comm_exchange_raw (dom, dom->gfv_send, dom->gfv_recv, (size_t) 3*L.n*L.n))) return r;
     dom->n_fused_mpi++;
   }
-#define AK(VL_, MPI_, SRC_, WPE_) hipLaunchKernelGGL ((advect3_tiled_kernel<VL_, MPI_, SRC_, WPE_>), grid, dim3 (GN), 0, \
-					    dom->stream, L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, G, vs)
+#define AK(VL_, MPI_, SRC_) do { \
+    if (corr) hipLaunchKernelGGL ((advect3_tiled_kernel<VL_, MPI_, SRC_, ADV3_WPE, true>), grid, dim3 (GN), 0, \
+				  dom->stream, L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, G, vs, K); \
+    else hipLaunchKernelGGL ((advect3_tiled_kernel<VL_, MPI_, SRC_, ADV3_WPE, false>), grid, dim3 (GN), 0, \
+			     dom->stream, L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, G, vs, K); } while (0)
   const bool srcs = dom->src[0] != 0. || dom->src[1] != 0. || dom->src[2] != 0.;
   if (srcs) {
-    if (mpi) { if (gradient) AK (true, true, true, 4); else AK (false, true, true, 4); }
-    else if (gradient) AK (true, false, true, 4);
-    else AK (false, false, true, 4);
+    if (mpi) { if (gradient) AK (true, true, true); else AK (false, true, true); }
+    else if (gradient) AK (true, false, true);
+    else AK (false, false, true);
   }
-  else if (mpi) { if (gradient) AK (true, true, false, 4); else AK (false, true, false, 4); }
-  else if (gradient) AK (true, false, false, 4);
-  else AK (false, false, false, 1);
+  else if (mpi) { if (gradient) AK (true, true, false); else AK (false, true, false); }
+  else if (gradient) AK (true, false, false);
+  else AK (false, false, false);
 #undef AK
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;

@@ -19,11 +19,13 @@ def pytest_configure(config):
     # library, the front end and the oracle are there.
     pkg = os.path.join(ROOT, "gerris-fft-particles_amd")
     need = [os.path.join(pkg, "lib", "libgfship.so"), os.path.join(pkg, "bin", "gfship2D"),
-            os.path.join(ROOT, "oracle", "libgfsoracle.so")]
+            os.path.join(ROOT, "oracle", "libgfsoracle.so"),
+            os.path.join(ROOT, "tests", "mock_rccl", "librccl_mock.so")]
     if not all(os.path.exists(f) for f in need):
         import subprocess
         subprocess.check_call(["bash", os.path.join(pkg, "csrc", "build.sh")])
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+        subprocess.check_call(["bash", os.path.join(ROOT, "tests", "mock_rccl", "build.sh")])
 
 
 @pytest.fixture(scope="session")

@@ -88,7 +88,7 @@ def flow(nboxes, level, nsteps, overlap, fast):
     return dict(bad=bad, differ=bool(not np.array_equal(dev[0]["u"], dev[1]["u"])),
                 lattice_cycles=[int(d["counts"][0]) for d in dev],
                 fused_mpi=[int(d["counts"][1]) for d in dev],
-                messages=[int(d["stats"][0]) for d in dev], **mock_counters())
+                sent=[int(d["stats"][0]) for d in dev], **mock_counters())
 
 
 def particles():

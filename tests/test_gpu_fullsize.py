@@ -109,16 +109,69 @@ def test_config_c_256_taylor_green_step_vs_oracle():
     osim.start()
     gs.start()
     _assert_same_state(osim, gs, "start")
+    # config D at its full size: 2e6 tracers on the device (the list bench.py times), and the oracle on
+    # a subset of 2e4 of them with the same ids -- tracers are independent of each other, so the
+    # subset pins the full-size kernel: one event on the start-up field, one on the field after the step
+    npart, stride = 2000000, 100
+    pos, ids = lcg_positions_fast(npart)
+    gpl = gfship.ParticleList(gs, pos, ids)
+    opl = O.Particles(osim, pos[::stride].copy(), ids[::stride].copy())
+
+    def same_tracers(what):
+        op, oi = opl.state()
+        gp, gi = gpl.download()
+        assert len(gi) == gpl.count() and len(np.unique(gi)) == len(gi)
+        order = np.argsort(gi, kind="stable")
+        at = order[np.searchsorted(gi[order], oi)]
+        assert np.array_equal(gi[at], oi), what          # every tracer of the subset is in the device list
+        assert np.array_equal(gp[at], op), (what, np.abs(gp[at] - op).max())
+        # ... and the device dropped exactly the tracers of the subset that the oracle dropped
+        assert np.array_equal(np.isin(ids[::stride], gi), np.isin(ids[::stride], oi)), what
+
+    opl.event()
+    gpl.event()
+    same_tracers("event 0")
     osim.step()
     gs.step()
     _assert_same_state(osim, gs, "step 0")
     _assert_same_un(osim, gs, "step 0")
+    opl.event()
+    gpl.event()
+    same_tracers("event 1")
+    assert gpl.count() > 0.99 * npart
     assert gs.projection_params.niter == osim.projection_params.niter
     assert gs.approx_projection_params.niter == osim.approx_projection_params.niter
     assert gs.projection_params.residual.infty == osim.projection_params.residual.infty
     assert gs.approx_projection_params.residual.infty == \
         osim.approx_projection_params.residual.infty
     assert gs.cfl() == O.lib().go_domain_cfl(osim.ptr)
+    gd.destroy()
+
+
+@pytest.mark.timeout(900)
+def test_viscous_taylor_green_128_pipelined_diffusion_sweeps_vs_oracle():
+    """implicit viscosity in 3-D at a size where the diffusion multigrid (gfs_diffusion_cycle,
+    src/poisson.c:1558-1690) runs its sweeps on the pipelined tile kernels with the diffusion_relax
+    cell update: the ring kernel (2 x 2 lines per lane) at 128^3, the six-wave kernel at 64^3 and
+    32^3, the LDS loop below -- one start-up and one full time step, bit for bit"""
+    level = 7
+    osim = oracle_taylor_green(level)
+    for c in range(3):
+        osim.set_viscosity(c, 2e-3)
+    gd, gs = _device_sim(osim, PERIODIC)
+    for c in range(3):
+        gs.set_viscosity(c, 2e-3)
+    osim.start()
+    gs.start()
+    _assert_same_state(osim, gs, "start")
+    osim.step()
+    gs.step()
+    _assert_same_state(osim, gs, "step 0")
+    for c in range(3):
+        a, b = osim.diffusion_params(c), gs.diffusion_params(c)
+        assert a.niter == b.niter and a.niter >= 1
+        assert a.residual.infty == b.residual.infty
+        assert a.residual_before.infty == b.residual_before.infty
     gd.destroy()
 
 

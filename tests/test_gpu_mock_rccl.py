@@ -34,11 +34,13 @@ def test_lattice_flow_over_the_library_transport_with_distinct_peers(nboxes, lev
     assert out["bad"] == [], out
     assert out["differ"]                       # the boxes hold different parts of the field
     assert out["mismatches"] == 0 and out["timeouts"] == 0
-    assert out["messages"] > 100 and min(out["messages"]) > 50
+    assert out["messages"] > 100 and min(out["sent"]) > 50
     if fast and not overlap:
         # the coarse end of every V-cycle after one all-gather, the tiled Godunov kernels with one
         # message of face states per side
-        assert min(out["lattice_cycles"]) >= 4 and min(out["fused_mpi"]) >= 4
+        assert min(out["lattice_cycles"]) >= 4
+        if level >= 5:       # the tiles of the Godunov kernels are 32 cells long
+            assert min(out["fused_mpi"]) >= 4
     else:
         assert max(out["lattice_cycles"]) == 0
 
