@@ -626,10 +626,8 @@ __device__ __forceinline__ FacePair face_values_dir (const Layout & L, const dou
   for (int cc = 0; cc < DIM; cc++)
     if (cc != D) {
       double vtan = use_centered_velocity ? u.p[cc][c] : (un.p[cc][c] + un.p[cc][c - off[cc]])/2.;
-      /* both neighbours are loaded and the upwind one selected: no load address depends on a loaded
-	 velocity (two dependent global loads in a row were most of the wait time of the tiled kernels) */
-      const double vm_ = v[c - off[cc]], vp_ = v[c + off[cc]];
-      double g = (vtan > 0. ? vm_ : vp_) - 1.*v0;
+      int nb = vtan > 0. ? c - off[cc] : c + off[cc];
+      double g = v[nb] - 1.*v0;
       if (vtan > 0.) g = - g;
       tt[cc] = dt*vtan*g*rsize2;
     }
@@ -1099,6 +1097,9 @@ boundary_face_values_kernel (Layout L, CPtr3 v, CPtr3 un, double dt, Visc3 visc,
 // after the correction rewrites.
 // LDS: 49.9 KB per tile (the x halos in arrays of their own size): three tiles per CU instead of two.
 struct AdvCorr { double dt; double * uc[3]; Layout Lc; };
+#ifndef ADV3_STENCIL
+#define ADV3_STENCIL 0     /* 1: the own cell selects its upwind neighbours from the loaded stencil (measured slower: 1.48 against 1.29 ms) */
+#endif
 #ifndef ADV3_WPE
 #define ADV3_WPE 4     /* two tiles of 512 threads per CU: 4 waves per SIMD, 128 VGPRs (80 for three tiles spills) */
 #endif
@@ -1121,10 +1122,11 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
   const int own = T.own ();
   double v0[3], fl[3][3], fr[3][3];
   {
-    // no load of the cell depends on the MAC velocities: the upwind neighbours are selected
     const AdvShared S = adv_shared (L, un, c, dt);
 #pragma unroll
     for (int q = 0; q < 3; q++) {
+#if ADV3_STENCIL
+      // the six neighbours are needed for the gradients anyway: the upwind ones are selected from them
       const Stencil7 W = load_stencil7 (v.p[q], c, off);
       v0[q] = W.v0;
       FacePair f = adv_face_values_s<0, VL, SRC> (W, S, dt, rsize2, src3.g[q]);
@@ -1133,6 +1135,20 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
       fl[q][1] = f.l; fr[q][1] = f.r;
       f = adv_face_values_s<2, VL, SRC> (W, S, dt, rsize2, src3.g[q]);
       fl[q][2] = f.l; fr[q][2] = f.r;
+#else
+      const double * vq = v.p[q];
+      v0[q] = vq[c];
+      double t[3];
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++)
+	t[cc] = adv_transverse (vq, c, off[cc], v0[q], S.vtan[cc], dt, rsize2);
+      FacePair f = adv_face_values<0, VL, SRC> (vq, c, off[0], v0[q], S.unorm[0], t[1], t[2], dt, src3.g[q]);
+      fl[q][0] = f.l; fr[q][0] = f.r;
+      f = adv_face_values<1, VL, SRC> (vq, c, off[1], v0[q], S.unorm[1], t[0], t[2], dt, src3.g[q]);
+      fl[q][1] = f.l; fr[q][1] = f.r;
+      f = adv_face_values<2, VL, SRC> (vq, c, off[2], v0[q], S.unorm[2], t[0], t[1], dt, src3.g[q]);
+      fl[q][2] = f.l; fr[q][2] = f.r;
+#endif
 #pragma unroll
       for (int d = 0; d < 3; d++)
 	R[q][d][own] = fr[q][d];
@@ -1159,8 +1175,11 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
 	const AdvShared S = adv_shared (L, un, ci, dt);
 #pragma unroll
 	for (int q = 0; q < 3; q++) {
-	  const Stencil7 W = load_stencil7 (v.p[q], ci, off);
-	  const FacePair f = adv_face_values_s<1, VL, SRC> (W, S, dt, rsize2, src3.g[q]);
+	  const double * vq = v.p[q];
+	  const double w0 = vq[ci];
+	  const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
+	  const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
+	  const FacePair f = adv_face_values<1, VL, SRC> (vq, ci, off[1], w0, S.unorm[1], ta, tb, dt, src3.g[q]);
 	  if (grp) hp[q][0][idx] = f.r; else hm[q][0][idx] = f.l;
 	}
       }
@@ -1179,8 +1198,11 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
 	const AdvShared S = adv_shared (L, un, ci, dt);
 #pragma unroll
 	for (int q = 0; q < 3; q++) {
-	  const Stencil7 W = load_stencil7 (v.p[q], ci, off);
-	  const FacePair f = adv_face_values_s<2, VL, SRC> (W, S, dt, rsize2, src3.g[q]);
+	  const double * vq = v.p[q];
+	  const double w0 = vq[ci];
+	  const double ta = adv_transverse (vq, ci, off[0], w0, S.vtan[0], dt, rsize2);
+	  const double tb = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
+	  const FacePair f = adv_face_values<2, VL, SRC> (vq, ci, off[2], w0, S.unorm[2], ta, tb, dt, src3.g[q]);
 	  if (grp == 3) hp[q][1][idx] = f.r; else hm[q][1][idx] = f.l;
 	}
       }
@@ -1200,8 +1222,11 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
 	const AdvShared S = adv_shared (L, un, ci, dt);
 #pragma unroll
 	for (int q = 0; q < 3; q++) {
-	  const Stencil7 W = load_stencil7 (v.p[q], ci, off);
-	  const FacePair f = adv_face_values_s<0, VL, SRC> (W, S, dt, rsize2, src3.g[q]);
+	  const double * vq = v.p[q];
+	  const double w0 = vq[ci];
+	  const double ta = adv_transverse (vq, ci, off[1], w0, S.vtan[1], dt, rsize2);
+	  const double tb = adv_transverse (vq, ci, off[2], w0, S.vtan[2], dt, rsize2);
+	  const FacePair f = adv_face_values<0, VL, SRC> (vq, ci, off[0], w0, S.unorm[0], ta, tb, dt, src3.g[q]);
 	  if (plus) hpx[q][hh] = f.r; else hmx[q][hh] = f.l;
 	}
       }
@@ -1336,6 +1361,374 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
 	}
 	K.uc[q][K.Lc.idx (pi, pj, pk)] = val/sa;
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The three velocity components advected by a sweep along z (periodic boxes): a workgroup owns a
+// column of SWX x SWY cells and marches over SWZ planes, keeping what the planes share in registers
+// and the neighbours inside a plane in LDS.
+//
+// Why (round 3, profiles/r03_pmc_advect3.json): the 32 x 4 x 4 tiles of advect3_tiled_kernel issue 77
+// global loads per cell (every stencil value of every component through the vector cache, whose 32 KB
+// hold a fraction of the 13 arrays x 34 x 6 x 6 cells of two resident tiles), evaluate 1.06 halo cells
+// per cell and spend 59 % of their wave cycles waiting for memory with the vector ALUs 36 % busy.
+// Here a cell loads its own values once per array (v, un, gm: the plane ahead; gc), its x / y
+// neighbours come from a plane buffer in LDS, its z neighbours are the registers of the planes before
+// and after, the face values of a plane are computed once and the flux through a z face is handed to
+// the next plane in a register; the only cells evaluated twice are the ring around the column:
+// 2 (SWX + SWY) of SWX SWY per plane, by 96 dedicated lanes of the first two waves.
+//
+// Pipeline, plane p = kb .. kb + SWZ + 1 (the planes kb and kb + SWZ + 1 only feed their neighbours):
+//   A (p)      face values fl, fr [component][direction] of every cell of plane p
+//   B (p - 1)  fluxes through the + faces of plane p - 1: x, y from the right states of the neighbours
+//              (LDS), z from fr_z (p) of the same thread
+//   C (p - 1)  the gather in the reference's scatter order, the update, the store
+// Same expressions as advect3_tiled_kernel (adv_face_values_v, adv_transverse_v, upwinded,
+// face_interp): bit-identical results (tests/test_gpu_timestep.py).
+// ---------------------------------------------------------------------------------------------
+#define SWX 32
+#define SWY 16
+#define SWN (SWX*SWY)
+#ifndef SWZ
+#define SWZ 32
+#endif
+
+struct SweepFv { double l[3], r[3]; };
+
+// the six face values of a cell from its stencil and the MAC velocities around it
+template <bool VL, bool SRC>
+__device__ __forceinline__ SweepFv sweep_face_values (const Stencil7 & W, const AdvShared & S, double dt,
+						      double rsize2, double gsrc)
+{
+  SweepFv F;
+  FacePair f = adv_face_values_s<0, VL, SRC> (W, S, dt, rsize2, gsrc);
+  F.l[0] = f.l; F.r[0] = f.r;
+  f = adv_face_values_s<1, VL, SRC> (W, S, dt, rsize2, gsrc);
+  F.l[1] = f.l; F.r[1] = f.r;
+  f = adv_face_values_s<2, VL, SRC> (W, S, dt, rsize2, gsrc);
+  F.l[2] = f.l; F.r[2] = f.r;
+  return F;
+}
+
+__device__ __forceinline__ AdvShared adv_shared_v (const double a[3], const double b[3], double dt, double rsize2)
+{
+  AdvShared S;
+#pragma unroll
+  for (int cc = 0; cc < 3; cc++) {
+    S.vtan[cc] = (a[cc] + b[cc])/2.;
+    S.unorm[cc] = dt*(a[cc] + b[cc])*rsize2;
+  }
+  return S;
+}
+
+// LDS of a workgroup
+struct SweepLds {
+  double V[3][SWY + 2][SWX + 2];          // plane p of the three components, with the ring
+  double UNx[SWY][SWX + 1], UNy[SWY + 1][SWX];   // un_x with the column before, un_y with the row before
+  double FRx[3][SWY][SWX + 1], FRy[3][SWY + 1][SWX];   // right states of plane p - 1 (+ ring after)
+  double FPx[3][SWY][SWX + 1], FPy[3][SWY + 1][SWX];   // + face fluxes of plane p - 1 (+ ring before)
+};
+
+#define SW_RING 128      /* two more waves: the ring cells (96 lanes) */
+
+// The ring waves: lane rid = 0..31 the row before the column (y -), 32..63 the row after (y +), 64..79
+// the column before (x -), 80..95 the column after (x +); one cell each, its face values in ONE
+// direction.  The - lanes also compute the flux through the face between their cell and the column.
+// Same loop and the same two barriers per plane as the compute waves.
+template <bool VL, bool SRC>
+__device__ __forceinline__ void sweep_ring_path (SweepLds & S_, const Layout & L, const CPtr3 & v, const CPtr3 & un,
+						 const CPtr3 & gm, double dt, const Visc3 & src3, int rid)
+{
+  const int n = L.n;
+  const double rn = (double) n, rsize2 = (double) n/2.;
+  const int sy = (int) L.sy, sz = (int) L.sz;
+  const int kb = blockIdx.z*SWZ;
+  auto plane = [n, sz] (int k) { return (k < 1 ? k + n : k > n ? k - n : k)*sz; };
+  int role = -1, hd = 0, hcol = 0, hslot = 0;
+  if (rid < 2*SWX) {
+    role = rid < SWX ? 0 : 1; hd = 1; hslot = rid % SWX;
+    int hj = blockIdx.y*SWY + (role ? SWY + 1 : 0);
+    hj = hj < 1 ? hj + n : hj > n ? hj - n : hj;
+    hcol = (int) L.idx (blockIdx.x*SWX + hslot + 1, hj, 0);
+  }
+  else if (rid < 2*SWX + 2*SWY) {
+    role = rid < 2*SWX + SWY ? 2 : 3; hd = 0; hslot = (rid - 2*SWX) % SWY;
+    int hi_ = blockIdx.x*SWX + (role == 3 ? SWX + 1 : 0);
+    hi_ = hi_ < 1 ? hi_ + n : hi_ > n ? hi_ - n : hi_;
+    hcol = (int) L.idx (hi_, blockIdx.y*SWY + hslot + 1, 0);
+  }
+  const bool ring = role >= 0, ring_minus = role == 0 || role == 2;
+  const int hoff = hd == 0 ? 1 : sy;                 // towards the column
+  const int ry = role == 0 ? 0 : role == 1 ? SWY + 1 : hslot + 1;
+  const int rx = role == 2 ? 0 : role == 3 ? SWX + 1 : hslot + 1;
+  double hvm[3], hv0[3] = { 0., 0., 0. }, hvp[3] = { 0., 0., 0. }, hvn[3] = { 0., 0., 0. };
+  double hunb = 0., hunzb = 0., hlo[3] = { 0., 0., 0. }, hgmo[3] = { 0., 0., 0. };
+  if (ring) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      hv0[q] = v.p[q][hcol + plane (kb - 1)];
+      hvp[q] = v.p[q][hcol + plane (kb)];
+      hvn[q] = v.p[q][hcol + plane (kb + 1)];
+    }
+    hunzb = un.p[2][hcol + plane (kb - 1)];
+  }
+  for (int p = kb; p <= kb + SWZ + 1; p++) {
+    const int zp = plane (p);
+    Stencil7 HW[3];
+    double hua[3] = { 0., 0., 0. }, hub[3] = { 0., 0., 0. };
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      hvm[q] = hv0[q]; hv0[q] = hvp[q]; hvp[q] = hvn[q];
+      HW[q].v0 = hv0[q];
+      HW[q].m[0] = HW[q].p[0] = HW[q].m[1] = HW[q].p[1] = 0.;
+      HW[q].m[2] = hvm[q]; HW[q].p[2] = hvp[q];
+    }
+    if (ring) {
+      const int hc = hcol + zp;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	hvn[q] = v.p[q][hcol + plane (p + 2)];
+	HW[q].m[0] = v.p[q][hc - 1];  HW[q].p[0] = v.p[q][hc + 1];
+	HW[q].m[1] = v.p[q][hc - sy]; HW[q].p[1] = v.p[q][hc + sy];
+      }
+      hua[0] = un.p[0][hc]; hub[0] = un.p[0][hc - 1];
+      hua[1] = un.p[1][hc]; hub[1] = un.p[1][hc - sy];
+      hua[2] = un.p[2][hc]; hub[2] = hunzb;
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+	S_.V[q][ry][rx] = hv0[q];
+      if (role == 2) S_.UNx[hslot][0] = hua[0];
+      if (role == 0) S_.UNy[0][hslot] = hua[1];
+    }
+    __syncthreads ();                                // (1)
+    double hl[3] = { 0., 0., 0. }, hr[3] = { 0., 0., 0. };
+    if (ring) {
+      const AdvShared S = adv_shared_v (hua, hub, dt, rsize2);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	const FacePair f = hd == 0 ? adv_face_values_s<0, VL, SRC> (HW[q], S, dt, rsize2, src3.g[q]) :
+	  adv_face_values_s<1, VL, SRC> (HW[q], S, dt, rsize2, src3.g[q]);
+	hl[q] = f.l; hr[q] = f.r;
+      }
+      // the face between the cell and the column, plane p - 1: by the - lanes, which hold the left state
+      // of their cell and read the right state of the cell of the column
+      if (p > kb && ring_minus) {
+	const int ho = hcol + plane (p - 1);
+	const double ua = hunb;
+	const double fu = 1.*ua*dt*rn;
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+	  const double rs = role == 2 ? S_.FRx[q][hslot][0] : S_.FRy[q][0][hslot];
+	  double f = fu;
+	  f *= upwinded (ua, hlo[q], rs) - face_interp (hgmo[q], gm.p[q][ho + hoff])*dt/2.;
+	  if (role == 2) S_.FPx[q][hslot][0] = f; else S_.FPy[q][0][hslot] = f;
+	}
+      }
+    }
+    __syncthreads ();                                // (2)
+    if (ring) {
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	if (role == 3) S_.FRx[q][hslot][SWX] = hr[q];
+	if (role == 1) S_.FRy[q][SWY][hslot] = hr[q];
+	hlo[q] = hl[q];
+	hgmo[q] = gm.p[q][hcol + zp];
+      }
+      hunb = hua[hd];
+      hunzb = hua[2];
+    }
+  }
+}
+
+template <bool VL, bool SRC, bool CORR>
+__global__ void __launch_bounds__(SWN + SW_RING)
+advect3_sweep_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt, Visc3 src3,
+		      AdvCorr K)
+{
+  __shared__ SweepLds S_;
+  const int tid = threadIdx.x;
+  if (tid >= SWN) {
+    sweep_ring_path<VL, SRC> (S_, L, v, un, gm, dt, src3, tid - SWN);
+    return;
+  }
+  const int tx = tid % SWX, ty = tid / SWX;
+  const int n = L.n;
+  const double rn = (double) n, rsize2 = (double) n/2.;
+  const int sy = (int) L.sy, sz = (int) L.sz;
+  const int i = blockIdx.x*SWX + tx + 1, j = blockIdx.y*SWY + ty + 1;
+  const int kb = blockIdx.z*SWZ;                     // output planes kb + 1 .. kb + SWZ
+  const int col = (int) L.idx (i, j, 0);
+  auto plane = [n, sz] (int k) { return (k < 1 ? k + n : k > n ? k - n : k)*sz; };   // periodic image
+
+  // ---- registers of the pipeline
+  double vm[3], v0[3], vp[3], vn[3];                 // planes p - 1, p, p + 1 and the load for p + 2
+  double una[3], unb[3];                             // un (p) of the own cell; un (p - 1) (B of plane p - 1)
+  double flo[3][3];                                  // left states of plane p - 1
+  double fpz[3] = { 0., 0., 0. };                    // fluxes through the z face below plane p - 1
+  double gmo[3];                                     // gm (p - 1) of the own cell
+  double low[3] = { 0., 0., 0. };                    // corrected values of the odd plane (coarse cells)
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    v0[q] = v.p[q][col + plane (kb - 1)];
+    vp[q] = v.p[q][col + plane (kb)];
+    vn[q] = v.p[q][col + plane (kb + 1)];
+    gmo[q] = gm.p[q][col + plane (kb)];       /* the first B is that of plane kb */
+#pragma unroll
+    for (int d = 0; d < 3; d++) flo[q][d] = 0.;
+  }
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    una[d] = un.p[d][col + plane (kb - 1)];
+    unb[d] = 0.;
+  }
+
+  for (int p = kb; p <= kb + SWZ + 1; p++) {
+    const int zp = plane (p);
+    // ---- shift the column registers; the loads of this iteration
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      vm[q] = v0[q]; v0[q] = vp[q]; vp[q] = vn[q];
+      vn[q] = v.p[q][col + plane (p + 2)];
+    }
+    const double unzb = una[2];                      // un_z (p - 1)
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      unb[d] = una[d];
+      una[d] = un.p[d][col + zp];
+    }
+    // ---- the plane into LDS
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+      S_.V[q][ty + 1][tx + 1] = v0[q];
+    S_.UNx[ty][tx + 1] = una[0];
+    S_.UNy[ty + 1][tx] = una[1];
+    __syncthreads ();                                // (1) plane p is there; nothing of FP is read any more
+    // ---- A (p)
+    SweepFv F[3];
+    {
+      const double b[3] = { S_.UNx[ty][tx], S_.UNy[ty][tx], unzb };
+      const AdvShared S = adv_shared_v (una, b, dt, rsize2);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	Stencil7 W;
+	W.v0 = v0[q];
+	W.m[0] = S_.V[q][ty + 1][tx];     W.p[0] = S_.V[q][ty + 1][tx + 2];
+	W.m[1] = S_.V[q][ty][tx + 1];     W.p[1] = S_.V[q][ty + 2][tx + 1];
+	W.m[2] = vm[q];                   W.p[2] = vp[q];
+	F[q] = sweep_face_values<VL, SRC> (W, S, dt, rsize2, src3.g[q]);
+      }
+    }
+    double Fp[3][3];
+    if (p > kb) {
+      // ---- B (o): fluxes through the + faces of plane o = p - 1
+      const int co = col + plane (p - 1);
+      const double fux = 1.*unb[0]*dt*rn, fuy = 1.*unb[1]*dt*rn, fuz = 1.*unb[2]*dt*rn;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	const double g0 = gmo[q];
+	const double gx = gm.p[q][co + 1], gy = gm.p[q][co + sy], gz = gm.p[q][col + zp];
+	double f = fux;
+	f *= upwinded (unb[0], flo[q][0], S_.FRx[q][ty][tx + 1]) - face_interp (g0, gx)*dt/2.;
+	Fp[q][0] = f;
+	f = fuy;
+	f *= upwinded (unb[1], flo[q][1], S_.FRy[q][ty + 1][tx]) - face_interp (g0, gy)*dt/2.;
+	Fp[q][1] = f;
+	f = fuz;
+	f *= upwinded (unb[2], flo[q][2], F[q].r[2]) - face_interp (g0, gz)*dt/2.;
+	Fp[q][2] = f;
+	gmo[q] = gz;
+	S_.FPx[q][ty][tx + 1] = Fp[q][0];
+	S_.FPy[q][ty + 1][tx] = Fp[q][1];
+      }
+    }
+    __syncthreads ();                                // (2) the fluxes of plane p - 1; plane p has been read
+    if (p > kb) {
+      const int o = p - 1, co = col + plane (o);
+      if (p > kb + 1) {
+	// ---- C (o): the gather in the reference's scatter order (flux_update_kernel), the update
+	const int k = o;
+	const unsigned J = n - j, K_ = n - k;
+	const bool back_first = __ffs (~J) > __ffs (~K_);
+	double res[3];
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+	  const double Fmx = S_.FPx[q][ty][tx], Fmy = S_.FPy[q][ty][tx], Fmz = fpz[q];
+	  double acc = 0.;
+	  if (i > 1)
+	    acc += Fmx;
+	  acc -= Fp[q][0];
+	  acc -= Fp[q][1];
+	  acc -= Fp[q][2];
+	  if (back_first) {
+	    if (k > 1) acc += Fmz;
+	    if (j > 1) acc += Fmy;
+	  }
+	  else {
+	    if (j > 1) acc += Fmy;
+	    if (k > 1) acc += Fmz;
+	  }
+	  if (i == 1)
+	    acc += Fmx;
+	  if (j == 1)
+	    acc += Fmy;
+	  if (k == 1)
+	    acc += Fmz;
+	  double val = vm[q];
+	  val += acc/1.;
+	  const double gcv = gc.p[q] ? gc.p[q][co] : 0.;
+	  if (gc.p[q])
+	    val -= gcv*dt;
+	  if (SRC && src3.g[q] != 0.) { /* gfs_domain_variable_centered_sources, src/source.c:62-108 */
+	    double sum = 0;
+	    sum += src3.g[q];
+	    val += dt*sum;
+	  }
+	  if (CORR)          /* correct (src/timestep.c:486-496): u[c] -= g[c]*dt with dt = K.dt */
+	    val = val - gcv*K.dt;
+	  out.p[q][co] = val;
+	  res[q] = val;
+	}
+	if (CORR && K.uc[0]) {
+	  // gfs_get_from_below_intensive of the corrected velocities (coarse_init_kernel): the children
+	  // of a coarse cell are 2 x 2 cells of this plane (k even: child ids 0-3) and of the plane
+	  // before (k odd, ids 4-7), gathered from the lanes of the wave (two rows of the column: the
+	  // first 32 lanes the lower j)
+	  if (k & 1) {
+#pragma unroll
+	    for (int q = 0; q < 3; q++) low[q] = res[q];
+	  }
+	  else {
+	    const int lane = tid & 63, lx = lane & 31;
+	    const bool head = !(lane & 32) && !(lx & 1);
+	    // id: bit 0 -> + x, bit 1 -> the lower j, (bit 2 -> the lower k: the plane before)
+	    const int src[4] = { lx + 32, lx + 33, lx, lx + 1 };
+#pragma unroll
+	    for (int q = 0; q < 3; q++) {
+	      double val = 0., sa = 0.;
+#pragma unroll
+	      for (int id = 0; id < 4; id++) { val += __shfl (res[q], src[id], 64)*1.; sa += 1.; }
+#pragma unroll
+	      for (int id = 0; id < 4; id++) { val += __shfl (low[q], src[id], 64)*1.; sa += 1.; }
+	      if (head)
+		K.uc[q][K.Lc.idx ((i + 1)/2, (j + 1)/2, k/2)] = val/sa;
+	    }
+	  }
+	}
+      }
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+	fpz[q] = Fp[q][2];
+    }
+    // ---- the states of plane p for the next iteration
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+#pragma unroll
+      for (int d = 0; d < 3; d++)
+	flo[q][d] = F[q].l[d];
+      S_.FRx[q][ty][tx] = F[q].r[0];
+      S_.FRy[q][ty][tx] = F[q].r[1];
     }
   }
 }
@@ -1803,6 +2196,22 @@ int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * con
     GFSHIP_HIP (hipGetLastError ());
     if ((r = comm_exchange_raw (dom, dom->gfv_send, dom->gfv_recv, (size_t) 3*L.n*L.n))) return r;
     dom->n_fused_mpi++;
+  }
+  const bool srcs0 = dom->src[0] != 0. || dom->src[1] != 0. || dom->src[2] != 0.;
+  static const bool sweep_ok = getenv ("GFSHIP_NO_ADVECT_SWEEP") == nullptr;
+  if (!mpi && sweep_ok && L.n % SWX == 0 && L.n % SWY == 0 && L.n % SWZ == 0) {
+    /* periodic box: the sweep along z (advect3_sweep_kernel) */
+    const dim3 sgrid (L.n/SWX, L.n/SWY, L.n/SWZ);
+#define SK3(VL_, SRC_) do { \
+      if (corr) hipLaunchKernelGGL ((advect3_sweep_kernel<VL_, SRC_, true>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
+				    L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K); \
+      else hipLaunchKernelGGL ((advect3_sweep_kernel<VL_, SRC_, false>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
+			       L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K); } while (0)
+    if (gradient) { if (srcs0) SK3 (true, true); else SK3 (true, false); }
+    else          { if (srcs0) SK3 (false, true); else SK3 (false, false); }
+#undef SK3
+    GFSHIP_HIP (hipGetLastError ());
+    return GFSHIP_OK;
   }
 #define AK(VL_, MPI_, SRC_) do { \
     if (corr) hipLaunchKernelGGL ((advect3_tiled_kernel<VL_, MPI_, SRC_, ADV3_WPE, true>), grid, dim3 (GN), 0, \
