@@ -28,7 +28,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 RELAX_BYTES_PER_CELL = 24.0    # read u, read rhs, write u
-PMC_SUMMARY = "r02_pmc_relax_loop_256.json"
+PMC_SUMMARY = "r03_pmc_relax_loop_256.json"
 
 
 def taylor_green(n):
@@ -165,9 +165,14 @@ def measure_roofline(dom, args, n):
                               % (nrelax, ", one pipelined launch" if fused else
                                  ", one launch per sweep", args.level, n),
                     "ms_per_launch": ms_loop if fused else ms_loop / nrelax,
-                    # the same loop as a V-cycle pays for it: BC kernel + copy into the skewed layout +
-                    # arming of the hand-off granules + the sweeps + ghost planes + copy back
+                    # the same loop with everything poisson_cycle runs on this level between the loop
+                    # of the level below and the corrected solution: prolongation straight into the
+                    # layout of the loop + BC kernel + the sweeps + ghost planes + the way out of the
+                    # layout with the correction u += dp in it (the granules are armed on a side stream
+                    # beside the coarser levels of the cycle, the rhs arrives with the restriction)
                     "inclusive": {"ms_per_loop": ms_incl,
+                                  "what": "get_from_above into the layout + BC + %d sweeps + ghost "
+                                          "planes + correct out of the layout" % nrelax,
                                   "achieved": bytes_loop / (ms_incl * 1e-3) / 1e9,
                                   "frac": bytes_loop / (ms_incl * 1e-3) / 1e9 / HBM_PEAK_GBS},
                     "ms_per_sweep_in_loop": ms_loop / nrelax,

@@ -273,8 +273,12 @@ int launch_project_correct (gfship_domain * dom, const double * p, double * cons
 int launch_cfl_from_max (gfship_domain * dom, double * cfl2);
 int launch_face_interp_div (gfship_domain * dom, double * const u[3], double * const un[3],
 			    double * div, double dt);
+// div != nullptr: the caller's next operation is the MAC projection with time step div_dt; where the
+// predictor runs as the sweep along z it also leaves the scaled divergence of the new face velocities
+// in div (*div_done set): mac_projection then skips its divergence pass
 int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt, int gradient,
-			     const double visc[3], double * const un[3]);
+			     const double visc[3], double * const un[3], double * div = nullptr,
+			     double div_dt = 0., bool * div_done = nullptr);
 // corr_dt != 0: gfs_correct_centered_velocities with gc and corr_dt applied in the same pass, and with uc
 // the level below the leaves of the corrected velocities (gfs_cell_coarse_init's first level)
 int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * const out[3],

@@ -626,7 +626,15 @@ int skew_time_sweeps (gfship_domain * dom, int level, Field * u, const double * 
 }
 
 // time `reps` relax loops (nrelax sweeps, homogeneous BC of u itself between them): the sweep
-// kernels alone
+// kernels alone (ms_per_loop), and -- ms_inclusive -- everything the V-cycle runs on this level between
+// the relax loop of the level below and the corrected solution, as poisson_cycle runs it: the
+// prolongation of the coarser level straight into the layout of the loop (get_from_above,
+// patch_prolong_kernel; the plain copy on the levels of the six-wave kernel), the BC kernel, the
+// sweeps, the ghost planes, and the way out of the layout with the correction `u += dp' in it
+// (patch_unpack_kernel with add).  The granules are armed before the timed region: in a V-cycle
+// that fill runs on the side stream beside the relax loops of the coarser levels (skew_arm_ahead).
+// The right-hand side is put into the layout once, outside the timed region (in a V-cycle: by the
+// restriction of the residual on the way down, patch_restrict_pack).
 int skew_time_loop (gfship_domain * dom, int level, Field * u, const double * rhs,
 		    const double * dia, bool dia_zero, unsigned nrelax, int reps,
 		    double * ms_per_loop, int * fused, double * ms_inclusive)
@@ -639,40 +647,61 @@ int skew_time_loop (gfship_domain * dom, int level, Field * u, const double * rh
   *fused = fuse;
   double total = 0., total_incl = 0.;
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  double * target = nullptr;          /* the solution the correction is added to */
+  const bool vcycle_like = ms_inclusive && fuse && level >= 1 && patch_level (dom, level);
   if (ms_inclusive) {
     GFSHIP_HIP (hipEventCreate (&e0));
     GFSHIP_HIP (hipEventCreate (&e1));
   }
-  for (int q = -1; q < reps; q++) {       /* q = -1: warm-up */
-    /* inclusive: everything a relax loop of the V-cycle costs on this level -- the BC kernel, the
-       copy into the skewed layout, arming the granules, the sweeps, the ghost planes, the copy back */
-    if (e0) GFSHIP_HIP (hipEventRecord (e0, dom->stream));
-    if ((r = launch_bc (dom, u, u, level, 1))) return r;
+  if (vcycle_like) {
+    GFSHIP_HIP (hipMalloc ((void **) &target, dom->lay[level].total*sizeof (double)));
+    GFSHIP_HIP (hipMemsetAsync (target, 0, dom->lay[level].total*sizeof (double), dom->stream));
+    /* the rhs (dia) once; u comes from the coarser level in every repetition */
     if ((r = skew_pack (dom, level, S, un, rhs, dia_zero ? nullptr : dia))) return r;
+  }
+  for (int q = -1; q < reps; q++) {       /* q = -1: warm-up */
     float ms = 0.f;
-    if (fuse) {
-      if ((r = skew_loop_run (dom, level, S, un, !dia_zero, nrelax, &ms, u))) return r;
-    }
-    else
-      for (unsigned w = 0; w < nrelax; w++) {
-	float m1 = 0.f;
-	if (!dom->skew_old) {
-	  if ((r = skew_loop_run (dom, level, S, un, !dia_zero, 1, &m1))) return r;
-	}
-	else {
-	  GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
-	  if (S->ntj > 1)
-	    GFSHIP_HIP (hipMemsetAsync (S->hb, 0xFF, 2*S->hb_words*sizeof (u64), dom->stream));
-	  GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
-	  if ((r = skew_launch (dom, level, S, un, !dia_zero))) return r;
-	  GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));
-	  GFSHIP_HIP (hipEventSynchronize (dom->ev1));
-	  GFSHIP_HIP (hipEventElapsedTime (&m1, dom->ev0, dom->ev1));
-	}
-	ms += m1;
-	if (w + 1 < nrelax && (r = launch_bc (dom, u, u, level, 1))) return r;
+    if (vcycle_like) {
+      /* armed ahead, outside the timed region */
+      if (S->hbf) {
+        if ((r = skew_arm_ahead (dom, level, nrelax))) return r;
+        GFSHIP_HIP (hipStreamSynchronize (dom->side_stream));
       }
-    if ((r = skew_unpack (dom, level, S, un))) return r;
+      GFSHIP_HIP (hipEventRecord (e0, dom->stream));
+      if ((r = skew_pack (dom, level, S, un, nullptr, nullptr, u->lev[level - 1]))) return r;
+      if ((r = launch_bc (dom, u, u, level, 1))) return r;
+      if ((r = skew_loop_run (dom, level, S, un, !dia_zero, nrelax, &ms, u))) return r;
+      if ((r = skew_unpack (dom, level, S, un, target))) return r;
+    }
+    else {
+      /* levels / modes without the fused path: BC kernel, copy in, sweeps, copy out */
+      if (e0) GFSHIP_HIP (hipEventRecord (e0, dom->stream));
+      if ((r = launch_bc (dom, u, u, level, 1))) return r;
+      if ((r = skew_pack (dom, level, S, un, rhs, dia_zero ? nullptr : dia))) return r;
+      if (fuse) {
+	if ((r = skew_loop_run (dom, level, S, un, !dia_zero, nrelax, &ms, u))) return r;
+      }
+      else
+	for (unsigned w = 0; w < nrelax; w++) {
+	  float m1 = 0.f;
+	  if (!dom->skew_old) {
+	    if ((r = skew_loop_run (dom, level, S, un, !dia_zero, 1, &m1))) return r;
+	  }
+	  else {
+	    GFSHIP_HIP (hipMemsetAsync (S->ctl, 0, sizeof (unsigned), dom->stream));
+	    if (S->ntj > 1)
+	      GFSHIP_HIP (hipMemsetAsync (S->hb, 0xFF, 2*S->hb_words*sizeof (u64), dom->stream));
+	    GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
+	    if ((r = skew_launch (dom, level, S, un, !dia_zero))) return r;
+	    GFSHIP_HIP (hipEventRecord (dom->ev1, dom->stream));
+	    GFSHIP_HIP (hipEventSynchronize (dom->ev1));
+	    GFSHIP_HIP (hipEventElapsedTime (&m1, dom->ev0, dom->ev1));
+	  }
+	  ms += m1;
+	  if (w + 1 < nrelax && (r = launch_bc (dom, u, u, level, 1))) return r;
+	}
+      if ((r = skew_unpack (dom, level, S, un))) return r;
+    }
     if (e0) {
       float mi = 0.f;
       GFSHIP_HIP (hipEventRecord (e1, dom->stream));
@@ -687,6 +716,10 @@ int skew_time_loop (gfship_domain * dom, int level, Field * u, const double * rh
     *ms_inclusive = total_incl/reps;
     (void) hipEventDestroy (e0);
     (void) hipEventDestroy (e1);
+  }
+  if (target) {
+    GFSHIP_HIP (hipStreamSynchronize (dom->stream));
+    (void) hipFree (target);
   }
   return GFSHIP_OK;
 }

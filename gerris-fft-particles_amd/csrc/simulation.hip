@@ -4,6 +4,7 @@
 #include "gfship_internal.hpp"
 #include <cmath>
 #include <cfloat>
+#include <cstdlib>
 
 using namespace gfship;
 
@@ -25,6 +26,8 @@ struct gfship_sim {
   gfship_multilevel_params diffusion_params[3];
   gfship_field drhs = -1, rhoc = -1;   // temporaries of variable_diffusion
   bool cfl_ready = false;              // maxima for the CFL condition left by the last projection
+  bool div_ready = false;              // div holds the scaled divergence of un for the MAC projection with div_dt
+  double div_dt = 0.;
   gfship_field adv_tmp = -1;           // output of the fused advection kernel (swapped with v)
   gfship_field adv_tmp3[3] = {-1, -1, -1};   // the same for the three-component kernel
   gfship_next_event_fn next_event = nullptr; void * next_event_ctx = nullptr;
@@ -88,8 +91,9 @@ int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, g
      interpolated from the centred ones, gfs_approximate_projection src/timestep.c:572-580) */
   if (approximate)
     TRY (launch_face_interp_div (dom, u, un, leaf (s, s->div), dt));
-  else
+  else if (!(s->div_ready && s->div_dt == dt))       /* left there by the predictor (sweep along z) */
     TRY (launch_divergence (dom, un, leaf (s, s->div), dt));
+  s->div_ready = false;
   TRY (gfship_poisson_solve (dom, par, p, s->div, s->res, s->dia, dt));
   /* gfs_correct_normal_velocities + gfs_scale_gradients, and for the approximate projection
      gfs_correct_centered_velocities (src/timestep.c:486-530), in one pass over p.  The pass
@@ -364,19 +368,37 @@ int gfship_sim_add_tracer (gfship_sim * s)
   return (int) s->tracers.size () - 1;
 }
 
+// mac_dt != 0: the loop body of simulation_run, where the MAC projection with time step mac_dt follows
+static int predicted_face_velocities (gfship_sim * s, double mac_dt);
+
 int gfship_predicted_face_velocities (gfship_sim * s)
 {
   GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  return predicted_face_velocities (s, 0.);
+}
+
+static int predicted_face_velocities (gfship_sim * s, double mac_dt)
+{
   double * fv[6];
   ptrs6 (s, fv);
+  s->div_ready = false;
   /* the reset of every face (gfs_face_reset_normal_velocity) is implied: each component's
      faces are all overwritten below */
   if (godunov_fused_supported (s->dom) || godunov_fused_mpi_supported (s->dom)) {
     double * u[3], * un[3];
     ptrs3 (s, s->u, u);
     ptrs3 (s, s->un, un);
-    return launch_predict_un_fused (s->dom, u, s->advection_params.dt,
-				    s->advection_params.gradient, s->visc, un);
+    const bool want_div = mac_dt != 0. && s->dom->dim == 3 && !getenv ("GFSHIP_NO_FUSED_DIVERGENCE");
+    bool done = false;
+    TRY (launch_predict_un_fused (s->dom, u, s->advection_params.dt,
+				  s->advection_params.gradient, s->visc, un,
+				  want_div ? leaf (s, s->div) : nullptr, mac_dt, &done));
+    if (done) {
+      s->div_ready = true;
+      s->div_dt = mac_dt;
+      s->dom->fields[s->div].zero[s->dom->depth] = false;
+    }
+    return GFSHIP_OK;
   }
   for (int c = 0; c < s->dom->dim; c++) {
     /* only the faces normal to component c are read by gfs_face_advected_normal_velocity */
@@ -697,7 +719,7 @@ int gfship_sim_step (gfship_sim * s)
   gfship_domain * dom = s->dom;
   const gfship_field * gc = s->g;
 
-  TRY (gfship_predicted_face_velocities (s));
+  TRY (predicted_face_velocities (s, s->advection_params.dt/2.));
 
   /* gfs_variables_swap (p, pmac); gfs_mac_projection (...dt/2, p, gmac); swap back
      (src/simulation.c:498-503): the projection runs on Pmac's storage with P's BCs */

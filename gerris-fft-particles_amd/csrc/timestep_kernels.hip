@@ -1389,10 +1389,12 @@ advect3_tiled_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
 // face_interp): bit-identical results (tests/test_gpu_timestep.py).
 // ---------------------------------------------------------------------------------------------
 #define SWX 32
+#ifndef SWY
 #define SWY 16
+#endif
 #define SWN (SWX*SWY)
 #ifndef SWZ
-#define SWZ 32
+#define SWZ 64
 #endif
 
 struct SweepFv { double l[3], r[3]; };
@@ -1730,6 +1732,249 @@ advect3_sweep_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
       S_.FRx[q][ty][tx] = F[q].r[0];
       S_.FRy[q][ty][tx] = F[q].r[1];
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The predictor of the three MAC velocities as the same sweep along z (periodic boxes):
+// gfs_face_advected_normal_velocity (src/advection.c:513-539) with the face values of u[d] along d
+// (use_centered_velocity = TRUE), predict_un_tiled_kernel's expressions -- and, with div != nullptr,
+// gfs_normal_divergence + scale_divergence of the MAC projection that follows (divergence_kernel) from
+// the face velocities while they are in registers / LDS: the pass over un that reads them back is
+// saved.  Pipeline as in advect3_sweep_kernel: A (p) the left / right states of u[d] along d of
+// plane p; B (p - 1) the face velocities of the + faces of plane p - 1; C (p - 1) the divergence.
+// ---------------------------------------------------------------------------------------------
+struct PredLds {
+  double V[3][SWY + 2][SWX + 2];
+  double FRx[2][SWY][SWX + 1], FRy[2][SWY + 1][SWX];     // right states of u_x along x, u_y along y, by parity
+  double UOx[SWY][SWX + 1], UOy[SWY + 1][SWX];           // face velocities of plane p - 1 (+ ring before)
+};
+
+// face values of v = u[D] along D in a cell whose stencil W of u[D] and centred velocities uc are
+// loaded: face_values_dir<3, D, true, VL, VS>
+template <int D, bool VL, bool VS>
+__device__ __forceinline__ FacePair cen_face_values_s (const Stencil7 & W, const double uc[3], double dt,
+						       int n, double visc, double gsrc)
+{
+  const double rsize = (double) n, rsize2 = (double) n/2.;
+  constexpr int A = D == 0 ? 1 : 0, B = D == 2 ? 1 : 2;
+  const double ta = adv_transverse_v (W.m[A], W.p[A], W.v0, uc[A], dt, rsize2);
+  const double tb = adv_transverse_v (W.m[B], W.p[B], W.v0, uc[B], dt, rsize2);
+  const double unorm = dt*uc[D]*rsize;
+  const double v0 = W.v0, v1 = W.m[D], v2 = W.p[D];
+  const double g = VL ? van_leer_gradient (v0, v1, v2) : center_gradient (v0, v1, v2);
+  const double vl = v0 + GMIN ((1. - unorm)/2., 0.5)*g;
+  const double vr = v0 + GMAX ((- 1. - unorm)/2., -0.5)*g;
+  double msrc = 0.;
+  if (VS && visc != 0.) {
+    /* source_diffusion_value, src/source.c:1105-1144 */
+    const double rh2 = (double) n*(double) n;
+    double ga = 0., gb = 0.;
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+      ga += visc*1.; gb += visc*W.p[cc];
+      ga += visc*1.; gb += visc*W.m[cc];
+    }
+    msrc = 0. + 1.*(gb - ga*v0)*rh2;
+  }
+  if (VS) msrc += gsrc;
+  const double src = dt*msrc/2.;
+  double dv = ta;
+  dv += tb;
+  FacePair f;
+  f.l = vl + src - dv;
+  f.r = vr + src - dv;
+  return f;
+}
+
+template <bool VL, bool VS>
+__device__ __forceinline__ void pred_ring_path (PredLds & S_, const Layout & L, const CPtr3 & u, double dt,
+						const Visc3 & visc, int rid)
+{
+  const int n = L.n;
+  const int sy = (int) L.sy, sz = (int) L.sz;
+  const int kb = blockIdx.z*SWZ;
+  auto plane = [n, sz] (int k) { return (k < 1 ? k + n : k > n ? k - n : k)*sz; };
+  int role = -1, hd = 0, hcol = 0, hslot = 0;
+  if (rid < 2*SWX) {
+    role = rid < SWX ? 0 : 1; hd = 1; hslot = rid % SWX;
+    int hj = blockIdx.y*SWY + (role ? SWY + 1 : 0);
+    hj = hj < 1 ? hj + n : hj > n ? hj - n : hj;
+    hcol = (int) L.idx (blockIdx.x*SWX + hslot + 1, hj, 0);
+  }
+  else if (rid < 2*SWX + 2*SWY) {
+    role = rid < 2*SWX + SWY ? 2 : 3; hd = 0; hslot = (rid - 2*SWX) % SWY;
+    int hi_ = blockIdx.x*SWX + (role == 3 ? SWX + 1 : 0);
+    hi_ = hi_ < 1 ? hi_ + n : hi_ > n ? hi_ - n : hi_;
+    hcol = (int) L.idx (hi_, blockIdx.y*SWY + hslot + 1, 0);
+  }
+  const bool ring = role >= 0, ring_minus = role == 0 || role == 2;
+  const int hoff = hd == 0 ? 1 : sy;
+  const int ry = role == 0 ? 0 : role == 1 ? SWY + 1 : hslot + 1;
+  const int rx = role == 2 ? 0 : role == 3 ? SWX + 1 : hslot + 1;
+  // the column of the ring cell: the three components (the ring of V), of which u[hd] is advected
+  double hvm[3], hv0[3] = { 0., 0., 0. }, hvp[3] = { 0., 0., 0. }, hvn[3] = { 0., 0., 0. };
+  double hlo = 0., hnb = 0., hnbn = 0.;        // left state of plane p - 1; u[hd] of the column's cell beside, planes p - 1 / p
+  if (ring) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      hv0[q] = u.p[q][hcol + plane (kb - 1)];
+      hvp[q] = u.p[q][hcol + plane (kb)];
+      hvn[q] = u.p[q][hcol + plane (kb + 1)];
+    }
+    hnbn = u.p[hd][hcol + hoff + plane (kb - 1)];
+  }
+  for (int p = kb; p <= kb + SWZ + 1; p++) {
+    const int zp = plane (p);
+    Stencil7 HW;
+    HW.m[0] = HW.p[0] = HW.m[1] = HW.p[1] = 0.;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      hvm[q] = hv0[q]; hv0[q] = hvp[q]; hvp[q] = hvn[q];
+    }
+    HW.v0 = hv0[hd]; HW.m[2] = hvm[hd]; HW.p[2] = hvp[hd];
+    hnb = hnbn;
+    if (ring) {
+      const int hc = hcol + zp;
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+	hvn[q] = u.p[q][hcol + plane (p + 2)];
+      const double * __restrict__ const w = u.p[hd];
+      HW.m[0] = w[hc - 1];  HW.p[0] = w[hc + 1];
+      HW.m[1] = w[hc - sy]; HW.p[1] = w[hc + sy];
+      hnbn = w[hcol + hoff + zp];                 /* plane p: the face of the next iteration */
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+	S_.V[q][ry][rx] = hv0[q];
+    }
+    __syncthreads ();                                // (1)
+    double hl = 0., hr = 0.;
+    if (ring) {
+      const FacePair f = hd == 0 ? cen_face_values_s<0, VL, VS> (HW, hv0, dt, n, visc.d[0], visc.g[0]) :
+	cen_face_values_s<1, VL, VS> (HW, hv0, dt, n, visc.d[1], visc.g[1]);
+      hl = f.l; hr = f.r;
+      if (role == 3) S_.FRx[p & 1][hslot][SWX] = hr;
+      if (role == 1) S_.FRy[p & 1][SWY][hslot] = hr;
+      // the face between the cell and the column, plane p - 1 (for the divergence of the column's cells)
+      if (p > kb && ring_minus) {
+	const double rs = role == 2 ? S_.FRx[(p - 1) & 1][hslot][0] : S_.FRy[(p - 1) & 1][0][hslot];
+	const double s0 = face_interp (hvm[hd], hnb);
+	const double val = upwinded (s0, hlo, rs);
+	if (role == 2) S_.UOx[hslot][0] = val; else S_.UOy[0][hslot] = val;
+      }
+    }
+    __syncthreads ();                                // (2)
+    hlo = hl;
+  }
+}
+
+template <bool VL, bool VS, bool DIV>
+__global__ void __launch_bounds__(SWN + SW_RING)
+predict_un_sweep_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc, double * __restrict__ div,
+			 double div_dt)
+{
+  __shared__ PredLds S_;
+  const int tid = threadIdx.x;
+  if (tid >= SWN) {
+    pred_ring_path<VL, VS> (S_, L, u, dt, visc, tid - SWN);
+    return;
+  }
+  const int tx = tid % SWX, ty = tid / SWX;
+  const int n = L.n;
+  const int sy = (int) L.sy, sz = (int) L.sz;
+  const int i = blockIdx.x*SWX + tx + 1, j = blockIdx.y*SWY + ty + 1;
+  const int kb = blockIdx.z*SWZ;
+  const int col = (int) L.idx (i, j, 0);
+  auto plane = [n, sz] (int k) { return (k < 1 ? k + n : k > n ? k - n : k)*sz; };
+  double vm[3], v0[3], vp[3], vn[3];
+  double flo[3] = { 0., 0., 0. };                    // left states of plane p - 1 (u[d] along d)
+  double uxp = 0., uyp = 0.;                         // u_x (c + 1), u_y (c + sy) of plane p - 1
+  double unzo = 0.;                                  // un_z of the plane before p - 1
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    v0[q] = u.p[q][col + plane (kb - 1)];
+    vp[q] = u.p[q][col + plane (kb)];
+    vn[q] = u.p[q][col + plane (kb + 1)];
+  }
+  for (int p = kb; p <= kb + SWZ + 1; p++) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      vm[q] = v0[q]; v0[q] = vp[q]; vp[q] = vn[q];
+      vn[q] = u.p[q][col + plane (p + 2)];
+      S_.V[q][ty + 1][tx + 1] = v0[q];
+    }
+    __syncthreads ();                                // (1)
+    const int rp = p & 1, ro = rp ^ 1;
+    FacePair F[3];
+    double uxpn, uypn;
+    {
+      Stencil7 W;
+      // u_x along x
+      W.v0 = v0[0];
+      W.m[0] = S_.V[0][ty + 1][tx];  W.p[0] = S_.V[0][ty + 1][tx + 2];
+      W.m[1] = S_.V[0][ty][tx + 1];  W.p[1] = S_.V[0][ty + 2][tx + 1];
+      W.m[2] = vm[0];                W.p[2] = vp[0];
+      uxpn = W.p[0];
+      F[0] = cen_face_values_s<0, VL, VS> (W, v0, dt, n, visc.d[0], visc.g[0]);
+      S_.FRx[rp][ty][tx] = F[0].r;
+      // u_y along y
+      W.v0 = v0[1];
+      W.m[0] = S_.V[1][ty + 1][tx];  W.p[0] = S_.V[1][ty + 1][tx + 2];
+      W.m[1] = S_.V[1][ty][tx + 1];  W.p[1] = S_.V[1][ty + 2][tx + 1];
+      W.m[2] = vm[1];                W.p[2] = vp[1];
+      uypn = W.p[1];
+      F[1] = cen_face_values_s<1, VL, VS> (W, v0, dt, n, visc.d[1], visc.g[1]);
+      S_.FRy[rp][ty][tx] = F[1].r;
+      // u_z along z
+      W.v0 = v0[2];
+      W.m[0] = S_.V[2][ty + 1][tx];  W.p[0] = S_.V[2][ty + 1][tx + 2];
+      W.m[1] = S_.V[2][ty][tx + 1];  W.p[1] = S_.V[2][ty + 2][tx + 1];
+      W.m[2] = vm[2];                W.p[2] = vp[2];
+      F[2] = cen_face_values_s<2, VL, VS> (W, v0, dt, n, visc.d[2], visc.g[2]);
+    }
+    double unv[3] = { 0., 0., 0. };
+    if (p > kb) {
+      // ---- B (o): the face velocities of the + faces of plane o = p - 1
+      const int o = p - 1, co = col + plane (o);
+      unv[0] = upwinded (face_interp (vm[0], uxp), flo[0], S_.FRx[ro][ty][tx + 1]);
+      unv[1] = upwinded (face_interp (vm[1], uyp), flo[1], S_.FRy[ro][ty + 1][tx]);
+      unv[2] = upwinded (face_interp (vm[2], v0[2]), flo[2], F[2].r);
+      if (o >= 1 && o <= n) {
+	un.p[0][co] = unv[0];
+	un.p[1][co] = unv[1];
+	un.p[2][co] = unv[2];
+	// the face on the low side of the box is the periodic image of the one on the high side
+	if (i == n) un.p[0][co - n] = unv[0];
+	if (j == n) un.p[1][co - n*sy] = unv[1];
+	if (o == n) un.p[2][co - n*sz] = unv[2];
+      }
+      if (DIV) {
+	S_.UOx[ty][tx + 1] = unv[0];
+	S_.UOy[ty + 1][tx] = unv[1];
+      }
+    }
+    __syncthreads ();                                // (2)
+    if (p > kb) {
+      if (DIV && p > kb + 1) {
+	// ---- C (o): gfs_normal_divergence + scale_divergence (divergence_kernel)
+	const int co = col + plane (p - 1);
+	const double h = 1./n;
+	double d_ = 0.;
+	d_ += 1.*unv[0]*1.;
+	d_ += -1.*S_.UOx[ty][tx]*1.;
+	d_ += 1.*unv[1]*1.;
+	d_ += -1.*S_.UOy[ty][tx]*1.;
+	d_ += 1.*unv[2]*1.;
+	d_ += -1.*unzo*1.;
+	const double w_ = d_*h;
+	div[co] = w_/div_dt;
+      }
+      unzo = unv[2];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+      flo[d] = F[d].l;
+    uxp = uxpn; uyp = uypn;
   }
 }
 
@@ -2109,7 +2354,8 @@ static int ghost_fv (gfship_domain * dom, GhostFv * G)
 }
 
 int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt, int gradient,
-			     const double visc[3], double * const un[3])
+			     const double visc[3], double * const un[3], double * div, double div_dt,
+			     bool * div_done)
 {
   const Layout & L = dom->lay[dom->depth];
   Visc3 vs;
@@ -2117,6 +2363,24 @@ int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt
   /* VS: the velocity components may have MAC sources (implicit viscosity, GfsSource) */
   const bool anyv = visc[0] != 0. || visc[1] != 0. || visc[2] != 0. ||
     dom->src[0] != 0. || dom->src[1] != 0. || dom->src[2] != 0.;
+  if (div_done) *div_done = false;
+  static const bool sweep_ok = getenv ("GFSHIP_NO_ADVECT_SWEEP") == nullptr;
+  if (!dom->has_external && sweep_ok && L.n % SWX == 0 && L.n % SWY == 0 && L.n % SWZ == 0) {
+    /* periodic box: the sweep along z, with the divergence of the MAC projection that follows */
+    const dim3 sgrid (L.n/SWX, L.n/SWY, L.n/SWZ);
+    const bool dv = div != nullptr && div_dt != 0.;
+#define PS(VL_, VS_) do { \
+      if (dv) hipLaunchKernelGGL ((predict_un_sweep_kernel<VL_, VS_, true>), sgrid, dim3 (SWN + SW_RING), 0, \
+				  dom->stream, L, c3 (u), m3 (un), dt, vs, div, div_dt); \
+      else hipLaunchKernelGGL ((predict_un_sweep_kernel<VL_, VS_, false>), sgrid, dim3 (SWN + SW_RING), 0, \
+			       dom->stream, L, c3 (u), m3 (un), dt, vs, div, div_dt); } while (0)
+    if (gradient) { if (anyv) PS (true, true); else PS (true, false); }
+    else          { if (anyv) PS (false, true); else PS (false, false); }
+#undef PS
+    GFSHIP_HIP (hipGetLastError ());
+    if (div_done) *div_done = dv;
+    return GFSHIP_OK;
+  }
   const dim3 grid (L.n/GX, L.n/GY, L.n/GZ);
   GhostFv G;
   for (int d = 0; d < 6; d++) { G.r[d] = nullptr; G.s[d] = nullptr; }
