@@ -1272,12 +1272,28 @@ residual_kernel (Layout L, const double * __restrict__ u, const double * __restr
   res[c] = rhs[c] - (b - u[c]*a);
 }
 
+template <bool NORM>
+__global__ void residual_norm2_kernel (Layout L, const double * __restrict__ u, const double * __restrict__ rhs,
+				       const double * __restrict__ dia, double * __restrict__ res, double inv,
+				       double weight, double * __restrict__ partial);
+
 int launch_residual (gfship_domain * dom, int level, const double * u, const double * rhs,
 		     const double * dia, double * res)
 {
   const Layout & L = dom->lay[level];
   dim3 grid, block;
   cell_grid (L, &grid, &block);
+  static const bool pairs = getenv ("GFSHIP_RN_SCALAR") == nullptr;
+  if (dom->dim == 3 && L.n >= 64 && pairs) {
+    /* two cells per thread, 16-byte accesses (residual_norm2_kernel without the norm) */
+    const long nitems = (long) L.n*L.n*(L.n/2);
+    long nb = (nitems + 255)/256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL (residual_norm2_kernel<false>, dim3 ((int) nb), dim3 (256), 0, dom->stream, L, u, rhs,
+			dia, res, 1., 1., nullptr);
+    GFSHIP_HIP (hipGetLastError ());
+    return GFSHIP_OK;
+  }
   if (dom->dim == 3)
     hipLaunchKernelGGL (residual_kernel<3>, grid, block, 0, dom->stream, L, u, rhs, dia, res);
   else
@@ -1736,6 +1752,7 @@ residual_norm_kernel (Layout L, const double * __restrict__ u, const double * __
 // two cells instead of 16 and 2 (the 8-byte version moved 3.1 TB/s of its 24 B per cell at 256^3: bound
 // by the number of requests, not by bytes).  Same arithmetic per cell; the sums are accumulated in
 // another order (they are tree-reduced anyway: 1e-12), the maximum is exact.
+template <bool NORM>
 __global__ void __launch_bounds__(256)
 residual_norm2_kernel (Layout L, const double * __restrict__ u, const double * __restrict__ rhs,
 		       const double * __restrict__ dia, double * __restrict__ res, double inv,
@@ -1779,6 +1796,7 @@ residual_norm2_kernel (Layout L, const double * __restrict__ u, const double * _
       out.y = rh.y - (b - uc.y*a);
     }
     *(d2 *) (res + c) = out;
+    if (NORM)
 #pragma unroll
     for (int e = 0; e < 2; e++) {
       const double raw = e ? out.y : out.x;
@@ -1791,6 +1809,7 @@ residual_norm2_kernel (Layout L, const double * __restrict__ u, const double * _
       s4 += raw;
     }
   }
+  if (!NORM) return;
   __shared__ double sh[5][4];
   s0 = wave_sum (s0); s1 = wave_sum (s1); s2 = wave_sum (s2); s3 = wave_max (s3); s4 = wave_sum (s4);
   int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1838,7 +1857,7 @@ int launch_residual_norm (gfship_domain * dom, int level, const double * u, cons
     const long nitems = (long) L.n*L.n*(L.n/2);
     long nb = (nitems + 255)/256;
     nblocks = (int) (nb > rn_blocks ? rn_blocks : nb);
-    hipLaunchKernelGGL (residual_norm2_kernel, dim3 (nblocks), dim3 (256), 0, dom->stream, L, u,
+    hipLaunchKernelGGL (residual_norm2_kernel<true>, dim3 (nblocks), dim3 (256), 0, dom->stream, L, u,
 			rhs, dia_zero ? nullptr : dia, res, 1./scale, weight, partial);
   }
   else if (dom->dim == 3)
