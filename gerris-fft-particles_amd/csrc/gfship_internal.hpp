@@ -271,8 +271,10 @@ bool godunov_fused_mpi_supported (const gfship_domain * dom);
 int launch_project_correct (gfship_domain * dom, const double * p, double * const un[3],
 			    double * const g[3], double * const u[3], double dt, bool want_max);
 int launch_cfl_from_max (gfship_domain * dom, double * cfl2);
-int launch_face_interp_div (gfship_domain * dom, double * const u[3], double * const un[3],
+int launch_face_interp_div (gfship_domain * dom, double * const u[3], double * const un[3] /* or nullptr */,
 			    double * div, double dt);
+int launch_project_correct_lazy (gfship_domain * dom, const double * p, double * const u[3],
+				 double * const g[3], double * const uo[3], double dt);
 // div != nullptr: the caller's next operation is the MAC projection with time step div_dt; where the
 // predictor runs as the sweep along z it also leaves the scaled divergence of the new face velocities
 // in div (*div_done set): mac_projection then skips its divergence pass

@@ -28,6 +28,13 @@ struct gfship_sim {
   bool cfl_ready = false;              // maxima for the CFL condition left by the last projection
   bool div_ready = false;              // div holds the scaled divergence of un for the MAC projection with div_dt
   double div_dt = 0.;
+  // the corrected MAC velocities of the last approximate projection have not been stored (nobody reads
+  // them before the next predictor overwrites them: project_correct_lazy_kernel); materialize_un
+  // rebuilds them from the uncorrected centred velocities (the leaf storage swapped out into adv_tmp3)
+  // and p when somebody asks
+  bool un_lazy = false;
+  double un_lazy_dt = 0.;
+  bool un_handle_given = false;        // the caller holds the field handles of un: no lazy path any more
   gfship_field adv_tmp = -1;           // output of the fused advection kernel (swapped with v)
   gfship_field adv_tmp3[3] = {-1, -1, -1};   // the same for the three-component kernel
   gfship_next_event_fn next_event = nullptr; void * next_event_ctx = nullptr;
@@ -70,10 +77,27 @@ int bc_leaf_vector (gfship_sim * s, const gfship_field v[3])
   return launch_bc_multi (s->dom, V, s->dom->dim, s->dom->depth, 0);
 }
 
+// the MAC velocities the last approximate projection left unstored (gfship_sim.un_lazy):
+// gfs_face_interpolated_normal_velocity of the uncorrected velocities + gfs_correct_normal_velocities,
+// the kernels the unfused path runs (same expressions as the fused ones: same bits)
+int materialize_un (gfship_sim * s)
+{
+  if (!s->un_lazy) return GFSHIP_OK;
+  s->un_lazy = false;
+  double * uold[3], * un[3];
+  ptrs3 (s, s->adv_tmp3, uold);
+  ptrs3 (s, s->un, un);
+  TRY (launch_face_interp_un (s->dom, uold, un));
+  TRY (launch_correct_un (s->dom, leaf (s, s->p), un, s->un_lazy_dt));
+  return GFSHIP_OK;
+}
+
 // mac_projection, src/timestep.c:356-444.  `pdata` supplies the storage of the pressure and
 // `pbc` the boundary conditions (gfs_variables_swap swaps storage only, src/variable.c:234-243).
+// lazy: the approximate projection of the loop body of simulation_run, whose corrected MAC velocities
+// nobody reads (no tracers, no handle given out): they are not stored (see gfship_sim.un_lazy)
 int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, gfship_field p,
-		    const gfship_field g[3], bool approximate = false)
+		    const gfship_field g[3], bool approximate = false, bool lazy = false)
 {
   gfship_domain * dom = s->dom;
   double * un[3], * gp[3], * u[3];
@@ -89,8 +113,17 @@ int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, g
       TRY (gfship_field_fill (dom, s->dia, l, 0.));
   /* MAC divergence, scaled by 1/dt (approximate projection: together with the MAC velocities
      interpolated from the centred ones, gfs_approximate_projection src/timestep.c:572-580) */
+  for (int c = 0; c < dom->dim; c++)
+    if (s->visc[c] != 0. || dom->src[c] != 0.) lazy = false;   /* the CFL needs the full kernel then */
+  if (!approximate || !s->tracers.empty () || s->un_handle_given || dom->has_external || p != s->p ||
+      getenv ("GFSHIP_NO_LAZY_UN"))
+    lazy = false;
+  if (!approximate)
+    TRY (materialize_un (s));          /* un is an input of the MAC projection */
+  else
+    s->un_lazy = false;                /* un is rewritten (or declared unstored) below */
   if (approximate)
-    TRY (launch_face_interp_div (dom, u, un, leaf (s, s->div), dt));
+    TRY (launch_face_interp_div (dom, u, lazy ? nullptr : un, leaf (s, s->div), dt));
   else if (!(s->div_ready && s->div_dt == dt))       /* left there by the predictor (sweep along z) */
     TRY (launch_divergence (dom, un, leaf (s, s->div), dt));
   s->div_ready = false;
@@ -102,7 +135,27 @@ int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, g
   bool want_max = approximate;
   for (int c = 0; c < dom->dim; c++)
     if (s->visc[c] != 0. || dom->src[c] != 0.) want_max = false;   /* the acceleration term needs the full kernel */
-  TRY (launch_project_correct (dom, leaf (s, p), un, gp, approximate ? u : nullptr, dt, want_max));
+  if (lazy) {
+    /* g and the corrected centred velocities (out of place: the faces read uncorrected neighbours), the
+       maxima of |un|, |u| for the CFL condition; the storage of U, V, W is swapped with the scratch */
+    const int L = dom->depth;
+    double * uo[3];
+    for (int c = 0; c < dom->dim; c++) {
+      if (s->adv_tmp3[c] < 0)
+	s->adv_tmp3[c] = gfship_field_alloc (dom, -1);
+      if (s->adv_tmp3[c] < 0) return s->adv_tmp3[c];
+    }
+    ptrs3 (s, s->adv_tmp3, uo);
+    TRY (launch_project_correct_lazy (dom, leaf (s, p), u, gp, uo, dt));
+    for (int c = 0; c < dom->dim; c++) {
+      std::swap (dom->fields[s->u[c]].lev[L], dom->fields[s->adv_tmp3[c]].lev[L]);
+      dom->fields[s->u[c]].zero[L] = false;
+    }
+    s->un_lazy = true;
+    s->un_lazy_dt = dt;
+  }
+  else
+    TRY (launch_project_correct (dom, leaf (s, p), un, gp, approximate ? u : nullptr, dt, want_max));
   s->cfl_ready = want_max;
   TRY (bc_leaf_vector (s, g));
   if (approximate)
@@ -221,6 +274,8 @@ int variable_diffusion (gfship_sim * s, int c, gfship_field rhs)
 
 int advance_tracers (gfship_sim * s, double dt)
 {
+  if (!s->tracers.empty ())
+    TRY (materialize_un (s));
   for (gfship_field t : s->tracers)
     TRY (gfship_tracer_advection (s, t, dt));
   return GFSHIP_OK;
@@ -305,7 +360,10 @@ gfship_field gfship_sim_variable (gfship_sim * s, int which, int c)
   case GFSHIP_VAR_TRACER:
     GFSHIP_CHECK ((size_t) c < s->tracers.size (), GFSHIP_EINVAL, "no tracer %d", c);
     return s->tracers[c];
-  case GFSHIP_VAR_UN: return s->un[c];
+  case GFSHIP_VAR_UN:
+    if (materialize_un (s) != GFSHIP_OK) return GFSHIP_EHIP;
+    s->un_handle_given = true;
+    return s->un[c];
   }
   set_error ("unknown variable kind %d", which);
   return GFSHIP_EINVAL;
@@ -382,6 +440,7 @@ static int predicted_face_velocities (gfship_sim * s, double mac_dt)
   double * fv[6];
   ptrs6 (s, fv);
   s->div_ready = false;
+  s->un_lazy = false;                  /* every face is rewritten below */
   /* the reset of every face (gfs_face_reset_normal_velocity) is implied: each component's
      faces are all overwritten below */
   if (godunov_fused_supported (s->dom) || godunov_fused_mpi_supported (s->dom)) {
@@ -508,6 +567,7 @@ static int centered_velocity_advection (gfship_sim * s, const gfship_field gmac[
 int gfship_tracer_advection (gfship_sim * s, gfship_field t, double dt)
 {
   GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  TRY (materialize_un (s));
   if (!get_field (s->dom, t)) return GFSHIP_EINVAL;
   /* tracers: van Leer gradient unless the file says otherwise + gfs_face_advection_flux
      (src/variable.c:427-431) */
@@ -527,8 +587,10 @@ static int domain_cfl (gfship_sim * s, double * cfl, bool cached)
   double c2;
   if (cached && s->cfl_ready)
     TRY (launch_cfl_from_max (s->dom, &c2));
-  else
+  else {
+    TRY (materialize_un (s));
     TRY (launch_cfl (s->dom, u, un, s->visc, &c2));
+  }
   s->cfl_ready = false;
   *cfl = sqrt (c2);
   return GFSHIP_OK;
@@ -542,6 +604,7 @@ int gfship_domain_cfl (gfship_sim * s, double * cfl)
   ptrs3 (s, s->un, un);
   double c2;
   s->cfl_ready = false;
+  TRY (materialize_un (s));
   TRY (launch_cfl (s->dom, u, un, s->visc, &c2));
   *cfl = sqrt (c2);
   return GFSHIP_OK;
@@ -705,6 +768,7 @@ int gfship_sim_restart (gfship_sim * s, double t, unsigned i)
 int gfship_sim_advection_step (gfship_sim * s)
 {
   GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  TRY (materialize_un (s));
   TRY (gfship_coarse_init (s));
   TRY (set_timestep (s, false));
   TRY (advance_tracers (s, s->advection_params.dt));
@@ -741,8 +805,7 @@ int gfship_sim_step (gfship_sim * s)
      values are those of the state before the approximate projection, so it cannot be deferred */
   TRY (coarse_init (s, u_coarse));
 
-  TRY (gfship_approximate_projection (s, &s->approx_projection_params, s->advection_params.dt,
-				      s->p, s->g));
+  TRY (mac_projection (s, &s->approx_projection_params, s->advection_params.dt, s->p, s->g, true, true));
   s->t = s->tnext;
   s->i++;
 
@@ -764,6 +827,7 @@ int gfship_sim_download_un (gfship_sim * s, int c, double * host)
 {
   GFSHIP_CHECK (s && host, GFSHIP_EINVAL, "null argument");
   GFSHIP_CHECK (c >= 0 && c < s->dom->dim, GFSHIP_EINVAL, "component %d out of range", c);
+  TRY (materialize_un (s));
   return gfship_field_download (s->dom, s->un[c], s->dom->depth, host);
 }
 

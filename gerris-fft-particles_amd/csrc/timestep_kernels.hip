@@ -273,6 +273,79 @@ project_correct_kernel (Layout L, const double * __restrict__ p, Ptr3 un, Ptr3 g
   }
 }
 
+// The update of the approximate projection when nobody reads the corrected MAC velocities before the
+// next predictor overwrites them (the loop body of simulation_run without tracers): the face
+// velocities are not stored at all -- un = face_interp (u) - dp dt is formed in registers for the
+// maximum of the CFL condition only -- and the centred velocities are corrected out of place (uo:
+// the faces read the uncorrected neighbours), the caller swaps the storage.  80 B per cell instead of
+// 128 (and 32 instead of 56 in the interpolation + divergence pass before it, which no longer writes
+// un).  Should somebody ask for the MAC velocities after all, they are rebuilt from the uncorrected
+// velocities kept in the swapped-out storage and p by face_interp_un_kernel + correct_un_kernel: the
+// same expressions, the same bits (materialize_un, simulation.hip).
+template <int DIM>
+__global__ void __launch_bounds__(256)
+project_correct_lazy_kernel (Layout L, const double * __restrict__ p, CPtr3 u, Ptr3 g, Ptr3 uo,
+			     double dt, double * __restrict__ partial_max)
+{
+  const int i1 = blockIdx.x*blockDim.x + threadIdx.x + 1;
+  const int j = blockIdx.y;
+  const int k = DIM == 3 ? blockIdx.z : 0;
+  const int n = L.n;
+  const double rn = (double) n;
+  const long off[3] = { 1, L.sy, L.sz };
+  double mx = 0.;
+  auto body = [&] (int i) {
+    const long c = L.idx (i, j, k);
+    const bool interior = i >= 1 && j >= 1 && (DIM == 2 || k >= 1);
+#pragma unroll
+    for (int cc = 0; cc < DIM; cc++) {
+      const bool valid = face_valid<DIM> (n, cc, i, j, k);
+      if (valid || interior) {
+	double dpp = (1.*p[c + off[cc]] - 1.*p[c])*rn;
+	dpp /= 1.;
+	const double uc = u.p[cc][c];
+	if (valid) {
+	  double w = face_interp (uc, u.p[cc][c + off[cc]]);
+	  w -= dpp*dt;
+	  mx = fmax (mx, fabs (w));
+	}
+	if (interior) {
+	  double dpm = (1.*p[c] - 1.*p[c - off[cc]])*rn;
+	  dpm /= 1.;
+	  double v = 0.;
+	  v += dpm*1.;
+	  v += dpp*1.;
+	  double gg = v/2.;
+	  g.p[cc][c] = gg;
+	  double w = uc;
+	  w -= gg*dt;
+	  uo.p[cc][c] = w;
+	  mx = fmax (mx, fabs (1.*w));
+	}
+      }
+    }
+  };
+  if (i1 <= n) {
+    body (i1);
+    if (i1 == 1)
+      body (0);
+  }
+  if (partial_max) {
+    __shared__ double sh[4];
+    mx = wave_max_d (mx);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads ();
+    if (threadIdx.x == 0) {
+      double r = sh[0];
+      for (int q = 1; q < (int) (blockDim.x >> 6); q++) r = fmax (r, sh[q]);
+      if (r > 0.)
+	atomicMax ((unsigned long long *) partial_max +
+		   ((blockIdx.x + gridDim.x*(blockIdx.y + (size_t) gridDim.y*blockIdx.z)) & 1023),
+		   (unsigned long long) __double_as_longlong (r));
+    }
+  }
+}
+
 // cfl^2 = (h/max)^2 from the 1024 slots, which are cleared for the next use
 __global__ void __launch_bounds__(256)
 cfl_from_max_kernel (double * __restrict__ partial_max, int nblocks, double length,
@@ -300,7 +373,9 @@ cfl_from_max_kernel (double * __restrict__ partial_max, int nblocks, double leng
 
 // K12 + K9 in one pass over the centred velocities (approximate projection): the MAC velocities
 // and their divergence scaled by 1/dt; the - face of a cell is recomputed, not read back
-template <int DIM>
+// WRITE_UN = false: only the divergence is wanted (the approximate projection of simulation_run, whose
+// corrected MAC velocities nobody reads: project_correct_lazy_kernel)
+template <int DIM, bool WRITE_UN>
 __global__ void __launch_bounds__(256)
 face_interp_div_kernel (Layout L, CPtr3 u, Ptr3 un, double * __restrict__ div, double dt)
 {
@@ -320,7 +395,7 @@ face_interp_div_kernel (Layout L, CPtr3 u, Ptr3 un, double * __restrict__ div, d
       double unp = 0.;
       if (valid || interior)
 	unp = face_interp (u.p[cc][c], u.p[cc][c + off[cc]]);
-      if (valid)
+      if (WRITE_UN && valid)
 	un.p[cc][c] = unp;
       if (interior) {
 	double unm = face_interp (u.p[cc][c - off[cc]], u.p[cc][c]);
@@ -2311,7 +2386,43 @@ int launch_face_interp_div (gfship_domain * dom, double * const u[3], double * c
   const Layout & L = dom->lay[dom->depth];
   dim3 grid, block;
   ext1_grid (L, &grid, &block);
-  DISPATCH (dom, face_interp_div_kernel, grid, block, L, c3 (u), m3 (un), div, dt);
+  if (un) {
+    if (dom->dim == 3) hipLaunchKernelGGL ((face_interp_div_kernel<3, true>), grid, block, 0, dom->stream, L, c3 (u), m3 (un), div, dt);
+    else hipLaunchKernelGGL ((face_interp_div_kernel<2, true>), grid, block, 0, dom->stream, L, c3 (u), m3 (un), div, dt);
+  }
+  else {
+    Ptr3 none = { { nullptr, nullptr, nullptr } };
+    if (dom->dim == 3) hipLaunchKernelGGL ((face_interp_div_kernel<3, false>), grid, block, 0, dom->stream, L, c3 (u), none, div, dt);
+    else hipLaunchKernelGGL ((face_interp_div_kernel<2, false>), grid, block, 0, dom->stream, L, c3 (u), none, div, dt);
+  }
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// the update of the approximate projection without the MAC velocities (project_correct_lazy_kernel):
+// g and the corrected centred velocities uo from p and the uncorrected u; the maxima for the CFL
+// condition are always left behind
+int launch_project_correct_lazy (gfship_domain * dom, const double * p, double * const u[3],
+				 double * const g[3], double * const uo[3], double dt)
+{
+  const Layout & L = dom->lay[dom->depth];
+  dim3 grid, block;
+  ext1_grid (L, &grid, &block);
+  const size_t nb = 1024;
+  if (!dom->cfl_partial) {
+    GFSHIP_HIP (hipMalloc ((void **) &dom->cfl_partial, nb*sizeof (double)));
+    GFSHIP_HIP (hipMemsetAsync (dom->cfl_partial, 0, nb*sizeof (double), dom->stream));
+    dom->cfl_nblocks = nb;
+  }
+  dom->cfl_used = nb;
+  if (dom->cfl_dirty)
+    GFSHIP_HIP (hipMemsetAsync (dom->cfl_partial, 0, nb*sizeof (double), dom->stream));
+  dom->cfl_dirty = true;
+  if (dom->dim == 3)
+    hipLaunchKernelGGL ((project_correct_lazy_kernel<3>), grid, block, 0, dom->stream, L, p, c3 (u), m3 (g), m3 (uo), dt, dom->cfl_partial);
+  else
+    hipLaunchKernelGGL ((project_correct_lazy_kernel<2>), grid, block, 0, dom->stream, L, p, c3 (u), m3 (g), m3 (uo), dt, dom->cfl_partial);
+  GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
 }
 
