@@ -115,8 +115,7 @@ int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, g
      interpolated from the centred ones, gfs_approximate_projection src/timestep.c:572-580) */
   for (int c = 0; c < dom->dim; c++)
     if (s->visc[c] != 0. || dom->src[c] != 0.) lazy = false;   /* the CFL needs the full kernel then */
-  if (!approximate || !s->tracers.empty () || s->un_handle_given || dom->has_external || p != s->p ||
-      getenv ("GFSHIP_NO_LAZY_UN"))
+  if (!approximate || !s->tracers.empty () || s->un_handle_given || p != s->p || getenv ("GFSHIP_NO_LAZY_UN"))
     lazy = false;
   if (!approximate)
     TRY (materialize_un (s));          /* un is an input of the MAC projection */
