@@ -320,6 +320,7 @@ int gfship_field_upload (gfship_domain * dom, gfship_field f, int level, const d
   GFSHIP_CHECK (host != nullptr, GFSHIP_EINVAL, "null host pointer");
   int r = check_level (dom, level);
   if (r) return r;
+  if (dom->before_write && (r = dom->before_write (dom->before_write_ctx))) return r;
   if ((r = coarse_flush (dom, F, level))) return r;
   const Layout & L = dom->lay[level];
   size_t rows = (size_t) L.rows*(dom->dim == 3 ? L.rows : 1);

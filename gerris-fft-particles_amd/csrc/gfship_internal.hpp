@@ -105,6 +105,10 @@ struct gfship_domain {
   hipStream_t side_stream = nullptr;
   hipEvent_t side_fork = nullptr;
   bool no_arm_ahead = false;       // GFSHIP_NO_ARM_AHEAD=1: the granules are armed in line, before the loop
+  // called before a caller overwrites a field of the domain (upload, snapshot read): a simulation that
+  // keeps derived state unstored (its MAC velocities, simulation.hip: materialize_un) stores it first
+  int (* before_write) (void *) = nullptr;
+  void * before_write_ctx = nullptr;
   double * d_scratch = nullptr;   // reduction scratch
   size_t scratch_doubles = 0;
   double * h_pinned = nullptr;    // pinned host buffer for small read-backs

@@ -747,6 +747,7 @@ relax_ring_loop_kernel (SkewLoopArgs A)
       }
       // LDS index of the new value of the line m + 1 (the partner of an even m in a 16-byte store)
       const int sX2 = g == 0 ? SK_T + XS*(m + 2) : g == 1 ? (m + 2) + XS*SK_T : g == 2 ? 1 + XS*(m + 2) : (m + 2) + XS*1;
+      (void) sX2;
       if (tile == A.fault_tile && sw == 0) sOn = false;     /* fault injection for the test of the error path */
       // the consumer tile of the stream runs on this XCD: plain stores (they stay in the common L2)
       const bool sNear = A.near_mode != 0 && patch_same_xcd (A, g == 0 ? tJp : g == 1 ? tKp : g == 2 ? tJm : tKm);

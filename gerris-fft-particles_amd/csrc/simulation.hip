@@ -327,6 +327,9 @@ int gfship_sim_create (gfship_sim ** out, gfship_domain * dom)
     gfship_sim_destroy (s);
     return GFSHIP_ENOMEM;
   }
+  /* the MAC velocities a step leaves unstored are stored before anybody overwrites a field */
+  dom->before_write = [] (void * ctx) -> int { return materialize_un ((gfship_sim *) ctx); };
+  dom->before_write_ctx = s;
   *out = s;
   return GFSHIP_OK;
 }
@@ -335,6 +338,7 @@ void gfship_sim_destroy (gfship_sim * s)
 {
   if (!s) return;
   gfship_domain * dom = s->dom;
+  if (dom->before_write_ctx == s) { dom->before_write = nullptr; dom->before_write_ctx = nullptr; }
   auto fr = [&] (gfship_field f) { if (f >= 0) gfship_field_free (dom, f); };
   fr (s->p); fr (s->pmac);
   for (int c = 0; c < 3; c++) { fr (s->u[c]); fr (s->g[c]); fr (s->gmac[c]); fr (s->un[c]); }

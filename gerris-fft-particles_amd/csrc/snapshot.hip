@@ -175,6 +175,7 @@ int gfship_snapshot_tree_read (gfship_domain * dom, int nvars, const gfship_fiel
   SnapArgs A;
   int r = snap_args (dom, nvars, vars, &A);
   if (r) return r;
+  if (dom->before_write && (r = dom->before_write (dom->before_write_ctx))) return r;
   const size_t need = gfship_snapshot_tree_bytes (dom, nvars);
   GFSHIP_CHECK (host_buf != nullptr, GFSHIP_EINVAL, "null buffer");
   GFSHIP_CHECK (bytes == need, GFSHIP_EINVAL,

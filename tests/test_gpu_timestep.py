@@ -395,6 +395,41 @@ def test_fused_periodic_paths_equal_general_paths(dim, level):
                               _interior(b, dim) if b.ndim == dim else b)
 
 
+@pytest.mark.parametrize("gradient,source,lazy", [(0, 0., True), (1, 0., True), (0, -0.7, True), (1, 0., False)])
+def test_sweep_kernels_64_several_steps_vs_oracle(gradient, source, lazy, monkeypatch):
+    """the Godunov kernels as sweeps along z (advect3_sweep_kernel with the centred correction and the
+    first coarse level fused, predict_un_sweep_kernel with the divergence of the MAC projection fused)
+    at the smallest size they run on (64^3: one z chunk), over several steps (the first step advects
+    with gmac in place of g), with the centred and the van Leer gradient and with a GfsSource; the MAC
+    velocities the approximate projection leaves unstored are rebuilt when they are downloaded
+    (materialize_un) -- every field, un included, against the oracle after every step"""
+    if not lazy:
+        monkeypatch.setenv("GFSHIP_NO_LAZY_UN", "1")
+    level = 6
+    osim = oracle_taylor_green(level)
+    osim.u[0].interior()[...] += 0.35         # upwind directions of both signs, faces of zero velocity
+    osim.u[2].interior()[...] -= 0.2
+    osim.advection_params.gradient = gradient
+    gd, gs = _device_sim(osim, PERIODIC)
+    if source:
+        osim.set_source(1, source)
+        gs.set_source(1, source)
+    osim.start()
+    gs.start()
+    _assert_same_state(osim, gs, "start")
+    for k in range(3):
+        osim.step()
+        gs.step()
+        _assert_same_state(osim, gs, "step %d" % k)
+        _assert_same_un(osim, gs, "step %d" % k)
+        # the level below the leaves (gfs_cell_coarse_init inside the step: filled by the advection sweep)
+        for c in range(3):
+            assert np.array_equal(osim.u[c].level(level - 1)[1:-1, 1:-1, 1:-1],
+                                  gs.u[c].download(level - 1)[1:-1, 1:-1, 1:-1]), (k, c)
+    assert gs.cfl() == O.lib().go_domain_cfl(osim.ptr)
+    gd.destroy()
+
+
 # ---------------------------------------------------------------------------------------------
 # GfsAdvection with a GfsVariableStreamFunction (test/advection): tracer in solid rotation
 # ---------------------------------------------------------------------------------------------
