@@ -1811,6 +1811,355 @@ advect3_sweep_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc,
 }
 
 // ---------------------------------------------------------------------------------------------
+// advect3_sweep2_kernel: the same sweep with every global load issued where nothing waits for it.
+// The counters of advect3_sweep_kernel (profiles/r03_pmc_advect3.json: 75 % of the wave cycles in
+// s_waitcnt / at barriers, the vector ALU 25 % busy) and its structure say where the time goes: three
+// loads per plane are consumed right after they are issued -- the MAC velocities of the plane (written
+// to LDS before the first barrier), gm (read by the flux stage), gc (read by the update) -- about 2 us
+// of exposed latency each of the 8 us a plane takes.  Here un (p + 1) is loaded a whole iteration
+// ahead, gm (p) and gc (p - 1) at the top of the iteration (consumed after the face values); to pay
+// for those registers the left states of a plane wait in the thread's own LDS slots instead of
+// registers, the x / y fluxes are re-read from LDS by the update, the right states go to LDS as soon
+// as they exist (double-buffered by the parity of the plane), and the x / y fluxes of plane p - 1 are
+// formed BEFORE the face values of plane p (only the z flux needs them).  Same expressions, same
+// order per cell: bit-identical.
+// ---------------------------------------------------------------------------------------------
+struct Sweep2Lds {
+  double V[3][SWY + 2][SWX + 2];
+  double UNx[SWY][SWX + 1], UNy[SWY + 1][SWX];
+  double FRx[2][3][SWY][SWX + 1], FRy[2][3][SWY + 1][SWX];   // right states of the planes p, p - 1 by parity
+  double FPx[3][SWY][SWX + 1], FPy[3][SWY + 1][SWX];
+  double GM[3][SWY + 1][SWX + 1];                      // gm of plane p - 1 (+ column and row after)
+  double FL[3][3][SWY][SWX];                           // left states of plane p - 1: every thread its own slots
+};
+
+template <bool VL, bool SRC>
+__device__ __forceinline__ void sweep2_ring_path (Sweep2Lds & S_, const Layout & L, const CPtr3 & v, const CPtr3 & un,
+						  const CPtr3 & gm, double dt, const Visc3 & src3, int rid)
+{
+  const int n = L.n;
+  const double rn = (double) n, rsize2 = (double) n/2.;
+  const int sy = (int) L.sy, sz = (int) L.sz;
+  const int kb = blockIdx.z*SWZ;
+  auto plane = [n, sz] (int k) { return (k < 1 ? k + n : k > n ? k - n : k)*sz; };
+  int role = -1, hd = 0, hcol = 0, hslot = 0;
+  if (rid < 2*SWX) {
+    role = rid < SWX ? 0 : 1; hd = 1; hslot = rid % SWX;
+    int hj = blockIdx.y*SWY + (role ? SWY + 1 : 0);
+    hj = hj < 1 ? hj + n : hj > n ? hj - n : hj;
+    hcol = (int) L.idx (blockIdx.x*SWX + hslot + 1, hj, 0);
+  }
+  else if (rid < 2*SWX + 2*SWY) {
+    role = rid < 2*SWX + SWY ? 2 : 3; hd = 0; hslot = (rid - 2*SWX) % SWY;
+    int hi_ = blockIdx.x*SWX + (role == 3 ? SWX + 1 : 0);
+    hi_ = hi_ < 1 ? hi_ + n : hi_ > n ? hi_ - n : hi_;
+    hcol = (int) L.idx (hi_, blockIdx.y*SWY + hslot + 1, 0);
+  }
+  const bool ring = role >= 0, ring_minus = role == 0 || role == 2;
+  const int hoff = hd == 0 ? 1 : sy;                 // towards the column
+  const int ry = role == 0 ? 0 : role == 1 ? SWY + 1 : hslot + 1;
+  const int rx = role == 2 ? 0 : role == 3 ? SWX + 1 : hslot + 1;
+  // everything is loaded one iteration before it is used (suffix n: for the next iteration)
+  double hvm[3], hv0[3] = { 0., 0., 0. }, hvp[3] = { 0., 0., 0. }, hvn[3] = { 0., 0., 0. };
+  double nbn[3][4];                                  // in-plane neighbours of the cell: x -, x +, y -, y +
+  double huan[3] = { 0., 0., 0. }, hubn[2] = { 0., 0. };
+  double hunb = 0., hunzb = 0., hlo[3] = { 0., 0., 0. }, hgmo[3], hgmn[3] = { 0., 0., 0. };
+  double hgcn[3] = { 0., 0., 0. };                   // gm of the column's cell beside the ring cell
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    hgmo[q] = 0.;
+#pragma unroll
+    for (int e = 0; e < 4; e++) nbn[q][e] = 0.;
+  }
+  if (ring) {
+    const int hc = hcol + plane (kb);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      hv0[q] = v.p[q][hcol + plane (kb - 1)];
+      hvp[q] = v.p[q][hc];
+      hvn[q] = v.p[q][hcol + plane (kb + 1)];
+      nbn[q][0] = v.p[q][hc - 1];  nbn[q][1] = v.p[q][hc + 1];
+      nbn[q][2] = v.p[q][hc - sy]; nbn[q][3] = v.p[q][hc + sy];
+    }
+    huan[0] = un.p[0][hc]; hubn[0] = un.p[0][hc - 1];
+    huan[1] = un.p[1][hc]; hubn[1] = un.p[1][hc - sy];
+    huan[2] = un.p[2][hc];
+    hunzb = un.p[2][hcol + plane (kb - 1)];
+  }
+  for (int p = kb; p <= kb + SWZ + 1; p++) {
+    const int zp = plane (p);
+    Stencil7 HW[3];
+    double hua[3], hub[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      hvm[q] = hv0[q]; hv0[q] = hvp[q]; hvp[q] = hvn[q];
+      HW[q].v0 = hv0[q];
+      HW[q].m[0] = nbn[q][0]; HW[q].p[0] = nbn[q][1];
+      HW[q].m[1] = nbn[q][2]; HW[q].p[1] = nbn[q][3];
+      HW[q].m[2] = hvm[q]; HW[q].p[2] = hvp[q];
+      hgmo[q] = hgmn[q];                             // gm (p - 1) of the ring cell
+    }
+    hua[0] = huan[0]; hua[1] = huan[1]; hua[2] = huan[2];
+    hub[0] = hubn[0]; hub[1] = hubn[1]; hub[2] = hunzb;
+    const double hgc[3] = { hgcn[0], hgcn[1], hgcn[2] };
+    if (ring) {
+      // the loads of the next iteration (plane p + 1; gm of plane p)
+      const int hc1 = hcol + plane (p + 1);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	hvn[q] = v.p[q][hcol + plane (p + 2)];
+	nbn[q][0] = v.p[q][hc1 - 1];  nbn[q][1] = v.p[q][hc1 + 1];
+	nbn[q][2] = v.p[q][hc1 - sy]; nbn[q][3] = v.p[q][hc1 + sy];
+	hgmn[q] = gm.p[q][hcol + zp];
+	hgcn[q] = gm.p[q][hcol + zp + hoff];
+      }
+      huan[0] = un.p[0][hc1]; hubn[0] = un.p[0][hc1 - 1];
+      huan[1] = un.p[1][hc1]; hubn[1] = un.p[1][hc1 - sy];
+      huan[2] = un.p[2][hc1];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	S_.V[q][ry][rx] = hv0[q];
+	if (role == 3) S_.GM[q][hslot][SWX] = hgmo[q];
+	if (role == 1) S_.GM[q][SWY][hslot] = hgmo[q];
+      }
+      if (role == 2) S_.UNx[hslot][0] = hua[0];
+      if (role == 0) S_.UNy[0][hslot] = hua[1];
+    }
+    __syncthreads ();                                // (1)
+    double hl[3] = { 0., 0., 0. };
+    if (ring) {
+      const AdvShared S = adv_shared_v (hua, hub, dt, rsize2);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	const FacePair f = hd == 0 ? adv_face_values_s<0, VL, SRC> (HW[q], S, dt, rsize2, src3.g[q]) :
+	  adv_face_values_s<1, VL, SRC> (HW[q], S, dt, rsize2, src3.g[q]);
+	hl[q] = f.l;
+	if (role == 3) S_.FRx[p & 1][q][hslot][SWX] = f.r;
+	if (role == 1) S_.FRy[p & 1][q][SWY][hslot] = f.r;
+      }
+      // the face between the cell and the column, plane p - 1
+      if (p > kb && ring_minus) {
+	const double ua = hunb;
+	const double fu = 1.*ua*dt*rn;
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+	  const double rs = role == 2 ? S_.FRx[(p - 1) & 1][q][hslot][0] : S_.FRy[(p - 1) & 1][q][0][hslot];
+	  double f = fu;
+	  f *= upwinded (ua, hlo[q], rs) - face_interp (hgmo[q], hgc[q])*dt/2.;
+	  if (role == 2) S_.FPx[q][hslot][0] = f; else S_.FPy[q][0][hslot] = f;
+	}
+      }
+    }
+    __syncthreads ();                                // (2)
+    if (ring) {
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+	hlo[q] = hl[q];
+      hunb = hua[hd];
+      hunzb = hua[2];
+    }
+  }
+}
+
+template <bool VL, bool SRC, bool CORR>
+__global__ void __launch_bounds__(SWN + SW_RING)
+advect3_sweep2_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt, Visc3 src3,
+		       AdvCorr K)
+{
+  __shared__ Sweep2Lds S_;
+  const int tid = threadIdx.x;
+  if (tid >= SWN) {
+    sweep2_ring_path<VL, SRC> (S_, L, v, un, gm, dt, src3, tid - SWN);
+    return;
+  }
+  const int tx = tid % SWX, ty = tid / SWX;
+  const int n = L.n;
+  const double rn = (double) n, rsize2 = (double) n/2.;
+  const int sz = (int) L.sz;
+  const int i = blockIdx.x*SWX + tx + 1, j = blockIdx.y*SWY + ty + 1;
+  const int kb = blockIdx.z*SWZ;                     // output planes kb + 1 .. kb + SWZ
+  const int col = (int) L.idx (i, j, 0);
+  auto plane = [n, sz] (int k) { return (k < 1 ? k + n : k > n ? k - n : k)*sz; };   // periodic image
+
+  double vm[3], v0[3], vp[3], vn[3];                 // planes p - 1, p, p + 1 and the load for p + 2
+  double una[3], unb[3], unn[3];                     // un (p), un (p - 1), un (p + 1)
+  double fpz[3] = { 0., 0., 0. };                    // fluxes through the z face below plane p - 1
+  double gmo[3], gmc[3];                             // gm (p - 1), gm (p) of the own cell
+  double low[3] = { 0., 0., 0. };                    // corrected values of the odd plane (coarse cells)
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    v0[q] = v.p[q][col + plane (kb - 1)];
+    vp[q] = v.p[q][col + plane (kb)];
+    vn[q] = v.p[q][col + plane (kb + 1)];
+    gmo[q] = 0.;
+    gmc[q] = gm.p[q][col + plane (kb - 1)];
+#pragma unroll
+    for (int d = 0; d < 3; d++) S_.FL[q][d][ty][tx] = 0.;
+  }
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    una[d] = un.p[d][col + plane (kb - 1)];
+    unn[d] = un.p[d][col + plane (kb)];
+    unb[d] = 0.;
+  }
+
+  for (int p = kb; p <= kb + SWZ + 1; p++) {
+    const int zp = plane (p);
+    const int rp = p & 1, ro = rp ^ 1;
+    // ---- shift the column registers; the loads (none is consumed before the face values are done,
+    // un not before the next iteration)
+    double gcv[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      vm[q] = v0[q]; v0[q] = vp[q]; vp[q] = vn[q];
+      vn[q] = v.p[q][col + plane (p + 2)];
+      gmo[q] = gmc[q];
+      gmc[q] = gm.p[q][col + zp];
+      gcv[q] = gc.p[q] ? gc.p[q][col + plane (p - 1)] : 0.;
+    }
+    const double unzb = una[2];                      // un_z (p - 1)
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      unb[d] = una[d];
+      una[d] = unn[d];
+      unn[d] = un.p[d][col + plane (p + 1)];
+    }
+    // ---- the plane into LDS
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      S_.V[q][ty + 1][tx + 1] = v0[q];
+      S_.GM[q][ty][tx] = gmo[q];
+    }
+    S_.UNx[ty][tx + 1] = una[0];
+    S_.UNy[ty + 1][tx] = una[1];
+    __syncthreads ();                                // (1)
+    double flz[3] = { 0., 0., 0. };
+    if (p > kb) {
+      // ---- B (o), x and y: fluxes through the + faces of plane o = p - 1 from its left states (own LDS
+      // slots), the right states of the neighbours (the other half of FR) and gm of the neighbours
+      const double fux = 1.*unb[0]*dt*rn, fuy = 1.*unb[1]*dt*rn;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	const double g0 = gmo[q];
+	double f = fux;
+	f *= upwinded (unb[0], S_.FL[q][0][ty][tx], S_.FRx[ro][q][ty][tx + 1]) - face_interp (g0, S_.GM[q][ty][tx + 1])*dt/2.;
+	S_.FPx[q][ty][tx + 1] = f;
+	f = fuy;
+	f *= upwinded (unb[1], S_.FL[q][1][ty][tx], S_.FRy[ro][q][ty + 1][tx]) - face_interp (g0, S_.GM[q][ty + 1][tx])*dt/2.;
+	S_.FPy[q][ty + 1][tx] = f;
+	flz[q] = S_.FL[q][2][ty][tx];
+      }
+    }
+    // ---- A (p): face values of plane p; the right states and the left states go to LDS at once
+    double frz[3];
+    {
+      const double b[3] = { S_.UNx[ty][tx], S_.UNy[ty][tx], unzb };
+      const AdvShared S = adv_shared_v (una, b, dt, rsize2);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	Stencil7 W;
+	W.v0 = v0[q];
+	W.m[0] = S_.V[q][ty + 1][tx];     W.p[0] = S_.V[q][ty + 1][tx + 2];
+	W.m[1] = S_.V[q][ty][tx + 1];     W.p[1] = S_.V[q][ty + 2][tx + 1];
+	W.m[2] = vm[q];                   W.p[2] = vp[q];
+	const SweepFv F = sweep_face_values<VL, SRC> (W, S, dt, rsize2, src3.g[q]);
+	S_.FRx[rp][q][ty][tx] = F.r[0];
+	S_.FRy[rp][q][ty][tx] = F.r[1];
+	frz[q] = F.r[2];
+#pragma unroll
+	for (int d = 0; d < 3; d++)
+	  S_.FL[q][d][ty][tx] = F.l[d];
+      }
+    }
+    double Fpz[3] = { 0., 0., 0. };
+    if (p > kb) {
+      // ---- B (o), z: the right state of plane p of the same thread
+      const double fuz = 1.*unb[2]*dt*rn;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+	double f = fuz;
+	f *= upwinded (unb[2], flz[q], frz[q]) - face_interp (gmo[q], gmc[q])*dt/2.;
+	Fpz[q] = f;
+      }
+    }
+    __syncthreads ();                                // (2) the fluxes of plane p - 1; plane p has been read
+    if (p > kb) {
+      const int o = p - 1, co = col + plane (o);
+      if (p > kb + 1) {
+	// ---- C (o): the gather in the reference's scatter order (flux_update_kernel), the update
+	const int k = o;
+	const unsigned J = n - j, K_ = n - k;
+	const bool back_first = __ffs (~J) > __ffs (~K_);
+	double res[3];
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+	  const double Fmx = S_.FPx[q][ty][tx], Fmy = S_.FPy[q][ty][tx], Fmz = fpz[q];
+	  const double Fpx = S_.FPx[q][ty][tx + 1], Fpy = S_.FPy[q][ty + 1][tx];
+	  double acc = 0.;
+	  if (i > 1)
+	    acc += Fmx;
+	  acc -= Fpx;
+	  acc -= Fpy;
+	  acc -= Fpz[q];
+	  if (back_first) {
+	    if (k > 1) acc += Fmz;
+	    if (j > 1) acc += Fmy;
+	  }
+	  else {
+	    if (j > 1) acc += Fmy;
+	    if (k > 1) acc += Fmz;
+	  }
+	  if (i == 1)
+	    acc += Fmx;
+	  if (j == 1)
+	    acc += Fmy;
+	  if (k == 1)
+	    acc += Fmz;
+	  double val = vm[q];
+	  val += acc/1.;
+	  if (gc.p[q])
+	    val -= gcv[q]*dt;
+	  if (SRC && src3.g[q] != 0.) { /* gfs_domain_variable_centered_sources, src/source.c:62-108 */
+	    double sum = 0;
+	    sum += src3.g[q];
+	    val += dt*sum;
+	  }
+	  if (CORR)          /* correct (src/timestep.c:486-496): u[c] -= g[c]*dt with dt = K.dt */
+	    val = val - gcv[q]*K.dt;
+	  out.p[q][co] = val;
+	  res[q] = val;
+	}
+	if (CORR && K.uc[0]) {
+	  // the first level of gfs_cell_coarse_init (see advect3_sweep_kernel)
+	  if (k & 1) {
+#pragma unroll
+	    for (int q = 0; q < 3; q++) low[q] = res[q];
+	  }
+	  else {
+	    const int lane = tid & 63, lx = lane & 31;
+	    const bool head = !(lane & 32) && !(lx & 1);
+	    const int src[4] = { lx + 32, lx + 33, lx, lx + 1 };
+#pragma unroll
+	    for (int q = 0; q < 3; q++) {
+	      double val = 0., sa = 0.;
+#pragma unroll
+	      for (int id = 0; id < 4; id++) { val += __shfl (res[q], src[id], 64)*1.; sa += 1.; }
+#pragma unroll
+	      for (int id = 0; id < 4; id++) { val += __shfl (low[q], src[id], 64)*1.; sa += 1.; }
+	      if (head)
+		K.uc[q][K.Lc.idx ((i + 1)/2, (j + 1)/2, k/2)] = val/sa;
+	    }
+	  }
+	}
+      }
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+	fpz[q] = Fpz[q];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The predictor of the three MAC velocities as the same sweep along z (periodic boxes):
 // gfs_face_advected_normal_velocity (src/advection.c:513-539) with the face values of u[d] along d
 // (use_centered_velocity = TRUE), predict_un_tiled_kernel's expressions -- and, with div != nullptr,
@@ -1890,6 +2239,7 @@ __device__ __forceinline__ void pred_ring_path (PredLds & S_, const Layout & L, 
   // the column of the ring cell: the three components (the ring of V), of which u[hd] is advected
   double hvm[3], hv0[3] = { 0., 0., 0. }, hvp[3] = { 0., 0., 0. }, hvn[3] = { 0., 0., 0. };
   double hlo = 0., hnb = 0., hnbn = 0.;        // left state of plane p - 1; u[hd] of the column's cell beside, planes p - 1 / p
+  double nbn[4] = { 0., 0., 0., 0. };          // in-plane neighbours of u[hd] at the cell, loaded one iteration ahead
   if (ring) {
 #pragma unroll
     for (int q = 0; q < 3; q++) {
@@ -1898,6 +2248,10 @@ __device__ __forceinline__ void pred_ring_path (PredLds & S_, const Layout & L, 
       hvn[q] = u.p[q][hcol + plane (kb + 1)];
     }
     hnbn = u.p[hd][hcol + hoff + plane (kb - 1)];
+    const double * __restrict__ const w = u.p[hd];
+    const int hc = hcol + plane (kb);
+    nbn[0] = w[hc - 1];  nbn[1] = w[hc + 1];
+    nbn[2] = w[hc - sy]; nbn[3] = w[hc + sy];
   }
   for (int p = kb; p <= kb + SWZ + 1; p++) {
     const int zp = plane (p);
@@ -1908,15 +2262,16 @@ __device__ __forceinline__ void pred_ring_path (PredLds & S_, const Layout & L, 
       hvm[q] = hv0[q]; hv0[q] = hvp[q]; hvp[q] = hvn[q];
     }
     HW.v0 = hv0[hd]; HW.m[2] = hvm[hd]; HW.p[2] = hvp[hd];
+    HW.m[0] = nbn[0]; HW.p[0] = nbn[1]; HW.m[1] = nbn[2]; HW.p[1] = nbn[3];
     hnb = hnbn;
     if (ring) {
-      const int hc = hcol + zp;
+      const int hc1 = hcol + plane (p + 1);
 #pragma unroll
       for (int q = 0; q < 3; q++)
 	hvn[q] = u.p[q][hcol + plane (p + 2)];
       const double * __restrict__ const w = u.p[hd];
-      HW.m[0] = w[hc - 1];  HW.p[0] = w[hc + 1];
-      HW.m[1] = w[hc - sy]; HW.p[1] = w[hc + sy];
+      nbn[0] = w[hc1 - 1];  nbn[1] = w[hc1 + 1];     /* plane p + 1: for the next iteration */
+      nbn[2] = w[hc1 - sy]; nbn[3] = w[hc1 + sy];
       hnbn = w[hcol + hoff + zp];                 /* plane p: the face of the next iteration */
 #pragma unroll
       for (int q = 0; q < 3; q++)
@@ -2577,10 +2932,16 @@ int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * con
   if (!mpi && sweep_ok && L.n % SWX == 0 && L.n % SWY == 0 && L.n % SWZ == 0) {
     /* periodic box: the sweep along z (advect3_sweep_kernel) */
     const dim3 sgrid (L.n/SWX, L.n/SWY, L.n/SWZ);
+    static const bool sweep1 = getenv ("GFSHIP_ADVECT_SWEEP1") != nullptr;
 #define SK3(VL_, SRC_) do { \
-      if (corr) hipLaunchKernelGGL ((advect3_sweep_kernel<VL_, SRC_, true>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
-				    L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K); \
-      else hipLaunchKernelGGL ((advect3_sweep_kernel<VL_, SRC_, false>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
+      if (sweep1) { \
+	if (corr) hipLaunchKernelGGL ((advect3_sweep_kernel<VL_, SRC_, true>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
+				      L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K); \
+	else hipLaunchKernelGGL ((advect3_sweep_kernel<VL_, SRC_, false>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
+				 L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K); } \
+      else if (corr) hipLaunchKernelGGL ((advect3_sweep2_kernel<VL_, SRC_, true>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
+					 L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K); \
+      else hipLaunchKernelGGL ((advect3_sweep2_kernel<VL_, SRC_, false>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
 			       L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K); } while (0)
     if (gradient) { if (srcs0) SK3 (true, true); else SK3 (true, false); }
     else          { if (srcs0) SK3 (false, true); else SK3 (false, false); }
