@@ -51,6 +51,8 @@ struct SkewPlan {
   int ntj = 0, RT = 0;
   size_t hb_words = 0;
   double * us = nullptr, * rs = nullptr, * ds = nullptr;
+  double * ws[6] = {};            // skewed face weights of the level (weighted relax), packed when ws_stamp is stale
+  unsigned long ws_stamp = 0;
   void * hb = nullptr;            // hand-off granules (J side then K side)
   void * hbf = nullptr;           // granules of the fused relax loop (relax_skew_loop.hip): two sets
   // the sets are used in turn: a loop kernel of relax_patch_loop.hip arms the OTHER set for the next
@@ -150,6 +152,7 @@ struct gfship_domain {
   bool force_hyperplane = false;  // debug/bench: per-hyperplane launches instead of relax_skew
   bool unit_weights = false;      // gfship_poisson_coefficients called with alpha = NULL
   bool weighted = false;          // gfship_poisson_coefficients_alpha: the face weights live in wf[]
+  unsigned long weights_stamp = 0; // bumped whenever wf[] is recomputed (skewed copies are then stale)
   gfship_field wf[6] = {-1, -1, -1, -1, -1, -1};   // GFS_STATE (cell)->f[d].v as Poisson weights, all levels
   gfship::SkewPlan skew[GFSHIP_MAXLEVEL + 1];
   double diff_w[GFSHIP_MAXLEVEL + 1] = {};  // diffusion face weight of each level
@@ -316,7 +319,8 @@ int  skew_arm_ahead (gfship_domain * dom, int level, unsigned nrelax);
 int  patch_resident_per_cu ();
 // the prolongation onto `level' can be done by the copy into the skewed layout of its relax loop
 bool prolongation_fused (gfship_domain * dom, unsigned dimension, int level, unsigned nrelax);
-inline bool patch_level (const gfship_domain * dom, int level) { return dom->patch && dom->lay[level].n >= dom->patch_min_n; }
+/* weighted sweeps (face weights from alpha) run on the six-wave kernel with its tile-skewed layout */
+inline bool patch_level (const gfship_domain * dom, int level) { return dom->patch && !dom->weighted && dom->lay[level].n >= dom->patch_min_n; }
 int  patch_pack (gfship_domain * dom, int level, SkewPlan * S, const double * u, const double * rhs,
 		 const double * dia, const double * coarse = nullptr);
 int  patch_unpack (gfship_domain * dom, int level, SkewPlan * S, double * u, double * add_into);

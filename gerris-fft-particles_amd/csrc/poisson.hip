@@ -11,6 +11,15 @@ using namespace gfship;
 
 namespace gfship {
 
+// weighted sweeps of this level run on the pipelined tile kernel (GFSHIP_WEIGHTED_HYPERPLANES=1: one
+// launch per hyperplane, the independent implementation)
+static bool weighted_pipelined (gfship_domain * dom, unsigned dimension, int level)
+{
+  static const bool off = getenv ("GFSHIP_WEIGHTED_HYPERPLANES") != nullptr;
+  return !off && dom->relax_mode == GFSHIP_RELAX_EXACT && dimension == 3 && dom->dim == 3 &&
+    skew_supported (dom, level) && !dom->force_hyperplane;
+}
+
 // gfs_relax on one level (src/poisson.c:604-632)
 static int relax_level (gfship_domain * dom, unsigned dimension, int level, double omega,
 			Field * u, Field * rhs, Field * dia)
@@ -18,8 +27,12 @@ static int relax_level (gfship_domain * dom, unsigned dimension, int level, doub
   u->zero[level] = false;
   if (dom->weighted) {
     /* face weights from a GfsFunction alpha: the exact-order sweep with the six weights of every
-       cell, one launch per hyperplane (the pipelined kernels carry the constant weight 1) */
+       cell streamed beside u / rhs / dia by the pipelined tile kernel (3-D levels >= 32^3), in one
+       launch per sweep by rows (2-D) or in LDS (small 3-D levels) */
     RelaxOp op = weighted_op (dom, level);
+    if (weighted_pipelined (dom, dimension, level))
+      return launch_relax_loop_skew (dom, level, u, u, rhs->lev[level], dia->lev[level], false, 1, false,
+				     nullptr, nullptr, &op);
     return launch_relax_exact (dom, dimension, level, omega, u->lev[level], rhs->lev[level],
 			       dia->lev[level], &op);
   }
@@ -44,7 +57,22 @@ static int relax_loop (gfship_domain * dom, Field * dp, Field * u, unsigned dime
 {
   int r;
   dp->zero[level] = false;
+  if (dom->weighted && weighted_pipelined (dom, dimension, level) &&
+      !(dom->has_external && dom->overlap && nrelax > 1)) {
+    /* the whole loop in one launch on boxes without MPI sides (the weights do not change between
+       the sweeps), else sweep by sweep with the BC between */
+    RelaxOp op = weighted_op (dom, level);
+    return launch_relax_loop_skew (dom, level, dp, u, rhs->lev[level], dia->lev[level], false, nrelax,
+				   true, nullptr, nullptr, &op);
+  }
   if (dom->weighted) {
+    RelaxOp op = weighted_op (dom, level);
+    bool done = false;
+    if ((r = launch_relax_loop_small (dom, dimension, level, omega, dp, u, rhs->lev[level],
+				      dia->lev[level], nrelax, &done, &op)))
+      return r;
+    if (done)
+      return GFSHIP_OK;
     if ((r = launch_bc (dom, u, dp, level, 1))) return r;
     for (unsigned n = 0; n < nrelax - 1; n++) {
       if ((r = relax_level (dom, dimension, level, omega, dp, rhs, dia))) return r;

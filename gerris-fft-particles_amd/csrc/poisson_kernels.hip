@@ -138,7 +138,7 @@ template <int OP>
 __global__ void __launch_bounds__(1024)
 relax_rows2d_kernel (Layout L, double omega, double w, double h2,
 		     double * __restrict__ u, const double * __restrict__ rhs,
-		     const double * __restrict__ dia)
+		     const double * __restrict__ dia, W6 wf)
 {
   __shared__ double N[2][1024 + 2], O[2][1024 + 2];
   const int n = L.n;
@@ -154,6 +154,12 @@ relax_rows2d_kernel (Layout L, double omega, double w, double h2,
   auto clampi = [n] (int i) { return i < 0 ? 0 : i > n + 1 ? n + 1 : i; };
   // at step t: I = t - J; right = u (I + 2, j) = row[I + 3]; rhs, dia, ghost row at i = I + 1
   double pR[RX_D], pH[RX_D], pD[RX_D], pE[RX_D];
+  // OP == 2: the four face weights of the cell (rows of the natural arrays f[d].v)
+  double pW[4][RX_D];
+  const double * wrow[4];
+#pragma unroll
+  for (int d = 0; d < 4; d++)
+    wrow[d] = OP == 2 ? wf.p[d] + L.idx (0, j, 0) - 1 : nullptr;
 #pragma unroll
   for (int q = 0; q < RX_D; q++) {
     const int i = q - J + 1;
@@ -161,6 +167,11 @@ relax_rows2d_kernel (Layout L, double omega, double w, double h2,
     pH[q] = rrow[clampi (i) + 1];
     pD[q] = drow[clampi (i) + 1];
     pE[q] = erow ? erow[clampi (i) + 1] : 0.;
+    if (OP == 2) {
+#pragma unroll
+      for (int d = 0; d < 4; d++)
+	pW[d][q] = wrow[d][clampi (i) + 1];
+    }
   }
   double left = row[0 + 1], cur = row[1 + 1];
   if (mine) {
@@ -177,6 +188,8 @@ relax_rows2d_kernel (Layout L, double omega, double w, double h2,
       const int t = t0 + q, I = t - J;
       const int rd = t & 1, wr = rd ^ 1;
       const double right = pR[q], rh = pH[q], di = pD[q], ex = pE[q];
+      double w0 = 0., w1 = 0., w2 = 0., w3 = 0.;
+      if (OP == 2) { w0 = pW[0][q]; w1 = pW[1][q]; w2 = pW[2][q]; w3 = pW[3][q]; }
       // the loads of step t + RX_D
       {
 	const int i = I + RX_D + 1;
@@ -184,6 +197,11 @@ relax_rows2d_kernel (Layout L, double omega, double w, double h2,
 	pH[q] = rrow[clampi (i) + 1];
 	pD[q] = drow[clampi (i) + 1];
 	if (erow) pE[q] = erow[clampi (i) + 1];
+	if (OP == 2) {
+#pragma unroll
+	  for (int d = 0; d < 4; d++)
+	    pW[d][q] = wrow[d][clampi (i) + 1];
+	}
       }
       double v = 0.;
       const bool active = mine && I >= 0 && I < n;
@@ -199,6 +217,15 @@ relax_rows2d_kernel (Layout L, double omega, double w, double h2,
 	  double a = di*h2;
 	  ga = 1. + ga/a;
 	  v = (gb/a + rh)/ga;
+	}
+	else if (OP == 2) {
+	  // relax2D with the face weights of the cell (src/poisson.c:532-557, src/fluid.c:858-864)
+	  double a = di, b = 0.;
+	  a += w0; b += w0*right;
+	  a += w1; b += w1*left;
+	  a += w2; b += w2*top;
+	  a += w3; b += w3*bottom;
+	  v = a != 0. ? (1. - omega)*cur + omega*(b - rh)/a : 0.;
 	}
 	else {
 	  double a = di, b = 0.;
@@ -223,16 +250,22 @@ relax_rows2d_kernel (Layout L, double omega, double w, double h2,
 }
 
 static int launch_relax_rows2d (gfship_domain * dom, int level, double omega, double * u,
-				const double * rhs, const double * dia, int kind, double w, double h2)
+				const double * rhs, const double * dia, int kind, double w, double h2,
+				const RelaxOp * op)
 {
   const Layout & L = dom->lay[level];
   const int block = L.n <= 64 ? 64 : L.n <= 128 ? 128 : L.n <= 256 ? 256 : L.n <= 512 ? 512 : 1024;
-  if (kind)
+  W6 wf;
+  for (int d = 0; d < 6; d++) wf.p[d] = op ? op->wf[d] : nullptr;
+  if (kind == 2)
+    hipLaunchKernelGGL (relax_rows2d_kernel<2>, dim3 (1), dim3 (block), 0, dom->stream, L, omega, w, h2,
+			u, rhs, dia, wf);
+  else if (kind)
     hipLaunchKernelGGL (relax_rows2d_kernel<1>, dim3 (1), dim3 (block), 0, dom->stream, L, omega, w, h2,
-			u, rhs, dia);
+			u, rhs, dia, wf);
   else
     hipLaunchKernelGGL (relax_rows2d_kernel<0>, dim3 (1), dim3 (block), 0, dom->stream, L, omega, w, h2,
-			u, rhs, dia);
+			u, rhs, dia, wf);
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
 }
@@ -245,8 +278,8 @@ int launch_relax_exact (gfship_domain * dom, unsigned dimension, int level, doub
   const Layout & L = dom->lay[level];
   int n = L.n;
   static const bool rows2d = getenv ("GFSHIP_NO_ROWS2D") == nullptr;
-  if (dom->dim == 2 && dimension == 2 && kind != 2 && n >= 8 && n <= 1024 && rows2d && !dom->force_hyperplane)
-    return launch_relax_rows2d (dom, level, omega, u, rhs, dia, kind, w, h2);
+  if (dom->dim == 2 && dimension == 2 && n >= 8 && n <= 1024 && rows2d && !dom->force_hyperplane)
+    return launch_relax_rows2d (dom, level, omega, u, rhs, dia, kind, w, h2, op);
   int nplanes = dom->dim == 3 ? 3*n - 2 : 2*n - 1;
   int nthreads = dom->dim == 3 ? n*n : n;
   int block = 256;
@@ -291,7 +324,7 @@ template <int DIM, int OP>
 __global__ void __launch_bounds__(1024)
 relax_loop_lds_kernel (Layout L, BcDesc bc, unsigned dimension, double omega, double w, double h2,
 		       unsigned nrelax, double * __restrict__ u, const double * __restrict__ rhs,
-		       const double * __restrict__ dia)
+		       const double * __restrict__ dia, W6 wf)
 {
   extern __shared__ double s[];
   const int n = L.n, r = n + 2;
@@ -349,7 +382,22 @@ relax_loop_lds_kernel (Layout L, BcDesc bc, unsigned dimension, double omega, do
 	  int i = I + 1, j = n - J, k = DIM == 3 ? n - K : 0;
 	  long c = i + ssy*j + ssz*k;
 	  long g = L.idx (i, j, k);
-	  s[c] = relax_value<DIM, OP> (s, c, ssy, ssz, rhs[g], dia[g], dimension, omega, w, h2);
+	  if (OP == 2) {
+	    // the face weights of the cell live in the natural arrays (index g), u in LDS (index c)
+	    double a = dia[g], b = 0.;
+	    { const double q = wf.p[0][g]; a += q; b += q*s[c + 1]; }
+	    { const double q = wf.p[1][g]; a += q; b += q*s[c - 1]; }
+	    { const double q = wf.p[2][g]; a += q; b += q*s[c + ssy]; }
+	    { const double q = wf.p[3][g]; a += q; b += q*s[c - ssy]; }
+	    if (DIM == 3) {
+	      { const double q = wf.p[4][g]; a += q; b += q*s[c + ssz]; }
+	      { const double q = wf.p[5][g]; a += q; b += q*s[c - ssz]; }
+	    }
+	    s[c] = dimension == 2 ? (a != 0. ? (1. - omega)*s[c] + omega*(b - rhs[g])/a : 0.) :
+	      (a != 0. ? (b - rhs[g])/a : 0.);
+	  }
+	  else
+	    s[c] = relax_value<DIM, OP> (s, c, ssy, ssz, rhs[g], dia[g], dimension, omega, w, h2);
 	}
       }
       __syncthreads ();
@@ -397,11 +445,13 @@ int launch_relax_loop_small (gfship_domain * dom, unsigned dimension, int level,
   bc.homogeneous = 1;
   int nface = dom->dim == 3 ? L.n*L.n : L.n;
   int block = nface <= 64 ? 64 : nface <= 256 ? 256 : 1024;
+  W6 wf;
+  for (int d = 0; d < 6; d++) wf.p[d] = op ? op->wf[d] : nullptr;
 #define LDS_LAUNCH(D, O) hipLaunchKernelGGL ((relax_loop_lds_kernel<D, O>), dim3 (1), dim3 (block), bytes, \
 					     dom->stream, L, bc, dimension, omega, w, h2, nrelax, \
-					     dp->lev[level], rhs, dia)
-  if (dom->dim == 3) { if (kind) LDS_LAUNCH (3, 1); else LDS_LAUNCH (3, 0); }
-  else               { if (kind) LDS_LAUNCH (2, 1); else LDS_LAUNCH (2, 0); }
+					     dp->lev[level], rhs, dia, wf)
+  if (dom->dim == 3) { if (kind == 2) LDS_LAUNCH (3, 2); else if (kind) LDS_LAUNCH (3, 1); else LDS_LAUNCH (3, 0); }
+  else               { if (kind == 2) LDS_LAUNCH (2, 2); else if (kind) LDS_LAUNCH (2, 1); else LDS_LAUNCH (2, 0); }
 #undef LDS_LAUNCH
   GFSHIP_HIP (hipGetLastError ());
   *done = true;

@@ -402,6 +402,7 @@ void skew_free (gfship_domain * dom)
     if (S.us) (void) hipFree (S.us);
     if (S.rs) (void) hipFree (S.rs);
     if (S.ds) (void) hipFree (S.ds);
+    for (int d = 0; d < 6; d++) if (S.ws[d]) (void) hipFree (S.ws[d]);
     if (S.hb) (void) hipFree (S.hb);
     if (S.hbf) (void) hipFree (S.hbf);
     if (S.arm_cum) (void) hipFree (S.arm_cum);
@@ -430,6 +431,32 @@ static int skew_pack (gfship_domain * dom, int level, SkewPlan * S, const double
   dim3 grid (A.L.n/SK_T, SK_T, S->ntj*S->ntj);
   hipLaunchKernelGGL (skew_pack_kernel, grid, dim3 (SK_NL), 0, dom->stream, A);
   GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// the six face weights of a level (gfs_poisson_coefficients with alpha) into the layout of the six-wave
+// kernel: once per recomputation of the weights (weights_stamp), whatever the number of sweeps
+static int skew_pack_weights (gfship_domain * dom, int level, SkewPlan * S, const RelaxOp * op)
+{
+  if (S->ws[0] && S->ws_stamp == dom->weights_stamp)
+    return GFSHIP_OK;
+  const size_t doubles = (size_t) S->ntj*S->ntj*(S->RT + 2*SK_FP)*SK_NL + 64;
+  for (int d = 0; d < 6; d++)
+    if (!S->ws[d]) {
+      GFSHIP_HIP (hipMalloc ((void **) &S->ws[d], doubles*sizeof (double)));
+      GFSHIP_HIP (hipMemsetAsync (S->ws[d], 0, doubles*sizeof (double), dom->stream));
+    }
+  for (int h = 0; h < 2; h++) {
+    PackArgs A;
+    A.add = nullptr;
+    A.L = dom->lay[level]; A.ntj = S->ntj; A.RT = S->RT;
+    A.narr = 3;
+    for (int q = 0; q < 3; q++) { A.src[q] = op->wf[3*h + q]; A.dst[q] = S->ws[3*h + q]; }
+    dim3 grid (A.L.n/SK_T, SK_T, S->ntj*S->ntj);
+    hipLaunchKernelGGL (skew_pack_kernel, grid, dim3 (SK_NL), 0, dom->stream, A);
+    GFSHIP_HIP (hipGetLastError ());
+  }
+  S->ws_stamp = dom->weights_stamp;
   return GFSHIP_OK;
 }
 
@@ -532,6 +559,10 @@ int launch_relax_loop_skew (gfship_domain * dom, int level, Field * dp, Field * 
   if ((r = skew_plan (dom, level, &S))) return r;
   double * u = dp->lev[level];
   if ((r = skew_loop_trial (dom, level, S, nrelax, bc))) return r;
+  if (op && op->kind == 2) {
+    if ((r = skew_pack_weights (dom, level, S, op))) return r;
+    dia_zero = false;           /* the weighted cell update always reads dia */
+  }
   /* get_from_above fused into the copy into the skewed layout: the natural array gets the cells
      along the box sides only (what the BC application reads), then the BC, then the loop */
   const bool fusedp = prolong_from != nullptr && bc && patch_level (dom, level);

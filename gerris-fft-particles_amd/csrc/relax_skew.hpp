@@ -94,8 +94,11 @@ struct SkewLoopArgs {
   int near_mode;           // stores towards a consumer on the same XCD: 0 agent scope like the others, 1 plain, 2 workgroup scope
   // cell update (RelaxOp): 0 = relax (src/poisson.c:507-530, unit weights), 1 = diffusion_relax
   // (:1455-1484) with the uniform face weight w of the level and h2 = h*h; dia is then rhoc
+  // 2 = relax with the six face weights f[d].v of every cell (gfs_poisson_coefficients with a
+  // GfsFunction alpha): ws[d] are skewed copies of the weights, streamed beside u / rhs / dia
   int op;
   double w, h2;
+  const double * ws[6];
 };
 
 typedef __attribute__((address_space(1))) u64 gu64;

@@ -73,15 +73,25 @@ __device__ __forceinline__ unsigned skew_claim_tile (const SkewLoopArgs & A)
 // loads and the row stores into further waves as well was tried and lost: the hops between tiles
 // became slower and the step no faster.)
 #define SK_NTHREADS (SK_NL + 128)
+// OP == 2 (the six face weights f[d].v of every cell, gfs_poisson_coefficients with alpha): a seventh
+// wave streams the rows of the six skewed weight arrays into a ring of SK_WR slots in LDS (LDS-DMA,
+// global_load_lds: 1 KB per instruction, no registers), SK_WD steps ahead, and retires them with a
+// counted s_waitcnt one step before the compute waves read them (the weights are not on the
+// dependent chain of a step; as register streams they cost the compute waves 290 spilled VGPRs)
+#define SK_WR 6              /* ring slots: divides the unroll factor SK_D of the step loop */
+#define SK_WD 5              /* rows ahead (<= SK_WR - 1; 12*(SK_WD - 1) < 64: the vmcnt counter) */
+#define SK_WBYTES (SK_WR*6*SK_NL*sizeof (double))
+static_assert (SK_D % SK_WR == 0, "slot numbers of the weight ring must be compile-time constants");
 
 template <bool HAS_DIA, int OP>
-__global__ void __launch_bounds__(SK_NTHREADS)
+__global__ void __launch_bounds__(OP == 2 ? SK_NTHREADS + 64 : SK_NTHREADS)
 relax_skew_loop_kernel (SkewLoopArgs A)
 {
   constexpr int XS = SK_T + 1;
   __shared__ double X[2][XS*XS];
   __shared__ double Y[2][XS*XS];
   __shared__ unsigned s_tile;
+  extern __shared__ double wring[];      // OP == 2: [SK_WR][6][SK_NL] face weights of the rows t .. t + SK_WD
 
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane (tid0 >> 6);                   // wave-uniform
@@ -106,6 +116,7 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 
   double * const ut = A.us + tile*tstride + SK_FP*SK_NL;
   const bool loader = wave == SK_NL/64, storer = wave == SK_NL/64 + 1;
+  const bool weigher = OP == 2 && wave == SK_NL/64 + 2;
 #if SK_EXP & 4
   if (compute) __builtin_amdgcn_s_setprio (3);     /* experiment: compute waves first on their SIMD */
 #endif
@@ -134,7 +145,6 @@ relax_skew_loop_kernel (SkewLoopArgs A)
     const double * qR = ut + SK_NL + tid;
     const double * qRhs = A.rs + tile*tstride + SK_FP*SK_NL + tid;
     const double * qDia = HAS_DIA ? A.ds + tile*tstride + SK_FP*SK_NL + tid : nullptr;
-
     // ---- halo streams of wave 0 ----
     const u64 * qH = A.dummy;
     int hs = 0;
@@ -274,7 +284,33 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 	SK_PREFETCH (q);
     }
 
-    __syncthreads ();      // the LDS grids of the previous sweep are no longer read
+    __syncthreads ();      // the LDS grids (and the weight ring) of the previous sweep are no longer read
+    // weights wave: rows 0 .. SK_WD - 1 of the six arrays into their slots
+    const int wlane = tid0 & 63;
+    // running pointers of the six arrays (a row further per step: the addresses stay one addition away)
+    const double * wp[6];
+#define SK_WROW(slot_)							\
+    do {								\
+      _Pragma ("unroll")						\
+      for (int d_ = 0; d_ < 6; d_++) {					\
+	double * dst_ = wring + ((slot_)*6 + d_)*SK_NL;			\
+	__builtin_amdgcn_global_load_lds ((const void *) wp[d_],	\
+					  (__attribute__((address_space(3))) void *) dst_, 16, 0, 0); \
+	__builtin_amdgcn_global_load_lds ((const void *) (wp[d_] + 128),	\
+					  (__attribute__((address_space(3))) void *) (dst_ + 128), 16, 0, 0); \
+	wp[d_] += SK_NL;						\
+	asm volatile ("" : "+v" (wp[d_]));      /* six running pointers, not one per unrolled row */ \
+      }									\
+    } while (0)
+    if (weigher) {
+#pragma unroll
+      for (int d = 0; d < 6; d++)
+	wp[d] = A.ws[d] + tile*tstride + SK_FP*SK_NL + 2*wlane;
+#pragma unroll
+      for (int r = 0; r < SK_WD; r++)
+	SK_WROW (r % SK_WR);
+      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     for (int q = tid0; q < 2*XS*XS; q += SK_NTHREADS) {
       (&X[0][0])[q] = 0.;
       (&Y[0][0])[q] = 0.;
@@ -322,6 +358,23 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 	}
       }
     }
+    else if (weigher) {
+      // ---- weights wave: row t + SK_WD into the slot the compute waves read at step t - 1 ----
+      for (int t0 = 0; t0 < T; t0 += SK_D) {
+#pragma unroll
+	for (int q = 0; q < SK_D; q++) {
+	  SK_WROW ((q + SK_WD) % SK_WR);
+	  {
+	    // rows up to t + 1 have landed: s_waitcnt vmcnt (12*(SK_WD - 1)) alone (gfx9 encoding
+	    // vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
+	    constexpr int N = 12*(SK_WD - 1);
+	    static_assert (N < 64, "the vmcnt counter holds 63");
+	    __builtin_amdgcn_s_waitcnt ((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+	  }
+	  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	}
+      }
+    }
     else {
       // ---- compute waves ----
       for (int t0 = 0; t0 < T; t0 += SK_D) {
@@ -341,6 +394,18 @@ relax_skew_loop_kernel (SkewLoopArgs A)
 	  aa += 1.; bb += 1.*Bo;
 	  aa += 1.; bb += 1.*Fn;
 	  aa += 1.; bb += 1.*Bk;
+	  if (OP == 2) {
+	    // relax with the face weights of the cell (src/poisson.c:507-530, face_weighted_gradient's
+	    // same-level branch src/fluid.c:858-864: g.a = w, g.b = w*u_nb), d = 0..5
+	    aa = pDia[q]; bb = 0.;
+	    const double * const wl = wring + (q % SK_WR)*(6*SK_NL) + tid;      // slot of row t
+	    { const double g = wl[0*SK_NL]; aa += g; bb += g*Rv; }
+	    { const double g = wl[1*SK_NL]; aa += g; bb += g*prev; }
+	    { const double g = wl[2*SK_NL]; aa += g; bb += g*Tn; }
+	    { const double g = wl[3*SK_NL]; aa += g; bb += g*Bo; }
+	    { const double g = wl[4*SK_NL]; aa += g; bb += g*Fn; }
+	    { const double g = wl[5*SK_NL]; aa += g; bb += g*Bk; }
+	  }
 	  const double v = OP == 1 ? diffusion_cell (Rv, prev, Tn, Bo, Fn, Bk, pRhs[q], pDia[q], A.w, A.h2) :
 	    HAS_DIA ? (aa != 0. ? (bb - pRhs[q])/aa : 0.) : divide_by_6 (bb - pRhs[q]);
 	  prev = act ? v : prev;
@@ -379,6 +444,7 @@ relax_skew_loop_kernel (SkewLoopArgs A)
       A.un[A.L.idx (n + 1, j, k)] = ghostR;
       A.un[A.L.idx (0, j, k)] = ghostL;
     }
+#undef SK_WROW
 #undef SK_PREFETCH
 #undef SK_PREFETCH_HALO
 #undef SK_HALO
@@ -756,17 +822,22 @@ skew_loop_ghosts_kernel (SkewLoopArgs A)
 static int skew_loop_resident (gfship_domain * dom, int level)
 {
   if (dom->skew_resident < 0) {
-    int per_cu = 0, per_cu_w = 0, dev = 0;
+    int per_cu = 0, per_cu_w = 0, per_cu_2 = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice (&dev) != hipSuccess || hipGetDeviceProperties (&prop, dev) != hipSuccess ||
 	hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, relax_skew_loop_kernel<true, 1>,
 						      SK_NTHREADS, 0) != hipSuccess ||
 	hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu_w, relax_wave_loop_kernel,
-						      WV_NTHREADS, 0) != hipSuccess) {
+						      WV_NTHREADS, 0) != hipSuccess ||
+	hipFuncSetAttribute ((const void *) relax_skew_loop_kernel<true, 2>,
+			     hipFuncAttributeMaxDynamicSharedMemorySize, SK_WBYTES) != hipSuccess ||
+	hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu_2, relax_skew_loop_kernel<true, 2>,
+						      SK_NTHREADS + 64, SK_WBYTES) != hipSuccess) {
       dom->skew_resident = 0;
       dom->patch_resident = 0;
     }
     else {
+      if (per_cu_2 < per_cu) per_cu = per_cu_2;
       dom->skew_resident = (per_cu < per_cu_w ? per_cu : per_cu_w)*prop.multiProcessorCount;
       dom->patch_resident = patch_resident_per_cu ()*prop.multiProcessorCount;
     }
@@ -845,8 +916,10 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
 {
   const Layout & L = dom->lay[level];
   int ntiles = S->ntj*S->ntj;
-  GFSHIP_CHECK (!op || op->kind == 0 || (op->kind == 1 && has_dia), GFSHIP_EUNSUPPORTED,
-		"the pipelined sweep knows the Poisson and the diffusion cell updates");
+  GFSHIP_CHECK (!op || op->kind == 0 || ((op->kind == 1 || op->kind == 2) && has_dia), GFSHIP_EUNSUPPORTED,
+		"the pipelined sweep knows the Poisson (unit or per-face weights) and the diffusion cell updates");
+  GFSHIP_CHECK (!op || op->kind != 2 || (S->ws[0] && !patch_level (dom, level)), GFSHIP_EINVAL,
+		"weighted sweep without the skewed copies of the face weights");
   /* 8 words in front of the granules: the ticket counter, armed with them (it then counts from all
      ones: the claims add one).  Two sets of granules used in turn.  With GFSHIP_KERNEL_ARMING=1 the
      2 x 2 loop kernels arm the other set for the next loop of this level themselves, while their
@@ -915,6 +988,7 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   A.op = op ? op->kind : 0;
   A.w = op ? op->w : 1.;
   A.h2 = op ? op->h2 : 1.;
+  for (int d = 0; d < 6; d++) A.ws[d] = S->ws[d];
   { const char * e = getenv ("GFSHIP_FAULT_DROP_HANDOFF"); A.fault_tile = e ? atoi (e) : -1; }
   if (patch_level (dom, level)) {
     /* the 2 x 2 kernels, GFSHIP_XCD_SCOPE=1: XCD blocks + narrower-scope stores towards consumers on
@@ -952,6 +1026,16 @@ int skew_loop_run (gfship_domain * dom, int level, SkewPlan * S, double * u_nat,
   if (ms) GFSHIP_HIP (hipEventRecord (dom->ev0, dom->stream));
   if (A.op == 1)                                     /* diffusion_relax */
     hipLaunchKernelGGL ((relax_skew_loop_kernel<true, 1>), dim3 (ntiles), dim3 (SK_NTHREADS), 0, dom->stream, A);
+  else if (A.op == 2) {                              /* relax with the face weights of every cell */
+    static bool attr = false;
+    if (!attr) {
+      GFSHIP_HIP (hipFuncSetAttribute ((const void *) relax_skew_loop_kernel<true, 2>,
+				       hipFuncAttributeMaxDynamicSharedMemorySize, SK_WBYTES));
+      attr = true;
+    }
+    hipLaunchKernelGGL ((relax_skew_loop_kernel<true, 2>), dim3 (ntiles), dim3 (SK_NTHREADS + 64), SK_WBYTES,
+			dom->stream, A);
+  }
   else if (dom->wave_loop && nrelax >= 2 && !has_dia)     /* one compute wave per tile */
     hipLaunchKernelGGL (relax_wave_loop_kernel, dim3 (ntiles), dim3 (WV_NTHREADS), 0, dom->stream, A);
   else if (has_dia)

@@ -533,7 +533,13 @@ def _alpha_pair(od, gd, rng, kind):
 
 
 @pytest.mark.parametrize("dim,level,kind", [(2, 5, "dirichlet"), (2, 4, "periodic"), (3, 4, "dirichlet"),
-                                            (3, 4, "periodic"), (3, 3, "mixed")])
+                                            (3, 4, "periodic"), (3, 3, "mixed"),
+                                            # levels of the pipelined weighted sweeps: the tile kernel with the
+                                            # six weight rows streamed through LDS (3-D, 32^3 and more: the whole
+                                            # loop in one launch on the periodic box, sweep by sweep otherwise),
+                                            # one launch per sweep by rows in 2-D
+                                            (3, 5, "periodic"), (3, 6, "dirichlet"), (3, 5, "mixed"),
+                                            (3, 6, "periodic"), (2, 7, "periodic"), (2, 8, "dirichlet")])
 def test_poisson_coefficients_with_alpha_bit_exact(dim, level, kind):
     """the face weights of every level (leaf faces from alpha, coarser cells by face_coeff_from_below),
     then sweeps, residual, V-cycles and a solve with them: everything equal to the oracle's bits"""
