@@ -280,6 +280,8 @@ int launch_project_correct (gfship_domain * dom, const double * p, double * cons
 int launch_cfl_from_max (gfship_domain * dom, double * cfl2);
 int launch_face_interp_div (gfship_domain * dom, double * const u[3], double * const un[3] /* or nullptr */,
 			    double * div, double dt);
+int launch_project_correct_weighted (gfship_domain * dom, const double * p, double * const un[3],
+				     double * const g[3], double * const u[3], double dt);
 int launch_project_correct_lazy (gfship_domain * dom, const double * p, double * const u[3],
 				 double * const g[3], double * const uo[3], double dt);
 // div != nullptr: the caller's next operation is the MAC projection with time step div_dt; where the

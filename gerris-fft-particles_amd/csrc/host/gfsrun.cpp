@@ -179,6 +179,12 @@ struct Run {
   Function * stream_function = nullptr;          // GfsVariableStreamFunction (2-D, GfsAdvection)
   std::vector<std::pair<std::string, Function *>> init;   // Init {} { var = f }
   double source[3] = { 0., 0., 0. };    // GfsSource intensities on U, V, W
+  // GfsPhysicalParams { alpha = f }: the inverse of the density, a function of x, y, z, t and tracers,
+  // evaluated on the faces before every step (gfs_function_face_value, src/utils.c:1268-1297)
+  Function * alpha = nullptr;
+  int alpha_line = 0;
+  gfship_field alpha_dev[3] = { -1, -1, -1 };
+  bool alpha_static = false;             // no variable and no t in it: evaluated once
   std::vector<Variable> vars;
   std::vector<std::string> device_vars;   // variables of the file that live on the device (GfsVariableTurbulentViscosity)
   std::vector<std::unique_ptr<Event>> events;
@@ -684,6 +690,26 @@ void parse_object (Run & R, Reader & r)
     if (t.block || !Reader::is_number (t.text))
       r.fail ("only a constant intensity is supported");
     R.source[c] += atof (t.text.c_str ());        /* several sources on a variable add up */
+  }
+  else if (cls == "PhysicalParams") {
+    // gfs_physical_params_read, src/simulation.c:1760-1835: g, L constants, alpha a GfsFunction
+    int l0 = r.line ();
+    Reader b (r.braces (), "simulation file", l0);
+    while (!b.eof ()) {
+      std::string key = b.word ();
+      b.expect ('=');
+      if (key == "alpha") {
+	R.alpha = R.functions.add (b.function (), b.line ());
+	R.alpha_line = b.line ();
+      }
+      else if (key == "L" || key == "g") {
+	FunctionText t = b.function ();
+	if (t.block || !Reader::is_number (t.text) || atof (t.text.c_str ()) != 1.)
+	  b.fail ("GfsPhysicalParams: only " + key + " = 1 is supported (got `" + t.text + "')");
+      }
+      else
+	b.fail ("unknown keyword `" + key + "'");
+    }
   }
   else if (cls == "VariableTracer") {
     std::string name = r.word (false);
@@ -1846,6 +1872,67 @@ int run_tree (Run & R)
   return 0;
 }
 
+// GfsPhysicalParams { alpha }: gfs_function_face_value (alpha, face) of every leaf face -- the function at
+// the centre of the face (ftt_face_pos), the variables it names interpolated onto the face
+// (gfs_face_interpolated_value, src/fluid.c:2186-2198: ((x1 - 0.5) v0 + 0.5 v1)/x1 with x1 = 1 between
+// cells of one level) -- in the layout gfship_poisson_coefficients_alpha takes: the entry of a cell is
+// its + face along c, the ghost entry in front of the first cell its - face.  Both projections of a
+// step evaluate alpha with the same time and the same tracers (gfs_advance_tracers comes last in the
+// loop body, src/simulation.c:479-548): once before every step.
+int refresh_alpha (Run & R)
+{
+  if (!R.alpha || (R.alpha_static && R.alpha_dev[0] >= 0))
+    return 0;
+  const Function * f = R.alpha;
+  const int n = R.n ();
+  const double h = 1./n;
+  std::vector<const std::vector<double> *> vals;
+  std::vector<int> used;
+  if (f->kind == Function::VARIABLE) used.push_back (f->var);
+  else if (f->kind == Function::COMPILED) used = f->args;
+  for (int a : used) {
+    /* the values beyond the box sides are those of the boundary conditions (the reference's ghost cells
+       hold them at this point: gfs_simulation_init / the end of the tracer's advection) */
+    Variable & V = R.vars[a];
+    CHECK (gfship_bc (R.dom, V.dev, V.dev, R.level));
+    V.host_time = -1.;
+    vals.push_back (&host_of (R, a));
+  }
+  if (vals.size () > 32) { fprintf (stderr, "gfship: too many variables in alpha\n"); return 1; }
+  bool first = R.alpha_dev[0] < 0;
+  std::vector<double> a (R.total ());
+  for (int c = 0; c < R.dim; c++) {
+    std::fill (a.begin (), a.end (), 0.);
+    const size_t off = c == 0 ? 1 : c == 1 ? R.idx (0, 1, 0) - R.idx (0, 0, 0) :
+      R.idx (0, 0, 1) - R.idx (0, 0, 0);
+    int lo[3] = { 1, 1, R.dim == 3 ? 1 : 0 }, hi[3] = { n, n, R.dim == 3 ? n : 0 };
+    lo[c] = 0;
+    for (int k = lo[2]; k <= hi[2]; k++)
+      for (int j = lo[1]; j <= hi[1]; j++)
+	for (int i = lo[0]; i <= hi[0]; i++) {
+	  const size_t cell = R.idx (i, j, k);
+	  double p[3];
+	  cell_pos (R, i, j, k, p);
+	  p[c] += h/2.;
+	  double v[32];
+	  for (size_t q = 0; q < vals.size (); q++) {
+	    const double x1 = 1., v0 = (*vals[q])[cell], v1 = (*vals[q])[cell + off];
+	    v[q] = ((x1 - 0.5)*v0 + 0.5*v1)/x1;
+	  }
+	  a[cell] = f->kind == Function::CONSTANT ? f->val : f->kind == Function::VARIABLE ? v[0] :
+	    f->fn (p[0], p[1], p[2], R.t, v);
+	}
+    if (first) {
+      R.alpha_dev[c] = gfship_field_alloc (R.dom, -1);
+      CHECK (R.alpha_dev[c]);
+    }
+    CHECK (gfship_field_upload (R.dom, R.alpha_dev[c], R.level, a.data ()));
+  }
+  if (first)
+    CHECK (gfship_sim_set_alpha (R.sim, R.alpha_dev));
+  return 0;
+}
+
 int run (Run & R)
 {
   R.clock0 = std::chrono::steady_clock::now ();
@@ -1854,6 +1941,23 @@ int run (Run & R)
   add_derived (R);
   R.functions.resolve (R.var_names ());
   resolve_refine (R);
+  if (R.alpha) {
+    if (R.tree_mode || R.sim_class != "Simulation") {
+      fprintf (stderr, "gfship: line %d: GfsPhysicalParams { alpha } is supported for a GfsSimulation on a uniform box\n", R.alpha_line);
+      return 1;
+    }
+    std::vector<int> used;
+    if (R.alpha->kind == Function::VARIABLE) used.push_back (R.alpha->var);
+    else if (R.alpha->kind == Function::COMPILED) used = R.alpha->args;
+    for (int v : used)
+      if (std::find (R.tracers.begin (), R.tracers.end (), R.vars[v].name) == R.tracers.end ()) {
+	/* anything else changes between the two projections of a step */
+	fprintf (stderr, "gfship: line %d: alpha may depend on x, y, z, t and tracers (got `%s')\n",
+		 R.alpha_line, R.vars[v].name.c_str ());
+	return 1;
+      }
+    R.alpha_static = used.empty () && !(R.alpha->kind == Function::COMPILED && R.alpha->uses_t);
+  }
   if (R.tree_mode)
     return run_tree (R);
   open_pipes (R);
@@ -2055,12 +2159,15 @@ int run (Run & R)
     // simulation_run, src/simulation.c:432-557
     CHECK (gfship_sim_set_time (R.sim, R.end, R.dtmax));
     CHECK (gfship_sim_set_next_event (R.sim, next_event_hook, &R));
+    if (refresh_alpha (R)) return 1;
     CHECK (gfship_sim_start (R.sim));
+    if (R.alpha && !R.alpha_static) invalidate_device_copies (R);   /* the half step of the tracers */
     while (R.t < R.end && R.i < R.iend) {
       events_do (R);
       /* a GfsEventStop may just have set time.end = time.t: the reference still completes this
 	 iteration of the loop and stops at the next test of its condition */
       CHECK (gfship_sim_set_time (R.sim, R.end, R.dtmax));
+      if (refresh_alpha (R)) return 1;
       CHECK (gfship_sim_step (R.sim));
       R.t = gfship_sim_time (R.sim);
       R.i = gfship_sim_iter (R.sim);

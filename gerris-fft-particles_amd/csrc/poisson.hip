@@ -241,6 +241,7 @@ int gfship_poisson_coefficients_alpha (gfship_domain * dom, const gfship_field a
   int r = launch_poisson_weights (dom, a);
   if (r) return r;
   dom->weighted = true;
+  dom->weights_stamp++;         /* the skewed copies of the pipelined sweeps are stale */
   dom->unit_weights = true;     /* "coefficients have been set" for the checks of the entry points */
   return GFSHIP_OK;
 }

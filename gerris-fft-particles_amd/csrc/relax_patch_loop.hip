@@ -1133,8 +1133,10 @@ patch_prolong_kernel (PatchPackArgs A)
   }
 }
 
+#ifndef PP_ROWS
 #define PP_ROWS 16
-#define PP_SPAN (PP_ROWS + 7)     /* cells along I touched by 16 rows of the 8 lanes of a B */
+#endif
+#define PP_SPAN (PP_ROWS + 7)     /* cells along I touched by PP_ROWS rows of the 8 lanes of a B */
 
 __global__ void __launch_bounds__(256)
 patch_pack_kernel (PatchPackArgs A)
@@ -1229,8 +1231,8 @@ patch_restrict_pack_kernel (PatchRestrictArgs A)
       A.dst[tbase + (long) rho*SK_NL + 128*(p >> 1) + 2*(PA + 8*PB) + (p & 1)] = buf[a + 16*db][I - I0];
   }
   // the coarse cells whose first child (I = 2 m) sits in one of this block's rows
-  if (tid < 8*PP_ROWS) {
-    const int PA = tid & 7, row = tid >> 3;
+  for (int e = tid; e < 8*PP_ROWS; e += 256) {
+    const int PA = e & 7, row = e >> 3;
     const int I = r0 + row - PA - PB;
     if (I >= 0 && I < n && !(I & 1)) {
       const int di = I - I0;

@@ -23,6 +23,10 @@ struct gfship_sim {
   double t = 0., end = DBL_MAX, dtmax = DBL_MAX, tnext = 0.;
   unsigned i = 0, iend = G_MAXINT;
   double visc[3] = {0., 0., 0.};   // GfsSourceDiffusion on U, V, W (constant coefficient)
+  // GfsPhysicalParams { alpha = ... }: gfs_function_face_value (alpha) on the faces normal to c, in the
+  // layout gfship_poisson_coefficients_alpha takes (gfship_sim_set_alpha); has_alpha = false: alpha = NULL
+  gfship_field alpha[3] = {-1, -1, -1};
+  bool has_alpha = false;
   gfship_multilevel_params diffusion_params[3];
   gfship_field drhs = -1, rhoc = -1;   // temporaries of variable_diffusion
   bool cfl_ready = false;              // maxima for the CFL condition left by the last projection
@@ -105,8 +109,13 @@ int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, g
   ptrs3 (s, g, gp);
   ptrs3 (s, s->u, u);
   /* gfs_reset_gradients + no face sources: g is overwritten by centered_gradient below */
-  /* gfs_poisson_coefficients (alpha = NULL): unit weights */
-  TRY (gfship_poisson_coefficients (dom));
+  /* gfs_poisson_coefficients: unit weights for alpha = NULL, else the face weights of every level */
+  if (s->has_alpha) {
+    TRY (gfship_poisson_coefficients_alpha (dom, s->alpha));
+    lazy = false;
+  }
+  else
+    TRY (gfship_poisson_coefficients (dom));
   /* dia = 0 on all levels (gfs_cell_reset on FTT_TRAVERSE_ALL) */
   for (int l = 0; l <= dom->depth; l++)
     if (!dom->fields[s->dia].zero[l])
@@ -134,7 +143,12 @@ int mac_projection (gfship_sim * s, gfship_multilevel_params * par, double dt, g
   bool want_max = approximate;
   for (int c = 0; c < dom->dim; c++)
     if (s->visc[c] != 0. || dom->src[c] != 0.) want_max = false;   /* the acceleration term needs the full kernel */
-  if (lazy) {
+  if (s->has_alpha) {
+    /* the same pass with gfs_face_weighted_gradient's weights (the CFL maxima come from their own pass) */
+    want_max = false;
+    TRY (launch_project_correct_weighted (dom, leaf (s, p), un, gp, approximate ? u : nullptr, dt));
+  }
+  else if (lazy) {
     /* g and the corrected centred velocities (out of place: the faces read uncorrected neighbours), the
        maxima of |un|, |u| for the CFL condition; the storage of U, V, W is swapped with the scratch */
     const int L = dom->depth;
@@ -218,7 +232,7 @@ int variable_sources (gfship_sim * s, gfship_field v, gfship_field sv, int gradi
   ptrs3 (s, s->un, un);
   ptrs6 (s, fv);
   int c = s->dom->fields[v].component;
-  if (godunov_fused_supported (s->dom)) {
+  if (godunov_fused_supported (s->dom) && gradient <= 1) {      /* limiters 2 .. 4: the general path */
     /* periodic box: face values recomputed inside the flux kernel, no face-value arrays */
     gfship_domain * dom = s->dom;
     const int L = dom->depth;
@@ -399,11 +413,33 @@ int gfship_sim_set_source (gfship_sim * s, int c, double intensity)
   return GFSHIP_OK;
 }
 
+int gfship_sim_set_alpha (gfship_sim * s, const gfship_field alpha[3])
+{
+  GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
+  if (!alpha) {
+    s->has_alpha = false;
+    return GFSHIP_OK;
+  }
+  for (int c = 0; c < s->dom->dim; c++) {
+    GFSHIP_CHECK (get_field (s->dom, alpha[c]) != nullptr, GFSHIP_EINVAL, "alpha[%d] is not a field of the domain", c);
+    s->alpha[c] = alpha[c];
+  }
+  for (int c = 0; c < s->dom->dim; c++)
+    GFSHIP_CHECK (s->visc[c] == 0., GFSHIP_EUNSUPPORTED,
+		  "GfsSourceDiffusion together with GfsPhysicalParams { alpha } (gfs_diffusion_coefficients "
+		  "with a variable density, src/poisson.c:1280-1348) is not supported");
+  s->has_alpha = true;
+  s->cfl_ready = false;
+  return GFSHIP_OK;
+}
+
 int gfship_sim_set_viscosity (gfship_sim * s, int c, double nu)
 {
   GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
   GFSHIP_CHECK (c >= 0 && c < s->dom->dim, GFSHIP_EINVAL, "component %d out of range", c);
   GFSHIP_CHECK (nu >= 0., GFSHIP_EINVAL, "the diffusion coefficient must be positive");
+  GFSHIP_CHECK (nu == 0. || !s->has_alpha, GFSHIP_EUNSUPPORTED,
+		"GfsSourceDiffusion together with GfsPhysicalParams { alpha } is not supported");
   s->visc[c] = nu;
   return GFSHIP_OK;
 }
@@ -446,7 +482,8 @@ static int predicted_face_velocities (gfship_sim * s, double mac_dt)
   s->un_lazy = false;                  /* every face is rewritten below */
   /* the reset of every face (gfs_face_reset_normal_velocity) is implied: each component's
      faces are all overwritten below */
-  if (godunov_fused_supported (s->dom) || godunov_fused_mpi_supported (s->dom)) {
+  if ((godunov_fused_supported (s->dom) || godunov_fused_mpi_supported (s->dom)) &&
+      s->advection_params.gradient <= 1) {
     double * u[3], * un[3];
     ptrs3 (s, s->u, u);
     ptrs3 (s, s->un, un);
@@ -506,7 +543,7 @@ static int centered_velocity_advection (gfship_sim * s, const gfship_field gmac[
   if (corrected) *corrected = false;
   if (u_coarse) *u_coarse = false;
   if (s->dom->dim == 3 && (godunov_fused_supported (s->dom) || godunov_fused_mpi_supported (s->dom)) &&
-      !s->dom->no_fused_godunov3 &&
+      !s->dom->no_fused_godunov3 && s->advection_params.gradient <= 1 &&
       s->visc[0] == 0. && s->visc[1] == 0. && s->visc[2] == 0.) {
     /* the three components in one pass over the box (same MAC velocities, nothing of one component
        feeds another): into scratch leaf levels, then the storage is swapped */
@@ -674,7 +711,8 @@ int gfship_sim_set_tracer_gradient (gfship_sim * s, int t, int gradient)
 {
   GFSHIP_CHECK (s != nullptr, GFSHIP_EINVAL, "null simulation");
   GFSHIP_CHECK (t >= 0 && (size_t) t < s->tracers.size (), GFSHIP_EINVAL, "no tracer %d", t);
-  GFSHIP_CHECK (gradient == 0 || gradient == 1, GFSHIP_EINVAL, "gradient: 0 centred, 1 van Leer");
+  GFSHIP_CHECK (gradient >= 0 && gradient <= 4, GFSHIP_EINVAL,
+		"gradient: 0 centred, 1 van Leer, 2 minmod, 3 superbee, 4 sweby");
   s->tracer_gradient[t] = gradient;
   return GFSHIP_OK;
 }
@@ -749,8 +787,14 @@ int gfship_sim_start (gfship_sim * s)
        bit */
     double * gp[3];
     ptrs3 (s, s->g, gp);
-    TRY (gfship_poisson_coefficients (s->dom));
-    TRY (launch_centered_gradient (s->dom, leaf (s, s->p), gp));
+    if (s->has_alpha) {
+      TRY (gfship_poisson_coefficients_alpha (s->dom, s->alpha));
+      TRY (launch_project_correct_weighted (s->dom, leaf (s, s->p), nullptr, gp, nullptr, 0.));
+    }
+    else {
+      TRY (gfship_poisson_coefficients (s->dom));
+      TRY (launch_centered_gradient (s->dom, leaf (s, s->p), gp));
+    }
     for (int c = 0; c < s->dom->dim; c++)
       TRY (bc_leaf (s, s->g[c]));
   }

@@ -273,6 +273,69 @@ project_correct_kernel (Layout L, const double * __restrict__ p, Ptr3 un, Ptr3 g
   }
 }
 
+// The same pass with the face weights f[d].v of gfs_poisson_coefficients with a GfsFunction alpha
+// (GfsPhysicalParams { alpha = ... }: variable density): correct_normal_velocity, src/timestep.c:118-144,
+// takes gfs_face_weighted_gradient (src/fluid.c:858-864: g.a = w, g.b = w*p_nb) with the weight of the
+// cell the face traversal visits the face FROM -- the cell on the low side (its direction 2 c), except
+// for the faces on the low side of the box, visited from the border cell in its direction 2 c + 1
+// (src/ftt.c:2152-2215).  dp = (w p_nb - w p_cell)/h either way (the change of sign of an odd direction
+// is exact).  un == nullptr: gfs_update_gradients (dt = 0: the face velocities stay as they are).
+struct W6t { const double * p[6]; };
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+project_correct_weighted_kernel (Layout L, const double * __restrict__ p, Ptr3 un, Ptr3 g, Ptr3 u,
+				 double dt, W6t wf)
+{
+  const int i1 = blockIdx.x*blockDim.x + threadIdx.x + 1;
+  const int j = blockIdx.y;
+  const int k = DIM == 3 ? blockIdx.z : 0;
+  const int n = L.n;
+  const double rn = (double) n;
+  const long off[3] = { 1, L.sy, L.sz };
+  auto body = [&] (int i) {
+    const long c = L.idx (i, j, k);
+    const int q[3] = { i, j, k };
+    const bool interior = i >= 1 && j >= 1 && (DIM == 2 || k >= 1);
+#pragma unroll
+    for (int cc = 0; cc < DIM; cc++) {
+      const bool valid = face_valid<DIM> (n, cc, i, j, k);
+      if (valid || interior) {
+	// + face of c: visited from c unless c is the ghost cell in front of the box
+	const double wp = q[cc] >= 1 ? wf.p[2*cc][c] : wf.p[2*cc + 1][c + off[cc]];
+	double dpp = (wp*p[c + off[cc]] - wp*p[c])*rn;
+	dpp /= 1.;
+	if (valid && un.p[cc]) {
+	  double w = un.p[cc][c];
+	  w -= dpp*dt;
+	  un.p[cc][c] = w;
+	}
+	if (interior) {
+	  // - face of c: visited from the cell below unless that is the ghost cell
+	  const double wm = q[cc] >= 2 ? wf.p[2*cc][c - off[cc]] : wf.p[2*cc + 1][c];
+	  double dpm = (wm*p[c] - wm*p[c - off[cc]])*rn;
+	  dpm /= 1.;
+	  double v = 0.;
+	  v += dpm*1.;
+	  v += dpp*1.;
+	  double gg = v/2.;
+	  g.p[cc][c] = gg;
+	  if (u.p[cc]) {
+	    double w = u.p[cc][c];
+	    w -= gg*dt;
+	    u.p[cc][c] = w;
+	  }
+	}
+      }
+    }
+  };
+  if (i1 <= n) {
+    body (i1);
+    if (i1 == 1)
+      body (0);
+  }
+}
+
 // The update of the approximate projection when nobody reads the corrected MAC velocities before the
 // next predictor overwrites them (the loop body of simulation_run without tracers): the face
 // velocities are not stored at all -- un = face_interp (u) - dp dt is formed in registers for the
@@ -443,6 +506,34 @@ __device__ __forceinline__ double van_leer_gradient (double v0, double v1, doubl
   return s1;
 }
 
+// gfs_center_minmod_gradient / superbee / sweby (src/fluid.c:563-690): center_limited_gradient with
+// generic_limiter (r, beta), beta = 1, 2, 1.5; both neighbours at the same level (x1 = x2 = 1.)
+__device__ __forceinline__ double limited_gradient (double v0, double v1, double v2, double beta)
+{
+  const double x1 = 1., x2 = 1.;
+  if (v0 == v1)
+    return 0.;
+  const double r = (v2 - v0)*x1/((v0 - v1)*x2);
+  double l1 = GMIN (r, beta), l2 = GMIN (beta*r, 1.);
+  l1 = GMAX (0., l1);
+  const double lim = GMAX (l1, l2);
+  return lim*(v0 - v1)/x1;
+}
+
+// GfsAdvectionParams.gradient / GfsVariableTracer { gradient = }: 0 gfs_center_gradient, 1 van Leer,
+// 2 minmod, 3 superbee, 4 sweby (the kernels with the gradient as a template parameter know 0 and 1:
+// the limiters of kinds 2 .. 4 run on the general path)
+__device__ __forceinline__ double cell_gradient (int kind, double v0, double v1, double v2)
+{
+  switch (kind) {
+  case 0: return center_gradient (v0, v1, v2);
+  case 1: return van_leer_gradient (v0, v1, v2);
+  case 2: return limited_gradient (v0, v1, v2, 1.);
+  case 3: return limited_gradient (v0, v1, v2, 2.);
+  default: return limited_gradient (v0, v1, v2, 1.5);
+  }
+}
+
 // source_diffusion_value, src/source.c:1105-1144: the explicit diffusion term of an implicit
 // GfsSourceDiffusion with constant coefficient D (gfs_face_gradient at the cell's level:
 // e.a = 1., e.b = neighbour value), used as MAC source of the predictor and in the CFL scale
@@ -493,7 +584,7 @@ advected_face_values_kernel (Layout L, const double * __restrict__ v, CPtr3 u, C
       dt*vel[cc]/size :
       dt*(un.p[cc][c] + un.p[cc][c - off[cc]])/(2.*size);
     double v1 = v[c - off[cc]], v2 = v[c + off[cc]];
-    double g = gradient ? van_leer_gradient (v0, v1, v2) : center_gradient (v0, v1, v2);
+    double g = cell_gradient (gradient, v0, v1, v2);
     double vl = v0 + GMIN ((1. - unorm)/2., 0.5)*g;
     double vr = v0 + GMAX ((- 1. - unorm)/2., -0.5)*g;
     /* gfs_variable_mac_source, src/source.c:38-59 */
@@ -2717,6 +2808,29 @@ int launch_project_correct (gfship_domain * dom, const double * p, double * cons
     if (u) hipLaunchKernelGGL ((project_correct_kernel<2, true>), grid, block, 0, dom->stream, L, p, m3 (un), m3 (g), m3 (u), dt, pm);
     else   hipLaunchKernelGGL ((project_correct_kernel<2, false>), grid, block, 0, dom->stream, L, p, m3 (un), m3 (g), none, dt, pm);
   }
+  GFSHIP_HIP (hipGetLastError ());
+  return GFSHIP_OK;
+}
+
+// gfs_correct_normal_velocities + gfs_scale_gradients (+ gfs_correct_centered_velocities) with the face
+// weights of the domain (gfship_poisson_coefficients_alpha); un == nullptr: gfs_update_gradients
+int launch_project_correct_weighted (gfship_domain * dom, const double * p, double * const un[3] /* or nullptr */,
+				     double * const g[3], double * const u[3] /* or nullptr */, double dt)
+{
+  const int Lv = dom->depth;
+  const Layout & L = dom->lay[Lv];
+  dim3 grid, block;
+  ext1_grid (L, &grid, &block);
+  W6t wf;
+  for (int d = 0; d < 6; d++)
+    wf.p[d] = d < 2*dom->dim ? dom->fields[dom->wf[d]].lev[Lv] : nullptr;
+  Ptr3 none = { { nullptr, nullptr, nullptr } };
+  if (dom->dim == 3)
+    hipLaunchKernelGGL ((project_correct_weighted_kernel<3>), grid, block, 0, dom->stream, L, p,
+			un ? m3 (un) : none, m3 (g), u ? m3 (u) : none, dt, wf);
+  else
+    hipLaunchKernelGGL ((project_correct_weighted_kernel<2>), grid, block, 0, dom->stream, L, p,
+			un ? m3 (un) : none, m3 (g), u ? m3 (u) : none, dt, wf);
   GFSHIP_HIP (hipGetLastError ());
   return GFSHIP_OK;
 }

@@ -96,6 +96,7 @@ SIGNATURES = {
     "gfship_sim_iter": (_u, [_vp]),
     "gfship_sim_add_tracer": (_i, [_vp]),
     "gfship_sim_set_viscosity": (_i, [_vp, _i, _d]),
+    "gfship_sim_set_alpha": (_i, [_vp, _pi]),
     "gfship_sim_set_source": (_i, [_vp, _i, _d]),
     "gfship_sim_diffusion_params": (C.POINTER(MultilevelParams), [_vp, _i]),
     "gfship_sim_start": (_i, [_vp]),
@@ -508,6 +509,14 @@ class Simulation:
     def set_source(self, c, g):
         """GfsSource {} U/V/W g: constant intensity"""
         _check(lib().gfship_sim_set_source(self.ptr, c, float(g)))
+
+    def set_alpha(self, alpha):
+        """GfsPhysicalParams { alpha }: dim Variables of face values (None: alpha = NULL)"""
+        if alpha is None:
+            _check(lib().gfship_sim_set_alpha(self.ptr, None))
+            return
+        h = (C.c_int * 3)(*([v.h for v in alpha] + [-1] * (3 - len(alpha))))
+        _check(lib().gfship_sim_set_alpha(self.ptr, h))
 
     def set_viscosity(self, c, nu):
         """SourceDiffusion {} U|V|W nu"""

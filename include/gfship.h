@@ -121,10 +121,11 @@ int  gfship_poisson_coefficients (gfship_domain * dom);
    face) of the leaf faces normal to c in the layout of a variable (the entry of a cell is its + face
    along c, the ghost entry in front of the first cell its - face).  Sets f[d].v of every cell of
    every level (poisson_coeff :769-797, face_coeff_from_below :826-853 with its one-neighbour rule);
-   relax, residual, cycle and solve then use them (exact sweep order, one launch per hyperplane: the
-   pipelined kernels are for the constant-density case).  alpha = NULL: gfship_poisson_coefficients.
-   The projections of a gfship_sim keep alpha = NULL (GfsPhysicalParams { alpha = ... } is not
-   supported at that level).  gfship_poisson_weights: the variable holding f[d].v, d = 0 .. 2 dim - 1. */
+   relax, residual, cycle and solve then use them (exact sweep order; 3-D levels of 32^3 and more on the
+   pipelined tile kernel with the six weight rows streamed beside u / rhs / dia, 2-D levels in one
+   launch per sweep).  alpha = NULL: gfship_poisson_coefficients.  The projections of a gfship_sim take
+   the alpha of gfship_sim_set_alpha.  gfship_poisson_weights: the variable holding f[d].v,
+   d = 0 .. 2 dim - 1. */
 int  gfship_poisson_coefficients_alpha (gfship_domain * dom, const gfship_field alpha[3]);
 int  gfship_poisson_weights (gfship_domain * dom, int d, gfship_field * w);
 /* gfs_relax, src/poisson.c:604-632: one in-place sweep of level `level` */
@@ -220,6 +221,14 @@ int      gfship_sim_set_tracer_gradient (gfship_sim * sim, int tracer, int gradi
    velocity component c (0. removes it), and the GfsMultilevelParams of its solver
    (tolerance 1e-6, beta 1: diffusion_init, src/source.c:966-974) */
 int      gfship_sim_set_viscosity (gfship_sim * sim, int c, double nu);
+/* GfsPhysicalParams { alpha = ... } (src/simulation.c:1306-1440): the inverse of the density as
+   gfs_function_face_value (alpha, face) on the leaf faces, alpha[c] in the layout of
+   gfship_poisson_coefficients_alpha (kept by handle: the caller may rewrite the fields between steps
+   when alpha depends on time or on a tracer).  Both projections then run gfs_poisson_coefficients
+   with it (src/timestep.c:376), the multigrid with the face weights, and gfs_correct_normal_velocities
+   / gfs_update_gradients with gfs_face_weighted_gradient's weights (:118-144,306-322).  NULL: alpha =
+   NULL again.  Not together with GfsSourceDiffusion (variable-density diffusion coefficients). */
+int      gfship_sim_set_alpha (gfship_sim * sim, const gfship_field alpha[3]);
 /* GfsSource {} U|V|W g (src/source.c:362-500) with a constant intensity g on velocity component c
    (0. removes it): a body force per unit mass -- the MAC source of gfs_cell_advected_face_values
    (src/advection.c:88, gfs_variable_mac_source), the centred source added at the end of

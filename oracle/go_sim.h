@@ -21,6 +21,9 @@ typedef struct GoSim {
   double src[3];                 /* GfsSource {} U g: constant intensity (src/source.c:398-403,476-481), 0 = none */
   GoMultilevelParams diffusion_params[3]; /* GfsDiffusion.par (source.c:966-974) */
   unsigned i, iend;
+  /* GfsPhysicalParams { alpha = ... } (simulation.c:1306-1440) as gfs_function_face_value (alpha) on the
+   * leaf faces: alpha[c] in the layout go_poisson_coefficients_alpha takes; NULL = alpha NULL */
+  GoField * alpha[3];
 } GoSim;
 
 GoSim * go_sim_new (int dim, int depth, const int side[6]);
@@ -54,6 +57,7 @@ void    go_advection_step (GoSim * s);
 void    go_divergence (GoSim * s, GoField * out);
 void    go_sim_set_viscosity (GoSim * s, int c, double nu);
 void    go_sim_set_source (GoSim * s, int c, double g);
+void    go_sim_set_alpha (GoSim * s, GoField * const alpha[3]);
 GoMultilevelParams * go_sim_diffusion_params (GoSim * s, int c);
 /* go_diffusion.c */
 double  go_source_diffusion_value (GoSim * s, GoField * phi, int cell, double D);

@@ -140,6 +140,24 @@ void go_sim_set_time (GoSim * s, double end, double dtmax)
 
 void go_sim_set_viscosity (GoSim * s, int c, double nu) { s->visc[c] = nu; }
 void go_sim_set_source (GoSim * s, int c, double g) { s->src[c] = g; }
+void go_sim_set_alpha (GoSim * s, GoField * const alpha[3])
+{
+  for (int c = 0; c < 3; c++)
+    s->alpha[c] = alpha && c < s->dom->dim ? alpha[c] : NULL;
+}
+
+/* gfs_poisson_coefficients (domain, alpha, ...) of the projections, timestep.c:318,376 */
+static void sim_poisson_coefficients (GoSim * s)
+{
+  if (s->alpha[0]) {
+    double * a[3] = { NULL, NULL, NULL };
+    for (int c = 0; c < s->dom->dim; c++)
+      a[c] = s->alpha[c]->lev[s->dom->depth];
+    go_poisson_coefficients_alpha (s->dom, a);
+  }
+  else
+    go_poisson_coefficients (s->dom);
+}
 
 /* gfs_variable_mac_source (source.c:38-59) of a velocity component: the sum over its sources that
  * have a mac_value -- the explicit diffusion term of an implicit GfsSourceDiffusion
@@ -269,7 +287,7 @@ static void mac_projection (GoSim * s, GoMultilevelParams * par, double dt, GoFi
   GoField * div = go_field_new (dom, -1);
   GoField * res1 = go_field_new (dom, -1);
 
-  go_poisson_coefficients (dom);
+  sim_poisson_coefficients (s);
   /* dia = 0 on all cells: fields are born zeroed */
 
   /* gfs_normal_divergence, fluid.c:2310-2324 */
@@ -342,6 +360,32 @@ static double center_gradient (const GoDomain * dom, int L, const double * v, in
   return (x1*x1*(v2 - v0) + x2*x2*(v0 - v1))/(x1*x2*(x2 + x1));
 }
 
+/* generic_limiter, fluid.c:563-568 */
+static double generic_limiter (double r, double beta)
+{
+  double v1 = MIN (r, beta), v2 = MIN (beta*r, 1.);
+  v1 = MAX (0., v1);
+  return MAX (v1, v2);
+}
+
+/* center_limited_gradient, fluid.c:585-614, with minmod_limiter (beta = 1.), superbee_limiter (2.),
+ * sweby_limiter (1.5) (:570-583): gfs_center_minmod_gradient / _superbee_ / _sweby_ (:616-690), both
+ * neighbours at the same level (x1 = x2 = 1.) */
+static double center_limited_gradient (const GoDomain * dom, int L, const double * v, int cell, int c,
+				       double beta)
+{
+  double v0 = v[cell];
+  double x1 = 1., x2 = 1.;
+  double v1 = v[cell + (int) dom->off[L][2*c + 1]];
+  double v2 = v[cell + (int) dom->off[L][2*c]];
+  double g;
+  if (v0 == v1)
+    g = 0.;
+  else
+    g = generic_limiter ((v2 - v0)*x1/((v0 - v1)*x2), beta)*(v0 - v1)/x1;
+  return g;
+}
+
 /* gfs_center_van_leer_gradient, fluid.c:522-561 */
 static double center_van_leer_gradient (const GoDomain * dom, int L, const double * v, int cell, int c)
 {
@@ -391,8 +435,9 @@ static void cell_advected_face_values (GoSim * s, const AdvPar * par, int cell)
     double unorm = par->use_centered_velocity ?
       par->dt*s->u[c]->lev[L][cell]/msize[c] :
       par->dt*(s->un[2*c][cell] + s->un[2*c + 1][cell])/(2.*msize[c]);
-    double g = par->gradient ? center_van_leer_gradient (dom, L, v, cell, c) :
-      center_gradient (dom, L, v, cell, c);
+    double g = par->gradient == 0 ? center_gradient (dom, L, v, cell, c) :
+      par->gradient == 1 ? center_van_leer_gradient (dom, L, v, cell, c) :
+      center_limited_gradient (dom, L, v, cell, c, par->gradient == 2 ? 1. : par->gradient == 3 ? 2. : 1.5);
     double vl = v[cell] + MIN ((1. - unorm)/2., 0.5)*g;
     double vr = v[cell] + MAX ((- 1. - unorm)/2., -0.5)*g;
     /* gfs_variable_mac_source (source.c:38-59): the explicit diffusion term of an implicit
@@ -762,7 +807,7 @@ void go_sim_start (GoSim * s)
     LEAF_LOOP (s, cell)                         /* gfs_reset_gradients */
       for (int c = 0; c < dim; c++)
 	g[c]->lev[L][cell] = 0.;
-    go_poisson_coefficients (s->dom);           /* gfs_poisson_coefficients (alpha = NULL) */
+    sim_poisson_coefficients (s);               /* gfs_poisson_coefficients (alpha) */
     correct_normal_velocities (s, s->p, g, 0.); /* dt = 0.: un -= dp*0., g += dp */
     scale_gradients (s, g);
   }

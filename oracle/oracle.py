@@ -221,6 +221,7 @@ def _sim_sigs(L):
         "go_tracer_advection": (None, [vp, vp, d]),
         "go_sim_set_viscosity": (None, [vp, i, d]),
         "go_sim_set_source": (None, [vp, i, d]),
+        "go_sim_set_alpha": (None, [vp, C.POINTER(vp)]),
         "go_variable_diffusion": (None, [vp, vp, vp, d, d, C.POINTER(MultilevelParams)]),
         "go_sim_diffusion_params": (C.POINTER(MultilevelParams), [vp, i]),
     }
@@ -317,6 +318,15 @@ class Sim:
     def set_source(self, c, g):
         """GfsSource {} U/V/W g: constant intensity (a body force per unit mass)"""
         lib().go_sim_set_source(self.ptr, c, g)
+
+    def set_alpha(self, alpha):
+        """GfsPhysicalParams { alpha }: dim Fields of face values (None: alpha = NULL)"""
+        if alpha is None:
+            lib().go_sim_set_alpha(self.ptr, None)
+            return
+        arr = (C.c_void_p * 3)(*([a.ptr for a in alpha] + [None] * (3 - len(alpha))))
+        self._alpha = list(alpha)
+        lib().go_sim_set_alpha(self.ptr, arr)
 
     def set_viscosity(self, c, nu):
         """SourceDiffusion {} U|V|W nu (implicit, Crank-Nicholson beta = 1 by default)"""

@@ -383,3 +383,61 @@ def test_refined_cube_case_3d():
     step = [l for l in lines if l.startswith("step:")][0].split()
     assert int(step[1]) == nsteps and float(step[3]) == pytest.approx(s.t, abs=1e-8)
     s.destroy()
+
+
+# ---------------------------------------------------------------------------------------------
+# GfsPhysicalParams { alpha = f (T) }: variable density following a tracer
+# ---------------------------------------------------------------------------------------------
+
+def test_check_variable_density_case():
+    out = _run("variable_density.gfs", {"LEVEL": 5, "NSTEPS": 4}, check=True)
+    assert "iend 4" in out
+    bad = "1 0 GfsSimulation GfsBox GfsGEdge {} {\n  Refine 4\n  PhysicalParams { L = 2 }\n}\nGfsBox {}\n"
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".gfs") as f:
+        f.write(bad)
+        f.flush()
+        r = subprocess.run([BIN, "--check", f.name], capture_output=True, text=True)
+    assert r.returncode != 0 and "only L = 1" in r.stderr
+
+
+@pytest.mark.gpu
+def test_variable_density_case_matches_the_oracle():
+    """tests/cases/variable_density.gfs through gfship2D against the oracle driven from Python: alpha
+    evaluated on the faces before every step from the face-interpolated tracer, exactly as
+    gfs_function_face_value does; the norms OutputScalarNorm prints, to the printed digits, and the time"""
+    from oracle import oracle as O
+    from flow_cases import PERIODIC
+    level, nsteps = 5, 4
+    out = _run("variable_density.gfs", {"LEVEL": level, "NSTEPS": nsteps})
+    s = O.Sim(2, level, PERIODIC)
+    x, y = s.dom.centres()
+    s.u[0].interior()[...] = - np.cos(2. * np.pi * x) * np.sin(2. * np.pi * y)
+    s.u[1].interior()[...] = np.sin(2. * np.pi * x) * np.cos(2. * np.pi * y)
+    T = s.add_tracer()
+    T.interior()[...] = np.exp(- 30. * ((x - 0.1) * (x - 0.1) + (y + 0.05) * (y + 0.05)))
+    s.approx_projection_params.tolerance = s.projection_params.tolerance = 1e-6
+    alpha = [O.Field(s.dom, -1) for _ in range(2)]
+    s.set_alpha(alpha)
+
+    def refresh():
+        t = T.leaf()                     # with the ghost layer of the last BC application
+        for c in range(2):
+            ax = 1 - c
+            nb = np.roll(t, -1, axis=ax)                       # the + neighbour (the last entry is unused)
+            tf = ((1. - 0.5) * t + 0.5 * nb) / 1.
+            alpha[c].leaf()[...] = 1. / (1. + 2. * tf)
+
+    O.lib().go_bc(T.ptr, T.ptr, level)
+    refresh()
+    s.start()
+    for _ in range(nsteps):
+        refresh()
+        s.step()
+    lines = out.splitlines()
+    n = 1 << level
+    for name, f in (("U", s.u[0]), ("P", s.p), ("T", T)):
+        a = np.abs(f.interior())
+        want = "%s time: %g first: % 10.3e second: % 10.3e infty: % 10.3e" % (
+            name, s.t, a.sum() / n ** 2, math.sqrt((a * a).sum() / n ** 2), a.max())
+        assert want in lines, (want, [l for l in lines if l.startswith(name + " time")])

@@ -550,3 +550,98 @@ def test_poiseuille_channel_steps_bit_exact(level):
         gs.step()
         _assert_same_state(osim, gs, "step %d" % k)
     assert gs.dt == osim.dt and osim.u[0].interior().max() > 0.05
+
+
+# ---------------------------------------------------------------------------------------------
+# GfsPhysicalParams { alpha = ... } (variable density): both projections with gfs_poisson_coefficients
+# (alpha), the multigrid with the face weights of every level, gfs_correct_normal_velocities with
+# gfs_face_weighted_gradient's weights (src/timestep.c:118-144,306-322,356-444).  The reference holds
+# no golden file for a variable-density run without VOF (test/ uses alpha only with interfaces): parity
+# is oracle against device, the oracle's weighted multigrid being the one pinned by K8's tests.
+# ---------------------------------------------------------------------------------------------
+
+def _alpha_faces(osim, gd, kind):
+    """1/rho at the face centres, rho = 1 + 0.5 sin (2 pi x) cos (2 pi y) [cos (2 pi z)]: oracle Fields and
+    device Variables in the layout of gfs_poisson_coefficients' alpha (the entry of a cell is its + face
+    along c, the ghost entry in front of the first cell its - face)"""
+    dim, depth = osim.dim, osim.depth
+    n = 1 << depth
+    h = 1. / n
+    idx = np.arange(n + 2)
+    centre = (idx - 0.5) * h - 0.5          # centre of cell i (ghosts included), box [-0.5, 0.5]
+    oa, ga = [], []
+    for c in range(dim):
+        axes = []
+        for ax in range(dim):               # array axes are [k, j, i] / [j, i]
+            comp = dim - 1 - ax
+            axes.append(centre + (0.5 * h if comp == c else 0.))
+        grids = np.meshgrid(*axes, indexing="ij")
+        xyz = [grids[dim - 1 - comp] for comp in range(dim)]
+        rho = 1. + 0.5 * np.sin(2. * np.pi * xyz[0]) * np.cos(2. * np.pi * xyz[1])
+        if dim == 3:
+            rho = rho * np.cos(2. * np.pi * xyz[2]) + (1. - np.cos(2. * np.pi * xyz[2]))
+        a = 1. / rho
+        if kind == "periodic":
+            ax = dim - 1 - c
+            sl0, sln = [slice(None)] * dim, [slice(None)] * dim
+            sl0[ax], sln[ax] = 0, -2
+            a[tuple(sl0)] = a[tuple(sln)]
+        of, gf = O.Field(osim.dom, -1), gd.variable()
+        of.leaf()[...] = a
+        gf.upload(a)
+        oa.append(of)
+        ga.append(gf)
+    return oa, ga
+
+
+@pytest.mark.parametrize("dim,level,kind", [(2, 5, "periodic"), (3, 4, "periodic"), (3, 5, "periodic"),
+                                            (2, 5, "box"), (3, 5, "box")])
+def test_variable_density_steps_bit_exact(dim, level, kind):
+    """time steps with GfsPhysicalParams { alpha }: U, g, P, Pmac, the MAC velocities and dt equal to the
+    oracle's bits at the start and after every step (32^3: the weighted sweeps on the pipelined kernel)"""
+    side = PERIODIC if kind == "periodic" else [O.SIDE_BOUNDARY] * 6
+    osim = O.Sim(dim, level, side)
+    cs = osim.dom.centres()
+    rng = np.random.default_rng(5)
+    if kind == "periodic":
+        if dim == 2:
+            vel = reynolds_init(*cs)
+        else:
+            vel = taylor_green_3d(*cs)
+    else:
+        if dim == 2:
+            x, y = cs
+            vel = [np.sin(np.pi * (x + .5)) * np.cos(np.pi * (y + .5)),
+                   -np.cos(np.pi * (x + .5)) * np.sin(np.pi * (y + .5))]
+        else:
+            x, y, z = cs
+            vel = [np.sin(np.pi * (x + .5)) * np.cos(np.pi * (y + .5)) * np.cos(np.pi * (z + .5)),
+                   -np.cos(np.pi * (x + .5)) * np.sin(np.pi * (y + .5)) * np.cos(np.pi * (z + .5)),
+                   0. * x * y * z]
+    for c in range(dim):
+        osim.u[c].interior()[...] = vel[c] + 0.01 * rng.standard_normal(np.shape(vel[c]))
+    gd, gs = _device_sim(osim, side)
+    oa, ga = _alpha_faces(osim, gd, kind)
+    osim.set_alpha(oa)
+    gs.set_alpha(ga)
+    osim.start()
+    gs.start()
+    _assert_same_state(osim, gs, "start")
+    _assert_same_un(osim, gs, "start")
+    for k in range(3):
+        osim.step()
+        gs.step()
+        _assert_same_state(osim, gs, "step %d" % k)
+        _assert_same_un(osim, gs, "step %d" % k)
+    # the weights made a difference: the same run with alpha = NULL gives another pressure
+    osim1 = O.Sim(dim, level, side)
+    for c in range(dim):
+        osim1.u[c].interior()[...] = vel[c] + 0.01 * np.random.default_rng(5).standard_normal(np.shape(vel[c]))
+    osim1.start()
+    assert not np.array_equal(osim1.p.interior(), osim.p.interior())
+    # and back to alpha = NULL on the same device simulation: the unit-weight kernels again
+    osim.set_alpha(None)
+    gs.set_alpha(None)
+    osim.step()
+    gs.step()
+    _assert_same_state(osim, gs, "alpha = NULL again")
