@@ -594,6 +594,18 @@ void write_simulation (Run & R, FILE * fp, const std::vector<int> & list, bool b
   fputs (R.edges_text.c_str (), fp);
 }
 
+// the gradient functions of GfsAdvectionParams / GfsVariableTracer (src/advection.c:944-1032):
+// gfs_center_gradient, and the limited gradients of src/fluid.c:522-690
+int gradient_kind (const std::string & name)
+{
+  static const char * names[] = { "gfs_center_gradient", "gfs_center_van_leer_gradient",
+				  "gfs_center_minmod_gradient", "gfs_center_superbee_gradient",
+				  "gfs_center_sweby_gradient" };
+  for (int k = 0; k < 5; k++)
+    if (name == names[k]) return k;
+  return -1;
+}
+
 void parse_object (Run & R, Reader & r)
 {
   int line = r.line ();
@@ -717,8 +729,7 @@ void parse_object (Run & R, Reader & r)
     if (r.peek (false) == '{') {
       auto m = r.assignments ();
       for (auto & kv : m)
-	if (kv.first == "gradient" && kv.second == "gfs_center_van_leer_gradient") gradient = 1;
-	else if (kv.first == "gradient" && kv.second == "gfs_center_gradient") gradient = 0;
+	if (kv.first == "gradient" && gradient_kind (kv.second) >= 0) gradient = gradient_kind (kv.second);
 	else
 	  r.fail ("unsupported GfsVariableTracer parameter " + kv.first + " = " + kv.second);
     }
@@ -1991,8 +2002,7 @@ int run (Run & R)
     if (kv.first == "cfl") adv->cfl = atof (kv.second.c_str ());
     else if (kv.first == "gc") adv->gc = atoi (kv.second.c_str ());
     else if (kv.first == "gradient") {
-      if (kv.second == "gfs_center_gradient") adv->gradient = 0;
-      else if (kv.second == "gfs_center_van_leer_gradient") adv->gradient = 1;
+      if (gradient_kind (kv.second) >= 0) adv->gradient = gradient_kind (kv.second);
       else { fprintf (stderr, "gfship: unsupported gradient `%s'\n", kv.second.c_str ()); return 1; }
     }
   }

@@ -35,11 +35,14 @@ using namespace gfship::tree;
 namespace {
 
 enum { V_P, V_PMAC, V_U /* 3 */, V_G = V_U + 3 /* 3 */, V_GM = V_G + 3 /* 3 */, V_UN = V_GM + 3 /* 6 */,
-       V_FV = V_UN + 6 /* 6 */, V_DIV = V_FV + 6, V_RES, V_DP, V_BCVAL, V_NVAR };
+       V_FV = V_UN + 6 /* 6 */, V_DIV = V_FV + 6, V_RES, V_DP, V_BCVAL, V_T /* 2: GfsVariableTracer */,
+       V_NVAR = V_T + 2 };
+#define TREE_MAXTRACERS 2
 
 // the variables of the C ABI (GFSHIP_TREE_*) -> storage
 const int abi_var[] = { V_P, V_PMAC, V_U, V_U + 1, V_G, V_G + 1, V_GM, V_GM + 1, V_UN, V_UN + 1, V_UN + 2,
-			V_UN + 3, V_U + 2, V_G + 2, V_GM + 2, V_UN + 4, V_UN + 5, V_DIV, V_BCVAL, V_RES };
+			V_UN + 3, V_U + 2, V_G + 2, V_GM + 2, V_UN + 4, V_UN + 5, V_DIV, V_BCVAL, V_RES,
+			V_T, V_T + 1 };
 const int abi_nvar = sizeof (abi_var)/sizeof (abi_var[0]);
 
 struct P3 { double * p[3]; };       // the components of a vector
@@ -129,6 +132,7 @@ struct gfship_tree {
   int bc_p[6] = { 0, 0, 0, 0, 0, 0 };             // condition of P on a GfsBoundary side (GFSHIP_BC_*)
   bool has_boundary = false;
   bool tape_attr_set = false;                     // dynamic-LDS limit of t_relax_tape raised on this device
+  int ntracers = 0, tracer_gradient[TREE_MAXTRACERS] = { 1, 1 };   // GfsVariableTracer: 0 centred, 1 van Leer
 };
 
 namespace {
@@ -599,6 +603,7 @@ struct AdvArgs {
   double * fv[6];
   double dt;
   int use_centered;
+  int gradient;            // 0 gfs_center_gradient, 1 gfs_center_van_leer_gradient
 };
 
 // transverse_term, src/advection.c:27-47
@@ -630,7 +635,7 @@ __global__ void t_face_values (Topo T, const Cell * cells, int n, AdvArgs A)
     const double msize = size;
     const double unorm = A.use_centered ? A.dt*A.u[c][g]/msize :
       A.dt*(A.un[2*c][g] + A.un[2*c + 1][g])/(2.*msize);
-    const double gr = center_gradient (T, cell, c, R);
+    const double gr = A.gradient ? van_leer_gradient (T, cell, c, R) : center_gradient (T, cell, c, R);
     const double m1 = (1. - unorm)/2., m2 = (- 1. - unorm)/2.;
     const double vl = v0 + (m1 < 0.5 ? m1 : 0.5)*gr;
     const double vr = v0 + (m2 > -0.5 ? m2 : -0.5)*gr;
@@ -763,6 +768,7 @@ __global__ void t_face_advected_un (Topo T, const FaceRec * faces, int n, Upwind
 }
 
 // gfs_face_velocity_advection_flux, src/advection.c:398-435: the flux of the face
+// gm == nullptr: gfs_face_advection_flux, src/advection.c:356-381 (a tracer)
 __global__ void t_face_flux (Topo T, const FaceRec * faces, int n, UpwindArgs A, const double * gm,
 			     double dt, double * fval)
 {
@@ -770,8 +776,13 @@ __global__ void t_face_flux (Topo T, const FaceRec * faces, int n, UpwindArgs A,
   if (t >= n) return;
   const Face f = { faces[t].cell, faces[t].neighbor, faces[t].d };
   DevReader G = { gm };
-  double flux = 1.*A.un[f.d][T.gi (f.cell)]*dt/T.size (f.cell);
-  flux *= face_upwinded_value (T, A, f, 0) - face_interpolated_value (T, f, G)*dt/2.;
+  double flux;
+  if (gm) {
+    flux = 1.*A.un[f.d][T.gi (f.cell)]*dt/T.size (f.cell);
+    flux *= face_upwinded_value (T, A, f, 0) - face_interpolated_value (T, f, G)*dt/2.;
+  }
+  else
+    flux = 1.*A.un[f.d][T.gi (f.cell)]*dt*face_upwinded_value (T, A, f, 0)/T.size (f.cell);
   if (f.d & 1)
     flux = - flux;
   fval[t] = flux;
@@ -1682,10 +1693,10 @@ UpwindArgs upwind_args (gfship_tree * tr)
   return A;
 }
 
-int face_values_set (gfship_tree * tr, const double * v, double dt, int use_centered, int comp)
+int face_values_set (gfship_tree * tr, const double * v, double dt, int use_centered, int comp, int gradient = 0)
 { /* src/timestep.c:644-654 */
   AdvArgs A;
-  A.v = v; A.dt = dt; A.use_centered = use_centered;
+  A.v = v; A.dt = dt; A.use_centered = use_centered; A.gradient = gradient;
   for (int c = 0; c < 3; c++) A.u[c] = tr->var[V_U + c];
   for (int d = 0; d < 6; d++) { A.un[d] = tr->var[V_UN + d]; A.fv[d] = tr->var[V_FV + d]; }
   t_face_values<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, A);
@@ -1728,6 +1739,43 @@ int centered_velocity_advection (gfship_tree * tr, int gmac, int g)
   }
   for (int c = 0; c < tr->H.dim; c++)
     if ((e = bc_leaves (tr, tr->var[V_U + c], c))) return e;
+  return 0;
+}
+
+// a scalar with the default GfsBc on the GfsBoundary sides (symmetry, src/boundary.c:45-62: the ghost
+// takes the value of the cell it touches), the periodic image elsewhere
+int bc_scalar (gfship_tree * tr, double * v)
+{
+  if (!tr->nghost_leaves) return 0;
+  Sgn6 sg;
+  for (int d = 0; d < 6; d++) sg.s[d] = 1.;
+  t_copy_ghosts_signed<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves, v, sg);
+  KCHECK ();
+  return 0;
+}
+
+// gfs_tracer_advection_diffusion (src/timestep.c:1028-1055, no diffusion) with variable_sources
+// :872-921: the face values with the gradient of the GfsVariableTracer, gfs_face_advection_flux, the
+// update, gfs_domain_bc
+int tracer_advection (gfship_tree * tr, int k, double dt)
+{
+  int e;
+  FaceSet & F = tr->fs[0];
+  double * v = tr->var[V_T + k];
+  if ((e = face_values_set (tr, v, dt, 0, -1, tr->tracer_gradient[k]))) return e;
+  t_face_flux<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, upwind_args (tr), nullptr, dt, F.fval);
+  KCHECK ();
+  t_gather_flux<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, F.faces, F.inc_off, F.inc, F.fval,
+      v, nullptr, dt);
+  KCHECK ();
+  return bc_scalar (tr, v);
+}
+
+int advance_tracers (gfship_tree * tr, double dt)   /* src/simulation.c:405-430 */
+{
+  int e;
+  for (int k = 0; k < tr->ntracers; k++)
+    if ((e = tracer_advection (tr, k, dt))) return e;
   return 0;
 }
 
@@ -1779,6 +1827,8 @@ int coarse_init (gfship_tree * tr)   /* src/adaptive.c:43-58 */
   const int vars[] = { V_P, V_PMAC, V_U, V_U + 1, V_U + 2 };
   for (int k = 0; k < 2 + tr->H.dim; k++)
     if ((e = from_below (tr, tr->var[vars[k]], 0))) return e;
+  for (int k = 0; k < tr->ntracers; k++)
+    if ((e = from_below (tr, tr->var[V_T + k], 0))) return e;
   return 0;
 }
 
@@ -2256,6 +2306,15 @@ int gfship_tree_sweep_levels (const gfship_tree * tr, int level, int * ncells, i
   return GFSHIP_OK;
 }
 
+int gfship_tree_add_tracer (gfship_tree * tr, int gradient)
+{
+  GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_add_tracer: null tree");
+  GFSHIP_CHECK (gradient == 0 || gradient == 1, GFSHIP_EINVAL, "gradient: 0 centred, 1 van Leer");
+  GFSHIP_CHECK (tr->ntracers < TREE_MAXTRACERS, GFSHIP_EUNSUPPORTED, "a tree carries %d tracers at most", TREE_MAXTRACERS);
+  tr->tracer_gradient[tr->ntracers] = gradient;
+  return GFSHIP_TREE_T0 + tr->ntracers++;
+}
+
 /* simulation_run up to the loop, src/simulation.c:458-476 */
 int gfship_tree_start (gfship_tree * tr)
 {
@@ -2268,10 +2327,13 @@ int gfship_tree_start (gfship_tree * tr)
   const int vars[] = { V_P, V_PMAC, V_U, V_U + 1, V_U + 2 };
   for (int k = 0; k < 2 + tr->H.dim; k++)
     if ((e = bc_leaves (tr, tr->var[vars[k]], k - 2))) return e;
+  for (int k = 0; k < tr->ntracers; k++)
+    if ((e = bc_scalar (tr, tr->var[V_T + k]))) return e;
   if ((e = coarse_init (tr))) return e;
   if ((e = set_timestep (tr))) return e;
   if ((e = approximate_projection (tr, &tr->approx_projection_params, tr->dt))) return e;
-  return set_timestep (tr);
+  if ((e = set_timestep (tr))) return e;
+  return advance_tracers (tr, tr->dt/2.);
 }
 
 /* one iteration of the loop, src/simulation.c:479-548 */
@@ -2291,7 +2353,8 @@ int gfship_tree_step (gfship_tree * tr)
   if ((e = approximate_projection (tr, &tr->approx_projection_params, tr->dt))) return e;
   tr->t = tr->tnext;
   tr->iter++;
-  return set_timestep (tr);
+  if ((e = set_timestep (tr))) return e;
+  return advance_tracers (tr, tr->dt);
 }
 
 } // extern "C"

@@ -265,6 +265,34 @@ __host__ __device__ inline double center_gradient (const Topo & T, Cell cell, in
   return 0.;
 }
 
+// gfs_center_van_leer_gradient, src/fluid.c:522-561
+template <class V>
+__host__ __device__ inline double van_leer_gradient (const Topo & T, Cell cell, int c, V & v)
+{
+  const int d = 2*c;
+  const Face f1 = { cell, T.neighbor (cell, d ^ 1), d ^ 1 };
+  if (exists (f1.neighbor)) {
+    const Face f2 = { cell, T.neighbor (cell, d), d };
+    if (exists (f2.neighbor)) {
+      double x1 = 1., x2 = 1.;
+      const double v0 = v (T, cell);
+      const double v1 = neighbor_value (T, f1, v, x1);
+      const double v2 = neighbor_value (T, f2, v, x2);
+      double s1 = 2.*(v0 - v1);
+      const double s2 = 2.*(v2 - v0);
+      if (s1*s2 <= 0.)
+	return 0.;
+      const double s0 = (x1*x1*(v2 - v0) + x2*x2*(v0 - v1))/(x1*x2*(x2 + x1));
+      if (fabs (s2) < fabs (s1))
+	s1 = s2;
+      if (fabs (s0) < fabs (s1))
+	return s0;
+      return s1;
+    }
+  }
+  return 0.;
+}
+
 // gfs_face_gradient; with unit weights also face_weighted_gradient (dimension 2)
 template <class V>
 __host__ __device__ inline Grad2 face_gradient (const Topo & T, const Face & face, V & v, int max_level)

@@ -170,6 +170,7 @@ SIGNATURES = {
     "gfship_tree_time": (_d, [_vp]),
     "gfship_tree_dt": (_d, [_vp]),
     "gfship_tree_iter": (_u, [_vp]),
+    "gfship_tree_add_tracer": (_i, [_vp, _i]),
     "gfship_tree_start": (_i, [_vp]),
     "gfship_tree_step": (_i, [_vp]),
     "gfship_tree_sweep_levels": (_i, [_vp, _i, _pi, _pi]),
@@ -693,7 +694,7 @@ def tree_host_check(refine, dim=2, sides=None, nrelax=4):
 class Tree:
     """gfship_tree: a GfsSimulation on one periodic box refined by a GfsRefine function (coarse-fine
     stencils; quadtree or octree).  refine (x, y) or refine (x, y, z) -> level wanted there."""
-    P, PMAC, U, V, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3, W, GZ, GMACZ, UN4, UN5, DIV, BCVAL, RES = range(20)
+    P, PMAC, U, V, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3, W, GZ, GMACZ, UN4, UN5, DIV, BCVAL, RES, T0, T1 = range(22)
 
     def __init__(self, refine, dim=2, device=0, sides=None):
         self.dim = dim
@@ -740,6 +741,10 @@ class Tree:
 
     def set_time(self, end, cfl):
         _check(lib().gfship_tree_set_time(self.ptr, end, cfl))
+
+    def add_tracer(self, gradient=1):
+        """GfsVariableTracer [{ gradient = }] (0 centred, 1 van Leer): the variable index (T0, T1)"""
+        return _check(lib().gfship_tree_add_tracer(self.ptr, gradient))
 
     def start(self):
         _check(lib().gfship_tree_start(self.ptr))

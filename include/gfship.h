@@ -188,7 +188,8 @@ typedef struct gfship_sim gfship_sim;   /* GfsSimulation on one box, src/simulat
 typedef struct {           /* the fields of GfsAdvectionParams used here, src/advection.h:50-69 */
   double cfl, dt;
   int gradient;            /* 0 gfs_center_gradient (src/fluid.c:434-475),
-			      1 gfs_center_van_leer_gradient (:522-561) */
+			      1 gfs_center_van_leer_gradient (:522-561), 2 gfs_center_minmod_gradient,
+			      3 gfs_center_superbee_gradient, 4 gfs_center_sweby_gradient (:563-690) */
   int gc;
 } gfship_advection_params;
 
@@ -215,7 +216,9 @@ int      gfship_sim_set_next_event (gfship_sim * sim, gfship_next_event_fn fn, v
 double   gfship_sim_time (gfship_sim * sim);
 unsigned gfship_sim_iter (gfship_sim * sim);
 int      gfship_sim_add_tracer (gfship_sim * sim);       /* GfsVariableTracer, src/variable.c:427-431 */
-/* GfsVariableTracer { gradient = gfs_center_gradient | gfs_center_van_leer_gradient }: 0 | 1 (default) */
+/* GfsVariableTracer { gradient = gfs_center_gradient | gfs_center_van_leer_gradient (default) |
+   gfs_center_minmod_gradient | gfs_center_superbee_gradient | gfs_center_sweby_gradient }: 0 .. 4
+   (src/fluid.c:434-690); the same numbers in gfship_advection_params.gradient */
 int      gfship_sim_set_tracer_gradient (gfship_sim * sim, int tracer, int gradient);
 /* GfsSourceDiffusion {} U|V|W nu (src/source.c:933-1160): constant implicit viscosity of
    velocity component c (0. removes it), and the GfsMultilevelParams of its solver
@@ -529,11 +532,13 @@ typedef double (* gfship_refine_fn) (double x, double y, double z, void * ctx);
 enum { GFSHIP_TREE_P = 0, GFSHIP_TREE_PMAC, GFSHIP_TREE_U, GFSHIP_TREE_V, GFSHIP_TREE_GX, GFSHIP_TREE_GY,
        GFSHIP_TREE_GMACX, GFSHIP_TREE_GMACY, GFSHIP_TREE_UN0, GFSHIP_TREE_UN1, GFSHIP_TREE_UN2,
        GFSHIP_TREE_UN3, GFSHIP_TREE_W, GFSHIP_TREE_GZ, GFSHIP_TREE_GMACZ, GFSHIP_TREE_UN4,
-       GFSHIP_TREE_UN5, GFSHIP_TREE_DIV, GFSHIP_TREE_BCVAL, GFSHIP_TREE_RES };
+       GFSHIP_TREE_UN5, GFSHIP_TREE_DIV, GFSHIP_TREE_BCVAL, GFSHIP_TREE_RES,
+       GFSHIP_TREE_T0, GFSHIP_TREE_T1 };
 				    /* variables of a tree: P, Pmac, U, V, g, gmac, f[d].un; then the 3-D ones;
 				       DIV: the result of gfship_tree_divergence / the right-hand side of
 				       gfship_tree_poisson_solve; BCVAL: the values of the conditions of P, one per
-				       ghost cell (at the face centres); RES: the residual of the last solve */
+				       ghost cell (at the face centres); RES: the residual of the last solve;
+				       T0, T1: the tracers of gfship_tree_add_tracer */
 int  gfship_tree_create (gfship_tree ** tree, int dim, gfship_refine_fn refine, void * ctx, int device);
 /* the same with GfsBoundary sides (side[d] = GFSHIP_SIDE_PERIODIC or GFSHIP_SIDE_BOUNDARY; the ghost
    cells of a boundary are refined like the cells they touch, gfs_domain_match): such a tree carries
@@ -563,6 +568,15 @@ double   gfship_tree_time (const gfship_tree * tree);
 double   gfship_tree_dt (const gfship_tree * tree);
 unsigned gfship_tree_iter (const gfship_tree * tree);
 /* simulation_run up to its loop (src/simulation.c:458-476) and one iteration of the loop (:479-548) */
+/* GfsVariableTracer [{ gradient = }] on a tree (src/variable.c:427-431): advected with the MAC
+   velocities at the end of every step and by half a step at the start (gfs_advance_tracers,
+   src/simulation.c:405-430,476,548; gfs_tracer_advection_diffusion src/timestep.c:1028-1055 with
+   gfs_face_advection_flux src/advection.c:356-381 -- flux/FTT_CELLS towards a coarse neighbour -- and the
+   gradient 0 gfs_center_gradient / 1 gfs_center_van_leer_gradient (default) through gfs_neighbor_value,
+   src/fluid.c:364-396,522-561), restricted by gfs_cell_coarse_init; default (symmetry) condition on
+   GfsBoundary sides.  Returns GFSHIP_TREE_T0 / _T1 (two tracers at most), to be called before
+   gfship_tree_start. */
+int  gfship_tree_add_tracer (gfship_tree * tree, int gradient);
 int  gfship_tree_start (gfship_tree * tree);
 int  gfship_tree_step (gfship_tree * tree);
 /* the derived variable `Divergence' (gfs_divergence, src/fluid.c:2357-2376, with

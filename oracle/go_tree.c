@@ -41,6 +41,7 @@
 #endif
 
 enum { GT_NONE = 0, GT_LEAF = 1, GT_NODE = 2 };
+#define GT_MAXTRACERS 2
 
 typedef struct { int l, q; } Cell;            /* q < 0: no such cell (NULL) */
 typedef struct { double * lev[GT_MAXL + 1]; } Var;
@@ -68,6 +69,10 @@ typedef struct GtSim {
   Var bcval;
   const Var * bc_var;                         /* the variable the conditions belong to (P) */
   int bc_homogeneous;                         /* set around the homogeneous BCs of a relax loop */
+  /* GfsVariableTracer (variable.c:427-431): advected with the MAC velocities at the end of a step
+     (gfs_advance_tracers, simulation.c:405-430); gradient 0 gfs_center_gradient, 1 van Leer (default) */
+  Var tracer[GT_MAXTRACERS];
+  int ntracers, tracer_gradient[GT_MAXTRACERS];
 } GtSim;
 
 static const Cell NOCELL = { 0, -1 };
@@ -353,6 +358,11 @@ static void bc_ghost (GtSim * s, int l, int side, int G, int image, void * data)
     p->v->lev[l][G] = comp == side/2 ? - nb : nb;
     return;
   }
+  for (int t = 0; t < s->ntracers; t++)
+    if (p->v == &s->tracer[t]) {      /* a scalar with the default GfsBc: symmetry, boundary.c:45-62 */
+      p->v->lev[l][G] = nb;
+      return;
+    }
   int kind = s->bc_p[side];
   if (s->bc_homogeneous)
     p->v->lev[l][G] = kind == GO_BC_DIRICHLET ? - nb : nb;
@@ -630,6 +640,33 @@ static double center_gradient (const GtSim * s, Cell cell, int c, const Var * v)
   if (exists (f2.neighbor)) {
     double x2 = 1.;
     return (neighbor_value (s, &f2, v, &x2) - v0)/x2;
+  }
+  return 0.;
+}
+
+/* gfs_center_van_leer_gradient, fluid.c:522-561 */
+static double center_van_leer_gradient (const GtSim * s, Cell cell, int c, const Var * v)
+{
+  int d = 2*c;
+  Face f1 = { cell, neighbor (s, cell, OPP (d)), OPP (d) };
+  if (exists (f1.neighbor)) {
+    Face f2 = { cell, neighbor (s, cell, d), d };
+    if (exists (f2.neighbor)) {
+      double x1 = 1., x2 = 1., v0, v1, v2;
+      v0 = *val (v, cell);
+      v1 = neighbor_value (s, &f1, v, &x1);
+      v2 = neighbor_value (s, &f2, v, &x2);
+      double s1 = 2.*(v0 - v1);
+      double s2 = 2.*(v2 - v0);
+      if (s1*s2 <= 0.)
+	return 0.;
+      double s0 = (x1*x1*(v2 - v0) + x2*x2*(v0 - v1))/(x1*x2*(x2 + x1));
+      if (fabs (s2) < fabs (s1))
+	s1 = s2;
+      if (fabs (s0) < fabs (s1))
+	return s0;
+      return s1;
+    }
   }
   return 0.;
 }
@@ -1125,7 +1162,7 @@ static void approximate_projection (GtSim * s, GoMultilevelParams * par, double 
 
 /* ---- Godunov advection: advection.c ------------------------------------------------------- */
 
-typedef struct { double dt; Var * v; int use_centered_velocity; } AdvPar;
+typedef struct { double dt; Var * v; int use_centered_velocity; int gradient; } AdvPar;
 
 static double transverse_term (GtSim * s, const AdvPar * par, Cell cell, const double * msize, int c)
 { /* advection.c:27-47 */
@@ -1151,7 +1188,8 @@ static void cell_advected_face_values (GtSim * s, Cell cell, void * data) /* adv
     double unorm = par->use_centered_velocity ?
       par->dt*(*val (&s->u[c], cell))/msize[c] :
       par->dt*(*val (&s->un[2*c], cell) + *val (&s->un[2*c + 1], cell))/(2.*msize[c]);
-    double g = center_gradient (s, cell, c, par->v);
+    double g = par->gradient ? center_van_leer_gradient (s, cell, c, par->v) :
+      center_gradient (s, cell, c, par->v);
     double vl = *val (par->v, cell) + MIN ((1. - unorm)/2., 0.5)*g;
     double vr = *val (par->v, cell) + MAX ((- 1. - unorm)/2., -0.5)*g;
     double src = par->dt*0./2.;
@@ -1356,6 +1394,20 @@ static void face_velocity_advection_flux (GtSim * s, const Face * face, void * d
     *val (par->fvar, face->neighbor) += flux/s->nc /* FTT_CELLS */;
 }
 
+static void face_advection_flux (GtSim * s, const Face * face, void * data)
+{ /* gfs_face_advection_flux, advection.c:356-381 */
+  FluxPar * par = data;
+  double flux = 1.*(*val (&s->un[face->d], face->cell))*par->dt*
+    face_upwinded_value (s, face, 0)/cell_size (face->cell);
+  if (face->d & 1)
+    flux = - flux;
+  *val (par->fvar, face->cell) -= flux;
+  if (!fine_coarse (face))
+    *val (par->fvar, face->neighbor) += flux;
+  else
+    *val (par->fvar, face->neighbor) += flux/s->nc /* FTT_CELLS */;
+}
+
 typedef struct { Var * sv, * fvar, * g; double dt; } UpdatePar;
 static void advection_update (GtSim * s, Cell cell, void * data) /* advection.c:784-819 */
 {
@@ -1374,7 +1426,7 @@ static void variable_sources (GtSim * s, int c, double dt, Var * gmac, Var * g)
   Var fvar;
   var_alloc (s, &fvar);
   FluxPar fp = { dt, &fvar, gmac, c };
-  AdvPar ap = { dt, &s->u[c], 0 };
+  AdvPar ap = { dt, &s->u[c], 0, 0 };
   face_traverse (s, -1, face_reset, &fp);
   face_values_set (s, &ap);
   face_traverse (s, -1, face_velocity_advection_flux, &fp);
@@ -1383,6 +1435,29 @@ static void variable_sources (GtSim * s, int c, double dt, Var * gmac, Var * g)
   var_free (s, &fvar);
   if (g)
     cell_traverse (s, 0, T_LEAFS, -1, add_pressure_gradient, &up);
+}
+
+/* gfs_tracer_advection_diffusion (timestep.c:1028-1055, no diffusion) with variable_sources :872-921:
+   gfs_face_advection_flux, the gradient of the GfsVariableTracer, then gfs_domain_bc */
+static void tracer_advection (GtSim * s, int t, double dt)
+{
+  Var fvar;
+  var_alloc (s, &fvar);
+  FluxPar fp = { dt, &fvar, NULL, -1 };
+  AdvPar ap = { dt, &s->tracer[t], 0, s->tracer_gradient[t] };
+  face_traverse (s, -1, face_reset, &fp);
+  face_values_set (s, &ap);
+  face_traverse (s, -1, face_advection_flux, &fp);
+  UpdatePar up = { &s->tracer[t], &fvar, NULL, dt };
+  cell_traverse (s, 0, T_LEAFS, -1, advection_update, &up);
+  var_free (s, &fvar);
+  bc (s, &s->tracer[t], T_LEAFS, -1);
+}
+
+static void advance_tracers (GtSim * s, double dt) /* simulation.c:405-430 */
+{
+  for (int t = 0; t < s->ntracers; t++)
+    tracer_advection (s, t, dt);
 }
 
 static void centered_velocity_advection (GtSim * s, Var * gmac, Var * g) /* timestep.c:976-1016 */
@@ -1470,6 +1545,8 @@ static void coarse_init (GtSim * s) /* adaptive.c:43-58 on every variable */
   Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1], &s->u[2] };
   for (int k = 0; k < 2 + s->dim; k++)
     cell_traverse (s, 1, T_NON_LEAFS, -1, get_from_below_intensive, all[k]);
+  for (int t = 0; t < s->ntracers; t++)
+    cell_traverse (s, 1, T_NON_LEAFS, -1, get_from_below_intensive, &s->tracer[t]);
 }
 
 /* ---- the simulation of test/periodic/periodic.gfs ------------------------------------------ */
@@ -1572,6 +1649,8 @@ void gt_destroy (GtSim * s)
     var_free (s, &s->w[d]);
   }
   var_free (s, &s->bcval);
+  for (int t = 0; t < s->ntracers; t++)
+    var_free (s, &s->tracer[t]);
   for (int l = 0; l <= s->depth; l++)
     free (s->flag[l]);
   free (s);
@@ -1583,10 +1662,13 @@ void gt_start (GtSim * s)
   Var * all[] = { &s->p, &s->pmac, &s->u[0], &s->u[1], &s->u[2] };
   for (int k = 0; k < 2 + s->dim; k++)
     bc (s, all[k], T_LEAFS, -1);
+  for (int t = 0; t < s->ntracers; t++)
+    bc (s, &s->tracer[t], T_LEAFS, -1);
   coarse_init (s);
   set_timestep (s);
   approximate_projection (s, &s->approx_projection_params, s->dt, &s->p, s->g);
   set_timestep (s);
+  advance_tracers (s, s->dt/2.);
 }
 
 /* one iteration of the loop, simulation.c:479-548 */
@@ -1601,6 +1683,17 @@ void gt_step (GtSim * s)
   s->t = s->tnext;
   s->i++;
   set_timestep (s);
+  advance_tracers (s, s->dt);
+}
+
+/* GfsVariableTracer T [{ gradient = ... }]: returns the index of gt_values (17 + t) */
+int gt_add_tracer (GtSim * s, int gradient)
+{
+  if (s->ntracers >= GT_MAXTRACERS)
+    return -1;
+  var_alloc (s, &s->tracer[s->ntracers]);
+  s->tracer_gradient[s->ntracers] = gradient;
+  return 17 + s->ntracers++;
 }
 
 double gt_time (const GtSim * s) { return s->t; }
@@ -1633,7 +1726,7 @@ double * gt_values (GtSim * s, int which, int l)
 {
   Var * v[] = { &s->u[0], &s->u[1], &s->p, &s->pmac, &s->g[0], &s->g[1], &s->gmac[0], &s->gmac[1],
 		&s->un[0], &s->un[1], &s->un[2], &s->un[3], &s->u[2], &s->g[2], &s->gmac[2],
-		&s->un[4], &s->un[5] };
+		&s->un[4], &s->un[5], &s->tracer[0], &s->tracer[1] };
   return v[which]->lev[l];
 }
 

@@ -558,6 +558,7 @@ def _tree_sigs(L):
         "gt_error_norm": (None, [vp, pd, pd, pd]),
         "gt_divergence_norm": (None, [vp, pd, pd, pd, pd]),
         "gt_divergence_level": (None, [vp, i, pd]),
+        "gt_add_tracer": (i, [vp, i]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -611,6 +612,12 @@ class Tree:
 
     def set_time(self, end, cfl):
         self.L.gt_set_time(self.ptr, end, cfl)
+
+    def add_tracer(self, gradient=1):
+        """GfsVariableTracer [{ gradient = }] (0 centred, 1 van Leer): the index for values ()"""
+        k = self.L.gt_add_tracer(self.ptr, gradient)
+        assert k >= 0
+        return k
 
     def start(self):
         self.L.gt_start(self.ptr)

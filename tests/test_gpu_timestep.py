@@ -645,3 +645,52 @@ def test_variable_density_steps_bit_exact(dim, level, kind):
     osim.step()
     gs.step()
     _assert_same_state(osim, gs, "alpha = NULL again")
+
+
+# ---------------------------------------------------------------------------------------------
+# the limited gradients of src/fluid.c:563-690 (minmod, superbee, sweby) in the Godunov face values:
+# GfsAdvectionParams { gradient = } and GfsVariableTracer { gradient = }
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("gradient", [2, 3, 4])
+@pytest.mark.parametrize("dim,kind", [(3, "periodic"), (2, "box")])
+def test_limited_gradients_steps_bit_exact(dim, kind, gradient):
+    """steps with gfs_center_minmod_gradient / superbee / sweby on the velocity and on a tracer: state,
+    MAC velocities and the tracer equal to the oracle's bits"""
+    level = 4
+    side = PERIODIC if kind == "periodic" else [O.SIDE_BOUNDARY] * 6
+    osim = O.Sim(dim, level, side)
+    cs = osim.dom.centres()
+    rng = np.random.default_rng(40 + gradient)
+    if dim == 3:
+        vel = taylor_green_3d(*cs)
+    else:
+        x, y = cs
+        vel = [np.sin(np.pi * (x + .5)) * np.cos(np.pi * (y + .5)),
+               -np.cos(np.pi * (x + .5)) * np.sin(np.pi * (y + .5))]
+    for c in range(dim):
+        osim.u[c].interior()[...] = vel[c] + 0.05 * rng.standard_normal(np.shape(vel[c]))
+    osim.advection_params.gradient = gradient
+    ot = osim.add_tracer(gradient=gradient)
+    r2 = sum((q - 0.1) ** 2 for q in cs)
+    ot.interior()[...] = (r2 < 0.08) * 1.          # a step profile: every branch of the limiters
+    gd, gs = _device_sim(osim, side)
+    gt = gs.add_tracer(gradient=gradient)
+    gt.upload(_with_ghosts(ot.interior(), dim))
+    osim.start()
+    gs.start()
+    _assert_same_state(osim, gs, "start")
+    for k in range(3):
+        osim.step()
+        gs.step()
+        _assert_same_state(osim, gs, "step %d" % k)
+        _assert_same_un(osim, gs, "step %d" % k)
+        assert np.array_equal(ot.interior(), _interior(gt.download(), dim)), "tracer, step %d" % k
+    # not the van Leer result
+    osim1 = O.Sim(dim, level, side)
+    for c in range(dim):
+        osim1.u[c].interior()[...] = vel[c] + 0.05 * np.random.default_rng(40 + gradient).standard_normal(np.shape(vel[c]))
+    osim1.advection_params.gradient = 1
+    osim1.start()
+    osim1.step()
+    assert osim1.dt > 0.

@@ -388,3 +388,66 @@ def test_tree_steps_with_slip_walls(dim, level, box):
                 assert np.array_equal(g.download(gv, l)[inner][leaf], o.values(ov, l)[inner][leaf]), (k, l, gv)
     o.destroy()
     g.destroy()
+
+
+# ---- GfsVariableTracer on a tree (gfs_advance_tracers with gfs_face_advection_flux and the van Leer /
+# centred gradient through gfs_neighbor_value): device against the tree oracle, which on uniform trees
+# gives the bits of the uniform oracle (tests/test_oracle_tree.py)
+
+@pytest.mark.parametrize("dim,level,box,kind,gradient", [(2, 4, 2, "periodic", 1), (2, 5, 1, "periodic", 0),
+                                                         (2, 4, 2, "walls", 1), (3, 3, 1, "periodic", 1),
+                                                         (3, 3, 1, "walls", 0)])
+def test_tracers_on_a_tree_bit_exact(dim, level, box, kind, gradient):
+    if kind == "walls":
+        refine = (lambda x, y: level + box if (x < -0.25 and y > 0.) else level) if dim == 2 else \
+            (lambda x, y, z: level + box if (x < -0.25 and y > 0. and abs(z) < 0.26) else level)
+        sides = [gfship.SIDE_BOUNDARY] * 4 + ([gfship.SIDE_PERIODIC] * 2 if dim == 3 else [])
+    else:
+        inside = lambda *q: all(abs(x) <= 0.25 for x in q)
+        refine = (lambda x, y: level + box if inside(x, y) else level) if dim == 2 else \
+            (lambda x, y, z: level + box if inside(x, y, z) else level)
+        sides = None
+    o = O.Tree(refine=refine, dim=dim, sides=sides)
+    g = gfship.Tree(refine, dim=dim, sides=sides)
+    T, G = O.Tree, gfship.Tree
+    ok, gk = o.add_tracer(gradient), g.add_tracer(gradient)
+    ok2, gk2 = o.add_tracer(1 - gradient), g.add_tracer(1 - gradient)      # a second one, the other gradient
+    assert gk == G.T0 and gk2 == G.T1
+    for l in range(o.depth + 1):
+        assert np.array_equal(g.flags(l), o.flags(l))
+        c = o.centres(l)
+        zf = np.cos(2. * np.pi * c[2]) if dim == 3 else 1.
+        if kind == "walls":
+            X, Y = c[0] + 0.5, c[1] + 0.5
+            u = (np.sin(np.pi * X) * np.cos(np.pi * Y) + 0.3 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y)) * zf
+            v = (-np.cos(np.pi * X) * np.sin(np.pi * Y) - 0.3 * np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y)) * zf
+        else:
+            u = (1. - 2. * np.cos(2. * np.pi * c[0]) * np.sin(2. * np.pi * c[1])) * zf
+            v = (1. + 2. * np.sin(2. * np.pi * c[0]) * np.cos(2. * np.pi * c[1])) * zf
+        t1 = np.exp(-30. * sum((q - 0.2) ** 2 for q in c))
+        t2 = (sum((q + 0.1) ** 2 for q in c) < 0.05) * 1.          # a step: the limiter's branches
+        for arr, ov, gv in ((u, T.U, G.U), (v, T.V, G.V), (t1, ok, gk), (t2, ok2, gk2)):
+            o.values(ov, l)[...] = arr
+            g.upload(gv, l, arr)
+    for p in (o.projection_params, o.approx_projection_params, g.projection_params, g.approx_projection_params):
+        p.tolerance = 1e-4
+    o.set_time(1e30, 0.75)
+    g.set_time(1e30, 0.75)
+    o.start()
+    g.start()
+    inner = (slice(1, -1),) * dim
+    for k in range(4):
+        for l in range(o.depth + 1):
+            leaf = o.flags(l)[inner] == 1
+            for gv, ov in ((G.U, T.U), (gk, ok), (gk2, ok2)):
+                assert np.array_equal(g.download(gv, l)[inner][leaf], o.values(ov, l)[inner][leaf]), (k, l, gv)
+        o.step()
+        g.step()
+        assert g.t == o.t and g.dt == o.dt
+    # the non-leaf cells hold the restriction of the tracers (gfs_cell_coarse_init of the last step)
+    for l in range(o.depth):
+        node = o.flags(l)[inner] == 2
+        if node.any():
+            assert np.array_equal(g.download(gk, l)[inner][node], o.values(ok, l)[inner][node]), l
+    o.destroy()
+    g.destroy()

@@ -285,3 +285,84 @@ def test_uniform_tree_with_slip_walls_equals_uniform_oracle():
     for which, f in ((O.Tree.U, b.u[0]), (O.Tree.V, b.u[1]), (O.Tree.P, b.p)):
         assert np.array_equal(a.values(which, level)[1:-1, 1:-1], f.interior())
     a.destroy()
+
+
+# ---- GfsVariableTracer on a tree.  The reference holds no golden file for a tracer on a refined tree
+# (test/advection is uniform): the pins are the uniform oracle (go_timestep.c, itself pinned on
+# test/advection/error.ref) on uniform trees, bit for bit, and conservation on refined ones.
+
+@pytest.mark.parametrize("dim,kind,gradient", [(2, "periodic", 1), (2, "periodic", 0), (2, "walls", 1),
+                                               (3, "periodic", 1)])
+def test_tracer_on_a_uniform_tree_equals_uniform_oracle(dim, kind, gradient):
+    level = 5 if dim == 2 else 4
+    sides = [O.SIDE_BOUNDARY] * 4 if kind == "walls" else None
+    refine = (lambda x, y: level) if dim == 2 else (lambda x, y, z: level)
+    a = O.Tree(refine=refine, dim=dim, sides=sides)
+    b = O.Sim(dim, level, sides + [O.SIDE_PERIODIC] * 2 if sides else [O.SIDE_PERIODIC] * 6)
+    c = a.centres(level)
+    inner = (slice(1, -1),) * dim
+    X, Y = c[0] + 0.5, c[1] + 0.5
+    zf = np.cos(2. * np.pi * c[2]) if dim == 3 else 1.
+    if kind == "walls":
+        u = np.sin(np.pi * X) * np.cos(np.pi * Y) + 0.3 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y)
+        v = -np.cos(np.pi * X) * np.sin(np.pi * Y) - 0.3 * np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y)
+    else:
+        u = (1. - 2. * np.cos(2. * np.pi * c[0]) * np.sin(2. * np.pi * c[1])) * zf
+        v = (1. + 2. * np.sin(2. * np.pi * c[0]) * np.cos(2. * np.pi * c[1])) * zf
+    T0 = np.exp(-30. * sum((q - 0.1) ** 2 for q in c)) + (sum((q + 0.2) ** 2 for q in c) < 0.03)
+    k = a.add_tracer(gradient)
+    bt = b.add_tracer(gradient=gradient)
+    a.values(O.Tree.U, level)[...] = u
+    a.values(O.Tree.V, level)[...] = v
+    a.values(k, level)[...] = T0
+    b.u[0].interior()[...] = u[inner]
+    b.u[1].interior()[...] = v[inner]
+    bt.interior()[...] = T0[inner]
+    if kind == "periodic" and dim == 2:
+        for p in (a.projection_params, a.approx_projection_params, b.projection_params, b.approx_projection_params):
+            p.tolerance = 1e-6
+    a.set_time(1e30, 0.8)
+    a.start()
+    b.start()
+    for _ in range(4):
+        a.step()
+        b.step()
+    assert a.t == b.t
+    assert np.array_equal(a.values(O.Tree.U, level)[inner], b.u[0].interior())
+    assert np.array_equal(a.values(k, level)[inner], bt.interior())
+    assert not np.array_equal(bt.interior(), T0[inner])
+    a.destroy()
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_tracer_on_a_refined_tree_is_conserved(dim):
+    """sum of T x volume over the leaves: the fluxes through fine-coarse faces (flux/FTT_CELLS towards the
+    coarse cell) cancel; periodic box, refined patch"""
+    level, box = (4, 2) if dim == 2 else (3, 1)
+    inside = lambda *q: all(abs(x) <= 0.25 for x in q)
+    refine = (lambda x, y: level + box if inside(x, y) else level) if dim == 2 else \
+        (lambda x, y, z: level + box if inside(x, y, z) else level)
+    a = O.Tree(refine=refine, dim=dim)
+    k = a.add_tracer(1)
+    inner = (slice(1, -1),) * dim
+
+    def total():
+        t = 0.
+        for l in range(a.depth + 1):
+            leaf = a.flags(l)[inner] == 1
+            t += a.values(k, l)[inner][leaf].sum() / (1 << l) ** dim
+        return t
+
+    for l in range(a.depth + 1):
+        c = a.centres(l)
+        zf = np.cos(2. * np.pi * c[2]) if dim == 3 else 1.
+        a.values(O.Tree.U, l)[...] = (1. - 2. * np.cos(2. * np.pi * c[0]) * np.sin(2. * np.pi * c[1])) * zf
+        a.values(O.Tree.V, l)[...] = (1. + 2. * np.sin(2. * np.pi * c[0]) * np.cos(2. * np.pi * c[1])) * zf
+        a.values(k, l)[...] = np.exp(-30. * sum((q - 0.2) ** 2 for q in c))
+    a.set_time(1e30, 0.75)
+    t0 = total()
+    a.start()
+    for _ in range(5):
+        a.step()
+    assert abs(total() - t0) < 1e-13 * abs(t0)
+    a.destroy()
