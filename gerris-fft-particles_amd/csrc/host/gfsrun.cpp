@@ -1792,7 +1792,9 @@ int run_tree (Run & R)
     fprintf (stderr, "gfship: %s is not supported on a refined tree\n", what);
     return 1;
   };
-  if (!R.tracers.empty ()) return refuse ("a tracer");
+  if (R.tracers.size () > 2) return refuse ("more than two tracers");
+  for (int g : R.tracer_gradient)
+    if (g > 1) return refuse ("this gradient of a GfsVariableTracer");
   if (!R.plists.empty ()) return refuse ("a particle list");
   if (!R.init_spectra.empty ()) return refuse ("GfsInitSpectra");
   if (!R.device_vars.empty ()) return refuse ("a turbulent-viscosity variable");
@@ -1859,6 +1861,11 @@ int run_tree (Run & R)
   R.vars[R.var_index ("V")].dev = GFSHIP_TREE_V;
   if (R.dim == 3)
     R.vars[R.var_index ("W")].dev = GFSHIP_TREE_W;
+  for (size_t k = 0; k < R.tracers.size (); k++) {
+    int v = gfship_tree_add_tracer (R.tree, R.tracer_gradient[k]);
+    CHECK (v);
+    R.vars[R.var_index (R.tracers[k])].dev = v;
+  }
   apply_multilevel (gfship_tree_projection_params (R.tree, 0), R.proj_set);
   apply_multilevel (gfship_tree_projection_params (R.tree, 1), R.approx_set);
   double cfl = 0.8;        /* gfs_advection_params_init, src/advection.c:922-942 */

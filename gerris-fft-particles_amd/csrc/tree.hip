@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstring>
 #include <functional>
 #include <new>
 
@@ -36,13 +37,14 @@ namespace {
 
 enum { V_P, V_PMAC, V_U /* 3 */, V_G = V_U + 3 /* 3 */, V_GM = V_G + 3 /* 3 */, V_UN = V_GM + 3 /* 6 */,
        V_FV = V_UN + 6 /* 6 */, V_DIV = V_FV + 6, V_RES, V_DP, V_BCVAL, V_T /* 2: GfsVariableTracer */,
-       V_NVAR = V_T + 2 };
+       V_BCU = V_T + 2 /* 3: the values of the conditions of U, V, W per ghost cell */,
+       V_DRHS = V_BCU + 3 /* right-hand side of the implicit diffusion */, V_NVAR };
 #define TREE_MAXTRACERS 2
 
 // the variables of the C ABI (GFSHIP_TREE_*) -> storage
 const int abi_var[] = { V_P, V_PMAC, V_U, V_U + 1, V_G, V_G + 1, V_GM, V_GM + 1, V_UN, V_UN + 1, V_UN + 2,
 			V_UN + 3, V_U + 2, V_G + 2, V_GM + 2, V_UN + 4, V_UN + 5, V_DIV, V_BCVAL, V_RES,
-			V_T, V_T + 1 };
+			V_T, V_T + 1, V_BCU, V_BCU + 1, V_BCU + 2 };
 const int abi_nvar = sizeof (abi_var)/sizeof (abi_var[0]);
 
 struct P3 { double * p[3]; };       // the components of a vector
@@ -87,7 +89,11 @@ struct Sweep {              // T_LEVEL_LEAFS (m) in dependency levels
     // host copies (gfship_tree_host_check)
     std::vector<int> h_ti, h_tv, h_node_off, h_node_g, h_node_level;
     std::vector<double> h_td;
+    double sg[6] = { 0., 0., 0., 0., 0., 0. };   // the homogeneous conditions compiled into the copies of the ghosts
   } loop;
+  // the loops of the diffusion solves (10 nrelax sweeps on the first level, the conditions of U, V, W)
+  Loop dloop[6];
+  int dloop_next = 0;
 };
 
 struct DevReader {
@@ -133,6 +139,11 @@ struct gfship_tree {
   bool has_boundary = false;
   bool tape_attr_set = false;                     // dynamic-LDS limit of t_relax_tape raised on this device
   int ntracers = 0, tracer_gradient[TREE_MAXTRACERS] = { 1, 1 };   // GfsVariableTracer: 0 centred, 1 van Leer
+  // conditions of U, V, W on GfsBoundary sides (GFSHIP_BC_SYMMETRY: the default GfsBc) with their values in
+  // V_BCU + c; GfsSourceDiffusion {} U|V|W nu with its GfsMultilevelParams
+  int bc_u[3][6] = {};
+  double visc[3] = { 0., 0., 0. };
+  gfship_multilevel_params diffusion_params[3];
 };
 
 namespace {
@@ -154,7 +165,7 @@ __global__ void t_copy_ghosts_signed (const Ghost * gh, int n, double * v, Sgn6 
 
 // the conditions of P on GfsBoundary sides (src/boundary.c:45-62,253-279,336-347): symmetry (scalar),
 // Dirichlet 2 val - nb, Neumann nb + val h; periodic sides: the copy
-__global__ void t_bc_values (const Ghost * gh, int n, double * v, const double * bcval, Sgn6 kind)
+__global__ void t_bc_values (const Ghost * gh, int n, double * v, const double * bcval, Sgn6 kind, int comp = -1)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
@@ -162,7 +173,9 @@ __global__ void t_bc_values (const Ghost * gh, int n, double * v, const double *
   const double nb = v[G.img];
   const int k = (int) kind.s[G.side];     /* -1 periodic, else GFSHIP_BC_* */
   double x = nb;
-  if (k == GFSHIP_BC_DIRICHLET)
+  if (k == GFSHIP_BC_SYMMETRY && comp == G.side/2)    /* the normal component of a vector, src/boundary.c:45-51 */
+    x = - nb;
+  else if (k == GFSHIP_BC_DIRICHLET)
     x = 2.*bcval[G.g] - nb;
   else if (k == GFSHIP_BC_NEUMANN)
     x = nb + bcval[G.g]*(1./(1 << G.l));
@@ -171,7 +184,10 @@ __global__ void t_bc_values (const Ghost * gh, int n, double * v, const double *
 
 // gfs_domain_face_bc on periodic sides (src/boundary.c:1251-1258,1343-1347): the leaf ghost beyond
 // side sd takes f[OPP (sd)].v of its image
-__global__ void t_face_bc (const Ghost * gh, int n, P6 fv, Sgn6 wall, int comp)
+// wall: 0 periodic, 1 + GFSHIP_BC_* of the variable on a GfsBoundary side (face_dirichlet src/boundary.c:270-275,
+// face_neumann :349-355 with the values of the condition per ghost cell)
+__global__ void t_face_bc (const Ghost * gh, int n, P6 fv, Sgn6 wall, int comp, const double * v = nullptr,
+			   const double * bcval = nullptr)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
@@ -179,6 +195,15 @@ __global__ void t_face_bc (const Ghost * gh, int n, P6 fv, Sgn6 wall, int comp)
   double * a = fv.p[G.side ^ 1];
   if (wall.s[G.side] == 0.) {       /* periodic side */
     a[G.g] = a[G.img];
+    return;
+  }
+  const int kind = (int) wall.s[G.side] - 1;
+  if (kind == GFSHIP_BC_DIRICHLET) {
+    a[G.g] = fv.p[G.side][G.img] = bcval[G.g];
+    return;
+  }
+  if (kind == GFSHIP_BC_NEUMANN) {
+    a[G.g] = v[G.img] + bcval[G.g]*(1./(1 << G.l))/2.;
     return;
   }
   // face_symmetry, src/boundary.c:64-74 (img: the cell the ghost touches)
@@ -253,7 +278,8 @@ __global__ void t_from_above (Topo T, const Cell * cells, int n, double * v)
 // dependency level
 __global__ void __launch_bounds__(1024)
 t_relax_loop (Topo T, const Cell * cells, const int * lev_off, int nlev, const Ghost * gh, int ngh,
-	      double * u, const double * rhs, unsigned nrelax, double omega, int max_level, Sgn6 sg)
+	      double * u, const double * rhs, unsigned nrelax, double omega, int max_level, Sgn6 sg,
+	      int op = 0, double w = 1.)
 {
   DevReader R = { u };
   for (int t = threadIdx.x; t < ngh; t += blockDim.x)
@@ -265,7 +291,8 @@ t_relax_loop (Topo T, const Cell * cells, const int * lev_off, int nlev, const G
       for (int t = a + threadIdx.x; t < b; t += blockDim.x) {
 	const Cell c = cells[t];
 	const int g = T.gi (c);
-	u[g] = relax_cell (T, c, R, rhs[g], omega, max_level);
+	u[g] = op == 0 ? relax_cell (T, c, R, rhs[g], omega, max_level) :
+	  diffusion_relax_cell (T, c, R, rhs[g], w, max_level);
       }
       __syncthreads ();
     }
@@ -316,7 +343,10 @@ __host__ __device__ inline double tape_interpolation (TapeCursor & c)
 }
 
 // the sums g.a, g.b of relax / residual_set over the faces of a cell (src/poisson.c:507-557,634-678)
-__host__ __device__ inline void tape_cell (TapeCursor & c, int nd, int dim, int ncd, double & ga, double & gb)
+// w: the weight every face carries (1. for the Poisson problem with alpha = NULL; the diffusion
+// coefficient of a quadtree, face_gradient_w of tree.hpp) -- the products by 1. leave the bits alone
+__host__ __device__ inline void tape_cell (TapeCursor & c, int nd, int dim, int ncd, double & ga, double & gb,
+					   double w = 1.)
 {
   ga = 0.; gb = 0.;
   for (int d = 0; d < nd; d++) {
@@ -325,16 +355,16 @@ __host__ __device__ inline void tape_cell (TapeCursor & c, int nd, int dim, int 
       continue;
     double na, nb;
     if (kind == K_SAME) {
-      na = 1.;
-      nb = *c.tv++;
+      na = w;
+      nb = w*(*c.tv++);
     }
     else if (kind == K_FC) {      /* gradient_fine_coarse towards a coarser neighbour */
       const double cb = *c.td++;
       const double uN = *c.tv++;
       const double pb = tape_interpolation (c);
       const double gc = 2.*pb/3.;
-      na = 2./3.;
-      nb = cb*uN + gc;
+      na = w*(2./3.);
+      nb = w*(cb*uN + gc);
     }
     else {                        /* the fine cells behind a face of a coarser leaf */
       const int nch = *c.ti++;
@@ -344,8 +374,8 @@ __host__ __device__ inline void tape_cell (TapeCursor & c, int nd, int dim, int 
 	const double uch = *c.tv++;
 	const double pb = tape_interpolation (c);
 	const double gc = 2.*pb/3.;
-	na += 1.*gbi;
-	nb += 1.*((2./3.)*uch - gc);
+	na += w*gbi;
+	nb += w*((2./3.)*uch - gc);
       }
       if (dim > 2) {
 	na /= ncd/2.;
@@ -414,7 +444,7 @@ t_relax_tape (Topo T, const Cell * cells, const int * cell_off, int ncells, cons
 __global__ void __launch_bounds__(1024)
 t_relax_nodes (Topo T, const int * node_g, const int * node_off, const int * chunk, int nchunks,
 	       const int * ti_g, const double * td_g, const int * tv_g, double * u, const double * rhs,
-	       double omega)
+	       double omega, int op = 0, double w = 1.)
 {
   extern __shared__ double lds[];
   const int nd = T.nd (), dim = T.dim, ncd = T.ncd ();
@@ -437,7 +467,7 @@ t_relax_nodes (Topo T, const int * node_g, const int * node_off, const int * chu
       const int g = node_g[c];
       if (*cur.ti == K_GHOST)       /* homogeneous condition / periodic copy: ghost = s * cell */
 	u[g] = (*cur.td)*(*cur.tv);
-      else {
+      else if (op == 0) {
 	const double self = *cur.tv++;
 	double ga, gb;
 	tape_cell (cur, nd, dim, ncd, ga, gb);
@@ -445,6 +475,17 @@ t_relax_nodes (Topo T, const int * node_g, const int * node_off, const int * chu
 	if (ga != 0.)
 	  x = dim == 2 ? (1. - omega)*self + omega*(gb - rhs[g])/ga : (gb - rhs[g])/ga;
 	u[g] = x;
+      }
+      else {      /* diffusion_relax, src/poisson.c:1455-1484 (rhoc = 1): diffusion_relax_cell of tree.hpp */
+	cur.tv++;
+	double ga, gb;
+	tape_cell (cur, nd, dim, ncd, ga, gb, w);
+	int l = 0;
+	while (g >= T.off[l + 1]) l++;
+	const double h = 1./(1 << l);
+	const double a = 1.*h*h;
+	ga = 1. + ga/a;
+	u[g] = (gb/a + rhs[g])/ga;
       }
     }
     __syncthreads ();
@@ -489,6 +530,45 @@ __global__ void t_correct (Topo T, const Cell * cells, int n, double * u, const 
 }
 
 // gfs_face_interpolated_normal_velocity, src/advection.c:549-573: the value of the face
+// gfs_diffusion_rhs, src/poisson.c:1392-1451 (rhoc = 1, the face weight w of a quadtree)
+__global__ void t_diffusion_rhs (Topo T, const Cell * cells, int n, const double * v, double * rhs, double w, double pbeta)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Cell c = cells[t];
+  DevReader R = { v };
+  rhs[T.gi (c)] += diffusion_rhs_cell (T, c, R, w, pbeta);
+}
+
+// gfs_diffusion_residual (src/poisson.c:1519-1556) on the leaves + gfs_domain_norm_variable
+// (src/domain.c:2197-2232: weights = cell volumes): the maximum is exact, the sums in no particular order
+__global__ void t_diffusion_residual (Topo T, const Cell * cells, int n, const double * u, const double * rhs,
+				      double * res, double w, double * red)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Cell c = cells[t];
+  DevReader R = { u };
+  const int g = T.gi (c);
+  const double r = diffusion_residual_cell (T, c, R, rhs[g], w);
+  res[g] = r;
+  const double size = T.size (c);
+  const double vol = T.dim == 3 ? size*size*size : size*size;
+  atomic_max_pos (&red[0], fabs (r));
+  atomicAdd (&red[1], vol*r);
+  atomicAdd (&red[2], vol*fabs (r));
+  atomicAdd (&red[3], vol*r*r);
+  atomicAdd (&red[4], vol);
+}
+
+__global__ void t_copy_leaves (Topo T, const Cell * cells, int n, const double * src, double * dst)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int g = T.gi (cells[t]);
+  dst[g] = src[g];
+}
+
 __global__ void t_face_interp (Topo T, const FaceRec * faces, int n, P3 u, double * fval)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
@@ -604,6 +684,7 @@ struct AdvArgs {
   double dt;
   int use_centered;
   int gradient;            // 0 gfs_center_gradient, 1 gfs_center_van_leer_gradient
+  double visc;             // GfsSourceDiffusion on the variable: its explicit term is the MAC source (0: none)
 };
 
 // transverse_term, src/advection.c:27-47
@@ -639,7 +720,13 @@ __global__ void t_face_values (Topo T, const Cell * cells, int n, AdvArgs A)
     const double m1 = (1. - unorm)/2., m2 = (- 1. - unorm)/2.;
     const double vl = v0 + (m1 < 0.5 ? m1 : 0.5)*gr;
     const double vr = v0 + (m2 > -0.5 ? m2 : -0.5)*gr;
-    const double src = A.dt*0./2.;
+    double msrc = 0.;        /* gfs_variable_mac_source, src/source.c:38-59 */
+    if (A.visc != 0.) {
+      double sum = 0.;
+      sum += source_diffusion_value (T, cell, R, A.visc);
+      msrc = sum;
+    }
+    const double src = A.dt*msrc/2.;
     double dv;
     if (T.dim == 2)
       dv = transverse_term (T, A, cell, g, v0, R, msize, (c + 1) % 2);
@@ -847,7 +934,8 @@ __global__ void t_cfl_faces (Topo T, const FaceRec * faces, int n, P6 un, double
   }
 }
 
-__global__ void t_cfl_cells (Topo T, const Cell * cells, int n, P3 u, double * red)
+struct D3 { double d[3]; };
+__global__ void t_cfl_cells (Topo T, const Cell * cells, int n, P3 u, double * red, D3 visc)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
@@ -858,6 +946,15 @@ __global__ void t_cfl_cells (Topo T, const Cell * cells, int n, P3 u, double * r
     if (u.p[c][g] != 0.) {
       const double cflu = length/fabs (fm*u.p[c][g]);
       atomic_min_pos (red, cflu*cflu);
+    }
+    if (visc.d[c] != 0.) {      /* p->v[c]->sources: the acceleration scale, src/domain.c:2882-2891 */
+      DevReader R = { u.p[c] };
+      double gs = 0.;
+      gs += source_diffusion_value (T, cells[t], R, visc.d[c]);
+      if (gs != 0.) {
+	const double cflg = 2.*length/fabs (fm*gs);
+	atomic_min_pos (red, cflg);
+      }
     }
   }
 }
@@ -1326,10 +1423,12 @@ void loop_free (Sweep::Loop & P)
 // write it must see, and of every write after the reads of the value it replaces (RAW, WAR, WAW of
 // the sequential program): the results are those of the sequential program, and sweep s + 1 follows
 // sweep s a few levels behind instead of waiting for its end
-int loop_plan (gfship_tree * tr, int m, unsigned nrelax, Sweep * S)
+int loop_plan (gfship_tree * tr, int m, unsigned nrelax, Sweep * S, Sweep::Loop * out = nullptr,
+	       const Sgn6 * signs = nullptr)
 {
-  loop_free (S->loop);
-  const Sgn6 sg = homogeneous_signs (tr);
+  Sweep::Loop & P = out ? *out : S->loop;
+  loop_free (P);
+  const Sgn6 sg = signs ? *signs : homogeneous_signs (tr);
   const size_t nc = S->h_g.size ();
   // the cells were sorted by single-sweep dependency level; the sequential order inside a sweep is
   // the tree order: recover it from the positions the sweep plan kept (sorted is stable per level,
@@ -1397,7 +1496,7 @@ int loop_plan (gfship_tree * tr, int m, unsigned nrelax, Sweep * S)
     if (e == c) return GFSHIP_EUNSUPPORTED;
     c = e;
   }
-  Sweep::Loop & P = S->loop;
+  for (int d = 0; d < 6; d++) P.sg[d] = sg.s[d];
   P.nchunks = (int) chunk.size ();
   chunk.push_back ((int) nodes.size ());
   P.nnodes = (int) nodes.size ();
@@ -1492,6 +1591,38 @@ int bc_leaves (gfship_tree * tr, double * v, int comp = -1)
   return 0;
 }
 
+// gfs_domain_bc of velocity component c: the conditions of gfship_tree_set_bc_u (symmetry by default)
+int bc_velocity (gfship_tree * tr, int c)
+{
+  bool plain = true;
+  for (int d = 0; d < 6; d++)
+    if (tr->side[d] != GFSHIP_SIDE_PERIODIC && tr->bc_u[c][d] != GFSHIP_BC_SYMMETRY) plain = false;
+  if (plain || !tr->nghost_leaves)
+    return bc_leaves (tr, tr->var[V_U + c], c);
+  Sgn6 kind;
+  for (int d = 0; d < 6; d++)
+    kind.s[d] = tr->side[d] == GFSHIP_SIDE_PERIODIC ? -1. : (double) tr->bc_u[c][d];
+  t_bc_values<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves, tr->var[V_U + c],
+      tr->var[V_BCU + c], kind, c);
+  KCHECK ();
+  return 0;
+}
+
+// the homogeneous conditions of velocity component c (gfs_domain_homogeneous_bc in the relax loops of its
+// diffusion solve): ghost = s * cell
+Sgn6 homogeneous_signs_u (const gfship_tree * tr, int c)
+{
+  Sgn6 sg;
+  for (int d = 0; d < 6; d++) {
+    sg.s[d] = 1.;
+    if (tr->side[d] != GFSHIP_SIDE_PERIODIC) {
+      const int k = tr->bc_u[c][d];
+      sg.s[d] = k == GFSHIP_BC_DIRICHLET ? -1. : k == GFSHIP_BC_NEUMANN ? 1. : (c == d/2 ? -1. : 1.);
+    }
+  }
+  return sg;
+}
+
 // post-order traversal of the non-leaf cells: deepest level first
 int from_below (gfship_tree * tr, double * v, int mode)
 {
@@ -1522,7 +1653,10 @@ int residual_norm (gfship_tree * tr, const double * u, const double * rhs, doubl
   return 0;
 }
 
-int relax_loop (gfship_tree * tr, int m, unsigned nrelax, double omega)
+// op 0: the Poisson relax on V_DP with the conditions of P; op 1: diffusion_relax with the face weight w and
+// the homogeneous conditions sg of the variable being diffused
+int relax_loop (gfship_tree * tr, int m, unsigned nrelax, double omega, int op = 0, double w = 1.,
+		const Sgn6 * sgp = nullptr)
 {
   Sweep & S = tr->sweep[m];
   static int use_template = -1;
@@ -1540,22 +1674,36 @@ int relax_loop (gfship_tree * tr, int m, unsigned nrelax, double omega)
     const char * e = getenv ("GFSHIP_TREE_NO_PIPELINE");      /* 1: sweep after sweep (t_relax_tape) */
     no_pipeline = e ? atoi (e) : 0;
   }
-  if (S.taped && !use_template && !no_pipeline) {
-    if (S.loop.nrelax != nrelax) {
+  const Sgn6 sg = sgp ? *sgp : homogeneous_signs (tr);
+  if (S.taped && !use_template && (!no_pipeline || op == 1)) {
+    Sweep::Loop * P = &S.loop;
+    if (op == 1) {
+      /* the plan with these conditions and this number of sweeps, kept from an earlier solve */
+      P = nullptr;
+      for (Sweep::Loop & Q : S.dloop)
+	if (Q.nrelax == nrelax && Q.nnodes > 0 && !memcmp (Q.sg, sg.s, sizeof (Q.sg))) P = &Q;
+      if (!P) {
+	P = &S.dloop[S.dloop_next];
+	S.dloop_next = (S.dloop_next + 1) % 6;
+	int e = loop_plan (tr, m, nrelax, &S, P, &sg);
+	if (e) return e;
+      }
+    }
+    else if (S.loop.nrelax != nrelax || memcmp (S.loop.sg, sg.s, sizeof (S.loop.sg))) {
       int e = loop_plan (tr, m, nrelax, &S);
       if (e) return e;
     }
     GFSHIP_HIP (hipFuncSetAttribute ((const void *) t_relax_nodes, hipFuncAttributeMaxDynamicSharedMemorySize,
 				     TAPE_LDS_BYTES));
-    t_relax_nodes<<<1, 1024, TAPE_LDS_BYTES, tr->stream>>> (tr->D, S.loop.node_g, S.loop.node_off, S.loop.chunk,
-	S.loop.nchunks, S.loop.ti, S.loop.td, S.loop.tv, tr->var[V_DP], tr->var[V_RES], omega);
+    t_relax_nodes<<<1, 1024, TAPE_LDS_BYTES, tr->stream>>> (tr->D, P->node_g, P->node_off, P->chunk,
+	P->nchunks, P->ti, P->td, P->tv, tr->var[V_DP], tr->var[V_RES], omega, op, w);
   }
   else if (S.taped && !use_template)
     t_relax_tape<<<1, 1024, TAPE_LDS_BYTES, tr->stream>>> (tr->D, S.cells, S.cell_off, S.ncells, S.chunk, S.nchunks,
-	S.ti, S.td, S.tv, S.ghosts, S.nghosts, tr->var[V_DP], tr->var[V_RES], nrelax, omega, homogeneous_signs (tr));
+	S.ti, S.td, S.tv, S.ghosts, S.nghosts, tr->var[V_DP], tr->var[V_RES], nrelax, omega, sg);
   else
     t_relax_loop<<<1, 1024, 0, tr->stream>>> (tr->D, S.cells, S.lev_off, S.nlev, S.ghosts, S.nghosts,
-					       tr->var[V_DP], tr->var[V_RES], nrelax, omega, m, homogeneous_signs (tr));
+					       tr->var[V_DP], tr->var[V_RES], nrelax, omega, m, sg, op, w);
   KCHECK ();
   return 0;
 }
@@ -1670,7 +1818,7 @@ int correct_centered (gfship_tree * tr, int gvar, double dt)   /* src/timestep.c
   t_scale<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, p3 (tr, V_U), dt, 1, p3 (tr, gvar));
   KCHECK ();
   for (int c = 0; c < tr->H.dim; c++)
-    if ((e = bc_leaves (tr, tr->var[V_U + c], c))) return e;
+    if ((e = bc_velocity (tr, c))) return e;
   return 0;
 }
 
@@ -1697,6 +1845,8 @@ int face_values_set (gfship_tree * tr, const double * v, double dt, int use_cent
 { /* src/timestep.c:644-654 */
   AdvArgs A;
   A.v = v; A.dt = dt; A.use_centered = use_centered; A.gradient = gradient;
+  A.visc = 0.;
+  for (int c = 0; c < 3; c++) if (v == tr->var[V_U + c]) A.visc = tr->visc[c];
   for (int c = 0; c < 3; c++) A.u[c] = tr->var[V_U + c];
   for (int d = 0; d < 6; d++) { A.un[d] = tr->var[V_UN + d]; A.fv[d] = tr->var[V_FV + d]; }
   t_face_values<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, A);
@@ -1704,10 +1854,85 @@ int face_values_set (gfship_tree * tr, const double * v, double dt, int use_cent
   if (tr->nghost_leaves)
   {
     Sgn6 wall;
-    for (int d = 0; d < 6; d++) wall.s[d] = tr->side[d] != GFSHIP_SIDE_PERIODIC ? 1. : 0.;
-    t_face_bc<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves, p6 (tr, V_FV), wall, comp);
+    int ucomp = -1;
+    for (int c = 0; c < 3; c++) if (v == tr->var[V_U + c]) ucomp = c;
+    for (int d = 0; d < 6; d++)
+      wall.s[d] = tr->side[d] != GFSHIP_SIDE_PERIODIC ? 1. + (ucomp >= 0 ? tr->bc_u[ucomp][d] : GFSHIP_BC_SYMMETRY) : 0.;
+    t_face_bc<<<blocks (tr->nghost_leaves), 256, 0, tr->stream>>> (tr->ghost_leaves, tr->nghost_leaves, p6 (tr, V_FV), wall, comp,
+	v, ucomp >= 0 ? tr->var[V_BCU + ucomp] : nullptr);
   }
   KCHECK ();
+  return 0;
+}
+
+// gfs_diffusion_residual + the norm of gfs_diffusion (src/timestep.c:756-760)
+int diffusion_residual_norm (gfship_tree * tr, const double * u, const double * rhs, double w, gfship_norm * out)
+{
+  GFSHIP_HIP (hipMemsetAsync (tr->d_red, 0, 5*sizeof (double), tr->stream));
+  t_diffusion_residual<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, u, rhs,
+      tr->var[V_RES], w, tr->d_red);
+  KCHECK ();
+  GFSHIP_HIP (hipMemcpyAsync (tr->h_red, tr->d_red, 5*sizeof (double), hipMemcpyDeviceToHost, tr->stream));
+  GFSHIP_HIP (hipStreamSynchronize (tr->stream));
+  const double ws = tr->h_red[4];
+  out->w = ws;
+  out->infty = ws > 0. ? tr->h_red[0] : 0.;
+  out->bias = ws > 0. ? tr->h_red[1]/ws : 0.;
+  out->first = ws > 0. ? tr->h_red[2]/ws : 0.;
+  out->second = ws > 0. ? sqrt (tr->h_red[3]/ws) : 0.;
+  return 0;
+}
+
+// gfs_diffusion_cycle, src/poisson.c:1633-1690: the residual restricted by gfs_get_from_below_intensive,
+// 10 nrelax sweeps on the first level, the homogeneous conditions of the variable in the loops
+int diffusion_cycle (gfship_tree * tr, unsigned levelmin, unsigned depth, unsigned nrelax, int c, double w)
+{
+  int e;
+  const Sgn6 sg = homogeneous_signs_u (tr, c);
+  double * u = tr->var[V_U + c];
+  if ((e = from_below (tr, tr->var[V_RES], 0))) return e;
+  GFSHIP_HIP (hipMemsetAsync (tr->var[V_DP], 0, tr->ncell*sizeof (double), tr->stream));
+  if ((e = relax_loop (tr, levelmin, 10*nrelax, 1., 1, w, &sg))) return e;
+  for (unsigned m = levelmin + 1; m <= depth; m++) {
+    if (tr->nnonleaf[m - 1]) {
+      t_from_above<<<blocks (tr->nnonleaf[m - 1]), 256, 0, tr->stream>>> (tr->D, tr->nonleaf[m - 1], tr->nnonleaf[m - 1], tr->var[V_DP]);
+      KCHECK ();
+    }
+    if ((e = relax_loop (tr, m, nrelax, 1., 1, w, &sg))) return e;
+  }
+  t_correct<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, u, tr->var[V_DP]);
+  KCHECK ();
+  return bc_velocity (tr, c);
+}
+
+// variable_diffusion (src/timestep.c:923-949) + gfs_diffusion (:735-788) of velocity component c; the
+// right-hand side is V_DRHS.  Quadtrees: every face carries the weight beta dt D (face_gradient_w)
+int variable_diffusion (gfship_tree * tr, int c)
+{
+  int e;
+  gfship_multilevel_params * par = &tr->diffusion_params[c];
+  const double w = 1.*(par->beta*tr->dt)*tr->visc[c]*1./1.;      /* diffusion_coef, src/poisson.c:1280-1285 */
+  double * v = tr->var[V_U + c], * rhs = tr->var[V_DRHS];
+  t_diffusion_rhs<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, v, rhs, w,
+      (1. - par->beta)/par->beta);
+  KCHECK ();
+  unsigned minlevel = par->minlevel;
+  const unsigned maxlevel = tr->H.depth;
+  if ((e = diffusion_residual_norm (tr, v, rhs, w, &par->residual))) return e;
+  par->residual_before = par->residual;
+  double res_max_before = par->residual.infty;
+  par->niter = 0;
+  while (par->niter < par->nitermin ||
+	 (par->residual.infty > par->tolerance && par->niter < par->nitermax)) {
+    if ((e = diffusion_cycle (tr, minlevel, maxlevel, par->nrelax, c, w))) return e;
+    if ((e = diffusion_residual_norm (tr, v, rhs, w, &par->residual))) return e;
+    if (par->residual.infty == res_max_before)
+      break;
+    if (par->residual.infty > res_max_before/1.1 && minlevel < maxlevel)
+      minlevel++;
+    res_max_before = par->residual.infty;
+    par->niter++;
+  }
   return 0;
 }
 
@@ -1733,12 +1958,21 @@ int centered_velocity_advection (gfship_tree * tr, int gmac, int g)
     if ((e = face_values_set (tr, tr->var[V_U + c], tr->dt, 0, c))) return e;
     t_face_flux<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, upwind_args (tr), tr->var[gmac + c], tr->dt, F.fval);
     KCHECK ();
+    double * sv = tr->var[V_U + c];
+    if (tr->visc[c] != 0.) {
+      /* source_diffusion (v[c]): rhs = copy of v, the sources into rhs, then the implicit solve
+	 (src/timestep.c:996-1007) */
+      sv = tr->var[V_DRHS];
+      t_copy_leaves<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, tr->var[V_U + c], sv);
+      KCHECK ();
+    }
     t_gather_flux<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, F.faces, F.inc_off, F.inc, F.fval,
-	tr->var[V_U + c], tr->var[g + c], tr->dt);
+	sv, tr->var[g + c], tr->dt);
     KCHECK ();
+    if (tr->visc[c] != 0. && (e = variable_diffusion (tr, c))) return e;
   }
   for (int c = 0; c < tr->H.dim; c++)
-    if ((e = bc_leaves (tr, tr->var[V_U + c], c))) return e;
+    if ((e = bc_velocity (tr, c))) return e;
   return 0;
 }
 
@@ -1786,7 +2020,8 @@ int domain_cfl (gfship_tree * tr, double * cfl)   /* src/domain.c:2899-2923 */
   FaceSet & F = tr->fs[0];
   t_cfl_faces<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, p6 (tr, V_UN), tr->d_red);
   KCHECK ();
-  t_cfl_cells<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, p3 (tr, V_U), tr->d_red);
+  D3 visc = { { tr->visc[0], tr->visc[1], tr->visc[2] } };
+  t_cfl_cells<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, p3 (tr, V_U), tr->d_red, visc);
   KCHECK ();
   GFSHIP_HIP (hipMemcpyAsync (tr->h_red, tr->d_red, sizeof (double), hipMemcpyDeviceToHost, tr->stream));
   GFSHIP_HIP (hipStreamSynchronize (tr->stream));
@@ -1846,6 +2081,7 @@ void tree_free (gfship_tree * tr)
     (void) hipFree (tr->sweep[l].ti); (void) hipFree (tr->sweep[l].td); (void) hipFree (tr->sweep[l].tv);
     (void) hipFree (tr->sweep[l].cell_off); (void) hipFree (tr->sweep[l].chunk);
     loop_free (tr->sweep[l].loop);
+    for (Sweep::Loop & P : tr->sweep[l].dloop) loop_free (P);
   }
   for (FaceSet & F : tr->fs) { (void) hipFree (F.faces); (void) hipFree (F.inc_off); (void) hipFree (F.inc); (void) hipFree (F.fval); }
   (void) hipFree (tr->d_red);
@@ -2049,8 +2285,8 @@ static int tree_create_sides (gfship_tree ** out, int dim, gfship_refine_fn refi
     TRYHIP (hipMemset (tr->var[v], 0, tr->ncell*sizeof (double)));
   }
   if (!g_host_only) {
-    TRYHIP (hipMalloc ((void **) &tr->d_red, 4*sizeof (double)));
-    TRYHIP (hipHostMalloc ((void **) &tr->h_red, 4*sizeof (double), 0));
+    TRYHIP (hipMalloc ((void **) &tr->d_red, 8*sizeof (double)));
+    TRYHIP (hipHostMalloc ((void **) &tr->h_red, 8*sizeof (double), 0));
   }
   traverse (T, root_cell (T), T_LEAFS, -1, [&] (Cell c) { tr->hleaves.push_back (c); });
   tr->nleaves = (int) tr->hleaves.size ();
@@ -2073,6 +2309,10 @@ static int tree_create_sides (gfship_tree ** out, int dim, gfship_refine_fn refi
 #undef TRYHIP
   gfship_multilevel_params_init (&tr->projection_params, dim);
   gfship_multilevel_params_init (&tr->approx_projection_params, dim);
+  for (int c = 0; c < 3; c++) {     /* diffusion_init, src/source.c:966-974 */
+    gfship_multilevel_params_init (&tr->diffusion_params[c], dim);
+    tr->diffusion_params[c].tolerance = 1e-6;
+  }
   *out = tr;
   return GFSHIP_OK;
 }
@@ -2306,6 +2546,33 @@ int gfship_tree_sweep_levels (const gfship_tree * tr, int level, int * ncells, i
   return GFSHIP_OK;
 }
 
+int gfship_tree_set_bc_u (gfship_tree * tr, int c, int d, int kind)
+{
+  GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_set_bc_u: null tree");
+  GFSHIP_CHECK (c >= 0 && c < tr->H.dim && d >= 0 && d < 2*tr->H.dim, GFSHIP_EINVAL, "component %d / side %d out of range", c, d);
+  GFSHIP_CHECK (kind == GFSHIP_BC_SYMMETRY || kind == GFSHIP_BC_DIRICHLET || kind == GFSHIP_BC_NEUMANN, GFSHIP_EINVAL,
+		"kind of condition %d", kind);
+  GFSHIP_CHECK (tr->side[d] != GFSHIP_SIDE_PERIODIC || kind == GFSHIP_BC_SYMMETRY, GFSHIP_EINVAL, "side %d is periodic", d);
+  tr->bc_u[c][d] = kind;
+  return GFSHIP_OK;
+}
+
+int gfship_tree_set_viscosity (gfship_tree * tr, int c, double nu)
+{
+  GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_set_viscosity: null tree");
+  GFSHIP_CHECK (c >= 0 && c < tr->H.dim, GFSHIP_EINVAL, "component %d out of range", c);
+  GFSHIP_CHECK (nu >= 0., GFSHIP_EINVAL, "the diffusion coefficient must be positive");
+  /* octrees: the face coefficients of the coarse side of a fine-coarse face are sums of four quarters that
+     may round (src/poisson.c:1280-1303): they would have to be kept per face */
+  GFSHIP_CHECK (nu == 0. || tr->H.dim == 2, GFSHIP_EUNSUPPORTED,
+		"GfsSourceDiffusion on a refined tree is supported on quadtrees (2-D)");
+  tr->visc[c] = nu;
+  return GFSHIP_OK;
+}
+
+gfship_multilevel_params * gfship_tree_diffusion_params (gfship_tree * tr, int c)
+{ return (tr && c >= 0 && c < 3) ? &tr->diffusion_params[c] : nullptr; }
+
 int gfship_tree_add_tracer (gfship_tree * tr, int gradient)
 {
   GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_add_tracer: null tree");
@@ -2319,14 +2586,11 @@ int gfship_tree_add_tracer (gfship_tree * tr, int gradient)
 int gfship_tree_start (gfship_tree * tr)
 {
   GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_start: null tree");
-  for (int d = 0; d < 2*tr->H.dim; d++)
-    GFSHIP_CHECK (tr->side[d] == GFSHIP_SIDE_PERIODIC || tr->bc_p[d] == GFSHIP_BC_SYMMETRY, GFSHIP_EUNSUPPORTED,
-		  "gfship_tree_start: the time step knows the default (symmetry) conditions on GfsBoundary sides only");
   GFSHIP_HIP (hipSetDevice (tr->device));
   int e;
   const int vars[] = { V_P, V_PMAC, V_U, V_U + 1, V_U + 2 };
   for (int k = 0; k < 2 + tr->H.dim; k++)
-    if ((e = bc_leaves (tr, tr->var[vars[k]], k - 2))) return e;
+    if ((e = k >= 2 ? bc_velocity (tr, k - 2) : bc_leaves (tr, tr->var[vars[k]], -1))) return e;
   for (int k = 0; k < tr->ntracers; k++)
     if ((e = bc_scalar (tr, tr->var[V_T + k]))) return e;
   if ((e = coarse_init (tr))) return e;

@@ -361,6 +361,125 @@ __host__ __device__ inline double face_interpolated_value_generic (const Topo & 
   return avg == 0. ? 0. : avg/(1.*n);
 }
 
+// face_weighted_gradient (src/fluid.c:833-893) / gfs_face_cm_weighted_gradient (:1300-1400, no metric)
+// with the SAME weight w on every face: the face coefficients of gfs_diffusion_coefficients with a
+// constant D on a quadtree (diffusion_coef gives every leaf face w, the coarse side of a fine-coarse
+// face w/2 + w/2 and face_coeff_from_below (w + w)/2, all exactly w; in 3-D the sums of four quarters
+// may round: not used there)
+template <class V>
+__host__ __device__ inline Grad2 face_gradient_w (const Topo & T, const Face & face, V & v, int max_level, double w)
+{
+  Grad2 g = { 0., 0. };
+  if (!exists (face.neighbor) || w == 0.)
+    return g;
+  const int level = face.cell.l;
+  if (face.neighbor.l < level) {
+    const Grad3 gcf = gradient_fine_coarse (T, face, v);
+    g.a = w*gcf.a;
+    g.b = w*(gcf.b*v (T, face.neighbor) + gcf.c);
+  }
+  else if (level == max_level || T.leaf (face.neighbor)) {
+    g.a = w;
+    g.b = w*v (T, face.neighbor);
+  }
+  else {
+    Face f;
+    f.d = face.d ^ 1;
+    f.neighbor = face.cell;
+    const int n = T.ncd ();
+    for (int i = 0; i < n; i++) {
+      f.cell = T.child_direction (face.neighbor, f.d, i);
+      if (exists (f.cell)) {
+	const Grad3 gcf = gradient_fine_coarse (T, f, v);
+	g.a += w*gcf.b;
+	g.b += w*(gcf.a*v (T, f.cell) - gcf.c);
+      }
+    }
+    if (T.dim > 2) {
+      g.a /= n/2.;
+      g.b /= n/2.;
+    }
+  }
+  return g;
+}
+
+// diffusion_relax, src/poisson.c:1455-1484 (rhoc = 1): the new value of u at `cell'
+template <class V>
+__host__ __device__ inline double diffusion_relax_cell (const Topo & T, Cell cell, V & u, double res, double w,
+							int max_level)
+{
+  Grad2 g = { 0., 0. };
+  Face f;
+  f.cell = cell;
+  for (f.d = 0; f.d < T.nd (); f.d++) {
+    f.neighbor = T.neighbor (cell, f.d);
+    const Grad2 ng = face_gradient_w (T, f, u, max_level, w);
+    g.a += ng.a;
+    g.b += ng.b;
+  }
+  const double h = T.size (cell);
+  const double a = 1.*h*h;
+  g.a = 1. + g.a/a;
+  return (g.b/a + res)/g.a;
+}
+
+// diffusion_residual, src/poisson.c:1519-1556 (rhoc = 1)
+template <class V>
+__host__ __device__ inline double diffusion_residual_cell (const Topo & T, Cell cell, V & u, double rhs, double w)
+{
+  Grad2 g = { 0., 0. };
+  Face f;
+  f.cell = cell;
+  for (f.d = 0; f.d < T.nd (); f.d++) {
+    f.neighbor = T.neighbor (cell, f.d);
+    const Grad2 ng = face_gradient_w (T, f, u, -1, w);
+    g.a += ng.a;
+    g.b += ng.b;
+  }
+  const double h = T.size (cell);
+  double a = 1.;
+  a *= h*h;
+  g.a = 1. + g.a/a;
+  g.b = rhs + g.b/a;
+  return g.b - g.a*u (T, cell);
+}
+
+// diffusion_rhs, src/poisson.c:1392-1421 (rhoc = 1): what is added to rhs
+template <class V>
+__host__ __device__ inline double diffusion_rhs_cell (const Topo & T, Cell cell, V & v, double w, double pbeta)
+{
+  double f = 0.;
+  const double h = T.size (cell), value = v (T, cell);
+  Face face;
+  face.cell = cell;
+  for (face.d = 0; face.d < T.nd (); face.d++) {
+    face.neighbor = T.neighbor (cell, face.d);
+    const Grad2 g = face_gradient_w (T, face, v, -1, w);
+    f += g.b - g.a*value;
+  }
+  return pbeta*f/(h*h*1.);
+}
+
+// source_diffusion_value, src/source.c:1105-1144 (phi = v, constant D, alpha = NULL)
+template <class V>
+__host__ __device__ inline double source_diffusion_value (const Topo & T, Cell cell, V & v, double D)
+{
+  Grad2 g = { 0., 0. };
+  const double v0 = v (T, cell);
+  Face f;
+  f.cell = cell;
+  for (f.d = 0; f.d < T.nd (); f.d++) {
+    f.neighbor = T.neighbor (cell, f.d);
+    if (exists (f.neighbor)) {
+      const Grad2 e = face_gradient (T, f, v, -1);
+      g.a += D*e.a;
+      g.b += D*e.b;
+    }
+  }
+  const double h = T.size (cell);
+  return 1.*(g.b - g.a*v0)/(h*h);
+}
+
 // relax2D (src/poisson.c:532-557) / relax (:507-530, no omega), dia = 0, unit weights: the new value of u at `cell'
 template <class V>
 __host__ __device__ inline double relax_cell (const Topo & T, Cell cell, V & u, double rhs, double omega,

@@ -171,6 +171,9 @@ SIGNATURES = {
     "gfship_tree_dt": (_d, [_vp]),
     "gfship_tree_iter": (_u, [_vp]),
     "gfship_tree_add_tracer": (_i, [_vp, _i]),
+    "gfship_tree_set_bc_u": (_i, [_vp, _i, _i, _i]),
+    "gfship_tree_set_viscosity": (_i, [_vp, _i, _d]),
+    "gfship_tree_diffusion_params": (C.POINTER(MultilevelParams), [_vp, _i]),
     "gfship_tree_start": (_i, [_vp]),
     "gfship_tree_step": (_i, [_vp]),
     "gfship_tree_sweep_levels": (_i, [_vp, _i, _pi, _pi]),
@@ -694,7 +697,7 @@ def tree_host_check(refine, dim=2, sides=None, nrelax=4):
 class Tree:
     """gfship_tree: a GfsSimulation on one periodic box refined by a GfsRefine function (coarse-fine
     stencils; quadtree or octree).  refine (x, y) or refine (x, y, z) -> level wanted there."""
-    P, PMAC, U, V, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3, W, GZ, GMACZ, UN4, UN5, DIV, BCVAL, RES, T0, T1 = range(22)
+    P, PMAC, U, V, GX, GY, GMACX, GMACY, UN0, UN1, UN2, UN3, W, GZ, GMACZ, UN4, UN5, DIV, BCVAL, RES, T0, T1, BCU, BCV, BCW = range(25)
 
     def __init__(self, refine, dim=2, device=0, sides=None):
         self.dim = dim
@@ -741,6 +744,20 @@ class Tree:
 
     def set_time(self, end, cfl):
         _check(lib().gfship_tree_set_time(self.ptr, end, cfl))
+
+    def set_bc_u(self, c, d, kind, values=None):
+        """condition of velocity component c on side d; values: per level, the arrays of the values at the
+        ghost cells (the oracle's gt_bc_values_u layout), uploaded to BCU + c"""
+        _check(lib().gfship_tree_set_bc_u(self.ptr, c, d, kind))
+        if values is not None:
+            for l, a in enumerate(values):
+                self.upload(Tree.BCU + c, l, a)
+
+    def set_viscosity(self, c, nu):
+        _check(lib().gfship_tree_set_viscosity(self.ptr, c, nu))
+
+    def diffusion_params(self, c):
+        return lib().gfship_tree_diffusion_params(self.ptr, c).contents
 
     def add_tracer(self, gradient=1):
         """GfsVariableTracer [{ gradient = }] (0 centred, 1 van Leer): the variable index (T0, T1)"""

@@ -533,12 +533,13 @@ enum { GFSHIP_TREE_P = 0, GFSHIP_TREE_PMAC, GFSHIP_TREE_U, GFSHIP_TREE_V, GFSHIP
        GFSHIP_TREE_GMACX, GFSHIP_TREE_GMACY, GFSHIP_TREE_UN0, GFSHIP_TREE_UN1, GFSHIP_TREE_UN2,
        GFSHIP_TREE_UN3, GFSHIP_TREE_W, GFSHIP_TREE_GZ, GFSHIP_TREE_GMACZ, GFSHIP_TREE_UN4,
        GFSHIP_TREE_UN5, GFSHIP_TREE_DIV, GFSHIP_TREE_BCVAL, GFSHIP_TREE_RES,
-       GFSHIP_TREE_T0, GFSHIP_TREE_T1 };
+       GFSHIP_TREE_T0, GFSHIP_TREE_T1, GFSHIP_TREE_BCU, GFSHIP_TREE_BCV, GFSHIP_TREE_BCW };
 				    /* variables of a tree: P, Pmac, U, V, g, gmac, f[d].un; then the 3-D ones;
 				       DIV: the result of gfship_tree_divergence / the right-hand side of
 				       gfship_tree_poisson_solve; BCVAL: the values of the conditions of P, one per
 				       ghost cell (at the face centres); RES: the residual of the last solve;
-				       T0, T1: the tracers of gfship_tree_add_tracer */
+				       T0, T1: the tracers of gfship_tree_add_tracer; BCU, BCV, BCW: the values of the
+				       conditions of U, V, W, one per ghost cell (at the face centres) */
 int  gfship_tree_create (gfship_tree ** tree, int dim, gfship_refine_fn refine, void * ctx, int device);
 /* the same with GfsBoundary sides (side[d] = GFSHIP_SIDE_PERIODIC or GFSHIP_SIDE_BOUNDARY; the ghost
    cells of a boundary are refined like the cells they touch, gfs_domain_match): such a tree carries
@@ -577,6 +578,19 @@ unsigned gfship_tree_iter (const gfship_tree * tree);
    GfsBoundary sides.  Returns GFSHIP_TREE_T0 / _T1 (two tracers at most), to be called before
    gfship_tree_start. */
 int  gfship_tree_add_tracer (gfship_tree * tree, int gradient);
+/* GfsBcDirichlet / GfsBcNeumann U|V|W on a GfsBoundary side of a tree (src/boundary.c:253-279,336-360 with
+   their face_* forms for the Godunov face values; GFSHIP_BC_SYMMETRY: the default GfsBc), the values per
+   ghost cell in GFSHIP_TREE_BCU + c; the conditions of P of gfship_tree_set_bc apply in the time step too
+   (an outflow: BcDirichlet P 0 + BcNeumann U 0).
+   GfsSourceDiffusion {} U|V|W nu on a tree: the implicit solve of gfs_diffusion (src/timestep.c:735-788,
+   923-949, src/poisson.c:1271-1690: coefficients with their fine-coarse forms, gfs_diffusion_rhs,
+   diffusion_relax in tree order with the homogeneous conditions of the component, gfs_diffusion_cycle with
+   10 nrelax sweeps on the first level), the explicit term as MAC source of the face values and in the
+   CFL condition.  Quadtrees only (GFSHIP_EUNSUPPORTED on an octree); with Dirichlet walls this is the
+   lid-driven cavity of test/lid on a refined tree. */
+int  gfship_tree_set_bc_u (gfship_tree * tree, int c, int d, int kind);
+int  gfship_tree_set_viscosity (gfship_tree * tree, int c, double nu);
+gfship_multilevel_params * gfship_tree_diffusion_params (gfship_tree * tree, int c);
 int  gfship_tree_start (gfship_tree * tree);
 int  gfship_tree_step (gfship_tree * tree);
 /* the derived variable `Divergence' (gfs_divergence, src/fluid.c:2357-2376, with

@@ -73,6 +73,16 @@ typedef struct GtSim {
      (gfs_advance_tracers, simulation.c:405-430); gradient 0 gfs_center_gradient, 1 van Leer (default) */
   Var tracer[GT_MAXTRACERS];
   int ntracers, tracer_gradient[GT_MAXTRACERS];
+  /* conditions of U, V, W on GfsBoundary sides: GO_BC_SYMMETRY (the default GfsBc), _DIRICHLET, _NEUMANN
+     with, per ghost cell, the value of the GfsFunction at the face centre (boundary.c:45-62,253-279,
+     336-347 and their face_* forms) */
+  int bc_u[3][6];
+  Var bcu[3];
+  int bcu_alloc;
+  const Var * bc_owner;                       /* the variable whose (homogeneous) conditions a relax loop applies to dp */
+  /* GfsSourceDiffusion {} U|V|W nu: constant implicit viscosity (source.c:933-1160) */
+  double visc[3];
+  GoMultilevelParams diffusion_params[3];
 } GtSim;
 
 static const Cell NOCELL = { 0, -1 };
@@ -353,13 +363,27 @@ static void bc_ghost (GtSim * s, int l, int side, int G, int image, void * data)
   /* GfsBoundary: symmetry (default, scalar) boundary.c:45-62, Dirichlet :253-279, Neumann :336-347 */
   double nb = p->v->lev[l][ghost_own (s, l, side, G)];
   double h = 1./s->n[l];
-  int comp = var_component (s, p->v);
+  const Var * owner = s->bc_owner ? s->bc_owner : p->v;     /* gfs_domain_homogeneous_bc (ov, v) */
+  int comp = var_component (s, owner);
+  int ucomp = -1;
+  for (int c = 0; c < 3; c++)
+    if (owner == &s->u[c]) ucomp = c;
+  if (ucomp >= 0 && s->bc_u[ucomp][side] != GO_BC_SYMMETRY) {
+    int kind = s->bc_u[ucomp][side];
+    if (s->bc_homogeneous)
+      p->v->lev[l][G] = kind == GO_BC_DIRICHLET ? - nb : nb;
+    else {
+      double value = s->bcu[ucomp].lev[l][G];
+      p->v->lev[l][G] = kind == GO_BC_DIRICHLET ? 2.*value - nb : nb + value*h;
+    }
+    return;
+  }
   if (comp >= 0) {      /* symmetry (the default GfsBc) of a vector component, boundary.c:45-62 */
     p->v->lev[l][G] = comp == side/2 ? - nb : nb;
     return;
   }
   for (int t = 0; t < s->ntracers; t++)
-    if (p->v == &s->tracer[t]) {      /* a scalar with the default GfsBc: symmetry, boundary.c:45-62 */
+    if (owner == &s->tracer[t]) {     /* a scalar with the default GfsBc: symmetry, boundary.c:45-62 */
       p->v->lev[l][G] = nb;
       return;
     }
@@ -1031,6 +1055,184 @@ static void poisson_solve (GtSim * s, GoMultilevelParams * par, Var * lhs, Var *
 
 /* ---- projection: timestep.c --------------------------------------------------------------- */
 
+/* ---- implicit diffusion: poisson.c:1271-1690, timestep.c:735-788,923-949 (constant D, alpha = NULL) - */
+
+static void get_from_below_intensive (GtSim * s, Cell cell, void * data);
+
+typedef struct { double v; } DiffCoef;
+static void diffusion_coef (GtSim * s, const Face * face, void * data) /* poisson.c:1280-1303 */
+{
+  double v = ((DiffCoef *) data)->v;
+  *val (&s->w[face->d], face->cell) = v;
+  if (!fine_coarse (face))
+    *val (&s->w[OPP (face->d)], face->neighbor) = v;
+  else
+    *val (&s->w[OPP (face->d)], face->neighbor) += v/(s->nc/2); /* FTT_CELLS_DIRECTION */
+}
+
+static void diffusion_mixed_coeff (GtSim * s, Cell c, void * data) /* poisson.c:1305-1334 */
+{
+  reset_coeff (s, c, NULL);
+  *val ((Var *) data, c) = 1.*1.;      /* rhoc = rho*fraction */
+}
+
+/* gfs_diffusion_coefficients, poisson.c:1350-1390 */
+static void diffusion_coefficients (GtSim * s, double D, double dt, double beta, Var * rhoc)
+{
+  for (int d = 0; d < s->nd; d++)
+    for (int l = 0; l <= s->depth; l++)
+      memset (s->w[d].lev[l], 0, s->size[l]*sizeof (double));
+  cell_traverse (s, 0, T_ALL, -1, diffusion_mixed_coeff, rhoc);
+  DiffCoef c = { 1.*(beta*dt)*D*1./1. };
+  face_traverse (s, -1, diffusion_coef, &c);
+  cell_traverse (s, 1, T_NON_LEAFS, -1, face_coeff_from_below, NULL);
+}
+
+typedef struct { Var * u, * rhs, * dia, * res; int maxlevel; double beta; } DiffParams;
+
+static void diffusion_rhs (GtSim * s, Cell cell, void * data) /* poisson.c:1392-1421 */
+{
+  DiffParams * p = data;
+  double f = 0., h = cell_size (cell), value = *val (p->u, cell);
+  Face face;
+  face.cell = cell;
+  for (face.d = 0; face.d < s->nd; face.d++) {
+    GfsGradient g;
+    face.neighbor = neighbor (s, cell, face.d);
+    face_weighted_gradient (s, &face, &g, p->u, -1);   /* gfs_face_cm_weighted_gradient, cm = 1 */
+    f += g.b - g.a*value;
+  }
+  *val (p->rhs, cell) += p->beta*f/(h*h*(*val (p->dia, cell)));
+}
+
+static void diffusion_relax (GtSim * s, Cell cell, void * data) /* poisson.c:1455-1484 */
+{
+  DiffParams * p = data;
+  GfsGradient g = { 0., 0. };
+  double h = cell_size (cell);
+  Face face;
+  face.cell = cell;
+  for (face.d = 0; face.d < s->nd; face.d++) {
+    GfsGradient ng;
+    face.neighbor = neighbor (s, cell, face.d);
+    face_weighted_gradient (s, &face, &ng, p->u, p->maxlevel);
+    g.a += ng.a;
+    g.b += ng.b;
+  }
+  double a = *val (p->dia, cell)*h*h;
+  g.a = 1. + g.a/a;
+  *val (p->u, cell) = (g.b/a + *val (p->res, cell))/g.a;
+}
+
+static void diffusion_residual_cell (GtSim * s, Cell cell, void * data) /* poisson.c:1519-1556 */
+{
+  DiffParams * p = data;
+  GfsGradient g = { 0., 0. };
+  double h = cell_size (cell), a = *val (p->dia, cell);
+  Face face;
+  face.cell = cell;
+  for (face.d = 0; face.d < s->nd; face.d++) {
+    GfsGradient ng;
+    face.neighbor = neighbor (s, cell, face.d);
+    face_weighted_gradient (s, &face, &ng, p->u, -1);
+    g.a += ng.a;
+    g.b += ng.b;
+  }
+  a *= h*h;
+  g.a = 1. + g.a/a;
+  g.b = *val (p->rhs, cell) + g.b/a;
+  *val (p->res, cell) = g.b - g.a*(*val (p->u, cell));
+}
+
+static void diffusion_residual (GtSim * s, Var * u, Var * rhs, Var * rhoc, Var * res)
+{
+  DiffParams p = { u, rhs, rhoc, res, -1, 0. };
+  cell_traverse (s, 0, T_LEAFS, -1, diffusion_residual_cell, &p);
+}
+
+/* relax_loop (poisson.c:1070-1089) with diffusion_relax; the homogeneous conditions are those of u */
+static void diffusion_relax_loop (GtSim * s, Var * dp, const Var * u, DiffParams * q, unsigned nrelax)
+{
+  s->bc_homogeneous = 1;
+  s->bc_owner = u;
+  bc (s, dp, T_LEVEL_LEAFS, q->maxlevel);
+  for (unsigned n = 0; n < nrelax - 1; n++) {
+    cell_traverse (s, 0, T_LEVEL_LEAFS, q->maxlevel, diffusion_relax, q);
+    bc (s, dp, T_LEVEL_LEAFS, q->maxlevel);
+  }
+  s->bc_homogeneous = 0;
+  s->bc_owner = NULL;
+  cell_traverse (s, 0, T_LEVEL_LEAFS, q->maxlevel, diffusion_relax, q);
+}
+
+/* gfs_diffusion_cycle, poisson.c:1633-1690 */
+static void diffusion_cycle (GtSim * s, unsigned levelmin, unsigned depth, unsigned nrelax,
+			     Var * u, Var * rhs, Var * rhoc, Var * res)
+{
+  Var dp;
+  var_alloc (s, &dp);
+  cell_traverse (s, 1, T_NON_LEAFS, -1, get_from_below_intensive, res);
+  DiffParams q = { &dp, NULL, rhoc, res, (int) levelmin, 0. };
+  cell_traverse (s, 0, T_LEVEL, levelmin, cell_reset, &dp);
+  diffusion_relax_loop (s, &dp, u, &q, 10*nrelax);
+  for (q.maxlevel = levelmin + 1; q.maxlevel <= (int) depth; q.maxlevel++) {
+    cell_traverse (s, 0, T_LEVEL_NON_LEAFS, q.maxlevel - 1, get_from_above, &dp);
+    diffusion_relax_loop (s, &dp, u, &q, nrelax);
+  }
+  CorrectData cd = { u, &dp };
+  cell_traverse (s, 0, T_LEAFS, -1, correct, &cd);
+  bc (s, u, T_LEAFS, -1);
+  diffusion_residual (s, u, rhs, rhoc, res);
+  var_free (s, &dp);
+}
+
+/* gfs_domain_norm_variable (domain.c:2197-2232) of the leaves: weights = cell volumes */
+typedef struct { Var * v; GoNorm n; } NormVarData;
+static void add_norm_variable (GtSim * s, Cell cell, void * data)
+{
+  NormVarData * p = data;
+  double size = cell_size (cell);
+  norm_add (&p->n, *val (p->v, cell), s->dim == 3 ? size*size*size : size*size);
+}
+static GoNorm norm_variable (GtSim * s, Var * v)
+{
+  NormVarData p = { v, { 0., 0., 0., - DBL_MAX, 0. } };
+  cell_traverse (s, 0, T_LEAFS, -1, add_norm_variable, &p);
+  norm_update (&p.n);
+  return p.n;
+}
+
+/* variable_diffusion (timestep.c:923-949) + gfs_diffusion (timestep.c:735-788) */
+static void variable_diffusion (GtSim * s, int c, Var * rhs)
+{
+  GoMultilevelParams * par = &s->diffusion_params[c];
+  Var * v = &s->u[c];
+  Var rhoc, res;
+  var_alloc (s, &rhoc);
+  var_alloc (s, &res);
+  diffusion_coefficients (s, s->visc[c], s->dt, par->beta, &rhoc);
+  DiffParams rp = { v, rhs, &rhoc, NULL, -1, (1. - par->beta)/par->beta };
+  cell_traverse (s, 0, T_LEAFS, -1, diffusion_rhs, &rp);
+  unsigned minlevel = par->minlevel, maxlevel = s->depth;
+  diffusion_residual (s, v, rhs, &rhoc, &res);
+  par->residual_before = par->residual = norm_variable (s, &res);
+  double res_max_before = par->residual.infty;
+  par->niter = 0;
+  while (par->niter < par->nitermin ||
+	 (par->residual.infty > par->tolerance && par->niter < par->nitermax)) {
+    diffusion_cycle (s, minlevel, maxlevel, par->nrelax, v, rhs, &rhoc, &res);
+    par->residual = norm_variable (s, &res);
+    if (par->residual.infty == res_max_before)
+      break;
+    if (par->residual.infty > res_max_before/1.1 && minlevel < maxlevel)
+      minlevel++;
+    res_max_before = par->residual.infty;
+    par->niter++;
+  }
+  var_free (s, &rhoc);
+  var_free (s, &res);
+}
+
 static void face_reset_un (GtSim * s, const Face * f, void * data) /* advection.c:575-587 */
 {
   *val (&s->un[OPP (f->d)], f->neighbor) = *val (&s->un[f->d], f->cell) = 0.;
@@ -1180,6 +1382,39 @@ static double transverse_term (GtSim * s, const AdvPar * par, Cell cell, const d
   return par->dt*vtan*g/(2.*msize[c]);
 }
 
+/* source_diffusion_value, source.c:1105-1144 (phi = v, alpha = NULL, constant D): the explicit
+   diffusion term of an implicit GfsSourceDiffusion */
+static double source_diffusion_value (GtSim * s, const Var * v, Cell cell, double D)
+{
+  GfsGradient g = { 0., 0. };
+  double v0 = *val (v, cell);
+  Face f;
+  f.cell = cell;
+  for (f.d = 0; f.d < s->nd; f.d++) {
+    f.neighbor = neighbor (s, cell, f.d);
+    if (exists (f.neighbor)) {
+      GfsGradient e;
+      face_gradient (s, &f, &e, v, -1);
+      g.a += D*e.a;
+      g.b += D*e.b;
+    }
+  }
+  double h = cell_size (cell);
+  return 1.*(g.b - g.a*v0)/(h*h);
+}
+
+/* gfs_variable_mac_source, source.c:38-59: the sources of v with a mac_value */
+static double variable_mac_source (GtSim * s, const Var * v, Cell cell)
+{
+  for (int c = 0; c < s->dim; c++)
+    if (v == &s->u[c] && s->visc[c] != 0.) {
+      double sum = 0.;
+      sum += source_diffusion_value (s, v, cell, s->visc[c]);
+      return sum;
+    }
+  return 0.;
+}
+
 static void cell_advected_face_values (GtSim * s, Cell cell, void * data) /* advection.c:58-99 */
 {
   const AdvPar * par = data;
@@ -1192,7 +1427,7 @@ static void cell_advected_face_values (GtSim * s, Cell cell, void * data) /* adv
       center_gradient (s, cell, c, par->v);
     double vl = *val (par->v, cell) + MIN ((1. - unorm)/2., 0.5)*g;
     double vr = *val (par->v, cell) + MAX ((- 1. - unorm)/2., -0.5)*g;
-    double src = par->dt*0./2.;
+    double src = par->dt*variable_mac_source (s, par->v, cell)/2.;
     double dv;
     if (s->dim == 2)
       dv = transverse_term (s, par, cell, msize, (c + 1) % 2);
@@ -1208,6 +1443,7 @@ static void cell_advected_face_values (GtSim * s, Cell cell, void * data) /* adv
 
 /* gfs_domain_face_bc (domain.c:1209-1232) on periodic sides (boundary.c:1251-1258,1343-1347): the
    leaf ghost cell beyond side sd holds the face value f[OPP (sd)].v of its periodic image */
+typedef struct { int comp, ucomp; const Var * v; } FaceBcPar;
 static void face_bc_ghost (GtSim * s, int l, int side, int G, int image, void * data)
 {
   if (s->flag[l][G] != GT_LEAF)
@@ -1216,8 +1452,19 @@ static void face_bc_ghost (GtSim * s, int l, int side, int G, int image, void * 
     s->fv[OPP (side)].lev[l][G] = s->fv[OPP (side)].lev[l][image];
     return;
   }
+  const FaceBcPar * fp = data;
+  int comp = fp->comp, own = ghost_own (s, l, side, G);
+  if (fp->ucomp >= 0 && s->bc_u[fp->ucomp][side] == GO_BC_DIRICHLET) {
+    /* face_dirichlet, boundary.c:270-275 */
+    s->fv[OPP (side)].lev[l][G] = s->fv[side].lev[l][own] = s->bcu[fp->ucomp].lev[l][G];
+    return;
+  }
+  if (fp->ucomp >= 0 && s->bc_u[fp->ucomp][side] == GO_BC_NEUMANN) {
+    /* face_neumann, boundary.c:349-355 */
+    s->fv[OPP (side)].lev[l][G] = fp->v->lev[l][own] + s->bcu[fp->ucomp].lev[l][G]*(1./s->n[l])/2.;
+    return;
+  }
   /* face_symmetry, boundary.c:64-74 */
-  int comp = *(int *) data, own = ghost_own (s, l, side, G);
   if (comp == side/2)
     s->fv[OPP (side)].lev[l][G] = s->fv[side].lev[l][own] = 0.;
   else
@@ -1226,9 +1473,11 @@ static void face_bc_ghost (GtSim * s, int l, int side, int G, int image, void * 
 
 static void face_bc (GtSim * s, const Var * v)
 {
-  int comp = var_component (s, v);
+  FaceBcPar fp = { var_component (s, v), -1, v };
+  for (int c = 0; c < 3; c++)
+    if (v == &s->u[c]) fp.ucomp = c;
   for (int l = 0; l <= s->depth; l++)
-    ghost_traverse (s, l, face_bc_ghost, &comp);
+    ghost_traverse (s, l, face_bc_ghost, &fp);
 }
 
 static void face_values_set (GtSim * s, AdvPar * par) /* timestep.c:644-654 */
@@ -1363,7 +1612,7 @@ static void face_advected_normal_velocity (GtSim * s, const Face * face, void * 
 static void predicted_face_velocities (GtSim * s) /* timestep.c:681-717 */
 {
   face_traverse (s, -1, face_reset_un, NULL);
-  AdvPar par = { s->dt, NULL, 1 };
+  AdvPar par = { s->dt, NULL, 1, 0 };
   for (int c = 0; c < s->dim; c++) {
     par.v = &s->u[c];
     face_values_set (s, &par);
@@ -1421,7 +1670,7 @@ static void add_pressure_gradient (GtSim * s, Cell cell, void * data) /* timeste
 }
 
 /* variable_sources, timestep.c:872-921, for a velocity component */
-static void variable_sources (GtSim * s, int c, double dt, Var * gmac, Var * g)
+static void variable_sources (GtSim * s, int c, Var * sv, double dt, Var * gmac, Var * g)
 {
   Var fvar;
   var_alloc (s, &fvar);
@@ -1430,7 +1679,7 @@ static void variable_sources (GtSim * s, int c, double dt, Var * gmac, Var * g)
   face_traverse (s, -1, face_reset, &fp);
   face_values_set (s, &ap);
   face_traverse (s, -1, face_velocity_advection_flux, &fp);
-  UpdatePar up = { &s->u[c], &fvar, g ? &g[c] : NULL, dt };
+  UpdatePar up = { sv, &fvar, g ? &g[c] : NULL, dt };
   cell_traverse (s, 0, T_LEAFS, -1, advection_update, &up);
   var_free (s, &fvar);
   if (g)
@@ -1460,10 +1709,28 @@ static void advance_tracers (GtSim * s, double dt) /* simulation.c:405-430 */
     tracer_advection (s, t, dt);
 }
 
+typedef struct { Var * dst; const Var * src; } CopyData;
+static void copy_v_rhs (GtSim * s, Cell c, void * data) /* timestep.c:951-954 */
+{
+  CopyData * d = data;
+  *val (d->dst, c) = *val (d->src, c);
+}
+
 static void centered_velocity_advection (GtSim * s, Var * gmac, Var * g) /* timestep.c:976-1016 */
 {
   for (int c = 0; c < s->dim; c++)
-    variable_sources (s, c, s->dt, gmac, g);
+    if (s->visc[c] != 0.) {
+      /* source_diffusion (v[c]): rhs = copy of v, the sources into rhs, then the implicit solve */
+      Var rhs;
+      var_alloc (s, &rhs);
+      CopyData cd = { &rhs, &s->u[c] };
+      cell_traverse (s, 0, T_LEAFS, -1, copy_v_rhs, &cd);
+      variable_sources (s, c, &rhs, s->dt, gmac, g);
+      variable_diffusion (s, c, &rhs);
+      var_free (s, &rhs);
+    }
+    else
+      variable_sources (s, c, &s->u[c], s->dt, gmac, g);
   for (int c = 0; c < s->dim; c++)
     bc (s, &s->u[c], T_LEAFS, -1);
 }
@@ -1492,6 +1759,14 @@ static void minimum_cfl (GtSim * s, Cell cell, void * data) /* domain.c:2858-289
       double cflu = length/fabs (fm*(*val (&s->u[c], cell)));
       if (cflu*cflu < *cfl)
 	*cfl = cflu*cflu;
+    }
+    if (s->visc[c] != 0.) {       /* p->v[c]->sources, domain.c:2882-2891 */
+      double g = variable_mac_source (s, &s->u[c], cell);
+      if (g != 0.) {
+	double cflg = 2.*length/fabs (fm*g);
+	if (cflg < *cfl)
+	  *cfl = cflg;
+      }
     }
   }
 }
@@ -1605,6 +1880,10 @@ static GtSim * gt_new_sides (int dim, GtRefineFunc refine, void * ctx, const int
   }
   go_multilevel_params_init (&s->projection_params, dim);
   go_multilevel_params_init (&s->approx_projection_params, dim);
+  for (int c = 0; c < 3; c++) {     /* diffusion_init, source.c:966-974 */
+    go_multilevel_params_init (&s->diffusion_params[c], dim);
+    s->diffusion_params[c].tolerance = 1e-6;
+  }
   s->cfl = 0.8;
   s->end = DBL_MAX;
   return s;
@@ -1651,6 +1930,9 @@ void gt_destroy (GtSim * s)
   var_free (s, &s->bcval);
   for (int t = 0; t < s->ntracers; t++)
     var_free (s, &s->tracer[t]);
+  if (s->bcu_alloc)
+    for (int q = 0; q < 3; q++)
+      var_free (s, &s->bcu[q]);
   for (int l = 0; l <= s->depth; l++)
     free (s->flag[l]);
   free (s);
@@ -1685,6 +1967,31 @@ void gt_step (GtSim * s)
   set_timestep (s);
   advance_tracers (s, s->dt);
 }
+
+/* conditions of velocity component c on side d: GO_BC_SYMMETRY (default) / _DIRICHLET / _NEUMANN; the
+   values per ghost cell (the GfsFunction at the face centre) in gt_bc_values_u (s, c, l) */
+void gt_set_bc_u (GtSim * s, int c, int d, int kind)
+{
+  if (!s->bcu_alloc) {
+    for (int q = 0; q < 3; q++)
+      var_alloc (s, &s->bcu[q]);
+    s->bcu_alloc = 1;
+  }
+  s->bc_u[c][d] = kind;
+}
+double * gt_bc_values_u (GtSim * s, int c, int l)
+{
+  if (!s->bcu_alloc) {
+    for (int q = 0; q < 3; q++)
+      var_alloc (s, &s->bcu[q]);
+    s->bcu_alloc = 1;
+  }
+  return s->bcu[c].lev[l];
+}
+/* GfsSourceDiffusion {} U|V|W nu, and its GfsMultilevelParams (tolerance 1e-6: diffusion_init,
+   source.c:966-974) */
+void gt_set_viscosity (GtSim * s, int c, double nu) { s->visc[c] = nu; }
+GoMultilevelParams * gt_diffusion_params (GtSim * s, int c) { return &s->diffusion_params[c]; }
 
 /* GfsVariableTracer T [{ gradient = ... }]: returns the index of gt_values (17 + t) */
 int gt_add_tracer (GtSim * s, int gradient)

@@ -559,6 +559,10 @@ def _tree_sigs(L):
         "gt_divergence_norm": (None, [vp, pd, pd, pd, pd]),
         "gt_divergence_level": (None, [vp, i, pd]),
         "gt_add_tracer": (i, [vp, i]),
+        "gt_set_bc_u": (None, [vp, i, i, i]),
+        "gt_bc_values_u": (pd, [vp, i, i]),
+        "gt_set_viscosity": (None, [vp, i, d]),
+        "gt_diffusion_params": (C.POINTER(MultilevelParams), [vp, i]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -612,6 +616,30 @@ class Tree:
 
     def set_time(self, end, cfl):
         self.L.gt_set_time(self.ptr, end, cfl)
+
+    def set_bc_u(self, c, d, kind, value=0.):
+        """condition of velocity component c on side d (BC_SYMMETRY / BC_DIRICHLET / BC_NEUMANN) with a
+        constant value, or a function value (x, y[, z]) of the face centres"""
+        self.L.gt_set_bc_u(self.ptr, c, d, kind)
+        for l in range(self.depth + 1):
+            r = (1 << l) + 2
+            a = np.ctypeslib.as_array(self.L.gt_bc_values_u(self.ptr, c, l), shape=(r,) * self.dim)
+            sl = [slice(None)] * self.dim
+            ax = self.dim - 1 - d // 2
+            sl[ax] = 0 if d & 1 else r - 1
+            if callable(value):
+                cs = list(self.centres(l))
+                h = 1. / (1 << l)
+                cs[d // 2] = cs[d // 2] + (0.5 * h if d & 1 else - 0.5 * h)      # ghost centre -> face centre
+                a[tuple(sl)] = (value(*cs) + 0. * cs[0])[tuple(sl)]
+            else:
+                a[tuple(sl)] = value
+
+    def set_viscosity(self, c, nu):
+        self.L.gt_set_viscosity(self.ptr, c, nu)
+
+    def diffusion_params(self, c):
+        return self.L.gt_diffusion_params(self.ptr, c).contents
 
     def add_tracer(self, gradient=1):
         """GfsVariableTracer [{ gradient = }] (0 centred, 1 van Leer): the index for values ()"""

@@ -441,3 +441,41 @@ def test_variable_density_case_matches_the_oracle():
         want = "%s time: %g first: % 10.3e second: % 10.3e infty: % 10.3e" % (
             name, s.t, a.sum() / n ** 2, math.sqrt((a * a).sum() / n ** 2), a.max())
         assert want in lines, (want, [l for l in lines if l.startswith(name + " time")])
+
+
+@pytest.mark.gpu
+def test_refined_tracer_case_matches_the_tree_oracle():
+    """tests/cases/refined_tracer.gfs (a GfsVariableTracer on the refined quadtree of test/periodic) through
+    gfship2D against the tree oracle: the volume-weighted norms and the sum OutputScalarNorm / OutputScalarSum
+    print, to the printed digits"""
+    from oracle import oracle as O
+    level, box, nsteps = 4, 2, 5
+    out = _run("refined_tracer.gfs", {"LEVEL": level, "BOX": box, "NSTEPS": nsteps})
+    s = O.Tree(periodic=(level, box))
+    k = s.add_tracer(1)
+    for l in range(s.depth + 1):
+        x, y = s.centres(l)
+        s.values(k, l)[...] = np.exp(- 30. * ((x - 0.2) * (x - 0.2) + (y - 0.2) * (y - 0.2)))
+    s.set_time(1e30, 0.75)
+    s.start()
+    for _ in range(nsteps):
+        s.step()
+    first = second = wsum = total = 0.
+    infty = 0.
+    for l in range(s.depth + 1):
+        leaf = s.flags(l)[1:-1, 1:-1] == 1
+        if not leaf.any():
+            continue
+        a = s.values(k, l)[1:-1, 1:-1][leaf]
+        w = 1. / (1 << l) ** 2
+        first += w * float(np.abs(a).sum())
+        second += w * float((a * a).sum())
+        total += w * float(a.sum())
+        wsum += w * a.size
+        infty = max(infty, float(np.abs(a).max()))
+    lines = out.splitlines()
+    want = "T time: %g first: % 10.3e second: % 10.3e infty: % 10.3e" % (
+        s.t, first / wsum, math.sqrt(second / wsum), infty)
+    assert want in lines, (want, [l for l in lines if l.startswith("T time")])
+    got = [l.split() for l in lines if l.startswith("T time") and "sum:" in l][0]
+    assert float(got[-1]) == pytest.approx(total, rel=1e-5)

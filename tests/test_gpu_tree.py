@@ -451,3 +451,136 @@ def test_tracers_on_a_tree_bit_exact(dim, level, box, kind, gradient):
             assert np.array_equal(g.download(gk, l)[inner][node], o.values(ok, l)[inner][node]), l
     o.destroy()
     g.destroy()
+
+
+# ---- Dirichlet / Neumann conditions on the velocity and GfsSourceDiffusion on a tree: the lid-driven cavity
+# of test/lid on a quadtree, an Euler flow through a refined channel (inflow profile, outflow)
+
+def _bc_values(o, c, d_values):
+    """per level, the array of the values of the conditions of component c (the oracle's copy)"""
+    L = O.lib()
+    out = []
+    for l in range(o.depth + 1):
+        r = (1 << l) + 2
+        out.append(np.ctypeslib.as_array(L.gt_bc_values_u(o.ptr, c, l), shape=(r,) * o.dim).copy())
+    return out
+
+
+def _lid_pair(level, refine, nu=1e-3):
+    sides = [gfship.SIDE_BOUNDARY] * 4
+    o = O.Tree(refine=refine, sides=sides)
+    g = gfship.Tree(refine, sides=sides)
+    for c in range(2):
+        for d in range(4):
+            o.set_bc_u(c, d, O.BC_DIRICHLET, 1. if (c == 0 and d == 2) else 0.)
+        o.set_viscosity(c, nu)
+        g.set_viscosity(c, nu)
+        vals = _bc_values(o, c, None)
+        for d in range(4):
+            g.set_bc_u(c, d, gfship.BC_DIRICHLET, vals)
+    o.set_time(300., 0.8)
+    g.set_time(300., 0.8)
+    return o, g
+
+
+def _same_leaves(o, g, names, what):
+    dim = o.dim
+    inner = (slice(1, -1),) * dim
+    for l in range(o.depth + 1):
+        leaf = o.flags(l)[inner] == 1
+        if not leaf.any():
+            continue
+        for gv, ov in names:
+            a, b = g.download(gv, l)[inner][leaf], o.values(ov, l)[inner][leaf]
+            assert np.array_equal(a, b), "%s: variable %d differs on level %d (max %g)" % (what, gv, l, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("kind", ["uniform", "walls", "corner"])
+def test_lid_driven_cavity_on_a_tree_bit_exact(kind):
+    level = 4
+    refine = {"uniform": lambda x, y: level + 1,
+              "walls": lambda x, y: level + 1 if (abs(x) > 0.25 or abs(y) > 0.25) else level,
+              "corner": lambda x, y: level + 2 if (x > 0.2 and y > 0.2) else level}[kind]
+    o, g = _lid_pair(level, refine)
+    T, G = O.Tree, gfship.Tree
+    o.start()
+    g.start()
+    assert g.dt == o.dt
+    for k in range(10):
+        o.step()
+        g.step()
+        assert g.t == o.t and g.dt == o.dt, k
+        _same_leaves(o, g, [(G.U, T.U), (G.V, T.V), (G.P, T.P), (G.PMAC, T.PMAC)], "step %d" % k)
+        for c in range(2):
+            pg, po = g.diffusion_params(c), o.diffusion_params(c)
+            assert pg.niter == po.niter and pg.residual.infty == po.residual.infty, (k, c)
+    o.destroy()
+    g.destroy()
+
+
+def test_refined_lid_driven_cavity_ghia_through_the_device(golden_dir):
+    """the refined cavity of tests/test_oracle_tree.py (32^2 / 64^2 near the walls) on the device to the
+    GfsEventStop steady state: the Ghia tolerances of test/lid/lid.sh"""
+    from test_oracle_tree import LID_REFINE, lid_profiles_error
+    o, g = _lid_pair(5, LID_REFINE)
+    o.destroy()
+    g.start()
+    G = gfship.Tree
+    flags = [g.flags(l) for l in range(g.depth + 1)]
+    old, end = None, 300.
+
+    def leaves():
+        return np.concatenate([g.download(G.U, l)[1:-1, 1:-1][flags[l][1:-1, 1:-1] == 1] for l in range(g.depth + 1)])
+    while g.t < end and g.i < 100000:
+        if g.i % 10 == 0:
+            cur = leaves()
+            if old is not None and np.abs(cur - old).max() <= 1e-4:
+                end = g.t
+            old = cur
+        g.step()
+    assert g.t < 300.
+    ex, ey = lid_profiles_error(lambda l: flags[l], lambda w, l: g.download(G.U if w == 0 else G.V, l), g.depth, golden_dir)
+    assert ex <= 2e-2 and ey <= 1.7e-2, (ex, ey)
+    g.destroy()
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_inflow_outflow_on_a_refined_tree_bit_exact(dim):
+    """Euler flow through a box with a refined patch: BcDirichlet U f (y) on the left, BcNeumann U 0 and
+    BcDirichlet P 0 on the right, slip walls (periodic in z in 3-D)"""
+    level = 4 if dim == 2 else 3
+    refine = (lambda x, y: level + 1 if (abs(x) < 0.26 and y > 0.) else level) if dim == 2 else \
+        (lambda x, y, z: level + 1 if (abs(x) < 0.26 and y > 0. and abs(z) < 0.26) else level)
+    sides = [gfship.SIDE_BOUNDARY] * 4 + ([gfship.SIDE_PERIODIC] * 2 if dim == 3 else [])
+    o = O.Tree(refine=refine, dim=dim, sides=sides)
+    g = gfship.Tree(refine, dim=dim, sides=sides)
+    T, G = O.Tree, gfship.Tree
+    prof = (lambda x, y: 1. + 0.3 * np.cos(2. * np.pi * y)) if dim == 2 else \
+        (lambda x, y, z: 1. + 0.3 * np.cos(2. * np.pi * y) * np.cos(2. * np.pi * z))
+    o.set_bc_u(0, 1, O.BC_DIRICHLET, prof)
+    o.set_bc_u(0, 0, O.BC_NEUMANN, 0.)
+    o.set_bc(0, O.BC_DIRICHLET)
+    vals = _bc_values(o, 0, None)
+    g.set_bc_u(0, 1, gfship.BC_DIRICHLET, vals)
+    g.set_bc_u(0, 0, gfship.BC_NEUMANN)
+    g.set_bc(0, gfship.BC_DIRICHLET)
+    for l in range(o.depth + 1):
+        assert np.array_equal(g.flags(l), o.flags(l))
+        u = prof(*o.centres(l))
+        o.values(T.U, l)[...] = u
+        g.upload(G.U, l, u)
+    for p in (o.projection_params, o.approx_projection_params, g.projection_params, g.approx_projection_params):
+        p.tolerance = 1e-4
+    o.set_time(1e30, 0.8)
+    g.set_time(1e30, 0.8)
+    o.start()
+    g.start()
+    names = [(G.U, T.U), (G.V, T.V), (G.P, T.P)] + ([(G.W, T.W)] if dim == 3 else [])
+    _same_leaves(o, g, names, "start")
+    for k in range(5):
+        o.step()
+        g.step()
+        assert g.t == o.t and g.dt == o.dt
+        _same_leaves(o, g, names, "step %d" % k)
+    o.destroy()
+    g.destroy()

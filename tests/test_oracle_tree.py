@@ -366,3 +366,149 @@ def test_tracer_on_a_refined_tree_is_conserved(dim):
         a.step()
     assert abs(total() - t0) < 1e-13 * abs(t0)
     a.destroy()
+
+
+# ---- Dirichlet / Neumann conditions on the velocity and GfsSourceDiffusion on a tree.  Pins: the uniform
+# oracle (go_timestep.c / go_diffusion.c, itself pinned on test/lid against the Ghia profiles and on
+# test/poiseuille/error.ref) on uniform trees, bit for bit; a refined lid-driven cavity against the same
+# Ghia tolerances (tests/test_gpu_tree.py runs it on the device).
+
+def _lid_tree(level, refine=None, nu=1e-3):
+    ref = refine if refine is not None else (lambda x, y: level)
+    sides = [O.SIDE_BOUNDARY] * 4
+    a = O.Tree(refine=ref, sides=sides)
+    for c in range(2):
+        for d in range(4):
+            a.set_bc_u(c, d, O.BC_DIRICHLET, 1. if (c == 0 and d == 2) else 0.)
+        a.set_viscosity(c, nu)
+    return a
+
+
+def test_lid_on_a_uniform_tree_equals_uniform_oracle():
+    from flow_cases import oracle_lid
+    level = 5
+    a = _lid_tree(level)
+    b = oracle_lid(level)
+    a.set_time(300., 0.8)
+    a.start()
+    b.start()
+    for k in range(12):
+        a.step()
+        b.step()
+        assert a.t == b.t, k
+        for which, f in ((O.Tree.U, b.u[0]), (O.Tree.V, b.u[1]), (O.Tree.P, b.p)):
+            assert np.array_equal(a.values(which, level)[1:-1, 1:-1], f.interior()), (k, which)
+    for c in range(2):
+        pa, pb = a.diffusion_params(c), b.diffusion_params(c)
+        assert pa.niter == pb.niter and pa.residual.infty == pb.residual.infty
+    a.destroy()
+
+
+def test_viscous_periodic_octree_uniform_equals_uniform_oracle():
+    from flow_cases import oracle_taylor_green, taylor_green_3d
+    level = 3
+    a = O.Tree(refine=lambda x, y, z: level, dim=3)
+    b = oracle_taylor_green(level)
+    x, y, z = a.centres(level)
+    for which, arr in zip((O.Tree.U, O.Tree.V, O.Tree.W), taylor_green_3d(x, y, z)):
+        a.values(which, level)[...] = arr
+    for c in range(3):
+        a.set_viscosity(c, 5e-3)
+        b.set_viscosity(c, 5e-3)
+    a.start()
+    b.start()
+    for _ in range(3):
+        a.step()
+        b.step()
+    assert a.t == b.t
+    for which, f in ((O.Tree.U, b.u[0]), (O.Tree.V, b.u[1]), (O.Tree.W, b.u[2]), (O.Tree.P, b.p)):
+        assert np.array_equal(a.values(which, level)[1:-1, 1:-1, 1:-1], f.interior())
+    a.destroy()
+
+
+def test_inflow_outflow_on_a_uniform_tree_equals_uniform_oracle():
+    """Dirichlet inflow with a profile on the left, Neumann outflow for U and Dirichlet P = 0 on the right
+    (BcDirichlet U f(y), BcNeumann U 0, BcDirichlet P 0), slip walls: Euler"""
+    level = 5
+    n = 1 << level
+    sides = [O.SIDE_BOUNDARY] * 4
+    a = O.Tree(refine=lambda x, y: level, sides=sides)
+    b = O.Sim(2, level, sides + [O.SIDE_PERIODIC] * 2)
+    prof = lambda x, y: 1. + 0.3 * np.cos(2. * np.pi * y)
+    yc = -0.5 + (np.arange(1, n + 1) - 0.5) / n
+    a.set_bc_u(0, 1, O.BC_DIRICHLET, prof)
+    b.u[0].set_bc(1, O.BC_DIRICHLET, prof(0., yc))
+    a.set_bc_u(0, 0, O.BC_NEUMANN, 0.)
+    b.u[0].set_bc(0, O.BC_NEUMANN, np.zeros(n))
+    a.set_bc(0, O.BC_DIRICHLET)
+    b.p.set_bc(0, O.BC_DIRICHLET, np.zeros(n))
+    b.pmac.set_bc(0, O.BC_DIRICHLET, np.zeros(n))
+    x, y = a.centres(level)
+    a.values(O.Tree.U, level)[...] = prof(x, y)
+    b.u[0].interior()[...] = prof(x, y)[1:-1, 1:-1]
+    a.set_time(1e30, 0.8)
+    a.start()
+    b.start()
+    for k in range(6):
+        a.step()
+        b.step()
+        assert a.t == b.t
+        for which, f in ((O.Tree.U, b.u[0]), (O.Tree.V, b.u[1]), (O.Tree.P, b.p)):
+            assert np.array_equal(a.values(which, level)[1:-1, 1:-1], f.interior()), (k, which)
+    a.destroy()
+
+
+def lid_profiles_error(flags, values, depth, golden_dir):
+    """U (y) on x = 0 and V (x) on y = 0 of a lid-driven cavity on a tree that is symmetric about both
+    centre lines (means of the two cells either side, the wall values at the ends) against the Ghia et al.
+    tables, as test/lid/lid.sh does with its OutputLocation profiles (infinity norm of the difference)"""
+    import os
+
+    def profile(which, axis):
+        pts = [(-0.5, 0.), (0.5, 1. if axis == 0 else 0.)]
+        for l in range(depth + 1):
+            n = 1 << l
+            f, v = flags(l), values(which, l)
+            m = n // 2
+            for q in range(1, n + 1):
+                if axis == 0 and f[q, m] == 1 and f[q, m + 1] == 1:
+                    pts.append((-0.5 + (q - 0.5) / n, 0.5 * (v[q, m] + v[q, m + 1])))
+                if axis == 1 and f[m, q] == 1 and f[m + 1, q] == 1:
+                    pts.append((-0.5 + (q - 0.5) / n, 0.5 * (v[m, q] + v[m + 1, q])))
+        pts.sort()
+        return np.array(pts)
+
+    g = os.path.join(golden_dir, "reference")
+    gx = np.loadtxt(os.path.join(g, "xprof.ghia"))
+    gy = np.loadtxt(os.path.join(g, "yprof.ghia"))
+    pu, pv = profile(0, 0), profile(1, 1)
+    ex = np.abs(np.interp(gx[:, 0], pu[:, 0], pu[:, 1]) - gx[:, 1]).max()
+    ey = np.abs(np.interp(gy[:, 0], pv[:, 0], pv[:, 1]) - gy[:, 1]).max()
+    return ex, ey
+
+
+LID_REFINE = lambda x, y: 6 if (abs(x) > 0.25 or abs(y) > 0.25) else 5
+
+
+def test_refined_lid_driven_cavity_ghia(golden_dir):
+    """test/lid on a quadtree: 32^2 in the middle, 64^2 within a quarter of the walls (3328 leaves instead of
+    4096), run to the GfsEventStop steady state: within the tolerances lid.sh asks of the uniform 64^2 run"""
+    a = _lid_tree(5, LID_REFINE)
+    a.set_time(300., 0.8)
+    a.start()
+    old, end = None, 300.
+
+    def leaves():
+        return np.concatenate([a.values(O.Tree.U, l)[1:-1, 1:-1][a.flags(l)[1:-1, 1:-1] == 1]
+                               for l in range(a.depth + 1)])
+    while a.t < end and a.i < 100000:
+        if a.i % 10 == 0:       # GfsEventStop { istep = 10 } U 1e-4
+            cur = leaves()
+            if old is not None and np.abs(cur - old).max() <= 1e-4:
+                end = a.t
+            old = cur
+        a.step()
+    assert a.t < 300.
+    ex, ey = lid_profiles_error(a.flags, lambda w, l: a.values(O.Tree.U if w == 0 else O.Tree.V, l), a.depth, golden_dir)
+    assert ex <= 2e-2 and ey <= 1.7e-2, (ex, ey)
+    a.destroy()
