@@ -1671,6 +1671,39 @@ void tree_leaves (Run & R, const std::vector<std::vector<unsigned char>> & flag,
 }
 
 // poisson_run (src/simulation.c:2213-2285) on a statically refined tree, sides periodic or GfsBoundary
+// the values of the conditions of variable `name' on the GfsBoundary sides of a tree: the GfsFunction at the
+// centre of the face of every leaf ghost cell (gfs_function_face_value at ftt_face_pos), uploaded to `var'
+int upload_tree_bc_values (Run & R, const std::vector<std::vector<unsigned char>> & flag, const std::string & name, int var)
+{
+  const int depth = gfship_tree_depth (R.tree);
+  for (int l = 0; l <= depth; l++) {
+    const int n = 1 << l, r = n + 2;
+    const double h = 1./n;
+    std::vector<double> val (R.tree_level_size (l), 0.);
+    bool any = false;
+    for (int d = 0; d < 2*R.dim; d++) {
+      if (R.side[d] != GFSHIP_SIDE_BOUNDARY || !R.bc[d].count (name) || !R.bc[d][name].val) continue;
+      const int c = d/2, ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
+      for (int b = 1; b <= (R.dim == 3 ? n : 1); b++)
+	for (int a = 1; a <= n; a++) {
+	  int g[3] = { 0, 0, 0 };
+	  g[c] = (d & 1) ? 0 : n + 1;
+	  g[ta] = a;
+	  g[tb] = R.dim == 3 ? b : 0;
+	  size_t G = g[0] + (size_t) r*(g[1] + (R.dim == 3 ? (size_t) r*g[2] : 0));
+	  if (flag[l][G] != 1) continue;          /* leaf ghost cells only */
+	  double p[3] = { -0.5 + (g[0] - 0.5)*h, -0.5 + (g[1] - 0.5)*h, R.dim == 3 ? -0.5 + (g[2] - 0.5)*h : 0. };
+	  p[c] = (d & 1) ? -0.5 : 0.5;            /* the face between the ghost cell and the box */
+	  val[G] = eval (R, R.bc[d][name].val, p, -1);
+	  any = true;
+	}
+    }
+    if (any)
+      CHECK (gfship_tree_upload (R.tree, var, l, val.data ()));
+  }
+  return 0;
+}
+
 int run_tree_poisson (Run & R)
 {
   static const char * ok[] = { "OutputErrorNorm", "OutputScalarNorm", "OutputScalarSum", "OutputScalarStats",
@@ -1712,31 +1745,7 @@ int run_tree_poisson (Run & R)
     if (kind == GFSHIP_BC_DIRICHLET) dirichlet = true;
     CHECK (gfship_tree_set_bc (R.tree, d, kind));
   }
-  for (int l = 0; l <= depth; l++) {
-    const int n = 1 << l, r = n + 2;
-    const double h = 1./n;
-    std::vector<double> val (R.tree_level_size (l), 0.);
-    bool any = false;
-    for (int d = 0; d < 2*R.dim; d++) {
-      if (R.side[d] != GFSHIP_SIDE_BOUNDARY || !R.bc[d].count ("P") || !R.bc[d]["P"].val) continue;
-      const int c = d/2, ta = c == 0 ? 1 : 0, tb = c == 2 ? 1 : 2;
-      for (int b = 1; b <= (R.dim == 3 ? n : 1); b++)
-	for (int a = 1; a <= n; a++) {
-	  int g[3] = { 0, 0, 0 };
-	  g[c] = (d & 1) ? 0 : n + 1;
-	  g[ta] = a;
-	  g[tb] = R.dim == 3 ? b : 0;
-	  size_t G = g[0] + (size_t) r*(g[1] + (R.dim == 3 ? (size_t) r*g[2] : 0));
-	  if (flag[l][G] != 1) continue;          /* leaf ghost cells only */
-	  double p[3] = { -0.5 + (g[0] - 0.5)*h, -0.5 + (g[1] - 0.5)*h, R.dim == 3 ? -0.5 + (g[2] - 0.5)*h : 0. };
-	  p[c] = (d & 1) ? -0.5 : 0.5;            /* the face between the ghost cell and the box */
-	  val[G] = eval (R, R.bc[d]["P"].val, p, -1);
-	  any = true;
-	}
-    }
-    if (any)
-      CHECK (gfship_tree_upload (R.tree, GFSHIP_TREE_BCVAL, l, val.data ()));
-  }
+  if (upload_tree_bc_values (R, flag, "P", GFSHIP_TREE_BCVAL)) return 1;
   apply_multilevel (gfship_tree_projection_params (R.tree, 1), R.approx_set);
   apply_init (R);
   events_init (R);
@@ -1800,8 +1809,9 @@ int run_tree (Run & R)
   if (!R.device_vars.empty ()) return refuse ("a turbulent-viscosity variable");
   if (R.snapshot.has_tree) return refuse ("cell data in the simulation file");
   if (R.dtmax != DBL_MAX) return refuse ("Time { dtmax }");
-  for (int c = 0; c < 3; c++)
-    if (R.visc[c] != 0. || R.source[c] != 0.) return refuse ("a source term");
+  for (int c = 0; c < 3; c++) {
+    if (R.visc[c] != 0. && R.dim == 3) return refuse ("GfsSourceDiffusion (octrees)");
+  }
   for (auto & kv : R.adv_set)
     if (kv.first != "cfl" && !(kv.first == "gradient" && kv.second == "gfs_center_gradient") &&
 	!(kv.first == "gc" && atoi (kv.second.c_str ()) == 1))
@@ -1840,11 +1850,16 @@ int run_tree (Run & R)
 	}
       };
   }
+  static const char * vel[3] = { "U", "V", "W" };
   for (int d = 0; d < 2*R.dim; d++)
-    if (!R.bc[d].empty ()) {     /* GfsBoundary sides: the default conditions (symmetry: slip walls) only */
-      fprintf (stderr, "gfship: a GfsSimulation on a refined tree knows the default boundary conditions only "
-	       "(side %s has a Bc)\n", side_name[d]);
-      return 1;
+    for (auto & kv : R.bc[d]) {     /* GfsBoundary sides: conditions on P and on the velocity components */
+      bool known = kv.first == "P";
+      for (int c = 0; c < R.dim; c++) if (kv.first == vel[c]) known = true;
+      if (!known) {
+	fprintf (stderr, "gfship: a boundary condition on `%s' is not supported on a refined tree (side %s)\n",
+		 kv.first.c_str (), side_name[d]);
+	return 1;
+      }
     }
   open_pipes (R);
   CHECK (gfship_tree_create_sides (&R.tree, R.dim, refine_hook, &R, R.side, R.device));
@@ -1866,6 +1881,23 @@ int run_tree (Run & R)
     CHECK (v);
     R.vars[R.var_index (R.tracers[k])].dev = v;
   }
+  for (int d = 0; d < 2*R.dim; d++) {
+    if (R.side[d] != GFSHIP_SIDE_BOUNDARY) continue;
+    if (R.bc[d].count ("P")) CHECK (gfship_tree_set_bc (R.tree, d, R.bc[d]["P"].kind));
+    for (int c = 0; c < R.dim; c++)
+      if (R.bc[d].count (vel[c])) CHECK (gfship_tree_set_bc_u (R.tree, c, d, R.bc[d][vel[c]].kind));
+  }
+  if (upload_tree_bc_values (R, flag, "P", GFSHIP_TREE_BCVAL)) return 1;
+  for (int c = 0; c < R.dim; c++)
+    if (upload_tree_bc_values (R, flag, vel[c], GFSHIP_TREE_BCU + c)) return 1;
+  for (int c = 0; c < R.dim; c++)
+    if (R.source[c] != 0.)
+      CHECK (gfship_tree_set_source (R.tree, c, R.source[c]));
+  for (int c = 0; c < R.dim; c++)
+    if (R.visc[c] != 0.) {
+      CHECK (gfship_tree_set_viscosity (R.tree, c, R.visc[c]));
+      apply_multilevel (gfship_tree_diffusion_params (R.tree, c), R.diff_set[c]);
+    }
   apply_multilevel (gfship_tree_projection_params (R.tree, 0), R.proj_set);
   apply_multilevel (gfship_tree_projection_params (R.tree, 1), R.approx_set);
   double cfl = 0.8;        /* gfs_advection_params_init, src/advection.c:922-942 */

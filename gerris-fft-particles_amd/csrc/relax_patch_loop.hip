@@ -1065,17 +1065,31 @@ __device__ __forceinline__ double patch_prolong (const Layout & Lc, const double
 // the wave, L1-resident for 32 rows) and 10 operations per 8 cells, 3 additions per cell.  Operand
 // order of patch_prolong / prolongate_kernel: val = p; val += rel_x h_x; += rel_y h_y; += rel_z h_z,
 // rel = -+ 1/4 (the products by -+ 1/4 are exact: formed once per coarse cell as 0.25 h, negated).
+#ifndef PR_ROWS
 #define PR_ROWS 16
+#endif
+#ifndef PR_WAVES
 #define PR_WAVES 4
+#endif
+
+// The seven coarse values of a lane are read from an LDS copy of the coarse cells the workgroup needs (10 x 10
+// coarse lines -- the 8 x 8 of the lanes + the lines beside them -- over the m range of its 64 rows + 1 on either
+// side), filled with coalesced loads: read straight from global memory the 64 lanes of a load touch 64
+// different coarse lines, and the address coalescer, not HBM, set the time of the kernel (60 us for 151 MB at
+// 256^3).  PR_LDS = 0: the loads from global memory.
+#ifndef PR_LDS
+#define PR_LDS 1
+#endif
+#define PR_W (((PR_ROWS*PR_WAVES + PK_SKEW) >> 1) + 4)      /* coarse cells along x the rows of a workgroup touch */
 
 __global__ void __launch_bounds__(64*PR_WAVES)
 patch_prolong_kernel (PatchPackArgs A)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.y;
-  const int r0 = (blockIdx.x*PR_WAVES + wave)*PR_ROWS;
+  const int R0 = blockIdx.x*PR_WAVES*PR_ROWS;
+  const int r0 = R0 + wave*PR_ROWS;
   const int n = A.L.n;
-  if (r0 >= n + PK_SKEW) return;
   const int P = tile % A.ntj, Q = tile / A.ntj;
   const int PA = lane & 7, PB = lane >> 3, s = PA + PB;
   double * const dst = A.dst[0] + (long) tile*(A.RT + 2*SK_FP)*SK_NL + SK_FP*SK_NL + 2*lane;
@@ -1084,6 +1098,27 @@ patch_prolong_kernel (PatchPackArgs A)
   const double * __restrict__ const vc = A.coarse;
   const long cline = A.Lc.idx (0, pj, pk);
   const long csy = A.Lc.sy, csz = A.Lc.sz;
+#if PR_LDS
+  __shared__ double cbuf[10][10][PR_W];
+  // coarse cells along x: index m + 1 with m = I >> 1 for the I of the workgroup's rows, and one either side
+  const int Ilo = R0 - PK_SKEW > 0 ? R0 - PK_SKEW : 0;
+  const int cx0 = Ilo >> 1;                              /* = (m_lo + 1) - 1 */
+  {
+    const int jb = n/2 - 8*P - 8, kb = n/2 - 8*Q - 8;   /* line (jl, kl) of the buffer = coarse line (jb + jl, kb + kl) */
+    const int xmax = A.Lc.n + 1;
+    for (int e = threadIdx.x; e < 100*PR_W; e += 64*PR_WAVES) {
+      const int line = e / PR_W, ix = e % PR_W;
+      const int jl = line % 10, kl = line / 10;
+      int cx = cx0 + ix;
+      if (cx > xmax) cx = xmax;                          /* beyond the last ghost cell: never used */
+      cbuf[kl][jl][ix] = vc[A.Lc.idx (cx, jb + jl, kb + kl)];
+    }
+  }
+  __syncthreads ();
+  const double * const cl = &cbuf[8 - PB][8 - PA][0] - cx0;     /* cl[m + 1] = vc[cline + m + 1] */
+  constexpr int lsy = PR_W, lsz = 10*PR_W;
+#endif
+  if (r0 >= n + PK_SKEW) return;
   // natural lines of the lane (p = da + 2 db) and whether they lie along a box side
   const int j0 = n - (SK_T*P + 2*PA), k0 = n - (SK_T*Q + 2*PB);
   const bool side_j[2] = { j0 == n, j0 - 1 == 1 }, side_k[2] = { k0 == n, k0 - 1 == 1 };
@@ -1096,6 +1131,22 @@ patch_prolong_kernel (PatchPackArgs A)
     const int m = I >> 1;
     if (m != cur_m) {
       cur_m = m;
+#if PR_LDS
+      const double * const q = cl + (m + 1);
+      pv = q[0];
+      {
+	const double g1 = q[1] - 1.*pv, g2 = q[-1] - 1.*pv;
+	qx = 0.25*((g1 - g2)/2.);
+      }
+      {
+	const double g1 = q[lsy] - 1.*pv, g2 = q[-lsy] - 1.*pv;
+	qy = 0.25*((g1 - g2)/2.);
+      }
+      {
+	const double g1 = q[lsz] - 1.*pv, g2 = q[-lsz] - 1.*pv;
+	qz = 0.25*((g1 - g2)/2.);
+      }
+#else
       const long p = cline + (m + 1);
       pv = vc[p];
       {
@@ -1110,6 +1161,7 @@ patch_prolong_kernel (PatchPackArgs A)
 	const double g1 = vc[p + csz] - 1.*pv, g2 = vc[p - csz] - 1.*pv;
 	qz = 0.25*((g1 - g2)/2.);
       }
+#endif
     }
     // i = I + 1 odd (I even): the first child along x, rel = -1/4; j even (a even): +1/4; k even: +1/4
     const double bx = pv + ((I & 1) ? qx : - qx);

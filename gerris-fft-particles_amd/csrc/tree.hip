@@ -144,6 +144,7 @@ struct gfship_tree {
   int bc_u[3][6] = {};
   double visc[3] = { 0., 0., 0. };
   gfship_multilevel_params diffusion_params[3];
+  double src[3] = { 0., 0., 0. };   // GfsSource {} U|V|W g: constant intensities
 };
 
 namespace {
@@ -685,6 +686,7 @@ struct AdvArgs {
   int use_centered;
   int gradient;            // 0 gfs_center_gradient, 1 gfs_center_van_leer_gradient
   double visc;             // GfsSourceDiffusion on the variable: its explicit term is the MAC source (0: none)
+  double gsrc;             // the intensity of a GfsSource on the variable (0: none)
 };
 
 // transverse_term, src/advection.c:27-47
@@ -721,9 +723,12 @@ __global__ void t_face_values (Topo T, const Cell * cells, int n, AdvArgs A)
     const double vl = v0 + (m1 < 0.5 ? m1 : 0.5)*gr;
     const double vr = v0 + (m2 > -0.5 ? m2 : -0.5)*gr;
     double msrc = 0.;        /* gfs_variable_mac_source, src/source.c:38-59 */
-    if (A.visc != 0.) {
+    if (A.visc != 0. || A.gsrc != 0.) {
       double sum = 0.;
-      sum += source_diffusion_value (T, cell, R, A.visc);
+      if (A.visc != 0.)
+	sum += source_diffusion_value (T, cell, R, A.visc);
+      if (A.gsrc != 0.)
+	sum += A.gsrc;
       msrc = sum;
     }
     const double src = A.dt*msrc/2.;
@@ -879,7 +884,7 @@ __global__ void t_face_flux (Topo T, const FaceRec * faces, int n, UpwindArgs A,
 // add_pressure_gradient (src/timestep.c:809-812)
 __global__ void t_gather_flux (Topo T, const Cell * cells, int n, const FaceRec * faces,
 			       const int * inc_off, const int * inc, const double * fval,
-			       double * v, const double * g, double dt)
+			       double * v, const double * g, double dt, double gsrc = 0.)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
@@ -900,6 +905,11 @@ __global__ void t_gather_flux (Topo T, const Cell * cells, int n, const FaceRec 
   x += f/1.;
   if (g)
     x -= g[gi]*dt;
+  if (gsrc != 0.) {     /* gfs_domain_variable_centered_sources, src/source.c:62-108: a GfsSource */
+    double sum = 0;
+    sum += gsrc;
+    x += dt*sum;
+  }
   v[gi] = x;
 }
 
@@ -935,7 +945,7 @@ __global__ void t_cfl_faces (Topo T, const FaceRec * faces, int n, P6 un, double
 }
 
 struct D3 { double d[3]; };
-__global__ void t_cfl_cells (Topo T, const Cell * cells, int n, P3 u, double * red, D3 visc)
+__global__ void t_cfl_cells (Topo T, const Cell * cells, int n, P3 u, double * red, D3 visc, D3 src)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= n) return;
@@ -947,10 +957,13 @@ __global__ void t_cfl_cells (Topo T, const Cell * cells, int n, P3 u, double * r
       const double cflu = length/fabs (fm*u.p[c][g]);
       atomic_min_pos (red, cflu*cflu);
     }
-    if (visc.d[c] != 0.) {      /* p->v[c]->sources: the acceleration scale, src/domain.c:2882-2891 */
+    if (visc.d[c] != 0. || src.d[c] != 0.) {      /* p->v[c]->sources: the acceleration scale, src/domain.c:2882-2891 */
       DevReader R = { u.p[c] };
       double gs = 0.;
-      gs += source_diffusion_value (T, cells[t], R, visc.d[c]);
+      if (visc.d[c] != 0.)
+	gs += source_diffusion_value (T, cells[t], R, visc.d[c]);
+      if (src.d[c] != 0.)
+	gs += src.d[c];
       if (gs != 0.) {
 	const double cflg = 2.*length/fabs (fm*gs);
 	atomic_min_pos (red, cflg);
@@ -1845,8 +1858,8 @@ int face_values_set (gfship_tree * tr, const double * v, double dt, int use_cent
 { /* src/timestep.c:644-654 */
   AdvArgs A;
   A.v = v; A.dt = dt; A.use_centered = use_centered; A.gradient = gradient;
-  A.visc = 0.;
-  for (int c = 0; c < 3; c++) if (v == tr->var[V_U + c]) A.visc = tr->visc[c];
+  A.visc = A.gsrc = 0.;
+  for (int c = 0; c < 3; c++) if (v == tr->var[V_U + c]) { A.visc = tr->visc[c]; A.gsrc = tr->src[c]; }
   for (int c = 0; c < 3; c++) A.u[c] = tr->var[V_U + c];
   for (int d = 0; d < 6; d++) { A.un[d] = tr->var[V_UN + d]; A.fv[d] = tr->var[V_FV + d]; }
   t_face_values<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, A);
@@ -1967,7 +1980,7 @@ int centered_velocity_advection (gfship_tree * tr, int gmac, int g)
       KCHECK ();
     }
     t_gather_flux<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, F.faces, F.inc_off, F.inc, F.fval,
-	sv, tr->var[g + c], tr->dt);
+	sv, tr->var[g + c], tr->dt, tr->src[c]);
     KCHECK ();
     if (tr->visc[c] != 0. && (e = variable_diffusion (tr, c))) return e;
   }
@@ -2020,8 +2033,8 @@ int domain_cfl (gfship_tree * tr, double * cfl)   /* src/domain.c:2899-2923 */
   FaceSet & F = tr->fs[0];
   t_cfl_faces<<<blocks (F.nfaces), 256, 0, tr->stream>>> (tr->D, F.faces, F.nfaces, p6 (tr, V_UN), tr->d_red);
   KCHECK ();
-  D3 visc = { { tr->visc[0], tr->visc[1], tr->visc[2] } };
-  t_cfl_cells<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, p3 (tr, V_U), tr->d_red, visc);
+  D3 visc = { { tr->visc[0], tr->visc[1], tr->visc[2] } }, srcs = { { tr->src[0], tr->src[1], tr->src[2] } };
+  t_cfl_cells<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, p3 (tr, V_U), tr->d_red, visc, srcs);
   KCHECK ();
   GFSHIP_HIP (hipMemcpyAsync (tr->h_red, tr->d_red, sizeof (double), hipMemcpyDeviceToHost, tr->stream));
   GFSHIP_HIP (hipStreamSynchronize (tr->stream));
@@ -2567,6 +2580,14 @@ int gfship_tree_set_viscosity (gfship_tree * tr, int c, double nu)
   GFSHIP_CHECK (nu == 0. || tr->H.dim == 2, GFSHIP_EUNSUPPORTED,
 		"GfsSourceDiffusion on a refined tree is supported on quadtrees (2-D)");
   tr->visc[c] = nu;
+  return GFSHIP_OK;
+}
+
+int gfship_tree_set_source (gfship_tree * tr, int c, double g)
+{
+  GFSHIP_CHECK (tr, GFSHIP_EINVAL, "gfship_tree_set_source: null tree");
+  GFSHIP_CHECK (c >= 0 && c < tr->H.dim, GFSHIP_EINVAL, "component %d out of range", c);
+  tr->src[c] = g;
   return GFSHIP_OK;
 }
 

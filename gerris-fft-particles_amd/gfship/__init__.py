@@ -173,6 +173,7 @@ SIGNATURES = {
     "gfship_tree_add_tracer": (_i, [_vp, _i]),
     "gfship_tree_set_bc_u": (_i, [_vp, _i, _i, _i]),
     "gfship_tree_set_viscosity": (_i, [_vp, _i, _d]),
+    "gfship_tree_set_source": (_i, [_vp, _i, _d]),
     "gfship_tree_diffusion_params": (C.POINTER(MultilevelParams), [_vp, _i]),
     "gfship_tree_start": (_i, [_vp]),
     "gfship_tree_step": (_i, [_vp]),
@@ -755,6 +756,9 @@ class Tree:
 
     def set_viscosity(self, c, nu):
         _check(lib().gfship_tree_set_viscosity(self.ptr, c, nu))
+
+    def set_source(self, c, g):
+        _check(lib().gfship_tree_set_source(self.ptr, c, g))
 
     def diffusion_params(self, c):
         return lib().gfship_tree_diffusion_params(self.ptr, c).contents

@@ -590,6 +590,9 @@ int  gfship_tree_add_tracer (gfship_tree * tree, int gradient);
    lid-driven cavity of test/lid on a refined tree. */
 int  gfship_tree_set_bc_u (gfship_tree * tree, int c, int d, int kind);
 int  gfship_tree_set_viscosity (gfship_tree * tree, int c, double nu);
+/* GfsSource {} U|V|W g with a constant intensity on a tree (as gfship_sim_set_source: MAC source of the face
+   values, centred source of the update, acceleration scale of the CFL condition) */
+int  gfship_tree_set_source (gfship_tree * tree, int c, double g);
 gfship_multilevel_params * gfship_tree_diffusion_params (gfship_tree * tree, int c);
 int  gfship_tree_start (gfship_tree * tree);
 int  gfship_tree_step (gfship_tree * tree);

@@ -83,6 +83,7 @@ typedef struct GtSim {
   /* GfsSourceDiffusion {} U|V|W nu: constant implicit viscosity (source.c:933-1160) */
   double visc[3];
   GoMultilevelParams diffusion_params[3];
+  double src[3];                              /* GfsSource {} U|V|W g: constant intensity (source.c:362-500) */
 } GtSim;
 
 static const Cell NOCELL = { 0, -1 };
@@ -1407,9 +1408,12 @@ static double source_diffusion_value (GtSim * s, const Var * v, Cell cell, doubl
 static double variable_mac_source (GtSim * s, const Var * v, Cell cell)
 {
   for (int c = 0; c < s->dim; c++)
-    if (v == &s->u[c] && s->visc[c] != 0.) {
+    if (v == &s->u[c] && (s->visc[c] != 0. || s->src[c] != 0.)) {
       double sum = 0.;
-      sum += source_diffusion_value (s, v, cell, s->visc[c]);
+      if (s->visc[c] != 0.)
+	sum += source_diffusion_value (s, v, cell, s->visc[c]);
+      if (s->src[c] != 0.)
+	sum += s->src[c];               /* source_value, source.c:398-403 */
       return sum;
     }
   return 0.;
@@ -1669,6 +1673,15 @@ static void add_pressure_gradient (GtSim * s, Cell cell, void * data) /* timeste
   *val (p->sv, cell) -= *val (p->g, cell)*p->dt;
 }
 
+typedef struct { Var * sv; double dt, g; } SrcData;
+static void add_centered_source (GtSim * s, Cell c, void * data)
+{
+  SrcData * d = data;
+  double sum = 0;
+  sum += d->g;
+  *val (d->sv, c) += d->dt*sum;
+}
+
 /* variable_sources, timestep.c:872-921, for a velocity component */
 static void variable_sources (GtSim * s, int c, Var * sv, double dt, Var * gmac, Var * g)
 {
@@ -1684,6 +1697,11 @@ static void variable_sources (GtSim * s, int c, Var * sv, double dt, Var * gmac,
   var_free (s, &fvar);
   if (g)
     cell_traverse (s, 0, T_LEAFS, -1, add_pressure_gradient, &up);
+  if (s->src[c] != 0.) {
+    /* gfs_domain_variable_centered_sources, source.c:62-108: the sources with a centered_value (a GfsSource) */
+    SrcData sd = { sv, dt, s->src[c] };
+    cell_traverse (s, 0, T_LEAFS, -1, add_centered_source, &sd);
+  }
 }
 
 /* gfs_tracer_advection_diffusion (timestep.c:1028-1055, no diffusion) with variable_sources :872-921:
@@ -1760,7 +1778,7 @@ static void minimum_cfl (GtSim * s, Cell cell, void * data) /* domain.c:2858-289
       if (cflu*cflu < *cfl)
 	*cfl = cflu*cflu;
     }
-    if (s->visc[c] != 0.) {       /* p->v[c]->sources, domain.c:2882-2891 */
+    if (s->visc[c] != 0. || s->src[c] != 0.) {       /* p->v[c]->sources, domain.c:2882-2891 */
       double g = variable_mac_source (s, &s->u[c], cell);
       if (g != 0.) {
 	double cflg = 2.*length/fabs (fm*g);
@@ -1991,6 +2009,7 @@ double * gt_bc_values_u (GtSim * s, int c, int l)
 /* GfsSourceDiffusion {} U|V|W nu, and its GfsMultilevelParams (tolerance 1e-6: diffusion_init,
    source.c:966-974) */
 void gt_set_viscosity (GtSim * s, int c, double nu) { s->visc[c] = nu; }
+void gt_set_source (GtSim * s, int c, double g) { s->src[c] = g; }
 GoMultilevelParams * gt_diffusion_params (GtSim * s, int c) { return &s->diffusion_params[c]; }
 
 /* GfsVariableTracer T [{ gradient = ... }]: returns the index of gt_values (17 + t) */

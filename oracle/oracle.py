@@ -562,6 +562,7 @@ def _tree_sigs(L):
         "gt_set_bc_u": (None, [vp, i, i, i]),
         "gt_bc_values_u": (pd, [vp, i, i]),
         "gt_set_viscosity": (None, [vp, i, d]),
+        "gt_set_source": (None, [vp, i, d]),
         "gt_diffusion_params": (C.POINTER(MultilevelParams), [vp, i]),
     }
     for name, (res, args) in sig.items():
@@ -637,6 +638,10 @@ class Tree:
 
     def set_viscosity(self, c, nu):
         self.L.gt_set_viscosity(self.ptr, c, nu)
+
+    def set_source(self, c, g):
+        """GfsSource {} U|V|W g: constant intensity"""
+        self.L.gt_set_source(self.ptr, c, g)
 
     def diffusion_params(self, c):
         return self.L.gt_diffusion_params(self.ptr, c).contents

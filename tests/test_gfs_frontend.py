@@ -479,3 +479,40 @@ def test_refined_tracer_case_matches_the_tree_oracle():
     assert want in lines, (want, [l for l in lines if l.startswith("T time")])
     got = [l.split() for l in lines if l.startswith("T time") and "sum:" in l][0]
     assert float(got[-1]) == pytest.approx(total, rel=1e-5)
+
+
+@pytest.mark.gpu
+def test_refined_cavity_case_matches_the_tree_oracle():
+    """tests/cases/refined_cavity.gfs (test/lid on a quadtree refined near the walls: BcDirichlet on U, V,
+    GfsSourceDiffusion) through gfship2D against the tree oracle after NSTEPS steps: the volume-weighted norms
+    OutputScalarNorm prints, to the printed digits, and the time"""
+    from oracle import oracle as O
+    level, nsteps = 4, 25
+    out = _run("refined_cavity.gfs", {"LEVEL": level, "NSTEPS": nsteps})
+    refine = lambda x, y: level + 1 if (x < -0.25 or x > 0.25 or y < -0.25 or y > 0.25) else level
+    s = O.Tree(refine=refine, sides=[O.SIDE_BOUNDARY] * 4)
+    for c in range(2):
+        for d in range(4):
+            s.set_bc_u(c, d, O.BC_DIRICHLET, 1. if (c == 0 and d == 2) else 0.)
+        s.set_viscosity(c, 1e-3)
+    s.set_time(300., 0.8)
+    s.start()
+    for _ in range(nsteps):
+        s.step()
+    lines = out.splitlines()
+    for name, which in (("U", O.Tree.U), ("V", O.Tree.V), ("P", O.Tree.P)):
+        first = second = wsum = 0.
+        infty = 0.
+        for l in range(s.depth + 1):
+            leaf = s.flags(l)[1:-1, 1:-1] == 1
+            if not leaf.any():
+                continue
+            a = np.abs(s.values(which, l)[1:-1, 1:-1][leaf])
+            w = 1. / (1 << l) ** 2
+            first += w * float(a.sum())
+            second += w * float((a * a).sum())
+            wsum += w * a.size
+            infty = max(infty, float(a.max()))
+        want = "%s time: %g first: % 10.3e second: % 10.3e infty: % 10.3e" % (
+            name, s.t, first / wsum, math.sqrt(second / wsum), infty)
+        assert want in lines, (want, [l for l in lines if l.startswith(name + " time")])

@@ -584,3 +584,38 @@ def test_inflow_outflow_on_a_refined_tree_bit_exact(dim):
         _same_leaves(o, g, names, "step %d" % k)
     o.destroy()
     g.destroy()
+
+
+def test_poiseuille_channel_on_a_refined_tree_bit_exact():
+    """test/poiseuille's channel (periodic in x, Dirichlet walls for U, GfsSource on U and V, implicit
+    viscosity) with the quadtree refined along the lower wall: device against the tree oracle"""
+    level = 4
+    refine = lambda x, y: level + 1 if y < -0.24 else level
+    sides = [gfship.SIDE_PERIODIC, gfship.SIDE_PERIODIC, gfship.SIDE_BOUNDARY, gfship.SIDE_BOUNDARY]
+    o = O.Tree(refine=refine, sides=sides)
+    g = gfship.Tree(refine, sides=sides)
+    T, G = O.Tree, gfship.Tree
+    for d in (2, 3):
+        o.set_bc_u(0, d, O.BC_DIRICHLET, 0.)
+    vals = _bc_values(o, 0, None)
+    for d in (2, 3):
+        g.set_bc_u(0, d, gfship.BC_DIRICHLET, vals)
+    for c in range(2):
+        for s in (o, g):
+            s.set_viscosity(c, 1.)
+            s.diffusion_params(c).beta = 1.
+            s.set_source(c, 1.)
+    for p in (o.projection_params, o.approx_projection_params, g.projection_params, g.approx_projection_params):
+        p.tolerance = 1e-6
+    o.set_time(1e30, 0.8)
+    g.set_time(1e30, 0.8)
+    o.start()
+    g.start()
+    assert g.dt == o.dt
+    for k in range(6):
+        o.step()
+        g.step()
+        assert g.t == o.t and g.dt == o.dt, k
+        _same_leaves(o, g, [(G.U, T.U), (G.V, T.V), (G.P, T.P)], "step %d" % k)
+    o.destroy()
+    g.destroy()

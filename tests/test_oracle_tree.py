@@ -512,3 +512,37 @@ def test_refined_lid_driven_cavity_ghia(golden_dir):
     ex, ey = lid_profiles_error(a.flags, lambda w, l: a.values(O.Tree.U if w == 0 else O.Tree.V, l), a.depth, golden_dir)
     assert ex <= 2e-2 and ey <= 1.7e-2, (ex, ey)
     a.destroy()
+
+
+def test_poiseuille_on_a_uniform_tree_equals_uniform_oracle():
+    """the set-up of test/poiseuille (periodic channel, Dirichlet walls for U, Source U 1, Source V 1,
+    SourceViscosity 1 { beta = 1 }) on a uniform tree: GfsSource as MAC source, centred source and in the CFL
+    condition -- the bits of the uniform oracle (itself pinned on test/poiseuille/error.ref)"""
+    level = 4
+    sides = [O.SIDE_PERIODIC, O.SIDE_PERIODIC, O.SIDE_BOUNDARY, O.SIDE_BOUNDARY]
+    a = O.Tree(refine=lambda x, y: level, sides=sides)
+    b = O.Sim(2, level, sides + [O.SIDE_BOUNDARY] * 2)
+    n = 1 << level
+    for d in (2, 3):
+        a.set_bc_u(0, d, O.BC_DIRICHLET, 0.)
+        b.u[0].set_bc(d, O.BC_DIRICHLET, np.zeros(n))
+    for c in range(2):
+        a.set_viscosity(c, 1.)
+        a.diffusion_params(c).beta = 1.
+        a.set_source(c, 1.)
+        b.set_viscosity(c, 1.)
+        b.diffusion_params(c).beta = 1.
+        b.set_source(c, 1.)
+    for p in (a.projection_params, a.approx_projection_params, b.projection_params, b.approx_projection_params):
+        p.tolerance = 1e-6
+    a.set_time(1e30, 0.8)
+    a.start()
+    b.start()
+    for k in range(6):
+        a.step()
+        b.step()
+        assert a.t == b.t, k
+        for which, f in ((O.Tree.U, b.u[0]), (O.Tree.V, b.u[1]), (O.Tree.P, b.p)):
+            assert np.array_equal(a.values(which, level)[1:-1, 1:-1], f.interior()), (k, which)
+    assert b.u[0].interior().max() > 0.05
+    a.destroy()
