@@ -1065,11 +1065,14 @@ __device__ __forceinline__ double patch_prolong (const Layout & Lc, const double
 // the wave, L1-resident for 32 rows) and 10 operations per 8 cells, 3 additions per cell.  Operand
 // order of patch_prolong / prolongate_kernel: val = p; val += rel_x h_x; += rel_y h_y; += rel_z h_z,
 // rel = -+ 1/4 (the products by -+ 1/4 are exact: formed once per coarse cell as 0.25 h, negated).
+/* rows per wave x waves per workgroup (64 rows of a tile per workgroup): measured at 256^3 / 128^3, average of
+   the four calls of a step: 16 x 4: 35-37 us, 8 x 8: 30.5, 4 x 16: 29.0, 32 x 2: 52 (a wave's rows are a chain of
+   LDS reads -> 10 operations -> two 1 KB stores: more waves hide it) */
 #ifndef PR_ROWS
-#define PR_ROWS 16
+#define PR_ROWS 4
 #endif
 #ifndef PR_WAVES
-#define PR_WAVES 4
+#define PR_WAVES 16
 #endif
 
 // The seven coarse values of a lane are read from an LDS copy of the coarse cells the workgroup needs (10 x 10
@@ -1096,9 +1099,11 @@ patch_prolong_kernel (PatchPackArgs A)
   // the coarse line of the lane and its neighbours
   const int pj = n/2 - 8*P - PA, pk = n/2 - 8*Q - PB;
   const double * __restrict__ const vc = A.coarse;
+#if !PR_LDS
   const long cline = A.Lc.idx (0, pj, pk);
   const long csy = A.Lc.sy, csz = A.Lc.sz;
-#if PR_LDS
+#else
+  (void) pj; (void) pk;
   __shared__ double cbuf[10][10][PR_W];
   // coarse cells along x: index m + 1 with m = I >> 1 for the I of the workgroup's rows, and one either side
   const int Ilo = R0 - PK_SKEW > 0 ? R0 - PK_SKEW : 0;

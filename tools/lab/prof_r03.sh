@@ -22,3 +22,8 @@ timeout -k 10 300 python bench.py --steps 10 --warmup 2 --self-mpi --no-cpu-base
 tail -c 300 $O/selfmpi.json
 ( time bash tools/periodic_rows.sh ) > $O/periodic_rows.txt 2>&1
 tail -5 $O/periodic_rows.txt
+# 6. the paths added late in round 3: the weighted cycle, the refined-tree bench, the refined lid-driven cavity
+( timeout -k 10 120 python tools/weighted_cycle.py 7; timeout -k 10 120 python tools/weighted_cycle.py 8 ) > $O/weighted_cycle.txt 2>&1
+( timeout -k 10 200 python tools/tree_bench.py 3 4 2 5; timeout -k 10 200 python tools/tree_bench.py 2 7 2 5 ) > $O/tree_bench.txt 2>&1
+( time gerris-fft-particles_amd/bin/gfship2D -DLEVEL=5 -DNSTEPS=100000 tests/cases/refined_cavity.gfs ) > $O/refined_cavity.txt 2>&1
+tail -3 $O/weighted_cycle.txt $O/tree_bench.txt $O/refined_cavity.txt

@@ -40,6 +40,11 @@ pr = os.path.join(SRC, "periodic_rows.txt")
 if os.path.exists(pr):
     shutil.copy(pr, os.path.join(DST, "r03_periodic_rows.txt"))
 
+for name in ("weighted_cycle", "tree_bench", "refined_cavity"):
+    src = os.path.join(SRC, name + ".txt")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(DST, "r03_%s.txt" % name))
+
 rows = {r["Name"]: r for r in csv.DictReader(open(stats))}
 
 
