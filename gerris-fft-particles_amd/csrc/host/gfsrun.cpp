@@ -892,11 +892,55 @@ void parse_object (Run & R, Reader & r)
     std::string vname = r.word (false);
     int v = R.var_index (vname);
     if (v < 0) r.fail ("unknown variable `" + vname + "'");
-    if (r.peek (false) == '{') r.braces ();
+    // { x0 = .. y0 = .. z0 = .. x1 = .. y1 = .. z1 = .. }: a box that is flat in one direction is a plane
+    // (realdim == 2, modules/fft.c:1119-1141); anything else is taken as the whole box
+    int normal = -1;
+    double plane_pos = 0.;
+    if (r.peek (false) == '{') {
+      auto m = r.assignments ();
+      const char * lo[3] = { "x0", "y0", "z0" }, * hi[3] = { "x1", "y1", "z1" };
+      for (int c = 0; c < 3; c++)
+	if (m.count (lo[c]) && m.count (hi[c]) && atof (m[lo[c]].c_str ()) == atof (m[hi[c]].c_str ())) {
+	  if (normal >= 0) r.fail ("GfsOutputSpectra: FFT in 1 dimension is not implemented (modules/fft.c:1142)");
+	  normal = c;
+	  plane_pos = atof (m[lo[c]].c_str ());
+	}
+    }
     auto digit = [] (char c) { return c >= '0' && c <= '9'; };
     if (digit (r.peek (false))) r.number ();
-    if (R.dim != 3) r.fail ("GfsOutputSpectra: only the 3-D box is transformed (a plane is sampled through the tree)");
+    if (R.dim != 3) r.fail ("GfsOutputSpectra: the 3-D box or one of its planes is transformed");
     Run * pr = &R;
+    if (normal >= 0) {
+      e->action = [pr, o, v, normal, plane_pos] () {
+	Run & R = *pr;
+	const int N = gfship_output_spectra_side (R.dom);
+	if (N <= 0) { fprintf (stderr, "gfship: %s\n", gfship_last_error ()); exit (1); }
+	const int nh = N/2 + 1;
+	std::vector<double> F ((size_t) 2*N*nh);
+	double ks = 0.;
+	if (gfship_output_spectra_plane (R.dom, R.vars[v].dev, normal, plane_pos, F.data (), &ks) != GFSHIP_OK) {
+	  fprintf (stderr, "gfship: %s\n", gfship_last_error ());
+	  exit (1);
+	}
+	// write_spectra, modules/fft.c:1047-1085 (L = 1): the flat direction first (one point, k = 0), then
+	// the two others in coordinate order, the last one halved
+	const int ca = normal == 0 ? 1 : 0, cb = normal == 2 ? 1 : 2;
+	FILE * fp = o->open ();
+	fprintf (fp, "# %i \n", N*N);
+	fputs ("# 1:kx 2:ky 3:kz 4:real 5:img\n", fp);
+	for (int j = 0; j < N; j++)
+	  for (int l = 0; l < nh; l++) {
+	    double k[3] = { 0., 0., 0. };
+	    k[ca] = ks*(j < nh ? j : j - N);
+	    k[cb] = ks*l;
+	    const size_t q = 2*((size_t) j*nh + l);
+	    fprintf (fp, "%g %g %g %g %g\n", k[0], k[1], k[2], F[q]*1., F[q + 1]*1.);
+	  }
+	fflush (fp);
+      };
+      add_event (R, e, cls, line);
+      return;
+    }
     e->action = [pr, o, v] () {
       Run & R = *pr;
       const int N = gfship_output_spectra_side (R.dom);

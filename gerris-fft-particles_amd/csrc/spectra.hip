@@ -250,6 +250,48 @@ turbulent_viscosity_kernel (Layout L, const double * __restrict__ u0, const doub
   out[c] = (Cs*h)*(Cs*h)*Dsigma;
 }
 
+// GfsOutputSpectra of a plane (modules/fft.c:1101-1160 with realdim == 2: fill_interpolated_cartesian_matrix,
+// :822-883): the values of the cells the points pos_min + j dx of the plane lie in (gfs_domain_locate, no
+// interpolation), minus their mean, divided by their number.  Plane normal to `normal' through the cells of
+// index kc along it; a = first, b = second in-plane coordinate (in coordinate order)
+__global__ void __launch_bounds__(256)
+spectra_plane_gather_kernel (Layout L, const double * __restrict__ u, int normal, int kc, double * __restrict__ a,
+			     double * __restrict__ sum)
+{
+  const int n = L.n;
+  const int q = blockIdx.x*blockDim.x + threadIdx.x;
+  double v = 0.;
+  if (q < n*n) {
+    const int ib = q % n + 1, ia = q / n + 1;
+    int ijk[3];
+    ijk[normal] = kc;
+    ijk[normal == 0 ? 1 : 0] = ia;
+    ijk[normal == 2 ? 1 : 2] = ib;
+    v = u[L.idx (ijk[0], ijk[1], ijk[2])];
+    a[q] = v;
+  }
+  __shared__ double sh[256];
+  sh[threadIdx.x] = v;
+  __syncthreads ();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int) threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads ();
+  }
+  if (threadIdx.x == 0) atomicAdd (sum, sh[0]);
+}
+
+__global__ void __launch_bounds__(256)
+spectra_plane_center_kernel (int np, const double * __restrict__ sum, double * __restrict__ a)
+{
+  const int q = blockIdx.x*blockDim.x + threadIdx.x;
+  if (q >= np) return;
+  const double avg = *sum/np;
+  double v = a[q];
+  v -= avg;
+  v /= np;
+  a[q] = v;
+}
+
 } // namespace gfship
 
 using namespace gfship;
@@ -447,6 +489,61 @@ int gfship_output_spectra (gfship_domain * dom, gfship_field v, double * out, do
     double dx = 1./dom->lay[dom->depth].n;
     *kstep = 2.*M_PI/((W.N - 1)*dx);
   }
+  return GFSHIP_OK;
+}
+
+// GfsOutputSpectra of a plane of a 3-D box (realdim == 2, modules/fft.c:1101-1160): the plane normal to
+// `normal' (0 x, 1 y, 2 z) at coordinate pos, over the whole box in the other two directions at the finest
+// level.  order_array (:800-820) puts the flat direction first and keeps the other two in coordinate order:
+// out receives N*(N/2 + 1) complex numbers, index ia*(N/2 + 1) + ib with ia the first and ib the second
+// in-plane coordinate (x, y for a z plane; x, z for a y plane; y, z for an x plane); write_spectra prints
+// k = kstep times the signed index in those directions and 0 in the normal one.
+int gfship_output_spectra_plane (gfship_domain * dom, gfship_field v, int normal, double pos, double * out,
+				 double * kstep)
+{
+  GFSHIP_CHECK (dom && out, GFSHIP_EINVAL, "null argument");
+  GFSHIP_CHECK (dom->dim == 3, GFSHIP_EUNSUPPORTED, "the spectrum of a plane is that of a plane of a 3-D box");
+  GFSHIP_CHECK (!dom->has_external, GFSHIP_EUNSUPPORTED, "the spectrum of a plane is computed on one box");
+  GFSHIP_CHECK (normal >= 0 && normal < 3, GFSHIP_EINVAL, "normal %d out of range", normal);
+  Field * F = get_field (dom, v);
+  if (!F) return GFSHIP_EINVAL;
+  const Layout & L = dom->lay[dom->depth];
+  const int N = L.n, nh = N/2 + 1;
+  /* gfs_domain_locate: the cell whose extent holds the point */
+  int kc = (int) floor ((pos + 0.5)*N) + 1;
+  GFSHIP_CHECK (kc >= 1 && kc <= N, GFSHIP_EINVAL, "the plane at %g lies outside the box", pos);
+  double * a = nullptr, * sum = nullptr;
+  double2 * Fo = nullptr;
+  hipfftHandle plan = 0;
+  int r = GFSHIP_OK;
+  hipError_t e = hipMalloc ((void **) &a, (size_t) N*N*sizeof (double));
+  if (e == hipSuccess) e = hipMalloc ((void **) &sum, sizeof (double));
+  if (e == hipSuccess) e = hipMalloc ((void **) &Fo, (size_t) N*nh*sizeof (double2));
+  if (e == hipSuccess) e = hipMemsetAsync (sum, 0, sizeof (double), dom->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL (spectra_plane_gather_kernel, dim3 ((N*N + 255)/256), dim3 (256), 0, dom->stream, L,
+			F->lev[dom->depth], normal, kc, a, sum);
+    hipLaunchKernelGGL (spectra_plane_center_kernel, dim3 ((N*N + 255)/256), dim3 (256), 0, dom->stream, N*N, sum, a);
+    e = hipGetLastError ();
+  }
+  if (e == hipSuccess) {
+    /* fftw_plan_dft_r2c_3d (1, N, N): a 2-D transform */
+    if (hipfftPlan2d (&plan, N, N, HIPFFT_D2Z) != HIPFFT_SUCCESS || hipfftSetStream (plan, dom->stream) != HIPFFT_SUCCESS ||
+	hipfftExecD2Z (plan, a, (hipfftDoubleComplex *) Fo) != HIPFFT_SUCCESS) {
+      gfship::set_error ("hipFFT error in the transform of a plane");
+      r = GFSHIP_EHIP;
+    }
+  }
+  if (e == hipSuccess && r == GFSHIP_OK)
+    e = hipMemcpyAsync (out, Fo, (size_t) N*nh*sizeof (double2), hipMemcpyDeviceToHost, dom->stream);
+  if (e == hipSuccess && r == GFSHIP_OK)
+    e = hipStreamSynchronize (dom->stream);
+  if (plan) (void) hipfftDestroy (plan);
+  (void) hipFree (a); (void) hipFree (sum); (void) hipFree (Fo);
+  if (r) return r;
+  GFSHIP_HIP (e);
+  if (kstep)
+    *kstep = 2.*M_PI/((N - 1)*(1./N));     /* init_kmax: 2 pi/(x1 - x0), first to last cell centre */
   return GFSHIP_OK;
 }
 

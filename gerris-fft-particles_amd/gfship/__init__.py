@@ -149,6 +149,7 @@ SIGNATURES = {
     "gfship_init_spectra": (_i, [_vp, _vp, C.POINTER(_i)]),
     "gfship_output_spectra_side": (_i, [_vp]),
     "gfship_output_spectra": (_i, [_vp, _i, _pd, C.POINTER(C.c_double)]),
+    "gfship_output_spectra_plane": (_i, [_vp, _i, _i, _d, _pd, _pd]),
     "gfship_turbulent_viscosity": (_i, [_vp, C.POINTER(_i), C.c_double, _i, _i]),
     "gfship_particles_set_particulate": (_i, [_vp, _pd, _pd, _pd]),
     "gfship_particles_set_forces": (_i, [_vp, _i, C.POINTER(_i), _pd]),
@@ -432,6 +433,16 @@ class Domain:
         out = np.empty((N, N, N // 2 + 1), dtype=np.complex128)
         ks = C.c_double()
         _check(lib().gfship_output_spectra(self.ptr, v.h, out.ctypes.data_as(_pd), C.byref(ks)))
+        return out, ks.value
+
+    def output_spectra_plane(self, v, normal, pos):
+        """GfsOutputSpectra of a plane of the 3-D box (realdim == 2): (F, kstep), F[ia][ib <= N/2] the 2-D r2c
+        DFT of the cell values on the plane minus their mean over their number"""
+        N = _check(lib().gfship_output_spectra_side(self.ptr))
+        out = np.empty((N, N // 2 + 1), dtype=np.complex128)
+        ks = C.c_double()
+        _check(lib().gfship_output_spectra_plane(self.ptr, v.h, int(normal), float(pos),
+                                                 out.ctypes.data_as(_pd), C.byref(ks)))
         return out, ks.value
 
     def turbulent_viscosity(self, u, Cs, out, model=1):

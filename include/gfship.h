@@ -318,10 +318,17 @@ int  gfship_energy_spectra (gfship_domain * dom, int ncomp, const gfship_field *
    (init_kmax, :1031-1045): write_spectra prints "kx ky kz re*L im*L" with k = kstep times the
    signed index.  On a box of a lattice (communicator or gather hook) every rank receives the
    transform of the whole lattice -- the reference redistributes slabs for FFTW-MPI (:467-669) --
-   and gfship_energy_spectra likewise bins the whole domain.  Planes (realdim == 2) and
-   GfsOutputSpectraInterface sample through the tree / the VOF interface: not provided. */
+   and gfship_energy_spectra likewise bins the whole domain.
+   gfship_output_spectra_plane: the same event with a flat box (realdim == 2, :1131-1141,
+   fill_interpolated_cartesian_matrix :822-883): the cells the points of the plane normal to `normal' (0 x,
+   1 y, 2 z) at coordinate pos lie in, minus their mean, over their number; the 2-D r2c DFT; out receives
+   N*(N/2 + 1) complex numbers, index ia*(N/2 + 1) + ib, ia / ib the first / second in-plane coordinate
+   (order_array keeps them in coordinate order behind the flat one); one box.  GfsOutputSpectraInterface
+   samples the position of a VOF interface (out of scope with VOF): not provided. */
 int  gfship_output_spectra_side (gfship_domain * dom);
 int  gfship_output_spectra (gfship_domain * dom, gfship_field v, double * out, double * kstep);
+int  gfship_output_spectra_plane (gfship_domain * dom, gfship_field v, int normal, double pos, double * out,
+				  double * kstep);
 
 /* GfsVariableTurbulentViscosity (modules/turbulence.c:953-1105): out = (Cs h)^2 |S| on the leaf cells
    from the centred differences of u (gfs_cm_gradient); model 1 = Smagorinsky (what the reference's

@@ -61,6 +61,25 @@ def output_spectra(u, n_box=None):
     return np.fft.rfftn(a), 2. * np.pi / ((n - 1) * dx)
 
 
+def output_spectra_plane(u, normal, pos):
+    """GfsOutputSpectra with a flat box (realdim == 2, modules/fft.c:1131-1141): the points
+    pos_min + j dx of the plane normal to `normal' (0 x, 1 y, 2 z) at coordinate pos take the value of the
+    cell they lie in (fill_interpolated_cartesian_matrix, :822-883: gfs_domain_locate + GFS_VALUE), the mean
+    of the np values is removed and the result divided by np; order_array (:800-820) puts the flat direction
+    first and keeps the other two in coordinate order; fftw_plan_dft_r2c_3d (1, N, N).  u: [k][j][i] of the
+    leaf level; returns F[ia][ib <= N/2] and the k step of write_spectra."""
+    n = u.shape[0]
+    kc = int(np.floor((pos + 0.5) * n))
+    a = np.transpose(u)                      # [i][j][k]
+    sl = [slice(None)] * 3
+    sl[normal] = kc
+    plane = a[tuple(sl)]                     # remaining axes in coordinate order
+    npnt = plane.size
+    avg = plane.sum() / npnt
+    plane = (plane - avg) / npnt
+    return np.fft.rfftn(plane), 2. * np.pi / ((n - 1) * (1. / n))
+
+
 def turbulent_viscosity(u, Cs, model=1):
     """GfsVariableTurbulentViscosity (modules/turbulence.c:953-1048) on a uniform box: u = components
     WITH their ghost layer, [k][j][i]; returns the interior values.  g[i][j] = gfs_cm_gradient of

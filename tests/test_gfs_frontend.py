@@ -273,6 +273,17 @@ def test_output_spectra_and_turbulent_viscosity_case(tmp_path):
     assert len(big) == 4                                   # kz >= 0 half: (+-1, +-1, 1)
     assert np.allclose(np.abs(big[:, :3]), dk, rtol=1e-5)
     assert np.allclose(np.hypot(big[:, 3], big[:, 4]), 0.125, rtol=1e-3)
+    # the plane z = 0.1 (a flat box: realdim == 2): N x (N/2 + 1) rows, kz = 0, the mode (+-1, 1) of
+    # sin (2 pi x) cos (2 pi y) with the amplitude cos (2 pi z_cell)/4
+    lines = open(tmp_path / "spectra-U-plane").read().splitlines()
+    assert lines[0].strip() == "# %d" % n ** 2
+    prow = np.array([[float(x) for x in l.split()] for l in lines[2:]])
+    assert len(prow) == n * (n // 2 + 1) and np.all(prow[:, 2] == 0.)
+    pamp = np.hypot(prow[:, 3], prow[:, 4])
+    pbig = prow[pamp > 0.05]
+    assert len(pbig) == 2 and np.allclose(np.abs(pbig[:, :2]), dk, rtol=1e-5)
+    zc = -0.5 + (np.floor((0.1 + 0.5) * n) + 0.5) / n
+    assert np.allclose(np.hypot(pbig[:, 3], pbig[:, 4]), abs(np.cos(2 * np.pi * zc)) / 4., rtol=1e-3)
     # the eddy viscosity against the numpy restatement on the initial field
     from oracle.go_spectra import turbulent_viscosity
     x = (np.arange(-1, n + 1) + 0.5) / n - 0.5

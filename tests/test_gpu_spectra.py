@@ -159,3 +159,27 @@ def test_turbulent_viscosity_matches_the_restatement(dim, model):
         assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
         assert (got > 0).any()
     gd.destroy()
+
+
+@pytest.mark.parametrize("normal,pos", [(2, 0.1), (0, -0.3), (1, 0.26)])
+def test_output_spectra_of_a_plane_matches_the_restatement(normal, pos):
+    """GfsOutputSpectra with a flat box (a plane of the 3-D box): the 2-D r2c DFT of the cell values on the
+    plane against the numpy restatement of modules/fft.c:822-883,1101-1160, and a single in-plane mode"""
+    from oracle import go_spectra as GS
+    level = 5
+    n = 1 << level
+    gd = gfship.Domain(3, level, [gfship.SIDE_PERIODIC] * 6)
+    v = gd.variable()
+    rng = np.random.default_rng(12)
+    a = np.zeros((n + 2,) * 3)
+    c = -0.5 + (np.arange(1, n + 1) - 0.5) / n
+    z, y, x = np.meshgrid(c, c, c, indexing="ij")
+    a[1:-1, 1:-1, 1:-1] = np.sin(2. * np.pi * 3. * x) * np.cos(2. * np.pi * 2. * y) * (1. + z) + \
+        0.1 * rng.standard_normal((n,) * 3)
+    v.upload(a)
+    F, ks = gd.output_spectra_plane(v, normal, pos)
+    Fo, kso = GS.output_spectra_plane(a[1:-1, 1:-1, 1:-1], normal, pos)
+    assert ks == kso
+    assert np.abs(F - Fo).max() <= 1e-13 * max(1., np.abs(Fo).max())
+    assert abs(F[0, 0]) <= 1e-15                   # the mean of the plane has been removed
+    gd.destroy()
