@@ -86,6 +86,9 @@ struct Sweep {              // T_LEVEL_LEAFS (m) in dependency levels
     int nnodes = 0, nlev = 0, nchunks = 0;
     int * ti = nullptr, * tv = nullptr, * node_off = nullptr, * node_g = nullptr, * chunk = nullptr;
     double * td = nullptr;
+    // the same plan for t_relax_nodes_pf: per chunk { c0, c1, i0, i1, d0, d1, v0, v1 }, per node { start in ti, td,
+    // tv, cell } -- one load each, issued a chunk ahead
+    int * desc = nullptr, * rec = nullptr;
     // host copies (gfship_tree_host_check)
     std::vector<int> h_ti, h_tv, h_node_off, h_node_g, h_node_level;
     std::vector<double> h_td;
@@ -490,6 +493,106 @@ t_relax_nodes (Topo T, const int * node_g, const int * node_off, const int * chu
       }
     }
     __syncthreads ();
+  }
+}
+
+// t_relax_nodes with everything that does not depend on the values loaded a chunk ahead.  A step of
+// t_relax_nodes is a chain of seven dependent global round trips (chunk bounds, node offsets, gather index,
+// value, node cell, right-hand side, store acknowledgement: 2.9 us); here the descriptor of the next chunk is
+// loaded while this one is staged, the node record and the gather indices of the next chunk while this one is
+// evaluated, its right-hand side behind the stores: what is left on the chain is the gather of the values,
+// the evaluation from LDS and the acknowledgement of the stores.
+#define PF_R 8      /* gather indices a thread keeps for the next chunk (chunks with more: loaded in place) */
+struct I8 { int v[8]; };
+
+__global__ void __launch_bounds__(1024)
+t_relax_nodes_pf (Topo T, const int * rec_g, const int * desc_g, int nchunks,
+		  const int * ti_g, const double * td_g, const int * tv_g, double * u, const double * rhs,
+		  double omega, int op, double w, const int * node_g, const int * node_off)
+{
+  extern __shared__ double lds[];
+  const int nd = T.nd (), dim = T.dim, ncd = T.ncd ();
+  const int tid = threadIdx.x;
+  typedef int int4v __attribute__((ext_vector_type(4)));
+  I8 D = *(const I8 *) desc_g;
+  int4v rec = { 0, 0, 0, 0 };
+  double rhs_r = 0.;
+  int idx[PF_R];
+  if (D.v[0] + tid < D.v[1]) {
+    rec = *(const int4v *) (rec_g + 4*(size_t) (D.v[0] + tid));
+    rhs_r = rhs[rec.w];
+  }
+#pragma unroll
+  for (int r = 0; r < PF_R; r++) {
+    const int t = tid + r*1024;
+    idx[r] = t < D.v[7] - D.v[6] ? tv_g[D.v[6] + t] : 0;
+  }
+  for (int k = 0; k < nchunks; k++) {
+    const int c0 = D.v[0], c1 = D.v[1], i0 = D.v[2], i1 = D.v[3], d0 = D.v[4], d1 = D.v[5], v0 = D.v[6], v1 = D.v[7];
+    double * lv = lds, * ld = lds + (v1 - v0);
+    int * li = (int *) (ld + (d1 - d0));
+    // ---- stage: the values (indices already here), the constants, the codes
+#pragma unroll
+    for (int r = 0; r < PF_R; r++) {
+      const int t = tid + r*1024;
+      if (t < v1 - v0) lv[t] = u[idx[r]];
+    }
+    for (int t = tid + PF_R*1024; t < v1 - v0; t += 1024)
+      lv[t] = u[tv_g[v0 + t]];
+    for (int t = tid; t < d1 - d0; t += 1024)
+      ld[t] = td_g[d0 + t];
+    for (int t = tid; t < i1 - i0; t += 1024)
+      li[t] = ti_g[i0 + t];
+    const I8 Dn = *(const I8 *) (desc_g + 8*(size_t) (k + 1));      /* zeros behind the last chunk */
+    __syncthreads ();
+    // ---- the loads for the next chunk that do not depend on this one's results
+    int4v recn = { 0, 0, 0, 0 };
+    int idxn[PF_R];
+    const bool nextnode = Dn.v[0] + tid < Dn.v[1];
+    if (nextnode)
+      recn = *(const int4v *) (rec_g + 4*(size_t) (Dn.v[0] + tid));
+#pragma unroll
+    for (int r = 0; r < PF_R; r++) {
+      const int t = tid + r*1024;
+      idxn[r] = t < Dn.v[7] - Dn.v[6] ? tv_g[Dn.v[6] + t] : 0;
+    }
+    // ---- evaluate
+    for (int c = c0 + tid; c < c1; c += 1024) {
+      int io, dof, vo, g;
+      double rh;
+      if (c == c0 + tid) { io = rec.x; dof = rec.y; vo = rec.z; g = rec.w; rh = rhs_r; }
+      else { io = node_off[3*c]; dof = node_off[3*c + 1]; vo = node_off[3*c + 2]; g = node_g[c]; rh = rhs[g]; }
+      TapeCursor cur = { li + (io - i0), ld + (dof - d0), lv + (vo - v0) };
+      if (*cur.ti == K_GHOST)       /* homogeneous condition / periodic copy: ghost = s * cell */
+	u[g] = (*cur.td)*(*cur.tv);
+      else if (op == 0) {
+	const double self = *cur.tv++;
+	double ga, gb;
+	tape_cell (cur, nd, dim, ncd, ga, gb);
+	double x = 0.;
+	if (ga != 0.)
+	  x = dim == 2 ? (1. - omega)*self + omega*(gb - rh)/ga : (gb - rh)/ga;
+	u[g] = x;
+      }
+      else {      /* diffusion_relax, src/poisson.c:1455-1484 (rhoc = 1) */
+	cur.tv++;
+	double ga, gb;
+	tape_cell (cur, nd, dim, ncd, ga, gb, w);
+	int l = 0;
+	while (g >= T.off[l + 1]) l++;
+	const double h = 1./(1 << l);
+	const double a = 1.*h*h;
+	ga = 1. + ga/a;
+	u[g] = (gb/a + rh)/ga;
+      }
+    }
+    double rhs_n = 0.;
+    if (nextnode)
+      rhs_n = rhs[recn.w];
+    __syncthreads ();
+    D = Dn; rec = recn; rhs_r = rhs_n;
+#pragma unroll
+    for (int r = 0; r < PF_R; r++) idx[r] = idxn[r];
   }
 }
 
@@ -1428,6 +1531,7 @@ void loop_free (Sweep::Loop & P)
 {
   (void) hipFree (P.ti); (void) hipFree (P.tv); (void) hipFree (P.td);
   (void) hipFree (P.node_off); (void) hipFree (P.node_g); (void) hipFree (P.chunk);
+  (void) hipFree (P.desc); (void) hipFree (P.rec);
   P = Sweep::Loop ();
 }
 
@@ -1519,6 +1623,23 @@ int loop_plan (gfship_tree * tr, int m, unsigned nrelax, Sweep * S, Sweep::Loop 
       (e = to_device (node_off, &P.node_off)) || (e = to_device (node_g, &P.node_g)) ||
       (e = to_device (chunk, &P.chunk)))
     return e;
+  {
+    std::vector<int> desc, rec;
+    for (int k = 0; k < P.nchunks; k++) {
+      const int c0 = chunk[k], c1 = chunk[k + 1];
+      const int v[8] = { c0, c1, node_off[3*c0], node_off[3*c1], node_off[3*c0 + 1], node_off[3*c1 + 1],
+			 node_off[3*c0 + 2], node_off[3*c1 + 2] };
+      desc.insert (desc.end (), v, v + 8);
+    }
+    for (int q = 0; q < 8; q++) desc.push_back (0);          /* the descriptor read past the last chunk */
+    for (size_t c = 0; c < nodes.size (); c++) {
+      rec.push_back (node_off[3*c]); rec.push_back (node_off[3*c + 1]); rec.push_back (node_off[3*c + 2]);
+      rec.push_back (node_g[c]);
+    }
+    for (int q = 0; q < 4; q++) rec.push_back (0);
+    if ((e = to_device (desc, &P.desc)) || (e = to_device (rec, &P.rec)))
+      return e;
+  }
   P.nrelax = nrelax;
   if (g_host_only) {
     P.h_ti = ti; P.h_tv = tv; P.h_td = td; P.h_node_off = node_off; P.h_node_g = node_g;
@@ -1706,10 +1827,23 @@ int relax_loop (gfship_tree * tr, int m, unsigned nrelax, double omega, int op =
       int e = loop_plan (tr, m, nrelax, &S);
       if (e) return e;
     }
-    GFSHIP_HIP (hipFuncSetAttribute ((const void *) t_relax_nodes, hipFuncAttributeMaxDynamicSharedMemorySize,
-				     TAPE_LDS_BYTES));
-    t_relax_nodes<<<1, 1024, TAPE_LDS_BYTES, tr->stream>>> (tr->D, P->node_g, P->node_off, P->chunk,
-	P->nchunks, P->ti, P->td, P->tv, tr->var[V_DP], tr->var[V_RES], omega, op, w);
+    static int old_nodes = -1;
+    if (old_nodes < 0) {
+      const char * e = getenv ("GFSHIP_TREE_NO_PREFETCH");      /* 1: t_relax_nodes (every load in place) */
+      old_nodes = e ? atoi (e) : 0;
+    }
+    if (old_nodes) {
+      GFSHIP_HIP (hipFuncSetAttribute ((const void *) t_relax_nodes, hipFuncAttributeMaxDynamicSharedMemorySize,
+				       TAPE_LDS_BYTES));
+      t_relax_nodes<<<1, 1024, TAPE_LDS_BYTES, tr->stream>>> (tr->D, P->node_g, P->node_off, P->chunk,
+	  P->nchunks, P->ti, P->td, P->tv, tr->var[V_DP], tr->var[V_RES], omega, op, w);
+    }
+    else {
+      GFSHIP_HIP (hipFuncSetAttribute ((const void *) t_relax_nodes_pf, hipFuncAttributeMaxDynamicSharedMemorySize,
+				       TAPE_LDS_BYTES));
+      t_relax_nodes_pf<<<1, 1024, TAPE_LDS_BYTES, tr->stream>>> (tr->D, P->rec, P->desc, P->nchunks, P->ti, P->td, P->tv,
+	  tr->var[V_DP], tr->var[V_RES], omega, op, w, P->node_g, P->node_off);
+    }
   }
   else if (S.taped && !use_template)
     t_relax_tape<<<1, 1024, TAPE_LDS_BYTES, tr->stream>>> (tr->D, S.cells, S.cell_off, S.ncells, S.chunk, S.nchunks,
