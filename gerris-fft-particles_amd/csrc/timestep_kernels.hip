@@ -1924,30 +1924,57 @@ struct Sweep2Lds {
   double FL[3][3][SWY][SWX];                           // left states of plane p - 1: every thread its own slots
 };
 
-template <bool VL, bool SRC>
+// MPI: a box with GfsBoundaryMpi sides (G.r[d] != nullptr: side d is one).  A ring cell beyond such a side is the
+// ghost cell itself (its value, gm and the MAC velocities of its faces are those the neighbour box sent), and its
+// state towards the column is what the neighbour computed for its own cell (boundary_face_values_kernel, one
+// message per side) instead of the recomputed periodic image: G.r[d][q n^2 + f].  Planes 0 and n + 1 likewise
+// along z (advect3_sweep2_kernel below).
+template <bool MPI>
+__device__ __forceinline__ int sweep2_plane (int k, int n, int sz, bool zlo, bool zhi)
+{
+  if (k < 1) k = MPI && zlo ? (k < 0 ? 0 : k) : k + n;
+  else if (k > n) k = MPI && zhi ? n + 1 : k - n;
+  return k*sz;
+}
+
+template <bool VL, bool SRC, bool MPI>
 __device__ __forceinline__ void sweep2_ring_path (Sweep2Lds & S_, const Layout & L, const CPtr3 & v, const CPtr3 & un,
-						  const CPtr3 & gm, double dt, const Visc3 & src3, int rid)
+						  const CPtr3 & gm, double dt, const Visc3 & src3, int rid,
+						  const GhostFv & G)
 {
   const int n = L.n;
   const double rn = (double) n, rsize2 = (double) n/2.;
-  const int sy = (int) L.sy, sz = (int) L.sz;
+  const int sy0 = (int) L.sy, sz = (int) L.sz;
   const int kb = blockIdx.z*SWZ;
-  auto plane = [n, sz] (int k) { return (k < 1 ? k + n : k > n ? k - n : k)*sz; };
+  const bool zlo = MPI && G.r[5] != nullptr, zhi = MPI && G.r[4] != nullptr;
+  auto plane = [=] (int k) { return sweep2_plane<MPI> (k, n, sz, zlo, zhi); };
   int role = -1, hd = 0, hcol = 0, hslot = 0;
+  const double * recv = nullptr;                     // the states of the ring cells beyond an MPI side, per plane n apart
   if (rid < 2*SWX) {
     role = rid < SWX ? 0 : 1; hd = 1; hslot = rid % SWX;
     int hj = blockIdx.y*SWY + (role ? SWY + 1 : 0);
-    hj = hj < 1 ? hj + n : hj > n ? hj - n : hj;
+    if (MPI && (hj < 1 || hj > n) && G.r[role ? 2 : 3])
+      recv = G.r[role ? 2 : 3] + (blockIdx.x*SWX + hslot);          /* f = (x - 1) + n (z - 1) */
+    else
+      hj = hj < 1 ? hj + n : hj > n ? hj - n : hj;
     hcol = (int) L.idx (blockIdx.x*SWX + hslot + 1, hj, 0);
   }
   else if (rid < 2*SWX + 2*SWY) {
     role = rid < 2*SWX + SWY ? 2 : 3; hd = 0; hslot = (rid - 2*SWX) % SWY;
     int hi_ = blockIdx.x*SWX + (role == 3 ? SWX + 1 : 0);
-    hi_ = hi_ < 1 ? hi_ + n : hi_ > n ? hi_ - n : hi_;
+    if (MPI && (hi_ < 1 || hi_ > n) && G.r[role == 3 ? 0 : 1])
+      recv = G.r[role == 3 ? 0 : 1] + (blockIdx.y*SWY + hslot);    /* f = (y - 1) + n (z - 1) */
+    else
+      hi_ = hi_ < 1 ? hi_ + n : hi_ > n ? hi_ - n : hi_;
     hcol = (int) L.idx (hi_, blockIdx.y*SWY + hslot + 1, 0);
   }
+  // a ghost row beyond a y side has no row beyond it: its y neighbours (never used: the state comes from recv)
+  // are read from the row itself
+  const int sy = MPI && recv && hd == 1 ? 0 : sy0;
+  const size_t nf = (size_t) n*n;
   const bool ring = role >= 0, ring_minus = role == 0 || role == 2;
-  const int hoff = hd == 0 ? 1 : sy;                 // towards the column
+  // towards the column (a ring cell beyond an MPI side on the + side has nothing of its own to read there)
+  const int hoff = MPI && recv && !ring_minus ? 0 : hd == 0 ? 1 : sy0;
   const int ry = role == 0 ? 0 : role == 1 ? SWY + 1 : hslot + 1;
   const int rx = role == 2 ? 0 : role == 3 ? SWX + 1 : hslot + 1;
   // everything is loaded one iteration before it is used (suffix n: for the next iteration)
@@ -2022,8 +2049,13 @@ __device__ __forceinline__ void sweep2_ring_path (Sweep2Lds & S_, const Layout &
       const AdvShared S = adv_shared_v (hua, hub, dt, rsize2);
 #pragma unroll
       for (int q = 0; q < 3; q++) {
-	const FacePair f = hd == 0 ? adv_face_values_s<0, VL, SRC> (HW[q], S, dt, rsize2, src3.g[q]) :
+	FacePair f = hd == 0 ? adv_face_values_s<0, VL, SRC> (HW[q], S, dt, rsize2, src3.g[q]) :
 	  adv_face_values_s<1, VL, SRC> (HW[q], S, dt, rsize2, src3.g[q]);
+	if (MPI && recv) {
+	  /* beyond an MPI side: the state the neighbour box sent (planes 0 and n + 1 feed nothing that is stored) */
+	  const int zc = p < 1 ? 0 : p > n ? n - 1 : p - 1;
+	  f.l = f.r = recv[q*nf + (size_t) n*zc];
+	}
 	hl[q] = f.l;
 	if (role == 3) S_.FRx[p & 1][q][hslot][SWX] = f.r;
 	if (role == 1) S_.FRy[p & 1][q][SWY][hslot] = f.r;
@@ -2052,15 +2084,15 @@ __device__ __forceinline__ void sweep2_ring_path (Sweep2Lds & S_, const Layout &
   }
 }
 
-template <bool VL, bool SRC, bool CORR>
+template <bool VL, bool SRC, bool CORR, bool MPI>
 __global__ void __launch_bounds__(SWN + SW_RING)
 advect3_sweep2_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc, double dt, Visc3 src3,
-		       AdvCorr K)
+		       AdvCorr K, GhostFv G)
 {
   __shared__ Sweep2Lds S_;
   const int tid = threadIdx.x;
   if (tid >= SWN) {
-    sweep2_ring_path<VL, SRC> (S_, L, v, un, gm, dt, src3, tid - SWN);
+    sweep2_ring_path<VL, SRC, MPI> (S_, L, v, un, gm, dt, src3, tid - SWN, G);
     return;
   }
   const int tx = tid % SWX, ty = tid / SWX;
@@ -2070,7 +2102,10 @@ advect3_sweep2_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc
   const int i = blockIdx.x*SWX + tx + 1, j = blockIdx.y*SWY + ty + 1;
   const int kb = blockIdx.z*SWZ;                     // output planes kb + 1 .. kb + SWZ
   const int col = (int) L.idx (i, j, 0);
-  auto plane = [n, sz] (int k) { return (k < 1 ? k + n : k > n ? k - n : k)*sz; };   // periodic image
+  const bool zlo = MPI && G.r[5] != nullptr, zhi = MPI && G.r[4] != nullptr;
+  auto plane = [=] (int k) { return sweep2_plane<MPI> (k, n, sz, zlo, zhi); };   // periodic image / ghost plane
+  const size_t nf = (size_t) n*n;
+  const int fpos = (i - 1) + n*(j - 1);              // face_pos (2, ...)
 
   double vm[3], v0[3], vp[3], vn[3];                 // planes p - 1, p, p + 1 and the load for p + 2
   double una[3], unb[3], unn[3];                     // un (p), un (p - 1), un (p + 1)
@@ -2160,6 +2195,11 @@ advect3_sweep2_kernel (Layout L, CPtr3 v, Ptr3 out, CPtr3 un, CPtr3 gm, CPtr3 gc
 #pragma unroll
 	for (int d = 0; d < 3; d++)
 	  S_.FL[q][d][ty][tx] = F.l[d];
+	if (MPI) {
+	  /* the planes beyond an MPI side along z: the states the neighbour boxes sent */
+	  if (zlo && p == 0) S_.FL[q][2][ty][tx] = G.r[5][q*nf + fpos];
+	  if (zhi && p == n + 1) frz[q] = G.r[4][q*nf + fpos];
+	}
       }
     }
     double Fpz[3] = { 0., 0., 0. };
@@ -3043,6 +3083,21 @@ int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * con
   }
   const bool srcs0 = dom->src[0] != 0. || dom->src[1] != 0. || dom->src[2] != 0.;
   static const bool sweep_ok = getenv ("GFSHIP_NO_ADVECT_SWEEP") == nullptr;
+  static const bool mpi_sweep_ok = getenv ("GFSHIP_NO_MPI_SWEEP") == nullptr;
+  if (mpi && sweep_ok && mpi_sweep_ok && L.n % SWX == 0 && L.n % SWY == 0 && L.n % SWZ == 0) {
+    /* a box with MPI sides: the same sweep with the states beyond those sides from the received buffers */
+    const dim3 sgrid (L.n/SWX, L.n/SWY, L.n/SWZ);
+#define SK3M(VL_, SRC_) do { \
+      if (corr) hipLaunchKernelGGL ((advect3_sweep2_kernel<VL_, SRC_, true, true>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
+				    L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K, G); \
+      else hipLaunchKernelGGL ((advect3_sweep2_kernel<VL_, SRC_, false, true>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
+			       L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K, G); } while (0)
+    if (gradient) { if (srcs0) SK3M (true, true); else SK3M (true, false); }
+    else          { if (srcs0) SK3M (false, true); else SK3M (false, false); }
+#undef SK3M
+    GFSHIP_HIP (hipGetLastError ());
+    return GFSHIP_OK;
+  }
   if (!mpi && sweep_ok && L.n % SWX == 0 && L.n % SWY == 0 && L.n % SWZ == 0) {
     /* periodic box: the sweep along z (advect3_sweep_kernel) */
     const dim3 sgrid (L.n/SWX, L.n/SWY, L.n/SWZ);
@@ -3053,10 +3108,10 @@ int launch_advect3_fused (gfship_domain * dom, double * const v[3], double * con
 				      L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K); \
 	else hipLaunchKernelGGL ((advect3_sweep_kernel<VL_, SRC_, false>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
 				 L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K); } \
-      else if (corr) hipLaunchKernelGGL ((advect3_sweep2_kernel<VL_, SRC_, true>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
-					 L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K); \
-      else hipLaunchKernelGGL ((advect3_sweep2_kernel<VL_, SRC_, false>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
-			       L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K); } while (0)
+      else if (corr) hipLaunchKernelGGL ((advect3_sweep2_kernel<VL_, SRC_, true, false>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
+					 L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K, G); \
+      else hipLaunchKernelGGL ((advect3_sweep2_kernel<VL_, SRC_, false, false>), sgrid, dim3 (SWN + SW_RING), 0, dom->stream, \
+			       L, c3 (v), m3 (out), c3 (un), c3 (gm), gcp, dt, vs, K, G); } while (0)
     if (gradient) { if (srcs0) SK3 (true, true); else SK3 (true, false); }
     else          { if (srcs0) SK3 (false, true); else SK3 (false, false); }
 #undef SK3
