@@ -2342,29 +2342,41 @@ __device__ __forceinline__ FacePair cen_face_values_s (const Stencil7 & W, const
   return f;
 }
 
-template <bool VL, bool VS>
+template <bool VL, bool VS, bool MPI>
 __device__ __forceinline__ void pred_ring_path (PredLds & S_, const Layout & L, const CPtr3 & u, double dt,
-						const Visc3 & visc, int rid)
+						const Visc3 & visc, int rid, const Ptr3 & un, const GhostFv & G)
 {
   const int n = L.n;
-  const int sy = (int) L.sy, sz = (int) L.sz;
+  const int sy0 = (int) L.sy, sz = (int) L.sz;
   const int kb = blockIdx.z*SWZ;
-  auto plane = [n, sz] (int k) { return (k < 1 ? k + n : k > n ? k - n : k)*sz; };
+  const bool zlo = MPI && G.r[5] != nullptr, zhi = MPI && G.r[4] != nullptr;
+  auto plane = [=] (int k) { return sweep2_plane<MPI> (k, n, sz, zlo, zhi); };
   int role = -1, hd = 0, hcol = 0, hslot = 0;
+  // MPI: the state of a ring cell beyond an MPI side is the one the neighbour box sent (one variable per
+  // direction: u[d] along d), the cell itself is the ghost cell; the face between it and the column on the low
+  // side of the box is computed here (the periodic box copies it from the high side)
+  const double * recv = nullptr;
   if (rid < 2*SWX) {
     role = rid < SWX ? 0 : 1; hd = 1; hslot = rid % SWX;
     int hj = blockIdx.y*SWY + (role ? SWY + 1 : 0);
-    hj = hj < 1 ? hj + n : hj > n ? hj - n : hj;
+    if (MPI && (hj < 1 || hj > n) && G.r[role ? 2 : 3])
+      recv = G.r[role ? 2 : 3] + (blockIdx.x*SWX + hslot);
+    else
+      hj = hj < 1 ? hj + n : hj > n ? hj - n : hj;
     hcol = (int) L.idx (blockIdx.x*SWX + hslot + 1, hj, 0);
   }
   else if (rid < 2*SWX + 2*SWY) {
     role = rid < 2*SWX + SWY ? 2 : 3; hd = 0; hslot = (rid - 2*SWX) % SWY;
     int hi_ = blockIdx.x*SWX + (role == 3 ? SWX + 1 : 0);
-    hi_ = hi_ < 1 ? hi_ + n : hi_ > n ? hi_ - n : hi_;
+    if (MPI && (hi_ < 1 || hi_ > n) && G.r[role == 3 ? 0 : 1])
+      recv = G.r[role == 3 ? 0 : 1] + (blockIdx.y*SWY + hslot);
+    else
+      hi_ = hi_ < 1 ? hi_ + n : hi_ > n ? hi_ - n : hi_;
     hcol = (int) L.idx (hi_, blockIdx.y*SWY + hslot + 1, 0);
   }
   const bool ring = role >= 0, ring_minus = role == 0 || role == 2;
-  const int hoff = hd == 0 ? 1 : sy;
+  const int sy = MPI && recv && hd == 1 ? 0 : sy0;          /* no row beyond a ghost row: never used then */
+  const int hoff = MPI && recv && !ring_minus ? 0 : hd == 0 ? 1 : sy0;
   const int ry = role == 0 ? 0 : role == 1 ? SWY + 1 : hslot + 1;
   const int rx = role == 2 ? 0 : role == 3 ? SWX + 1 : hslot + 1;
   // the column of the ring cell: the three components (the ring of V), of which u[hd] is advected
@@ -2414,6 +2426,10 @@ __device__ __forceinline__ void pred_ring_path (PredLds & S_, const Layout & L, 
       const FacePair f = hd == 0 ? cen_face_values_s<0, VL, VS> (HW, hv0, dt, n, visc.d[0], visc.g[0]) :
 	cen_face_values_s<1, VL, VS> (HW, hv0, dt, n, visc.d[1], visc.g[1]);
       hl = f.l; hr = f.r;
+      if (MPI && recv) {
+	const int zc = p < 1 ? 0 : p > n ? n - 1 : p - 1;
+	hl = hr = recv[(size_t) n*zc];
+      }
       if (role == 3) S_.FRx[p & 1][hslot][SWX] = hr;
       if (role == 1) S_.FRy[p & 1][SWY][hslot] = hr;
       // the face between the cell and the column, plane p - 1 (for the divergence of the column's cells)
@@ -2422,6 +2438,8 @@ __device__ __forceinline__ void pred_ring_path (PredLds & S_, const Layout & L, 
 	const double s0 = face_interp (hvm[hd], hnb);
 	const double val = upwinded (s0, hlo, rs);
 	if (role == 2) S_.UOx[hslot][0] = val; else S_.UOy[0][hslot] = val;
+	if (MPI && recv && p - 1 >= 1 && p - 1 <= n)      /* the face on the low side of the box */
+	  un.p[hd][hcol + plane (p - 1)] = val;
       }
     }
     __syncthreads ();                                // (2)
@@ -2429,15 +2447,15 @@ __device__ __forceinline__ void pred_ring_path (PredLds & S_, const Layout & L, 
   }
 }
 
-template <bool VL, bool VS, bool DIV>
+template <bool VL, bool VS, bool DIV, bool MPI>
 __global__ void __launch_bounds__(SWN + SW_RING)
 predict_un_sweep_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc, double * __restrict__ div,
-			 double div_dt)
+			 double div_dt, GhostFv G)
 {
   __shared__ PredLds S_;
   const int tid = threadIdx.x;
   if (tid >= SWN) {
-    pred_ring_path<VL, VS> (S_, L, u, dt, visc, tid - SWN);
+    pred_ring_path<VL, VS, MPI> (S_, L, u, dt, visc, tid - SWN, un, G);
     return;
   }
   const int tx = tid % SWX, ty = tid / SWX;
@@ -2446,7 +2464,10 @@ predict_un_sweep_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc, doub
   const int i = blockIdx.x*SWX + tx + 1, j = blockIdx.y*SWY + ty + 1;
   const int kb = blockIdx.z*SWZ;
   const int col = (int) L.idx (i, j, 0);
-  auto plane = [n, sz] (int k) { return (k < 1 ? k + n : k > n ? k - n : k)*sz; };
+  const bool zlo = MPI && G.r[5] != nullptr, zhi = MPI && G.r[4] != nullptr;
+  const bool xmpi = MPI && G.r[1] != nullptr, ympi = MPI && G.r[3] != nullptr;
+  auto plane = [=] (int k) { return sweep2_plane<MPI> (k, n, sz, zlo, zhi); };
+  const int fpos = (i - 1) + n*(j - 1);
   double vm[3], v0[3], vp[3], vn[3];
   double flo[3] = { 0., 0., 0. };                    // left states of plane p - 1 (u[d] along d)
   double uxp = 0., uyp = 0.;                         // u_x (c + 1), u_y (c + sy) of plane p - 1
@@ -2492,6 +2513,11 @@ predict_un_sweep_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc, doub
       W.m[1] = S_.V[2][ty][tx + 1];  W.p[1] = S_.V[2][ty + 2][tx + 1];
       W.m[2] = vm[2];                W.p[2] = vp[2];
       F[2] = cen_face_values_s<2, VL, VS> (W, v0, dt, n, visc.d[2], visc.g[2]);
+      if (MPI) {
+	/* the planes beyond an MPI side along z: the states the neighbour boxes sent */
+	if (zlo && p == 0) F[2].l = G.r[5][fpos];
+	if (zhi && p == n + 1) F[2].r = G.r[4][fpos];
+      }
     }
     double unv[3] = { 0., 0., 0. };
     if (p > kb) {
@@ -2504,11 +2530,14 @@ predict_un_sweep_kernel (Layout L, CPtr3 u, Ptr3 un, double dt, Visc3 visc, doub
 	un.p[0][co] = unv[0];
 	un.p[1][co] = unv[1];
 	un.p[2][co] = unv[2];
-	// the face on the low side of the box is the periodic image of the one on the high side
-	if (i == n) un.p[0][co - n] = unv[0];
-	if (j == n) un.p[1][co - n*sy] = unv[1];
-	if (o == n) un.p[2][co - n*sz] = unv[2];
+	// the face on the low side of the box is the periodic image of the one on the high side (beyond an MPI
+	// side it is the face of the ghost cell: the ring lanes / the plane 0 compute it)
+	if (i == n && !xmpi) un.p[0][co - n] = unv[0];
+	if (j == n && !ympi) un.p[1][co - n*sy] = unv[1];
+	if (o == n && !zlo) un.p[2][co - n*sz] = unv[2];
       }
+      else if (MPI && zlo && o == 0)
+	un.p[2][co] = unv[2];
       if (DIV) {
 	S_.UOx[ty][tx + 1] = unv[0];
 	S_.UOy[ty + 1][tx] = unv[1];
@@ -2989,11 +3018,13 @@ int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt
     /* periodic box: the sweep along z, with the divergence of the MAC projection that follows */
     const dim3 sgrid (L.n/SWX, L.n/SWY, L.n/SWZ);
     const bool dv = div != nullptr && div_dt != 0.;
+    GhostFv G0;
+    for (int d = 0; d < 6; d++) { G0.r[d] = nullptr; G0.s[d] = nullptr; }
 #define PS(VL_, VS_) do { \
-      if (dv) hipLaunchKernelGGL ((predict_un_sweep_kernel<VL_, VS_, true>), sgrid, dim3 (SWN + SW_RING), 0, \
-				  dom->stream, L, c3 (u), m3 (un), dt, vs, div, div_dt); \
-      else hipLaunchKernelGGL ((predict_un_sweep_kernel<VL_, VS_, false>), sgrid, dim3 (SWN + SW_RING), 0, \
-			       dom->stream, L, c3 (u), m3 (un), dt, vs, div, div_dt); } while (0)
+      if (dv) hipLaunchKernelGGL ((predict_un_sweep_kernel<VL_, VS_, true, false>), sgrid, dim3 (SWN + SW_RING), 0, \
+				  dom->stream, L, c3 (u), m3 (un), dt, vs, div, div_dt, G0); \
+      else hipLaunchKernelGGL ((predict_un_sweep_kernel<VL_, VS_, false, false>), sgrid, dim3 (SWN + SW_RING), 0, \
+			       dom->stream, L, c3 (u), m3 (un), dt, vs, div, div_dt, G0); } while (0)
     if (gradient) { if (anyv) PS (true, true); else PS (true, false); }
     else          { if (anyv) PS (false, true); else PS (false, false); }
 #undef PS
@@ -3017,6 +3048,23 @@ int launch_predict_un_fused (gfship_domain * dom, double * const u[3], double dt
     GFSHIP_HIP (hipGetLastError ());
     if ((r = comm_exchange_raw (dom, dom->gfv_send, dom->gfv_recv, (size_t) L.n*L.n))) return r;
     dom->n_fused_mpi++;
+    static const bool mpi_sweep_ok = getenv ("GFSHIP_NO_MPI_SWEEP") == nullptr;
+    if (sweep_ok && mpi_sweep_ok && L.n % SWX == 0 && L.n % SWY == 0 && L.n % SWZ == 0) {
+      /* the sweep along z with the states beyond the MPI sides from the received buffers, and the divergence */
+      const dim3 sgrid (L.n/SWX, L.n/SWY, L.n/SWZ);
+      const bool dv = div != nullptr && div_dt != 0.;
+#define PSM(VL_, VS_) do { \
+	if (dv) hipLaunchKernelGGL ((predict_un_sweep_kernel<VL_, VS_, true, true>), sgrid, dim3 (SWN + SW_RING), 0, \
+				    dom->stream, L, c3 (u), m3 (un), dt, vs, div, div_dt, G); \
+	else hipLaunchKernelGGL ((predict_un_sweep_kernel<VL_, VS_, false, true>), sgrid, dim3 (SWN + SW_RING), 0, \
+				 dom->stream, L, c3 (u), m3 (un), dt, vs, div, div_dt, G); } while (0)
+      if (gradient) { if (anyv) PSM (true, true); else PSM (true, false); }
+      else          { if (anyv) PSM (false, true); else PSM (false, false); }
+#undef PSM
+      GFSHIP_HIP (hipGetLastError ());
+      if (div_done) *div_done = dv;
+      return GFSHIP_OK;
+    }
   }
 #define PK(VL_, VS_) do { if (mpi) hipLaunchKernelGGL ((predict_un_tiled_kernel<VL_, VS_, true>), grid, dim3 (GN), 0, 							dom->stream, L, c3 (u), m3 (un), dt, vs, G);     else hipLaunchKernelGGL ((predict_un_tiled_kernel<VL_, VS_, false>), grid, dim3 (GN), 0, 			     dom->stream, L, c3 (u), m3 (un), dt, vs, G); } while (0)
   if (gradient) { if (anyv) PK (true, true); else PK (true, false); }
