@@ -1298,11 +1298,15 @@ patch_restrict_pack_kernel (PatchRestrictArgs A)
     if (I >= 0 && I < n)
       A.dst[tbase + (long) rho*SK_NL + 128*(p >> 1) + 2*(PA + 8*PB) + (p & 1)] = buf[a + 16*db][I - I0];
   }
-  // the coarse cells whose first child (I = 2 m) sits in one of this block's rows
-  for (int e = tid; e < 8*PPR_ROWS; e += 256) {
-    const int PA = e & 7, row = e >> 3;
+  // the coarse cells whose first child (I = 2 m) sits in one of this block's rows: 32 consecutive lanes take 32
+  // consecutive m of one coarse line (PA), so that the stores to the coarse level are 256 contiguous bytes
+  // (one lane per row and PA, half of them idle, scattered the stores over eight coarse lines per instruction)
+  for (int e = tid; e < 8*(PPR_ROWS/2); e += 256) {
+    const int PA = e / (PPR_ROWS/2), mi = e % (PPR_ROWS/2);
+    const int par = (PA + PB + r0) & 1;            /* rows of the block whose I = r0 + row - PA - PB is even */
+    const int row = 2*mi + par;
     const int I = r0 + row - PA - PB;
-    if (I >= 0 && I < n && !(I & 1)) {
+    if (I >= 0 && I < n) {
       const int di = I - I0;
       double val = 0.;
       // children in child-id order: bit 0 -> +x, bit 1 -> -y (da = 1), bit 2 -> -z (db = 1)
