@@ -62,6 +62,8 @@ struct FaceSet {            // the faces of one ftt_face_traverse, in its order
   double * fval = nullptr;            // device, one number per face
 };
 
+struct FlowPlan;            // tree_flow.hpp: the relax loop as a dataflow program of micro-operations
+
 struct Sweep {              // T_LEVEL_LEAFS (m) in dependency levels
   int ncells = 0, nlev = 0;
   Cell * cells = nullptr;             // device, sorted by level (stable: traversal order inside)
@@ -93,6 +95,7 @@ struct Sweep {              // T_LEVEL_LEAFS (m) in dependency levels
     std::vector<int> h_ti, h_tv, h_node_off, h_node_g, h_node_level;
     std::vector<double> h_td;
     double sg[6] = { 0., 0., 0., 0., 0., 0. };   // the homogeneous conditions compiled into the copies of the ghosts
+    FlowPlan * flow = nullptr;                   // the same loop for t_relax_flow (nullptr: not expressible)
   } loop;
   // the loops of the diffusion solves (10 nrelax sweeps on the first level, the conditions of U, V, W)
   Loop dloop[6];
@@ -390,6 +393,8 @@ __host__ __device__ inline void tape_cell (TapeCursor & c, int nd, int dim, int 
     gb += nb;
   }
 }
+
+#include "tree_flow.hpp"
 
 #define TAPE_LDS_BYTES (120*1024)
 
@@ -1532,6 +1537,7 @@ void loop_free (Sweep::Loop & P)
   (void) hipFree (P.ti); (void) hipFree (P.tv); (void) hipFree (P.td);
   (void) hipFree (P.node_off); (void) hipFree (P.node_g); (void) hipFree (P.chunk);
   (void) hipFree (P.desc); (void) hipFree (P.rec);
+  if (P.flow) { flow_free (*P.flow); delete P.flow; }
   P = Sweep::Loop ();
 }
 
@@ -1645,9 +1651,22 @@ int loop_plan (gfship_tree * tr, int m, unsigned nrelax, Sweep * S, Sweep::Loop 
     P.h_ti = ti; P.h_tv = tv; P.h_td = td; P.h_node_off = node_off; P.h_node_g = node_g;
     for (const Node & N : nodes) P.h_node_level.push_back (N.level);
   }
+  {
+    // the same loop as a flow plan (tree_flow.hpp)
+    std::vector<int> level_of (tr->ncell, 0);
+    for (int l = 0; l <= tr->H.depth; l++)
+      for (int g = tr->H.off[l]; g < tr->H.off[l + 1]; g++) level_of[g] = l;
+    P.flow = new FlowPlan;
+    if (!flow_plan (tr->ncell, tr->H.dim, S, nrelax, sg, level_of.data (), tr->H.dim == 2, P.flow, g_host_only)) {
+      flow_free (*P.flow);
+      delete P.flow;
+      P.flow = nullptr;
+    }
+  }
   if (getenv ("GFSHIP_TREE_DEBUG"))
-    fprintf (stderr, "gfship_tree: relax loop of level %d: %u sweeps, %d nodes in %d levels, %d chunks\n",
-	     m, nrelax, P.nnodes, P.nlev, P.nchunks);
+    fprintf (stderr, "gfship_tree: relax loop of level %d: %u sweeps, %d nodes in %d levels, %d chunks; flow plan: %d operations in %d levels, %d constants\n",
+	     m, nrelax, P.nnodes, P.nlev, P.nchunks, P.flow ? P.flow->nops : -1, P.flow ? P.flow->nlev : -1,
+	     P.flow ? P.flow->nct : -1);
   return 0;
 }
 
@@ -1826,6 +1845,22 @@ int relax_loop (gfship_tree * tr, int m, unsigned nrelax, double omega, int op =
     else if (S.loop.nrelax != nrelax || memcmp (S.loop.sg, sg.s, sizeof (S.loop.sg))) {
       int e = loop_plan (tr, m, nrelax, &S);
       if (e) return e;
+    }
+    static int no_flow = -1;
+    if (no_flow < 0) {
+      const char * e = getenv ("GFSHIP_TREE_NO_FLOW");          /* 1: the tape kernels (t_relax_nodes_pf) */
+      no_flow = e ? atoi (e) : 0;
+    }
+    if (P->flow && !no_flow) {
+      const FlowPlan & F = *P->flow;
+      if (tr->H.dim == 3)
+	t_relax_flow<3><<<1, FLOW_WIDTH, 0, tr->stream>>> (F.rec, F.lev_off, F.nlev, F.ct, F.nct, tr->var[V_DP],
+							   tr->var[V_RES], omega, op, w);
+      else
+	t_relax_flow<2><<<1, FLOW_WIDTH, 0, tr->stream>>> (F.rec, F.lev_off, F.nlev, F.ct, F.nct, tr->var[V_DP],
+							   tr->var[V_RES], omega, op, w);
+      KCHECK ();
+      return 0;
     }
     static int old_nodes = -1;
     if (old_nodes < 0) {
@@ -2674,9 +2709,27 @@ int gfship_tree_host_check (int dim, gfship_refine_fn refine, void * ctx, const 
 	k0 = k1;
       }
     }
+    // (4) the flow plan (tree_flow.hpp) with the kernel's timing of loads and stores
+    std::vector<double> c4 = u0;
+    if (S.loop.flow) {
+      const long long hz = flow_emulate (*S.loop.flow, T.dim, c4, rhs, omega, 0, 1.);
+      stats[3] += hz;
+      if (getenv ("GFSHIP_TREE_DEBUG")) {
+	long long nd4 = 0;
+	for (int g = 0; g < tr->ncell; g++) nd4 += memcmp (&a[g], &c4[g], sizeof (double)) != 0;
+	fprintf (stderr, "gfship_tree: flow plan of level %d: %lld hazards, %lld values differ\n", m, hz, nd4);
+	int widest = 0;
+	for (int L = 0; L < S.loop.flow->nlev; L++)
+	  widest = std::max (widest, S.loop.flow->h_lev_off[L + 1] - S.loop.flow->h_lev_off[L]);
+	fprintf (stderr, "gfship_tree: flow plan of level %d: %d levels, widest %d\n", m, S.loop.flow->nlev, widest);
+      }
+    }
+    else
+      c4 = a;
     stats[0] += (long long) order.size ()*nrelax;
     for (int g = 0; g < tr->ncell; g++)
-      if (memcmp (&a[g], &b[g], sizeof (double)) || memcmp (&a[g], &c3[g], sizeof (double)))
+      if (memcmp (&a[g], &b[g], sizeof (double)) || memcmp (&a[g], &c3[g], sizeof (double)) ||
+	  memcmp (&a[g], &c4[g], sizeof (double)))
 	stats[3]++;
   }
   tree_free (tr);
