@@ -1657,7 +1657,12 @@ int loop_plan (gfship_tree * tr, int m, unsigned nrelax, Sweep * S, Sweep::Loop 
     for (int l = 0; l <= tr->H.depth; l++)
       for (int g = tr->H.off[l]; g < tr->H.off[l + 1]; g++) level_of[g] = l;
     P.flow = new FlowPlan;
-    if (!flow_plan (tr->ncell, tr->H.dim, S, nrelax, sg, level_of.data (), tr->H.dim == 2, P.flow, g_host_only)) {
+    static int flow_width = -1;
+    if (flow_width < 0) {
+      const char * e = getenv ("GFSHIP_FLOW_WIDTH");      /* lab: operations per level (a multiple of 64 up to 512) */
+      flow_width = e ? std::min (FLOW_WIDTH, std::max (64, atoi (e)/64*64)) : FLOW_WIDTH;
+    }
+    if (!flow_plan (tr->ncell, tr->H.dim, S, nrelax, sg, level_of.data (), tr->H.dim == 2, P.flow, g_host_only, flow_width)) {
       flow_free (*P.flow);
       delete P.flow;
       P.flow = nullptr;
@@ -1853,12 +1858,12 @@ int relax_loop (gfship_tree * tr, int m, unsigned nrelax, double omega, int op =
     }
     if (P->flow && !no_flow) {
       const FlowPlan & F = *P->flow;
+      t_flow_pack<<<blocks (F.npos), 256, 0, tr->stream>>> (F.gidx, F.npos, tr->var[V_DP], tr->var[V_RES], F.up, F.rp);
       if (tr->H.dim == 3)
-	t_relax_flow<3><<<1, FLOW_WIDTH, 0, tr->stream>>> (F.rec, F.lev_off, F.nlev, F.ct, F.nct, tr->var[V_DP],
-							   tr->var[V_RES], omega, op, w);
+	t_relax_flow<3><<<1, F.width + 64, 0, tr->stream>>> (F.rec, F.lev_off, F.nlev, F.ct, F.nct, F.up, F.rp, F.npos, omega, op, w);
       else
-	t_relax_flow<2><<<1, FLOW_WIDTH, 0, tr->stream>>> (F.rec, F.lev_off, F.nlev, F.ct, F.nct, tr->var[V_DP],
-							   tr->var[V_RES], omega, op, w);
+	t_relax_flow<2><<<1, F.width + 64, 0, tr->stream>>> (F.rec, F.lev_off, F.nlev, F.ct, F.nct, F.up, F.rp, F.npos, omega, op, w);
+      t_flow_unpack<<<blocks (F.npos), 256, 0, tr->stream>>> (F.gidx, F.npos, F.up, tr->var[V_DP]);
       KCHECK ();
       return 0;
     }

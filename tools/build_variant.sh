@@ -11,7 +11,7 @@ OBJS=""
 for f in "$SRC"/*.hip; do
   b="$(basename "${f%.hip}")"
   case "$b" in
-    relax_skew|relax_skew_loop|relax_patch_loop|timestep_kernels) /opt/rocm/bin/hipcc $FLAGS -c "$f" -o "$OUT/${b}_$NAME.o" & OBJS="$OBJS $OUT/${b}_$NAME.o" ;;
+    relax_skew|relax_skew_loop|relax_patch_loop|timestep_kernels|tree) /opt/rocm/bin/hipcc $FLAGS -c "$f" -o "$OUT/${b}_$NAME.o" & OBJS="$OBJS $OUT/${b}_$NAME.o" ;;
     *) OBJS="$OBJS $OUT/$b.o" ;;
   esac
 done
