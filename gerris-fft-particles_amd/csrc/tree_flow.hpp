@@ -79,7 +79,7 @@ template <int DIM> struct FlowShape {
   static constexpr int NIN = DIM == 3 ? 9 : 5;           /* inputs a record of this dimension uses */
 };
 
-struct FlowPair { double x, y; };
+struct __attribute__((aligned(16))) FlowPair { double x, y; };
 
 // one micro-operation, arithmetic only.  x[j]: the input j (a value from global memory or the result of an
 // operation of the previous level), y[j]: the second number of the pair when input j is a pair; rh: the
@@ -264,10 +264,15 @@ struct FlowAnyDev {
   __device__ inline bool operator() (bool b) const { return __any (b); }
 };
 
+// One level of one wavefront: the inputs from the LDS, the arithmetic.  A wavefront of one kind reads only
+// what that kind can use (FC / CHILD: nine values; CELL: the values and the pairs of its faces; SUM: pairs) --
+// the reads of the LDS are a third of the time of a level when every lane reads ten pairs.
 template <int DIM>
-__device__ inline FlowPair flow_eval_wave (unsigned w0, const double * x, const double * y, double rh,
+__device__ inline FlowPair flow_eval_wave (const FlowRec & r, const double * v, const FlowPair * lo,
 					   const double * ct, double omega, int op, double w)
 {
+  constexpr int NIN = FlowShape<DIM>::NIN;
+  const unsigned w0 = r.w0;
   const int kind = flow_class (w0 & 7);
   const unsigned long long busy = __ballot (kind != F_NOP);
   FlowPair o = { 0., 0. };
@@ -275,12 +280,38 @@ __device__ inline FlowPair flow_eval_wave (unsigned w0, const double * x, const 
     return o;
   const int first = __builtin_amdgcn_readlane (kind, __ffsll ((long long) busy) - 1);
   const FlowAnyDev any;
-  if (__ballot (kind != F_NOP && kind != first) != 0ull)
-    return flow_eval<DIM> (w0, x, y, rh, ct, omega, op, w);
-  if (first == F_CELL) return flow_eval_uniform<DIM, F_CELL> (w0, x, y, rh, ct, omega, op, w, any);
-  if (first == F_FC) return flow_eval_uniform<DIM, F_FC> (w0, x, y, rh, ct, omega, op, w, any);
-  if (first == F_SUM) return flow_eval_uniform<DIM, F_SUM> (w0, x, y, rh, ct, omega, op, w, any);
-  return flow_eval_uniform<DIM, F_GHOST> (w0, x, y, rh, ct, omega, op, w, any);
+  double x[NIN], y[NIN];
+#define FLOW_X(j) { const double px = *(const double *) ((const char *) lo + FLOW_LDS_ADDR (r.in[j])); \
+    x[j] = FLOW_IS_LDS (r.in[j]) ? px : v[j]; y[j] = 0.; }
+#define FLOW_XY(j) { const FlowPair p = *(const FlowPair *) ((const char *) lo + FLOW_LDS_ADDR (r.in[j])); \
+    x[j] = FLOW_IS_LDS (r.in[j]) ? p.x : v[j]; y[j] = p.y; }
+  if (__ballot (kind != F_NOP && kind != first) != 0ull) {
+#pragma unroll
+    for (int j = 0; j < NIN; j++) FLOW_XY (j)
+    return flow_eval<DIM> (w0, x, y, v[FLOW_NIN], ct, omega, op, w);
+  }
+#pragma unroll
+  for (int j = 0; j < NIN; j++) { x[j] = 0.; y[j] = 0.; }
+  if (first == F_CELL) {
+    if (DIM == 2) FLOW_X (0)
+#pragma unroll
+    for (int j = 1; j <= 2*DIM; j++) FLOW_XY (j)
+    return flow_eval_uniform<DIM, F_CELL> (w0, x, y, v[FLOW_NIN], ct, omega, op, w, any);
+  }
+  if (first == F_FC) {
+#pragma unroll
+    for (int j = 0; j < 1 + (DIM - 1)*FlowShape<DIM>::TS; j++) FLOW_X (j)
+    return flow_eval_uniform<DIM, F_FC> (w0, x, y, v[FLOW_NIN], ct, omega, op, w, any);
+  }
+  if (first == F_SUM) {
+#pragma unroll
+    for (int j = 0; j < (DIM == 3 ? 4 : 2); j++) FLOW_XY (j)
+    return flow_eval_uniform<DIM, F_SUM> (w0, x, y, v[FLOW_NIN], ct, omega, op, w, any);
+  }
+  FLOW_X (0)
+  return flow_eval_uniform<DIM, F_GHOST> (w0, x, y, v[FLOW_NIN], ct, omega, op, w, any);
+#undef FLOW_X
+#undef FLOW_XY
 }
 
 // The loads of the kernel are unconditional (an idle thread loads the last record of the level and turns it
@@ -298,7 +329,8 @@ __device__ inline FlowRec flow_load_rec (const FlowRec * rec, const int * loff, 
   typedef int int3v __attribute__((ext_vector_type(3)));
   const int a = loff[L], b = loff[L + 1];      /* from the LDS: from global memory the load of the record would wait for this one */
   const bool valid = a + tid < b;
-  const int * q = (const int *) (rec + (valid ? a + tid : b - 1));
+  const int * q = (const int *) (rec + a + tid);      /* an idle lane reads on (the array ends with spare records): every
+							 lane at the same address is the slowest access there is */
   FlowRec r;
   const int4v q0 = *(const int4v *) q;
   r.w0 = valid ? (unsigned) q0.x : (unsigned) F_NOP;
@@ -322,12 +354,13 @@ __device__ inline FlowRec flow_load_rec (const FlowRec * rec, const int * loff, 
 }
 
 template <int DIM>
-__device__ inline void flow_prefetch (const FlowRec & r, const double * u, const double * rhs, double * v)
+__device__ inline void flow_prefetch (const FlowRec & r, const double * u, const double * rhs, double * v, int idle)
 {
+  /* idle: 8 tid -- an input that is not in global memory loads a place of its own (the copies have 576 at least) */
 #pragma unroll
   for (int j = 0; j < FlowShape<DIM>::NIN; j++)
-    v[j] = *(const double *) ((const char *) u + (unsigned) max (r.in[j], 0));
-  v[FLOW_NIN] = *(const double *) ((const char *) rhs + (unsigned) max (r.out_g, 0));
+    v[j] = *(const double *) ((const char *) u + (unsigned) (r.in[j] < 0 ? idle : r.in[j]));
+  v[FLOW_NIN] = *(const double *) ((const char *) rhs + (unsigned) (r.out_g < 0 ? idle : r.out_g));
 }
 
 // the whole relax loop: one workgroup, one operation per thread and level
@@ -396,43 +429,96 @@ t_relax_flow (const FlowRec * __restrict__ rec, const int * __restrict__ lev_off
   FlowRec r2 = flow_load_rec<DIM> (rec, loff, 2, tid);
   FlowRec r3;
   double v0[FLOW_NIN + 1], v1[FLOW_NIN + 1];
-  flow_prefetch<DIM> (r0, u, rhs, v0);
-  flow_prefetch<DIM> (r1, u, rhs, v1);      /* (loaded again in level 0; keeps v1 defined for the lab switches) */
+  flow_prefetch<DIM> (r0, u, rhs, v0, 8*tid);
+  flow_prefetch<DIM> (r1, u, rhs, v1, 8*tid);      /* (loaded again in level 0; keeps v1 defined for the lab switches) */
   __syncthreads ();
-  // FLOW_LAB (lab only, wrong results): 1 no arithmetic, 2 no loads of old values, 4 no loads of records,
-  // 8 no reads of the LDS -- what each part of a level costs
+  // FLOW_LAB (lab only): 1 no arithmetic, 2 no loads of old values, 4 no loads of records (wrong results);
+  // 32 the times of the parts of eight levels printed (s_memtime); 64 every wavefront in the same order
 #ifndef FLOW_LAB
 #define FLOW_LAB 0
 #endif
-#define FLOW_STEP(L, R0, R1, R3, V0, V1) {				\
-    if (!(FLOW_LAB & 2)) flow_prefetch<DIM> (R1, u, rhs, V1);		\
-    if (!(FLOW_LAB & 4)) R3 = flow_load_rec<DIM> (rec, loff, (L) + 3, tid); else R3 = R0; \
-    double x[NIN], y[NIN];						\
-    _Pragma ("unroll")							\
-    for (int j = 0; j < NIN; j++) {					\
-      FlowPair p = { 0., 0. };						\
-      if (!(FLOW_LAB & 8)) p = *(const FlowPair *) ((const char *) lo + FLOW_LDS_ADDR (R0.in[j])); \
-      x[j] = FLOW_IS_LDS (R0.in[j]) ? p.x : V0[j];			\
-      y[j] = p.y;							\
-    }									\
-    FlowPair o = { x[0] + x[1], y[0] };					\
-    if (!(FLOW_LAB & 1)) o = flow_eval_wave<DIM> (R0.w0, x, y, V0[FLOW_NIN], ct, omega, op, w); \
+#if FLOW_LAB & 32
+#define FLOW_TS(L, k) if ((tid & 63) == 0 && (L) >= 300 && (L) < 308)	\
+    tstamp[tid >> 6][(L) - 300][k] = __builtin_amdgcn_s_memtime ();
+#else
+#define FLOW_TS(L, k)
+#endif
+#define FLOW_LOADS(L, R0, R1, R3, V1)					\
+    if (!(FLOW_LAB & 2)) flow_prefetch<DIM> (R1, u, rhs, V1, 8*tid);	\
+    if (!(FLOW_LAB & 4)) R3 = flow_load_rec<DIM> (rec, loff, (L) + 3, tid); else R3 = R0;
+#define FLOW_COMPUTE(L, R0, V0) {					\
+    FLOW_TS (L, 2)							\
+    FlowPair o = { V0[0] + V0[1], V0[2] };				\
+    if (!(FLOW_LAB & 1)) o = flow_eval_wave<DIM> (R0, V0, lo, ct, omega, op, w); \
+    if ((FLOW_LAB & 32) && o.x == 1.2345e-300) ct[FLOW_NCONST - 4] = o.x; \
+    FLOW_TS (L, 3)							\
     lo[buf*width + tid] = o;						\
     lout[buf*width + tid] = R0.out_g;					\
     buf = buf == FLOW_NBUF - 1 ? 0 : buf + 1;				\
+  }
+  // Two orders of a level.  Every wavefront of a level wants the vector memory pipeline, then the LDS, then
+  // the vector ALU, and the barrier keeps them in step: three units, one busy at a time (measured with
+  // s_memtime, FLOW_LAB=32: 900 cycles to issue the 14 loads of a level, 850 for the reads of the LDS, 950 to
+  // 1900 of arithmetic, the rest waiting for the slowest).  So the odd wavefronts issue their loads AFTER
+  // their arithmetic (their old values then have the barrier and the next level's LDS reads to arrive):
+  // they compute while the even ones load, and the other way round.
+#define FLOW_STEP_A(L, R0, R1, R3, V0, V1) {				\
+    FLOW_TS (L, 0)							\
+    FLOW_LOADS (L, R0, R1, R3, V1)					\
+    FLOW_TS (L, 1)							\
+    FLOW_COMPUTE (L, R0, V0)						\
     __syncthreads ();							\
+    FLOW_TS (L, 4)							\
+  }
+#define FLOW_STEP_B(L, R0, R1, R3, V0, V1) {				\
+    FLOW_TS (L, 0)							\
+    FLOW_TS (L, 1)							\
+    FLOW_COMPUTE (L, R0, V0)						\
+    FLOW_LOADS (L, R0, R1, R3, V1)					\
+    __syncthreads ();							\
+    FLOW_TS (L, 4)							\
   }
   int buf = 0;
-  for (int L = 0; L < nlev; L += 4) {
-    FLOW_STEP (L, r0, r1, r3, v0, v1);
-    if (L + 1 >= nlev) break;
-    FLOW_STEP (L + 1, r1, r2, r0, v1, v0);
-    if (L + 2 >= nlev) break;
-    FLOW_STEP (L + 2, r2, r3, r1, v0, v1);
-    if (L + 3 >= nlev) break;
-    FLOW_STEP (L + 3, r3, r0, r2, v1, v0);
+#if FLOW_LAB & 32
+  __shared__ unsigned long long tstamp[8][8][5];
+#endif
+  if ((tid >> 6) & 1 & !(FLOW_LAB & 64)) {
+    for (int L = 0; L < nlev; L += 4) {
+      FLOW_STEP_B (L, r0, r1, r3, v0, v1);
+      if (L + 1 >= nlev) break;
+      FLOW_STEP_B (L + 1, r1, r2, r0, v1, v0);
+      if (L + 2 >= nlev) break;
+      FLOW_STEP_B (L + 2, r2, r3, r1, v0, v1);
+      if (L + 3 >= nlev) break;
+      FLOW_STEP_B (L + 3, r3, r0, r2, v1, v0);
+    }
   }
-#undef FLOW_STEP
+  else {
+    for (int L = 0; L < nlev; L += 4) {
+      FLOW_STEP_A (L, r0, r1, r3, v0, v1);
+      if (L + 1 >= nlev) break;
+      FLOW_STEP_A (L + 1, r1, r2, r0, v1, v0);
+      if (L + 2 >= nlev) break;
+      FLOW_STEP_A (L + 2, r2, r3, r1, v0, v1);
+      if (L + 3 >= nlev) break;
+      FLOW_STEP_A (L + 3, r3, r0, r2, v1, v0);
+    }
+  }
+#undef FLOW_STEP_A
+#undef FLOW_STEP_B
+#undef FLOW_LOADS
+#undef FLOW_COMPUTE
+#if FLOW_LAB & 32
+  __syncthreads ();
+  if (tid == 0 && nlev > 320)
+    for (int wv = 0; wv < width/64; wv++)
+      for (int q = 0; q < 8; q++) {
+	const unsigned long long * t = tstamp[wv][q];
+	printf ("flow lab: wave %d level %d kind %d: issue %llu gather %llu eval %llu barrier %llu | next start +%llu\n", wv, 300 + q,
+		(int) (rec[loff[300 + q] + min (wv*64, loff[301 + q] - loff[300 + q] - 1)].w0 & 7),
+		t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], q < 7 ? tstamp[wv][q + 1][0] - t[4] : 0ull);
+      }
+#endif
 }
 
 // into / out of the order of the plan
@@ -713,6 +799,7 @@ inline bool flow_plan (int ncell, int dim, const Sweep * S, unsigned nrelax, con
     }
     if (gidx.empty ()) gidx.push_back (0);
     F.npos = (int) gidx.size ();
+    while (gidx.size () < FLOW_WIDTH + 64) gidx.push_back (gidx[0]);      /* spare places the idle lanes load (not unpacked) */
   }
   F.nlev = (int) B.lev.size ();
   std::vector<FlowRec> rec;
@@ -726,6 +813,7 @@ inline bool flow_plan (int ncell, int dim, const Sweep * S, unsigned nrelax, con
     rec.push_back (FlowBuilder::blank (F_NOP));
     off.push_back ((int) rec.size ());
   }
+  for (int k = 0; k < FLOW_WIDTH; k++) rec.push_back (FlowBuilder::blank (F_NOP));      /* what the idle lanes read */
   F.nct = (int) B.ct.size ();
   if (host_only) { F.h_rec = rec; F.h_lev_off = off; F.h_ct = B.ct; return true; }
   const std::vector<int> gidx = F.h_gidx;
