@@ -610,24 +610,51 @@ __device__ inline void atomic_min_pos (double * addr, double v)
   atomicMin ((unsigned long long *) addr, (unsigned long long) __double_as_longlong (v));
 }
 
+// the sum / maximum / minimum of a wavefront in lane 0 (every lane of the wavefront calls these): one atomic
+// per wavefront and number instead of one per cell -- 40 000 atomics on four addresses were the time of
+// t_residual (80 us)
+__device__ inline double wave_sum (double v)
+{
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down (v, o);
+  return v;
+}
+__device__ inline double wave_max (double v)
+{
+  for (int o = 32; o > 0; o >>= 1) {      /* a NaN wins, as it does in atomic_max_pos (its bits are the largest) */
+    const double b = __shfl_down (v, o);
+    v = (v > b || v != v) ? v : b;
+  }
+  return v;
+}
+__device__ inline double wave_min (double v)
+{
+  for (int o = 32; o > 0; o >>= 1) v = fmin (v, __shfl_down (v, o));
+  return v;
+}
+
 // gfs_residual on the leaves + add_norm_residual (src/domain.c:2239-2246): the maximum is exact, the
 // sums are accumulated in no particular order (reported, never branched on)
 __global__ void t_residual (Topo T, const Cell * cells, int n, const double * u, const double * rhs,
 			    double * res, double * red)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const Cell c = cells[t];
-  DevReader R = { u };
-  const int g = T.gi (c);
-  const double r = residual_cell (T, c, R, rhs[g]);
-  res[g] = r;
-  const double size = T.size (c);
-  const double val = r/(1.*size*size);
-  atomic_max_pos (&red[0], fabs (val));
-  atomicAdd (&red[1], r);
-  atomicAdd (&red[2], fabs (val));
-  atomicAdd (&red[3], val*val);
+  double r = 0., val = 0.;
+  if (t < n) {
+    const Cell c = cells[t];
+    DevReader R = { u };
+    const int g = T.gi (c);
+    r = residual_cell (T, c, R, rhs[g]);
+    res[g] = r;
+    const double size = T.size (c);
+    val = r/(1.*size*size);
+  }
+  const double m = wave_max (fabs (val)), s1 = wave_sum (r), s2 = wave_sum (fabs (val)), s3 = wave_sum (val*val);
+  if ((threadIdx.x & 63) == 0) {
+    atomic_max_pos (&red[0], m);
+    atomicAdd (&red[1], s1);
+    atomicAdd (&red[2], s2);
+    atomicAdd (&red[3], s3);
+  }
 }
 
 __global__ void t_correct (Topo T, const Cell * cells, int n, double * u, const double * dp)
@@ -655,19 +682,25 @@ __global__ void t_diffusion_residual (Topo T, const Cell * cells, int n, const d
 				      double * res, double w, double * red)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const Cell c = cells[t];
-  DevReader R = { u };
-  const int g = T.gi (c);
-  const double r = diffusion_residual_cell (T, c, R, rhs[g], w);
-  res[g] = r;
-  const double size = T.size (c);
-  const double vol = T.dim == 3 ? size*size*size : size*size;
-  atomic_max_pos (&red[0], fabs (r));
-  atomicAdd (&red[1], vol*r);
-  atomicAdd (&red[2], vol*fabs (r));
-  atomicAdd (&red[3], vol*r*r);
-  atomicAdd (&red[4], vol);
+  double r = 0., vol = 0.;
+  if (t < n) {
+    const Cell c = cells[t];
+    DevReader R = { u };
+    const int g = T.gi (c);
+    r = diffusion_residual_cell (T, c, R, rhs[g], w);
+    res[g] = r;
+    const double size = T.size (c);
+    vol = T.dim == 3 ? size*size*size : size*size;
+  }
+  const double m = wave_max (fabs (r)), s1 = wave_sum (vol*r), s2 = wave_sum (vol*fabs (r)), s3 = wave_sum (vol*r*r),
+    s4 = wave_sum (vol);
+  if ((threadIdx.x & 63) == 0) {
+    atomic_max_pos (&red[0], m);
+    atomicAdd (&red[1], s1);
+    atomicAdd (&red[2], s2);
+    atomicAdd (&red[3], s3);
+    atomicAdd (&red[4], s4);
+  }
 }
 
 __global__ void t_copy_leaves (Topo T, const Cell * cells, int n, const double * src, double * dst)
@@ -1044,26 +1077,33 @@ __global__ void t_divergence_centered (Topo T, const Cell * cells, int n, P3 u, 
 __global__ void t_cfl_faces (Topo T, const FaceRec * faces, int n, P6 un, double * red)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const double u = un.p[faces[t].d][T.gi (faces[t].cell)];
-  if (u != 0.) {
-    const double cflu = T.size (faces[t].cell)/fabs (u);
-    atomic_min_pos (red, cflu*cflu);
+  double best = DBL_MAX;
+  if (t < n) {
+    const double u = un.p[faces[t].d][T.gi (faces[t].cell)];
+    if (u != 0.) {
+      const double cflu = T.size (faces[t].cell)/fabs (u);
+      best = cflu*cflu;
+    }
   }
+  best = wave_min (best);
+  if ((threadIdx.x & 63) == 0 && best != DBL_MAX)
+    atomic_min_pos (red, best);
 }
 
 struct D3 { double d[3]; };
 __global__ void t_cfl_cells (Topo T, const Cell * cells, int n, P3 u, double * red, D3 visc, D3 src)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
-  if (t >= n) return;
+  double best = DBL_MAX;
+  const bool in = t < n;
+  if (!in) t = 0;
   const int g = T.gi (cells[t]);
   const double length = T.size (cells[t]);
   for (int c = 0; c < T.dim; c++) {
     const double fm = 1.;
-    if (u.p[c][g] != 0.) {
+    if (in && u.p[c][g] != 0.) {
       const double cflu = length/fabs (fm*u.p[c][g]);
-      atomic_min_pos (red, cflu*cflu);
+      best = fmin (best, cflu*cflu);
     }
     if (visc.d[c] != 0. || src.d[c] != 0.) {      /* p->v[c]->sources: the acceleration scale, src/domain.c:2882-2891 */
       DevReader R = { u.p[c] };
@@ -1072,12 +1112,15 @@ __global__ void t_cfl_cells (Topo T, const Cell * cells, int n, P3 u, double * r
 	gs += source_diffusion_value (T, cells[t], R, visc.d[c]);
       if (src.d[c] != 0.)
 	gs += src.d[c];
-      if (gs != 0.) {
+      if (in && gs != 0.) {
 	const double cflg = 2.*length/fabs (fm*gs);
-	atomic_min_pos (red, cflg);
+	best = fmin (best, cflg);
       }
     }
   }
+  best = wave_min (best);
+  if ((threadIdx.x & 63) == 0 && best != DBL_MAX)
+    atomic_min_pos (red, best);
 }
 
 inline int blocks (int n) { return (n + 255)/256; }

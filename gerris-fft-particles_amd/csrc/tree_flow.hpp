@@ -765,9 +765,31 @@ inline bool flow_plan (int ncell, int dim, const Sweep * S, unsigned nrelax, con
       for (size_t i = 0; i < idx.size (); i++) idx[i] = (int) i;
       std::stable_sort (idx.begin (), idx.end (), [&] (int a, int b) {
 	  return order_of[ops[a].w0 & 7] < order_of[ops[b].w0 & 7]; });
+      // where the level has room, a kind starts at a multiple of 64: a wavefront with two kinds runs the
+      // branchy arithmetic, twice the time of the others, and the level waits for it.  CELL | FC, CHILD |
+      // SUM, GHOST (the last two are short and share)
+      int count[3] = { 0, 0, 0 };
+      for (const FlowRec & r : ops) count[std::min (order_of[r.w0 & 7], 2)]++;
+      int base[3] = { 0, count[0], count[0] + count[1] };
+      {
+	const int b1 = (count[0] + 63)/64*64, b2a = (b1 + count[1] + 63)/64*64, b2b = (count[0] + count[1] + 63)/64*64;
+	if (count[1] + count[2] > 0 && b1 + count[1] + count[2] <= width) {
+	  base[1] = b1;
+	  base[2] = count[2] > 0 && b2a + count[2] <= width ? b2a : b1 + count[1];
+	}
+	else if (count[2] > 0 && b2b + count[2] <= width)
+	  base[2] = b2b;
+      }
+      const int total = std::max (base[2] + count[2], std::max (base[1] + count[1], count[0]));
       place[L - 1].resize (ops.size ());
-      std::vector<FlowRec> sorted (ops.size ());
-      for (size_t i = 0; i < idx.size (); i++) { sorted[i] = ops[idx[i]]; place[L - 1][idx[i]] = (int) i; }
+      std::vector<FlowRec> sorted (total, FlowBuilder::blank (F_NOP));
+      int rank[3] = { 0, 0, 0 };
+      for (size_t i = 0; i < idx.size (); i++) {
+	const int k = std::min (order_of[ops[idx[i]].w0 & 7], 2);
+	const int at = base[k] + rank[k]++;
+	sorted[at] = ops[idx[i]];
+	place[L - 1][idx[i]] = at;
+      }
       ops.swap (sorted);
     }
     for (int L = 1; L <= nl; L++)
@@ -887,24 +909,25 @@ inline long long flow_emulate (const FlowPlan & F, int dim, std::vector<double> 
       }
       // the wavefront of this operation: the 64 operations around it (flow_eval_wave)
       const int w0i = F.h_lev_off[L] + (i - F.h_lev_off[L])/64*64, w1i = std::min (w0i + 64, F.h_lev_off[L + 1]);
-      const int first = flow_class (F.h_rec[w0i].w0 & 7);
+      int first = F_NOP;      /* the kind of the first operation that is not a NOP, as flow_eval_wave takes it */
+      for (int q = w0i; q < w1i && first == F_NOP; q++) first = flow_class (F.h_rec[q].w0 & 7);
       bool uniform = true, any3 = false;
       for (int q = w0i; q < w1i; q++) {
 	const unsigned qw = F.h_rec[q].w0;
-	if (flow_class (qw & 7) != first) uniform = false;
+	if (flow_class (qw & 7) != first && flow_class (qw & 7) != F_NOP) uniform = false;
 	if (flow_class (qw & 7) == F_FC)
 	  for (int t = 0; t < dim - 1; t++)
 	    if (t < (int) ((qw >> 3) & 3) && ((qw >> (5 + 3*t)) & 7) == 3) any3 = true;
       }
       struct AnyHost { bool v; bool operator() (bool) const { return v; } } any = { any3 };
-      FlowPair o;
+      FlowPair o = { 0., 0. };
 #define FLOW_EMU(D)							\
       o = !uniform ? flow_eval<D> (r.w0, x, y, vi[FLOW_NIN], F.h_ct.data (), omega, op, w) : \
 	first == F_CELL ? flow_eval_uniform<D, F_CELL> (r.w0, x, y, vi[FLOW_NIN], F.h_ct.data (), omega, op, w, any) : \
 	first == F_FC ? flow_eval_uniform<D, F_FC> (r.w0, x, y, vi[FLOW_NIN], F.h_ct.data (), omega, op, w, any) : \
 	first == F_SUM ? flow_eval_uniform<D, F_SUM> (r.w0, x, y, vi[FLOW_NIN], F.h_ct.data (), omega, op, w, any) : \
 	flow_eval_uniform<D, F_GHOST> (r.w0, x, y, vi[FLOW_NIN], F.h_ct.data (), omega, op, w, any)
-      if (dim == 3) { FLOW_EMU (3); } else { FLOW_EMU (2); }
+      if ((r.w0 & 7) != F_NOP) { if (dim == 3) { FLOW_EMU (3); } else { FLOW_EMU (2); } }
 #undef FLOW_EMU
       cur[i - F.h_lev_off[L]] = o;
       if (r.out_g >= 0) stores.push_back ({ r.out_g/8, o.x });
