@@ -24,6 +24,7 @@
 #include "gfship_internal.hpp"
 #include "tree.hpp"
 #include <algorithm>
+#include <array>
 #include <cfloat>
 #include <cmath>
 #include <cstring>

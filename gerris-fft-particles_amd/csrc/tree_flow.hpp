@@ -621,6 +621,8 @@ struct FlowBuilder {
   int width = FLOW_WIDTH;
   std::vector<int> wlev, wop, rlev;                 /* per cell: level and operation of its last write; last read */
   std::vector<std::vector<FlowRec>> lev;            /* lev[L - 1]: the operations of level L */
+  std::vector<std::array<int, 3>> cls;              /* of which CELL | FC, CHILD | SUM, GHOST */
+  bool padded = true;                               /* a level has room for every kind to start at a multiple of 64 */
   std::vector<double> ct;
   bool ok = true;
 
@@ -634,7 +636,16 @@ struct FlowBuilder {
   }
   int slot (int L, int i) const { return ((L - 1) % FLOW_NBUF)*width + i; }   /* result i of level L */
   int fill (int L) const { return L >= 1 && L <= (int) lev.size () ? (int) lev[L - 1].size () : 0; }
-  void need (int L) { if ((int) lev.size () < L) lev.resize (L); }
+  void need (int L) { if ((int) lev.size () < L) { lev.resize (L); cls.resize (L, std::array<int, 3> { { 0, 0, 0 } }); } }
+  static int class_of (int kind) { return kind == F_CELL ? 0 : kind == F_FC || kind == F_CHILD ? 1 : 2; }
+  // room on level L for a0 / a1 / a2 more operations of the three classes
+  bool room (int L, int a0, int a1, int a2) const
+  {
+    int c0 = a0, c1 = a1, c2 = a2;
+    if (L >= 1 && L <= (int) cls.size ()) { c0 += cls[L - 1][0]; c1 += cls[L - 1][1]; c2 += cls[L - 1][2]; }
+    if (!padded) return c0 + c1 + c2 <= width;
+    return (c0 + 63)/64*64 + (c1 + 63)/64*64 + c2 <= width;
+  }
   int ready (const FlowItem & it) const           /* first level an FC / CHILD may run at */
   {
     int L = wlev[it.g];
@@ -649,7 +660,13 @@ struct FlowBuilder {
     /* level 0: the values before the loop; a value at most FLOW_PD + 1 levels old is still in the LDS */
     return wlev[g] > 0 && L - wlev[g] <= FLOW_PD + 1 ? FLOW_LDS_REF (slot (wlev[g], wop[g])) : 8*g;
   }
-  int emit (int L, const FlowRec & r) { need (L); lev[L - 1].push_back (r); return (int) lev[L - 1].size () - 1; }
+  int emit (int L, const FlowRec & r)
+  {
+    need (L);
+    lev[L - 1].push_back (r);
+    cls[L - 1][class_of (r.w0 & 7)]++;
+    return (int) lev[L - 1].size () - 1;
+  }
   static FlowRec blank (int kind)
   {
     FlowRec r;
@@ -675,7 +692,7 @@ struct FlowBuilder {
   void ghost (int g, int img, double s)
   {
     int L = std::max (wlev[img], std::max (rlev[g], wlev[g])) + 1;
-    while (fill (L) >= width) L++;
+    while (!room (L, 0, 0, 1)) L++;
     FlowRec r = blank (F_GHOST);
     r.w0 |= (unsigned) constant (s) << 11;
     r.out_g = 8*g;
@@ -686,19 +703,19 @@ struct FlowBuilder {
   void cell (int g, int self, const FlowFace * f, int cell_level, bool reads_self)
   {
     int L = std::max (rlev[g], wlev[g]) + 1;
-    int n1 = 0, n2 = 0;      /* operations one and two levels before the cell's */
+    int nfc = 0, nsum = 0, n2 = 0;      /* FC and SUM one level before the cell's, CHILD two levels before */
     if (reads_self) L = std::max (L, wlev[self] + 1);
     for (int d = 0; d < 2*dim; d++) {
       const FlowFace & F = f[d];
       if (F.kind == K_SAME) L = std::max (L, wlev[F.g] + 1);
-      else if (F.kind == K_FC) { L = std::max (L, ready (F.fc) + 1); n1++; }
+      else if (F.kind == K_FC) { L = std::max (L, ready (F.fc) + 1); nfc++; }
       else if (F.kind == K_DEEP) {
 	for (int i = 0; i < F.nch; i++) { L = std::max (L, ready (F.ch[i]) + 2); n2++; }
-	n1++;
+	nsum++;
       }
     }
-    if (n2) L = std::max (L, 3); else if (n1) L = std::max (L, 2);
-    while (fill (L) + 1 > width || (n1 && fill (L - 1) + n1 > width) || (n2 && fill (L - 2) + n2 > width))
+    if (n2) L = std::max (L, 3); else if (nfc + nsum) L = std::max (L, 2);
+    while (!room (L, 1, 0, 0) || ((nfc || nsum) && !room (L - 1, 0, nfc, nsum)) || (n2 && !room (L - 2, 0, n2, 0)))
       L++;
     FlowRec r = blank (F_CELL);
     r.w0 |= (unsigned) cell_level << 15;
@@ -752,6 +769,7 @@ inline bool flow_plan (int ncell, int dim, const Sweep * S, unsigned nrelax, con
       B.cell (S->h_g[c], selfs[c], &faces[6*c], cell_level_of[S->h_g[c]], reads_self);
   }
   if (!B.ok || (int) B.lev.size () > FLOW_MAXLEV) return false;
+  int nmixed_out = 0;
   {
     // the operations of a level sorted by kind (stable); the inputs that name an operation of the level by its
     // place follow.  An input of level L in buffer b was produced by the level L' in [L - FLOW_PD - 1, L - 1]
@@ -759,6 +777,7 @@ inline bool flow_plan (int ncell, int dim, const Sweep * S, unsigned nrelax, con
     static const int order_of[8] = { 0, 1, 1, 2, 3, 4, 4, 4 };       /* CELL, FC / CHILD, SUM, GHOST */
     const int nl = (int) B.lev.size ();
     std::vector<std::vector<int>> place (nl);      /* place[L - 1][old] = new */
+    int nmixed = 0;      /* levels where CELL and FC / CHILD (or CELL and the short kinds) share a wavefront */
     for (int L = 1; L <= nl; L++) {
       std::vector<FlowRec> & ops = B.lev[L - 1];
       std::vector<int> idx (ops.size ());
@@ -781,6 +800,7 @@ inline bool flow_plan (int ncell, int dim, const Sweep * S, unsigned nrelax, con
 	  base[2] = b2b;
       }
       const int total = std::max (base[2] + count[2], std::max (base[1] + count[1], count[0]));
+      if ((count[1] > 0 && base[1] % 64) || (count[2] > 0 && count[0] + count[1] > 0 && base[2] % 64 && count[1] == 0)) nmixed++;
       place[L - 1].resize (ops.size ());
       std::vector<FlowRec> sorted (total, FlowBuilder::blank (F_NOP));
       int rank[3] = { 0, 0, 0 };
@@ -803,9 +823,11 @@ inline bool flow_plan (int ncell, int dim, const Sweep * S, unsigned nrelax, con
 	    if (Lp < 0 || i >= (int) place[Lp - 1].size ()) return false;
 	    r.in[j] = FLOW_LDS_REF (b*width + place[Lp - 1][i]);
 	  }
+    nmixed_out = nmixed;
   }
   FlowPlan & F = *out;
   F.width = width;
+  if (getenv ("GFSHIP_TREE_DEBUG")) fprintf (stderr, "gfship_tree: flow plan: %d of %zu levels have a wavefront with two kinds\n", nmixed_out, B.lev.size ());
   {
     // places in the order of the plan
     std::vector<int> pos (ncell, -1);
