@@ -692,7 +692,7 @@ struct FlowBuilder {
   void ghost (int g, int img, double s)
   {
     int L = std::max (wlev[img], std::max (rlev[g], wlev[g])) + 1;
-    while (!room (L, 0, 0, 1)) L++;
+    for (int tries = 0; !room (L, 0, 0, 1); L++) if (++tries > 1000000) { ok = false; return; }
     FlowRec r = blank (F_GHOST);
     r.w0 |= (unsigned) constant (s) << 11;
     r.out_g = 8*g;
@@ -715,8 +715,8 @@ struct FlowBuilder {
       }
     }
     if (n2) L = std::max (L, 3); else if (nfc + nsum) L = std::max (L, 2);
-    while (!room (L, 1, 0, 0) || ((nfc || nsum) && !room (L - 1, 0, nfc, nsum)) || (n2 && !room (L - 2, 0, n2, 0)))
-      L++;
+    for (int tries = 0; !room (L, 1, 0, 0) || ((nfc || nsum) && !room (L - 1, 0, nfc, nsum)) || (n2 && !room (L - 2, 0, n2, 0)); L++)
+      if (++tries > 1000000) { ok = false; return; }
     FlowRec r = blank (F_CELL);
     r.w0 |= (unsigned) cell_level << 15;
     r.out_g = 8*g;
@@ -755,6 +755,7 @@ inline bool flow_plan (int ncell, int dim, const Sweep * S, unsigned nrelax, con
   FlowBuilder B;
   B.dim = dim;
   B.width = width;
+  B.padded = width >= 256;      /* narrower plans (lab) pack the kinds: three kinds at multiples of 64 need the room */
   B.wlev.assign (ncell, 0); B.wop.assign (ncell, 0); B.rlev.assign (ncell, 0);
   const size_t nc = S->h_g.size ();
   std::vector<FlowFace> faces (nc*6);
