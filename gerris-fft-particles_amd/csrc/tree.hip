@@ -13,7 +13,10 @@
 //    order (src/poisson.c:604-632): the host derives, from the very stencil code the kernels run
 //    (tree.hpp with a recording reader), which cells each cell reads, and groups the cells of the
 //    sweep into dependency levels; one workgroup then runs a whole relax loop (nrelax sweeps with
-//    the periodic copies between them, src/poisson.c:1070-1089), level after level, barrier between.
+//    the periodic copies between them, src/poisson.c:1070-1089), level after level, barrier between
+//    -- by default as a dataflow program of fixed-format micro-operations (tree_flow.hpp, t_relax_flow),
+//    else from the tapes of the compiled stencils (t_relax_nodes_pf, t_relax_tape) or by the code that
+//    walks the tree (t_relax_loop).
 // The 2-D refined cases are small (10^4 - 10^5 cells): this path is about the reference's results on
 // a tree, not about bandwidth; the uniform 3-D path of the other files is the one that is benchmarked.
 //
