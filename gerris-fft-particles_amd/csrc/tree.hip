@@ -326,11 +326,19 @@ t_relax_loop (Topo T, const Cell * cells, const int * lev_off, int nlev, const G
 // thread), then evaluates them from LDS: same operations in the same order as the template code.
 enum { K_NONE = 0, K_SAME = 1, K_FC = 2, K_DEEP = 3, K_GHOST = 4 };
 
-struct TapeCursor { const int * ti; const double * td; const double * tv; };
+struct TapeCursor {          // the streams of a cell, the values gathered beforehand (LDS / host)
+  const int * ti; const double * td; const double * tv;
+  __host__ __device__ inline double val () { return *tv++; }
+};
+struct TapeCursorG {         // the same with the values read through the stream of cells (global memory)
+  const int * ti; const double * td; const int * tvi; const double * u;
+  __device__ inline double val () { return u[*tvi++]; }
+};
 
 // p.b of interpolate_1D1 / interpolate_2D1 from the streams: sum of a_j * P_j, P_j a value or the
 // average of the children of a refined neighbour (average_neighbor_value)
-__host__ __device__ inline double tape_interpolation (TapeCursor & c)
+template <class CUR>
+__host__ __device__ inline double tape_interpolation (CUR & c)
 {
   const int nt = *c.ti++;
   double pb = 0.;
@@ -339,12 +347,12 @@ __host__ __device__ inline double tape_interpolation (TapeCursor & c)
     const int cnt = *c.ti++;
     double P;
     if (cnt == 0)
-      P = *c.tv++;
+      P = c.val ();
     else {
       double av = 0., n = 0.;
       for (int k = 0; k < cnt; k++) {
 	n += 1.;
-	av += 1.*(*c.tv++);
+	av += 1.*(c.val ());
       }
       P = av/n;
     }
@@ -356,7 +364,8 @@ __host__ __device__ inline double tape_interpolation (TapeCursor & c)
 // the sums g.a, g.b of relax / residual_set over the faces of a cell (src/poisson.c:507-557,634-678)
 // w: the weight every face carries (1. for the Poisson problem with alpha = NULL; the diffusion
 // coefficient of a quadtree, face_gradient_w of tree.hpp) -- the products by 1. leave the bits alone
-__host__ __device__ inline void tape_cell (TapeCursor & c, int nd, int dim, int ncd, double & ga, double & gb,
+template <class CUR>
+__host__ __device__ inline void tape_cell (CUR & c, int nd, int dim, int ncd, double & ga, double & gb,
 					   double w = 1.)
 {
   ga = 0.; gb = 0.;
@@ -367,11 +376,11 @@ __host__ __device__ inline void tape_cell (TapeCursor & c, int nd, int dim, int 
     double na, nb;
     if (kind == K_SAME) {
       na = w;
-      nb = w*(*c.tv++);
+      nb = w*(c.val ());
     }
     else if (kind == K_FC) {      /* gradient_fine_coarse towards a coarser neighbour */
       const double cb = *c.td++;
-      const double uN = *c.tv++;
+      const double uN = c.val ();
       const double pb = tape_interpolation (c);
       const double gc = 2.*pb/3.;
       na = w*(2./3.);
@@ -382,7 +391,7 @@ __host__ __device__ inline void tape_cell (TapeCursor & c, int nd, int dim, int 
       na = 0.; nb = 0.;
       for (int i = 0; i < nch; i++) {
 	const double gbi = *c.td++;
-	const double uch = *c.tv++;
+	const double uch = c.val ();
 	const double pb = tape_interpolation (c);
 	const double gc = 2.*pb/3.;
 	na += w*gbi;
@@ -641,6 +650,8 @@ __device__ inline double wave_min (double v)
 __global__ void t_residual (Topo T, const Cell * cells, int n, const double * u, const double * rhs,
 			    double * res, double * red)
 {
+  // (eight lanes per leaf, one per face, with the sums in direction order by lane 0: 74 -> 244 us -- the lanes of a
+  // wavefront then walk eight different ways through the tree)
   int t = blockIdx.x*blockDim.x + threadIdx.x;
   double r = 0., val = 0.;
   if (t < n) {
@@ -650,6 +661,35 @@ __global__ void t_residual (Topo T, const Cell * cells, int n, const double * u,
     r = residual_cell (T, c, R, rhs[g]);
     res[g] = r;
     const double size = T.size (c);
+    val = r/(1.*size*size);
+  }
+  const double m = wave_max (fabs (val)), s1 = wave_sum (r), s2 = wave_sum (fabs (val)), s3 = wave_sum (val*val);
+  if ((threadIdx.x & 63) == 0) {
+    atomic_max_pos (&red[0], m);
+    atomicAdd (&red[1], s1);
+    atomicAdd (&red[2], s2);
+    atomicAdd (&red[3], s3);
+  }
+}
+
+// the same from the compiled stencils of the finest sweep (its cells are the leaves): the streams of a cell say
+// which values to read -- two dependent loads each instead of the chain of loads through the tree (tree.hpp)
+// that made t_residual run at the latency of its longest thread
+__global__ void t_residual_tape (Topo T, const Cell * cells, const int * cell_off, int n, const int * ti_g,
+				 const double * td_g, const int * tv_g, const double * u, const double * rhs,
+				 double * res, double * red)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  double r = 0., val = 0.;
+  if (t < n) {
+    TapeCursorG cur = { ti_g + cell_off[3*t], td_g + cell_off[3*t + 1], tv_g + cell_off[3*t + 2], u };
+    const double self = cur.val ();
+    double ga, gb;
+    tape_cell (cur, T.nd (), T.dim, T.ncd (), ga, gb);
+    const int g = T.gi (cells[t]);
+    r = rhs[g] - (gb - self*ga);
+    res[g] = r;
+    const double size = T.size (cells[t]);
     val = r/(1.*size*size);
   }
   const double m = wave_max (fabs (val)), s1 = wave_sum (r), s2 = wave_sum (fabs (val)), s3 = wave_sum (val*val);
@@ -850,16 +890,20 @@ __device__ inline double transverse_term (const Topo & T, const AdvArgs & A, Cel
 }
 
 // gfs_cell_advected_face_values, src/advection.c:58-99 (centred gradient, no sources)
+// one thread per leaf and direction: the three directions of a leaf are independent, and each is a chain of
+// dependent loads through the tree (a leaf per thread left less than one wavefront per compute unit on the
+// trees of the benches: the kernel ran at the latency of the longest chain)
 __global__ void t_face_values (Topo T, const Cell * cells, int n, AdvArgs A)
 {
   int t = blockIdx.x*blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const Cell cell = cells[t];
+  if (t >= n*T.dim) return;
+  const Cell cell = cells[t/T.dim];
   const int g = T.gi (cell);
   DevReader R = { A.v };
   const double size = T.size (cell);
   const double v0 = A.v[g];
-  for (int c = 0; c < T.dim; c++) {
+  {
+    const int c = t % T.dim;
     const double msize = size;
     const double unorm = A.use_centered ? A.dt*A.u[c][g]/msize :
       A.dt*(A.un[2*c][g] + A.un[2*c + 1][g])/(2.*msize);
@@ -1847,7 +1891,19 @@ int residual_norm (gfship_tree * tr, const double * u, const double * rhs, doubl
 		   gfship_norm * out)
 {
   GFSHIP_HIP (hipMemsetAsync (tr->d_red, 0, 4*sizeof (double), tr->stream));
-  t_residual<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, u, rhs, res, tr->d_red);
+  {
+    static int no_tape = -1;
+    if (no_tape < 0) {
+      const char * e = getenv ("GFSHIP_TREE_NO_RESIDUAL_TAPE");      /* 1: the residual by the code that walks the tree */
+      no_tape = e ? atoi (e) : 0;
+    }
+    const Sweep & S = tr->sweep[tr->H.depth];
+    if (!no_tape && S.taped && S.ncells == tr->nleaves)
+      t_residual_tape<<<blocks (S.ncells), 256, 0, tr->stream>>> (tr->D, S.cells, S.cell_off, S.ncells, S.ti, S.td, S.tv,
+								   u, rhs, res, tr->d_red);
+    else
+      t_residual<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, u, rhs, res, tr->d_red);
+  }
   KCHECK ();
   GFSHIP_HIP (hipMemcpyAsync (tr->h_red, tr->d_red, 4*sizeof (double), hipMemcpyDeviceToHost, tr->stream));
   GFSHIP_HIP (hipStreamSynchronize (tr->stream));
@@ -2087,7 +2143,7 @@ int face_values_set (gfship_tree * tr, const double * v, double dt, int use_cent
   for (int c = 0; c < 3; c++) if (v == tr->var[V_U + c]) { A.visc = tr->visc[c]; A.gsrc = tr->src[c]; }
   for (int c = 0; c < 3; c++) A.u[c] = tr->var[V_U + c];
   for (int d = 0; d < 6; d++) { A.un[d] = tr->var[V_UN + d]; A.fv[d] = tr->var[V_FV + d]; }
-  t_face_values<<<blocks (tr->nleaves), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, A);
+  t_face_values<<<blocks (tr->nleaves*tr->H.dim), 256, 0, tr->stream>>> (tr->D, tr->leaves, tr->nleaves, A);
   KCHECK ();
   if (tr->nghost_leaves)
   {
