@@ -35,15 +35,19 @@
 // host with the kernel's timing of loads and stores (and its choice of the branch-free arithmetic per
 // wavefront) and compares with the reference's program.
 //
-// Measured (octree bench, tools/tree_bench.py 3 4 2: 39 712 leaves, levels 4-6; profiles/r03_tree_flow.txt):
-// the loop of the finest level 3.43 ms (t_relax_nodes_pf, 349 levels of the tape plan) -> 1.15 ms (661 levels
-// of 512 operations), the cycle 6.6 -> 2.2 ms.  A level costs 1.3-1.7 us whatever its width (64 to 512
-// operations): the instruction stream of one micro-operation on the slowest wavefront (~230 instructions,
-// two thirds of them selects and address arithmetic around ~40 f64 operations and one division, ~10 cycles
-// each with two wavefronts per SIMD) plus the barrier.  Tried without a gain at that point, and left in or
-// out as said: loads two levels ahead (out: 15-fold unrolling, 224 VGPRs); the storing wavefront (in);
-// the working copies read into the L2 once at the start (in); the lines of the record stream touched
-// eight levels ahead by LDS-DMA loads (out); 128 / 256 / 384 operations per level (GFSHIP_FLOW_WIDTH).
+// Measured (octree bench, tools/tree_bench.py 3 4 2: 39 712 leaves, levels 4-6; profiles/r03_tree_flow.txt;
+// DESIGN.md 11.15 has the whole account): the loop of the finest level 3.43 ms (t_relax_nodes_pf, 349 levels of
+// the tape plan) -> 0.79 ms (681 levels of 512 operations), the cycle 6.6 -> 1.5 ms.  A level costs 1.0-1.2 us
+// whatever its width: every wavefront of a level wants the vector memory pipeline (14 loads per thread), then the
+// LDS, then the vector ALU (~100 instructions around ~40 f64 operations and one division) and the barrier keeps
+// them in step.  What paid, in order: fixed-format operations with independent loads instead of the tape (2.7 x);
+// even and odd wavefronts in different orders (17 %); the kinds of a level at multiples of 64, i.e. no wavefront
+// with two kinds (14 %); the working copies in plan order (18 % on the finest loop).  Tried without a gain, and left
+// in or out as said: loads two levels ahead (out: 15-fold unrolling, 224 VGPRs); the storing wavefront (in); the
+// working copies read into the L2 once at the start (in); the lines of the record stream touched eight levels
+// ahead by LDS-DMA loads (out); 128 / 256 / 384 operations per level (GFSHIP_FLOW_WIDTH; 256 is the default on
+// quadtrees); on quadtrees a CELL with the FC / CHILD / SUM of its faces in the same operation (out: 38 % fewer
+// levels, each twice as expensive); a select-free CELL / FC (out: 5 % slower).
 
 enum { F_CELL = 0, F_FC = 1, F_CHILD = 2, F_SUM = 3, F_GHOST = 4, F_NOP = 5 };
 enum { FK_NONE = 0, FK_SAME = 1, FK_PAIR = 2 };
@@ -70,9 +74,9 @@ struct __attribute__((aligned(16))) FlowRec { unsigned w0; int out_g; int in[FLO
 //          value), 11-17 / 18-24 / 25-31 the constants cb (gbi), a0, a1 in the table
 //          in[0] the coarse neighbour (the child), in[1 + TS t + k] value k of term t
 //   SUM    3-5 children;  in[i] the pair of child i
-// The operations of a level are sorted by kind (CELL, FC / CHILD, SUM, GHOST): a wavefront mostly runs one
-// branch of flow_eval
 //   GHOST  11-17 the constant (the sign of the homogeneous condition);  in[0] the image
+// The operations of a level are sorted by kind (CELL | FC, CHILD | SUM, GHOST), each kind starting at a multiple of
+// 64 when the plan is 256 wide at least (the schedule keeps the room): a wavefront runs one branch of flow_eval
 
 template <int DIM> struct FlowShape {
   static constexpr int TS = DIM == 3 ? 4 : 2;            /* values of one interpolation term */
