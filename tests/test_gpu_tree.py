@@ -286,7 +286,8 @@ def test_other_relax_kernels_give_the_same_bits(switch):
     import sys
     code = ("import sys; sys.path.insert(0, %r); import test_gpu_tree as t; "
             "t.test_tree_steps_bit_exact(4, 2, 3); t.test_octree_steps_bit_exact('blob', 3, 2, 2); "
-            "t.test_poisson_on_a_tree_with_boundaries(t.gfship.BC_NEUMANN, 5, 3)"
+            "t.test_poisson_on_a_tree_with_boundaries(t.gfship.BC_NEUMANN, 5, 3); "
+            "t.test_lid_driven_cavity_on_a_tree_bit_exact('walls')"
             % os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     for kv in switch.split():
