@@ -1877,6 +1877,36 @@ Sgn6 homogeneous_signs_u (const gfship_tree * tr, int c)
 }
 
 // post-order traversal of the non-leaf cells: deepest level first
+// the same for several variables in one launch per level (gfs_cell_coarse_init restricts five to seven variables:
+// thirty to forty launches of a few microseconds each per step otherwise)
+struct PN { double * p[8]; };
+__global__ void t_from_below_n (Topo T, const Cell * cells, int n, PN V, int nv)
+{
+  int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n*nv) return;
+  const Cell c = cells[t/nv];
+  double * v = V.p[t % nv];
+  double val = 0., sa = 0.;
+  for (int k = 0; k < T.nc (); k++) {
+    const Cell ch = T.child (c, k);
+    if (exists (ch)) {
+      val += v[T.gi (ch)]*1.;
+      sa += 1.;
+    }
+  }
+  v[T.gi (c)] = val/sa;
+}
+
+int from_below_n (gfship_tree * tr, const PN & V, int nv)
+{
+  for (int l = tr->H.depth - 1; l >= 0; l--)
+    if (tr->nnonleaf[l]) {
+      t_from_below_n<<<blocks (tr->nnonleaf[l]*nv), 256, 0, tr->stream>>> (tr->D, tr->nonleaf[l], tr->nnonleaf[l], V, nv);
+      KCHECK ();
+    }
+  return 0;
+}
+
 int from_below (gfship_tree * tr, double * v, int mode)
 {
   for (int l = tr->H.depth - 1; l >= 0; l--)
@@ -2352,13 +2382,12 @@ int set_timestep (gfship_tree * tr)   /* src/simulation.c:1569-1633; the only ev
 
 int coarse_init (gfship_tree * tr)   /* src/adaptive.c:43-58 */
 {
-  int e;
   const int vars[] = { V_P, V_PMAC, V_U, V_U + 1, V_U + 2 };
-  for (int k = 0; k < 2 + tr->H.dim; k++)
-    if ((e = from_below (tr, tr->var[vars[k]], 0))) return e;
-  for (int k = 0; k < tr->ntracers; k++)
-    if ((e = from_below (tr, tr->var[V_T + k], 0))) return e;
-  return 0;
+  PN V;
+  int nv = 0;
+  for (int k = 0; k < 2 + tr->H.dim; k++) V.p[nv++] = tr->var[vars[k]];
+  for (int k = 0; k < tr->ntracers && nv < 8; k++) V.p[nv++] = tr->var[V_T + k];
+  return from_below_n (tr, V, nv);
 }
 
 void tree_free (gfship_tree * tr)

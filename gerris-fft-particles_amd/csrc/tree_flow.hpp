@@ -378,7 +378,6 @@ t_relax_flow (const FlowRec * __restrict__ rec, const int * __restrict__ lev_off
   __shared__ int lout[FLOW_NBUF*FLOW_WIDTH];
   __shared__ int loff[FLOW_MAXLEV + FLOW_PD + 4];
   __shared__ double ct[FLOW_NCONST];
-  constexpr int NIN = FlowShape<DIM>::NIN;
   const int tid = threadIdx.x;
   if (tid < nct) ct[tid] = ctab[tid];
   const int width = blockDim.x - 64;      /* the width the plan was made for; the last wavefront stores */
