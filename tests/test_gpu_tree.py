@@ -273,14 +273,15 @@ def test_poisson_on_a_tree_with_boundaries(kind, level, cycles):
 
 @pytest.mark.parametrize("switch", ["GFSHIP_TREE_TEMPLATE_RELAX=1", "GFSHIP_TREE_NO_PIPELINE=1", "GFSHIP_TREE_NO_FLOW=1",
                                     "GFSHIP_TREE_NO_FLOW=1 GFSHIP_TREE_NO_PREFETCH=1", "GFSHIP_FLOW_WIDTH=128",
-                                    "GFSHIP_FLOW_WIDTH=64"])
+                                    "GFSHIP_FLOW_WIDTH=64", "GFSHIP_TREE_NO_RESIDUAL_TAPE=1"])
 def test_other_relax_kernels_give_the_same_bits(switch):
     """The default is the relax loop as a dataflow program (t_relax_flow, csrc/tree_flow.hpp).
     GFSHIP_TREE_TEMPLATE_RELAX=1: the sweeps by the kernel that walks the tree for every cell
     (the code the compiled stencils were derived from); GFSHIP_TREE_NO_PIPELINE=1: compiled stencils,
     sweep after sweep instead of the plan of a whole loop; GFSHIP_TREE_NO_FLOW=1: the plan of the whole loop
     interpreted from the tapes (t_relax_nodes_pf; with GFSHIP_TREE_NO_PREFETCH=1 t_relax_nodes);
-    GFSHIP_FLOW_WIDTH: fewer operations per level of the flow plan: the same comparison with the oracle, in a
+    GFSHIP_FLOW_WIDTH: fewer operations per level of the flow plan; GFSHIP_TREE_NO_RESIDUAL_TAPE=1: the residual
+    by the code that walks the tree instead of the compiled stencils: the same comparison with the oracle, in a
     process of its own (the switches are read once)"""
     import subprocess
     import sys
